@@ -1,0 +1,205 @@
+/*
+ * mrs_tg.h -- C ABI of the MI355X-native batched polynomial trajectory optimiser.
+ *
+ * Drop-in boundary for the numerical core of ctu-mrs/mrs_uav_trajectory_generation:
+ * everything MrsTrajectoryGeneration::findTrajectory() does between building its vertices and
+ * receiving the sampled states (/root/reference/src/mrs_trajectory_generation.cpp:1046-1169),
+ * for a whole batch of independent paths at once.  The reference has no FFI for this path; the
+ * seam is a C++ call sequence, so each entry point names the reference calls it replaces
+ * (paths relative to /root/reference/, "linear_impl.h" / "nonlinear_impl.h" are
+ * include/eth_trajectory_generation/impl/polynomial_optimization_{linear,nonlinear}_impl.h).
+ *
+ * Conventions
+ *   - plain C types, caller-owned buffers, no exceptions cross the boundary;
+ *   - every function returns MRS_TG_OK (0) or a negative MRS_TG_ERR_* and records a message
+ *     retrievable with mrs_tg_last_error();
+ *   - 4 dimensions (x, y, z, heading), 10 coefficients per polynomial in ascending powers
+ *     (include/eth_trajectory_generation/polynomial.h:35-37), IEEE double throughout;
+ *   - a batch is CSR over segments: path p owns segments [seg_offsets[p], seg_offsets[p+1]) and
+ *     vertices [seg_offsets[p] + p, seg_offsets[p+1] + p + 1);
+ *   - per-path results carry an nlopt-style status (src/mrs_trajectory_generation.cpp:1138-1149
+ *     accepts >= 1 except 6, and -1).
+ *   - there is NO CPU fallback: without a usable HIP device every call fails with
+ *     MRS_TG_ERR_NO_DEVICE.
+ */
+#ifndef MRS_TG_H_
+#define MRS_TG_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MRS_TG_ABI_VERSION 1
+#define MRS_TG_N_COEFF 10
+#define MRS_TG_N_DIM 4
+#define MRS_TG_N_SLOT 5 /* derivative slots per vertex: position .. snap */
+
+enum {
+  MRS_TG_OK = 0,
+  MRS_TG_ERR_INVALID_ARG = -1,
+  MRS_TG_ERR_NO_DEVICE = -2,
+  MRS_TG_ERR_HIP = -3,
+  MRS_TG_ERR_UNSUPPORTED = -4,
+  MRS_TG_ERR_NOMEM = -5
+};
+
+/* per-path status values (nlopt.h result codes, as consumed by the nodelet) */
+enum {
+  MRS_TG_STATUS_FAILURE = -1,
+  MRS_TG_STATUS_INVALID_ARGS = -2,
+  MRS_TG_STATUS_SUCCESS = 1,
+  MRS_TG_STATUS_FTOL_REACHED = 3,
+  MRS_TG_STATUS_XTOL_REACHED = 4,
+  MRS_TG_STATUS_MAXEVAL_REACHED = 5,
+  MRS_TG_STATUS_MAXTIME_REACHED = 6
+};
+
+/* time_alloc_method (NonlinearOptimizationParameters::TimeAllocMethod,
+ * include/eth_trajectory_generation/polynomial_optimization_nonlinear.h:92-100) */
+enum {
+  MRS_TG_TIME_ALLOC_NONE = -1,     /* fixed segment times: PolynomialOptimization::solveLinear only */
+  MRS_TG_TIME_ALLOC_MELLINGER = 2  /* kMellingerOuterLoop, the shipping default
+                                      (config/private/trajectory_generation.yaml:7) */
+};
+
+enum {
+  MRS_TG_FLAG_FUSED_ASSEMBLY = 1 /* linear mode: recompute the per-segment blocks inside the solve
+                                    kernel instead of reading the materialised ones */
+};
+
+typedef struct mrs_tg_options {
+  int32_t derivative_to_optimize; /* 2 acceleration, 3 jerk, 4 snap (src/...cpp:904-919) */
+  int32_t time_alloc_method;      /* MRS_TG_TIME_ALLOC_* */
+  int32_t estimate_times;         /* != 0: initial times from estimateSegmentTimes (src/...cpp:1046,
+                                     vertex.cpp:491-565); 0: use seg_times_inout as given */
+  int32_t max_iterations;         /* nlopt maxeval (nonlinear_impl.h:73; param max_iterations) */
+  double f_rel, f_abs;            /* nlopt ftol (src/...cpp:884; nonlinear.h:42-46) */
+  double x_rel, x_abs;            /* nlopt xtol (src/...cpp:885; nonlinear.h:48-54) */
+  double sampling_dt;             /* > 0: sample the result (sampleWholeTrajectory, src/...cpp:1169) */
+  int32_t sample_capacity;        /* samples_out holds this many samples per path */
+  int32_t flags;                  /* MRS_TG_FLAG_* */
+} mrs_tg_options;
+
+typedef struct mrs_tg_ctx mrs_tg_ctx;
+typedef struct mrs_tg_plan mrs_tg_plan;
+
+/* ---- context ------------------------------------------------------------------------------- */
+
+/* Bind a context to HIP device `device_ordinal`.  One context per thread/stream; re-entrant
+ * across contexts.  Replaces the construction of PolynomialOptimizationNonLinear<10>
+ * (src/mrs_trajectory_generation.cpp:1064). */
+int mrs_tg_create(int device_ordinal, mrs_tg_ctx** ctx_out);
+void mrs_tg_destroy(mrs_tg_ctx* ctx);
+const char* mrs_tg_last_error(const mrs_tg_ctx* ctx); /* ctx may be NULL: last global error */
+int mrs_tg_abi_version(void);
+void mrs_tg_default_options(mrs_tg_options* opt);
+
+/* Launch on a caller-owned hipStream_t (e.g. torch.cuda.current_stream().cuda_stream) instead of
+ * the context's own stream.  NULL restores the context's stream. */
+int mrs_tg_set_stream(mrs_tg_ctx* ctx, void* hip_stream);
+int mrs_tg_synchronize(mrs_tg_ctx* ctx);
+
+/* ---- one-call host interface ---------------------------------------------------------------- */
+
+/* Host buffers in, host buffers out; blocking.  A batch of one path reproduces the nodelet's call.
+ * Replaces: estimateSegmentTimes (src/...cpp:1046), setupFromVertices (:1065; linear_impl.h:62-106),
+ * the 12 addMaximumMagnitudeConstraint calls (:1067-1081, folded into `limits`), optimize() (:1083;
+ * nonlinear_impl.h:90-234,336-408), getTrajectory (:1163) and sampleWholeTrajectory (:1169).
+ *
+ *   waypoints      [sum V][4]      x, y, z, heading (already unwrapped as at src/...cpp:935)
+ *   fixed_mask     [sum V][5]      != 0: derivative k of the vertex is constrained (Vertex::addConstraint)
+ *   fixed_values   [sum V][5][4]   the constrained values (ignored where the mask is 0)
+ *   limits         [n_paths][9]    {v,a,j} x {horizontal, vertical, heading}: index 3*(k-1)+group;
+ *                                  a heading limit >= FLT_MAX means relax_heading (src/...cpp:1030-1038)
+ *   seg_times_inout[sum S]         in: segment times (unless estimate_times); out: final times
+ *   coeffs_out     [sum S][4][10]
+ *   status_out     [n_paths]       nlopt-style code;  cost_out [n_paths] J_d (computeCost) -- may be NULL
+ *   n_samples_out  [n_paths], samples_out [n_paths][sample_capacity][4] (x, y, z, heading wrapped to
+ *                  (-pi, pi] as the nodelet reads it, src/...cpp:1582-1599) -- may be NULL when
+ *                  sampling_dt <= 0.  n_samples_out reports the count the reference would produce even
+ *                  when it exceeds sample_capacity (then only the first sample_capacity are written).
+ */
+int mrs_tg_solve_batch(mrs_tg_ctx* ctx, int32_t n_paths, const int32_t* seg_offsets, const double* waypoints,
+                       const uint8_t* fixed_mask, const double* fixed_values, const double* limits,
+                       const mrs_tg_options* opt, double* seg_times_inout, double* coeffs_out, int32_t* status_out,
+                       double* cost_out, int32_t* n_samples_out, double* samples_out);
+
+/* ---- plan interface: analysis once, device-resident data, asynchronous ----------------------- */
+
+/* Analyse the batch structure (host seg_offsets): sorts paths by segment count, sizes the
+ * workspace, uploads the CSR structure.  Corresponds to the structural half of setupFromVertices
+ * (setupConstraintReorderingMatrix, linear_impl.h:184-257). */
+int mrs_tg_plan_create(mrs_tg_ctx* ctx, int32_t n_paths, const int32_t* seg_offsets_host, mrs_tg_plan** plan_out);
+void mrs_tg_plan_destroy(mrs_tg_plan* plan);
+int32_t mrs_tg_plan_n_paths(const mrs_tg_plan* plan);
+int32_t mrs_tg_plan_n_segments(const mrs_tg_plan* plan);
+int32_t mrs_tg_plan_max_segments(const mrs_tg_plan* plan);
+/* order_out[q] = index of the path processed in position q (paths sorted by segment count, longest
+ * first, stable).  The materialised blocks below are laid out by position q. */
+int mrs_tg_plan_get_order(const mrs_tg_plan* plan, int32_t* order_out);
+
+/* The Hessian / mapping-block assembly kernel on its own: for every segment of every path
+ * H_i = A_i^-T Q_i A_i^-1 and A_i^-1, both full 10x10 f64 (updateSegmentTimes linear_impl.h:289-304
+ * + the block products of constructR :317-320).  seg_times_dev [sum S] (CSR order).
+ * Output layout ("slot-major SoA", stated in DESIGN.md): element (r, c) of the block of segment j of
+ * the path at position q lives at  ((j * 100 + r * 10 + c) * n_paths + q);  each output holds
+ * max_segments * 100 * n_paths doubles; slots j >= S_q are left untouched. Asynchronous. */
+int mrs_tg_plan_assemble(mrs_tg_plan* plan, int32_t derivative_to_optimize, const double* seg_times_dev,
+                         double* H_dev, double* Ainv_dev);
+/* Bytes needed for each of H_dev / Ainv_dev. */
+size_t mrs_tg_plan_block_bytes(const mrs_tg_plan* plan);
+
+/* Same contract as mrs_tg_solve_batch but every pointer is DEVICE memory (inputs already resident in
+ * HBM) and the call is asynchronous on the context's stream.  samples/cost pointers may be NULL. */
+int mrs_tg_plan_solve(mrs_tg_plan* plan, const double* waypoints_dev, const uint8_t* fixed_mask_dev,
+                      const double* fixed_values_dev, const double* limits_dev, const mrs_tg_options* opt,
+                      double* seg_times_inout_dev, double* coeffs_out_dev, int32_t* status_out_dev,
+                      double* cost_out_dev, int32_t* n_samples_out_dev, double* samples_out_dev);
+
+/* Building blocks of the outer loop, exposed for parity tests (device pointers, asynchronous):
+ * J_d and the h = 0.1 forward-difference gradient at the given times
+ * (getCostAndGradientMellinger, nonlinear_impl.h:257-333): cost_out_dev [n_paths], grad_out_dev [sum S]. */
+int mrs_tg_plan_cost_gradient(mrs_tg_plan* plan, int32_t derivative_to_optimize, const uint8_t* fixed_mask_dev,
+                              const double* fixed_values_dev, const double* seg_times_dev, double* cost_out_dev,
+                              double* grad_out_dev);
+/* Per-segment maxima of |p^(k)| for k = 1..3 and the groups {x,y}, {z}, {heading}
+ * (Trajectory::computeMaxDerivatives*, trajectory.cpp:422-565): maxima_out_dev [sum S][3][3] indexed
+ * [segment][k-1][group]. */
+int mrs_tg_plan_segment_maxima(mrs_tg_plan* plan, const double* coeffs_dev, const double* seg_times_dev,
+                               double* maxima_out_dev);
+
+/* Duration in milliseconds of the most recent launch of a kernel family, measured with HIP events on
+ * the launch stream (requires mrs_tg_set_profiling(ctx, 1)); kernel_id: 0 assemble, 1 linear solve,
+ * 2 nonlinear outer loop.  Blocks until that launch has finished. */
+int mrs_tg_set_profiling(mrs_tg_ctx* ctx, int enabled);
+int mrs_tg_last_kernel_ms(mrs_tg_ctx* ctx, int kernel_id, float* ms_out);
+
+/* ---- single-path convenience mirroring findTrajectory()'s signature ------------------------- */
+
+typedef struct mrs_tg_waypoint {
+  double coords[4]; /* x, y, z, heading  (Waypoint_t, src/mrs_trajectory_generation.cpp:66-70) */
+  uint8_t stop_at;
+} mrs_tg_waypoint;
+
+typedef struct mrs_tg_initial_state { /* the TrackerCommand fields read at src/...cpp:925-957 */
+  double heading;
+  double velocity[4], acceleration[4], jerk[4]; /* xyz + heading rate / acceleration / jerk */
+} mrs_tg_initial_state;
+
+/* findTrajectory(waypoints, initial_state, sampling_dt, relax_heading) for one path
+ * (src/mrs_trajectory_generation.cpp:857-1209): builds the vertices (:923-977), estimates times,
+ * optimises, samples.  limits9 as above.  Returns MRS_TG_OK and *n_samples_out > 0 on success; the
+ * nodelet's accept/reject gate on the nlopt code (:1138-1149) is applied: a rejected code yields
+ * *n_samples_out = 0.  samples_out [sample_capacity][4]. initial_state may be NULL. */
+int mrs_tg_find_trajectory(mrs_tg_ctx* ctx, const mrs_tg_waypoint* waypoints, int32_t n_waypoints,
+                           const mrs_tg_initial_state* initial_state, const double* limits9,
+                           const mrs_tg_options* opt, int32_t relax_heading, double* seg_times_out,
+                           double* coeffs_out, int32_t* status_out, int32_t* n_samples_out, double* samples_out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MRS_TG_H_ */

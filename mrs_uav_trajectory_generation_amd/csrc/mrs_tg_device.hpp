@@ -1,0 +1,267 @@
+// mrs_tg_device.hpp -- device-side numerics of the batched minimum-derivative QP (gfx950).
+//
+// What the reference computes per path (all citations relative to /root/reference/include/
+// eth_trajectory_generation/impl/): per-segment A^-1 and H = A^-T Q A^-1
+// (polynomial_optimization_linear_impl.h:113-177,311-320,606-618), the reduced system
+// d_p = -R_pp^-1 R_pf d_f (:341-373) and the coefficients c = A^-1 C d (:264-282).
+//
+// How it is computed here (DESIGN.md "numerical formulation"): time-normalised exact constants
+// (mrs_tg_constants.h) so no matrix is inverted at run time, and R_pp is never formed: it is block
+// tridiagonal over vertices (one 4x4 block of the free derivatives v,a,j,s per vertex; the position
+// slot is always constrained by every caller of the reference, src/mrs_trajectory_generation.cpp:944,
+// 963,967), so one sweep of block Cholesky over the vertices eliminates it.  Constrained slots are
+// masked to identity rows, which keeps every path on the same instruction stream.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "mrs_tg_constants.h"
+
+namespace mrs_tg {
+
+constexpr int kN = 10;     // coefficients per polynomial
+constexpr int kHalf = 5;   // derivative slots per vertex
+constexpr int kD = 4;      // dimensions
+constexpr int kNB = 4;     // free-candidate slots per vertex (velocity..snap)
+constexpr int kSlot0 = 1;  // first free-candidate slot
+constexpr double kTimeLowerBound = 0.01;  // kOptimizationTimeLowerBound (polynomial_optimization_nonlinear.h:304)
+
+__constant__ double c_abar_inv[kN][kN] = MRS_TG_ABAR_INV_INIT;
+__constant__ double c_hbar[kHalf][kN][kN] = MRS_TG_HBAR_INIT;
+
+// index into a packed lower-triangular 4x4 (r >= c)
+__device__ __forceinline__ constexpr int tri(int r, int c) { return r * (r + 1) / 2 + c; }
+// index into the packed upper triangle of the symmetric 10x10 (a <= b)
+__device__ __forceinline__ constexpr int sym10(int a, int b) {
+  return (a <= b) ? (a * kN - a * (a - 1) / 2 + (b - a)) : (b * kN - b * (b - 1) / 2 + (a - b));
+}
+constexpr int kSym10 = 55;
+
+// p2[m] = T^(m + 1 - 2d), m = 0..8: H(a,b) = HBAR[a][b] * p2[(a%5)+(b%5)]
+__device__ __forceinline__ void hessian_powers(double T, int d, double (&p2)[9]) {
+  const double t2 = T * T;
+  double td = 1.0;
+  if (d == 1) td = T;
+  else if (d == 2) td = t2;
+  else if (d == 3) td = t2 * T;
+  else if (d == 4) td = t2 * t2;
+  p2[0] = T / (td * td);
+#pragma unroll
+  for (int m = 1; m < 9; ++m) p2[m] = p2[m - 1] * T;
+}
+
+// Hs[sym10(a,b)] for one segment, from the exact unit-time constants
+__device__ __forceinline__ void hessian_from_time(double T, int d, double (&Hs)[kSym10]) {
+  double p2[9];
+  hessian_powers(T, d, p2);
+#pragma unroll
+  for (int a = 0; a < kN; ++a)
+#pragma unroll
+    for (int b = a; b < kN; ++b) Hs[sym10(a, b)] = c_hbar[d][a][b] * p2[(a % kHalf) + (b % kHalf)];
+}
+
+// ---------------------------------------------------------------------------------------------
+// Forward elimination over the vertices of one path for ND of the 4 dimensions.
+//
+// State while standing on vertex v (before its segment v is absorbed):
+//   Sm  : Schur complement accumulated so far for vertex v's 4x4 block (packed lower)
+//   y   : right-hand side accumulated so far, per dimension
+//   qf  : sum over segments of f^T H f (f = constrained part of the end-point derivatives)
+//   red : sum over vertices of |L^-1 y|^2 ; the optimal cost is 0.5 * (qf - red)
+template <int ND>
+struct Elim {
+  double Sm[10];
+  double y[kNB][ND];
+  double qf, red;
+
+  __device__ __forceinline__ void init() {
+#pragma unroll
+    for (int i = 0; i < 10; ++i) Sm[i] = 0.0;
+#pragma unroll
+    for (int k = 0; k < kNB; ++k)
+#pragma unroll
+      for (int q = 0; q < ND; ++q) y[k][q] = 0.0;
+    qf = 0.0;
+    red = 0.0;
+  }
+
+  // mask the current vertex (bit k of free_mask set = slot kSlot0+k is free), factor its block,
+  // z = L^-1 y.  L (packed lower) and z are returned for the caller to keep if it back-substitutes.
+  __device__ __forceinline__ void factor_vertex(unsigned free_mask, double (&L)[10], double (&z)[kNB][ND]) {
+#pragma unroll
+    for (int r = 0; r < kNB; ++r) {
+      const bool fr = (free_mask >> r) & 1u;
+#pragma unroll
+      for (int c = 0; c <= r; ++c) {
+        const bool fc = (free_mask >> c) & 1u;
+        double v = Sm[tri(r, c)];
+        if (r == c) v = fr ? v : 1.0;
+        else v = (fr && fc) ? v : 0.0;
+        Sm[tri(r, c)] = v;
+      }
+#pragma unroll
+      for (int q = 0; q < ND; ++q) y[r][q] = fr ? y[r][q] : 0.0;
+    }
+    // Cholesky, column by column
+#pragma unroll
+    for (int c = 0; c < kNB; ++c) {
+      double dsum = Sm[tri(c, c)];
+#pragma unroll
+      for (int m = 0; m < c; ++m) dsum -= L[tri(c, m)] * L[tri(c, m)];
+      const double lcc = sqrt(dsum);
+      const double inv = 1.0 / lcc;
+      L[tri(c, c)] = lcc;
+#pragma unroll
+      for (int r = c + 1; r < kNB; ++r) {
+        double s = Sm[tri(r, c)];
+#pragma unroll
+        for (int m = 0; m < c; ++m) s -= L[tri(r, m)] * L[tri(c, m)];
+        L[tri(r, c)] = s * inv;
+      }
+    }
+    // z = L^-1 y
+#pragma unroll
+    for (int q = 0; q < ND; ++q) {
+#pragma unroll
+      for (int r = 0; r < kNB; ++r) {
+        double s = y[r][q];
+#pragma unroll
+        for (int m = 0; m < r; ++m) s -= L[tri(r, m)] * z[m][q];
+        z[r][q] = s / L[tri(r, r)];
+        red += z[r][q] * z[r][q];
+      }
+    }
+  }
+
+  // Absorb segment v (between the current vertex v and vertex v+1):
+  //   Hs        packed symmetric 10x10 Hessian of the segment
+  //   fs, fe    constrained derivative values (0 where free) of vertex v / v+1, [slot][dim]
+  //   free_s/e  free masks of vertex v / v+1
+  // On return the state stands on vertex v+1.  L, z, W describe vertex v for back-substitution:
+  //   x_v = L^-T (z - W x_{v+1}).
+  __device__ __forceinline__ void absorb_segment(const double (&Hs)[kSym10], const double (&fs)[kHalf][ND],
+                                                 const double (&fe)[kHalf][ND], unsigned free_s, unsigned free_e,
+                                                 double (&L)[10], double (&z)[kNB][ND], double (&W)[kNB][kNB]) {
+    // u = H [fs; fe]; the free rows feed the right-hand sides, all rows feed qf
+    double ue[kNB][ND];
+#pragma unroll
+    for (int q = 0; q < ND; ++q) {
+#pragma unroll
+      for (int a = 0; a < kN; ++a) {
+        double u = 0.0;
+#pragma unroll
+        for (int b = 0; b < kHalf; ++b) u += Hs[sym10(a, b)] * fs[b][q];
+#pragma unroll
+        for (int b = 0; b < kHalf; ++b) u += Hs[sym10(a, kHalf + b)] * fe[b][q];
+        const double fa = (a < kHalf) ? fs[a][q] : fe[a - kHalf][q];
+        qf += fa * u;
+        if (a >= kSlot0 && a < kHalf) y[a - kSlot0][q] -= u;
+        if (a >= kHalf + kSlot0) ue[a - kHalf - kSlot0][q] = u;
+      }
+    }
+    // start block of this segment completes vertex v's diagonal block
+#pragma unroll
+    for (int r = 0; r < kNB; ++r)
+#pragma unroll
+      for (int c = 0; c <= r; ++c) Sm[tri(r, c)] += Hs[sym10(kSlot0 + r, kSlot0 + c)];
+    factor_vertex(free_s, L, z);
+    // W = L^-1 E~,  E~ = coupling block with constrained rows (vertex v) / columns (vertex v+1) zeroed
+#pragma unroll
+    for (int c = 0; c < kNB; ++c) {
+      const bool fc = (free_e >> c) & 1u;
+#pragma unroll
+      for (int r = 0; r < kNB; ++r) {
+        const bool fr = (free_s >> r) & 1u;
+        double s = (fr && fc) ? Hs[sym10(kSlot0 + r, kHalf + kSlot0 + c)] : 0.0;
+#pragma unroll
+        for (int m = 0; m < r; ++m) s -= L[tri(r, m)] * W[m][c];
+        W[r][c] = s / L[tri(r, r)];
+      }
+    }
+    // next vertex: Sm = Hee - W^T W ; y = -ue - W^T z
+#pragma unroll
+    for (int r = 0; r < kNB; ++r) {
+#pragma unroll
+      for (int c = 0; c <= r; ++c) {
+        double s = Hs[sym10(kHalf + kSlot0 + r, kHalf + kSlot0 + c)];
+#pragma unroll
+        for (int m = 0; m < kNB; ++m) s -= W[m][r] * W[m][c];
+        Sm[tri(r, c)] = s;
+      }
+#pragma unroll
+      for (int q = 0; q < ND; ++q) {
+        double s = -ue[r][q];
+#pragma unroll
+        for (int m = 0; m < kNB; ++m) s -= W[m][r] * z[m][q];
+        y[r][q] = s;
+      }
+    }
+  }
+};
+
+// x = L^-T (z - W x_next)   (x_next = 0 and W ignored for the last vertex)
+template <int ND>
+__device__ __forceinline__ void back_substitute(const double (&L)[10], const double (&z)[kNB][ND],
+                                                const double (&W)[kNB][kNB], const double (&xn)[kNB][ND], bool last,
+                                                double (&x)[kNB][ND]) {
+#pragma unroll
+  for (int q = 0; q < ND; ++q) {
+    double t[kNB];
+#pragma unroll
+    for (int r = 0; r < kNB; ++r) {
+      double s = z[r][q];
+      if (!last) {
+#pragma unroll
+        for (int c = 0; c < kNB; ++c) s -= W[r][c] * xn[c][q];
+      }
+      t[r] = s;
+    }
+#pragma unroll
+    for (int r = kNB - 1; r >= 0; --r) {
+      double s = t[r];
+#pragma unroll
+      for (int m = r + 1; m < kNB; ++m) s -= L[tri(m, r)] * x[m][q];
+      x[r][q] = s / L[tri(r, r)];
+    }
+  }
+}
+
+// c_k = T^-k * sum_j ABAR_INV[k][j] * T^(j%5) * d_j   for one dimension; d = [d_start(5); d_end(5)]
+__device__ __forceinline__ void coefficients_from_time(double T, const double (&dv)[kN], double (&c)[kN]) {
+  double w[kHalf];
+  w[0] = 1.0;
+#pragma unroll
+  for (int k = 1; k < kHalf; ++k) w[k] = w[k - 1] * T;
+  double db[kN];
+#pragma unroll
+  for (int j = 0; j < kN; ++j) db[j] = dv[j] * w[j % kHalf];
+  const double ti = 1.0 / T;
+  double tik = 1.0;
+#pragma unroll
+  for (int k = 0; k < kN; ++k) {
+    double s = 0.0;
+    if (k < kHalf) {
+      s = c_abar_inv[k][k] * db[k];  // the upper half of ABAR_INV is diag(1/k!)
+    } else {
+#pragma unroll
+      for (int j = 0; j < kN; ++j) s += c_abar_inv[k][j] * db[j];
+    }
+    c[k] = s * tik;
+    tik *= ti;
+  }
+}
+
+// Horner with the derivative table (same evaluation scheme as Polynomial::evaluate,
+// include/eth_trajectory_generation/polynomial.h:150-163)
+__device__ __forceinline__ double poly_eval(const double* c, double t, int derivative) {
+  // B[derivative][j] = j!/(j-derivative)!
+  auto bc = [derivative](int j) {
+    double v = 1.0;
+    for (int n = 0; n < derivative; ++n) v *= (double)(j - n);
+    return v;
+  };
+  double acc = bc(kN - 1) * c[kN - 1];
+  for (int j = kN - 2; j >= derivative; --j) acc = acc * t + bc(j) * c[j];
+  return acc;
+}
+
+}  // namespace mrs_tg

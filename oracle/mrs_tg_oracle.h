@@ -1,0 +1,145 @@
+/*
+ * mrs_tg_oracle.h -- CPU ORACLE (test infrastructure, NOT product code).
+ *
+ * A plain-C restatement of the hot path of ctu-mrs/mrs_uav_trajectory_generation
+ * (MrsTrajectoryGeneration::findTrajectory, src/mrs_trajectory_generation.cpp:857-1209, and
+ * the vendored eth_trajectory_generation library below it).  Each function cites the
+ * reference file:line it follows.  It deliberately uses the reference's own arithmetic route
+ * (per-segment A(T), Schur-complement inverse, H = A^-T Q A^-1, dense R = C^T H C, QR solve,
+ * Jenkins-Traub roots) and shares NO code or constants with the HIP product path.
+ *
+ * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load this library.
+ *
+ * PARITY UNPINNED: the reference ships no golden vectors / known-answer tests for this path
+ *  and cannot be compiled here (Eigen3, NLopt, mrs_lib, ROS absent), so
+ * this oracle is pinned only against closed-form known answers and 60-digit mpmath ground
+ * truth of the same formulas (tests/golden, oracle/gen_golden.py), not against reference output.
+ *
+ * All file:line citations are relative to /root/reference/.
+ */
+#ifndef MRS_TG_ORACLE_H_
+#define MRS_TG_ORACLE_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MTO_N 10    /* coefficients per polynomial   (src/mrs_trajectory_generation.cpp:1063) */
+#define MTO_D 4     /* dimensions x,y,z,heading      (src/mrs_trajectory_generation.cpp:902)  */
+#define MTO_HALF 5  /* derivative slots per segment end (N/2) */
+#define MTO_MAX_SEG 128
+
+/* nlopt-style result codes (nlopt.h; gate at src/mrs_trajectory_generation.cpp:1138-1149) */
+enum {
+  MTO_FAILURE = -1, MTO_INVALID_ARGS = -2,
+  MTO_SUCCESS = 1, MTO_STOPVAL_REACHED = 2, MTO_FTOL_REACHED = 3, MTO_XTOL_REACHED = 4,
+  MTO_MAXEVAL_REACHED = 5, MTO_MAXTIME_REACHED = 6
+};
+
+/* One path.  Vertex v has 5 derivative slots k (0=position..4=snap); fixed_mask[v*5+k] != 0
+ * means the vertex carries a constraint on derivative k (Vertex::addConstraint,
+ * src/eth_trajectory_generation/vertex.cpp:134-137) with value fixed_values[(v*5+k)*4+dim]. */
+typedef struct {
+  int n_seg;                    /* S; vertices = S+1 */
+  int derivative_to_optimize;   /* 2,3,4 (acc, jerk, snap) src/mrs_trajectory_generation.cpp:904-919 */
+  const uint8_t* fixed_mask;    /* [(S+1)*5] */
+  const double* fixed_values;   /* [(S+1)*5*4] */
+} mto_path;
+
+typedef struct {
+  int max_iterations;           /* nlopt maxeval            nonlinear_impl.h:73  */
+  double f_rel, f_abs;          /* nlopt ftol               nonlinear_impl.h:69-70 */
+  double x_rel, x_abs;          /* nlopt xtol               nonlinear_impl.h:71-72 */
+} mto_nlopt_params;
+
+/* ---- polynomial primitives ---------------------------------------------------------- */
+/* B[r][k] = k!/(k-r)!  polynomial.cpp:155-170 */
+double mto_base_coeff(int r, int k);
+/* Horner with derivative table, polynomial.h:150-163 */
+double mto_poly_eval(const double* c, int n, double t, int derivative);
+/* derivative coefficients zero-padded to n, polynomial.h:108-119 */
+void mto_poly_derivative(const double* c, int n, int derivative, double* out);
+/* discrete convolution, polynomial.cpp:176-192; out has nd+nk-1 entries */
+void mto_convolve(const double* data, int nd, const double* kernel, int nk, double* out);
+/* all complex roots of a real polynomial given in INCREASING powers
+ * (findRootsJenkinsTraub, rpoly/rpoly_ak1.cpp:76-120 + rpoly_ak1 :148-932).
+ * returns number of roots written (0 if none), -1 on failure. */
+int mto_find_roots_jenkins_traub(const double* coeffs_increasing, int n_coeffs, double* re, double* im);
+
+/* ---- per-segment matrices (row-major 10x10) ----------------------------------------- */
+void mto_mapping_matrix(double T, double* A);                          /* linear_impl.h:113-121 */
+void mto_invert_mapping_matrix(const double* A, double* Ainv);         /* linear_impl.h:148-177 */
+void mto_cost_matrix(int derivative, double T, double* Q);             /* linear_impl.h:606-618 */
+void mto_segment_hessian(int derivative, double T, double* Hout, double* Ainv_out); /* linear_impl.h:320 */
+
+/* ---- linear QP ------------------------------------------------------------------------ */
+/* setupFromVertices + solveLinear (linear_impl.h:62-106,184-257,311-373).
+ * coeffs_out [S][4][10] ascending powers. Returns 0 on success. */
+int mto_solve_linear(const mto_path* path, const double* seg_times, double* coeffs_out);
+/* computeCost linear_impl.h:128-141 */
+double mto_compute_cost(int n_seg, int derivative, const double* seg_times, const double* coeffs);
+
+/* ---- nonlinear time allocation (mode 2, Mellinger) ------------------------------------ */
+/* getCostAndGradientMellinger nonlinear_impl.h:257-333; grad may be NULL */
+double mto_cost_and_gradient_mellinger(const mto_path* path, const double* seg_times, double* grad);
+/* Self-defined deterministic projected L-BFGS standing in for NLopt LD_LBFGS
+ * (optimizeTimeMellingerOuterLoop nonlinear_impl.h:160-234).  See DESIGN.md "outer loop".
+ * seg_times is in/out: on return it holds the LAST EVALUATED point (that is what the
+ * reference's poly_opt_ holds when scaleSegmentTimesWithViolation runs, nonlinear_impl.h:213).
+ * n_eval_out may be NULL. */
+int mto_optimize_times_mellinger(const mto_path* path, const mto_nlopt_params* prm, double* seg_times,
+                                 int* n_eval_out, double* final_cost_out);
+
+/* ---- feasibility ---------------------------------------------------------------------- */
+/* Trajectory::computeMinMaxMagnitude for one segment (trajectory.cpp:211-243,
+ * segment.cpp:113-212): maximum over candidates of the norm of derivative `derivative`
+ * restricted to dims[0..n_dims). coeffs = that segment's [4][10]. */
+double mto_segment_max_magnitude(const double* seg_coeffs, double T, int derivative, const int* dims, int n_dims);
+/* Trajectory::scaleSegmentTimesToMeetConstraints trajectory.cpp:598-692.
+ * limits[9] = {v_h, v_v, v_hdg, a_h, a_v, a_hdg, j_h, j_v, j_hdg}. Scales coeffs in place and
+ * seg_times in place; returns within_range (0/1); n_sweeps_out may be NULL. */
+int mto_scale_segment_times_to_meet_constraints(int n_seg, double* coeffs, double* seg_times,
+                                                const double* limits, int* n_sweeps_out);
+
+/* ---- sampling --------------------------------------------------------------------------- */
+/* sampleWholeTrajectory -> Trajectory::evaluateRange (trajectory_sampling.cpp:49-124,
+ * trajectory.cpp:93-151). Writes up to capacity samples of [x,y,z,heading_raw] for derivative
+ * `derivative`; returns the number the reference would produce (may exceed capacity). */
+int mto_sample_trajectory(int n_seg, const double* coeffs, const double* seg_times, double dt,
+                          int derivative, double* out, int capacity);
+/* yaw after the quaternion round trip (eth_mav_msgs/common.h:130-140, eigen_mav_msgs.h setFromYaw/getYaw) */
+double mto_wrap_yaw(double yaw);
+
+/* ---- input side -------------------------------------------------------------------------- */
+/* estimateSegmentTimesEuclidean vertex.cpp:491-565. waypoints [S+1][4].
+ * limits as above (heading limits >= FLT_MAX disable the heading term). */
+void mto_estimate_segment_times_euclidean(int n_seg, const double* waypoints, const double* limits, double* times_out);
+/* estimateSegmentTimesBaca vertex.cpp:301-485 */
+void mto_estimate_segment_times_baca(int n_seg, const double* waypoints, const double* limits, double* times_out);
+/* sradians::unwrap as used at src/mrs_trajectory_generation.cpp:935 */
+double mto_unwrap_heading(double what, double from);
+
+/* ---- whole path: findTrajectory core (src/mrs_trajectory_generation.cpp:1046-1169) ------ */
+typedef struct {
+  int derivative_to_optimize;
+  int time_alloc_method;      /* -1: fixed times, linear only;  2: Mellinger outer loop + scaling */
+  int estimate_times;         /* 1: seg_times from the Euclidean estimator, 0: as given */
+  mto_nlopt_params nlopt;
+  double sampling_dt;         /* <= 0: no sampling */
+} mto_options;
+
+/* Batch driver in the C-ABI's CSR layout (include/mrs_tg.h). Single thread when n_threads<=1,
+ * otherwise a static partition over pthreads. samples_out [n_paths][sample_capacity][4]
+ * (x,y,z,wrapped heading) or NULL. */
+int mto_solve_batch(int n_paths, const int32_t* seg_offsets, const double* waypoints,
+                    const uint8_t* fixed_mask, const double* fixed_values, const double* limits,
+                    const mto_options* opt, double* seg_times_inout, double* coeffs_out,
+                    int32_t* status_out, double* cost_out, int32_t* n_samples_out, double* samples_out,
+                    int sample_capacity, int n_threads);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

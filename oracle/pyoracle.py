@@ -1,0 +1,222 @@
+"""ctypes binding of the CPU oracle (oracle/libmrs_tg_oracle.so).
+
+TEST INFRASTRUCTURE ONLY: importable from tests/, __graft_entry__.smoke() and bench.py's
+cpu_baseline leg -- never from the product package (mrs_uav_trajectory_generation_amd).
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "libmrs_tg_oracle.so")
+
+N, D, HALF = 10, 4, 5
+
+
+def build(force=False):
+    if force or not os.path.exists(_LIB_PATH):
+        subprocess.check_call(["make", "-C", _HERE, "-s"] + (["-B"] if force else []))
+    return _LIB_PATH
+
+
+class _Path(C.Structure):
+    _fields_ = [("n_seg", C.c_int), ("derivative_to_optimize", C.c_int),
+                ("fixed_mask", C.POINTER(C.c_uint8)), ("fixed_values", C.POINTER(C.c_double))]
+
+
+class NloptParams(C.Structure):
+    _fields_ = [("max_iterations", C.c_int), ("f_rel", C.c_double), ("f_abs", C.c_double),
+                ("x_rel", C.c_double), ("x_abs", C.c_double)]
+
+
+class Options(C.Structure):
+    _fields_ = [("derivative_to_optimize", C.c_int), ("time_alloc_method", C.c_int),
+                ("estimate_times", C.c_int), ("nlopt", NloptParams), ("sampling_dt", C.c_double)]
+
+
+def default_nlopt(max_iterations=10):
+    # f_rel 0.05 / x_rel 0.1: /root/reference/src/mrs_trajectory_generation.cpp:884-885;
+    # f_abs/x_abs -1 (disabled): polynomial_optimization_nonlinear.h:42-54
+    return NloptParams(max_iterations, 0.05, -1.0, 0.1, -1.0)
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        L = C.CDLL(_LIB_PATH)
+        dp = C.POINTER(C.c_double)
+        L.mto_base_coeff.restype = C.c_double
+        L.mto_base_coeff.argtypes = [C.c_int, C.c_int]
+        L.mto_poly_eval.restype = C.c_double
+        L.mto_poly_eval.argtypes = [dp, C.c_int, C.c_double, C.c_int]
+        L.mto_find_roots_jenkins_traub.restype = C.c_int
+        L.mto_find_roots_jenkins_traub.argtypes = [dp, C.c_int, dp, dp]
+        L.mto_segment_hessian.argtypes = [C.c_int, C.c_double, dp, dp]
+        L.mto_solve_linear.restype = C.c_int
+        L.mto_solve_linear.argtypes = [C.POINTER(_Path), dp, dp]
+        L.mto_compute_cost.restype = C.c_double
+        L.mto_compute_cost.argtypes = [C.c_int, C.c_int, dp, dp]
+        L.mto_cost_and_gradient_mellinger.restype = C.c_double
+        L.mto_cost_and_gradient_mellinger.argtypes = [C.POINTER(_Path), dp, dp]
+        L.mto_optimize_times_mellinger.restype = C.c_int
+        L.mto_optimize_times_mellinger.argtypes = [C.POINTER(_Path), C.POINTER(NloptParams), dp, C.POINTER(C.c_int), dp]
+        L.mto_segment_max_magnitude.restype = C.c_double
+        L.mto_segment_max_magnitude.argtypes = [dp, C.c_double, C.c_int, C.POINTER(C.c_int), C.c_int]
+        L.mto_scale_segment_times_to_meet_constraints.restype = C.c_int
+        L.mto_scale_segment_times_to_meet_constraints.argtypes = [C.c_int, dp, dp, dp, C.POINTER(C.c_int)]
+        L.mto_sample_trajectory.restype = C.c_int
+        L.mto_sample_trajectory.argtypes = [C.c_int, dp, dp, C.c_double, C.c_int, dp, C.c_int]
+        L.mto_wrap_yaw.restype = C.c_double
+        L.mto_wrap_yaw.argtypes = [C.c_double]
+        L.mto_estimate_segment_times_euclidean.argtypes = [C.c_int, dp, dp, dp]
+        L.mto_estimate_segment_times_baca.argtypes = [C.c_int, dp, dp, dp]
+        L.mto_unwrap_heading.restype = C.c_double
+        L.mto_unwrap_heading.argtypes = [C.c_double, C.c_double]
+        L.mto_solve_batch.restype = C.c_int
+        L.mto_solve_batch.argtypes = [C.c_int, C.POINTER(C.c_int32), dp, C.POINTER(C.c_uint8), dp, dp,
+                                      C.POINTER(Options), dp, dp, C.POINTER(C.c_int32), dp,
+                                      C.POINTER(C.c_int32), dp, C.c_int, C.c_int]
+        _lib = L
+    return _lib
+
+
+def _dp(a):
+    return a.ctypes.data_as(C.POINTER(C.c_double))
+
+
+def _f64(a):
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+def _make_path(n_seg, deriv, fixed_mask, fixed_values):
+    m = np.ascontiguousarray(fixed_mask, dtype=np.uint8).reshape(-1)
+    v = _f64(fixed_values).reshape(-1)
+    assert m.size == (n_seg + 1) * 5 and v.size == (n_seg + 1) * 20
+    p = _Path(n_seg, deriv, m.ctypes.data_as(C.POINTER(C.c_uint8)), _dp(v))
+    p._keep = (m, v)
+    return p
+
+
+def segment_hessian(deriv, T):
+    H = np.zeros((N, N))
+    Ai = np.zeros((N, N))
+    lib().mto_segment_hessian(deriv, float(T), _dp(H), _dp(Ai))
+    return H, Ai
+
+
+def solve_linear(deriv, fixed_mask, fixed_values, seg_times):
+    t = _f64(seg_times)
+    S = t.size
+    p = _make_path(S, deriv, fixed_mask, fixed_values)
+    c = np.zeros((S, D, N))
+    rc = lib().mto_solve_linear(C.byref(p), _dp(t), _dp(c))
+    assert rc == 0, rc
+    return c
+
+
+def compute_cost(deriv, seg_times, coeffs):
+    t = _f64(seg_times)
+    c = _f64(coeffs)
+    return lib().mto_compute_cost(t.size, deriv, _dp(t), _dp(c))
+
+
+def cost_and_gradient(deriv, fixed_mask, fixed_values, seg_times):
+    t = _f64(seg_times)
+    p = _make_path(t.size, deriv, fixed_mask, fixed_values)
+    g = np.zeros(t.size)
+    J = lib().mto_cost_and_gradient_mellinger(C.byref(p), _dp(t), _dp(g))
+    return J, g
+
+
+def optimize_times(deriv, fixed_mask, fixed_values, seg_times, params=None):
+    t = _f64(seg_times).copy()
+    p = _make_path(t.size, deriv, fixed_mask, fixed_values)
+    prm = params or default_nlopt()
+    ne = C.c_int(0)
+    fc = C.c_double(0)
+    rc = lib().mto_optimize_times_mellinger(C.byref(p), C.byref(prm), _dp(t), C.byref(ne), C.byref(fc))
+    return rc, t, ne.value, fc.value
+
+
+def find_roots(coeffs_increasing):
+    c = _f64(coeffs_increasing)
+    re = np.zeros(128)
+    im = np.zeros(128)
+    n = lib().mto_find_roots_jenkins_traub(_dp(c), c.size, _dp(re), _dp(im))
+    if n <= 0:
+        return np.zeros(0, dtype=complex)
+    return re[:n] + 1j * im[:n]
+
+
+def segment_max_magnitude(seg_coeffs, T, derivative, dims):
+    c = _f64(seg_coeffs)
+    dd = (C.c_int * len(dims))(*dims)
+    return lib().mto_segment_max_magnitude(_dp(c), float(T), derivative, dd, len(dims))
+
+
+def scale_segment_times(coeffs, seg_times, limits):
+    c = _f64(coeffs).copy()
+    t = _f64(seg_times).copy()
+    lim = _f64(limits)
+    sw = C.c_int(0)
+    ok = lib().mto_scale_segment_times_to_meet_constraints(t.size, _dp(c), _dp(t), _dp(lim), C.byref(sw))
+    return ok, c, t, sw.value
+
+
+def sample_trajectory(coeffs, seg_times, dt, derivative=0, capacity=4096):
+    c = _f64(coeffs)
+    t = _f64(seg_times)
+    out = np.zeros((capacity, D))
+    n = lib().mto_sample_trajectory(t.size, _dp(c), _dp(t), float(dt), derivative, _dp(out), capacity)
+    return out[:min(n, capacity)].copy(), n
+
+
+def wrap_yaw(y):
+    return lib().mto_wrap_yaw(float(y))
+
+
+def estimate_times(waypoints, limits, baca=False):
+    w = _f64(waypoints)
+    S = w.shape[0] - 1
+    out = np.zeros(S)
+    lim = _f64(limits)
+    f = lib().mto_estimate_segment_times_baca if baca else lib().mto_estimate_segment_times_euclidean
+    f(S, _dp(w), _dp(lim), _dp(out))
+    return out
+
+
+def unwrap_heading(what, frm):
+    return lib().mto_unwrap_heading(float(what), float(frm))
+
+
+def solve_batch(seg_offsets, waypoints, fixed_mask, fixed_values, limits, seg_times, *, deriv=4,
+                time_alloc_method=-1, estimate_times=False, max_iterations=10, sampling_dt=0.0,
+                sample_capacity=0, n_threads=1):
+    """Batch driver in the C-ABI's CSR layout. Returns dict(times, coeffs, status, cost, n_samples, samples)."""
+    so = np.ascontiguousarray(seg_offsets, dtype=np.int32)
+    P = so.size - 1
+    total_S = int(so[-1])
+    w = _f64(waypoints)
+    m = np.ascontiguousarray(fixed_mask, dtype=np.uint8)
+    v = _f64(fixed_values)
+    lim = _f64(limits)
+    t = _f64(seg_times).copy()
+    coeffs = np.zeros((total_S, D, N))
+    status = np.zeros(P, dtype=np.int32)
+    cost = np.zeros(P)
+    ns = np.zeros(P, dtype=np.int32)
+    samples = np.zeros((P, max(sample_capacity, 1), D))
+    opt = Options(deriv, time_alloc_method, int(estimate_times), default_nlopt(max_iterations), float(sampling_dt))
+    lib().mto_solve_batch(P, so.ctypes.data_as(C.POINTER(C.c_int32)), _dp(w), m.ctypes.data_as(C.POINTER(C.c_uint8)),
+                          _dp(v), _dp(lim), C.byref(opt), _dp(t), _dp(coeffs),
+                          status.ctypes.data_as(C.POINTER(C.c_int32)), _dp(cost),
+                          ns.ctypes.data_as(C.POINTER(C.c_int32)), _dp(samples) if sample_capacity > 0 else None,
+                          sample_capacity, n_threads)
+    return dict(times=t, coeffs=coeffs, status=status, cost=cost, n_samples=ns,
+                samples=samples if sample_capacity > 0 else None)
