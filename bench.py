@@ -1,0 +1,226 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark: trajectories/s for a batch of 10-segment min-snap paths.
+
+    python bench.py --gpus N --steps K --warmup W        (N > 1: launched by torch.distributed.run)
+
+A "step" is one pass of the hot path over one batch whose inputs already sit in HBM.  Default
+workload = BASELINE.json configs[1]: 1024 random 10-segment order-10 min-snap paths, fixed (Euclidean)
+segment times, linear QP only: the Hessian/mapping-block assembly kernel + the block-Cholesky solve
+kernel per step.  `--workload nonlinear` times configs[2] (Mellinger outer loop + feasibility scaling +
+sampling) instead.  Weak scaling: every rank owns `--paths` paths; for N > 1 each step ends with the one
+RCCL gather of coefficients / times / status to rank 0.
+
+Prints ONE JSON line (rank 0) with `roofline` (assembly kernel, HBM-write bound, HIP-event timed on the
+launch stream) and `cpu_baseline` (the C oracle timed on this box's host cores).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+ASSEMBLY_BYTES_PER_SEGMENT = 8 + 800 + 800   # read T, write full 10x10 f64 H and A^-1
+
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--workload", choices=["linear", "nonlinear"], default="linear")
+    ap.add_argument("--paths", type=int, default=1024, help="paths per GPU")
+    ap.add_argument("--segments", type=int, default=10)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip the secondary (other workload) measurement")
+    return ap.parse_args()
+
+
+def time_steps(step_fn, steps, warmup, dist, torch):
+    for _ in range(warmup):
+        step_fn()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step_fn()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    return elapsed
+
+
+def kernel_event_ms(launch_fn, reps, torch):
+    """Average duration of one launch, HIP events on the launch stream around every single launch."""
+    starts = [torch.cuda.Event(enable_timing=True) for _ in range(reps)]
+    stops = [torch.cuda.Event(enable_timing=True) for _ in range(reps)]
+    for i in range(reps):
+        starts[i].record()
+        launch_fn()
+        stops[i].record()
+    torch.cuda.synchronize()
+    per = sorted(s.elapsed_time(e) for s, e in zip(starts, stops))
+    return float(np.mean(per)), float(per[len(per) // 2])
+
+
+def main():
+    args = parse_args()
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    import torch
+    dist = None
+    if world > 1:
+        import torch.distributed as dist_mod
+        torch.cuda.set_device(local_rank)
+        dist_mod.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        dist = dist_mod
+    else:
+        torch.cuda.set_device(0)
+    dev = torch.device("cuda", local_rank if world > 1 else 0)
+
+    from mrs_uav_trajectory_generation_amd import api, problem as pr
+
+    # every rank generates its own shard: path p of rank r is seeded with r * paths + p
+    batch = pr.random_batch(args.paths, args.segments, seed0=rank * args.paths)
+    ctx = api.Context(dev.index)
+    ctx.use_torch_stream()
+    plan = api.Plan(ctx, batch.seg_offsets)
+    db = api.DeviceBatch(batch, dev, sample_capacity=512)
+    nS, P = batch.n_segments, batch.n_paths
+
+    # initial (Euclidean) segment times are computed once on the device and kept: "fixed times"
+    est = api.default_options(derivative_to_optimize=4, estimate_times=1)
+    plan.solve(est, db.fixed_mask, db.fixed_values, db.seg_times, db.coeffs, db.status, db.cost,
+               waypoints=db.waypoints, limits=db.limits)
+    torch.cuda.synchronize()
+    t_init = db.seg_times.clone()
+
+    opt_lin = api.default_options(derivative_to_optimize=4)
+    opt_nl = api.default_options(derivative_to_optimize=4, time_alloc_method=api.TIME_ALLOC_MELLINGER,
+                                 sampling_dt=0.2, sample_capacity=512)
+
+    gather_bufs = None
+    if dist is not None:
+        gather_bufs = dict(
+            coeffs=[torch.empty_like(db.coeffs) for _ in range(world)] if rank == 0 else None,
+            times=[torch.empty_like(db.seg_times) for _ in range(world)] if rank == 0 else None,
+            status=[torch.empty_like(db.status) for _ in range(world)] if rank == 0 else None)
+
+    def final_gather():
+        dist.gather(db.coeffs, gather_bufs["coeffs"], dst=0)
+        dist.gather(db.seg_times, gather_bufs["times"], dst=0)
+        dist.gather(db.status, gather_bufs["status"], dst=0)
+
+    def step_linear():
+        plan.solve(opt_lin, db.fixed_mask, db.fixed_values, db.seg_times, db.coeffs, db.status, db.cost)
+        if dist is not None:
+            final_gather()
+
+    def step_nonlinear():
+        db.seg_times.copy_(t_init)   # the outer loop overwrites the times: restart from the same point
+        plan.solve(opt_nl, db.fixed_mask, db.fixed_values, db.seg_times, db.coeffs, db.status, db.cost,
+                   limits=db.limits, n_samples=db.n_samples, samples=db.samples)
+        if dist is not None:
+            final_gather()
+
+    steps_fn = {"linear": step_linear, "nonlinear": step_nonlinear}
+    elapsed = time_steps(steps_fn[args.workload], args.steps, args.warmup, dist, torch)
+    total_paths = P * world * args.steps
+    value = total_paths / elapsed
+
+    # ---- roofline of the assembly kernel (rank 0's device; HIP events on the launch stream) ----
+    Hbuf = torch.empty(plan.block_doubles, dtype=torch.float64, device=dev)
+    Abuf = torch.empty(plan.block_doubles, dtype=torch.float64, device=dev)
+
+    def launch_assemble():
+        plan.assemble(4, t_init, Hbuf, Abuf)
+
+    for _ in range(10):
+        launch_assemble()
+    torch.cuda.synchronize()
+    mean_ms, med_ms = kernel_event_ms(launch_assemble, 200, torch)
+    alg_bytes = ASSEMBLY_BYTES_PER_SEGMENT * nS
+    achieved = alg_bytes / (mean_ms * 1e-3) / 1e9
+    roofline = dict(kernel="assemble_blocks_kernel", bound="hbm", achieved=achieved, peak=HBM_PEAK_GBS, unit="GB/s",
+                    frac=achieved / HBM_PEAK_GBS, traffic=None, bytes_per_launch=alg_bytes,
+                    avg_launch_us=mean_ms * 1e3, median_launch_us=med_ms * 1e3)
+
+    extras = {}
+    if not args.no_extras:
+        other = "nonlinear" if args.workload == "linear" else "linear"
+        k2 = max(5, args.steps // 10) if other == "nonlinear" else args.steps
+        el2 = time_steps(steps_fn[other], k2, 3, dist, torch)
+        extras[other] = dict(value=P * world * k2 / el2, unit="trajectories/s", steps=k2, ms_per_step=el2 / k2 * 1e3)
+
+    # ---- parity of this very batch against the oracle (max-coeff err vs CPU ref) + CPU baseline ----
+    cpu = None
+    err = None
+    if rank == 0 and not args.no_cpu_baseline:
+        from oracle import pyoracle as po
+        steps_fn["linear"]()
+        torch.cuda.synchronize()
+        times = t_init.cpu().numpy()
+        n_cpu = min(P, 1024)
+        sub = batch.select(range(n_cpu)) if n_cpu < P else batch
+        sub_t = times[:sub.n_segments]
+        t0 = time.perf_counter()
+        ref = po.solve_batch(sub.seg_offsets, sub.waypoints, sub.fixed_mask, sub.fixed_values, sub.limits, sub_t, deriv=4)
+        dt1 = time.perf_counter() - t0
+        cores = os.cpu_count() or 1
+        t0 = time.perf_counter()
+        po.solve_batch(sub.seg_offsets, sub.waypoints, sub.fixed_mask, sub.fixed_values, sub.limits, sub_t, deriv=4,
+                       n_threads=cores)
+        dtn = time.perf_counter() - t0
+        gpu_c = db.coeffs.cpu().numpy()[:sub.n_segments]
+        worst = 0.0
+        for p in range(sub.n_paths):
+            a, b = sub.seg_offsets[p], sub.seg_offsets[p + 1]
+            worst = max(worst, float(np.max(np.abs(gpu_c[a:b] - ref["coeffs"][a:b])) / np.max(np.abs(ref["coeffs"][a:b]))))
+        err = worst
+        cpu = dict(value=n_cpu / dt1, unit="trajectories/s", cores=1, kind="port",
+                   sample="%d of the %d paths of this batch, linear QP, C oracle (reference-style arithmetic, dense QR)"
+                          % (n_cpu, P),
+                   value_all_cores=n_cpu / dtn, cores_all=cores)
+        if args.workload == "nonlinear" or not args.no_extras:
+            n_nl = min(P, 256)
+            subn = batch.select(range(n_nl))
+            t0 = time.perf_counter()
+            po.solve_batch(subn.seg_offsets, subn.waypoints, subn.fixed_mask, subn.fixed_values, subn.limits,
+                           times[:subn.n_segments], deriv=4, time_alloc_method=2, sampling_dt=0.2, sample_capacity=512)
+            cpu["nonlinear_value"] = n_nl / (time.perf_counter() - t0)
+            cpu["nonlinear_sample"] = "%d paths, Mellinger outer loop + scaling + sampling, 1 thread" % n_nl
+
+    if rank == 0:
+        line = dict(metric="trajectories/sec (batch of N-seg min-snap paths)", value=value, unit="trajectories/s",
+                    n_gpus=world, steps=args.steps, warmup=args.warmup, ms_per_step=elapsed / args.steps * 1e3,
+                    higher_is_better=True, scaling="weak", vs_baseline=None, dtype="f64", data="synthetic",
+                    config=dict(workload=("BASELINE configs[1]: %d random %d-segment order-10 min-snap paths per GPU, "
+                                          "fixed times, linear QP" if args.workload == "linear" else
+                                          "BASELINE configs[2]: %d random %d-segment paths per GPU, Mellinger outer loop "
+                                          "(<=10 evaluations) + feasibility scaling + sampling dt 0.2") % (P, args.segments),
+                                paths_per_gpu=P, segments=args.segments, parallelism="independent paths sharded per rank; "
+                                "RCCL gather of results to rank 0" if world > 1 else "single GPU"),
+                    max_coeff_err_vs_cpu_ref=err, roofline=roofline, cpu_baseline=cpu, extras=extras)
+        print(json.dumps(line), flush=True)
+    plan.close()
+    ctx.close()
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

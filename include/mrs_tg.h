@@ -98,8 +98,10 @@ int mrs_tg_abi_version(void);
 void mrs_tg_default_options(mrs_tg_options* opt);
 
 /* Launch on a caller-owned hipStream_t (e.g. torch.cuda.current_stream().cuda_stream) instead of
- * the context's own stream.  NULL restores the context's stream. */
+ * the context's own stream.  NULL means HIP's null (default) stream, which is what torch uses unless a
+ * side stream is current.  mrs_tg_reset_stream() goes back to the context's own stream. */
 int mrs_tg_set_stream(mrs_tg_ctx* ctx, void* hip_stream);
+int mrs_tg_reset_stream(mrs_tg_ctx* ctx);
 int mrs_tg_synchronize(mrs_tg_ctx* ctx);
 
 /* ---- one-call host interface ---------------------------------------------------------------- */

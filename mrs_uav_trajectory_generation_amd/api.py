@@ -1,0 +1,321 @@
+"""Python host binding of the C ABI (include/mrs_tg.h) -- ctypes only, no numerics here.
+
+The library is the product; this module only marshals buffers.  There is no CPU fallback: if
+libmrs_tg.so is missing or no HIP device is usable, the calls raise.
+
+Two ways in, mirroring the ABI:
+  * Context.solve_batch(batch, seg_times, ...)  host numpy arrays in / out (the nodelet-style call,
+    /root/reference/src/mrs_trajectory_generation.cpp:1046-1169 for a whole batch);
+  * Plan(...)  analysis once, then device-resident torch tensors, asynchronous on torch's current
+    stream (what bench.py times).
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+from .problem import Batch, N_COEFF, N_DIM
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libmrs_tg.so")
+
+TIME_ALLOC_NONE = -1
+TIME_ALLOC_MELLINGER = 2
+FLAG_FUSED_ASSEMBLY = 1
+
+KERNEL_ASSEMBLE, KERNEL_SOLVE_LINEAR, KERNEL_NONLINEAR = 0, 1, 2
+
+
+class MrsTgError(RuntimeError):
+    pass
+
+
+class Options(C.Structure):
+    _fields_ = [("derivative_to_optimize", C.c_int32), ("time_alloc_method", C.c_int32),
+                ("estimate_times", C.c_int32), ("max_iterations", C.c_int32),
+                ("f_rel", C.c_double), ("f_abs", C.c_double), ("x_rel", C.c_double), ("x_abs", C.c_double),
+                ("sampling_dt", C.c_double), ("sample_capacity", C.c_int32), ("flags", C.c_int32)]
+
+
+class Waypoint(C.Structure):
+    _fields_ = [("coords", C.c_double * 4), ("stop_at", C.c_uint8)]
+
+
+class InitialState(C.Structure):
+    _fields_ = [("heading", C.c_double), ("velocity", C.c_double * 4), ("acceleration", C.c_double * 4),
+                ("jerk", C.c_double * 4)]
+
+
+EXPORTED_SYMBOLS = [
+    "mrs_tg_create", "mrs_tg_destroy", "mrs_tg_last_error", "mrs_tg_abi_version", "mrs_tg_default_options",
+    "mrs_tg_set_stream", "mrs_tg_reset_stream", "mrs_tg_synchronize", "mrs_tg_solve_batch", "mrs_tg_plan_create", "mrs_tg_plan_destroy",
+    "mrs_tg_plan_n_paths", "mrs_tg_plan_n_segments", "mrs_tg_plan_max_segments", "mrs_tg_plan_get_order",
+    "mrs_tg_plan_assemble", "mrs_tg_plan_block_bytes", "mrs_tg_plan_solve", "mrs_tg_plan_cost_gradient",
+    "mrs_tg_plan_segment_maxima", "mrs_tg_set_profiling", "mrs_tg_last_kernel_ms", "mrs_tg_find_trajectory",
+]
+
+_lib = None
+
+
+def load_library():
+    """dlopen libmrs_tg.so (built in-tree by mrs_uav_trajectory_generation_amd.build). Raises if absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise MrsTgError("HIP extension %s is missing: run `python -m mrs_uav_trajectory_generation_amd.build` "
+                         "(there is no CPU fallback)" % LIB_PATH)
+    L = C.CDLL(LIB_PATH)
+    vp, dp, ip, bp = C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p  # raw addresses (host or device)
+    L.mrs_tg_create.restype = C.c_int
+    L.mrs_tg_create.argtypes = [C.c_int, C.POINTER(vp)]
+    L.mrs_tg_destroy.restype = None
+    L.mrs_tg_destroy.argtypes = [vp]
+    L.mrs_tg_last_error.restype = C.c_char_p
+    L.mrs_tg_last_error.argtypes = [vp]
+    L.mrs_tg_abi_version.restype = C.c_int
+    L.mrs_tg_default_options.restype = None
+    L.mrs_tg_default_options.argtypes = [C.POINTER(Options)]
+    L.mrs_tg_set_stream.restype = C.c_int
+    L.mrs_tg_set_stream.argtypes = [vp, vp]
+    L.mrs_tg_reset_stream.restype = C.c_int
+    L.mrs_tg_reset_stream.argtypes = [vp]
+    L.mrs_tg_synchronize.restype = C.c_int
+    L.mrs_tg_synchronize.argtypes = [vp]
+    L.mrs_tg_solve_batch.restype = C.c_int
+    L.mrs_tg_solve_batch.argtypes = [vp, C.c_int32, ip, dp, bp, dp, dp, C.POINTER(Options), dp, dp, ip, dp, ip, dp]
+    L.mrs_tg_plan_create.restype = C.c_int
+    L.mrs_tg_plan_create.argtypes = [vp, C.c_int32, ip, C.POINTER(vp)]
+    L.mrs_tg_plan_destroy.restype = None
+    L.mrs_tg_plan_destroy.argtypes = [vp]
+    for name in ("mrs_tg_plan_n_paths", "mrs_tg_plan_n_segments", "mrs_tg_plan_max_segments"):
+        getattr(L, name).restype = C.c_int32
+        getattr(L, name).argtypes = [vp]
+    L.mrs_tg_plan_get_order.restype = C.c_int
+    L.mrs_tg_plan_get_order.argtypes = [vp, ip]
+    L.mrs_tg_plan_assemble.restype = C.c_int
+    L.mrs_tg_plan_assemble.argtypes = [vp, C.c_int32, dp, dp, dp]
+    L.mrs_tg_plan_block_bytes.restype = C.c_size_t
+    L.mrs_tg_plan_block_bytes.argtypes = [vp]
+    L.mrs_tg_plan_solve.restype = C.c_int
+    L.mrs_tg_plan_solve.argtypes = [vp, dp, bp, dp, dp, C.POINTER(Options), dp, dp, ip, dp, ip, dp]
+    L.mrs_tg_plan_cost_gradient.restype = C.c_int
+    L.mrs_tg_plan_cost_gradient.argtypes = [vp, C.c_int32, bp, dp, dp, dp, dp]
+    L.mrs_tg_plan_segment_maxima.restype = C.c_int
+    L.mrs_tg_plan_segment_maxima.argtypes = [vp, dp, dp, dp]
+    L.mrs_tg_set_profiling.restype = C.c_int
+    L.mrs_tg_set_profiling.argtypes = [vp, C.c_int]
+    L.mrs_tg_last_kernel_ms.restype = C.c_int
+    L.mrs_tg_last_kernel_ms.argtypes = [vp, C.c_int, C.POINTER(C.c_float)]
+    L.mrs_tg_find_trajectory.restype = C.c_int
+    L.mrs_tg_find_trajectory.argtypes = [vp, C.POINTER(Waypoint), C.c_int32, C.POINTER(InitialState), dp,
+                                         C.POINTER(Options), C.c_int32, dp, dp, ip, ip, dp]
+    _lib = L
+    return L
+
+
+def default_options(**overrides):
+    opt = Options()
+    load_library().mrs_tg_default_options(C.byref(opt))
+    for k, v in overrides.items():
+        if not hasattr(opt, k):
+            raise TypeError("unknown option %r" % k)
+        setattr(opt, k, v)
+    return opt
+
+
+def _np_ptr(a):
+    return C.c_void_p(a.ctypes.data) if a is not None else None
+
+
+def _t_ptr(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else None
+
+
+class Context:
+    """One HIP device + stream (mrs_tg_ctx)."""
+
+    def __init__(self, device=0):
+        self._L = load_library()
+        h = C.c_void_p()
+        rc = self._L.mrs_tg_create(int(device), C.byref(h))
+        if rc != 0:
+            raise MrsTgError("mrs_tg_create failed (%d): %s" % (rc, self._L.mrs_tg_last_error(None).decode()))
+        self._h = h
+        self.device = int(device)
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._L.mrs_tg_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc, what):
+        if rc != 0:
+            raise MrsTgError("%s failed (%d): %s" % (what, rc, self._L.mrs_tg_last_error(self._h).decode()))
+
+    def use_torch_stream(self):
+        """Launch on torch's current HIP stream so torch events / allocator ordering apply."""
+        import torch
+        self._check(self._L.mrs_tg_set_stream(self._h, C.c_void_p(torch.cuda.current_stream().cuda_stream)), "set_stream")
+
+    def synchronize(self):
+        self._check(self._L.mrs_tg_synchronize(self._h), "synchronize")
+
+    def set_profiling(self, enabled):
+        self._check(self._L.mrs_tg_set_profiling(self._h, int(bool(enabled))), "set_profiling")
+
+    def last_kernel_ms(self, kernel_id):
+        ms = C.c_float(0)
+        self._check(self._L.mrs_tg_last_kernel_ms(self._h, int(kernel_id), C.byref(ms)), "last_kernel_ms")
+        return ms.value
+
+    def solve_batch(self, batch: Batch, seg_times=None, **opts):
+        """Host arrays in, host arrays out (mrs_tg_solve_batch).  seg_times None => estimate_times."""
+        opt = default_options(derivative_to_optimize=batch.derivative_to_optimize, **opts)
+        nS, P = batch.n_segments, batch.n_paths
+        if seg_times is None:
+            opt.estimate_times = 1
+            t = np.zeros(nS)
+        else:
+            t = np.ascontiguousarray(seg_times, dtype=np.float64).copy()
+            assert t.size == nS
+        coeffs = np.zeros((nS, N_DIM, N_COEFF))
+        status = np.zeros(P, dtype=np.int32)
+        cost = np.zeros(P)
+        sampling = opt.sampling_dt > 0
+        n_samples = np.zeros(P, dtype=np.int32) if sampling else None
+        samples = np.zeros((P, max(opt.sample_capacity, 1), N_DIM)) if sampling else None
+        rc = self._L.mrs_tg_solve_batch(self._h, P, _np_ptr(batch.seg_offsets), _np_ptr(batch.waypoints),
+                                        _np_ptr(batch.fixed_mask), _np_ptr(batch.fixed_values), _np_ptr(batch.limits),
+                                        C.byref(opt), _np_ptr(t), _np_ptr(coeffs), _np_ptr(status), _np_ptr(cost),
+                                        _np_ptr(n_samples), _np_ptr(samples))
+        self._check(rc, "mrs_tg_solve_batch")
+        return dict(times=t, coeffs=coeffs, status=status, cost=cost, n_samples=n_samples, samples=samples)
+
+    def find_trajectory(self, waypoints, stop_at=None, initial_state=None, limits=None, relax_heading=False,
+                        sample_capacity=4096, **opts):
+        """findTrajectory() for one path (mrs_tg_find_trajectory)."""
+        from .problem import DEFAULT_LIMITS
+        wp = np.asarray(waypoints, dtype=np.float64).reshape(-1, 4)
+        n = wp.shape[0]
+        arr = (Waypoint * n)()
+        for i in range(n):
+            for k in range(4):
+                arr[i].coords[k] = wp[i, k]
+            arr[i].stop_at = int(bool(stop_at[i])) if stop_at is not None else 0
+        init = None
+        if initial_state is not None:
+            init = InitialState()
+            init.heading = float(initial_state["heading"])
+            for k in range(4):
+                init.velocity[k] = float(initial_state["velocity"][k])
+                init.acceleration[k] = float(initial_state["acceleration"][k])
+                init.jerk[k] = float(initial_state["jerk"][k])
+        lim = np.ascontiguousarray(DEFAULT_LIMITS if limits is None else limits, dtype=np.float64)
+        opts.setdefault("time_alloc_method", TIME_ALLOC_MELLINGER)
+        opts.setdefault("sampling_dt", 0.2)
+        opt = default_options(sample_capacity=sample_capacity, **opts)
+        S = n - 1
+        times = np.zeros(S)
+        coeffs = np.zeros((S, N_DIM, N_COEFF))
+        status = C.c_int32(0)
+        ns = C.c_int32(0)
+        samples = np.zeros((sample_capacity, N_DIM))
+        rc = self._L.mrs_tg_find_trajectory(self._h, arr, n, C.byref(init) if init is not None else None, _np_ptr(lim),
+                                            C.byref(opt), int(bool(relax_heading)), _np_ptr(times), _np_ptr(coeffs),
+                                            C.cast(C.byref(status), C.c_void_p), C.cast(C.byref(ns), C.c_void_p),
+                                            _np_ptr(samples))
+        self._check(rc, "mrs_tg_find_trajectory")
+        return dict(times=times, coeffs=coeffs, status=status.value, n_samples=ns.value,
+                    samples=samples[:min(ns.value, sample_capacity)])
+
+
+class Plan:
+    """Batch structure analysed once; device-resident (torch) operands afterwards (mrs_tg_plan)."""
+
+    def __init__(self, ctx: Context, seg_offsets):
+        self.ctx = ctx
+        self._L = ctx._L
+        so = np.ascontiguousarray(seg_offsets, dtype=np.int32)
+        h = C.c_void_p()
+        ctx._check(self._L.mrs_tg_plan_create(ctx._h, so.size - 1, _np_ptr(so), C.byref(h)), "mrs_tg_plan_create")
+        self._h = h
+        self.seg_offsets = so
+        self.n_paths = self._L.mrs_tg_plan_n_paths(h)
+        self.n_segments = self._L.mrs_tg_plan_n_segments(h)
+        self.max_segments = self._L.mrs_tg_plan_max_segments(h)
+        order = np.zeros(max(self.n_paths, 1), dtype=np.int32)
+        ctx._check(self._L.mrs_tg_plan_get_order(h, _np_ptr(order)), "mrs_tg_plan_get_order")
+        self.order = order[:self.n_paths]
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._L.mrs_tg_plan_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @property
+    def block_doubles(self):
+        return self._L.mrs_tg_plan_block_bytes(self._h) // 8
+
+    def assemble(self, derivative, seg_times_dev, H_dev, Ainv_dev):
+        self.ctx._check(self._L.mrs_tg_plan_assemble(self._h, int(derivative), _t_ptr(seg_times_dev), _t_ptr(H_dev),
+                                                     _t_ptr(Ainv_dev)), "mrs_tg_plan_assemble")
+
+    def blocks_to_segments(self, blocks):
+        """Slot-major SoA block buffer (torch or numpy) -> numpy [sum S][10][10] in CSR segment order."""
+        arr = blocks.detach().cpu().numpy() if hasattr(blocks, "detach") else np.asarray(blocks)
+        P = self.n_paths
+        soa = arr.reshape(self.max_segments, 100, P)
+        out = np.zeros((self.n_segments, 10, 10))
+        for q, p in enumerate(self.order):
+            s0, s1 = int(self.seg_offsets[p]), int(self.seg_offsets[p + 1])
+            out[s0:s1] = soa[:s1 - s0, :, q].reshape(s1 - s0, 10, 10)
+        return out
+
+    def solve(self, opt, fixed_mask, fixed_values, seg_times, coeffs, status, cost=None, waypoints=None, limits=None,
+              n_samples=None, samples=None):
+        self.ctx._check(self._L.mrs_tg_plan_solve(self._h, _t_ptr(waypoints), _t_ptr(fixed_mask), _t_ptr(fixed_values),
+                                                  _t_ptr(limits), C.byref(opt), _t_ptr(seg_times), _t_ptr(coeffs),
+                                                  _t_ptr(status), _t_ptr(cost), _t_ptr(n_samples), _t_ptr(samples)),
+                        "mrs_tg_plan_solve")
+
+    def cost_gradient(self, derivative, fixed_mask, fixed_values, seg_times, cost, grad):
+        self.ctx._check(self._L.mrs_tg_plan_cost_gradient(self._h, int(derivative), _t_ptr(fixed_mask),
+                                                          _t_ptr(fixed_values), _t_ptr(seg_times), _t_ptr(cost),
+                                                          _t_ptr(grad)), "mrs_tg_plan_cost_gradient")
+
+    def segment_maxima(self, coeffs, seg_times, maxima):
+        self.ctx._check(self._L.mrs_tg_plan_segment_maxima(self._h, _t_ptr(coeffs), _t_ptr(seg_times), _t_ptr(maxima)),
+                        "mrs_tg_plan_segment_maxima")
+
+
+class DeviceBatch:
+    """A Batch uploaded to HBM as torch tensors, plus output tensors, for the plan interface."""
+
+    def __init__(self, batch: Batch, device="cuda:0", sample_capacity=0):
+        import torch
+        dev = torch.device(device)
+        self.batch = batch
+        self.waypoints = torch.from_numpy(batch.waypoints).to(dev)
+        self.fixed_mask = torch.from_numpy(batch.fixed_mask).to(dev)
+        self.fixed_values = torch.from_numpy(batch.fixed_values).to(dev)
+        self.limits = torch.from_numpy(batch.limits).to(dev)
+        nS, P = batch.n_segments, batch.n_paths
+        self.seg_times = torch.zeros(nS, dtype=torch.float64, device=dev)
+        self.coeffs = torch.zeros((nS, N_DIM, N_COEFF), dtype=torch.float64, device=dev)
+        self.status = torch.zeros(P, dtype=torch.int32, device=dev)
+        self.cost = torch.zeros(P, dtype=torch.float64, device=dev)
+        self.n_samples = torch.zeros(P, dtype=torch.int32, device=dev)
+        self.samples = torch.zeros((P, max(sample_capacity, 1), N_DIM), dtype=torch.float64, device=dev)

@@ -1,0 +1,541 @@
+// mrs_tg_abi.hip -- implementation of the C ABI declared in include/mrs_tg.h.
+// Context / plan bookkeeping, workspace management, host<->device marshalling and the launch
+// sequences.  No numerics live here and nothing falls back to the CPU: every failure is reported.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cfloat>
+#include <cstdarg>
+#include <cstdio>
+#include <cmath>
+#include <cstring>
+#include <mutex>
+#include <new>
+#include <numeric>
+#include <string>
+#include <vector>
+
+#include "../../include/mrs_tg.h"
+#include "mrs_tg_launch.h"
+#include "mrs_tg_nonlinear.h"
+
+namespace {
+
+std::mutex g_err_mutex;
+std::string g_last_error;
+
+void set_global_error(const std::string& s) {
+  std::lock_guard<std::mutex> lk(g_err_mutex);
+  g_last_error = s;
+}
+
+}  // namespace
+
+struct mrs_tg_ctx {
+  int device = -1;
+  hipStream_t own_stream = nullptr;
+  hipStream_t stream = nullptr;
+  std::string last_error;
+  bool profiling = false;
+  hipEvent_t ev_start[3] = {nullptr, nullptr, nullptr};
+  hipEvent_t ev_stop[3] = {nullptr, nullptr, nullptr};
+  bool ev_valid[3] = {false, false, false};
+  hipDeviceProp_t prop;
+};
+
+struct mrs_tg_plan {
+  mrs_tg_ctx* ctx = nullptr;
+  mrs_tg::BatchView view{};
+  std::vector<int32_t> order_host;
+  std::vector<int32_t> seg_offsets_host;
+  int32_t* d_seg_offsets = nullptr;
+  int32_t* d_order = nullptr;
+  int32_t* d_slot_start = nullptr;
+  // lazily allocated scratch
+  double* d_ws = nullptr;
+  size_t ws_doubles = 0;
+  double* d_H = nullptr;
+  double* d_Ainv = nullptr;
+  mrs_tg::NonlinearPlan nl;
+};
+
+namespace {
+
+int fail(mrs_tg_ctx* ctx, int code, const char* fmt, ...) {
+  char buf[512];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof(buf), fmt, ap);
+  va_end(ap);
+  if (ctx) ctx->last_error = buf;
+  set_global_error(buf);
+  return code;
+}
+
+#define HIP_TRY(ctx, expr)                                                                        \
+  do {                                                                                            \
+    hipError_t e__ = (expr);                                                                      \
+    if (e__ != hipSuccess) return fail((ctx), MRS_TG_ERR_HIP, "%s failed: %s", #expr, hipGetErrorString(e__)); \
+  } while (0)
+
+struct ProfileScope {
+  mrs_tg_ctx* ctx;
+  int id;
+  ProfileScope(mrs_tg_ctx* c, int kernel_id) : ctx(c), id(kernel_id) {
+    if (ctx->profiling) (void)hipEventRecord(ctx->ev_start[id], ctx->stream);
+  }
+  ~ProfileScope() {
+    if (ctx->profiling) {
+      (void)hipEventRecord(ctx->ev_stop[id], ctx->stream);
+      ctx->ev_valid[id] = true;
+    }
+  }
+};
+
+int ensure_ws(mrs_tg_plan* plan, size_t doubles) {
+  if (plan->ws_doubles >= doubles) return MRS_TG_OK;
+  if (plan->d_ws) (void)hipFree(plan->d_ws);
+  plan->d_ws = nullptr;
+  plan->ws_doubles = 0;
+  HIP_TRY(plan->ctx, hipMalloc(&plan->d_ws, doubles * sizeof(double)));
+  plan->ws_doubles = doubles;
+  return MRS_TG_OK;
+}
+
+int ensure_blocks(mrs_tg_plan* plan) {
+  if (plan->d_H) return MRS_TG_OK;
+  const size_t bytes = mrs_tg_plan_block_bytes(plan);
+  HIP_TRY(plan->ctx, hipMalloc(&plan->d_H, bytes));
+  HIP_TRY(plan->ctx, hipMalloc(&plan->d_Ainv, bytes));
+  return MRS_TG_OK;
+}
+
+int check_options(mrs_tg_ctx* ctx, const mrs_tg_options* opt) {
+  if (!opt) return fail(ctx, MRS_TG_ERR_INVALID_ARG, "options is NULL");
+  if (opt->derivative_to_optimize < 0 || opt->derivative_to_optimize > 4)
+    return fail(ctx, MRS_TG_ERR_INVALID_ARG, "derivative_to_optimize %d outside [0, 4]", opt->derivative_to_optimize);
+  if (opt->time_alloc_method != MRS_TG_TIME_ALLOC_NONE && opt->time_alloc_method != MRS_TG_TIME_ALLOC_MELLINGER)
+    return fail(ctx, MRS_TG_ERR_UNSUPPORTED,
+                "time_alloc_method %d is not implemented on the HIP path (supported: -1 fixed times, 2 Mellinger)",
+                opt->time_alloc_method);
+  if (opt->sampling_dt > 0 && opt->sample_capacity < 0)
+    return fail(ctx, MRS_TG_ERR_INVALID_ARG, "negative sample_capacity");
+  return MRS_TG_OK;
+}
+
+}  // namespace
+
+namespace {
+struct DevBuf {
+  void* p = nullptr;
+  ~DevBuf() {
+    if (p) (void)hipFree(p);
+  }
+  hipError_t alloc(size_t bytes) { return hipMalloc(&p, bytes ? bytes : 8); }
+  template <class T>
+  T* as() {
+    return static_cast<T*>(p);
+  }
+};
+struct PlanGuard {
+  mrs_tg_plan* p = nullptr;
+  ~PlanGuard() { mrs_tg_plan_destroy(p); }
+};
+}  // namespace
+
+namespace {
+double wrap_pi_host(double a) {
+  const double two_pi = 2.0 * M_PI;
+  double r = std::fmod(a + M_PI, two_pi);
+  if (r < 0) r += two_pi;
+  return r - M_PI;
+}
+// mrs_lib sradians::unwrap(what, from) as used at src/mrs_trajectory_generation.cpp:935
+double unwrap_heading(double what, double from) {
+  const double two_pi = 2.0 * M_PI;
+  double d = wrap_pi_host(what) - wrap_pi_host(from);
+  if (d < -M_PI) d += two_pi;
+  else if (d >= M_PI) d -= two_pi;
+  return from + d;
+}
+}  // namespace
+
+extern "C" {
+
+int mrs_tg_abi_version(void) { return MRS_TG_ABI_VERSION; }
+
+void mrs_tg_default_options(mrs_tg_options* opt) {
+  if (!opt) return;
+  std::memset(opt, 0, sizeof(*opt));
+  opt->derivative_to_optimize = 4;
+  opt->time_alloc_method = MRS_TG_TIME_ALLOC_NONE;
+  opt->estimate_times = 0;
+  opt->max_iterations = 10;  // config/private/trajectory_generation.yaml:10
+  opt->f_rel = 0.05;         // src/mrs_trajectory_generation.cpp:884
+  opt->f_abs = -1.0;
+  opt->x_rel = 0.1;          // src/mrs_trajectory_generation.cpp:885
+  opt->x_abs = -1.0;
+  opt->sampling_dt = 0.0;
+  opt->sample_capacity = 0;
+  opt->flags = 0;
+}
+
+const char* mrs_tg_last_error(const mrs_tg_ctx* ctx) {
+  if (ctx) return ctx->last_error.c_str();
+  static thread_local std::string copy;
+  std::lock_guard<std::mutex> lk(g_err_mutex);
+  copy = g_last_error;
+  return copy.c_str();
+}
+
+int mrs_tg_create(int device_ordinal, mrs_tg_ctx** ctx_out) {
+  if (!ctx_out) return fail(nullptr, MRS_TG_ERR_INVALID_ARG, "ctx_out is NULL");
+  *ctx_out = nullptr;
+  int n = 0;
+  hipError_t e = hipGetDeviceCount(&n);
+  if (e != hipSuccess || n <= 0)
+    return fail(nullptr, MRS_TG_ERR_NO_DEVICE, "no HIP device available (%s); this library has no CPU fallback",
+                e != hipSuccess ? hipGetErrorString(e) : "device count is 0");
+  if (device_ordinal < 0 || device_ordinal >= n)
+    return fail(nullptr, MRS_TG_ERR_INVALID_ARG, "device ordinal %d outside [0, %d)", device_ordinal, n);
+  mrs_tg_ctx* ctx = new (std::nothrow) mrs_tg_ctx();
+  if (!ctx) return fail(nullptr, MRS_TG_ERR_NOMEM, "out of host memory");
+  ctx->device = device_ordinal;
+  if ((e = hipSetDevice(device_ordinal)) != hipSuccess || (e = hipGetDeviceProperties(&ctx->prop, device_ordinal)) != hipSuccess ||
+      (e = hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking)) != hipSuccess) {
+    delete ctx;
+    return fail(nullptr, MRS_TG_ERR_HIP, "device setup failed: %s", hipGetErrorString(e));
+  }
+  ctx->stream = ctx->own_stream;
+  for (int i = 0; i < 3; ++i) {
+    (void)hipEventCreate(&ctx->ev_start[i]);
+    (void)hipEventCreate(&ctx->ev_stop[i]);
+  }
+  *ctx_out = ctx;
+  return MRS_TG_OK;
+}
+
+void mrs_tg_destroy(mrs_tg_ctx* ctx) {
+  if (!ctx) return;
+  (void)hipSetDevice(ctx->device);
+  (void)hipStreamSynchronize(ctx->stream);
+  for (int i = 0; i < 3; ++i) {
+    if (ctx->ev_start[i]) (void)hipEventDestroy(ctx->ev_start[i]);
+    if (ctx->ev_stop[i]) (void)hipEventDestroy(ctx->ev_stop[i]);
+  }
+  if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
+  delete ctx;
+}
+
+int mrs_tg_set_stream(mrs_tg_ctx* ctx, void* hip_stream) {
+  if (!ctx) return fail(nullptr, MRS_TG_ERR_INVALID_ARG, "ctx is NULL");
+  ctx->stream = reinterpret_cast<hipStream_t>(hip_stream);
+  return MRS_TG_OK;
+}
+
+int mrs_tg_reset_stream(mrs_tg_ctx* ctx) {
+  if (!ctx) return fail(nullptr, MRS_TG_ERR_INVALID_ARG, "ctx is NULL");
+  ctx->stream = ctx->own_stream;
+  return MRS_TG_OK;
+}
+
+int mrs_tg_synchronize(mrs_tg_ctx* ctx) {
+  if (!ctx) return fail(nullptr, MRS_TG_ERR_INVALID_ARG, "ctx is NULL");
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  return MRS_TG_OK;
+}
+
+int mrs_tg_set_profiling(mrs_tg_ctx* ctx, int enabled) {
+  if (!ctx) return fail(nullptr, MRS_TG_ERR_INVALID_ARG, "ctx is NULL");
+  ctx->profiling = enabled != 0;
+  return MRS_TG_OK;
+}
+
+int mrs_tg_last_kernel_ms(mrs_tg_ctx* ctx, int kernel_id, float* ms_out) {
+  if (!ctx || !ms_out) return fail(ctx, MRS_TG_ERR_INVALID_ARG, "NULL argument");
+  if (kernel_id < 0 || kernel_id > 2 || !ctx->ev_valid[kernel_id])
+    return fail(ctx, MRS_TG_ERR_INVALID_ARG, "no timed launch recorded for kernel id %d", kernel_id);
+  HIP_TRY(ctx, hipEventSynchronize(ctx->ev_stop[kernel_id]));
+  HIP_TRY(ctx, hipEventElapsedTime(ms_out, ctx->ev_start[kernel_id], ctx->ev_stop[kernel_id]));
+  return MRS_TG_OK;
+}
+
+// ---- plan ------------------------------------------------------------------------------------
+
+int mrs_tg_plan_create(mrs_tg_ctx* ctx, int32_t n_paths, const int32_t* so, mrs_tg_plan** plan_out) {
+  if (!ctx || !plan_out || !so) return fail(ctx, MRS_TG_ERR_INVALID_ARG, "NULL argument");
+  *plan_out = nullptr;
+  if (n_paths < 0) return fail(ctx, MRS_TG_ERR_INVALID_ARG, "negative n_paths");
+  if (so[0] != 0) return fail(ctx, MRS_TG_ERR_INVALID_ARG, "seg_offsets[0] must be 0");
+  int max_S = 0, min_S = n_paths ? INT32_MAX : 0;
+  for (int p = 0; p < n_paths; ++p) {
+    const int S = so[p + 1] - so[p];
+    if (S < 1) return fail(ctx, MRS_TG_ERR_INVALID_ARG, "path %d has %d segments (need >= 1)", p, S);
+    max_S = std::max(max_S, S);
+    min_S = std::min(min_S, S);
+  }
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  mrs_tg_plan* plan = new (std::nothrow) mrs_tg_plan();
+  if (!plan) return fail(ctx, MRS_TG_ERR_NOMEM, "out of host memory");
+  plan->ctx = ctx;
+  plan->seg_offsets_host.assign(so, so + n_paths + 1);
+  plan->order_host.resize(n_paths);
+  std::iota(plan->order_host.begin(), plan->order_host.end(), 0);
+  std::stable_sort(plan->order_host.begin(), plan->order_host.end(),
+                   [so](int a, int b) { return (so[a + 1] - so[a]) > (so[b + 1] - so[b]); });
+  // slot_start[j] = number of (q, j') pairs with j' < j; paths sorted longest first => slot j is a prefix
+  std::vector<int32_t> slot_start(max_S + 1, 0);
+  {
+    std::vector<int32_t> cnt(max_S + 1, 0);
+    for (int p = 0; p < n_paths; ++p) cnt[so[p + 1] - so[p]]++;  // paths with exactly S segments
+    int longer = 0;                                              // paths with S > j
+    std::vector<int32_t> per_slot(max_S, 0);
+    for (int j = max_S - 1; j >= 0; --j) {
+      longer += cnt[j + 1];
+      per_slot[j] = longer;
+    }
+    for (int j = 0; j < max_S; ++j) slot_start[j + 1] = slot_start[j] + per_slot[j];
+  }
+  auto cleanup = [&](int code) {
+    mrs_tg_plan_destroy(plan);
+    return code;
+  };
+  hipError_t e;
+  if ((e = hipMalloc(&plan->d_seg_offsets, sizeof(int32_t) * (n_paths + 1))) != hipSuccess ||
+      (e = hipMalloc(&plan->d_order, sizeof(int32_t) * std::max(n_paths, 1))) != hipSuccess ||
+      (e = hipMalloc(&plan->d_slot_start, sizeof(int32_t) * (max_S + 1))) != hipSuccess ||
+      (e = hipMemcpy(plan->d_seg_offsets, so, sizeof(int32_t) * (n_paths + 1), hipMemcpyHostToDevice)) != hipSuccess ||
+      (n_paths > 0 && (e = hipMemcpy(plan->d_order, plan->order_host.data(), sizeof(int32_t) * n_paths,
+                                     hipMemcpyHostToDevice)) != hipSuccess) ||
+      (e = hipMemcpy(plan->d_slot_start, slot_start.data(), sizeof(int32_t) * (max_S + 1), hipMemcpyHostToDevice)) !=
+          hipSuccess)
+    return cleanup(fail(ctx, MRS_TG_ERR_HIP, "plan allocation failed: %s", hipGetErrorString(e)));
+  plan->view.n_paths = n_paths;
+  plan->view.n_segments = so[n_paths];
+  plan->view.max_segments = max_S;
+  plan->view.uniform_S = (n_paths > 0 && min_S == max_S) ? max_S : 0;
+  plan->view.seg_offsets = plan->d_seg_offsets;
+  plan->view.order = plan->d_order;
+  plan->view.slot_start = plan->d_slot_start;
+  const int rc = mrs_tg::nonlinear_plan_build(plan->nl, plan->seg_offsets_host, plan->order_host);
+  if (rc != 0) return cleanup(fail(ctx, MRS_TG_ERR_HIP, "nonlinear plan setup failed"));
+  *plan_out = plan;
+  return MRS_TG_OK;
+}
+
+void mrs_tg_plan_destroy(mrs_tg_plan* plan) {
+  if (!plan) return;
+  (void)hipSetDevice(plan->ctx->device);
+  (void)hipStreamSynchronize(plan->ctx->stream);
+  mrs_tg::nonlinear_plan_free(plan->nl);
+  if (plan->d_seg_offsets) (void)hipFree(plan->d_seg_offsets);
+  if (plan->d_order) (void)hipFree(plan->d_order);
+  if (plan->d_slot_start) (void)hipFree(plan->d_slot_start);
+  if (plan->d_ws) (void)hipFree(plan->d_ws);
+  if (plan->d_H) (void)hipFree(plan->d_H);
+  if (plan->d_Ainv) (void)hipFree(plan->d_Ainv);
+  delete plan;
+}
+
+int32_t mrs_tg_plan_n_paths(const mrs_tg_plan* plan) { return plan ? plan->view.n_paths : 0; }
+int32_t mrs_tg_plan_n_segments(const mrs_tg_plan* plan) { return plan ? plan->view.n_segments : 0; }
+int32_t mrs_tg_plan_max_segments(const mrs_tg_plan* plan) { return plan ? plan->view.max_segments : 0; }
+
+int mrs_tg_plan_get_order(const mrs_tg_plan* plan, int32_t* order_out) {
+  if (!plan || !order_out) return fail(plan ? plan->ctx : nullptr, MRS_TG_ERR_INVALID_ARG, "NULL argument");
+  std::copy(plan->order_host.begin(), plan->order_host.end(), order_out);
+  return MRS_TG_OK;
+}
+
+size_t mrs_tg_plan_block_bytes(const mrs_tg_plan* plan) {
+  if (!plan) return 0;
+  return (size_t)plan->view.max_segments * 100 * (size_t)plan->view.n_paths * sizeof(double);
+}
+
+int mrs_tg_plan_assemble(mrs_tg_plan* plan, int32_t d, const double* seg_times_dev, double* H_dev, double* Ainv_dev) {
+  if (!plan || !seg_times_dev || !H_dev || !Ainv_dev)
+    return fail(plan ? plan->ctx : nullptr, MRS_TG_ERR_INVALID_ARG, "NULL argument");
+  mrs_tg_ctx* ctx = plan->ctx;
+  if (d < 0 || d > 4) return fail(ctx, MRS_TG_ERR_INVALID_ARG, "derivative_to_optimize %d outside [0, 4]", d);
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  ProfileScope ps(ctx, 0);
+  HIP_TRY(ctx, mrs_tg::launch_assemble(plan->view, d, seg_times_dev, H_dev, Ainv_dev, ctx->stream));
+  return MRS_TG_OK;
+}
+
+int mrs_tg_plan_solve(mrs_tg_plan* plan, const double* wp, const uint8_t* mask, const double* vals, const double* limits,
+                      const mrs_tg_options* opt, double* seg_times, double* coeffs, int32_t* status, double* cost,
+                      int32_t* n_samples, double* samples) {
+  if (!plan) return fail(nullptr, MRS_TG_ERR_INVALID_ARG, "plan is NULL");
+  mrs_tg_ctx* ctx = plan->ctx;
+  int rc = check_options(ctx, opt);
+  if (rc != MRS_TG_OK) return rc;
+  if (!mask || !vals || !seg_times || !coeffs || !status)
+    return fail(ctx, MRS_TG_ERR_INVALID_ARG, "fixed_mask, fixed_values, seg_times, coeffs_out and status_out are required");
+  if ((opt->estimate_times || opt->time_alloc_method == MRS_TG_TIME_ALLOC_MELLINGER) && !limits)
+    return fail(ctx, MRS_TG_ERR_INVALID_ARG, "limits are required for time estimation and for the Mellinger mode");
+  if (opt->estimate_times && !wp) return fail(ctx, MRS_TG_ERR_INVALID_ARG, "waypoints are required when estimate_times is set");
+  if (opt->sampling_dt > 0 && !n_samples) return fail(ctx, MRS_TG_ERR_INVALID_ARG, "n_samples_out is required when sampling");
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  const mrs_tg::BatchView& b = plan->view;
+  const int d = opt->derivative_to_optimize;
+  if (opt->estimate_times) HIP_TRY(ctx, mrs_tg::launch_estimate_times(b, wp, limits, seg_times, ctx->stream));
+
+  if (opt->time_alloc_method == MRS_TG_TIME_ALLOC_MELLINGER) {
+    mrs_tg::NonlinearParams prm;
+    prm.derivative = d;
+    prm.max_iterations = opt->max_iterations;
+    prm.f_rel = opt->f_rel;
+    prm.f_abs = opt->f_abs;
+    prm.x_rel = opt->x_rel;
+    prm.x_abs = opt->x_abs;
+    ProfileScope ps(ctx, 2);
+    HIP_TRY(ctx, mrs_tg::launch_nonlinear(plan->nl, b, prm, mask, vals, limits, seg_times, coeffs, status, cost,
+                                          ctx->stream));
+  } else {
+    const bool fused = (opt->flags & MRS_TG_FLAG_FUSED_ASSEMBLY) != 0;
+    if ((rc = ensure_ws(plan, mrs_tg::linear_workspace_doubles(b))) != MRS_TG_OK) return rc;
+    if (!fused) {
+      if ((rc = ensure_blocks(plan)) != MRS_TG_OK) return rc;
+      ProfileScope ps(ctx, 0);
+      HIP_TRY(ctx, mrs_tg::launch_assemble(b, d, seg_times, plan->d_H, plan->d_Ainv, ctx->stream));
+    }
+    ProfileScope ps(ctx, 1);
+    HIP_TRY(ctx, mrs_tg::launch_solve_linear(b, d, fused, mask, vals, seg_times, plan->d_H, plan->d_Ainv, plan->d_ws,
+                                             coeffs, status, cost, ctx->stream));
+  }
+  if (opt->sampling_dt > 0)
+    HIP_TRY(ctx, mrs_tg::launch_sample(b, coeffs, seg_times, opt->sampling_dt, opt->sample_capacity, n_samples, samples,
+                                       ctx->stream));
+  return MRS_TG_OK;
+}
+
+int mrs_tg_plan_cost_gradient(mrs_tg_plan* plan, int32_t d, const uint8_t* mask, const double* vals,
+                              const double* seg_times, double* cost, double* grad) {
+  if (!plan || !mask || !vals || !seg_times || !cost || !grad)
+    return fail(plan ? plan->ctx : nullptr, MRS_TG_ERR_INVALID_ARG, "NULL argument");
+  mrs_tg_ctx* ctx = plan->ctx;
+  if (d < 0 || d > 4) return fail(ctx, MRS_TG_ERR_INVALID_ARG, "derivative_to_optimize %d outside [0, 4]", d);
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  HIP_TRY(ctx, mrs_tg::launch_cost_gradient(plan->nl, plan->view, d, mask, vals, seg_times, cost, grad, ctx->stream));
+  return MRS_TG_OK;
+}
+
+int mrs_tg_plan_segment_maxima(mrs_tg_plan* plan, const double* coeffs, const double* seg_times, double* maxima) {
+  if (!plan || !coeffs || !seg_times || !maxima)
+    return fail(plan ? plan->ctx : nullptr, MRS_TG_ERR_INVALID_ARG, "NULL argument");
+  mrs_tg_ctx* ctx = plan->ctx;
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  HIP_TRY(ctx, mrs_tg::launch_segment_maxima(plan->view, coeffs, seg_times, maxima, ctx->stream));
+  return MRS_TG_OK;
+}
+
+// ---- one-call host interface ------------------------------------------------------------------
+
+
+int mrs_tg_solve_batch(mrs_tg_ctx* ctx, int32_t n_paths, const int32_t* so, const double* wp, const uint8_t* mask,
+                       const double* vals, const double* limits, const mrs_tg_options* opt, double* seg_times,
+                       double* coeffs, int32_t* status, double* cost, int32_t* n_samples, double* samples) {
+  if (!ctx) return fail(nullptr, MRS_TG_ERR_INVALID_ARG, "ctx is NULL");
+  int rc = check_options(ctx, opt);
+  if (rc != MRS_TG_OK) return rc;
+  if (!so || !mask || !vals || !seg_times || !coeffs || !status)
+    return fail(ctx, MRS_TG_ERR_INVALID_ARG, "seg_offsets, fixed_mask, fixed_values, seg_times, coeffs_out, status_out are required");
+  if (n_paths == 0) return MRS_TG_OK;
+  PlanGuard pg;
+  if ((rc = mrs_tg_plan_create(ctx, n_paths, so, &pg.p)) != MRS_TG_OK) return rc;
+  const size_t nS = (size_t)so[n_paths], nV = nS + (size_t)n_paths;
+  const bool sampling = opt->sampling_dt > 0;
+  if (sampling && !n_samples) return fail(ctx, MRS_TG_ERR_INVALID_ARG, "n_samples_out is required when sampling");
+  const size_t samp_doubles = sampling && samples ? (size_t)n_paths * (size_t)opt->sample_capacity * 4 : 0;
+  DevBuf d_wp, d_mask, d_vals, d_lim, d_t, d_c, d_st, d_cost, d_ns, d_smp;
+  HIP_TRY(ctx, d_wp.alloc(nV * 4 * sizeof(double)));
+  HIP_TRY(ctx, d_mask.alloc(nV * 5));
+  HIP_TRY(ctx, d_vals.alloc(nV * 20 * sizeof(double)));
+  HIP_TRY(ctx, d_lim.alloc((size_t)n_paths * 9 * sizeof(double)));
+  HIP_TRY(ctx, d_t.alloc(nS * sizeof(double)));
+  HIP_TRY(ctx, d_c.alloc(nS * 40 * sizeof(double)));
+  HIP_TRY(ctx, d_st.alloc((size_t)n_paths * sizeof(int32_t)));
+  HIP_TRY(ctx, d_cost.alloc((size_t)n_paths * sizeof(double)));
+  HIP_TRY(ctx, d_ns.alloc((size_t)n_paths * sizeof(int32_t)));
+  HIP_TRY(ctx, d_smp.alloc(samp_doubles * sizeof(double)));
+  hipStream_t s = ctx->stream;
+  if (wp) HIP_TRY(ctx, hipMemcpyAsync(d_wp.p, wp, nV * 4 * sizeof(double), hipMemcpyHostToDevice, s));
+  HIP_TRY(ctx, hipMemcpyAsync(d_mask.p, mask, nV * 5, hipMemcpyHostToDevice, s));
+  HIP_TRY(ctx, hipMemcpyAsync(d_vals.p, vals, nV * 20 * sizeof(double), hipMemcpyHostToDevice, s));
+  if (limits) HIP_TRY(ctx, hipMemcpyAsync(d_lim.p, limits, (size_t)n_paths * 9 * sizeof(double), hipMemcpyHostToDevice, s));
+  HIP_TRY(ctx, hipMemcpyAsync(d_t.p, seg_times, nS * sizeof(double), hipMemcpyHostToDevice, s));
+  rc = mrs_tg_plan_solve(pg.p, wp ? d_wp.as<double>() : nullptr, d_mask.as<uint8_t>(), d_vals.as<double>(),
+                         limits ? d_lim.as<double>() : nullptr, opt, d_t.as<double>(), d_c.as<double>(),
+                         d_st.as<int32_t>(), d_cost.as<double>(), sampling ? d_ns.as<int32_t>() : nullptr,
+                         samp_doubles ? d_smp.as<double>() : nullptr);
+  if (rc != MRS_TG_OK) return rc;
+  HIP_TRY(ctx, hipMemcpyAsync(seg_times, d_t.p, nS * sizeof(double), hipMemcpyDeviceToHost, s));
+  HIP_TRY(ctx, hipMemcpyAsync(coeffs, d_c.p, nS * 40 * sizeof(double), hipMemcpyDeviceToHost, s));
+  HIP_TRY(ctx, hipMemcpyAsync(status, d_st.p, (size_t)n_paths * sizeof(int32_t), hipMemcpyDeviceToHost, s));
+  if (cost) HIP_TRY(ctx, hipMemcpyAsync(cost, d_cost.p, (size_t)n_paths * sizeof(double), hipMemcpyDeviceToHost, s));
+  if (sampling) HIP_TRY(ctx, hipMemcpyAsync(n_samples, d_ns.p, (size_t)n_paths * sizeof(int32_t), hipMemcpyDeviceToHost, s));
+  if (samp_doubles) HIP_TRY(ctx, hipMemcpyAsync(samples, d_smp.p, samp_doubles * sizeof(double), hipMemcpyDeviceToHost, s));
+  HIP_TRY(ctx, hipStreamSynchronize(s));
+  return MRS_TG_OK;
+}
+
+// ---- single path, findTrajectory()'s signature -------------------------------------------------
+
+
+int mrs_tg_find_trajectory(mrs_tg_ctx* ctx, const mrs_tg_waypoint* wps, int32_t n_wp, const mrs_tg_initial_state* init,
+                           const double* limits9, const mrs_tg_options* opt_in, int32_t relax_heading,
+                           double* seg_times_out, double* coeffs_out, int32_t* status_out, int32_t* n_samples_out,
+                           double* samples_out) {
+  if (!ctx) return fail(nullptr, MRS_TG_ERR_INVALID_ARG, "ctx is NULL");
+  if (!wps || !limits9 || !opt_in || !seg_times_out || !coeffs_out || !status_out || !n_samples_out)
+    return fail(ctx, MRS_TG_ERR_INVALID_ARG, "NULL argument");
+  if (n_wp < 2) return fail(ctx, MRS_TG_ERR_INVALID_ARG, "need at least 2 waypoints, got %d", n_wp);
+  const int d = opt_in->derivative_to_optimize;
+  if (d < 2 || d > 4) return fail(ctx, MRS_TG_ERR_INVALID_ARG, "derivative_to_optimize must be 2, 3 or 4");
+  const int V = n_wp, S = n_wp - 1;
+  std::vector<double> wp(V * 4), vals(V * 20, 0.0);
+  std::vector<uint8_t> mask(V * 5, 0);
+  // vertices: src/mrs_trajectory_generation.cpp:923-977
+  double last_heading = init ? init->heading : wps[0].coords[3];
+  for (int i = 0; i < V; ++i) {
+    for (int k = 0; k < 3; ++k) wp[i * 4 + k] = wps[i].coords[k];
+    const double heading = unwrap_heading(wps[i].coords[3], last_heading);
+    last_heading = heading;
+    wp[i * 4 + 3] = heading;
+    mask[i * 5 + 0] = 1;
+    for (int k = 0; k < 4; ++k) vals[(i * 5 + 0) * 4 + k] = wp[i * 4 + k];
+    if (i == 0 || i == V - 1) {
+      for (int k = 1; k <= d; ++k) mask[i * 5 + k] = 1;  // makeStartOrEnd: zeros
+      if (i == 0 && init) {
+        for (int k = 0; k < 4; ++k) {
+          vals[(0 * 5 + 1) * 4 + k] = init->velocity[k];
+          vals[(0 * 5 + 2) * 4 + k] = init->acceleration[k];
+          vals[(0 * 5 + 3) * 4 + k] = init->jerk[k];
+        }
+        mask[1] = mask[2] = mask[3] = 1;
+      }
+    } else if (wps[i].stop_at) {
+      mask[i * 5 + 1] = mask[i * 5 + 2] = mask[i * 5 + 3] = 1;
+    }
+  }
+  double lim[9];
+  for (int k = 0; k < 9; ++k) lim[k] = limits9[k];
+  if (relax_heading) lim[2] = lim[5] = lim[8] = (double)FLT_MAX;  // src/...cpp:1030-1034
+  mrs_tg_options opt = *opt_in;
+  opt.estimate_times = 1;
+  const int32_t so[2] = {0, S};
+  double cost = 0.0;
+  *n_samples_out = 0;
+  int rc = mrs_tg_solve_batch(ctx, 1, so, wp.data(), mask.data(), vals.data(), lim, &opt, seg_times_out, coeffs_out,
+                              status_out, &cost, n_samples_out, samples_out);
+  if (rc != MRS_TG_OK) return rc;
+  // accept >= 1 except MAXTIME(6), and -1 (src/mrs_trajectory_generation.cpp:1138-1149)
+  const int st = *status_out;
+  const bool accepted = (st >= 1 && st != 6) || st == -1;
+  if (!accepted) *n_samples_out = 0;
+  return MRS_TG_OK;
+}
+
+}  // extern "C"

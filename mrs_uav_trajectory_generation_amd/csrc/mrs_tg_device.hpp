@@ -15,6 +15,7 @@
 #include <hip/hip_runtime.h>
 
 #include "mrs_tg_constants.h"
+#include "mrs_tg_launch.h"
 
 namespace mrs_tg {
 
@@ -25,8 +26,8 @@ constexpr int kNB = 4;     // free-candidate slots per vertex (velocity..snap)
 constexpr int kSlot0 = 1;  // first free-candidate slot
 constexpr double kTimeLowerBound = 0.01;  // kOptimizationTimeLowerBound (polynomial_optimization_nonlinear.h:304)
 
-__constant__ double c_abar_inv[kN][kN] = MRS_TG_ABAR_INV_INIT;
-__constant__ double c_hbar[kHalf][kN][kN] = MRS_TG_HBAR_INIT;
+static __constant__ double c_abar_inv[kN][kN] = MRS_TG_ABAR_INV_INIT;
+static __constant__ double c_hbar[kHalf][kN][kN] = MRS_TG_HBAR_INIT;
 
 // index into a packed lower-triangular 4x4 (r >= c)
 __device__ __forceinline__ constexpr int tri(int r, int c) { return r * (r + 1) / 2 + c; }
@@ -263,5 +264,42 @@ __device__ __forceinline__ double poly_eval(const double* c, double t, int deriv
   for (int j = kN - 2; j >= derivative; --j) acc = acc * t + bc(j) * c[j];
   return acc;
 }
+
+// ---------------------------------------------------------------------------------------------
+// batch addressing shared by all kernels
+
+struct PathRef {
+  int p;   // path index in the caller's order
+  int s0;  // first segment (CSR)
+  int S;   // number of segments
+  int v0;  // first vertex
+};
+
+__device__ __forceinline__ PathRef path_at(const BatchView& b, int q) {
+  PathRef r;
+  r.p = b.order[q];
+  r.s0 = b.seg_offsets[r.p];
+  r.S = b.seg_offsets[r.p + 1] - r.s0;
+  r.v0 = r.s0 + r.p;
+  return r;
+}
+
+// constrained values (0 where free) and the free mask of the candidate slots of one vertex
+template <int ND>
+__device__ __forceinline__ unsigned load_vertex(const uint8_t* __restrict__ mask, const double* __restrict__ vals, int v,
+                                                int dim0, double (&f)[kHalf][ND], bool& position_fixed) {
+  unsigned free_bits = 0;
+#pragma unroll
+  for (int k = 0; k < kHalf; ++k) {
+    const bool fixed = mask[(size_t)v * kHalf + k] != 0;
+    if (k == 0) position_fixed = fixed;
+    if (k >= kSlot0 && !fixed) free_bits |= 1u << (k - kSlot0);
+#pragma unroll
+    for (int q = 0; q < ND; ++q) f[k][q] = fixed ? vals[((size_t)v * kHalf + k) * kD + dim0 + q] : 0.0;
+  }
+  return free_bits;
+}
+
+constexpr int kWsPerVertex = 10 + kNB * kD + kNB * kNB;  // L, z, W = 42 doubles per vertex
 
 }  // namespace mrs_tg

@@ -1,0 +1,417 @@
+// mrs_tg_kernels.hip -- gfx950 kernels of the batched trajectory optimiser and their launchers.
+//
+// Data layout in HBM (DESIGN.md "layout"):
+//   * ABI-facing arrays are CSR/AoS exactly as include/mrs_tg.h states;
+//   * materialised per-segment blocks (H, A^-1) are slot-major SoA: element e = r*10+c of segment j of
+//     the path at sorted position q sits at ((j*100 + e) * P + q), so consecutive lanes (consecutive q)
+//     touch consecutive doubles for every (j, e): both the assembly kernel's stores and the solve
+//     kernel's loads are fully coalesced without any LDS transposition;
+//   * the back-substitution workspace uses the same idea: ((v*42 + e) * P + q).
+#include <hip/hip_runtime.h>
+
+#include <cfloat>
+#include <cmath>
+#include <cstdint>
+
+#include "mrs_tg_device.hpp"
+#include "mrs_tg_launch.h"
+
+namespace mrs_tg {
+
+// ---------------------------------------------------------------------------------------------
+// K1: Hessian / mapping-block assembly.  HBM-write bound: 8 B read + 1600 B written per segment.
+// One thread per (segment, matrix row); blockIdx.y is the row so that the row's constants are
+// wave-uniform (scalar loads) and every store instruction writes 64 consecutive doubles.
+
+__global__ __launch_bounds__(256) void assemble_blocks_kernel(BatchView b, int d, const double* __restrict__ seg_times,
+                                                              double* __restrict__ Hout, double* __restrict__ Aout) {
+  const int idx = blockIdx.x * 256 + threadIdx.x;
+  if (idx >= b.n_segments) return;
+  const int a = blockIdx.y;
+  // slot j such that slot_start[j] <= idx < slot_start[j+1]
+  int j;
+  if (b.uniform_S > 0) {
+    j = idx / b.n_paths;
+  } else {
+    int lo = 0, hi = b.max_segments;
+    while (hi - lo > 1) {
+      const int mid = (lo + hi) >> 1;
+      if (b.slot_start[mid] <= idx) lo = mid;
+      else hi = mid;
+    }
+    j = lo;
+  }
+  const int q = idx - b.slot_start[j];
+  const int p = b.order[q];
+  const double T = seg_times[b.seg_offsets[p] + j];
+
+  double w[kHalf];
+  w[0] = 1.0;
+#pragma unroll
+  for (int k = 1; k < kHalf; ++k) w[k] = w[k - 1] * T;
+  const int pa = a % kHalf;
+  // T^(1-2d) * T^pa
+  double td = 1.0;
+  if (d == 1) td = w[1];
+  else if (d == 2) td = w[2];
+  else if (d == 3) td = w[3];
+  else if (d == 4) td = w[4];
+  double wa = 1.0;
+  if (pa == 1) wa = w[1];
+  else if (pa == 2) wa = w[2];
+  else if (pa == 3) wa = w[3];
+  else if (pa == 4) wa = w[4];
+  const double sa = (T / (td * td)) * wa;
+  const size_t P = (size_t)b.n_paths;
+  const size_t base = ((size_t)j * 100 + (size_t)a * kN) * P + (size_t)q;
+#pragma unroll
+  for (int c = 0; c < kN; ++c) Hout[base + (size_t)c * P] = c_hbar[d][a][c] * sa * w[c % kHalf];
+  // A^-1(T)[a][c] = ABAR_INV[a][c] * T^(c%5) / T^a
+  const double ti = 1.0 / T;
+  double tia = 1.0;
+  for (int k = 0; k < a; ++k) tia *= ti;
+#pragma unroll
+  for (int c = 0; c < kN; ++c) Aout[base + (size_t)c * P] = c_abar_inv[a][c] * w[c % kHalf] * tia;
+}
+
+// ---------------------------------------------------------------------------------------------
+// K2: linear QP solve, one thread per path: block-Cholesky sweep over the vertices, back-substitution,
+// coefficient recovery.  FUSED=false consumes the materialised blocks written by K1.
+
+template <bool FUSED>
+__global__ __launch_bounds__(64) void solve_linear_kernel(BatchView b, int d, const uint8_t* __restrict__ mask,
+                                                          const double* __restrict__ vals,
+                                                          const double* __restrict__ seg_times,
+                                                          const double* __restrict__ Hblk, const double* __restrict__ Ablk,
+                                                          double* __restrict__ ws, double* __restrict__ coeffs,
+                                                          int32_t* __restrict__ status, double* __restrict__ cost) {
+  const int q = blockIdx.x * 64 + threadIdx.x;
+  if (q >= b.n_paths) return;
+  const PathRef pr = path_at(b, q);
+  const size_t P = (size_t)b.n_paths;
+
+  Elim<kD> st;
+  st.init();
+  double fs[kHalf][kD], fe[kHalf][kD];
+  double L[10], z[kNB][kD], W[kNB][kNB];
+  bool pos_ok = true, pos_fixed;
+  unsigned free_s = load_vertex<kD>(mask, vals, pr.v0, 0, fs, pos_fixed);
+  pos_ok = pos_ok && pos_fixed;
+
+  for (int i = 0; i < pr.S; ++i) {
+    const unsigned free_e = load_vertex<kD>(mask, vals, pr.v0 + i + 1, 0, fe, pos_fixed);
+    pos_ok = pos_ok && pos_fixed;
+    double Hs[kSym10];
+    if (FUSED) {
+      hessian_from_time(seg_times[pr.s0 + i], d, Hs);
+    } else {
+#pragma unroll
+      for (int a = 0; a < kN; ++a)
+#pragma unroll
+        for (int c = a; c < kN; ++c) Hs[sym10(a, c)] = Hblk[((size_t)i * 100 + a * kN + c) * P + q];
+    }
+    st.absorb_segment(Hs, fs, fe, free_s, free_e, L, z, W);
+    double* w = ws + (size_t)i * kWsPerVertex * P + q;
+#pragma unroll
+    for (int e = 0; e < 10; ++e) w[(size_t)e * P] = L[e];
+#pragma unroll
+    for (int r = 0; r < kNB; ++r)
+#pragma unroll
+      for (int k = 0; k < kD; ++k) w[(size_t)(10 + r * kD + k) * P] = z[r][k];
+#pragma unroll
+    for (int r = 0; r < kNB; ++r)
+#pragma unroll
+      for (int c = 0; c < kNB; ++c) w[(size_t)(10 + kNB * kD + r * kNB + c) * P] = W[r][c];
+#pragma unroll
+    for (int k = 0; k < kHalf; ++k)
+#pragma unroll
+      for (int dd = 0; dd < kD; ++dd) fs[k][dd] = fe[k][dd];
+    free_s = free_e;
+  }
+  st.factor_vertex(free_s, L, z);
+  if (cost) cost[pr.p] = 0.5 * (st.qf - st.red);
+  if (status) status[pr.p] = pos_ok ? 1 : -2;
+
+  // backward sweep: fs currently holds vertex S's constrained values
+  double xn[kNB][kD], x[kNB][kD], dn[kHalf][kD], dc[kHalf][kD];
+  back_substitute<kD>(L, z, W, xn, true, x);
+#pragma unroll
+  for (int k = 0; k < kHalf; ++k)
+#pragma unroll
+    for (int dd = 0; dd < kD; ++dd) dn[k][dd] = fs[k][dd] + (k >= kSlot0 ? x[k - kSlot0][dd] : 0.0);
+#pragma unroll
+  for (int r = 0; r < kNB; ++r)
+#pragma unroll
+    for (int dd = 0; dd < kD; ++dd) xn[r][dd] = x[r][dd];
+
+  for (int i = pr.S - 1; i >= 0; --i) {
+    const double* w = ws + (size_t)i * kWsPerVertex * P + q;
+#pragma unroll
+    for (int e = 0; e < 10; ++e) L[e] = w[(size_t)e * P];
+#pragma unroll
+    for (int r = 0; r < kNB; ++r)
+#pragma unroll
+      for (int k = 0; k < kD; ++k) z[r][k] = w[(size_t)(10 + r * kD + k) * P];
+#pragma unroll
+    for (int r = 0; r < kNB; ++r)
+#pragma unroll
+      for (int c = 0; c < kNB; ++c) W[r][c] = w[(size_t)(10 + kNB * kD + r * kNB + c) * P];
+    back_substitute<kD>(L, z, W, xn, false, x);
+    load_vertex<kD>(mask, vals, pr.v0 + i, 0, fs, pos_fixed);
+#pragma unroll
+    for (int k = 0; k < kHalf; ++k)
+#pragma unroll
+      for (int dd = 0; dd < kD; ++dd) dc[k][dd] = fs[k][dd] + (k >= kSlot0 ? x[k - kSlot0][dd] : 0.0);
+    // coefficients of segment i
+    double* cout = coeffs + (size_t)(pr.s0 + i) * kD * kN;
+    if (FUSED) {
+      const double T = seg_times[pr.s0 + i];
+#pragma unroll
+      for (int dd = 0; dd < kD; ++dd) {
+        double dv[kN], c[kN];
+#pragma unroll
+        for (int k = 0; k < kHalf; ++k) {
+          dv[k] = dc[k][dd];
+          dv[kHalf + k] = dn[k][dd];
+        }
+        coefficients_from_time(T, dv, c);
+#pragma unroll
+        for (int k = 0; k < kN; ++k) cout[dd * kN + k] = c[k];
+      }
+    } else {
+      // c = A^-1 d with the materialised block: upper half is diagonal, lower half dense
+#pragma unroll
+      for (int k = 0; k < kN; ++k) {
+        double acc[kD];
+#pragma unroll
+        for (int dd = 0; dd < kD; ++dd) acc[dd] = 0.0;
+        if (k < kHalf) {
+          const double a = Ablk[((size_t)i * 100 + k * kN + k) * P + q];
+#pragma unroll
+          for (int dd = 0; dd < kD; ++dd) acc[dd] = a * dc[k][dd];
+        } else {
+#pragma unroll
+          for (int c = 0; c < kN; ++c) {
+            const double a = Ablk[((size_t)i * 100 + k * kN + c) * P + q];
+#pragma unroll
+            for (int dd = 0; dd < kD; ++dd) acc[dd] += a * (c < kHalf ? dc[c][dd] : dn[c - kHalf][dd]);
+          }
+        }
+#pragma unroll
+        for (int dd = 0; dd < kD; ++dd) cout[dd * kN + k] = acc[dd];
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < kHalf; ++k)
+#pragma unroll
+      for (int dd = 0; dd < kD; ++dd) dn[k][dd] = dc[k][dd];
+#pragma unroll
+    for (int r = 0; r < kNB; ++r)
+#pragma unroll
+      for (int dd = 0; dd < kD; ++dd) xn[r][dd] = x[r][dd];
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// segment-time initialisation: estimateSegmentTimesEuclidean
+// (/root/reference/src/eth_trajectory_generation/vertex.cpp:491-565), one thread per segment
+
+__device__ __forceinline__ double wrap_pi(double a) {
+  const double two_pi = 2.0 * M_PI;
+  double r = fmod(a + M_PI, two_pi);
+  if (r < 0) r += two_pi;
+  return r - M_PI;
+}
+
+__device__ __forceinline__ double angle_dist(double a, double bb) {
+  const double two_pi = 2.0 * M_PI;
+  double dlt = wrap_pi(a) - wrap_pi(bb);
+  if (dlt < -M_PI) dlt += two_pi;
+  else if (dlt >= M_PI) dlt -= two_pi;
+  return fabs(dlt);
+}
+
+__global__ __launch_bounds__(256) void estimate_times_kernel(BatchView b, const double* __restrict__ wp,
+                                                             const double* __restrict__ limits,
+                                                             double* __restrict__ seg_times) {
+  const int idx = blockIdx.x * 256 + threadIdx.x;
+  if (idx >= b.n_segments) return;
+  // path of CSR segment idx: binary search over seg_offsets
+  int lo = 0, hi = b.n_paths;
+  while (hi - lo > 1) {
+    const int mid = (lo + hi) >> 1;
+    if (b.seg_offsets[mid] <= idx) lo = mid;
+    else hi = mid;
+  }
+  const int p = lo;
+  const int v = idx + p;  // vertex index of the segment's start
+  const double* s = wp + (size_t)v * 4;
+  const double* e = s + 4;
+  const double* lim = limits + (size_t)p * 9;
+  const double v_h = lim[0], v_v = lim[1], w_max = lim[2], a_max = lim[5];
+  const double dx = e[0] - s[0], dy = e[1] - s[1], dz = e[2] - s[2];
+  const double inclinator = atan2(dz, sqrt(dx * dx + dy * dy));
+  const double thr = atan2(v_v, v_h);
+  const double vmax = (inclinator > thr || inclinator < -thr) ? fabs(v_v / sin(inclinator)) : fabs(v_h / cos(inclinator));
+  double t = sqrt(dx * dx + dy * dy + dz * dz) / vmax;
+  if (t < 0.01) t = 0.01;
+  const double ang = angle_dist(s[3], e[3]);
+  double t_vel = 0.0, t_acc = 0.0;
+  if (w_max < (double)FLT_MAX && a_max < (double)FLT_MAX) {
+    const double reduced = (ang - (w_max * w_max) / a_max) / w_max;
+    t_vel = (reduced < 0) ? ang / w_max : reduced;
+    if (ang > M_PI / 4) t_acc = 2 * (w_max / a_max);
+  }
+  const double hf = 1.5 * (t_vel + t_acc);
+  if (hf > t) t = hf;
+  seg_times[idx] = t;
+}
+
+// ---------------------------------------------------------------------------------------------
+// sampler: Trajectory::evaluateRange's accumulate-and-carry walk
+// (/root/reference/src/eth_trajectory_generation/trajectory.cpp:93-151), positions + wrapped heading
+// (the only fields the nodelet reads, src/mrs_trajectory_generation.cpp:1582-1599).
+// One wavefront per path: lane 0 replays the walk to find (segment, time-in-segment) of every sample
+// in chunks of 64, then all lanes evaluate their sample in parallel.
+
+__global__ __launch_bounds__(64) void sample_kernel(BatchView b, const double* __restrict__ coeffs,
+                                                    const double* __restrict__ seg_times, double dt, int capacity,
+                                                    int32_t* __restrict__ n_samples, double* __restrict__ samples) {
+  const int q = blockIdx.x;
+  const PathRef pr = path_at(b, q);
+  const int lane = threadIdx.x;
+  __shared__ int s_seg[64];
+  __shared__ double s_tin[64];
+  __shared__ int s_cnt, s_done;
+  __shared__ int w_i;
+  __shared__ double w_tin, w_acc, w_tend;
+  if (lane == 0) {
+    double t_end = 0.0;
+    for (int i = 0; i < pr.S; ++i) t_end += seg_times[pr.s0 + i];
+    // first segment with accumulated time > 0
+    double acc = 0.0;
+    int i = 0;
+    for (i = 0; i < pr.S; ++i) {
+      acc += seg_times[pr.s0 + i];
+      if (acc > 0.0) break;
+    }
+    s_done = (i >= pr.S) ? 1 : 0;
+    if (i < pr.S) acc -= seg_times[pr.s0 + i];
+    w_i = i;
+    w_acc = acc;
+    w_tin = 0.0 - acc;
+    w_tend = t_end;
+  }
+  __syncthreads();
+  int total = 0;
+  double* out = samples ? samples + (size_t)pr.p * capacity * kD : nullptr;
+  while (true) {
+    if (lane == 0) {
+      int cnt = 0;
+      if (!s_done) {
+        int i = w_i;
+        double tin = w_tin, acc = w_acc;
+        const double t_end = w_tend;
+        while (cnt < 64) {
+          if (!(acc < t_end)) {
+            s_done = 1;
+            break;
+          }
+          const double Ti = seg_times[pr.s0 + i];
+          if (tin > Ti) {
+            tin = tin - Ti;
+            ++i;
+            if (i >= pr.S) {
+              s_done = 1;
+              break;
+            }
+            continue;
+          }
+          s_seg[cnt] = i;
+          s_tin[cnt] = tin;
+          ++cnt;
+          tin += dt;
+          acc += dt;
+        }
+        w_i = i;
+        w_tin = tin;
+        w_acc = acc;
+      }
+      s_cnt = cnt;
+    }
+    __syncthreads();
+    const int cnt = s_cnt;
+    if (lane < cnt) {
+      const int n = total + lane;
+      if (out && n < capacity) {
+        const double* c = coeffs + (size_t)(pr.s0 + s_seg[lane]) * kD * kN;
+        const double t = s_tin[lane];
+        double v[kD];
+#pragma unroll
+        for (int dd = 0; dd < kD; ++dd) {
+          double accv = c[dd * kN + kN - 1];
+#pragma unroll
+          for (int k = kN - 2; k >= 0; --k) accv = accv * t + c[dd * kN + k];
+          v[dd] = accv;
+        }
+        // heading after the quaternion round trip (eth_mav_msgs/common.h:130-140)
+        const double hw = cos(v[3] * 0.5), hz = sin(v[3] * 0.5);
+        v[3] = atan2(2.0 * (hw * hz), 1.0 - 2.0 * (hz * hz));
+#pragma unroll
+        for (int dd = 0; dd < kD; ++dd) out[(size_t)n * kD + dd] = v[dd];
+      }
+    }
+    total += cnt;
+    const int done = s_done;
+    __syncthreads();
+    if (done) break;
+  }
+  if (lane == 0 && n_samples) n_samples[pr.p] = total;
+}
+
+// ---------------------------------------------------------------------------------------------
+// launchers
+
+static inline unsigned cdiv(long long a, long long b) { return (unsigned)((a + b - 1) / b); }
+
+hipError_t launch_assemble(const BatchView& b, int d, const double* seg_times, double* H, double* Ainv,
+                           hipStream_t stream) {
+  if (b.n_segments == 0) return hipSuccess;
+  dim3 grid(cdiv(b.n_segments, 256), kN);
+  hipLaunchKernelGGL(assemble_blocks_kernel, grid, dim3(256), 0, stream, b, d, seg_times, H, Ainv);
+  return hipGetLastError();
+}
+
+hipError_t launch_solve_linear(const BatchView& b, int d, bool fused, const uint8_t* mask, const double* vals,
+                               const double* seg_times, const double* H, const double* Ainv, double* ws,
+                               double* coeffs, int32_t* status, double* cost, hipStream_t stream) {
+  if (b.n_paths == 0) return hipSuccess;
+  dim3 grid(cdiv(b.n_paths, 64));
+  if (fused)
+    hipLaunchKernelGGL(solve_linear_kernel<true>, grid, dim3(64), 0, stream, b, d, mask, vals, seg_times, H, Ainv, ws,
+                       coeffs, status, cost);
+  else
+    hipLaunchKernelGGL(solve_linear_kernel<false>, grid, dim3(64), 0, stream, b, d, mask, vals, seg_times, H, Ainv, ws,
+                       coeffs, status, cost);
+  return hipGetLastError();
+}
+
+hipError_t launch_estimate_times(const BatchView& b, const double* wp, const double* limits, double* seg_times,
+                                 hipStream_t stream) {
+  if (b.n_segments == 0) return hipSuccess;
+  hipLaunchKernelGGL(estimate_times_kernel, dim3(cdiv(b.n_segments, 256)), dim3(256), 0, stream, b, wp, limits,
+                     seg_times);
+  return hipGetLastError();
+}
+
+hipError_t launch_sample(const BatchView& b, const double* coeffs, const double* seg_times, double dt, int capacity,
+                         int32_t* n_samples, double* samples, hipStream_t stream) {
+  if (b.n_paths == 0) return hipSuccess;
+  hipLaunchKernelGGL(sample_kernel, dim3(b.n_paths), dim3(64), 0, stream, b, coeffs, seg_times, dt, capacity,
+                     n_samples, samples);
+  return hipGetLastError();
+}
+
+size_t linear_workspace_doubles(const BatchView& b) { return (size_t)b.max_segments * kWsPerVertex * (size_t)b.n_paths; }
+
+}  // namespace mrs_tg

@@ -1,0 +1,32 @@
+// mrs_tg_launch.h -- host-visible view of a batch and the kernel launchers (internal to the library).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstddef>
+#include <cstdint>
+
+namespace mrs_tg {
+
+// Device-resident structure of a batch (built once per plan).
+struct BatchView {
+  int n_paths;
+  int n_segments;            // sum of S over the batch
+  int max_segments;          // largest S
+  int uniform_S;             // S if every path has the same segment count, else 0
+  const int32_t* seg_offsets;  // [n_paths + 1] CSR over segments (caller's path order)
+  const int32_t* order;        // [n_paths] position q -> path index, sorted by S descending (stable)
+  const int32_t* slot_start;   // [max_segments + 1] slot_start[j] = number of (q, j') pairs with j' < j
+};
+
+hipError_t launch_assemble(const BatchView& b, int d, const double* seg_times, double* H, double* Ainv,
+                           hipStream_t stream);
+hipError_t launch_solve_linear(const BatchView& b, int d, bool fused, const uint8_t* mask, const double* vals,
+                               const double* seg_times, const double* H, const double* Ainv, double* ws,
+                               double* coeffs, int32_t* status, double* cost, hipStream_t stream);
+hipError_t launch_estimate_times(const BatchView& b, const double* wp, const double* limits, double* seg_times,
+                                 hipStream_t stream);
+hipError_t launch_sample(const BatchView& b, const double* coeffs, const double* seg_times, double dt, int capacity,
+                         int32_t* n_samples, double* samples, hipStream_t stream);
+size_t linear_workspace_doubles(const BatchView& b);
+
+}  // namespace mrs_tg

@@ -1,0 +1,45 @@
+// mrs_tg_nonlinear.h -- launch interface of the segment-time outer loop (internal to the library).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <vector>
+
+#include "mrs_tg_launch.h"
+
+namespace mrs_tg {
+
+struct NonlinearParams {
+  int derivative;
+  int max_iterations;
+  double f_rel, f_abs, x_rel, x_abs;
+};
+
+// Paths are sorted by segment count (longest first), so every lane-group class is a contiguous range
+// of positions q.  A path with S segments uses a group of G = min(64, pow2ceil(S + 1)) lanes: lane k of
+// the group evaluates the cost at the k-th perturbed time vector (k = 0: unperturbed).
+struct NonlinearBin {
+  int group;      // lanes per path: 4, 8, 16, 32 or 64
+  int q_begin;    // first position of the bin
+  int q_count;    // number of paths in the bin
+  int max_S;      // largest segment count in the bin
+};
+
+struct NonlinearPlan {
+  std::vector<NonlinearBin> bins;
+  double* d_ws = nullptr;     // back-substitution workspace, (max_S + 1) * 42 * n_paths doubles
+  size_t ws_doubles = 0;
+};
+
+int nonlinear_plan_build(NonlinearPlan& nl, const std::vector<int32_t>& seg_offsets, const std::vector<int32_t>& order);
+void nonlinear_plan_free(NonlinearPlan& nl);
+
+hipError_t launch_nonlinear(NonlinearPlan& nl, const BatchView& b, const NonlinearParams& prm, const uint8_t* mask,
+                            const double* vals, const double* limits, double* seg_times, double* coeffs,
+                            int32_t* status, double* cost, hipStream_t stream);
+hipError_t launch_cost_gradient(NonlinearPlan& nl, const BatchView& b, int d, const uint8_t* mask, const double* vals,
+                                const double* seg_times, double* cost, double* grad, hipStream_t stream);
+hipError_t launch_segment_maxima(const BatchView& b, const double* coeffs, const double* seg_times, double* maxima,
+                                 hipStream_t stream);
+
+}  // namespace mrs_tg

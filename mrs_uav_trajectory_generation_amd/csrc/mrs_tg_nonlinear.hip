@@ -1,0 +1,696 @@
+// mrs_tg_nonlinear.hip -- segment-time outer loop (mode 2, Mellinger), feasibility scaling and the
+// final re-solve, fused in one kernel; plus the two building-block kernels exposed for parity tests.
+//
+// Reference behaviour being reproduced (paths relative to /root/reference/):
+//   include/eth_trajectory_generation/impl/polynomial_optimization_nonlinear_impl.h
+//     :160-234  optimizeTimeMellingerOuterLoop      :257-333  getCostAndGradientMellinger
+//     :336-408  scaleSegmentTimesWithViolation      :617-649  objectiveFunctionTimeMellingerOuterLoop
+//   src/eth_trajectory_generation/trajectory.cpp:598-692  scaleSegmentTimesToMeetConstraints
+//   src/eth_trajectory_generation/segment.cpp:113-212     magnitude extremum candidates
+//
+// Mapping onto the wavefront: one GROUP of G lanes per path, G = min(64, pow2ceil(S+1)), 64/G paths per
+// wavefront, one wavefront per workgroup.  An objective evaluation needs the cost at S+1 time vectors
+// (unperturbed + one per segment, nonlinear_impl.h:282-323); lane k of the group runs the whole
+// block-Cholesky sweep for vector k in registers, so the S+1 solves of an evaluation run side by side
+// and the gradient is assembled with one cross-lane broadcast.  Only the cost is needed there, so the
+// sweep is forward-only (cost = (f^T R_ff f - |L^-1 b|^2)/2) and touches no memory besides the vertex
+// constraints.  The optimiser's vectors live in LDS; its scalar control flow is replicated in every
+// lane of the group (all lanes see identical reduced values).  NLopt's LD_LBFGS is not reproducible
+// (un-vendored, Luksan PLIS); the optimiser is the project's own projected L-BFGS, specified in
+// DESIGN.md and restated on the CPU in oracle/mto_nonlinear.c.
+#include <hip/hip_runtime.h>
+
+#include <cfloat>
+#include <cmath>
+#include <cstdint>
+
+#include "mrs_tg_device.hpp"
+#include "mrs_tg_nonlinear.h"
+
+namespace mrs_tg {
+
+constexpr int kLbfgsM = 5;
+constexpr double kGradStep = 0.1;  // increment_time, nonlinear_impl.h:281
+
+// ---------------------------------------------------------------------------------------------
+// cost of the QP at the k-th perturbed time vector (k = 0: xs itself), forward sweep only
+
+__device__ __forceinline__ double perturbed_time(const double* xs, int i, int k, double corr) {
+  double T = xs[i];
+  if (k > 0) {
+    T += (i == k - 1) ? kGradStep : -corr;
+    T = fmax(T, kTimeLowerBound);
+  }
+  return T;
+}
+
+__device__ double forward_cost(const uint8_t* __restrict__ mask, const double* __restrict__ vals, int v0, int S, int d,
+                               const double* xs, int k) {
+  Elim<kD> st;
+  st.init();
+  double fs[kHalf][kD], fe[kHalf][kD];
+  double L[10], z[kNB][kD], W[kNB][kNB];
+  bool pf;
+  unsigned free_s = load_vertex<kD>(mask, vals, v0, 0, fs, pf);
+  const double corr = kGradStep / ((double)S - 1.0);
+  for (int i = 0; i < S; ++i) {
+    const unsigned free_e = load_vertex<kD>(mask, vals, v0 + i + 1, 0, fe, pf);
+    double Hs[kSym10];
+    hessian_from_time(perturbed_time(xs, i, k, corr), d, Hs);
+    st.absorb_segment(Hs, fs, fe, free_s, free_e, L, z, W);
+#pragma unroll
+    for (int s = 0; s < kHalf; ++s)
+#pragma unroll
+      for (int dd = 0; dd < kD; ++dd) fs[s][dd] = fe[s][dd];
+    free_s = free_e;
+  }
+  st.factor_vertex(free_s, L, z);
+  return 0.5 * (st.qf - st.red);
+}
+
+// full solve at times xs: coefficients of every segment to `coeffs` (global, [S][4][10]); returns cost.
+// ws: back-substitution workspace with element stride `wstride`.
+__device__ double full_solve(const uint8_t* __restrict__ mask, const double* __restrict__ vals, int v0, int S, int d,
+                             const double* xs, double* ws, size_t wstride, double* __restrict__ coeffs, bool& pos_ok) {
+  Elim<kD> st;
+  st.init();
+  double fs[kHalf][kD], fe[kHalf][kD];
+  double L[10], z[kNB][kD], W[kNB][kNB];
+  bool pf;
+  pos_ok = true;
+  unsigned free_s = load_vertex<kD>(mask, vals, v0, 0, fs, pf);
+  pos_ok = pos_ok && pf;
+  for (int i = 0; i < S; ++i) {
+    const unsigned free_e = load_vertex<kD>(mask, vals, v0 + i + 1, 0, fe, pf);
+    pos_ok = pos_ok && pf;
+    double Hs[kSym10];
+    hessian_from_time(xs[i], d, Hs);
+    st.absorb_segment(Hs, fs, fe, free_s, free_e, L, z, W);
+    double* w = ws + (size_t)i * kWsPerVertex * wstride;
+#pragma unroll
+    for (int e = 0; e < 10; ++e) w[(size_t)e * wstride] = L[e];
+#pragma unroll
+    for (int r = 0; r < kNB; ++r)
+#pragma unroll
+      for (int c = 0; c < kD; ++c) w[(size_t)(10 + r * kD + c) * wstride] = z[r][c];
+#pragma unroll
+    for (int r = 0; r < kNB; ++r)
+#pragma unroll
+      for (int c = 0; c < kNB; ++c) w[(size_t)(10 + kNB * kD + r * kNB + c) * wstride] = W[r][c];
+#pragma unroll
+    for (int s = 0; s < kHalf; ++s)
+#pragma unroll
+      for (int dd = 0; dd < kD; ++dd) fs[s][dd] = fe[s][dd];
+    free_s = free_e;
+  }
+  st.factor_vertex(free_s, L, z);
+  const double cost = 0.5 * (st.qf - st.red);
+
+  double xn[kNB][kD], x[kNB][kD], dn[kHalf][kD], dc[kHalf][kD];
+  back_substitute<kD>(L, z, W, xn, true, x);
+#pragma unroll
+  for (int s = 0; s < kHalf; ++s)
+#pragma unroll
+    for (int dd = 0; dd < kD; ++dd) dn[s][dd] = fs[s][dd] + (s >= kSlot0 ? x[s - kSlot0][dd] : 0.0);
+#pragma unroll
+  for (int r = 0; r < kNB; ++r)
+#pragma unroll
+    for (int dd = 0; dd < kD; ++dd) xn[r][dd] = x[r][dd];
+  for (int i = S - 1; i >= 0; --i) {
+    const double* w = ws + (size_t)i * kWsPerVertex * wstride;
+#pragma unroll
+    for (int e = 0; e < 10; ++e) L[e] = w[(size_t)e * wstride];
+#pragma unroll
+    for (int r = 0; r < kNB; ++r)
+#pragma unroll
+      for (int c = 0; c < kD; ++c) z[r][c] = w[(size_t)(10 + r * kD + c) * wstride];
+#pragma unroll
+    for (int r = 0; r < kNB; ++r)
+#pragma unroll
+      for (int c = 0; c < kNB; ++c) W[r][c] = w[(size_t)(10 + kNB * kD + r * kNB + c) * wstride];
+    back_substitute<kD>(L, z, W, xn, false, x);
+    load_vertex<kD>(mask, vals, v0 + i, 0, fs, pf);
+#pragma unroll
+    for (int s = 0; s < kHalf; ++s)
+#pragma unroll
+      for (int dd = 0; dd < kD; ++dd) dc[s][dd] = fs[s][dd] + (s >= kSlot0 ? x[s - kSlot0][dd] : 0.0);
+    const double T = xs[i];
+    double* cout = coeffs + (size_t)i * kD * kN;
+#pragma unroll
+    for (int dd = 0; dd < kD; ++dd) {
+      double dv[kN], c[kN];
+#pragma unroll
+      for (int s = 0; s < kHalf; ++s) {
+        dv[s] = dc[s][dd];
+        dv[kHalf + s] = dn[s][dd];
+      }
+      coefficients_from_time(T, dv, c);
+#pragma unroll
+      for (int s = 0; s < kN; ++s) cout[dd * kN + s] = c[s];
+    }
+#pragma unroll
+    for (int s = 0; s < kHalf; ++s)
+#pragma unroll
+      for (int dd = 0; dd < kD; ++dd) dn[s][dd] = dc[s][dd];
+#pragma unroll
+    for (int r = 0; r < kNB; ++r)
+#pragma unroll
+      for (int dd = 0; dd < kD; ++dd) xn[r][dd] = x[r][dd];
+  }
+  return cost;
+}
+
+// ---------------------------------------------------------------------------------------------
+// per-segment maxima of |p^(k)| over [0, T] for k = 1..3 and the groups {x,y}, {z}, {heading}.
+//
+// The reference finds every complex root of d/dt |p^(k)|^2 with Jenkins-Traub and keeps the real
+// ones inside the segment plus both end points (segment.cpp:113-156, polynomial.cpp:36-63,
+// rpoly_ak1.cpp).  Only the maximum VALUE is consumed (trajectory.cpp:625-642), so this path brackets
+// the local maxima of m(tau)^2 = sum_dim q^(k)(tau)^2 on a uniform grid in normalised time tau = t/T
+// (sign change + -> - of its derivative), polishes each with safeguarded Newton steps and takes the
+// largest of {end points, grid points, polished maxima}.  Every candidate is a true value of the
+// function, so the result never exceeds the exact maximum.
+
+constexpr int kGridCells = 32;
+
+struct DerivEval {
+  double v0, v1, v2;  // q^(k), q^(k+1), q^(k+2) at tau (derivatives with respect to tau)
+};
+
+// cb: normalised coefficients cbar_j = c_j T^j of one dimension
+__device__ __forceinline__ DerivEval eval_derivs(const double (&cb)[kN], double tau, int k) {
+  // Horner for three consecutive derivatives; falling factorials built incrementally
+  double a0 = 0.0, a1 = 0.0, a2 = 0.0;
+  for (int j = kN - 1; j >= k; --j) {
+    double f0 = 1.0;
+    for (int n = 0; n < k; ++n) f0 *= (double)(j - n);  // j!/(j-k)!
+    const double f1 = f0 * (double)(j - k);             // j!/(j-k-1)!
+    const double f2 = f1 * (double)(j - k - 1);         // j!/(j-k-2)!
+    a0 = a0 * tau + f0 * cb[j];
+    if (j >= k + 1) a1 = a1 * tau + f1 * cb[j];
+    if (j >= k + 2) a2 = a2 * tau + f2 * cb[j];
+  }
+  DerivEval r;
+  r.v0 = a0;
+  r.v1 = a1;
+  r.v2 = a2;
+  return r;
+}
+
+template <int NDIM>
+__device__ __forceinline__ void mag_eval(const double (&cb)[NDIM][kN], double tau, int k, double& m2, double& g,
+                                         double& dg) {
+  m2 = 0.0;
+  g = 0.0;
+  dg = 0.0;
+#pragma unroll
+  for (int q = 0; q < NDIM; ++q) {
+    const DerivEval e = eval_derivs(cb[q], tau, k);
+    m2 += e.v0 * e.v0;
+    g += e.v0 * e.v1;                // (1/2) d/dtau m2
+    dg += e.v1 * e.v1 + e.v0 * e.v2;  // derivative of g
+  }
+}
+
+// max over tau in [0,1] of sum_dim q^(k)(tau)^2
+template <int NDIM>
+__device__ double max_mag2(const double (&cb)[NDIM][kN], int k) {
+  double m2, g, dg;
+  mag_eval<NDIM>(cb, 0.0, k, m2, g, dg);
+  double best = m2;
+  double g_prev = g;
+  const double h = 1.0 / kGridCells;
+  for (int i = 1; i <= kGridCells; ++i) {
+    const double tau = (i == kGridCells) ? 1.0 : i * h;
+    mag_eval<NDIM>(cb, tau, k, m2, g, dg);
+    best = fmax(best, m2);
+    if (g_prev > 0.0 && g <= 0.0) {
+      // a local maximum of m2 lies in (tau - h, tau]: safeguarded Newton on g
+      double lo = tau - h, hi = tau;
+      double t = 0.5 * (lo + hi);
+      for (int it = 0; it < 60; ++it) {
+        double mm, gg, dd;
+        mag_eval<NDIM>(cb, t, k, mm, gg, dd);
+        best = fmax(best, mm);
+        if (gg > 0.0) lo = t;
+        else hi = t;
+        double tn = (dd < 0.0) ? t - gg / dd : 0.5 * (lo + hi);
+        if (!(tn > lo && tn < hi)) tn = 0.5 * (lo + hi);
+        if (fabs(tn - t) < 1e-10 || hi - lo < 1e-14) break;
+        t = tn;
+      }
+    }
+    g_prev = g;
+  }
+  return best;
+}
+
+// out[(k-1)*3 + group]; c = [4][10] coefficients of the segment (ascending powers of t)
+__device__ void segment_maxima(const double* __restrict__ c, double T, double (&out)[9]) {
+  double cb_h[2][kN], cb_v[1][kN], cb_y[1][kN];
+  double tp = 1.0;
+#pragma unroll
+  for (int j = 0; j < kN; ++j) {
+    cb_h[0][j] = c[0 * kN + j] * tp;
+    cb_h[1][j] = c[1 * kN + j] * tp;
+    cb_v[0][j] = c[2 * kN + j] * tp;
+    cb_y[0][j] = c[3 * kN + j] * tp;
+    tp *= T;
+  }
+  const double ti = 1.0 / T;
+  double tik = ti;
+  for (int k = 1; k <= 3; ++k) {
+    out[(k - 1) * 3 + 0] = sqrt(max_mag2<2>(cb_h, k)) * tik;
+    out[(k - 1) * 3 + 1] = sqrt(max_mag2<1>(cb_v, k)) * tik;
+    out[(k - 1) * 3 + 2] = sqrt(max_mag2<1>(cb_y, k)) * tik;
+    tik *= ti;
+  }
+}
+
+// violation scaling of one segment: max(1, v, sqrt(a), cbrt(j))  (trajectory.cpp:625-642)
+__device__ __forceinline__ double violation_scaling(const double (&mx)[9], const double* __restrict__ lim) {
+  double viol[3];
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    const double h = mx[k * 3 + 0] / lim[k * 3 + 0];
+    const double v = mx[k * 3 + 1] / lim[k * 3 + 1];
+    const double y = mx[k * 3 + 2] / lim[k * 3 + 2];
+    viol[k] = fmax(fmax(h, v), y);
+  }
+  return fmax(1.0, fmax(fmax(viol[0], sqrt(viol[1])), cbrt(viol[2])));
+}
+
+// ---------------------------------------------------------------------------------------------
+// group helpers (G lanes, G a power of two <= 64, groups aligned to G)
+
+__device__ __forceinline__ double group_sum(double v, int G) {
+  for (int m = G >> 1; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
+  return v;
+}
+
+__device__ __forceinline__ int group_and(int v, int G) {
+  for (int m = G >> 1; m >= 1; m >>= 1) v &= __shfl_xor(v, m, 64);
+  return v;
+}
+
+__device__ __forceinline__ double group_dot(const double* a, const double* b, int S, int g, int G) {
+  double s = 0.0;
+  for (int i = g; i < S; i += G) s += a[i] * b[i];
+  return group_sum(s, G);
+}
+
+__device__ __forceinline__ bool relstop(double vold, double vnew, double reltol, double abstol) {
+  // NLopt's scalar stopping rule
+  if (isinf(vold)) return false;
+  const double dv = fabs(vnew - vold);
+  return dv < abstol || dv < reltol * (fabs(vnew) + fabs(vold)) * 0.5 || (reltol > 0 && vnew == vold);
+}
+
+// per-group LDS block (doubles): x, g, xn, gn, dir [5*Sb], s[M][Sb], y[M][Sb], rho[M]
+__host__ __device__ constexpr int group_lds_doubles(int Sb) { return (5 + 2 * kLbfgsM) * Sb + kLbfgsM; }
+
+// objective evaluation at `pt`: cost returned to every lane of the group, gradient to `grad` (LDS).
+// (objectiveFunctionTimeMellingerOuterLoop + getCostAndGradientMellinger)
+__device__ __forceinline__ double evaluate_objective(const uint8_t* __restrict__ mask, const double* __restrict__ vals,
+                                                     int v0, int S, int d, const double* pt, double* grad, int g, int G,
+                                                     bool active) {
+  double J0 = 0.0;
+  // lane k handles time vectors k, k+G, ... (k = 0 is the unperturbed one)
+  const int rounds = (S + 1 + G - 1) / G;
+  for (int r = 0; r < rounds; ++r) {
+    const int k = g + r * G;
+    double Jk = 0.0;
+    if (active && k <= S && (k == 0 || S > 1)) Jk = forward_cost(mask, vals, v0, S, d, pt, k);
+    if (r == 0) J0 = __shfl(Jk, (threadIdx.x & ~(G - 1)), 64);  // lane 0 of the group
+    if (active && k >= 1 && k <= S) grad[k - 1] = (S > 1) ? (Jk - J0) / kGradStep : 0.0;
+  }
+  return J0;
+}
+
+// ---------------------------------------------------------------------------------------------
+// the fused outer-loop kernel: optimiser ticks (one objective evaluation each), then
+// scaleSegmentTimesWithViolation: solve at the last evaluated times, per-segment scaling, final solve.
+
+__global__ __launch_bounds__(64) void nonlinear_kernel(BatchView b, NonlinearParams prm, int G, int q_begin, int q_count,
+                                                       int Sb, const uint8_t* __restrict__ mask,
+                                                       const double* __restrict__ vals, const double* __restrict__ limits,
+                                                       double* __restrict__ seg_times, double* __restrict__ coeffs,
+                                                       int32_t* __restrict__ status, double* __restrict__ cost_out,
+                                                       double* __restrict__ ws) {
+  extern __shared__ double lds[];
+  const int lane = threadIdx.x;
+  const int g = lane & (G - 1);
+  const int grp = lane / G;
+  const int per_block = 64 / G;
+  const int qi = blockIdx.x * per_block + grp;
+  const bool active = qi < q_count;
+  const int q = q_begin + (active ? qi : 0);
+  const PathRef pr = path_at(b, q);
+  const int S = pr.S, d = prm.derivative;
+  const size_t P = (size_t)b.n_paths;
+
+  double* base = lds + (size_t)grp * group_lds_doubles(Sb);
+  double* x = base;
+  double* gr = x + Sb;
+  double* xn = gr + Sb;
+  double* gn = xn + Sb;
+  double* dir = gn + Sb;
+  double* sm = dir + Sb;            // [M][Sb]
+  double* ym = sm + kLbfgsM * Sb;   // [M][Sb]
+  double* rho = ym + kLbfgsM * Sb;  // [M]
+
+  // ---- start point; NLopt rejects a start below the lower bound (-> INVALID_ARGS)
+  int ok = 1;
+  if (active)
+    for (int i = g; i < S; i += G) {
+      const double t = seg_times[pr.s0 + i];
+      x[i] = t;
+      xn[i] = t;
+      if (t < kTimeLowerBound) ok = 0;
+    }
+  const bool bad = active && !group_and(ok, G);
+  __syncthreads();
+
+  const int maxeval = prm.max_iterations;
+  int ret = -1;
+  bool done = !active || bad;
+  int neval = 0, npairs = 0, head = 0;
+  double f = 0.0, alpha = 1.0;
+  bool first = true;
+
+  while (true) {
+    int running = done ? 0 : 1;
+    for (int m = 32; m >= 1; m >>= 1) running |= __shfl_xor(running, m, 64);
+    if (!running) break;
+
+    // (1) one objective evaluation at the trial point
+    const double fn = evaluate_objective(mask, vals, pr.v0, S, d, xn, gn, g, G, !done);
+    __syncthreads();
+    bool new_dir = false;
+    if (!done) {
+      ++neval;
+      if (first) {
+        f = fn;
+        for (int i = g; i < S; i += G) {
+          x[i] = xn[i];
+          gr[i] = gn[i];
+        }
+        if (maxeval > 0 && neval >= maxeval) {
+          ret = 5;
+          done = true;
+        } else {
+          new_dir = true;
+        }
+      } else {
+        double slope = 0.0;
+        for (int i = g; i < S; i += G) slope += gr[i] * (xn[i] - x[i]);
+        slope = group_sum(slope, G);
+        if (fn <= f + 1e-4 * slope) {
+          // accepted step: stopping rules, curvature pair, move
+          int stop = 0;
+          if (relstop(f, fn, prm.f_rel, prm.f_abs)) {
+            stop = 3;
+          } else {
+            int allx = 1;
+            for (int i = g; i < S; i += G)
+              if (!relstop(x[i], xn[i], prm.x_rel, prm.x_abs)) allx = 0;
+            if (group_and(allx, G)) stop = 4;
+          }
+          double sy = 0.0, ss = 0.0, yy = 0.0;
+          for (int i = g; i < S; i += G) {
+            const double si = xn[i] - x[i], yi = gn[i] - gr[i];
+            sy += si * yi;
+            ss += si * si;
+            yy += yi * yi;
+          }
+          sy = group_sum(sy, G);
+          ss = group_sum(ss, G);
+          yy = group_sum(yy, G);
+          const bool budget_out = maxeval > 0 && neval >= maxeval;
+          int slot = -1;
+          if (!stop && !budget_out && sy > 1e-10 * sqrt(ss) * sqrt(yy)) {
+            if (npairs == kLbfgsM) {
+              slot = head;  // overwrite the oldest pair
+              head = (head + 1) % kLbfgsM;
+            } else {
+              slot = (head + npairs) % kLbfgsM;
+              ++npairs;
+            }
+          }
+          for (int i = g; i < S; i += G) {
+            if (slot >= 0) {
+              sm[slot * Sb + i] = xn[i] - x[i];
+              ym[slot * Sb + i] = gn[i] - gr[i];
+            }
+            x[i] = xn[i];
+            gr[i] = gn[i];
+          }
+          if (slot >= 0 && g == 0) rho[slot] = 1.0 / sy;
+          f = fn;
+          if (stop) {
+            ret = stop;
+            done = true;
+          } else if (budget_out) {
+            ret = 5;
+            done = true;
+          } else {
+            new_dir = true;
+          }
+        } else if (maxeval > 0 && neval >= maxeval) {
+          // budget ends on a rejected trial: the last evaluated point is what the reference keeps
+          for (int i = g; i < S; i += G) x[i] = xn[i];
+          ret = 5;
+          done = true;
+        } else {
+          alpha *= 0.5;
+          if (alpha < 1e-12) {
+            for (int i = g; i < S; i += G) x[i] = xn[i];
+            ret = 4;
+            done = true;
+          }
+        }
+      }
+    }
+    first = false;
+    __syncthreads();
+
+    // (2) search direction: L-BFGS two-loop recursion, projected on the lower bound
+    if (new_dir) {
+      double al[kLbfgsM];
+      for (int i = g; i < S; i += G) dir[i] = -gr[i];
+      if (npairs > 0) {
+        for (int k = npairs - 1; k >= 0; --k) {
+          const int id = (head + k) % kLbfgsM;
+          const double sd = group_dot(sm + id * Sb, dir, S, g, G);
+          al[k] = rho[id] * sd;
+          for (int i = g; i < S; i += G) dir[i] -= al[k] * ym[id * Sb + i];
+        }
+        const int nw = (head + npairs - 1) % kLbfgsM;
+        const double sy = group_dot(sm + nw * Sb, ym + nw * Sb, S, g, G);
+        const double yy = group_dot(ym + nw * Sb, ym + nw * Sb, S, g, G);
+        const double gamma = sy / yy;
+        for (int i = g; i < S; i += G) dir[i] *= gamma;
+        for (int k = 0; k < npairs; ++k) {
+          const int id = (head + k) % kLbfgsM;
+          const double yd = group_dot(ym + id * Sb, dir, S, g, G);
+          const double beta = rho[id] * yd;
+          for (int i = g; i < S; i += G) dir[i] += (al[k] - beta) * sm[id * Sb + i];
+        }
+      }
+      double gd = 0.0;
+      for (int i = g; i < S; i += G) {
+        if (x[i] <= kTimeLowerBound && dir[i] < 0.0) dir[i] = 0.0;
+        gd += gr[i] * dir[i];
+      }
+      gd = group_sum(gd, G);
+      if (!(gd < 0.0)) {
+        // not a descent direction: projected steepest descent, forget the curvature pairs
+        gd = 0.0;
+        for (int i = g; i < S; i += G) {
+          double v = -gr[i];
+          if (x[i] <= kTimeLowerBound && v < 0.0) v = 0.0;
+          dir[i] = v;
+          gd += gr[i] * v;
+        }
+        gd = group_sum(gd, G);
+        npairs = 0;
+        head = 0;
+        if (!(gd < 0.0)) {
+          ret = 1;
+          done = true;
+        }
+      }
+      alpha = 1.0;
+      if (!done && npairs == 0) {
+        // first trial step of a restart moves x by at most 10 % in norm
+        double nx = 0.0, nd = 0.0;
+        for (int i = g; i < S; i += G) {
+          nx += x[i] * x[i];
+          nd += dir[i] * dir[i];
+        }
+        nx = group_sum(nx, G);
+        nd = group_sum(nd, G);
+        const double cap = 0.1 * sqrt(nx) / sqrt(nd);
+        if (cap < alpha) alpha = cap;
+      }
+    }
+    // (3) next trial point
+    if (!done)
+      for (int i = g; i < S; i += G) xn[i] = fmax(x[i] + alpha * dir[i], kTimeLowerBound);
+    __syncthreads();
+  }
+
+  // ---- scaleSegmentTimesWithViolation (nonlinear_impl.h:336-408) and the final solve
+  bool pos_ok = true;
+  double cost = 0.0;
+  const bool scale = active && !bad;
+  double* my_coeffs = coeffs + (size_t)pr.s0 * kD * kN;
+  for (int pass = 0; pass < 2; ++pass) {
+    if (active && g == 0 && (pass == 1 || scale))
+      cost = full_solve(mask, vals, pr.v0, S, d, x, ws + q, P, my_coeffs, pos_ok);
+    __threadfence_block();
+    __syncthreads();
+    if (pass == 0) {
+      if (scale) {
+        for (int i = g; i < S; i += G) {
+          double mx[9];
+          segment_maxima(my_coeffs + (size_t)i * kD * kN, x[i], mx);
+          x[i] = x[i] * violation_scaling(mx, limits + (size_t)pr.p * 9);
+        }
+      }
+      __syncthreads();
+    }
+  }
+  if (active) {
+    for (int i = g; i < S; i += G) seg_times[pr.s0 + i] = x[i];
+    if (g == 0) {
+      // a rejected start never reaches the optimiser: the reference reports FAILURE (-1) there
+      status[pr.p] = !pos_ok ? -2 : (bad ? -1 : ret);
+      if (cost_out) cost_out[pr.p] = cost;
+    }
+  }
+}
+
+// J_d and the forward-difference gradient at the given times (parity-test building block)
+__global__ __launch_bounds__(64) void cost_gradient_kernel(BatchView b, int d, int G, int q_begin, int q_count, int Sb,
+                                                           const uint8_t* __restrict__ mask,
+                                                           const double* __restrict__ vals,
+                                                           const double* __restrict__ seg_times,
+                                                           double* __restrict__ cost, double* __restrict__ grad) {
+  extern __shared__ double lds[];
+  const int lane = threadIdx.x;
+  const int g = lane & (G - 1);
+  const int grp = lane / G;
+  const int qi = blockIdx.x * (64 / G) + grp;
+  const bool active = qi < q_count;
+  const PathRef pr = path_at(b, q_begin + (active ? qi : 0));
+  double* x = lds + (size_t)grp * 2 * Sb;
+  double* gr = x + Sb;
+  if (active)
+    for (int i = g; i < pr.S; i += G) x[i] = seg_times[pr.s0 + i];
+  __syncthreads();
+  const double J = evaluate_objective(mask, vals, pr.v0, pr.S, d, x, gr, g, G, active);
+  __syncthreads();
+  if (active) {
+    for (int i = g; i < pr.S; i += G) grad[pr.s0 + i] = gr[i];
+    if (g == 0) cost[pr.p] = J;
+  }
+}
+
+// maxima[seg][k-1][group] for every CSR segment (parity-test building block)
+__global__ __launch_bounds__(64) void segment_maxima_kernel(int n_segments, const double* __restrict__ coeffs,
+                                                            const double* __restrict__ seg_times,
+                                                            double* __restrict__ maxima) {
+  const int s = blockIdx.x * 64 + threadIdx.x;
+  if (s >= n_segments) return;
+  double mx[9];
+  segment_maxima(coeffs + (size_t)s * kD * kN, seg_times[s], mx);
+#pragma unroll
+  for (int i = 0; i < 9; ++i) maxima[(size_t)s * 9 + i] = mx[i];
+}
+
+// ---------------------------------------------------------------------------------------------
+// host side
+
+static int group_for(int S) {
+  int G = 4;
+  while (G < S + 1 && G < 64) G <<= 1;
+  return G;
+}
+
+int nonlinear_plan_build(NonlinearPlan& nl, const std::vector<int32_t>& so, const std::vector<int32_t>& order) {
+  nl.bins.clear();
+  const int P = (int)order.size();
+  int q = 0;
+  while (q < P) {
+    const int p = order[q];
+    const int S = so[p + 1] - so[p];
+    NonlinearBin bin;
+    bin.group = group_for(S);
+    bin.q_begin = q;
+    bin.max_S = S;  // sorted longest first: the first path of a bin is its longest
+    int e = q;
+    while (e < P && group_for(so[order[e] + 1] - so[order[e]]) == bin.group) ++e;
+    bin.q_count = e - q;
+    nl.bins.push_back(bin);
+    q = e;
+  }
+  return 0;
+}
+
+void nonlinear_plan_free(NonlinearPlan& nl) {
+  if (nl.d_ws) (void)hipFree(nl.d_ws);
+  nl.d_ws = nullptr;
+  nl.ws_doubles = 0;
+}
+
+static unsigned cdiv_u(long long a, long long b) { return (unsigned)((a + b - 1) / b); }
+
+hipError_t launch_nonlinear(NonlinearPlan& nl, const BatchView& b, const NonlinearParams& prm, const uint8_t* mask,
+                            const double* vals, const double* limits, double* seg_times, double* coeffs,
+                            int32_t* status, double* cost, hipStream_t stream) {
+  const size_t need = (size_t)b.max_segments * kWsPerVertex * (size_t)b.n_paths;
+  if (nl.ws_doubles < need) {
+    if (nl.d_ws) (void)hipFree(nl.d_ws);
+    nl.d_ws = nullptr;
+    nl.ws_doubles = 0;
+    hipError_t e = hipMalloc(&nl.d_ws, need * sizeof(double));
+    if (e != hipSuccess) return e;
+    nl.ws_doubles = need;
+  }
+  for (const NonlinearBin& bin : nl.bins) {
+    const int per_block = 64 / bin.group;
+    const size_t lds_bytes = (size_t)per_block * group_lds_doubles(bin.max_S) * sizeof(double);
+    if (lds_bytes > 160 * 1024) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(nonlinear_kernel, dim3(cdiv_u(bin.q_count, per_block)), dim3(64), lds_bytes, stream, b, prm,
+                       bin.group, bin.q_begin, bin.q_count, bin.max_S, mask, vals, limits, seg_times, coeffs, status,
+                       cost, nl.d_ws);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return e;
+  }
+  return hipSuccess;
+}
+
+hipError_t launch_cost_gradient(NonlinearPlan& nl, const BatchView& b, int d, const uint8_t* mask, const double* vals,
+                                const double* seg_times, double* cost, double* grad, hipStream_t stream) {
+  for (const NonlinearBin& bin : nl.bins) {
+    const int per_block = 64 / bin.group;
+    const size_t lds_bytes = (size_t)per_block * 2 * bin.max_S * sizeof(double);
+    if (lds_bytes > 160 * 1024) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(cost_gradient_kernel, dim3(cdiv_u(bin.q_count, per_block)), dim3(64), lds_bytes, stream, b, d,
+                       bin.group, bin.q_begin, bin.q_count, bin.max_S, mask, vals, seg_times, cost, grad);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return e;
+  }
+  return hipSuccess;
+}
+
+hipError_t launch_segment_maxima(const BatchView& b, const double* coeffs, const double* seg_times, double* maxima,
+                                 hipStream_t stream) {
+  if (b.n_segments == 0) return hipSuccess;
+  hipLaunchKernelGGL(segment_maxima_kernel, dim3(cdiv_u(b.n_segments, 64)), dim3(64), 0, stream, b.n_segments, coeffs,
+                     seg_times, maxima);
+  return hipGetLastError();
+}
+
+}  // namespace mrs_tg
