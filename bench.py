@@ -108,25 +108,22 @@ def main():
                waypoints=db.waypoints, limits=db.limits)
     torch.cuda.synchronize()
     t_init = db.seg_times.clone()
+    t_fixed = t_init.clone()   # linear mode never writes the times
 
     opt_lin = api.default_options(derivative_to_optimize=4)
     opt_nl = api.default_options(derivative_to_optimize=4, time_alloc_method=api.TIME_ALLOC_MELLINGER,
                                  sampling_dt=0.2, sample_capacity=512)
 
-    gather_bufs = None
-    if dist is not None:
-        gather_bufs = dict(
-            coeffs=[torch.empty_like(db.coeffs) for _ in range(world)] if rank == 0 else None,
-            times=[torch.empty_like(db.seg_times) for _ in range(world)] if rank == 0 else None,
-            status=[torch.empty_like(db.status) for _ in range(world)] if rank == 0 else None)
+    from mrs_uav_trajectory_generation_amd import shard
 
     def final_gather():
-        dist.gather(db.coeffs, gather_bufs["coeffs"], dst=0)
-        dist.gather(db.seg_times, gather_bufs["times"], dst=0)
-        dist.gather(db.status, gather_bufs["status"], dst=0)
+        # the job's only collective: results of every rank to rank 0 (RCCL over xGMI)
+        shard.gather_to_root(db.coeffs, dist)
+        shard.gather_to_root(db.seg_times, dist)
+        shard.gather_to_root(db.status, dist)
 
     def step_linear():
-        plan.solve(opt_lin, db.fixed_mask, db.fixed_values, db.seg_times, db.coeffs, db.status, db.cost)
+        plan.solve(opt_lin, db.fixed_mask, db.fixed_values, t_fixed, db.coeffs, db.status, db.cost)
         if dist is not None:
             final_gather()
 
@@ -171,6 +168,7 @@ def main():
     err = None
     if rank == 0 and not args.no_cpu_baseline:
         from oracle import pyoracle as po
+        db.seg_times.copy_(t_init)
         steps_fn["linear"]()
         torch.cuda.synchronize()
         times = t_init.cpu().numpy()

@@ -1,0 +1,60 @@
+"""Multi-GPU sharding of a batch of independent paths, and the one collective of the job.
+
+Paths are independent units (one QP + outer loop each; the reference itself handles one path per
+request, /root/reference/src/mrs_trajectory_generation.cpp:1064-1083), so a batch shards with no
+data-path collective: every rank solves its own contiguous range (uniform batches) or a greedily balanced
+subset (ragged batches), and the only exchange is the final gather of coefficients / times / status to
+rank 0.  Works with any torch.distributed backend ("nccl" = RCCL over xGMI on the GPU
+box, "gloo" in the CPU tests).
+"""
+import numpy as np
+
+
+def contiguous_shard(n_paths, rank, world):
+    """[begin, end) of the paths owned by `rank`: sizes differ by at most one."""
+    base, rem = divmod(int(n_paths), int(world))
+    begin = rank * base + min(rank, rem)
+    return begin, begin + base + (1 if rank < rem else 0)
+
+
+def balanced_shard(seg_counts, world):
+    """Ragged batches: longest-processing-time-first greedy on the segment count.
+    Returns a list (one entry per rank) of sorted path-index arrays."""
+    seg_counts = np.asarray(seg_counts)
+    order = np.argsort(-seg_counts, kind="stable")
+    load = np.zeros(world, dtype=np.int64)
+    owner = [[] for _ in range(world)]
+    for p in order:
+        r = int(np.argmin(load))
+        owner[r].append(int(p))
+        load[r] += int(seg_counts[p])
+    return [np.array(sorted(o), dtype=np.int64) for o in owner]
+
+
+def gather_to_root(tensor, dist, dst=0):
+    """Gather equally-shaped per-rank tensors on `dst`; returns the list there, None elsewhere."""
+    world = dist.get_world_size()
+    bufs = None
+    if dist.get_rank() == dst:
+        import torch
+        bufs = [torch.empty_like(tensor) for _ in range(world)]
+    dist.gather(tensor, bufs, dst=dst)
+    return bufs
+
+
+def gather_ragged_to_root(tensor, dist, dst=0):
+    """Gather per-rank tensors whose leading dimension differs (ragged shards): sizes first, then padded
+    payloads; returns the list of correctly sized tensors on `dst`, None elsewhere."""
+    import torch
+    world = dist.get_world_size()
+    n = torch.tensor([tensor.shape[0]], dtype=torch.int64, device=tensor.device)
+    sizes = [torch.zeros_like(n) for _ in range(world)]
+    dist.all_gather(sizes, n)
+    sizes = [int(s.item()) for s in sizes]
+    cap = max(sizes)
+    padded = torch.zeros((cap,) + tuple(tensor.shape[1:]), dtype=tensor.dtype, device=tensor.device)
+    padded[:tensor.shape[0]] = tensor
+    bufs = gather_to_root(padded, dist, dst)
+    if bufs is None:
+        return None
+    return [b[:s] for b, s in zip(bufs, sizes)]

@@ -1,0 +1,58 @@
+"""The C-ABI shared library without a GPU: it loads, exports every symbol include/mrs_tg.h declares,
+agrees with the header's constants, and fails loudly (no CPU fallback) when no device is present."""
+import ctypes as C
+import os
+import re
+
+import pytest
+
+from mrs_uav_trajectory_generation_amd import api, build
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    build.build()          # hipcc cross-compiles for gfx950 without a GPU
+    return api.load_library()
+
+
+def _declared_functions():
+    text = open(os.path.join(ROOT, "include", "mrs_tg.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(mrs_tg_[a-z_0-9]+)\s*\(", text)))
+
+
+def test_every_declared_symbol_is_exported(lib):
+    names = _declared_functions()
+    assert len(names) >= 20
+    for n in names:
+        assert hasattr(lib, n), n
+    assert sorted(api.EXPORTED_SYMBOLS) == names
+
+
+def test_abi_version_and_default_options(lib):
+    assert lib.mrs_tg_abi_version() == 1
+    opt = api.default_options()
+    # defaults follow the reference's parameters (src/mrs_trajectory_generation.cpp:884-885,
+    # config/private/trajectory_generation.yaml:10)
+    assert (opt.f_rel, opt.x_rel, opt.max_iterations) == (0.05, 0.1, 10)
+    assert opt.f_abs == -1.0 and opt.x_abs == -1.0 and opt.time_alloc_method == -1
+    assert C.sizeof(api.Options) == 64
+
+
+def test_no_device_is_a_loud_error(lib):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present; this test covers the GPU-less container")
+    with pytest.raises(api.MrsTgError, match="no CPU fallback"):
+        api.Context(0)
+
+
+def test_product_package_does_not_import_the_oracle():
+    pkg = os.path.join(ROOT, "mrs_uav_trajectory_generation_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".hpp", ".h", ".cpp")):
+                src = open(os.path.join(dirpath, f)).read()
+                assert "pyoracle" not in src and "mrs_tg_oracle" not in src and "libmrs_tg_oracle" not in src, f
