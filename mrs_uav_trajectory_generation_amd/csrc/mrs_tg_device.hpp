@@ -72,6 +72,7 @@ template <int ND>
 struct Elim {
   double Sm[10];
   double y[kNB][ND];
+  double Linv[kNB];  // reciprocals of the diagonal of the most recent Cholesky factor
   double qf, red;
 
   __device__ __forceinline__ void init() {
@@ -111,6 +112,7 @@ struct Elim {
       const double lcc = sqrt(dsum);
       const double inv = 1.0 / lcc;
       L[tri(c, c)] = lcc;
+      Linv[c] = inv;
 #pragma unroll
       for (int r = c + 1; r < kNB; ++r) {
         double s = Sm[tri(r, c)];
@@ -127,7 +129,7 @@ struct Elim {
         double s = y[r][q];
 #pragma unroll
         for (int m = 0; m < r; ++m) s -= L[tri(r, m)] * z[m][q];
-        z[r][q] = s / L[tri(r, r)];
+        z[r][q] = s * Linv[r];
         red += z[r][q] * z[r][q];
       }
     }
@@ -175,7 +177,7 @@ struct Elim {
         double s = (fr && fc) ? Hs[sym10(kSlot0 + r, kHalf + kSlot0 + c)] : 0.0;
 #pragma unroll
         for (int m = 0; m < r; ++m) s -= L[tri(r, m)] * W[m][c];
-        W[r][c] = s / L[tri(r, r)];
+        W[r][c] = s * Linv[r];
       }
     }
     // next vertex: Sm = Hee - W^T W ; y = -ue - W^T z

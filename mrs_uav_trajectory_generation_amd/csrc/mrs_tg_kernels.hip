@@ -14,6 +14,7 @@
 #include <cstdint>
 
 #include "mrs_tg_device.hpp"
+#include "mrs_tg_solve.hpp"
 #include "mrs_tg_launch.h"
 
 namespace mrs_tg {
@@ -75,140 +76,34 @@ __global__ __launch_bounds__(256) void assemble_blocks_kernel(BatchView b, int d
 }
 
 // ---------------------------------------------------------------------------------------------
-// K2: linear QP solve, one thread per path: block-Cholesky sweep over the vertices, back-substitution,
-// coefficient recovery.  FUSED=false consumes the materialised blocks written by K1.
+// K2: linear QP solve (mrs_tg_solve.hpp).  ND = 4: one lane per path; ND = 1: four lanes per path.
+// FUSED = false consumes the materialised blocks written by K1, FUSED = true recomputes them from T.
 
-template <bool FUSED>
+template <int ND, bool FUSED>
 __global__ __launch_bounds__(64) void solve_linear_kernel(BatchView b, int d, const uint8_t* __restrict__ mask,
                                                           const double* __restrict__ vals,
                                                           const double* __restrict__ seg_times,
                                                           const double* __restrict__ Hblk, const double* __restrict__ Ablk,
                                                           double* __restrict__ ws, double* __restrict__ coeffs,
                                                           int32_t* __restrict__ status, double* __restrict__ cost) {
-  const int q = blockIdx.x * 64 + threadIdx.x;
-  if (q >= b.n_paths) return;
+  constexpr int LPP = kD / ND;  // lanes per path
+  const int tid = blockIdx.x * 64 + threadIdx.x;
+  const int lanes_total = b.n_paths * LPP;
+  if (tid >= lanes_total) return;
+  const int q = tid / LPP;
+  const int dim0 = (tid % LPP) * ND;
   const PathRef pr = path_at(b, q);
-  const size_t P = (size_t)b.n_paths;
-
-  Elim<kD> st;
-  st.init();
-  double fs[kHalf][kD], fe[kHalf][kD];
-  double L[10], z[kNB][kD], W[kNB][kNB];
-  bool pos_ok = true, pos_fixed;
-  unsigned free_s = load_vertex<kD>(mask, vals, pr.v0, 0, fs, pos_fixed);
-  pos_ok = pos_ok && pos_fixed;
-
-  for (int i = 0; i < pr.S; ++i) {
-    const unsigned free_e = load_vertex<kD>(mask, vals, pr.v0 + i + 1, 0, fe, pos_fixed);
-    pos_ok = pos_ok && pos_fixed;
-    double Hs[kSym10];
-    if (FUSED) {
-      hessian_from_time(seg_times[pr.s0 + i], d, Hs);
-    } else {
-#pragma unroll
-      for (int a = 0; a < kN; ++a)
-#pragma unroll
-        for (int c = a; c < kN; ++c) Hs[sym10(a, c)] = Hblk[((size_t)i * 100 + a * kN + c) * P + q];
-    }
-    st.absorb_segment(Hs, fs, fe, free_s, free_e, L, z, W);
-    double* w = ws + (size_t)i * kWsPerVertex * P + q;
-#pragma unroll
-    for (int e = 0; e < 10; ++e) w[(size_t)e * P] = L[e];
-#pragma unroll
-    for (int r = 0; r < kNB; ++r)
-#pragma unroll
-      for (int k = 0; k < kD; ++k) w[(size_t)(10 + r * kD + k) * P] = z[r][k];
-#pragma unroll
-    for (int r = 0; r < kNB; ++r)
-#pragma unroll
-      for (int c = 0; c < kNB; ++c) w[(size_t)(10 + kNB * kD + r * kNB + c) * P] = W[r][c];
-#pragma unroll
-    for (int k = 0; k < kHalf; ++k)
-#pragma unroll
-      for (int dd = 0; dd < kD; ++dd) fs[k][dd] = fe[k][dd];
-    free_s = free_e;
+  BlockSource src{Hblk, Ablk, (size_t)b.n_paths, q};
+  bool pos_ok;
+  double c = solve_path<ND, FUSED>(mask, vals, pr.v0, pr.S, d, seg_times + pr.s0, dim0, src, ws + tid,
+                                   (size_t)lanes_total, coeffs + (size_t)pr.s0 * kD * kN, pos_ok);
+  if (LPP == 4) {
+    c += __shfl_xor(c, 1, 64);
+    c += __shfl_xor(c, 2, 64);
   }
-  st.factor_vertex(free_s, L, z);
-  if (cost) cost[pr.p] = 0.5 * (st.qf - st.red);
-  if (status) status[pr.p] = pos_ok ? 1 : -2;
-
-  // backward sweep: fs currently holds vertex S's constrained values
-  double xn[kNB][kD], x[kNB][kD], dn[kHalf][kD], dc[kHalf][kD];
-  back_substitute<kD>(L, z, W, xn, true, x);
-#pragma unroll
-  for (int k = 0; k < kHalf; ++k)
-#pragma unroll
-    for (int dd = 0; dd < kD; ++dd) dn[k][dd] = fs[k][dd] + (k >= kSlot0 ? x[k - kSlot0][dd] : 0.0);
-#pragma unroll
-  for (int r = 0; r < kNB; ++r)
-#pragma unroll
-    for (int dd = 0; dd < kD; ++dd) xn[r][dd] = x[r][dd];
-
-  for (int i = pr.S - 1; i >= 0; --i) {
-    const double* w = ws + (size_t)i * kWsPerVertex * P + q;
-#pragma unroll
-    for (int e = 0; e < 10; ++e) L[e] = w[(size_t)e * P];
-#pragma unroll
-    for (int r = 0; r < kNB; ++r)
-#pragma unroll
-      for (int k = 0; k < kD; ++k) z[r][k] = w[(size_t)(10 + r * kD + k) * P];
-#pragma unroll
-    for (int r = 0; r < kNB; ++r)
-#pragma unroll
-      for (int c = 0; c < kNB; ++c) W[r][c] = w[(size_t)(10 + kNB * kD + r * kNB + c) * P];
-    back_substitute<kD>(L, z, W, xn, false, x);
-    load_vertex<kD>(mask, vals, pr.v0 + i, 0, fs, pos_fixed);
-#pragma unroll
-    for (int k = 0; k < kHalf; ++k)
-#pragma unroll
-      for (int dd = 0; dd < kD; ++dd) dc[k][dd] = fs[k][dd] + (k >= kSlot0 ? x[k - kSlot0][dd] : 0.0);
-    // coefficients of segment i
-    double* cout = coeffs + (size_t)(pr.s0 + i) * kD * kN;
-    if (FUSED) {
-      const double T = seg_times[pr.s0 + i];
-#pragma unroll
-      for (int dd = 0; dd < kD; ++dd) {
-        double dv[kN], c[kN];
-#pragma unroll
-        for (int k = 0; k < kHalf; ++k) {
-          dv[k] = dc[k][dd];
-          dv[kHalf + k] = dn[k][dd];
-        }
-        coefficients_from_time(T, dv, c);
-#pragma unroll
-        for (int k = 0; k < kN; ++k) cout[dd * kN + k] = c[k];
-      }
-    } else {
-      // c = A^-1 d with the materialised block: upper half is diagonal, lower half dense
-#pragma unroll
-      for (int k = 0; k < kN; ++k) {
-        double acc[kD];
-#pragma unroll
-        for (int dd = 0; dd < kD; ++dd) acc[dd] = 0.0;
-        if (k < kHalf) {
-          const double a = Ablk[((size_t)i * 100 + k * kN + k) * P + q];
-#pragma unroll
-          for (int dd = 0; dd < kD; ++dd) acc[dd] = a * dc[k][dd];
-        } else {
-#pragma unroll
-          for (int c = 0; c < kN; ++c) {
-            const double a = Ablk[((size_t)i * 100 + k * kN + c) * P + q];
-#pragma unroll
-            for (int dd = 0; dd < kD; ++dd) acc[dd] += a * (c < kHalf ? dc[c][dd] : dn[c - kHalf][dd]);
-          }
-        }
-#pragma unroll
-        for (int dd = 0; dd < kD; ++dd) cout[dd * kN + k] = acc[dd];
-      }
-    }
-#pragma unroll
-    for (int k = 0; k < kHalf; ++k)
-#pragma unroll
-      for (int dd = 0; dd < kD; ++dd) dn[k][dd] = dc[k][dd];
-#pragma unroll
-    for (int r = 0; r < kNB; ++r)
-#pragma unroll
-      for (int dd = 0; dd < kD; ++dd) xn[r][dd] = x[r][dd];
+  if (dim0 == 0) {
+    if (cost) cost[pr.p] = c;
+    if (status) status[pr.p] = pos_ok ? 1 : -2;
   }
 }
 
@@ -277,30 +172,32 @@ __global__ __launch_bounds__(256) void estimate_times_kernel(BatchView b, const 
 __global__ __launch_bounds__(64) void sample_kernel(BatchView b, const double* __restrict__ coeffs,
                                                     const double* __restrict__ seg_times, double dt, int capacity,
                                                     int32_t* __restrict__ n_samples, double* __restrict__ samples) {
+  extern __shared__ double s_T[];  // [max_segments] segment times of this path
   const int q = blockIdx.x;
   const PathRef pr = path_at(b, q);
   const int lane = threadIdx.x;
   __shared__ int s_seg[64];
   __shared__ double s_tin[64];
   __shared__ int s_cnt, s_done;
-  __shared__ int w_i;
-  __shared__ double w_tin, w_acc, w_tend;
+  for (int i = lane; i < pr.S; i += 64) s_T[i] = seg_times[pr.s0 + i];
+  __syncthreads();
+  // walk state, private to lane 0
+  int w_i = 0;
+  double w_tin = 0.0, w_acc = 0.0, w_tend = 0.0;
   if (lane == 0) {
-    double t_end = 0.0;
-    for (int i = 0; i < pr.S; ++i) t_end += seg_times[pr.s0 + i];
-    // first segment with accumulated time > 0
+    for (int i = 0; i < pr.S; ++i) w_tend += s_T[i];
+    // first segment whose accumulated time exceeds t_start = 0
     double acc = 0.0;
     int i = 0;
     for (i = 0; i < pr.S; ++i) {
-      acc += seg_times[pr.s0 + i];
+      acc += s_T[i];
       if (acc > 0.0) break;
     }
     s_done = (i >= pr.S) ? 1 : 0;
-    if (i < pr.S) acc -= seg_times[pr.s0 + i];
+    if (i < pr.S) acc -= s_T[i];
     w_i = i;
     w_acc = acc;
     w_tin = 0.0 - acc;
-    w_tend = t_end;
   }
   __syncthreads();
   int total = 0;
@@ -309,33 +206,28 @@ __global__ __launch_bounds__(64) void sample_kernel(BatchView b, const double* _
     if (lane == 0) {
       int cnt = 0;
       if (!s_done) {
-        int i = w_i;
-        double tin = w_tin, acc = w_acc;
-        const double t_end = w_tend;
+        double Ti = s_T[w_i];
         while (cnt < 64) {
-          if (!(acc < t_end)) {
+          if (!(w_acc < w_tend)) {
             s_done = 1;
             break;
           }
-          const double Ti = seg_times[pr.s0 + i];
-          if (tin > Ti) {
-            tin = tin - Ti;
-            ++i;
-            if (i >= pr.S) {
+          if (w_tin > Ti) {
+            w_tin = w_tin - Ti;
+            ++w_i;
+            if (w_i >= pr.S) {
               s_done = 1;
               break;
             }
+            Ti = s_T[w_i];
             continue;
           }
-          s_seg[cnt] = i;
-          s_tin[cnt] = tin;
+          s_seg[cnt] = w_i;
+          s_tin[cnt] = w_tin;
           ++cnt;
-          tin += dt;
-          acc += dt;
+          w_tin += dt;
+          w_acc += dt;
         }
-        w_i = i;
-        w_tin = tin;
-        w_acc = acc;
       }
       s_cnt = cnt;
     }
@@ -382,17 +274,31 @@ hipError_t launch_assemble(const BatchView& b, int d, const double* seg_times, d
   return hipGetLastError();
 }
 
+// four lanes per path shorten the dependency chain ~4x but repeat the factorisation: worth it until the
+// lanes of the 1-lane variant alone fill the machine
+static inline bool use_split_dims(int n_paths) { return n_paths <= 32768; }
+
 hipError_t launch_solve_linear(const BatchView& b, int d, bool fused, const uint8_t* mask, const double* vals,
                                const double* seg_times, const double* H, const double* Ainv, double* ws,
                                double* coeffs, int32_t* status, double* cost, hipStream_t stream) {
   if (b.n_paths == 0) return hipSuccess;
-  dim3 grid(cdiv(b.n_paths, 64));
-  if (fused)
-    hipLaunchKernelGGL(solve_linear_kernel<true>, grid, dim3(64), 0, stream, b, d, mask, vals, seg_times, H, Ainv, ws,
-                       coeffs, status, cost);
-  else
-    hipLaunchKernelGGL(solve_linear_kernel<false>, grid, dim3(64), 0, stream, b, d, mask, vals, seg_times, H, Ainv, ws,
-                       coeffs, status, cost);
+  if (use_split_dims(b.n_paths)) {
+    dim3 grid(cdiv((long long)b.n_paths * 4, 64));
+    if (fused)
+      hipLaunchKernelGGL((solve_linear_kernel<1, true>), grid, dim3(64), 0, stream, b, d, mask, vals, seg_times, H, Ainv,
+                         ws, coeffs, status, cost);
+    else
+      hipLaunchKernelGGL((solve_linear_kernel<1, false>), grid, dim3(64), 0, stream, b, d, mask, vals, seg_times, H,
+                         Ainv, ws, coeffs, status, cost);
+  } else {
+    dim3 grid(cdiv(b.n_paths, 64));
+    if (fused)
+      hipLaunchKernelGGL((solve_linear_kernel<4, true>), grid, dim3(64), 0, stream, b, d, mask, vals, seg_times, H, Ainv,
+                         ws, coeffs, status, cost);
+    else
+      hipLaunchKernelGGL((solve_linear_kernel<4, false>), grid, dim3(64), 0, stream, b, d, mask, vals, seg_times, H,
+                         Ainv, ws, coeffs, status, cost);
+  }
   return hipGetLastError();
 }
 
@@ -407,11 +313,14 @@ hipError_t launch_estimate_times(const BatchView& b, const double* wp, const dou
 hipError_t launch_sample(const BatchView& b, const double* coeffs, const double* seg_times, double dt, int capacity,
                          int32_t* n_samples, double* samples, hipStream_t stream) {
   if (b.n_paths == 0) return hipSuccess;
-  hipLaunchKernelGGL(sample_kernel, dim3(b.n_paths), dim3(64), 0, stream, b, coeffs, seg_times, dt, capacity,
-                     n_samples, samples);
+  hipLaunchKernelGGL(sample_kernel, dim3(b.n_paths), dim3(64), sizeof(double) * (size_t)b.max_segments, stream, b,
+                     coeffs, seg_times, dt, capacity, n_samples, samples);
   return hipGetLastError();
 }
 
-size_t linear_workspace_doubles(const BatchView& b) { return (size_t)b.max_segments * kWsPerVertex * (size_t)b.n_paths; }
+size_t linear_workspace_doubles(const BatchView& b) {
+  // worst case: four lanes per path, ws_per_vertex<1>() doubles each
+  return (size_t)b.max_segments * ws_per_vertex<1>() * 4 * (size_t)b.n_paths;
+}
 
 }  // namespace mrs_tg

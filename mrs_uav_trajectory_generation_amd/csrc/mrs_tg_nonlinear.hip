@@ -25,6 +25,7 @@
 #include <cstdint>
 
 #include "mrs_tg_device.hpp"
+#include "mrs_tg_solve.hpp"
 #include "mrs_tg_nonlinear.h"
 
 namespace mrs_tg {
@@ -68,98 +69,6 @@ __device__ double forward_cost(const uint8_t* __restrict__ mask, const double* _
   return 0.5 * (st.qf - st.red);
 }
 
-// full solve at times xs: coefficients of every segment to `coeffs` (global, [S][4][10]); returns cost.
-// ws: back-substitution workspace with element stride `wstride`.
-__device__ double full_solve(const uint8_t* __restrict__ mask, const double* __restrict__ vals, int v0, int S, int d,
-                             const double* xs, double* ws, size_t wstride, double* __restrict__ coeffs, bool& pos_ok) {
-  Elim<kD> st;
-  st.init();
-  double fs[kHalf][kD], fe[kHalf][kD];
-  double L[10], z[kNB][kD], W[kNB][kNB];
-  bool pf;
-  pos_ok = true;
-  unsigned free_s = load_vertex<kD>(mask, vals, v0, 0, fs, pf);
-  pos_ok = pos_ok && pf;
-  for (int i = 0; i < S; ++i) {
-    const unsigned free_e = load_vertex<kD>(mask, vals, v0 + i + 1, 0, fe, pf);
-    pos_ok = pos_ok && pf;
-    double Hs[kSym10];
-    hessian_from_time(xs[i], d, Hs);
-    st.absorb_segment(Hs, fs, fe, free_s, free_e, L, z, W);
-    double* w = ws + (size_t)i * kWsPerVertex * wstride;
-#pragma unroll
-    for (int e = 0; e < 10; ++e) w[(size_t)e * wstride] = L[e];
-#pragma unroll
-    for (int r = 0; r < kNB; ++r)
-#pragma unroll
-      for (int c = 0; c < kD; ++c) w[(size_t)(10 + r * kD + c) * wstride] = z[r][c];
-#pragma unroll
-    for (int r = 0; r < kNB; ++r)
-#pragma unroll
-      for (int c = 0; c < kNB; ++c) w[(size_t)(10 + kNB * kD + r * kNB + c) * wstride] = W[r][c];
-#pragma unroll
-    for (int s = 0; s < kHalf; ++s)
-#pragma unroll
-      for (int dd = 0; dd < kD; ++dd) fs[s][dd] = fe[s][dd];
-    free_s = free_e;
-  }
-  st.factor_vertex(free_s, L, z);
-  const double cost = 0.5 * (st.qf - st.red);
-
-  double xn[kNB][kD], x[kNB][kD], dn[kHalf][kD], dc[kHalf][kD];
-  back_substitute<kD>(L, z, W, xn, true, x);
-#pragma unroll
-  for (int s = 0; s < kHalf; ++s)
-#pragma unroll
-    for (int dd = 0; dd < kD; ++dd) dn[s][dd] = fs[s][dd] + (s >= kSlot0 ? x[s - kSlot0][dd] : 0.0);
-#pragma unroll
-  for (int r = 0; r < kNB; ++r)
-#pragma unroll
-    for (int dd = 0; dd < kD; ++dd) xn[r][dd] = x[r][dd];
-  for (int i = S - 1; i >= 0; --i) {
-    const double* w = ws + (size_t)i * kWsPerVertex * wstride;
-#pragma unroll
-    for (int e = 0; e < 10; ++e) L[e] = w[(size_t)e * wstride];
-#pragma unroll
-    for (int r = 0; r < kNB; ++r)
-#pragma unroll
-      for (int c = 0; c < kD; ++c) z[r][c] = w[(size_t)(10 + r * kD + c) * wstride];
-#pragma unroll
-    for (int r = 0; r < kNB; ++r)
-#pragma unroll
-      for (int c = 0; c < kNB; ++c) W[r][c] = w[(size_t)(10 + kNB * kD + r * kNB + c) * wstride];
-    back_substitute<kD>(L, z, W, xn, false, x);
-    load_vertex<kD>(mask, vals, v0 + i, 0, fs, pf);
-#pragma unroll
-    for (int s = 0; s < kHalf; ++s)
-#pragma unroll
-      for (int dd = 0; dd < kD; ++dd) dc[s][dd] = fs[s][dd] + (s >= kSlot0 ? x[s - kSlot0][dd] : 0.0);
-    const double T = xs[i];
-    double* cout = coeffs + (size_t)i * kD * kN;
-#pragma unroll
-    for (int dd = 0; dd < kD; ++dd) {
-      double dv[kN], c[kN];
-#pragma unroll
-      for (int s = 0; s < kHalf; ++s) {
-        dv[s] = dc[s][dd];
-        dv[kHalf + s] = dn[s][dd];
-      }
-      coefficients_from_time(T, dv, c);
-#pragma unroll
-      for (int s = 0; s < kN; ++s) cout[dd * kN + s] = c[s];
-    }
-#pragma unroll
-    for (int s = 0; s < kHalf; ++s)
-#pragma unroll
-      for (int dd = 0; dd < kD; ++dd) dn[s][dd] = dc[s][dd];
-#pragma unroll
-    for (int r = 0; r < kNB; ++r)
-#pragma unroll
-      for (int dd = 0; dd < kD; ++dd) xn[r][dd] = x[r][dd];
-  }
-  return cost;
-}
-
 // ---------------------------------------------------------------------------------------------
 // per-segment maxima of |p^(k)| over [0, T] for k = 1..3 and the groups {x,y}, {z}, {heading}.
 //
@@ -172,75 +81,112 @@ __device__ double full_solve(const uint8_t* __restrict__ mask, const double* __r
 // function, so the result never exceeds the exact maximum.
 
 constexpr int kGridCells = 32;
+constexpr int kPolishIters = 17;
 
-struct DerivEval {
-  double v0, v1, v2;  // q^(k), q^(k+1), q^(k+2) at tau (derivatives with respect to tau)
+// falling factorial j!/(j-k)! as a compile-time constant
+__host__ __device__ constexpr double falling(int j, int k) {
+  double v = 1.0;
+  for (int n = 0; n < k; ++n) v *= (double)(j - n);
+  return v;
+}
+
+// Coefficients of q^(K), q^(K+1), q^(K+2) (derivatives in normalised time) of NDIM dimensions, kept in
+// registers; every loop below has compile-time bounds so nothing is indexed dynamically.
+template <int K, int NDIM>
+struct MagPoly {
+  static constexpr int N0 = kN - K, N1 = kN - K - 1, N2 = kN - K - 2;
+  double d0[NDIM][N0], d1[NDIM][N1], d2[NDIM][N2];
+
+  __device__ __forceinline__ void init(const double (&cb)[NDIM][kN]) {
+#pragma unroll
+    for (int q = 0; q < NDIM; ++q) {
+#pragma unroll
+      for (int j = 0; j < N0; ++j) d0[q][j] = cb[q][j + K] * falling(j + K, K);
+#pragma unroll
+      for (int j = 0; j < N1; ++j) d1[q][j] = cb[q][j + K + 1] * falling(j + K + 1, K + 1);
+#pragma unroll
+      for (int j = 0; j < N2; ++j) d2[q][j] = cb[q][j + K + 2] * falling(j + K + 2, K + 2);
+    }
+  }
+  // m2 = sum q^(K)^2 ;  g = (1/2) d m2 / dtau
+  __device__ __forceinline__ void eval(double tau, double& m2, double& g) const {
+    m2 = 0.0;
+    g = 0.0;
+#pragma unroll
+    for (int q = 0; q < NDIM; ++q) {
+      double v0 = d0[q][N0 - 1], v1 = d1[q][N1 - 1];
+#pragma unroll
+      for (int j = N0 - 2; j >= 0; --j) v0 = v0 * tau + d0[q][j];
+#pragma unroll
+      for (int j = N1 - 2; j >= 0; --j) v1 = v1 * tau + d1[q][j];
+      m2 += v0 * v0;
+      g += v0 * v1;
+    }
+  }
+  // the same plus dg = derivative of g (Newton)
+  __device__ __forceinline__ void eval2(double tau, double& m2, double& g, double& dg) const {
+    m2 = 0.0;
+    g = 0.0;
+    dg = 0.0;
+#pragma unroll
+    for (int q = 0; q < NDIM; ++q) {
+      double v0 = d0[q][N0 - 1], v1 = d1[q][N1 - 1], v2 = d2[q][N2 - 1];
+#pragma unroll
+      for (int j = N0 - 2; j >= 0; --j) v0 = v0 * tau + d0[q][j];
+#pragma unroll
+      for (int j = N1 - 2; j >= 0; --j) v1 = v1 * tau + d1[q][j];
+#pragma unroll
+      for (int j = N2 - 2; j >= 0; --j) v2 = v2 * tau + d2[q][j];
+      m2 += v0 * v0;
+      g += v0 * v1;
+      dg += v1 * v1 + v0 * v2;
+    }
+  }
 };
 
-// cb: normalised coefficients cbar_j = c_j T^j of one dimension
-__device__ __forceinline__ DerivEval eval_derivs(const double (&cb)[kN], double tau, int k) {
-  // Horner for three consecutive derivatives; falling factorials built incrementally
-  double a0 = 0.0, a1 = 0.0, a2 = 0.0;
-  for (int j = kN - 1; j >= k; --j) {
-    double f0 = 1.0;
-    for (int n = 0; n < k; ++n) f0 *= (double)(j - n);  // j!/(j-k)!
-    const double f1 = f0 * (double)(j - k);             // j!/(j-k-1)!
-    const double f2 = f1 * (double)(j - k - 1);         // j!/(j-k-2)!
-    a0 = a0 * tau + f0 * cb[j];
-    if (j >= k + 1) a1 = a1 * tau + f1 * cb[j];
-    if (j >= k + 2) a2 = a2 * tau + f2 * cb[j];
-  }
-  DerivEval r;
-  r.v0 = a0;
-  r.v1 = a1;
-  r.v2 = a2;
-  return r;
-}
-
-template <int NDIM>
-__device__ __forceinline__ void mag_eval(const double (&cb)[NDIM][kN], double tau, int k, double& m2, double& g,
-                                         double& dg) {
-  m2 = 0.0;
-  g = 0.0;
-  dg = 0.0;
-#pragma unroll
-  for (int q = 0; q < NDIM; ++q) {
-    const DerivEval e = eval_derivs(cb[q], tau, k);
-    m2 += e.v0 * e.v0;
-    g += e.v0 * e.v1;                // (1/2) d/dtau m2
-    dg += e.v1 * e.v1 + e.v0 * e.v2;  // derivative of g
-  }
-}
-
-// max over tau in [0,1] of sum_dim q^(k)(tau)^2
-template <int NDIM>
-__device__ double max_mag2(const double (&cb)[NDIM][kN], int k) {
-  double m2, g, dg;
-  mag_eval<NDIM>(cb, 0.0, k, m2, g, dg);
+// max over tau in [0,1] of sum_dim q^(K)(tau)^2.
+// Pass 1 walks the grid and records, as a bit mask, the cells where g changes sign + -> - (a local
+// maximum inside).  Pass 2 polishes the recorded cells.  Keeping the two apart matters on a 64-wide
+// wavefront: lanes hold different polynomials, and polishing inside the grid loop would make every lane
+// wait for a Newton loop in almost every cell.
+template <int K, int NDIM>
+__device__ __forceinline__ double max_mag2(const double (&cb)[NDIM][kN]) {
+  static_assert(kGridCells <= 32, "cell mask is 32 bits");
+  MagPoly<K, NDIM> mp;
+  mp.init(cb);
+  double m2, g;
+  mp.eval(0.0, m2, g);
   double best = m2;
   double g_prev = g;
   const double h = 1.0 / kGridCells;
+  unsigned cells = 0u;
   for (int i = 1; i <= kGridCells; ++i) {
     const double tau = (i == kGridCells) ? 1.0 : i * h;
-    mag_eval<NDIM>(cb, tau, k, m2, g, dg);
+    mp.eval(tau, m2, g);
     best = fmax(best, m2);
-    if (g_prev > 0.0 && g <= 0.0) {
-      // a local maximum of m2 lies in (tau - h, tau]: safeguarded Newton on g
-      double lo = tau - h, hi = tau;
-      double t = 0.5 * (lo + hi);
-      for (int it = 0; it < 60; ++it) {
-        double mm, gg, dd;
-        mag_eval<NDIM>(cb, t, k, mm, gg, dd);
-        best = fmax(best, mm);
-        if (gg > 0.0) lo = t;
-        else hi = t;
-        double tn = (dd < 0.0) ? t - gg / dd : 0.5 * (lo + hi);
-        if (!(tn > lo && tn < hi)) tn = 0.5 * (lo + hi);
-        if (fabs(tn - t) < 1e-10 || hi - lo < 1e-14) break;
-        t = tn;
-      }
-    }
+    if (g_prev > 0.0 && g <= 0.0) cells |= 1u << (i - 1);
     g_prev = g;
+  }
+  while (cells) {
+    const int cell = __ffs(cells) - 1;
+    cells &= cells - 1;
+    // safeguarded Newton on g inside (cell*h, (cell+1)*h]
+    double lo = cell * h, hi = (cell + 1 == kGridCells) ? 1.0 : (cell + 1) * h;
+    double t = 0.5 * (lo + hi);
+    // m2 is flat at its maximum: an abscissa error e costs ~ m2'' e^2 / 2, so |e| ~ 1e-8 already gives
+    // the value to ~1e-16; the iteration cap bounds the slowest lane of the wavefront (pure bisection
+    // from a 1/32 cell reaches 2e-7 after 17 halvings, i.e. a value error below 1e-12).
+    for (int it = 0; it < kPolishIters; ++it) {
+      double mm, gg, dd;
+      mp.eval2(t, mm, gg, dd);
+      best = fmax(best, mm);
+      if (gg > 0.0) lo = t;
+      else hi = t;
+      double tn = (dd < 0.0) ? t - gg / dd : 0.5 * (lo + hi);
+      if (!(tn > lo && tn < hi)) tn = 0.5 * (lo + hi);
+      if (fabs(tn - t) < 1e-9) break;
+      t = tn;
+    }
   }
   return best;
 }
@@ -258,13 +204,16 @@ __device__ void segment_maxima(const double* __restrict__ c, double T, double (&
     tp *= T;
   }
   const double ti = 1.0 / T;
-  double tik = ti;
-  for (int k = 1; k <= 3; ++k) {
-    out[(k - 1) * 3 + 0] = sqrt(max_mag2<2>(cb_h, k)) * tik;
-    out[(k - 1) * 3 + 1] = sqrt(max_mag2<1>(cb_v, k)) * tik;
-    out[(k - 1) * 3 + 2] = sqrt(max_mag2<1>(cb_y, k)) * tik;
-    tik *= ti;
-  }
+  const double ti2 = ti * ti, ti3 = ti2 * ti;
+  out[0] = sqrt(max_mag2<1, 2>(cb_h)) * ti;
+  out[1] = sqrt(max_mag2<1, 1>(cb_v)) * ti;
+  out[2] = sqrt(max_mag2<1, 1>(cb_y)) * ti;
+  out[3] = sqrt(max_mag2<2, 2>(cb_h)) * ti2;
+  out[4] = sqrt(max_mag2<2, 1>(cb_v)) * ti2;
+  out[5] = sqrt(max_mag2<2, 1>(cb_y)) * ti2;
+  out[6] = sqrt(max_mag2<3, 2>(cb_h)) * ti3;
+  out[7] = sqrt(max_mag2<3, 1>(cb_v)) * ti3;
+  out[8] = sqrt(max_mag2<3, 1>(cb_y)) * ti3;
 }
 
 // violation scaling of one segment: max(1, v, sqrt(a), cbrt(j))  (trajectory.cpp:625-642)
@@ -540,14 +489,22 @@ __global__ __launch_bounds__(64) void nonlinear_kernel(BatchView b, NonlinearPar
     __syncthreads();
   }
 
-  // ---- scaleSegmentTimesWithViolation (nonlinear_impl.h:336-408) and the final solve
+  // ---- scaleSegmentTimesWithViolation (nonlinear_impl.h:336-408) and the final solve.
+  // Lanes 0..3 of the group each solve one dimension (G >= 4 always).
   bool pos_ok = true;
   double cost = 0.0;
   const bool scale = active && !bad;
   double* my_coeffs = coeffs + (size_t)pr.s0 * kD * kN;
+  const BlockSource no_blocks{nullptr, nullptr, 0, 0};
+  const size_t ws_lanes = 4 * P;
   for (int pass = 0; pass < 2; ++pass) {
-    if (active && g == 0 && (pass == 1 || scale))
-      cost = full_solve(mask, vals, pr.v0, S, d, x, ws + q, P, my_coeffs, pos_ok);
+    double part = 0.0;
+    if (active && g < 4 && (pass == 1 || scale))
+      part = solve_path<1, true>(mask, vals, pr.v0, S, d, x, g, no_blocks, ws + (size_t)q * 4 + g, ws_lanes, my_coeffs,
+                                 pos_ok);
+    part += __shfl_xor(part, 1, 64);
+    part += __shfl_xor(part, 2, 64);
+    cost = part;  // valid in lanes 0..3 of the group
     __threadfence_block();
     __syncthreads();
     if (pass == 0) {
@@ -649,7 +606,7 @@ static unsigned cdiv_u(long long a, long long b) { return (unsigned)((a + b - 1)
 hipError_t launch_nonlinear(NonlinearPlan& nl, const BatchView& b, const NonlinearParams& prm, const uint8_t* mask,
                             const double* vals, const double* limits, double* seg_times, double* coeffs,
                             int32_t* status, double* cost, hipStream_t stream) {
-  const size_t need = (size_t)b.max_segments * kWsPerVertex * (size_t)b.n_paths;
+  const size_t need = (size_t)b.max_segments * ws_per_vertex<1>() * 4 * (size_t)b.n_paths;
   if (nl.ws_doubles < need) {
     if (nl.d_ws) (void)hipFree(nl.d_ws);
     nl.d_ws = nullptr;
