@@ -157,6 +157,32 @@ def main():
                     avg_launch_us=mean_ms * 1e3, median_launch_us=med_ms * 1e3)
 
     extras = {}
+    if not args.no_extras and rank == 0:
+        # the same kernel on a batch that is not launch-ramp dominated (65536 x 10 segments = 1.05 GB per launch)
+        big_P = 65536
+        so_big = (np.arange(big_P + 1, dtype=np.int64) * args.segments).astype(np.int32)
+        plan_big = api.Plan(ctx, so_big)
+        t_big = t_init.repeat((big_P * args.segments + nS - 1) // nS)[:big_P * args.segments].contiguous()
+        Hb = torch.empty(plan_big.block_doubles, dtype=torch.float64, device=dev)
+        Ab = torch.empty(plan_big.block_doubles, dtype=torch.float64, device=dev)
+        for _ in range(3):
+            plan_big.assemble(4, t_big, Hb, Ab)
+        torch.cuda.synchronize()
+        m_big, _ = kernel_event_ms(lambda: plan_big.assemble(4, t_big, Hb, Ab), 20, torch)
+        bytes_big = ASSEMBLY_BYTES_PER_SEGMENT * big_P * args.segments
+        extras["roofline_large"] = dict(kernel="assemble_blocks_kernel", paths=big_P, bytes_per_launch=bytes_big,
+                                        avg_launch_us=m_big * 1e3, achieved=bytes_big / (m_big * 1e-3) / 1e9,
+                                        unit="GB/s", frac=bytes_big / (m_big * 1e-3) / 1e9 / HBM_PEAK_GBS)
+        del Hb, Ab
+        plan_big.close()
+        # PCIe-inclusive rate of the one-call host interface (plan creation + H2D + kernels + D2H); never the headline
+        times_host = t_init.cpu().numpy()
+        ctx.solve_batch(batch, times_host)
+        t0 = time.perf_counter()
+        for _ in range(5):
+            ctx.solve_batch(batch, times_host)
+        extras["host_buffer_call"] = dict(value=5 * P / (time.perf_counter() - t0), unit="trajectories/s",
+                                          note="mrs_tg_solve_batch with host buffers, linear QP, includes PCIe copies")
     if not args.no_extras:
         other = "nonlinear" if args.workload == "linear" else "linear"
         k2 = max(5, args.steps // 10) if other == "nonlinear" else args.steps

@@ -290,14 +290,26 @@ __device__ __forceinline__ PathRef path_at(const BatchView& b, int q) {
 template <int ND>
 __device__ __forceinline__ unsigned load_vertex(const uint8_t* __restrict__ mask, const double* __restrict__ vals, int v,
                                                 int dim0, double (&f)[kHalf][ND], bool& position_fixed) {
+  // all loads are unconditional (the ABI guarantees the value array exists for every slot; entries of
+  // unconstrained slots are ignored), so they issue back to back instead of one branch per slot
+  const uint8_t* __restrict__ mrow = mask + (size_t)v * kHalf;
+  const double* __restrict__ vrow = vals + (size_t)v * kHalf * kD + dim0;
+  uint8_t mk[kHalf];
+  double raw[kHalf][ND];
+#pragma unroll
+  for (int k = 0; k < kHalf; ++k) mk[k] = mrow[k];
+#pragma unroll
+  for (int k = 0; k < kHalf; ++k)
+#pragma unroll
+    for (int q = 0; q < ND; ++q) raw[k][q] = vrow[k * kD + q];
   unsigned free_bits = 0;
 #pragma unroll
   for (int k = 0; k < kHalf; ++k) {
-    const bool fixed = mask[(size_t)v * kHalf + k] != 0;
+    const bool fixed = mk[k] != 0;
     if (k == 0) position_fixed = fixed;
     if (k >= kSlot0 && !fixed) free_bits |= 1u << (k - kSlot0);
 #pragma unroll
-    for (int q = 0; q < ND; ++q) f[k][q] = fixed ? vals[((size_t)v * kHalf + k) * kD + dim0 + q] : 0.0;
+    for (int q = 0; q < ND; ++q) f[k][q] = fixed ? raw[k][q] : 0.0;
   }
   return free_bits;
 }

@@ -500,8 +500,8 @@ __global__ __launch_bounds__(64) void nonlinear_kernel(BatchView b, NonlinearPar
   for (int pass = 0; pass < 2; ++pass) {
     double part = 0.0;
     if (active && g < 4 && (pass == 1 || scale))
-      part = solve_path<1, true>(mask, vals, pr.v0, S, d, x, g, no_blocks, ws + (size_t)q * 4 + g, ws_lanes, my_coeffs,
-                                 pos_ok);
+      part = solve_path<1, true>(mask, vals, pr.v0, S, d, x, g, no_blocks, ws, ws_lanes, (unsigned)(q * 4 + g),
+                                 my_coeffs, pos_ok);
     part += __shfl_xor(part, 1, 64);
     part += __shfl_xor(part, 2, 64);
     cost = part;  // valid in lanes 0..3 of the group

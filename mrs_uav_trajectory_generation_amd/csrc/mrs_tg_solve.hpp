@@ -40,11 +40,17 @@ __device__ __forceinline__ void fetch_vertex(const uint8_t* __restrict__ mask, c
   out.free_bits = load_vertex<ND>(mask, vals, v, dim0, out.f, out.pos_fixed);
 }
 
+// Addressing discipline for the SoA buffers: every address is (wave-uniform row pointer) + (32-bit lane
+// index).  Written that way the compiler keeps the row pointers in SGPRs and emits
+// global_load/store ... v_off, s[base] with one shared lane offset instead of 64-bit VALU address math
+// per access.
 __device__ __forceinline__ void load_H_blocks(const BlockSource& src, int seg, double (&Hs)[kSym10]) {
+  const double* __restrict__ blk = src.H + (size_t)seg * 100 * src.P;
+  const unsigned q = (unsigned)src.q;
 #pragma unroll
   for (int a = 0; a < kN; ++a)
 #pragma unroll
-    for (int c = a; c < kN; ++c) Hs[sym10(a, c)] = src.H[((size_t)seg * 100 + a * kN + c) * src.P + src.q];
+    for (int c = a; c < kN; ++c) Hs[sym10(a, c)] = (blk + (size_t)(a * kN + c) * src.P)[q];
 }
 
 // lower half (rows 5..9) of A^-1 and its diagonal upper half
@@ -54,12 +60,14 @@ struct AinvRows {
 };
 
 __device__ __forceinline__ void load_A_blocks(const BlockSource& src, int seg, AinvRows& a) {
+  const double* __restrict__ blk = src.A + (size_t)seg * 100 * src.P;
+  const unsigned q = (unsigned)src.q;
 #pragma unroll
-  for (int k = 0; k < kHalf; ++k) a.diag[k] = src.A[((size_t)seg * 100 + k * kN + k) * src.P + src.q];
+  for (int k = 0; k < kHalf; ++k) a.diag[k] = (blk + (size_t)(k * kN + k) * src.P)[q];
 #pragma unroll
   for (int k = 0; k < kHalf; ++k)
 #pragma unroll
-    for (int c = 0; c < kN; ++c) a.low[k][c] = src.A[((size_t)seg * 100 + (kHalf + k) * kN + c) * src.P + src.q];
+    for (int c = 0; c < kN; ++c) a.low[k][c] = (blk + (size_t)((kHalf + k) * kN + c) * src.P)[q];
 }
 
 template <int ND>
@@ -69,44 +77,50 @@ struct SavedFactors {
   double z[kNB][ND];
 };
 
+// w: uniform pointer to element 0 of this vertex's record; element e of lane `lane` at w[e * stride + lane]
 template <int ND>
-__device__ __forceinline__ void store_factors(double* w, size_t stride, const SavedFactors<ND>& s) {
+__device__ __forceinline__ void store_factors(double* w, size_t stride, unsigned lane, const SavedFactors<ND>& s) {
 #pragma unroll
-  for (int e = 0; e < 10; ++e) w[(size_t)e * stride] = s.L[e];
-#pragma unroll
-  for (int r = 0; r < kNB; ++r)
-#pragma unroll
-    for (int c = 0; c < kNB; ++c) w[(size_t)(10 + r * kNB + c) * stride] = s.W[r][c];
+  for (int e = 0; e < 10; ++e) (w + (size_t)e * stride)[lane] = s.L[e];
 #pragma unroll
   for (int r = 0; r < kNB; ++r)
 #pragma unroll
-    for (int c = 0; c < ND; ++c) w[(size_t)(10 + kNB * kNB + r * ND + c) * stride] = s.z[r][c];
+    for (int c = 0; c < kNB; ++c) (w + (size_t)(10 + r * kNB + c) * stride)[lane] = s.W[r][c];
+#pragma unroll
+  for (int r = 0; r < kNB; ++r)
+#pragma unroll
+    for (int c = 0; c < ND; ++c) (w + (size_t)(10 + kNB * kNB + r * ND + c) * stride)[lane] = s.z[r][c];
 }
 
 template <int ND>
-__device__ __forceinline__ void load_factors(const double* w, size_t stride, SavedFactors<ND>& s) {
+__device__ __forceinline__ void load_factors(const double* w, size_t stride, unsigned lane, SavedFactors<ND>& s) {
 #pragma unroll
-  for (int e = 0; e < 10; ++e) s.L[e] = w[(size_t)e * stride];
-#pragma unroll
-  for (int r = 0; r < kNB; ++r)
-#pragma unroll
-    for (int c = 0; c < kNB; ++c) s.W[r][c] = w[(size_t)(10 + r * kNB + c) * stride];
+  for (int e = 0; e < 10; ++e) s.L[e] = (w + (size_t)e * stride)[lane];
 #pragma unroll
   for (int r = 0; r < kNB; ++r)
 #pragma unroll
-    for (int c = 0; c < ND; ++c) s.z[r][c] = w[(size_t)(10 + kNB * kNB + r * ND + c) * stride];
+    for (int c = 0; c < kNB; ++c) s.W[r][c] = (w + (size_t)(10 + r * kNB + c) * stride)[lane];
+#pragma unroll
+  for (int r = 0; r < kNB; ++r)
+#pragma unroll
+    for (int c = 0; c < ND; ++c) s.z[r][c] = (w + (size_t)(10 + kNB * kNB + r * ND + c) * stride)[lane];
 }
 
 // Solve one path for dimensions [dim0, dim0 + ND).
 //   times   segment times of this path (global or LDS)
-//   ws      this lane's private factor store; element e of vertex v at ws[(v * ws_per_vertex<ND>() + e) * wstride]
+//   ws      factor store (uniform base); element e of vertex v of lane `wlane` at ws[(v * ws_per_vertex<ND>() + e) * wstride + wlane]
 //   coeffs  [S][4][10] of this path
 // Returns this lane's share of the cost, 0.5 * (qf - red) over its dimensions.
 template <int ND, bool FUSED>
 __device__ __forceinline__ double solve_path(const uint8_t* __restrict__ mask, const double* __restrict__ vals, int v0,
                                              int S, int d, const double* times, int dim0, const BlockSource& src,
-                                             double* ws, size_t wstride, double* __restrict__ coeffs, bool& pos_ok) {
+                                             double* ws, size_t wstride, unsigned wlane, double* __restrict__ coeffs,
+                                             bool& pos_ok) {
   constexpr int WSV = ws_per_vertex<ND>();
+  // one-segment-ahead prefetch of the materialised blocks doubles their register footprint: worth it in the
+  // latency-bound 4-lanes-per-path mode, a spill hazard in the throughput mode (ND = 4) where other
+  // wavefronts hide the latency anyway
+  constexpr bool kPrefetchBlocks = (ND == 1);
   Elim<ND> st;
   st.init();
   VertexData<ND> vs, ve, vn;
@@ -117,7 +131,7 @@ __device__ __forceinline__ double solve_path(const uint8_t* __restrict__ mask, c
   double Hn[kSym10];
   double Tn = 0.0;
   if (FUSED) Tn = times[0];
-  else load_H_blocks(src, 0, Hn);
+  else if (kPrefetchBlocks) load_H_blocks(src, 0, Hn);
 
   for (int i = 0; i < S; ++i) {
     double Hs[kSym10];
@@ -127,13 +141,15 @@ __device__ __forceinline__ double solve_path(const uint8_t* __restrict__ mask, c
       const double T = Tn;
       if (i + 1 < S) Tn = times[i + 1];
       hessian_from_time(T, d, Hs);
-    } else {
+    } else if (kPrefetchBlocks) {
 #pragma unroll
       for (int e = 0; e < kSym10; ++e) Hs[e] = Hn[e];
       if (i + 1 < S) load_H_blocks(src, i + 1, Hn);
+    } else {
+      load_H_blocks(src, i, Hs);
     }
     st.absorb_segment(Hs, vs.f, ve.f, vs.free_bits, ve.free_bits, sf.L, sf.z, sf.W);
-    store_factors<ND>(ws + (size_t)i * WSV * wstride, wstride, sf);
+    store_factors<ND>(ws + (size_t)i * WSV * wstride, wstride, wlane, sf);
     vs = ve;
     if (i + 2 <= S) {
       ve = vn;
@@ -159,22 +175,25 @@ __device__ __forceinline__ double solve_path(const uint8_t* __restrict__ mask, c
   VertexData<ND> vc, vp;
   AinvRows an;
   double Tb = 0.0;
-  load_factors<ND>(ws + (size_t)(S - 1) * WSV * wstride, wstride, sn);
+  load_factors<ND>(ws + (size_t)(S - 1) * WSV * wstride, wstride, wlane, sn);
   fetch_vertex<ND>(mask, vals, v0 + S - 1, dim0, vp);
   if (FUSED) Tb = times[S - 1];
-  else load_A_blocks(src, S - 1, an);
+  else if (kPrefetchBlocks) load_A_blocks(src, S - 1, an);
 
   for (int i = S - 1; i >= 0; --i) {
     sf = sn;
     vc = vp;
     const double T = Tb;
     AinvRows ac;
-    if (!FUSED) ac = an;
+    if (!FUSED) {
+      if (kPrefetchBlocks) ac = an;
+      else load_A_blocks(src, i, ac);
+    }
     if (i > 0) {
-      load_factors<ND>(ws + (size_t)(i - 1) * WSV * wstride, wstride, sn);
+      load_factors<ND>(ws + (size_t)(i - 1) * WSV * wstride, wstride, wlane, sn);
       fetch_vertex<ND>(mask, vals, v0 + i - 1, dim0, vp);
       if (FUSED) Tb = times[i - 1];
-      else load_A_blocks(src, i - 1, an);
+      else if (kPrefetchBlocks) load_A_blocks(src, i - 1, an);
     }
     back_substitute<ND>(sf.L, sf.z, sf.W, xn, false, x);
 #pragma unroll

@@ -56,3 +56,39 @@ def test_product_package_does_not_import_the_oracle():
             if f.endswith((".py", ".hip", ".hpp", ".h", ".cpp")):
                 src = open(os.path.join(dirpath, f)).read()
                 assert "pyoracle" not in src and "mrs_tg_oracle" not in src and "libmrs_tg_oracle" not in src, f
+
+
+def test_cpp_wrapper_compiles_and_links(lib, tmp_path):
+    """include/mrs_tg.hpp (the findTrajectory-shaped C++ wrapper of INTEGRATION.md) builds against the library."""
+    import subprocess
+    import torch
+    src = tmp_path / "host.cpp"
+    src.write_text(r"""
+#include <cstdio>
+#include "mrs_tg.hpp"
+int main() {
+  try {
+    mrs_tg::TrajectoryGenerator tg(0);
+    std::vector<mrs_tg::Waypoint> wps = {{{-5, -5, 5, 1}, false}, {{-5, 5, 5, 2}, false}, {{5, -5, 5, 3}, false}, {{5, 5, 5, 4}, false}};
+    mrs_tg::DynamicsConstraints dc{2, 2, 20, 2, 2, 2, 2, 20, 20, 1, 2, 20};
+    tg.options().derivative_to_optimize = 4;
+    auto pts = tg.findTrajectory(wps, std::nullopt, dc, 0.2, false);
+    std::printf("samples %zu status %d\n", pts ? pts->size() : 0, tg.status());
+    return pts ? 0 : 2;
+  } catch (const std::exception& e) {
+    std::printf("error: %s\n", e.what());
+    return 3;
+  }
+}
+""")
+    exe = tmp_path / "host"
+    libdir = os.path.dirname(api.LIB_PATH)
+    subprocess.check_call(["g++", "-std=c++17", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe),
+                           "-L", libdir, "-l:libmrs_tg.so", "-Wl,-rpath," + libdir, "-Wl,-rpath,/opt/rocm/lib",
+                           "-L/opt/rocm/lib", "-lamdhip64"])
+    r = subprocess.run([str(exe)], capture_output=True, text=True)
+    if torch.cuda.is_available():
+        assert r.returncode == 0 and "samples" in r.stdout, r.stdout + r.stderr
+    else:
+        # no device: the constructor throws the library's loud error, nothing falls back to the CPU
+        assert r.returncode == 3 and "no CPU fallback" in r.stdout, r.stdout + r.stderr
