@@ -195,99 +195,104 @@ __global__ __launch_bounds__(256) void estimate_times_kernel(BatchView b, const 
 // sampler: Trajectory::evaluateRange's accumulate-and-carry walk
 // (/root/reference/src/eth_trajectory_generation/trajectory.cpp:93-151), positions + wrapped heading
 // (the only fields the nodelet reads, src/mrs_trajectory_generation.cpp:1582-1599).
-// One wavefront per path: lane 0 replays the walk to find (segment, time-in-segment) of every sample
-// in chunks of 64, then all lanes evaluate their sample in parallel.
+//
+// The reference's sample times are defined by repeated floating-point addition
+// (time_in_segment += dt; accumulated += dt, with the remainder carried into the next segment), so the
+// sample count and the segment a boundary sample falls into depend on that exact rounding.  One wavefront
+// per path:
+//   1. lane 0 replays the recurrence in a register-only loop and records, per segment, the index of its
+//      first sample and the time_in_segment of that sample (S entries instead of one per sample);
+//   2. every lane takes samples n = lane, lane+64, ...: finds the segment, re-adds dt (n - first) times from
+//      the segment's start value -- the same additions in the same order, so bit-identical to the
+//      reference's running sum -- and evaluates the four polynomials.
+// The heading goes through the reference's quaternion round trip, atan2(2wz, 1-2z^2) with
+// w = cos(y/2), z = sin(y/2) (eth_mav_msgs/common.h:130-140), which is the wrap of y to (-pi, pi];
+// it is computed as y - 2 pi rint(y / 2 pi) (agreement 1e-15; same value at the +-pi seam).
+
+__device__ __forceinline__ double wrap_heading(double y) {
+  const double two_pi_hi = 6.283185307179586232e+00, two_pi_lo = 2.449293598294706414e-16;
+  const double kf = rint(y * 1.591549430918953456e-01);
+  return fma(-kf, two_pi_lo, fma(-kf, two_pi_hi, y));
+}
 
 __global__ __launch_bounds__(64) void sample_kernel(BatchView b, const double* __restrict__ coeffs,
                                                     const double* __restrict__ seg_times, double dt, int capacity,
                                                     int32_t* __restrict__ n_samples, double* __restrict__ samples) {
-  extern __shared__ double s_T[];  // [max_segments] segment times of this path
+  extern __shared__ double s_mem[];  // [S] times | [S] first-sample tin | [S+1] first-sample index (as int)
   const int q = blockIdx.x;
   const PathRef pr = path_at(b, q);
+  const int S = pr.S;
   const int lane = threadIdx.x;
-  __shared__ int s_seg[64];
-  __shared__ double s_tin[64];
-  __shared__ int s_cnt, s_done;
-  for (int i = lane; i < pr.S; i += 64) s_T[i] = seg_times[pr.s0 + i];
+  double* s_T = s_mem;
+  double* s_tin0 = s_mem + b.max_segments;
+  int* s_first = reinterpret_cast<int*>(s_mem + 2 * b.max_segments);
+  for (int i = lane; i < S; i += 64) s_T[i] = seg_times[pr.s0 + i];
   __syncthreads();
-  // walk state, private to lane 0
-  int w_i = 0;
-  double w_tin = 0.0, w_acc = 0.0, w_tend = 0.0;
   if (lane == 0) {
-    for (int i = 0; i < pr.S; ++i) w_tend += s_T[i];
-    // first segment whose accumulated time exceeds t_start = 0
+    double t_end = 0.0;
+    for (int i = 0; i < S; ++i) t_end += s_T[i];
+    // first segment whose accumulated time exceeds t_start = 0 (trajectory.cpp:108-120)
     double acc = 0.0;
     int i = 0;
-    for (i = 0; i < pr.S; ++i) {
+    for (i = 0; i < S; ++i) {
       acc += s_T[i];
       if (acc > 0.0) break;
     }
-    s_done = (i >= pr.S) ? 1 : 0;
-    if (i < pr.S) acc -= s_T[i];
-    w_i = i;
-    w_acc = acc;
-    w_tin = 0.0 - acc;
+    int n = 0;
+    if (i < S) {
+      acc -= s_T[i];
+      double tin = 0.0 - acc;
+      double Ti = s_T[i];
+      for (int j = 0; j <= i; ++j) s_first[j] = 0;
+      s_tin0[i] = tin;
+      while (acc < t_end) {  // trajectory.cpp:131-150
+        if (tin > Ti) {
+          tin = tin - Ti;
+          ++i;
+          if (i >= S) break;
+          Ti = s_T[i];
+          s_first[i] = n;
+          s_tin0[i] = tin;
+          continue;
+        }
+        ++n;
+        tin += dt;
+        acc += dt;
+      }
+      for (int j = (i < S ? i + 1 : S); j <= S; ++j) s_first[j] = n;
+    } else {
+      for (int j = 0; j <= S; ++j) s_first[j] = 0;
+    }
+    if (n_samples) n_samples[pr.p] = n;
   }
   __syncthreads();
-  int total = 0;
-  double* out = samples ? samples + (size_t)pr.p * capacity * kD : nullptr;
-  while (true) {
-    if (lane == 0) {
-      int cnt = 0;
-      if (!s_done) {
-        double Ti = s_T[w_i];
-        while (cnt < 64) {
-          if (!(w_acc < w_tend)) {
-            s_done = 1;
-            break;
-          }
-          if (w_tin > Ti) {
-            w_tin = w_tin - Ti;
-            ++w_i;
-            if (w_i >= pr.S) {
-              s_done = 1;
-              break;
-            }
-            Ti = s_T[w_i];
-            continue;
-          }
-          s_seg[cnt] = w_i;
-          s_tin[cnt] = w_tin;
-          ++cnt;
-          w_tin += dt;
-          w_acc += dt;
-        }
-      }
-      s_cnt = cnt;
+  const int N = s_first[S];
+  if (!samples) return;
+  double* out = samples + (size_t)pr.p * capacity * kD;
+  const int n_out = N < capacity ? N : capacity;
+  for (int n = lane; n < n_out; n += 64) {
+    // last segment whose first sample index is <= n
+    int lo = 0, hi = S;  // s_first[lo] <= n < s_first[hi] = N
+    while (hi - lo > 1) {
+      const int mid = (lo + hi) >> 1;
+      if (s_first[mid] <= n) lo = mid;
+      else hi = mid;
     }
-    __syncthreads();
-    const int cnt = s_cnt;
-    if (lane < cnt) {
-      const int n = total + lane;
-      if (out && n < capacity) {
-        const double* c = coeffs + (size_t)(pr.s0 + s_seg[lane]) * kD * kN;
-        const double t = s_tin[lane];
-        double v[kD];
+    double t = s_tin0[lo];
+    for (int r = n - s_first[lo]; r > 0; --r) t += dt;
+    const double* c = coeffs + (size_t)(pr.s0 + lo) * kD * kN;
+    double v[kD];
 #pragma unroll
-        for (int dd = 0; dd < kD; ++dd) {
-          double accv = c[dd * kN + kN - 1];
+    for (int dd = 0; dd < kD; ++dd) {
+      double accv = c[dd * kN + kN - 1];
 #pragma unroll
-          for (int k = kN - 2; k >= 0; --k) accv = accv * t + c[dd * kN + k];
-          v[dd] = accv;
-        }
-        // heading after the quaternion round trip (eth_mav_msgs/common.h:130-140)
-        const double hw = cos(v[3] * 0.5), hz = sin(v[3] * 0.5);
-        v[3] = atan2(2.0 * (hw * hz), 1.0 - 2.0 * (hz * hz));
-#pragma unroll
-        for (int dd = 0; dd < kD; ++dd) out[(size_t)n * kD + dd] = v[dd];
-      }
+      for (int k = kN - 2; k >= 0; --k) accv = accv * t + c[dd * kN + k];
+      v[dd] = accv;
     }
-    total += cnt;
-    const int done = s_done;
-    __syncthreads();
-    if (done) break;
+    v[3] = wrap_heading(v[3]);
+#pragma unroll
+    for (int dd = 0; dd < kD; ++dd) out[(size_t)n * kD + dd] = v[dd];
   }
-  if (lane == 0 && n_samples) n_samples[pr.p] = total;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -318,6 +323,8 @@ hipError_t launch_solve_linear(const BatchView& b, int d, bool fused, const uint
                                const double* seg_times, const double* H, const double* Ainv, double* ws,
                                double* coeffs, int32_t* status, double* cost, hipStream_t stream) {
   if (b.n_paths == 0) return hipSuccess;
+  if (tile_kernel_applies(b))
+    return launch_solve_tile(b, d, fused, mask, vals, seg_times, H, Ainv, coeffs, status, cost, stream);
   if (use_split_dims(b.n_paths)) {
     dim3 grid(cdiv((long long)b.n_paths * 4, 64));
     if (fused)
@@ -349,8 +356,9 @@ hipError_t launch_estimate_times(const BatchView& b, const double* wp, const dou
 hipError_t launch_sample(const BatchView& b, const double* coeffs, const double* seg_times, double dt, int capacity,
                          int32_t* n_samples, double* samples, hipStream_t stream) {
   if (b.n_paths == 0) return hipSuccess;
-  hipLaunchKernelGGL(sample_kernel, dim3(b.n_paths), dim3(64), sizeof(double) * (size_t)b.max_segments, stream, b,
-                     coeffs, seg_times, dt, capacity, n_samples, samples);
+  const size_t lds = sizeof(double) * (size_t)(3 * b.max_segments + 2);
+  hipLaunchKernelGGL(sample_kernel, dim3(b.n_paths), dim3(64), lds, stream, b, coeffs, seg_times, dt, capacity,
+                     n_samples, samples);
   return hipGetLastError();
 }
 

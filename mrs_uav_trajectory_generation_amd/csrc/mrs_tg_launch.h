@@ -28,5 +28,10 @@ hipError_t launch_estimate_times(const BatchView& b, const double* wp, const dou
 hipError_t launch_sample(const BatchView& b, const double* coeffs, const double* seg_times, double dt, int capacity,
                          int32_t* n_samples, double* samples, hipStream_t stream);
 size_t linear_workspace_doubles(const BatchView& b);
+// phase-split tile kernel (mrs_tg_tile.hip): small and medium batches whose per-path state fits in LDS
+bool tile_kernel_applies(const BatchView& b);
+hipError_t launch_solve_tile(const BatchView& b, int d, bool fused, const uint8_t* mask, const double* vals,
+                             const double* seg_times, const double* H, const double* Ainv, double* coeffs,
+                             int32_t* status, double* cost, hipStream_t stream);
 
 }  // namespace mrs_tg

@@ -1,0 +1,343 @@
+// mrs_tg_tile.hip -- linear QP solve, phase-split over a tile of paths (the latency-optimised K2).
+//
+// The per-path solve has two kinds of work:
+//   * work that is independent per (segment, dimension): u = H [f_i; f_{i+1}] (the right-hand-side and
+//     f^T H f contributions), masking of the 4x4 blocks, and at the end c = A^-1 d;
+//   * an inherently serial chain over the vertices: block Cholesky / forward substitution / back
+//     substitution (PolynomialOptimization::solveLinear,
+//     /root/reference/include/eth_trajectory_generation/impl/polynomial_optimization_linear_impl.h:341-373).
+// One-lane-per-path kernels run both on the serial lane.  Here a workgroup owns a tile of TP paths, stages
+// everything in LDS and runs
+//   A0  one lane per vertex:               constraints -> f, free masks                     (parallel)
+//   A1  one lane per (segment, dimension): blocks (from HBM or from T) -> u, masked blocks  (parallel)
+//   B   four lanes per path (one per dimension): the vertex chain on LDS-resident 4x4 blocks (serial)
+//   C   one lane per (segment, dimension): c = A^-1 d -> global coefficients                (parallel)
+// so the serial lanes execute only the chain (~1/3 of the instructions of the one-lane kernel).
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+
+#include "mrs_tg_device.hpp"
+#include "mrs_tg_solve.hpp"
+
+namespace mrs_tg {
+
+// LDS record sizes (doubles)
+constexpr int kSegRec = 10 + 16 + 10 + 16 + 16 + 4;  // HssM, EM, HeeM, ustart[r][dim], uend[r][dim], qf[dim] = 72
+constexpr int kVtxRec = 42 + 20 + 2;                 // L[10] W[16] z[4][4] | d[5][4] | free bits, flags
+
+__host__ __device__ constexpr int tile_path_doubles(int S) { return S * kSegRec + (S + 1) * kVtxRec; }
+
+template <bool FUSED>
+__global__ __launch_bounds__(128) void solve_tile_kernel(BatchView b, int d, int TP, int Smax,
+                                                         const uint8_t* __restrict__ mask,
+                                                         const double* __restrict__ vals,
+                                                         const double* __restrict__ seg_times,
+                                                         const double* __restrict__ Hblk, const double* __restrict__ Ablk,
+                                                         double* __restrict__ coeffs, int32_t* __restrict__ status,
+                                                         double* __restrict__ cost) {
+  extern __shared__ double lds[];
+  __shared__ int s_S[16], s_s0[16], s_v0[16], s_p[16];
+  const int tid = threadIdx.x;
+  const int q0 = blockIdx.x * TP;
+  const int n_here = min(TP, b.n_paths - q0);
+  const int PS = tile_path_doubles(Smax);
+  const size_t P = (size_t)b.n_paths;
+
+  if (tid < n_here) {
+    const PathRef pr = path_at(b, q0 + tid);
+    s_S[tid] = pr.S;
+    s_s0[tid] = pr.s0;
+    s_v0[tid] = pr.v0;
+    s_p[tid] = pr.p;
+  }
+  __syncthreads();
+
+  auto seg_rec = [&](int t, int i) { return lds + (size_t)t * PS + (size_t)i * kSegRec; };
+  auto vtx_rec = [&](int t, int v) { return lds + (size_t)t * PS + (size_t)Smax * kSegRec + (size_t)v * kVtxRec; };
+
+  // ---- A0: vertex constraints -> d (constrained values, 0 where free), free bits
+  for (int item = tid; item < n_here * (Smax + 1); item += 128) {
+    const int t = item % n_here, v = item / n_here;
+    if (v > s_S[t]) continue;
+    double f[kHalf][kD];
+    bool pos_fixed;
+    const unsigned fb = load_vertex<kD>(mask, vals, s_v0[t] + v, 0, f, pos_fixed);
+    double* r = vtx_rec(t, v);
+#pragma unroll
+    for (int k = 0; k < kHalf; ++k)
+#pragma unroll
+      for (int dd = 0; dd < kD; ++dd) r[42 + k * kD + dd] = f[k][dd];
+    r[62] = (double)fb;
+    r[63] = pos_fixed ? 1.0 : 0.0;
+  }
+  __syncthreads();
+
+  // ---- A1: per (segment, dimension): u = H [f_i; f_{i+1}], masked 4x4 blocks
+  for (int item = tid; item < n_here * Smax * kD; item += 128) {
+    const int dim = item % kD;
+    const int t = (item / kD) % n_here;
+    const int i = item / (kD * n_here);
+    if (i >= s_S[t]) continue;
+    double Hs[kSym10];
+    if (FUSED) {
+      hessian_from_time(seg_times[s_s0[t] + i], d, Hs);
+    } else {
+      const BlockSource src{Hblk, Ablk, P, q0 + t};
+      load_H_blocks(src, i, Hs);
+    }
+    const double* vs = vtx_rec(t, i);
+    const double* ve = vtx_rec(t, i + 1);
+    const unsigned free_s = (unsigned)vs[62], free_e = (unsigned)ve[62];
+    double f[kN];
+#pragma unroll
+    for (int k = 0; k < kHalf; ++k) {
+      f[k] = vs[42 + k * kD + dim];
+      f[kHalf + k] = ve[42 + k * kD + dim];
+    }
+    double* rec = seg_rec(t, i);
+    double qf = 0.0;
+#pragma unroll
+    for (int a = 0; a < kN; ++a) {
+      double u = 0.0;
+#pragma unroll
+      for (int c = 0; c < kN; ++c) u += Hs[sym10(a, c)] * f[c];
+      qf += f[a] * u;
+      if (a >= kSlot0 && a < kHalf) rec[36 + (a - kSlot0) * kD + dim] = ((free_s >> (a - kSlot0)) & 1u) ? u : 0.0;
+      if (a >= kHalf + kSlot0) rec[52 + (a - kHalf - kSlot0) * kD + dim] = ((free_e >> (a - kHalf - kSlot0)) & 1u) ? u : 0.0;
+    }
+    rec[68 + dim] = qf;
+    if (dim == 0) {
+#pragma unroll
+      for (int r = 0; r < kNB; ++r) {
+        const bool sr = (free_s >> r) & 1u, er = (free_e >> r) & 1u;
+#pragma unroll
+        for (int c = 0; c <= r; ++c) {
+          const bool sc = (free_s >> c) & 1u, ec = (free_e >> c) & 1u;
+          rec[tri(r, c)] = (sr && sc) ? Hs[sym10(kSlot0 + r, kSlot0 + c)] : 0.0;
+          rec[26 + tri(r, c)] = (er && ec) ? Hs[sym10(kHalf + kSlot0 + r, kHalf + kSlot0 + c)] : 0.0;
+        }
+#pragma unroll
+        for (int c = 0; c < kNB; ++c) {
+          const bool ec = (free_e >> c) & 1u;
+          rec[10 + r * kNB + c] = (sr && ec) ? Hs[sym10(kSlot0 + r, kHalf + kSlot0 + c)] : 0.0;
+        }
+      }
+    }
+  }
+  __syncthreads();
+
+  // ---- B: the vertex chain, four lanes per path (lane = dimension)
+  if (tid < n_here * kD) {
+    const int t = tid / kD, dim = tid % kD;
+    const int S = s_S[t];
+    double Wp[kNB][kNB], zp[kNB];
+    double L[10], Linv[kNB], z[kNB], W[kNB][kNB];
+    double red = 0.0, qf = 0.0;
+    bool pos_ok = true;
+#pragma unroll
+    for (int r = 0; r < kNB; ++r) {
+      zp[r] = 0.0;
+#pragma unroll
+      for (int c = 0; c < kNB; ++c) Wp[r][c] = 0.0;
+    }
+    for (int v = 0; v <= S; ++v) {
+      const double* prev = (v > 0) ? seg_rec(t, v - 1) : nullptr;
+      const double* cur = (v < S) ? seg_rec(t, v) : nullptr;
+      double* vr = vtx_rec(t, v);
+      const unsigned fb = (unsigned)vr[62];
+      pos_ok = pos_ok && (vr[63] != 0.0);
+      double Sm[10], y[kNB];
+#pragma unroll
+      for (int r = 0; r < kNB; ++r) {
+        const bool fr = (fb >> r) & 1u;
+#pragma unroll
+        for (int c = 0; c <= r; ++c) {
+          double s = 0.0;
+          if (v > 0) {
+            s = prev[26 + tri(r, c)];
+#pragma unroll
+            for (int m = 0; m < kNB; ++m) s -= Wp[m][r] * Wp[m][c];
+          }
+          if (v < S) s += cur[tri(r, c)];
+          Sm[tri(r, c)] = (r == c && !fr) ? 1.0 : s;
+        }
+        double s = 0.0;
+        if (v > 0) {
+          s = -prev[52 + r * kD + dim];
+#pragma unroll
+          for (int m = 0; m < kNB; ++m) s -= Wp[m][r] * zp[m];
+        }
+        if (v < S) s -= cur[36 + r * kD + dim];
+        y[r] = s;
+      }
+      if (v < S) qf += cur[68 + dim];
+      // Cholesky (masked rows are already identity rows / zero right-hand sides)
+#pragma unroll
+      for (int c = 0; c < kNB; ++c) {
+        double dsum = Sm[tri(c, c)];
+#pragma unroll
+        for (int m = 0; m < c; ++m) dsum -= L[tri(c, m)] * L[tri(c, m)];
+        const double inv = rsqrt_refined(dsum);
+        L[tri(c, c)] = dsum * inv;
+        Linv[c] = inv;
+#pragma unroll
+        for (int r = c + 1; r < kNB; ++r) {
+          double s = Sm[tri(r, c)];
+#pragma unroll
+          for (int m = 0; m < c; ++m) s -= L[tri(r, m)] * L[tri(c, m)];
+          L[tri(r, c)] = s * inv;
+        }
+      }
+#pragma unroll
+      for (int r = 0; r < kNB; ++r) {
+        double s = y[r];
+#pragma unroll
+        for (int m = 0; m < r; ++m) s -= L[tri(r, m)] * z[m];
+        z[r] = s * Linv[r];
+        red += z[r] * z[r];
+      }
+      if (v < S) {
+#pragma unroll
+        for (int c = 0; c < kNB; ++c)
+#pragma unroll
+          for (int r = 0; r < kNB; ++r) {
+            double s = cur[10 + r * kNB + c];
+#pragma unroll
+            for (int m = 0; m < r; ++m) s -= L[tri(r, m)] * W[m][c];
+            W[r][c] = s * Linv[r];
+          }
+      }
+      // keep the factors for the backward sweep (L, Linv stored as L with reciprocal diagonal, W by lane 0)
+      if (dim == 0) {
+#pragma unroll
+        for (int e = 0; e < 10; ++e) vr[e] = L[e];
+#pragma unroll
+        for (int r = 0; r < kNB; ++r) vr[tri(r, r)] = Linv[r];  // the backward sweep only divides by the diagonal
+#pragma unroll
+        for (int r = 0; r < kNB; ++r)
+#pragma unroll
+          for (int c = 0; c < kNB; ++c) vr[10 + r * kNB + c] = W[r][c];
+      }
+#pragma unroll
+      for (int r = 0; r < kNB; ++r) vr[26 + r * kD + dim] = z[r];
+#pragma unroll
+      for (int r = 0; r < kNB; ++r) {
+        zp[r] = z[r];
+#pragma unroll
+        for (int c = 0; c < kNB; ++c) Wp[r][c] = W[r][c];
+      }
+    }
+    double part = 0.5 * (qf - red);
+    part += __shfl_xor(part, 1, 64);
+    part += __shfl_xor(part, 2, 64);
+    if (dim == 0) {
+      if (cost) cost[s_p[t]] = part;
+      if (status) status[s_p[t]] = pos_ok ? 1 : -2;
+    }
+    // backward: x_v = L^-T (z - W x_{v+1}); the four lanes of a path run in lockstep, so the factors
+    // written by lane 0 above are visible here (same wavefront, program order)
+    double xn[kNB] = {0.0, 0.0, 0.0, 0.0};
+    for (int v = S; v >= 0; --v) {
+      double* vr = vtx_rec(t, v);
+      double tv[kNB], x[kNB];
+#pragma unroll
+      for (int r = 0; r < kNB; ++r) {
+        double s = vr[26 + r * kD + dim];
+        if (v < S) {
+#pragma unroll
+          for (int c = 0; c < kNB; ++c) s -= vr[10 + r * kNB + c] * xn[c];
+        }
+        tv[r] = s;
+      }
+#pragma unroll
+      for (int r = kNB - 1; r >= 0; --r) {
+        double s = tv[r];
+#pragma unroll
+        for (int m = r + 1; m < kNB; ++m) s -= vr[tri(m, r)] * x[m];
+        x[r] = s * vr[tri(r, r)];
+      }
+#pragma unroll
+      for (int r = 0; r < kNB; ++r) {
+        vr[42 + (kSlot0 + r) * kD + dim] += x[r];  // d = f + x (x is 0 on constrained slots)
+        xn[r] = x[r];
+      }
+    }
+  }
+  __syncthreads();
+
+  // ---- C: coefficients c = A^-1 [d_i; d_{i+1}] per (segment, dimension)
+  for (int item = tid; item < n_here * Smax * kD; item += 128) {
+    const int dim = item % kD;
+    const int t = (item / kD) % n_here;
+    const int i = item / (kD * n_here);
+    if (i >= s_S[t]) continue;
+    const double* vs = vtx_rec(t, i);
+    const double* ve = vtx_rec(t, i + 1);
+    double dv[kN], c[kN];
+#pragma unroll
+    for (int k = 0; k < kHalf; ++k) {
+      dv[k] = vs[42 + k * kD + dim];
+      dv[kHalf + k] = ve[42 + k * kD + dim];
+    }
+    if (FUSED) {
+      coefficients_from_time(seg_times[s_s0[t] + i], dv, c);
+    } else {
+      const BlockSource src{Hblk, Ablk, P, q0 + t};
+      AinvRows ar;
+      load_A_blocks(src, i, ar);
+#pragma unroll
+      for (int k = 0; k < kHalf; ++k) c[k] = ar.diag[k] * dv[k];
+#pragma unroll
+      for (int k = 0; k < kHalf; ++k) {
+        double acc = 0.0;
+#pragma unroll
+        for (int s = 0; s < kN; ++s) acc += ar.low[k][s] * dv[s];
+        c[kHalf + k] = acc;
+      }
+    }
+    double* out = coeffs + ((size_t)(s_s0[t] + i) * kD + dim) * kN;
+#pragma unroll
+    for (int k = 0; k < kN; ++k) out[k] = c[k];
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// launcher: returns false when the tile kernel does not apply (caller falls back to the per-lane kernel)
+
+static constexpr size_t kTileLdsBudget = 144 * 1024;
+
+bool tile_kernel_applies(const BatchView& b) {
+  // measured on MI355X (10 segments): 47 vs 60 us at 1024 paths, but 154 vs 86 us at 8192 paths, where the
+  // per-lane kernel already fills the machine and the tile kernel's serial phase leaves most lanes idle
+  if (b.n_paths == 0 || b.n_paths > 2048) return false;
+  return (size_t)tile_path_doubles(b.max_segments) * sizeof(double) <= kTileLdsBudget;
+}
+
+hipError_t launch_solve_tile(const BatchView& b, int d, bool fused, const uint8_t* mask, const double* vals,
+                             const double* seg_times, const double* H, const double* Ainv, double* coeffs,
+                             int32_t* status, double* cost, hipStream_t stream) {
+  const size_t per_path = (size_t)tile_path_doubles(b.max_segments) * sizeof(double);
+  int TP = (int)(kTileLdsBudget / per_path);
+  if (TP > 16) TP = 16;
+  // more, smaller tiles so that every CU gets work (256 CUs) and several tiles share a CU
+  while (TP > 4 && (b.n_paths + TP - 1) / TP < 512) TP >>= 1;
+  const size_t lds_bytes = per_path * (size_t)TP;
+  const unsigned grid = (unsigned)((b.n_paths + TP - 1) / TP);
+  if (fused) {
+    hipError_t e = hipFuncSetAttribute((const void*)solve_tile_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       (int)kTileLdsBudget);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(solve_tile_kernel<true>, dim3(grid), dim3(128), lds_bytes, stream, b, d, TP, b.max_segments, mask,
+                       vals, seg_times, H, Ainv, coeffs, status, cost);
+  } else {
+    hipError_t e = hipFuncSetAttribute((const void*)solve_tile_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       (int)kTileLdsBudget);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(solve_tile_kernel<false>, dim3(grid), dim3(128), lds_bytes, stream, b, d, TP, b.max_segments, mask,
+                       vals, seg_times, H, Ainv, coeffs, status, cost);
+  }
+  return hipGetLastError();
+}
+
+}  // namespace mrs_tg
