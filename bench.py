@@ -149,12 +149,28 @@ def main():
     for _ in range(10):
         launch_assemble()
     torch.cuda.synchronize()
-    mean_ms, med_ms = kernel_event_ms(launch_assemble, 200, torch)
+    # (a) two events around a run of back-to-back launches: mean launch duration without per-launch event cost
+    reps = 200
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        launch_assemble()
+    e1.record()
+    torch.cuda.synchronize()
+    mean_ms = e0.elapsed_time(e1) / reps
+    # (b) an event pair around every single launch (adds the event packets' own time to each sample)
+    per_launch_mean_ms, per_launch_med_ms = kernel_event_ms(launch_assemble, 200, torch)
     alg_bytes = ASSEMBLY_BYTES_PER_SEGMENT * nS
     achieved = alg_bytes / (mean_ms * 1e-3) / 1e9
-    roofline = dict(kernel="assemble_blocks_kernel", bound="hbm", achieved=achieved, peak=HBM_PEAK_GBS, unit="GB/s",
-                    frac=achieved / HBM_PEAK_GBS, traffic=None, bytes_per_launch=alg_bytes,
-                    avg_launch_us=mean_ms * 1e3, median_launch_us=med_ms * 1e3)
+    # HBM traffic from PMC counters (separate rocprofv3 passes, profiles/round1_pmc_assemble_hbm_traffic.csv):
+    # WRITE_SIZE is exact for 16-B stores; FETCH_SIZE is doubled as MI355X_MICROARCH.md prescribes for gfx950.
+    # Measured for the 1024 x 10 launch: 16000 KiB written + 2 x 200 KiB fetched.
+    traffic = (16000 + 2 * 200) * 1024 if (P == 1024 and args.segments == 10) else None
+    roofline = dict(kernel="assemble_blocks_uniform_kernel", bound="hbm", achieved=achieved, peak=HBM_PEAK_GBS, unit="GB/s",
+                    frac=achieved / HBM_PEAK_GBS, traffic=traffic, bytes_per_launch=alg_bytes,
+                    avg_launch_us=mean_ms * 1e3, per_launch_event_us=per_launch_mean_ms * 1e3,
+                    per_launch_event_median_us=per_launch_med_ms * 1e3,
+                    note="16 MB per launch: launch-ramp bound, see extras.roofline_large for the same kernel at 1 GB")
 
     extras = {}
     if not args.no_extras and rank == 0:

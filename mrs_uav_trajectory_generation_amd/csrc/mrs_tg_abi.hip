@@ -403,7 +403,7 @@ int mrs_tg_plan_solve(mrs_tg_plan* plan, const double* wp, const uint8_t* mask, 
     }
     ProfileScope ps(ctx, 1);
     HIP_TRY(ctx, mrs_tg::launch_solve_linear(b, d, fused, mask, vals, seg_times, plan->d_H, plan->d_Ainv, plan->d_ws,
-                                             coeffs, status, cost, ctx->stream));
+                                             coeffs, status, cost, nullptr, ctx->stream));
   }
   if (opt->sampling_dt > 0)
     HIP_TRY(ctx, mrs_tg::launch_sample(b, coeffs, seg_times, opt->sampling_dt, opt->sample_capacity, n_samples, samples,

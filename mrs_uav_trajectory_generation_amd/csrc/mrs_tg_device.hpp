@@ -322,6 +322,17 @@ __device__ __forceinline__ unsigned load_vertex(const uint8_t* __restrict__ mask
   return free_bits;
 }
 
+// Per-path status written by the solve kernels: -2 when a vertex leaves its position free (unsupported);
+// otherwise 1 for the plain linear solve, or the outer loop's stopping reason when one is handed in
+// (a start rejected by the optimiser, recorded there as -2, surfaces as FAILURE -1 like the reference's
+// caught NLopt exception, nonlinear_impl.h:193-197).
+__device__ __forceinline__ int merge_status(bool pos_ok, const int32_t* __restrict__ status_in, int p) {
+  if (!pos_ok) return -2;
+  if (!status_in) return 1;
+  const int s = status_in[p];
+  return s == -2 ? -1 : s;
+}
+
 constexpr int kWsPerVertex = 10 + kNB * kD + kNB * kNB;  // L, z, W = 42 doubles per vertex
 
 }  // namespace mrs_tg

@@ -114,7 +114,8 @@ __global__ __launch_bounds__(64) void solve_linear_kernel(BatchView b, int d, co
                                                           const double* __restrict__ seg_times,
                                                           const double* __restrict__ Hblk, const double* __restrict__ Ablk,
                                                           double* __restrict__ ws, double* __restrict__ coeffs,
-                                                          int32_t* __restrict__ status, double* __restrict__ cost) {
+                                                          int32_t* __restrict__ status, double* __restrict__ cost,
+                                                          const int32_t* __restrict__ status_in) {
   constexpr int LPP = kD / ND;  // lanes per path
   const int tid = blockIdx.x * 64 + threadIdx.x;
   const int lanes_total = b.n_paths * LPP;
@@ -132,7 +133,7 @@ __global__ __launch_bounds__(64) void solve_linear_kernel(BatchView b, int d, co
   }
   if (dim0 == 0) {
     if (cost) cost[pr.p] = c;
-    if (status) status[pr.p] = pos_ok ? 1 : -2;
+    if (status) status[pr.p] = merge_status(pos_ok, status_in, pr.p);
   }
 }
 
@@ -321,26 +322,27 @@ static inline bool use_split_dims(int n_paths) { return n_paths <= 32768; }
 
 hipError_t launch_solve_linear(const BatchView& b, int d, bool fused, const uint8_t* mask, const double* vals,
                                const double* seg_times, const double* H, const double* Ainv, double* ws,
-                               double* coeffs, int32_t* status, double* cost, hipStream_t stream) {
+                               double* coeffs, int32_t* status, double* cost, const int32_t* status_in,
+                               hipStream_t stream) {
   if (b.n_paths == 0) return hipSuccess;
   if (tile_kernel_applies(b))
-    return launch_solve_tile(b, d, fused, mask, vals, seg_times, H, Ainv, coeffs, status, cost, stream);
+    return launch_solve_tile(b, d, fused, mask, vals, seg_times, H, Ainv, coeffs, status, cost, status_in, stream);
   if (use_split_dims(b.n_paths)) {
     dim3 grid(cdiv((long long)b.n_paths * 4, 64));
     if (fused)
       hipLaunchKernelGGL((solve_linear_kernel<1, true>), grid, dim3(64), 0, stream, b, d, mask, vals, seg_times, H, Ainv,
-                         ws, coeffs, status, cost);
+                         ws, coeffs, status, cost, status_in);
     else
       hipLaunchKernelGGL((solve_linear_kernel<1, false>), grid, dim3(64), 0, stream, b, d, mask, vals, seg_times, H,
-                         Ainv, ws, coeffs, status, cost);
+                         Ainv, ws, coeffs, status, cost, status_in);
   } else {
     dim3 grid(cdiv(b.n_paths, 64));
     if (fused)
       hipLaunchKernelGGL((solve_linear_kernel<4, true>), grid, dim3(64), 0, stream, b, d, mask, vals, seg_times, H, Ainv,
-                         ws, coeffs, status, cost);
+                         ws, coeffs, status, cost, status_in);
     else
       hipLaunchKernelGGL((solve_linear_kernel<4, false>), grid, dim3(64), 0, stream, b, d, mask, vals, seg_times, H,
-                         Ainv, ws, coeffs, status, cost);
+                         Ainv, ws, coeffs, status, cost, status_in);
   }
   return hipGetLastError();
 }

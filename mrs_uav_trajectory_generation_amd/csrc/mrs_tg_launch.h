@@ -22,7 +22,8 @@ hipError_t launch_assemble(const BatchView& b, int d, const double* seg_times, d
                            hipStream_t stream);
 hipError_t launch_solve_linear(const BatchView& b, int d, bool fused, const uint8_t* mask, const double* vals,
                                const double* seg_times, const double* H, const double* Ainv, double* ws,
-                               double* coeffs, int32_t* status, double* cost, hipStream_t stream);
+                               double* coeffs, int32_t* status, double* cost, const int32_t* status_in,
+                               hipStream_t stream);
 hipError_t launch_estimate_times(const BatchView& b, const double* wp, const double* limits, double* seg_times,
                                  hipStream_t stream);
 hipError_t launch_sample(const BatchView& b, const double* coeffs, const double* seg_times, double dt, int capacity,
@@ -32,6 +33,6 @@ size_t linear_workspace_doubles(const BatchView& b);
 bool tile_kernel_applies(const BatchView& b);
 hipError_t launch_solve_tile(const BatchView& b, int d, bool fused, const uint8_t* mask, const double* vals,
                              const double* seg_times, const double* H, const double* Ainv, double* coeffs,
-                             int32_t* status, double* cost, hipStream_t stream);
+                             int32_t* status, double* cost, const int32_t* status_in, hipStream_t stream);
 
 }  // namespace mrs_tg

@@ -27,8 +27,11 @@ struct NonlinearBin {
 
 struct NonlinearPlan {
   std::vector<NonlinearBin> bins;
-  double* d_ws = nullptr;     // back-substitution workspace, (max_S + 1) * 42 * n_paths doubles
+  int dim_split = 1;               // lanes per time vector in the outer loop: 1 (compact) or 4 (one per dimension)
+  double* d_ws = nullptr;          // factor store of the per-lane linear solve
   size_t ws_doubles = 0;
+  int32_t* d_opt_status = nullptr; // stopping reason of the outer loop per path
+  double* d_maxima = nullptr;      // [n_segments][9] per-segment maxima
 };
 
 int nonlinear_plan_build(NonlinearPlan& nl, const std::vector<int32_t>& seg_offsets, const std::vector<int32_t>& order);

@@ -8,16 +8,24 @@
 //   src/eth_trajectory_generation/trajectory.cpp:598-692  scaleSegmentTimesToMeetConstraints
 //   src/eth_trajectory_generation/segment.cpp:113-212     magnitude extremum candidates
 //
-// Mapping onto the wavefront: one GROUP of G lanes per path, G = min(64, pow2ceil(S+1)), 64/G paths per
-// wavefront, one wavefront per workgroup.  An objective evaluation needs the cost at S+1 time vectors
-// (unperturbed + one per segment, nonlinear_impl.h:282-323); lane k of the group runs the whole
-// block-Cholesky sweep for vector k in registers, so the S+1 solves of an evaluation run side by side
-// and the gradient is assembled with one cross-lane broadcast.  Only the cost is needed there, so the
-// sweep is forward-only (cost = (f^T R_ff f - |L^-1 b|^2)/2) and touches no memory besides the vertex
-// constraints.  The optimiser's vectors live in LDS; its scalar control flow is replicated in every
-// lane of the group (all lanes see identical reduced values).  NLopt's LD_LBFGS is not reproducible
-// (un-vendored, Luksan PLIS); the optimiser is the project's own projected L-BFGS, specified in
-// DESIGN.md and restated on the CPU in oracle/mto_nonlinear.c.
+// Pipeline per bin of paths (host-orchestrated, one stream):
+//   optimize_kernel      the outer loop; every tick = one objective evaluation = S+1 forward cost sweeps
+//   solve (fused)        coefficients at the last evaluated times             (mrs_tg_kernels / mrs_tg_tile)
+//   segment_maxima9      max |p^(k)| per segment, one (k, group) per blockIdx.y so wavefronts stay uniform
+//   apply_scaling        T <- T * max(1, v, sqrt a, cbrt j)
+//   solve (fused)        final coefficients, cost, merged status
+//
+// Mapping of the outer loop onto the wavefront: one GROUP of G lanes per path, one wavefront per workgroup.
+// An objective evaluation needs the cost at S+1 time vectors (unperturbed + one per segment,
+// nonlinear_impl.h:282-323).  Compact mapping (DS = 1, big batches): lane k runs the whole forward sweep of
+// vector k for all four dimensions, G = min(64, pow2ceil(S+1)).  Split mapping (DS = 4, small batches):
+// four lanes per vector, one dimension each (the 4x4 factorisation is repeated, the dependency chain is
+// ~3x shorter), G = min(64, pow2ceil(4(S+1))).  Only the cost is needed, so the sweeps are forward-only
+// (cost = (f^T R_ff f - |L^-1 b|^2)/2) and touch no memory besides the vertex constraints.  The optimiser's
+// vectors live in LDS; its scalar control flow is replicated in every lane of the group (all lanes see
+// identical reduced values).  NLopt's LD_LBFGS is not reproducible (un-vendored, Luksan PLIS); the optimiser
+// is the project's own projected L-BFGS, specified in DESIGN.md and restated on the CPU in
+// oracle/mto_nonlinear.c.
 #include <hip/hip_runtime.h>
 
 #include <cfloat>
@@ -45,24 +53,25 @@ __device__ __forceinline__ double perturbed_time(const double* xs, int i, int k,
   return T;
 }
 
-__device__ double forward_cost(const uint8_t* __restrict__ mask, const double* __restrict__ vals, int v0, int S, int d,
-                               const double* xs, int k) {
-  Elim<kD> st;
+template <int ND>
+__device__ __forceinline__ double forward_cost(const uint8_t* __restrict__ mask, const double* __restrict__ vals, int v0,
+                                               int S, int d, const double* xs, int k, int dim0) {
+  Elim<ND> st;
   st.init();
-  double fs[kHalf][kD], fe[kHalf][kD];
-  double L[10], z[kNB][kD], W[kNB][kNB];
+  double fs[kHalf][ND], fe[kHalf][ND];
+  double L[10], z[kNB][ND], W[kNB][kNB];
   bool pf;
-  unsigned free_s = load_vertex<kD>(mask, vals, v0, 0, fs, pf);
+  unsigned free_s = load_vertex<ND>(mask, vals, v0, dim0, fs, pf);
   const double corr = kGradStep / ((double)S - 1.0);
   for (int i = 0; i < S; ++i) {
-    const unsigned free_e = load_vertex<kD>(mask, vals, v0 + i + 1, 0, fe, pf);
+    const unsigned free_e = load_vertex<ND>(mask, vals, v0 + i + 1, dim0, fe, pf);
     double Hs[kSym10];
     hessian_from_time(perturbed_time(xs, i, k, corr), d, Hs);
     st.absorb_segment(Hs, fs, fe, free_s, free_e, L, z, W);
 #pragma unroll
     for (int s = 0; s < kHalf; ++s)
 #pragma unroll
-      for (int dd = 0; dd < kD; ++dd) fs[s][dd] = fe[s][dd];
+      for (int dd = 0; dd < ND; ++dd) fs[s][dd] = fe[s][dd];
     free_s = free_e;
   }
   st.factor_vertex(free_s, L, z);
@@ -191,33 +200,39 @@ __device__ __forceinline__ double max_mag2(const double (&cb)[NDIM][kN]) {
   return best;
 }
 
-// out[(k-1)*3 + group]; c = [4][10] coefficients of the segment (ascending powers of t)
-__device__ void segment_maxima(const double* __restrict__ c, double T, double (&out)[9]) {
-  double cb_h[2][kN], cb_v[1][kN], cb_y[1][kN];
+// which = 3*(k-1) + group: maximum of |p^(k)| over [0, T] for one (k, group) of one segment
+__device__ __forceinline__ double segment_maximum(const double* __restrict__ c, double T, int which) {
+  const int k = which / 3 + 1, grp = which % 3;
   double tp = 1.0;
-#pragma unroll
-  for (int j = 0; j < kN; ++j) {
-    cb_h[0][j] = c[0 * kN + j] * tp;
-    cb_h[1][j] = c[1 * kN + j] * tp;
-    cb_v[0][j] = c[2 * kN + j] * tp;
-    cb_y[0][j] = c[3 * kN + j] * tp;
-    tp *= T;
-  }
   const double ti = 1.0 / T;
-  const double ti2 = ti * ti, ti3 = ti2 * ti;
-  out[0] = sqrt(max_mag2<1, 2>(cb_h)) * ti;
-  out[1] = sqrt(max_mag2<1, 1>(cb_v)) * ti;
-  out[2] = sqrt(max_mag2<1, 1>(cb_y)) * ti;
-  out[3] = sqrt(max_mag2<2, 2>(cb_h)) * ti2;
-  out[4] = sqrt(max_mag2<2, 1>(cb_v)) * ti2;
-  out[5] = sqrt(max_mag2<2, 1>(cb_y)) * ti2;
-  out[6] = sqrt(max_mag2<3, 2>(cb_h)) * ti3;
-  out[7] = sqrt(max_mag2<3, 1>(cb_v)) * ti3;
-  out[8] = sqrt(max_mag2<3, 1>(cb_y)) * ti3;
+  double scale = ti;
+  if (k == 2) scale = ti * ti;
+  else if (k == 3) scale = ti * ti * ti;
+  double m2;
+  if (grp == 0) {
+    double cb[2][kN];
+#pragma unroll
+    for (int j = 0; j < kN; ++j) {
+      cb[0][j] = c[0 * kN + j] * tp;
+      cb[1][j] = c[1 * kN + j] * tp;
+      tp *= T;
+    }
+    m2 = (k == 1) ? max_mag2<1, 2>(cb) : (k == 2) ? max_mag2<2, 2>(cb) : max_mag2<3, 2>(cb);
+  } else {
+    double cb[1][kN];
+    const int dim = (grp == 1) ? 2 : 3;
+#pragma unroll
+    for (int j = 0; j < kN; ++j) {
+      cb[0][j] = c[dim * kN + j] * tp;
+      tp *= T;
+    }
+    m2 = (k == 1) ? max_mag2<1, 1>(cb) : (k == 2) ? max_mag2<2, 1>(cb) : max_mag2<3, 1>(cb);
+  }
+  return sqrt(m2) * scale;
 }
 
 // violation scaling of one segment: max(1, v, sqrt(a), cbrt(j))  (trajectory.cpp:625-642)
-__device__ __forceinline__ double violation_scaling(const double (&mx)[9], const double* __restrict__ lim) {
+__device__ __forceinline__ double violation_scaling(const double* __restrict__ mx, const double* __restrict__ lim) {
   double viol[3];
 #pragma unroll
   for (int k = 0; k < 3; ++k) {
@@ -260,32 +275,39 @@ __host__ __device__ constexpr int group_lds_doubles(int Sb) { return (5 + 2 * kL
 
 // objective evaluation at `pt`: cost returned to every lane of the group, gradient to `grad` (LDS).
 // (objectiveFunctionTimeMellingerOuterLoop + getCostAndGradientMellinger)
+// DS lanes share one time vector (DS = 1: one lane, four dimensions; DS = 4: four lanes, one dimension each).
+template <int DS>
 __device__ __forceinline__ double evaluate_objective(const uint8_t* __restrict__ mask, const double* __restrict__ vals,
                                                      int v0, int S, int d, const double* pt, double* grad, int g, int G,
                                                      bool active) {
+  constexpr int ND = kD / DS;
+  const int kl = G / DS;  // time vectors handled per round
+  const int kk = g / DS, dim0 = (g % DS) * ND;
   double J0 = 0.0;
-  // lane k handles time vectors k, k+G, ... (k = 0 is the unperturbed one)
-  const int rounds = (S + 1 + G - 1) / G;
+  const int rounds = (S + 1 + kl - 1) / kl;
   for (int r = 0; r < rounds; ++r) {
-    const int k = g + r * G;
+    const int k = kk + r * kl;
     double Jk = 0.0;
-    if (active && k <= S && (k == 0 || S > 1)) Jk = forward_cost(mask, vals, v0, S, d, pt, k);
-    if (r == 0) J0 = __shfl(Jk, (threadIdx.x & ~(G - 1)), 64);  // lane 0 of the group
-    if (active && k >= 1 && k <= S) grad[k - 1] = (S > 1) ? (Jk - J0) / kGradStep : 0.0;
+    if (active && k <= S && (k == 0 || S > 1)) Jk = forward_cost<ND>(mask, vals, v0, S, d, pt, k, dim0);
+    if (DS == 4) {
+      Jk += __shfl_xor(Jk, 1, 64);
+      Jk += __shfl_xor(Jk, 2, 64);
+    }
+    if (r == 0) J0 = __shfl(Jk, (threadIdx.x & ~(G - 1)), 64);  // lane 0 of the group holds k = 0
+    if (active && dim0 == 0 && k >= 1 && k <= S) grad[k - 1] = (S > 1) ? (Jk - J0) / kGradStep : 0.0;
   }
   return J0;
 }
 
 // ---------------------------------------------------------------------------------------------
-// the fused outer-loop kernel: optimiser ticks (one objective evaluation each), then
-// scaleSegmentTimesWithViolation: solve at the last evaluated times, per-segment scaling, final solve.
+// the outer-loop kernel: optimiser ticks (one objective evaluation each).  On exit seg_times holds the
+// last evaluated point and opt_status the stopping reason (-2: start rejected, as NLopt would).
 
-__global__ __launch_bounds__(64) void nonlinear_kernel(BatchView b, NonlinearParams prm, int G, int q_begin, int q_count,
-                                                       int Sb, const uint8_t* __restrict__ mask,
-                                                       const double* __restrict__ vals, const double* __restrict__ limits,
-                                                       double* __restrict__ seg_times, double* __restrict__ coeffs,
-                                                       int32_t* __restrict__ status, double* __restrict__ cost_out,
-                                                       double* __restrict__ ws) {
+template <int DS>
+__global__ __launch_bounds__(64) void optimize_kernel(BatchView b, NonlinearParams prm, int G, int q_begin, int q_count,
+                                                      int Sb, const uint8_t* __restrict__ mask,
+                                                      const double* __restrict__ vals, double* __restrict__ seg_times,
+                                                      int32_t* __restrict__ opt_status) {
   extern __shared__ double lds[];
   const int lane = threadIdx.x;
   const int g = lane & (G - 1);
@@ -296,7 +318,6 @@ __global__ __launch_bounds__(64) void nonlinear_kernel(BatchView b, NonlinearPar
   const int q = q_begin + (active ? qi : 0);
   const PathRef pr = path_at(b, q);
   const int S = pr.S, d = prm.derivative;
-  const size_t P = (size_t)b.n_paths;
 
   double* base = lds + (size_t)grp * group_lds_doubles(Sb);
   double* x = base;
@@ -333,7 +354,7 @@ __global__ __launch_bounds__(64) void nonlinear_kernel(BatchView b, NonlinearPar
     if (!running) break;
 
     // (1) one objective evaluation at the trial point
-    const double fn = evaluate_objective(mask, vals, pr.v0, S, d, xn, gn, g, G, !done);
+    const double fn = evaluate_objective<DS>(mask, vals, pr.v0, S, d, xn, gn, g, G, !done);
     __syncthreads();
     bool new_dir = false;
     if (!done) {
@@ -489,46 +510,43 @@ __global__ __launch_bounds__(64) void nonlinear_kernel(BatchView b, NonlinearPar
     __syncthreads();
   }
 
-  // ---- scaleSegmentTimesWithViolation (nonlinear_impl.h:336-408) and the final solve.
-  // Lanes 0..3 of the group each solve one dimension (G >= 4 always).
-  bool pos_ok = true;
-  double cost = 0.0;
-  const bool scale = active && !bad;
-  double* my_coeffs = coeffs + (size_t)pr.s0 * kD * kN;
-  const BlockSource no_blocks{nullptr, nullptr, 0, 0};
-  const size_t ws_lanes = 4 * P;
-  for (int pass = 0; pass < 2; ++pass) {
-    double part = 0.0;
-    if (active && g < 4 && (pass == 1 || scale))
-      part = solve_path<1, true>(mask, vals, pr.v0, S, d, x, g, no_blocks, ws, ws_lanes, (unsigned)(q * 4 + g),
-                                 my_coeffs, pos_ok);
-    part += __shfl_xor(part, 1, 64);
-    part += __shfl_xor(part, 2, 64);
-    cost = part;  // valid in lanes 0..3 of the group
-    __threadfence_block();
-    __syncthreads();
-    if (pass == 0) {
-      if (scale) {
-        for (int i = g; i < S; i += G) {
-          double mx[9];
-          segment_maxima(my_coeffs + (size_t)i * kD * kN, x[i], mx);
-          x[i] = x[i] * violation_scaling(mx, limits + (size_t)pr.p * 9);
-        }
-      }
-      __syncthreads();
-    }
-  }
   if (active) {
     for (int i = g; i < S; i += G) seg_times[pr.s0 + i] = x[i];
-    if (g == 0) {
-      // a rejected start never reaches the optimiser: the reference reports FAILURE (-1) there
-      status[pr.p] = !pos_ok ? -2 : (bad ? -1 : ret);
-      if (cost_out) cost_out[pr.p] = cost;
-    }
+    if (g == 0) opt_status[pr.p] = bad ? -2 : ret;
   }
 }
 
+// per-segment maxima, one (k, group) per blockIdx.y: maxima[seg * 9 + 3 (k-1) + group]
+__global__ __launch_bounds__(64) void segment_maxima9_kernel(int n_segments, const double* __restrict__ coeffs,
+                                                             const double* __restrict__ seg_times,
+                                                             double* __restrict__ maxima) {
+  const int s = blockIdx.x * 64 + threadIdx.x;
+  if (s >= n_segments) return;
+  const int which = blockIdx.y;
+  maxima[(size_t)s * 9 + which] = segment_maximum(coeffs + (size_t)s * kD * kN, seg_times[s], which);
+}
+
+// scaleSegmentTimesToMeetConstraints' per-segment step (trajectory.cpp:610-658): T <- T * max(1, v, sqrt a, cbrt j).
+// Paths whose start the optimiser rejected are left alone (they never reach this step in the reference).
+__global__ __launch_bounds__(256) void apply_scaling_kernel(BatchView b, const double* __restrict__ maxima,
+                                                            const double* __restrict__ limits,
+                                                            const int32_t* __restrict__ opt_status,
+                                                            double* __restrict__ seg_times) {
+  const int idx = blockIdx.x * 256 + threadIdx.x;
+  if (idx >= b.n_segments) return;
+  int lo = 0, hi = b.n_paths;
+  while (hi - lo > 1) {
+    const int mid = (lo + hi) >> 1;
+    if (b.seg_offsets[mid] <= idx) lo = mid;
+    else hi = mid;
+  }
+  const int p = lo;
+  if (opt_status[p] == -2) return;
+  seg_times[idx] = seg_times[idx] * violation_scaling(maxima + (size_t)idx * 9, limits + (size_t)p * 9);
+}
+
 // J_d and the forward-difference gradient at the given times (parity-test building block)
+template <int DS>
 __global__ __launch_bounds__(64) void cost_gradient_kernel(BatchView b, int d, int G, int q_begin, int q_count, int Sb,
                                                            const uint8_t* __restrict__ mask,
                                                            const double* __restrict__ vals,
@@ -546,7 +564,7 @@ __global__ __launch_bounds__(64) void cost_gradient_kernel(BatchView b, int d, i
   if (active)
     for (int i = g; i < pr.S; i += G) x[i] = seg_times[pr.s0 + i];
   __syncthreads();
-  const double J = evaluate_objective(mask, vals, pr.v0, pr.S, d, x, gr, g, G, active);
+  const double J = evaluate_objective<DS>(mask, vals, pr.v0, pr.S, d, x, gr, g, G, active);
   __syncthreads();
   if (active) {
     for (int i = g; i < pr.S; i += G) grad[pr.s0 + i] = gr[i];
@@ -554,40 +572,32 @@ __global__ __launch_bounds__(64) void cost_gradient_kernel(BatchView b, int d, i
   }
 }
 
-// maxima[seg][k-1][group] for every CSR segment (parity-test building block)
-__global__ __launch_bounds__(64) void segment_maxima_kernel(int n_segments, const double* __restrict__ coeffs,
-                                                            const double* __restrict__ seg_times,
-                                                            double* __restrict__ maxima) {
-  const int s = blockIdx.x * 64 + threadIdx.x;
-  if (s >= n_segments) return;
-  double mx[9];
-  segment_maxima(coeffs + (size_t)s * kD * kN, seg_times[s], mx);
-#pragma unroll
-  for (int i = 0; i < 9; ++i) maxima[(size_t)s * 9 + i] = mx[i];
-}
-
 // ---------------------------------------------------------------------------------------------
 // host side
 
-static int group_for(int S) {
+// split the four dimensions over lanes while the batch is too small to fill the machine otherwise
+static int dim_split_for(int n_paths) { return n_paths <= 4096 ? 4 : 1; }
+
+static int group_for(int S, int ds) {
   int G = 4;
-  while (G < S + 1 && G < 64) G <<= 1;
+  while (G < (S + 1) * ds && G < 64) G <<= 1;
   return G;
 }
 
 int nonlinear_plan_build(NonlinearPlan& nl, const std::vector<int32_t>& so, const std::vector<int32_t>& order) {
   nl.bins.clear();
   const int P = (int)order.size();
+  nl.dim_split = dim_split_for(P);
   int q = 0;
   while (q < P) {
     const int p = order[q];
     const int S = so[p + 1] - so[p];
     NonlinearBin bin;
-    bin.group = group_for(S);
+    bin.group = group_for(S, nl.dim_split);
     bin.q_begin = q;
     bin.max_S = S;  // sorted longest first: the first path of a bin is its longest
     int e = q;
-    while (e < P && group_for(so[order[e] + 1] - so[order[e]]) == bin.group) ++e;
+    while (e < P && group_for(so[order[e] + 1] - so[order[e]], nl.dim_split) == bin.group) ++e;
     bin.q_count = e - q;
     nl.bins.push_back(bin);
     q = e;
@@ -597,35 +607,67 @@ int nonlinear_plan_build(NonlinearPlan& nl, const std::vector<int32_t>& so, cons
 
 void nonlinear_plan_free(NonlinearPlan& nl) {
   if (nl.d_ws) (void)hipFree(nl.d_ws);
+  if (nl.d_opt_status) (void)hipFree(nl.d_opt_status);
+  if (nl.d_maxima) (void)hipFree(nl.d_maxima);
   nl.d_ws = nullptr;
+  nl.d_opt_status = nullptr;
+  nl.d_maxima = nullptr;
   nl.ws_doubles = 0;
 }
 
 static unsigned cdiv_u(long long a, long long b) { return (unsigned)((a + b - 1) / b); }
 
-hipError_t launch_nonlinear(NonlinearPlan& nl, const BatchView& b, const NonlinearParams& prm, const uint8_t* mask,
-                            const double* vals, const double* limits, double* seg_times, double* coeffs,
-                            int32_t* status, double* cost, hipStream_t stream) {
-  const size_t need = (size_t)b.max_segments * ws_per_vertex<1>() * 4 * (size_t)b.n_paths;
+static hipError_t ensure_buffers(NonlinearPlan& nl, const BatchView& b) {
+  hipError_t e;
+  const size_t need = linear_workspace_doubles(b);
   if (nl.ws_doubles < need) {
     if (nl.d_ws) (void)hipFree(nl.d_ws);
     nl.d_ws = nullptr;
     nl.ws_doubles = 0;
-    hipError_t e = hipMalloc(&nl.d_ws, need * sizeof(double));
-    if (e != hipSuccess) return e;
+    if ((e = hipMalloc(&nl.d_ws, need * sizeof(double))) != hipSuccess) return e;
     nl.ws_doubles = need;
   }
+  if (!nl.d_opt_status && (e = hipMalloc(&nl.d_opt_status, sizeof(int32_t) * (size_t)(b.n_paths > 0 ? b.n_paths : 1))) != hipSuccess)
+    return e;
+  if (!nl.d_maxima && (e = hipMalloc(&nl.d_maxima, sizeof(double) * 9 * (size_t)(b.n_segments > 0 ? b.n_segments : 1))) != hipSuccess)
+    return e;
+  return hipSuccess;
+}
+
+hipError_t launch_nonlinear(NonlinearPlan& nl, const BatchView& b, const NonlinearParams& prm, const uint8_t* mask,
+                            const double* vals, const double* limits, double* seg_times, double* coeffs,
+                            int32_t* status, double* cost, hipStream_t stream) {
+  if (b.n_paths == 0) return hipSuccess;
+  hipError_t e = ensure_buffers(nl, b);
+  if (e != hipSuccess) return e;
+  // 1. outer loop
   for (const NonlinearBin& bin : nl.bins) {
     const int per_block = 64 / bin.group;
     const size_t lds_bytes = (size_t)per_block * group_lds_doubles(bin.max_S) * sizeof(double);
     if (lds_bytes > 160 * 1024) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(nonlinear_kernel, dim3(cdiv_u(bin.q_count, per_block)), dim3(64), lds_bytes, stream, b, prm,
-                       bin.group, bin.q_begin, bin.q_count, bin.max_S, mask, vals, limits, seg_times, coeffs, status,
-                       cost, nl.d_ws);
-    hipError_t e = hipGetLastError();
-    if (e != hipSuccess) return e;
+    const dim3 grid(cdiv_u(bin.q_count, per_block));
+    if (nl.dim_split == 4)
+      hipLaunchKernelGGL(optimize_kernel<4>, grid, dim3(64), lds_bytes, stream, b, prm, bin.group, bin.q_begin,
+                         bin.q_count, bin.max_S, mask, vals, seg_times, nl.d_opt_status);
+    else
+      hipLaunchKernelGGL(optimize_kernel<1>, grid, dim3(64), lds_bytes, stream, b, prm, bin.group, bin.q_begin,
+                         bin.q_count, bin.max_S, mask, vals, seg_times, nl.d_opt_status);
+    if ((e = hipGetLastError()) != hipSuccess) return e;
   }
-  return hipSuccess;
+  // 2. trajectory of the last evaluated point (scaleSegmentTimesWithViolation works on poly_opt_'s state)
+  if ((e = launch_solve_linear(b, prm.derivative, true, mask, vals, seg_times, nullptr, nullptr, nl.d_ws, coeffs, nullptr,
+                               nullptr, nullptr, stream)) != hipSuccess)
+    return e;
+  // 3. per-segment maxima and time scaling
+  hipLaunchKernelGGL(segment_maxima9_kernel, dim3(cdiv_u(b.n_segments, 64), 9), dim3(64), 0, stream, b.n_segments, coeffs,
+                     seg_times, nl.d_maxima);
+  if ((e = hipGetLastError()) != hipSuccess) return e;
+  hipLaunchKernelGGL(apply_scaling_kernel, dim3(cdiv_u(b.n_segments, 256)), dim3(256), 0, stream, b, nl.d_maxima, limits,
+                     nl.d_opt_status, seg_times);
+  if ((e = hipGetLastError()) != hipSuccess) return e;
+  // 4. updateSegmentTimes + solveLinear with the scaled times (nonlinear_impl.h:405-408), final status
+  return launch_solve_linear(b, prm.derivative, true, mask, vals, seg_times, nullptr, nullptr, nl.d_ws, coeffs, status,
+                             cost, nl.d_opt_status, stream);
 }
 
 hipError_t launch_cost_gradient(NonlinearPlan& nl, const BatchView& b, int d, const uint8_t* mask, const double* vals,
@@ -634,8 +676,13 @@ hipError_t launch_cost_gradient(NonlinearPlan& nl, const BatchView& b, int d, co
     const int per_block = 64 / bin.group;
     const size_t lds_bytes = (size_t)per_block * 2 * bin.max_S * sizeof(double);
     if (lds_bytes > 160 * 1024) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(cost_gradient_kernel, dim3(cdiv_u(bin.q_count, per_block)), dim3(64), lds_bytes, stream, b, d,
-                       bin.group, bin.q_begin, bin.q_count, bin.max_S, mask, vals, seg_times, cost, grad);
+    const dim3 grid(cdiv_u(bin.q_count, per_block));
+    if (nl.dim_split == 4)
+      hipLaunchKernelGGL(cost_gradient_kernel<4>, grid, dim3(64), lds_bytes, stream, b, d, bin.group, bin.q_begin,
+                         bin.q_count, bin.max_S, mask, vals, seg_times, cost, grad);
+    else
+      hipLaunchKernelGGL(cost_gradient_kernel<1>, grid, dim3(64), lds_bytes, stream, b, d, bin.group, bin.q_begin,
+                         bin.q_count, bin.max_S, mask, vals, seg_times, cost, grad);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
   }
@@ -645,7 +692,7 @@ hipError_t launch_cost_gradient(NonlinearPlan& nl, const BatchView& b, int d, co
 hipError_t launch_segment_maxima(const BatchView& b, const double* coeffs, const double* seg_times, double* maxima,
                                  hipStream_t stream) {
   if (b.n_segments == 0) return hipSuccess;
-  hipLaunchKernelGGL(segment_maxima_kernel, dim3(cdiv_u(b.n_segments, 64)), dim3(64), 0, stream, b.n_segments, coeffs,
+  hipLaunchKernelGGL(segment_maxima9_kernel, dim3(cdiv_u(b.n_segments, 64), 9), dim3(64), 0, stream, b.n_segments, coeffs,
                      seg_times, maxima);
   return hipGetLastError();
 }

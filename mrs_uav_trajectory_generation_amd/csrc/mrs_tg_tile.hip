@@ -35,7 +35,8 @@ __global__ __launch_bounds__(128) void solve_tile_kernel(BatchView b, int d, int
                                                          const double* __restrict__ seg_times,
                                                          const double* __restrict__ Hblk, const double* __restrict__ Ablk,
                                                          double* __restrict__ coeffs, int32_t* __restrict__ status,
-                                                         double* __restrict__ cost) {
+                                                         double* __restrict__ cost,
+                                                         const int32_t* __restrict__ status_in) {
   extern __shared__ double lds[];
   __shared__ int s_S[16], s_s0[16], s_v0[16], s_p[16];
   const int tid = threadIdx.x;
@@ -233,7 +234,7 @@ __global__ __launch_bounds__(128) void solve_tile_kernel(BatchView b, int d, int
     part += __shfl_xor(part, 2, 64);
     if (dim == 0) {
       if (cost) cost[s_p[t]] = part;
-      if (status) status[s_p[t]] = pos_ok ? 1 : -2;
+      if (status) status[s_p[t]] = merge_status(pos_ok, status_in, s_p[t]);
     }
     // backward: x_v = L^-T (z - W x_{v+1}); the four lanes of a path run in lockstep, so the factors
     // written by lane 0 above are visible here (same wavefront, program order)
@@ -316,7 +317,7 @@ bool tile_kernel_applies(const BatchView& b) {
 
 hipError_t launch_solve_tile(const BatchView& b, int d, bool fused, const uint8_t* mask, const double* vals,
                              const double* seg_times, const double* H, const double* Ainv, double* coeffs,
-                             int32_t* status, double* cost, hipStream_t stream) {
+                             int32_t* status, double* cost, const int32_t* status_in, hipStream_t stream) {
   const size_t per_path = (size_t)tile_path_doubles(b.max_segments) * sizeof(double);
   int TP = (int)(kTileLdsBudget / per_path);
   if (TP > 16) TP = 16;
@@ -329,13 +330,13 @@ hipError_t launch_solve_tile(const BatchView& b, int d, bool fused, const uint8_
                                        (int)kTileLdsBudget);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(solve_tile_kernel<true>, dim3(grid), dim3(128), lds_bytes, stream, b, d, TP, b.max_segments, mask,
-                       vals, seg_times, H, Ainv, coeffs, status, cost);
+                       vals, seg_times, H, Ainv, coeffs, status, cost, status_in);
   } else {
     hipError_t e = hipFuncSetAttribute((const void*)solve_tile_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                        (int)kTileLdsBudget);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(solve_tile_kernel<false>, dim3(grid), dim3(128), lds_bytes, stream, b, d, TP, b.max_segments, mask,
-                       vals, seg_times, H, Ainv, coeffs, status, cost);
+                       vals, seg_times, H, Ainv, coeffs, status, cost, status_in);
   }
   return hipGetLastError();
 }
