@@ -121,8 +121,10 @@ int mrs_tg_synchronize(mrs_tg_ctx* ctx);
  *   status_out     [n_paths]       nlopt-style code;  cost_out [n_paths] J_d (computeCost) -- may be NULL
  *   n_samples_out  [n_paths], samples_out [n_paths][sample_capacity][4] (x, y, z, heading wrapped to
  *                  (-pi, pi] as the nodelet reads it, src/...cpp:1582-1599) -- may be NULL when
- *                  sampling_dt <= 0.  n_samples_out reports the count the reference would produce even
- *                  when it exceeds sample_capacity (then only the first sample_capacity are written).
+ *                  sampling_dt <= 0.  n_samples_out reports the count the reference would produce when it
+ *                  fits; a longer trajectory is reported as sample_capacity + 1 (only the first
+ *                  sample_capacity samples are written) -- size the capacity from the length the caller
+ *                  would still accept (the nodelet's max_trajectory_len_factor check, src/...cpp:1178-1186).
  */
 int mrs_tg_solve_batch(mrs_tg_ctx* ctx, int32_t n_paths, const int32_t* seg_offsets, const double* waypoints,
                        const uint8_t* fixed_mask, const double* fixed_values, const double* limits,

@@ -209,6 +209,10 @@ __global__ __launch_bounds__(256) void estimate_times_kernel(BatchView b, const 
 // The heading goes through the reference's quaternion round trip, atan2(2wz, 1-2z^2) with
 // w = cos(y/2), z = sin(y/2) (eth_mav_msgs/common.h:130-140), which is the wrap of y to (-pi, pi];
 // it is computed as y - 2 pi rint(y / 2 pi) (agreement 1e-15; same value at the +-pi seam).
+// A trajectory longer than the caller's capacity is reported as capacity + 1 samples ("too long": the
+// nodelet rejects such results by its length check, src/mrs_trajectory_generation.cpp:1178-1199); this
+// bounds the serial walk, which matters because a path whose outer loop ended on a rejected trial point
+// can come back with segment times of thousands of seconds.
 
 __device__ __forceinline__ double wrap_heading(double y) {
   const double two_pi_hi = 6.283185307179586232e+00, two_pi_lo = 2.449293598294706414e-16;
@@ -259,6 +263,7 @@ __global__ __launch_bounds__(64) void sample_kernel(BatchView b, const double* _
         ++n;
         tin += dt;
         acc += dt;
+        if (n > capacity) break;  // overflow: report capacity + 1, keep the serial walk bounded
       }
       for (int j = (i < S ? i + 1 : S); j <= S; ++j) s_first[j] = n;
     } else {

@@ -107,7 +107,7 @@ def test_nonlinear_end_to_end_vs_oracle(gpu_ctx, n_seg, n_paths):
         a, b = batch.seg_offsets[p], batch.seg_offsets[p + 1]
         dt = np.max(np.abs(out["times"][a:b] - ref["times"][a:b]) / ref["times"][a:b])
         dc = util.coeff_error(out["coeffs"][a:b], ref["coeffs"][a:b])
-        same = out["status"][p] == ref["status"][p] and out["n_samples"][p] == ref["n_samples"][p]
+        same = out["status"][p] == ref["status"][p] and out["n_samples"][p] == min(ref["n_samples"][p], cap + 1)
         ds = np.inf
         if same:
             n = min(out["n_samples"][p], cap)
@@ -160,7 +160,8 @@ def test_sampling_matches_oracle_on_linear_solution(gpu_ctx):
     for p in range(batch.n_paths):
         a, b = batch.seg_offsets[p], batch.seg_offsets[p + 1]
         s, n = po.sample_trajectory(out["coeffs"][a:b], out["times"][a:b], 0.2, 0, cap)
-        assert n == out["n_samples"][p]
+        assert min(n, cap + 1) == out["n_samples"][p]
+        n = min(n, cap)
         got = out["samples"][p, :n]
         assert np.max(np.abs(got[:, :3] - s[:, :3])) < 1e-11
         yaw = np.array([po.wrap_yaw(y) for y in s[:, 3]])
@@ -186,3 +187,12 @@ def test_find_trajectory_single_path(gpu_ctx):
         hit = np.nonzero(dist < 0.5)[0]
         assert hit.size, w
         idx += int(hit[0])
+
+
+def test_sample_overflow_is_reported_as_capacity_plus_one(gpu_ctx):
+    batch = pr.random_batch(8, 10, seed0=2)
+    out = gpu_ctx.solve_batch(batch, None, sampling_dt=0.2, sample_capacity=16)
+    assert np.all(out["n_samples"] == 17)
+    big = gpu_ctx.solve_batch(batch, None, sampling_dt=0.2, sample_capacity=4096)
+    assert np.all(big["n_samples"] < 4096)
+    assert np.array_equal(out["samples"][:, :16], big["samples"][:, :16])
