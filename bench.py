@@ -38,6 +38,7 @@ def parse_args():
     ap.add_argument("--segments", type=int, default=10)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the secondary (other workload) measurement")
+    ap.add_argument("--force-dist", action="store_true", help="initialise torch.distributed even for one rank (tests the RCCL path)")
     return ap.parse_args()
 
 
@@ -83,14 +84,14 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     import torch
     dist = None
-    if world > 1:
+    if world > 1 or args.force_dist:
         import torch.distributed as dist_mod
         torch.cuda.set_device(local_rank)
         dist_mod.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
         dist = dist_mod
     else:
         torch.cuda.set_device(0)
-    dev = torch.device("cuda", local_rank if world > 1 else 0)
+    dev = torch.device("cuda", local_rank if dist is not None else 0)
 
     from mrs_uav_trajectory_generation_amd import api, problem as pr
 
@@ -116,23 +117,54 @@ def main():
 
     from mrs_uav_trajectory_generation_amd import shard
 
-    def final_gather():
-        # the job's only collective: results of every rank to rank 0 (RCCL over xGMI)
-        shard.gather_to_root(db.coeffs, dist)
-        shard.gather_to_root(db.seg_times, dist)
-        shard.gather_to_root(db.status, dist)
+    # Output double buffer: results of step k are gathered to rank 0 on a side stream while step k+1 computes
+    # (the gather is the job's only collective; RCCL over xGMI).  Coefficients, times and status share one
+    # f64 buffer per slot so that the gather is a single collective.
+    n_slots = 2 if dist is not None else 1
+    packed = [torch.zeros(nS * 41 + P, dtype=torch.float64, device=dev) for _ in range(n_slots)]
+    out_coeffs = [p[:nS * 40].view(nS, 4, 10) for p in packed]
+    out_times = [p[nS * 40:nS * 41] for p in packed]
+    status_i32 = [torch.zeros(P, dtype=torch.int32, device=dev) for _ in range(n_slots)]
+    for tt in out_times:
+        tt.copy_(t_init)
+    db.coeffs, db.seg_times, db.status = out_coeffs[0], out_times[0], status_i32[0]
+    comm_stream = torch.cuda.Stream(device=dev) if dist is not None else None
+    recv = [[torch.empty_like(packed[0]) for _ in range(world)] if (dist is not None and rank == 0) else None
+            for _ in range(n_slots)]
+    slot_free = [None] * n_slots      # event: the gather that read this slot has finished
+    step_no = [0]
+
+    def finish_step(slot, with_times):
+        if dist is None:
+            return
+        packed[slot][nS * 41:].copy_(status_i32[slot])          # int32 -> f64 tail of the packed buffer
+        ready = torch.cuda.Event()
+        ready.record()
+        with torch.cuda.stream(comm_stream):
+            comm_stream.wait_event(ready)
+            shard.gather_to_root(packed[slot], dist, bufs=recv[slot])
+            done = torch.cuda.Event()
+            done.record()
+        slot_free[slot] = done
+
+    def begin_step():
+        slot = step_no[0] % n_slots
+        step_no[0] += 1
+        if slot_free[slot] is not None:
+            torch.cuda.current_stream().wait_event(slot_free[slot])
+        return slot
 
     def step_linear():
-        plan.solve(opt_lin, db.fixed_mask, db.fixed_values, t_fixed, db.coeffs, db.status, db.cost)
-        if dist is not None:
-            final_gather()
+        slot = begin_step()
+        plan.solve(opt_lin, db.fixed_mask, db.fixed_values, t_fixed, out_coeffs[slot], status_i32[slot], db.cost)
+        finish_step(slot, False)
 
     def step_nonlinear():
-        db.seg_times.copy_(t_init)   # the outer loop overwrites the times: restart from the same point
-        plan.solve(opt_nl, db.fixed_mask, db.fixed_values, db.seg_times, db.coeffs, db.status, db.cost,
+        slot = begin_step()
+        out_times[slot].copy_(t_init)   # the outer loop overwrites the times: restart from the same point
+        plan.solve(opt_nl, db.fixed_mask, db.fixed_values, out_times[slot], out_coeffs[slot], status_i32[slot], db.cost,
                    limits=db.limits, n_samples=db.n_samples, samples=db.samples)
-        if dist is not None:
-            final_gather()
+        finish_step(slot, True)
 
     steps_fn = {"linear": step_linear, "nonlinear": step_nonlinear}
     elapsed = time_steps(steps_fn[args.workload], args.steps, args.warmup, dist, torch)
@@ -210,9 +242,10 @@ def main():
     err = None
     if rank == 0 and not args.no_cpu_baseline:
         from oracle import pyoracle as po
-        db.seg_times.copy_(t_init)
+        step_no[0] = 0
         steps_fn["linear"]()
         torch.cuda.synchronize()
+        db.coeffs = out_coeffs[0]
         times = t_init.cpu().numpy()
         n_cpu = min(P, 1024)
         sub = batch.select(range(n_cpu)) if n_cpu < P else batch

@@ -31,13 +31,16 @@ def balanced_shard(seg_counts, world):
     return [np.array(sorted(o), dtype=np.int64) for o in owner]
 
 
-def gather_to_root(tensor, dist, dst=0):
-    """Gather equally-shaped per-rank tensors on `dst`; returns the list there, None elsewhere."""
+def gather_to_root(tensor, dist, dst=0, bufs=None):
+    """Gather equally-shaped per-rank tensors on `dst`; returns the list there, None elsewhere.
+    `bufs` lets the caller reuse receive buffers across calls (root only)."""
     world = dist.get_world_size()
-    bufs = None
     if dist.get_rank() == dst:
-        import torch
-        bufs = [torch.empty_like(tensor) for _ in range(world)]
+        if bufs is None:
+            import torch
+            bufs = [torch.empty_like(tensor) for _ in range(world)]
+    else:
+        bufs = None
     dist.gather(tensor, bufs, dst=dst)
     return bufs
 
