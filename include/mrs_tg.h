@@ -203,6 +203,47 @@ int mrs_tg_find_trajectory(mrs_tg_ctx* ctx, const mrs_tg_waypoint* waypoints, in
                            const mrs_tg_options* opt, int32_t relax_heading, double* seg_times_out,
                            double* coeffs_out, int32_t* status_out, int32_t* n_samples_out, double* samples_out);
 
+
+/* ---- path-policy layer: optimize() around findTrajectory(), for a batch of paths ------------- */
+
+/* Parameters of the reference's policy layer (config/public/trajectory_generation.yaml; defaults by
+ * mrs_tg_default_policy_options). */
+typedef struct mrs_tg_policy_options {
+  mrs_tg_options solver;               /* derivative, time allocation, sampling_dt ... of findTrajectory */
+  int32_t check_deviation_enabled;     /* check_trajectory_deviation/enabled */
+  double max_deviation;                /* check_trajectory_deviation/max_deviation [m] */
+  int32_t max_deviation_iterations;    /* check_trajectory_deviation/max_iterations */
+  int32_t max_deviation_first_segment; /* max_deviation_first_segment_ (src/...cpp:874-878) */
+  double min_waypoint_distance;        /* preprocessPath (:484) */
+  int32_t path_straightener_enabled;   /* path_straightener/... (:448-477) */
+  double path_straightener_max_deviation, path_straightener_max_hdg_deviation;
+  double max_trajectory_len_factor, min_trajectory_len_factor; /* length sanity check (:1178-1199) */
+  int32_t fallback_sampling;           /* use findTrajectoryFallback (:1215-1395) instead of the optimiser */
+  double fallback_speed_factor, fallback_accel_factor, fallback_stopping_time;
+  int32_t override_heading_atan2;      /* getTrajectoryReference (:1582-1597) */
+} mrs_tg_policy_options;
+
+void mrs_tg_default_policy_options(mrs_tg_policy_options* opt);
+
+/* MrsTrajectoryGeneration::optimize() (src/mrs_trajectory_generation.cpp:620-851) for n_paths independent
+ * paths: preprocessPath, solve (all still-active paths of a round in ONE batched GPU call), Baca length
+ * sanity check, validateTrajectorySpatial, mid-point insertion into unsafe segments, re-solve -- up to
+ * max_deviation_iterations rounds.  ROS-only branches (tf, stamps, prediction splicing, overtime) are absent.
+ *   wp_offsets [n_paths+1] CSR over `waypoints`; the first waypoint of a path is its initial condition when
+ *   has_initial_state[p] != 0 (then initial_states[p] supplies the derivatives, :946-957).
+ *   limits [n_paths][9]; relax_heading [n_paths] or NULL.
+ *   samples_out [n_paths][sample_capacity][4] (x, y, z, heading); a path needing more samples fails.
+ *   success_out [n_paths] 1/0; max_deviation_out, n_waypoints_out (after subdivision), iterations_out may be NULL. */
+int mrs_tg_optimize_paths(mrs_tg_ctx* ctx, int32_t n_paths, const int32_t* wp_offsets, const mrs_tg_waypoint* waypoints,
+                          const mrs_tg_initial_state* initial_states, const uint8_t* has_initial_state, const double* limits,
+                          const uint8_t* relax_heading, const mrs_tg_policy_options* opt, int32_t sample_capacity,
+                          int32_t* success_out, int32_t* n_samples_out, double* samples_out, double* max_deviation_out,
+                          int32_t* n_waypoints_out, int32_t* iterations_out);
+
+/* getWaypointInTrajectoryIdxs (src/...cpp:1461-1499) for one path; returns the number of indices written. */
+int32_t mrs_tg_waypoint_trajectory_idxs(const double* samples, int32_t n_samples, const mrs_tg_waypoint* waypoints,
+                                        int32_t n_waypoints, int32_t* idxs_out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -37,6 +37,17 @@ class Options(C.Structure):
                 ("sampling_dt", C.c_double), ("sample_capacity", C.c_int32), ("flags", C.c_int32)]
 
 
+class PolicyOptions(C.Structure):
+    _fields_ = [("solver", Options), ("check_deviation_enabled", C.c_int32), ("max_deviation", C.c_double),
+                ("max_deviation_iterations", C.c_int32), ("max_deviation_first_segment", C.c_int32),
+                ("min_waypoint_distance", C.c_double), ("path_straightener_enabled", C.c_int32),
+                ("path_straightener_max_deviation", C.c_double), ("path_straightener_max_hdg_deviation", C.c_double),
+                ("max_trajectory_len_factor", C.c_double), ("min_trajectory_len_factor", C.c_double),
+                ("fallback_sampling", C.c_int32), ("fallback_speed_factor", C.c_double),
+                ("fallback_accel_factor", C.c_double), ("fallback_stopping_time", C.c_double),
+                ("override_heading_atan2", C.c_int32)]
+
+
 class Waypoint(C.Structure):
     _fields_ = [("coords", C.c_double * 4), ("stop_at", C.c_uint8)]
 
@@ -52,6 +63,7 @@ EXPORTED_SYMBOLS = [
     "mrs_tg_plan_n_paths", "mrs_tg_plan_n_segments", "mrs_tg_plan_max_segments", "mrs_tg_plan_get_order",
     "mrs_tg_plan_assemble", "mrs_tg_plan_block_bytes", "mrs_tg_plan_solve", "mrs_tg_plan_cost_gradient",
     "mrs_tg_plan_segment_maxima", "mrs_tg_set_profiling", "mrs_tg_last_kernel_ms", "mrs_tg_find_trajectory",
+    "mrs_tg_default_policy_options", "mrs_tg_optimize_paths", "mrs_tg_waypoint_trajectory_idxs",
 ]
 
 _lib = None
@@ -110,8 +122,29 @@ def load_library():
     L.mrs_tg_find_trajectory.restype = C.c_int
     L.mrs_tg_find_trajectory.argtypes = [vp, C.POINTER(Waypoint), C.c_int32, C.POINTER(InitialState), dp,
                                          C.POINTER(Options), C.c_int32, dp, dp, ip, ip, dp]
+    L.mrs_tg_default_policy_options.restype = None
+    L.mrs_tg_default_policy_options.argtypes = [C.POINTER(PolicyOptions)]
+    L.mrs_tg_optimize_paths.restype = C.c_int
+    L.mrs_tg_optimize_paths.argtypes = [vp, C.c_int32, ip, C.POINTER(Waypoint), C.POINTER(InitialState), bp, dp, bp,
+                                        C.POINTER(PolicyOptions), C.c_int32, ip, ip, dp, dp, ip, ip]
+    L.mrs_tg_waypoint_trajectory_idxs.restype = C.c_int32
+    L.mrs_tg_waypoint_trajectory_idxs.argtypes = [dp, C.c_int32, C.POINTER(Waypoint), C.c_int32, ip]
     _lib = L
     return L
+
+
+def default_policy_options(solver=None, **overrides):
+    opt = PolicyOptions()
+    load_library().mrs_tg_default_policy_options(C.byref(opt))
+    for k, v in (solver or {}).items():
+        if not hasattr(opt.solver, k):
+            raise TypeError("unknown solver option %r" % k)
+        setattr(opt.solver, k, v)
+    for k, v in overrides.items():
+        if not hasattr(opt, k):
+            raise TypeError("unknown policy option %r" % k)
+        setattr(opt, k, v)
+    return opt
 
 
 def default_options(**overrides):
@@ -234,6 +267,57 @@ class Context:
         self._check(rc, "mrs_tg_find_trajectory")
         return dict(times=times, coeffs=coeffs, status=status.value, n_samples=ns.value,
                     samples=samples[:min(ns.value, sample_capacity)])
+
+
+def _waypoint_array(paths, stop_flags=None):
+    n = sum(len(p) for p in paths)
+    arr = (Waypoint * n)()
+    off = np.zeros(len(paths) + 1, dtype=np.int32)
+    i = 0
+    for pi, p in enumerate(paths):
+        p = np.asarray(p, dtype=np.float64).reshape(-1, 4)
+        for j in range(p.shape[0]):
+            for k in range(4):
+                arr[i].coords[k] = p[j, k]
+            arr[i].stop_at = int(bool(stop_flags[pi][j])) if stop_flags is not None and stop_flags[pi] is not None else 0
+            i += 1
+        off[pi + 1] = i
+    return arr, off
+
+
+def optimize_paths(ctx, paths, limits=None, stop_flags=None, initial_states=None, relax_heading=None, policy=None,
+                   sample_capacity=4096):
+    """mrs_tg_optimize_paths: the reference's optimize() policy loop for a list of waypoint paths
+    (each [n][4] array; its first row is the initial condition when initial_states[p] is given)."""
+    from .problem import DEFAULT_LIMITS
+    P = len(paths)
+    arr, off = _waypoint_array(paths, stop_flags)
+    lim = np.ascontiguousarray(np.tile(DEFAULT_LIMITS, (P, 1)) if limits is None else limits, dtype=np.float64).reshape(P, 9)
+    inits = (InitialState * max(P, 1))()
+    has = np.zeros(max(P, 1), dtype=np.uint8)
+    if initial_states is not None:
+        for p, st in enumerate(initial_states):
+            if st is None:
+                continue
+            has[p] = 1
+            inits[p].heading = float(st["heading"])
+            for k in range(4):
+                inits[p].velocity[k] = float(st["velocity"][k])
+                inits[p].acceleration[k] = float(st["acceleration"][k])
+                inits[p].jerk[k] = float(st["jerk"][k])
+    relax = np.ascontiguousarray(relax_heading if relax_heading is not None else np.zeros(max(P, 1)), dtype=np.uint8)
+    pol = policy or default_policy_options()
+    success = np.zeros(P, dtype=np.int32)
+    ns = np.zeros(P, dtype=np.int32)
+    samples = np.zeros((P, sample_capacity, 4))
+    maxdev = np.zeros(P)
+    nwp = np.zeros(P, dtype=np.int32)
+    iters = np.zeros(P, dtype=np.int32)
+    rc = ctx._L.mrs_tg_optimize_paths(ctx._h, P, _np_ptr(off), arr, inits, _np_ptr(has), _np_ptr(lim), _np_ptr(relax),
+                                      C.byref(pol), int(sample_capacity), _np_ptr(success), _np_ptr(ns), _np_ptr(samples),
+                                      _np_ptr(maxdev), _np_ptr(nwp), _np_ptr(iters))
+    ctx._check(rc, "mrs_tg_optimize_paths")
+    return dict(success=success, n_samples=ns, samples=samples, max_deviation=maxdev, n_waypoints=nwp, iterations=iters)
 
 
 class Plan:

@@ -139,6 +139,40 @@ int mto_solve_batch(int n_paths, const int32_t* seg_offsets, const double* waypo
                     int32_t* status_out, double* cost_out, int32_t* n_samples_out, double* samples_out,
                     int sample_capacity, int n_threads);
 
+
+/* ---- path-policy layer (SURVEY.md 8 f: the rows ranked "next") ------------------------------ */
+typedef struct {
+  int check_deviation_enabled;     /* check_trajectory_deviation/enabled        (config/public/trajectory_generation.yaml) */
+  double max_deviation;            /* check_trajectory_deviation/max_deviation  0.05 m */
+  int max_deviation_iterations;    /* check_trajectory_deviation/max_iterations 6 */
+  int max_deviation_first_segment; /* member flag set at src/mrs_trajectory_generation.cpp:874-878 */
+  double min_waypoint_distance;    /* 0.05 m */
+  int path_straightener_enabled;
+  double path_straightener_max_deviation, path_straightener_max_hdg_deviation;
+  double max_trajectory_len_factor, min_trajectory_len_factor; /* 3.0, 0.33 */
+  int fallback_sampling;           /* use findTrajectoryFallback instead of the optimiser */
+  double fallback_speed_factor, fallback_accel_factor, fallback_stopping_time;
+  int override_heading_atan2;
+} mto_policy_params;
+
+void mto_default_policy_params(mto_policy_params* p);
+double mto_dist_from_segment(const double* point, const double* seg1, const double* seg2);        /* :1533-1554 */
+void mto_interpolate_point(const double* a, const double* b, double coeff, double* out);          /* :1612-1625 */
+int mto_preprocess_path(const double* wp_in, const uint8_t* stop_in, int n_in, const mto_policy_params* prm,
+                        double* wp_out, uint8_t* stop_out);                                        /* :431-500 */
+int mto_validate_trajectory_spatial(const double* samples, int n_samples, const double* wps, int n_wp,
+                                    const mto_policy_params* prm, uint8_t* segment_safe, double* max_deviation_out); /* :1401-1455 */
+int mto_waypoint_trajectory_idxs(const double* samples, int n_samples, const double* wps, int n_wp, int32_t* idxs); /* :1461-1499 */
+int mto_fallback_sampling(const double* wps, const uint8_t* stop_at, int n_wp, const double* limits9, int relax_heading,
+                          const mto_policy_params* prm, double dt, double* out, int capacity);    /* :1215-1395 */
+/* optimize() :620-851 for one path. wps_in [n_in][4] (first = initial condition when initial_state != NULL),
+ * initial_state = {heading, velocity[4], acceleration[4], jerk[4]} or NULL. samples_out [capacity][4].
+ * Returns success (1/0). */
+int mto_optimize_path(const double* wps_in, const uint8_t* stop_in, int n_in, const double* initial_state,
+                      const double* limits9, int relax_heading, const mto_options* sopt, const mto_policy_params* prm,
+                      double* samples_out, int capacity, int* n_samples_out, double* max_deviation_out,
+                      int* n_waypoints_out, int* iterations_out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -36,6 +36,16 @@ class Options(C.Structure):
                 ("estimate_times", C.c_int), ("nlopt", NloptParams), ("sampling_dt", C.c_double)]
 
 
+class PolicyParams(C.Structure):
+    _fields_ = [("check_deviation_enabled", C.c_int), ("max_deviation", C.c_double), ("max_deviation_iterations", C.c_int),
+                ("max_deviation_first_segment", C.c_int), ("min_waypoint_distance", C.c_double),
+                ("path_straightener_enabled", C.c_int), ("path_straightener_max_deviation", C.c_double),
+                ("path_straightener_max_hdg_deviation", C.c_double), ("max_trajectory_len_factor", C.c_double),
+                ("min_trajectory_len_factor", C.c_double), ("fallback_sampling", C.c_int),
+                ("fallback_speed_factor", C.c_double), ("fallback_accel_factor", C.c_double),
+                ("fallback_stopping_time", C.c_double), ("override_heading_atan2", C.c_int)]
+
+
 def default_nlopt(max_iterations=10):
     # f_rel 0.05 / x_rel 0.1: /root/reference/src/mrs_trajectory_generation.cpp:884-885;
     # f_abs/x_abs -1 (disabled): polynomial_optimization_nonlinear.h:42-54
@@ -82,8 +92,56 @@ def lib():
         L.mto_solve_batch.argtypes = [C.c_int, C.POINTER(C.c_int32), dp, C.POINTER(C.c_uint8), dp, dp,
                                       C.POINTER(Options), dp, dp, C.POINTER(C.c_int32), dp,
                                       C.POINTER(C.c_int32), dp, C.c_int, C.c_int]
+        L.mto_default_policy_params.argtypes = [C.POINTER(PolicyParams)]
+        L.mto_dist_from_segment.restype = C.c_double
+        L.mto_dist_from_segment.argtypes = [dp, dp, dp]
+        L.mto_preprocess_path.restype = C.c_int
+        L.mto_preprocess_path.argtypes = [dp, C.POINTER(C.c_uint8), C.c_int, C.POINTER(PolicyParams), dp, C.POINTER(C.c_uint8)]
+        L.mto_validate_trajectory_spatial.restype = C.c_int
+        L.mto_validate_trajectory_spatial.argtypes = [dp, C.c_int, dp, C.c_int, C.POINTER(PolicyParams), C.POINTER(C.c_uint8), dp]
+        L.mto_waypoint_trajectory_idxs.restype = C.c_int
+        L.mto_waypoint_trajectory_idxs.argtypes = [dp, C.c_int, dp, C.c_int, C.POINTER(C.c_int32)]
+        L.mto_fallback_sampling.restype = C.c_int
+        L.mto_fallback_sampling.argtypes = [dp, C.POINTER(C.c_uint8), C.c_int, dp, C.c_int, C.POINTER(PolicyParams), C.c_double, dp, C.c_int]
+        L.mto_optimize_path.restype = C.c_int
+        L.mto_optimize_path.argtypes = [dp, C.POINTER(C.c_uint8), C.c_int, dp, dp, C.c_int, C.POINTER(Options),
+                                        C.POINTER(PolicyParams), dp, C.c_int, C.POINTER(C.c_int), dp, C.POINTER(C.c_int),
+                                        C.POINTER(C.c_int)]
         _lib = L
     return _lib
+
+
+def default_policy(**overrides):
+    p = PolicyParams()
+    lib().mto_default_policy_params(C.byref(p))
+    for k, v in overrides.items():
+        if not hasattr(p, k):
+            raise TypeError(k)
+        setattr(p, k, v)
+    return p
+
+
+def optimize_path(waypoints, stop_at=None, initial_state=None, limits=None, relax_heading=False, policy=None, deriv=2,
+                  time_alloc_method=2, max_iterations=10, sampling_dt=0.2, capacity=4096):
+    """optimize() for one path. Returns dict(success, samples, n_samples, max_deviation, n_waypoints, iterations)."""
+    w = _f64(waypoints).reshape(-1, 4)
+    n = w.shape[0]
+    st = np.ascontiguousarray(stop_at if stop_at is not None else np.zeros(n), dtype=np.uint8)
+    init = None
+    if initial_state is not None:
+        init = _f64(np.concatenate([[initial_state["heading"]], initial_state["velocity"], initial_state["acceleration"],
+                                    initial_state["jerk"]]))
+    lim = _f64(limits)
+    pol = policy or default_policy()
+    opt = Options(deriv, time_alloc_method, 1, default_nlopt(max_iterations), float(sampling_dt))
+    out = np.zeros((capacity, 4))
+    ns, nw, it = C.c_int(0), C.c_int(0), C.c_int(0)
+    md = C.c_double(0)
+    ok = lib().mto_optimize_path(_dp(w), st.ctypes.data_as(C.POINTER(C.c_uint8)), n, _dp(init) if init is not None else None,
+                                 _dp(lim), int(bool(relax_heading)), C.byref(opt), C.byref(pol), _dp(out), capacity,
+                                 C.byref(ns), C.byref(md), C.byref(nw), C.byref(it))
+    return dict(success=int(ok), samples=out[:ns.value].copy(), n_samples=ns.value, max_deviation=md.value,
+                n_waypoints=nw.value, iterations=it.value)
 
 
 def _dp(a):

@@ -1,0 +1,75 @@
+"""CPU tests of the oracle's path-policy layer: geometry helpers, preprocessing,
+spatial validation, the fallback sampler and the optimize() loop."""
+import math
+
+import numpy as np
+
+from mrs_uav_trajectory_generation_amd import problem as pr
+from oracle import pyoracle as po
+
+
+def _dist(p, a, b):
+    L = po.lib()
+    f = lambda x: np.ascontiguousarray(x, dtype=np.float64)
+    return L.mto_dist_from_segment(po._dp(f(p)), po._dp(f(a)), po._dp(f(b)))
+
+
+def test_dist_from_segment():
+    assert abs(_dist([0.5, 1.0, 0], [0, 0, 0], [1, 0, 0]) - 1.0) < 1e-15      # projection inside
+    assert abs(_dist([-3, 4, 0], [0, 0, 0], [1, 0, 0]) - 5.0) < 1e-15         # before the start
+    assert abs(_dist([4, 4, 0], [0, 0, 0], [1, 0, 0]) - 5.0) < 1e-15          # past the end
+    assert abs(_dist([1, 2, 2], [0, 0, 0], [0, 0, 0]) - 3.0) < 1e-15          # degenerate segment
+
+
+def test_preprocess_drops_close_waypoints_and_keeps_ends():
+    L = po.lib()
+    wp = np.array([[0, 0, 1, 0], [0.01, 0, 1, 0], [1, 0, 1, 0], [1.02, 0, 1, 0], [2, 0, 1, 0], [2.001, 0, 1, 0.5]], float)
+    stop = np.array([0, 1, 0, 1, 1, 0], dtype=np.uint8)
+    out = np.zeros_like(wp)
+    so = np.zeros(6, dtype=np.uint8)
+    pol = po.default_policy()
+    import ctypes as C
+    n = L.mto_preprocess_path(po._dp(wp), stop.ctypes.data_as(C.POINTER(C.c_uint8)), 6, C.byref(pol), po._dp(out),
+                              so.ctypes.data_as(C.POINTER(C.c_uint8)))
+    # interior points closer than 0.05 m to the last kept one are dropped; the last point always stays
+    assert n == 4 and np.array_equal(out[:4, 0], [0, 1, 2, 2.001]) and so[:4].tolist() == [0, 0, 1, 0]
+    # the straightener removes collinear interior points
+    wp2 = np.array([[0, 0, 1, 0], [1, 0, 1, 0], [2, 0, 1, 0], [2, 2, 1, 0]], float)
+    pol2 = po.default_policy(path_straightener_enabled=1)
+    n2 = L.mto_preprocess_path(po._dp(wp2), None, 4, C.byref(pol2), po._dp(out), so.ctypes.data_as(C.POINTER(C.c_uint8)))
+    assert n2 == 3 and np.array_equal(out[:3, :2], [[0, 0], [2, 0], [2, 2]])
+
+
+def test_fallback_sampler_is_piecewise_linear_and_dwells():
+    wp = np.array([[0, 0, 2, 0.0], [4, 0, 2, 0.5], [4, 3, 2, 1.0]])
+    r = po.optimize_path(wp, stop_at=[0, 1, 0], limits=pr.DEFAULT_LIMITS, policy=po.default_policy(fallback_sampling=1))
+    s = r["samples"]
+    assert r["success"] == 1 and r["iterations"] == 0 and r["max_deviation"] < 1e-12
+    assert np.allclose(s[0, :3], wp[0, :3]) and np.allclose(s[-1, :3], wp[-1, :3])
+    # dwell: round(2.0 / 0.2) = 10 extra copies of the stop_at waypoint
+    at_stop = np.sum(np.all(np.abs(s[:, :3] - wp[1, :3]) < 1e-12, axis=1))
+    assert at_stop == 11
+    # every sample lies on the polyline
+    for q in s:
+        assert min(_dist(q[:3], wp[0, :3], wp[1, :3]), _dist(q[:3], wp[1, :3], wp[2, :3])) < 1e-12
+
+
+def test_optimize_loop_subdivides_until_safe_or_budget():
+    for seed in range(4):
+        wp = pr.random_walk_waypoints(6, seed)
+        r = po.optimize_path(wp, limits=pr.DEFAULT_LIMITS, deriv=2)
+        assert r["success"] == 1 and r["n_waypoints"] >= 7 and 0 <= r["iterations"] <= 6
+        if r["iterations"] < 6:
+            assert r["max_deviation"] <= 0.05          # stopped because it is safe
+        # the samples start at the first and end near the last waypoint
+        assert np.linalg.norm(r["samples"][0, :3] - wp[0, :3]) < 1e-9
+        assert np.linalg.norm(r["samples"][-1, :3] - wp[-1, :3]) < 0.5
+    # deviation check disabled: one solve, no subdivision
+    r = po.optimize_path(pr.random_walk_waypoints(6, 0), limits=pr.DEFAULT_LIMITS, deriv=2,
+                         policy=po.default_policy(check_deviation_enabled=0))
+    assert r["iterations"] == 0 and r["n_waypoints"] == 7
+
+
+def test_single_waypoint_path_is_rejected():
+    r = po.optimize_path(np.array([[1.0, 2.0, 3.0, 0.0]]), limits=pr.DEFAULT_LIMITS)
+    assert r["success"] == 0 and r["n_samples"] == 0
