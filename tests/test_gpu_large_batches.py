@@ -1,0 +1,89 @@
+"""Kernel variants that only engage on larger batches (the library picks the lane mapping from the batch
+size): one-lane-per-dimension solve (2048 < P <= 32768), one-lane-per-path solve (P > 32768), compact
+outer-loop mapping (P > 4096).  Parity is checked against the oracle on a strided subset (the oracle needs
+~30 us per linear path and ~2 ms per nonlinear path), and on every path through size-independent
+properties: continuity, constraints, linearity, agreement between the materialised-block and the fused
+pipelines, and agreement with the same paths solved in a small batch (different kernels, same answer)."""
+import numpy as np
+import pytest
+
+from mrs_uav_trajectory_generation_amd import api, problem as pr
+from oracle import pyoracle as po
+from tests import util
+
+pytestmark = pytest.mark.gpu
+
+
+def _subset_vs_oracle(batch, out, idx, tol):
+    sub = batch.select(idx)
+    t = np.concatenate([out["times"][batch.seg_offsets[p]:batch.seg_offsets[p + 1]] for p in idx])
+    ref = util.oracle_linear(sub, t)
+    got = np.concatenate([out["coeffs"][batch.seg_offsets[p]:batch.seg_offsets[p + 1]] for p in idx])
+    assert util.coeff_error(got, ref["coeffs"], sub.seg_offsets) < tol
+
+
+@pytest.mark.parametrize("n_paths", [2304, 33024])
+def test_linear_large_batches(gpu_ctx, n_paths):
+    batch = pr.random_batch(n_paths, 10, seed0=7000)
+    out = gpu_ctx.solve_batch(batch, None)
+    fused = gpu_ctx.solve_batch(batch, out["times"], flags=api.FLAG_FUSED_ASSEMBLY)
+    assert np.all(out["status"] == 1) and np.all(fused["status"] == 1)
+    # The two pipelines round the block entries differently (1 ulp); the solution moves by cond(R_pp) * eps,
+    # and among tens of thousands of random paths a few have a 0.05 s segment next to 10 s ones (cond ~1e9).
+    err = np.array([util.coeff_error(out["coeffs"][a:b], fused["coeffs"][a:b])
+                    for a, b in zip(batch.seg_offsets[:-1], batch.seg_offsets[1:])])
+    assert np.percentile(err, 99) < 1e-10 and err.max() < 1e-5, (np.percentile(err, 99), err.max())
+    assert np.percentile(np.abs(out["cost"] - fused["cost"]) / np.abs(fused["cost"]), 99) < 1e-10
+    idx = list(range(0, n_paths, n_paths // 97))
+    _subset_vs_oracle(batch, out, idx, 1e-7)
+    # the same paths in a small batch go through the tile kernel: same answer
+    small = batch.select(idx)
+    ts = np.concatenate([out["times"][batch.seg_offsets[p]:batch.seg_offsets[p + 1]] for p in idx])
+    sout = gpu_ctx.solve_batch(small, ts)
+    got = np.concatenate([out["coeffs"][batch.seg_offsets[p]:batch.seg_offsets[p + 1]] for p in idx])
+    assert util.coeff_error(got, sout["coeffs"], small.seg_offsets) < 1e-9
+    chk = batch.select(range(0, n_paths, n_paths // 31))
+    tc = np.concatenate([out["times"][batch.seg_offsets[p]:batch.seg_offsets[p + 1]] for p in range(0, n_paths, n_paths // 31)])
+    cc = np.concatenate([out["coeffs"][batch.seg_offsets[p]:batch.seg_offsets[p + 1]] for p in range(0, n_paths, n_paths // 31)])
+    assert util.continuity_defect(chk, cc, tc) < 1e-9 and util.constraint_defect(chk, cc, tc) < 1e-9
+
+
+def test_linear_ragged_large_batch(gpu_ctx):
+    batch = pr.random_batch(4500, "ragged", seed0=8000)     # BASELINE config 5 shape, per-lane kernels
+    out = gpu_ctx.solve_batch(batch, None)
+    assert np.all(out["status"] == 1)
+    _subset_vs_oracle(batch, out, list(range(0, 4500, 41)), 1e-7)
+
+
+def test_long_paths_fall_back_to_per_lane_kernel(gpu_ctx):
+    batch = pr.random_batch(6, 120, seed0=8100)             # 120 segments: too large for the LDS tile
+    out = gpu_ctx.solve_batch(batch, None)
+    assert np.all(out["status"] == 1)
+    _subset_vs_oracle(batch, out, list(range(6)), 1e-6)
+    nl = gpu_ctx.solve_batch(batch.select([0, 1]), None, time_alloc_method=api.TIME_ALLOC_MELLINGER)
+    assert np.all(np.isin(nl["status"], (1, 3, 4, 5))) and np.all(np.isfinite(nl["coeffs"]))
+
+
+def test_nonlinear_compact_mapping_matches_split_mapping(gpu_ctx):
+    # P > 4096 switches the outer loop to one lane per time vector; the same paths in a small batch use four
+    batch = pr.random_batch(4200, 10, seed0=9000)
+    out = gpu_ctx.solve_batch(batch, None, time_alloc_method=api.TIME_ALLOC_MELLINGER, sampling_dt=0.2, sample_capacity=64)
+    assert np.all(np.isin(out["status"], (1, 3, 4, 5)))
+    idx = list(range(0, 4200, 35))
+    small = gpu_ctx.solve_batch(batch.select(idx), None, time_alloc_method=api.TIME_ALLOC_MELLINGER, sampling_dt=0.2,
+                                sample_capacity=64)
+    agree = 0
+    for k, p in enumerate(idx):
+        a, b = batch.seg_offsets[p], batch.seg_offsets[p + 1]
+        if out["status"][p] == small["status"][k] and \
+                np.max(np.abs(out["times"][a:b] - small["times"][10 * k:10 * k + 10]) / small["times"][10 * k:10 * k + 10]) < 1e-7:
+            agree += 1
+    assert agree >= 0.97 * len(idx), agree
+    # and against the oracle on a handful
+    few = idx[:12]
+    ref = po.solve_batch(batch.select(few).seg_offsets, batch.select(few).waypoints, batch.select(few).fixed_mask,
+                         batch.select(few).fixed_values, batch.select(few).limits, np.zeros(120), deriv=4,
+                         time_alloc_method=2, estimate_times=True, n_threads=4)
+    good = sum(1 for k, p in enumerate(few)
+               if np.max(np.abs(out["times"][10 * p:10 * p + 10] - ref["times"][10 * k:10 * k + 10]) / ref["times"][10 * k:10 * k + 10]) < 1e-6)
+    assert good >= len(few) - 1
