@@ -1,0 +1,77 @@
+#!/usr/bin/env python3
+"""Measure every BASELINE.json config on one MI355X (device-resident inputs, kernel pipeline only) and
+write profiles/<tag>_configs.json.  Not the headline benchmark (that is bench.py); a record of the other
+configs' throughput.  Config 4 is measured as its per-GPU shard (8192 paths) and, for reference, as the whole
+65536-path batch on one GPU."""
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from mrs_uav_trajectory_generation_amd import api, problem as pr  # noqa: E402
+
+
+def measure(ctx, batch, nonlinear, reps):
+    plan = api.Plan(ctx, batch.seg_offsets)
+    db = api.DeviceBatch(batch, "cuda:0", sample_capacity=512)
+    est = api.default_options(derivative_to_optimize=4, estimate_times=1)
+    plan.solve(est, db.fixed_mask, db.fixed_values, db.seg_times, db.coeffs, db.status, db.cost, waypoints=db.waypoints,
+               limits=db.limits)
+    torch.cuda.synchronize()
+    t0 = db.seg_times.clone()
+    if nonlinear:
+        opt = api.default_options(derivative_to_optimize=4, time_alloc_method=api.TIME_ALLOC_MELLINGER, sampling_dt=0.2,
+                                  sample_capacity=512)
+
+        def step():
+            db.seg_times.copy_(t0)
+            plan.solve(opt, db.fixed_mask, db.fixed_values, db.seg_times, db.coeffs, db.status, db.cost, limits=db.limits,
+                       n_samples=db.n_samples, samples=db.samples)
+    else:
+        opt = api.default_options(derivative_to_optimize=4)
+
+        def step():
+            plan.solve(opt, db.fixed_mask, db.fixed_values, t0, db.coeffs, db.status, db.cost)
+    for _ in range(3):
+        step()
+    torch.cuda.synchronize()
+    t = time.perf_counter()
+    for _ in range(reps):
+        step()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t) / reps
+    st = db.status.cpu().numpy()
+    plan.close()
+    return dict(paths=batch.n_paths, segments=int(batch.n_segments), ms_per_step=dt * 1e3,
+                trajectories_per_s=batch.n_paths / dt, status_histogram={int(k): int(v) for k, v in zip(*np.unique(st, return_counts=True))})
+
+
+def main():
+    tag = sys.argv[1] if len(sys.argv) > 1 else "round1"
+    ctx = api.Context(0)
+    ctx.use_torch_stream()
+    out = {}
+    out["config1_single_4wp_path_linear"] = measure(ctx, pr.config1_batch(), False, 200)
+    out["config2_1024x10_linear"] = measure(ctx, pr.random_batch(1024, 10, seed0=0), False, 200)
+    out["config3_1024x10_nonlinear_sampled"] = measure(ctx, pr.random_batch(1024, 10, seed0=0), True, 50)
+    b8192 = pr.random_batch(8192, 10, seed0=0)
+    out["config4_shard_8192x10_nonlinear_sampled"] = measure(ctx, b8192, True, 20)
+    out["config4_shard_8192x10_linear"] = measure(ctx, b8192, False, 50)
+    out["config5_8192_ragged_3to30_nonlinear_sampled"] = measure(ctx, pr.random_batch(8192, "ragged", seed0=0), True, 10)
+    big = pr.random_batch(65536, 10, seed0=0)
+    out["config4_whole_65536x10_linear_one_gpu"] = measure(ctx, big, False, 10)
+    out["config4_whole_65536x10_nonlinear_sampled_one_gpu"] = measure(ctx, big, True, 5)
+    path = os.path.join(ROOT, "profiles", "%s_configs.json" % tag)
+    with open(path, "w") as f:
+        json.dump(out, f, indent=1)
+    for k, v in out.items():
+        print("%-52s %10.3f ms/step %14.0f traj/s" % (k, v["ms_per_step"], v["trajectories_per_s"]))
+
+
+if __name__ == "__main__":
+    main()
