@@ -152,21 +152,52 @@ struct Elim {
   __device__ __forceinline__ void absorb_segment(const double (&Hs)[kSym10], const double (&fs)[kHalf][ND],
                                                  const double (&fe)[kHalf][ND], unsigned free_s, unsigned free_e,
                                                  double (&L)[10], double (&z)[kNB][ND], double (&W)[kNB][kNB]) {
-    // u = H [fs; fe]; the free rows feed the right-hand sides, all rows feed qf
+    // u = H [fs; fe]; the free rows feed the right-hand sides, all rows feed qf.
+    // Every vertex constrains its position, and the other constrained derivatives are zero except for an
+    // initial state, so the two position columns are always processed and the eight derivative columns
+    // only where some constrained derivative value is non-zero (one branch per segment, uniform across the
+    // wavefront in practice): 20 instead of 100 multiply-adds per dimension.
+    bool deriv_nonzero = false;
+#pragma unroll
+    for (int q = 0; q < ND; ++q)
+#pragma unroll
+      for (int b = 1; b < kHalf; ++b) deriv_nonzero = deriv_nonzero || (fs[b][q] != 0.0) || (fe[b][q] != 0.0);
+    double u[kN][ND];
+#pragma unroll
+    for (int q = 0; q < ND; ++q) {
+#pragma unroll
+      for (int a = 0; a < kN; ++a) u[a][q] = Hs[sym10(a, 0)] * fs[0][q] + Hs[sym10(a, kHalf)] * fe[0][q];
+      qf += fs[0][q] * u[0][q] + fe[0][q] * u[kHalf][q];
+    }
+    if (deriv_nonzero) {
+#pragma unroll
+      for (int q = 0; q < ND; ++q) {
+        double extra = 0.0;
+#pragma unroll
+        for (int a = 0; a < kN; ++a) {
+          double s = 0.0;
+#pragma unroll
+          for (int b = 1; b < kHalf; ++b) s += Hs[sym10(a, b)] * fs[b][q] + Hs[sym10(a, kHalf + b)] * fe[b][q];
+          u[a][q] += s;
+        }
+        // qf = f^T u over all ten rows: the position rows were added above with the incomplete u, fix them up
+#pragma unroll
+        for (int b = 1; b < kHalf; ++b) extra += fs[b][q] * u[b][q] + fe[b][q] * u[kHalf + b][q];
+        double pos_fix = 0.0;
+#pragma unroll
+        for (int b = 1; b < kHalf; ++b)
+          pos_fix += fs[0][q] * (Hs[sym10(0, b)] * fs[b][q] + Hs[sym10(0, kHalf + b)] * fe[b][q]) +
+                     fe[0][q] * (Hs[sym10(kHalf, b)] * fs[b][q] + Hs[sym10(kHalf, kHalf + b)] * fe[b][q]);
+        qf += extra + pos_fix;
+      }
+    }
     double ue[kNB][ND];
 #pragma unroll
     for (int q = 0; q < ND; ++q) {
 #pragma unroll
-      for (int a = 0; a < kN; ++a) {
-        double u = 0.0;
-#pragma unroll
-        for (int b = 0; b < kHalf; ++b) u += Hs[sym10(a, b)] * fs[b][q];
-#pragma unroll
-        for (int b = 0; b < kHalf; ++b) u += Hs[sym10(a, kHalf + b)] * fe[b][q];
-        const double fa = (a < kHalf) ? fs[a][q] : fe[a - kHalf][q];
-        qf += fa * u;
-        if (a >= kSlot0 && a < kHalf) y[a - kSlot0][q] -= u;
-        if (a >= kHalf + kSlot0) ue[a - kHalf - kSlot0][q] = u;
+      for (int r = 0; r < kNB; ++r) {
+        y[r][q] -= u[kSlot0 + r][q];
+        ue[r][q] = u[kHalf + kSlot0 + r][q];
       }
     }
     // start block of this segment completes vertex v's diagonal block

@@ -10,7 +10,8 @@
 // everything in LDS and runs
 //   A0  one lane per vertex:               constraints -> f, free masks                     (parallel)
 //   A1  one lane per (segment, dimension): blocks (from HBM or from T) -> u, masked blocks  (parallel)
-//   B   four lanes per path (one per dimension): the vertex chain on LDS-resident 4x4 blocks (serial)
+//   B   eight lanes per path (direction x dimension): two-sided elimination of the vertex chain on the
+//       LDS-resident 4x4 blocks, meeting at the middle vertex                                  (serial, S/2 deep)
 //   C   one lane per (segment, dimension): c = A^-1 d -> global coefficients                (parallel)
 // so the serial lanes execute only the chain (~1/3 of the instructions of the one-lane kernel).
 #include <hip/hip_runtime.h>
@@ -128,26 +129,32 @@ __global__ __launch_bounds__(128) void solve_tile_kernel(BatchView b, int d, int
   }
   __syncthreads();
 
-  // ---- B: the vertex chain, four lanes per path (lane = dimension)
-  if (tid < n_here * kD) {
-    const int t = tid / kD, dim = tid % kD;
+  // ---- B: the vertex chain, eight lanes per path: lane = (direction, dimension).
+  // Two-sided ("twisted") block elimination: direction 0 eliminates vertices 0, 1, ... from the left,
+  // direction 1 eliminates S, S-1, ... from the right, both towards the middle vertex m = S/2; then the
+  // middle block (which receives a Schur update from each side) is solved and the two halves are
+  // back-substituted outwards.  Same minimiser, same cost 0.5 (qf - sum |z|^2), half the dependent steps.
+  if (tid < n_here * 2 * kD) {
+    const int t = tid / (2 * kD), dir = (tid / kD) & 1, dim = tid % kD;
     const int S = s_S[t];
+    const int m = S / 2;                       // middle vertex
+    const int len = dir ? (S - m) : m;         // vertices this side eliminates: [0, m) or (m, S]
     double Wp[kNB][kNB], zp[kNB];
     double L[10], Linv[kNB], z[kNB], W[kNB][kNB];
-    double red = 0.0, qf = 0.0;
-    bool pos_ok = true;
+    double red = 0.0;
 #pragma unroll
     for (int r = 0; r < kNB; ++r) {
       zp[r] = 0.0;
 #pragma unroll
       for (int c = 0; c < kNB; ++c) Wp[r][c] = 0.0;
     }
-    for (int v = 0; v <= S; ++v) {
-      const double* prev = (v > 0) ? seg_rec(t, v - 1) : nullptr;
-      const double* cur = (v < S) ? seg_rec(t, v) : nullptr;
+    // one elimination step at vertex v; `outer` = the already eliminated neighbour exists (Wp, zp valid);
+    // `inner` = there is a next vertex towards the middle to couple with
+    auto eliminate = [&](int v, bool outer, bool inner, bool middle) {
       double* vr = vtx_rec(t, v);
       const unsigned fb = (unsigned)vr[62];
-      pos_ok = pos_ok && (vr[63] != 0.0);
+      const double* left = (v > 0) ? seg_rec(t, v - 1) : nullptr;   // segment v-1 ends at v
+      const double* right = (v < S) ? seg_rec(t, v) : nullptr;      // segment v starts at v
       double Sm[10], y[kNB];
 #pragma unroll
       for (int r = 0; r < kNB; ++r) {
@@ -155,30 +162,38 @@ __global__ __launch_bounds__(128) void solve_tile_kernel(BatchView b, int d, int
 #pragma unroll
         for (int c = 0; c <= r; ++c) {
           double s = 0.0;
-          if (v > 0) {
-            s = prev[26 + tri(r, c)];
+          if (left) s += left[26 + tri(r, c)];
+          if (right) s += right[tri(r, c)];
+          if (outer) {
 #pragma unroll
-            for (int m = 0; m < kNB; ++m) s -= Wp[m][r] * Wp[m][c];
+            for (int k = 0; k < kNB; ++k) s -= Wp[k][r] * Wp[k][c];
           }
-          if (v < S) s += cur[tri(r, c)];
           Sm[tri(r, c)] = (r == c && !fr) ? 1.0 : s;
         }
         double s = 0.0;
-        if (v > 0) {
-          s = -prev[52 + r * kD + dim];
+        if (left) s -= left[52 + r * kD + dim];
+        if (right) s -= right[36 + r * kD + dim];
+        if (outer) {
 #pragma unroll
-          for (int m = 0; m < kNB; ++m) s -= Wp[m][r] * zp[m];
+          for (int k = 0; k < kNB; ++k) s -= Wp[k][r] * zp[k];
         }
-        if (v < S) s -= cur[36 + r * kD + dim];
         y[r] = s;
       }
-      if (v < S) qf += cur[68 + dim];
-      // Cholesky (masked rows are already identity rows / zero right-hand sides)
+      if (middle) {
+        // the other side's Schur update and right-hand side, left in this vertex's record by direction 1
+#pragma unroll
+        for (int r = 0; r < kNB; ++r) {
+#pragma unroll
+          for (int c = 0; c <= r; ++c)
+            if (!(r == c && !((fb >> r) & 1u))) Sm[tri(r, c)] -= vr[tri(r, c)];
+          y[r] -= vr[26 + r * kD + dim];
+        }
+      }
 #pragma unroll
       for (int c = 0; c < kNB; ++c) {
         double dsum = Sm[tri(c, c)];
 #pragma unroll
-        for (int m = 0; m < c; ++m) dsum -= L[tri(c, m)] * L[tri(c, m)];
+        for (int k = 0; k < c; ++k) dsum -= L[tri(c, k)] * L[tri(c, k)];
         const double inv = rsqrt_refined(dsum);
         L[tri(c, c)] = dsum * inv;
         Linv[c] = inv;
@@ -186,7 +201,7 @@ __global__ __launch_bounds__(128) void solve_tile_kernel(BatchView b, int d, int
         for (int r = c + 1; r < kNB; ++r) {
           double s = Sm[tri(r, c)];
 #pragma unroll
-          for (int m = 0; m < c; ++m) s -= L[tri(r, m)] * L[tri(c, m)];
+          for (int k = 0; k < c; ++k) s -= L[tri(r, k)] * L[tri(c, k)];
           L[tri(r, c)] = s * inv;
         }
       }
@@ -194,31 +209,36 @@ __global__ __launch_bounds__(128) void solve_tile_kernel(BatchView b, int d, int
       for (int r = 0; r < kNB; ++r) {
         double s = y[r];
 #pragma unroll
-        for (int m = 0; m < r; ++m) s -= L[tri(r, m)] * z[m];
+        for (int k = 0; k < r; ++k) s -= L[tri(r, k)] * z[k];
         z[r] = s * Linv[r];
         red += z[r] * z[r];
       }
-      if (v < S) {
+      if (inner) {
+        // coupling block between v (rows) and the next vertex towards the middle (columns):
+        // direction 0: E~_v[r][c]; direction 1: E~_{v-1} transposed
+        const double* cb = dir ? left : right;
 #pragma unroll
         for (int c = 0; c < kNB; ++c)
 #pragma unroll
           for (int r = 0; r < kNB; ++r) {
-            double s = cur[10 + r * kNB + c];
+            double s = dir ? cb[10 + c * kNB + r] : cb[10 + r * kNB + c];
 #pragma unroll
-            for (int m = 0; m < r; ++m) s -= L[tri(r, m)] * W[m][c];
+            for (int k = 0; k < r; ++k) s -= L[tri(r, k)] * W[k][c];
             W[r][c] = s * Linv[r];
           }
       }
-      // keep the factors for the backward sweep (L, Linv stored as L with reciprocal diagonal, W by lane 0)
+      // keep the factors for the backward sweep (reciprocal diagonal; W written by the dim-0 lane)
       if (dim == 0) {
 #pragma unroll
         for (int e = 0; e < 10; ++e) vr[e] = L[e];
 #pragma unroll
-        for (int r = 0; r < kNB; ++r) vr[tri(r, r)] = Linv[r];  // the backward sweep only divides by the diagonal
+        for (int r = 0; r < kNB; ++r) vr[tri(r, r)] = Linv[r];
+        if (inner) {
 #pragma unroll
-        for (int r = 0; r < kNB; ++r)
+          for (int r = 0; r < kNB; ++r)
 #pragma unroll
-          for (int c = 0; c < kNB; ++c) vr[10 + r * kNB + c] = W[r][c];
+            for (int c = 0; c < kNB; ++c) vr[10 + r * kNB + c] = W[r][c];
+        }
       }
 #pragma unroll
       for (int r = 0; r < kNB; ++r) vr[26 + r * kD + dim] = z[r];
@@ -228,35 +248,99 @@ __global__ __launch_bounds__(128) void solve_tile_kernel(BatchView b, int d, int
 #pragma unroll
         for (int c = 0; c < kNB; ++c) Wp[r][c] = W[r][c];
       }
+    };
+
+    for (int s = 0; s < len; ++s) {
+      const int v = dir ? (S - s) : s;
+      eliminate(v, s > 0, true, false);
     }
-    double part = 0.5 * (qf - red);
-    part += __shfl_xor(part, 1, 64);
-    part += __shfl_xor(part, 2, 64);
-    if (dim == 0) {
-      if (cost) cost[s_p[t]] = part;
+    // direction 1 hands its Schur update W^T W and right-hand-side update W^T z for the middle vertex over
+    // through that vertex's (still unused) record
+    if (dir == 1 && len > 0) {
+      double* vm = vtx_rec(t, m);
+      if (dim == 0) {
+#pragma unroll
+        for (int r = 0; r < kNB; ++r)
+#pragma unroll
+          for (int c = 0; c <= r; ++c) {
+            double s = 0.0;
+#pragma unroll
+            for (int k = 0; k < kNB; ++k) s += Wp[k][r] * Wp[k][c];
+            vm[tri(r, c)] = s;
+          }
+      }
+#pragma unroll
+      for (int r = 0; r < kNB; ++r) {
+        double s = 0.0;
+#pragma unroll
+        for (int k = 0; k < kNB; ++k) s += Wp[k][r] * zp[k];
+        vm[26 + r * kD + dim] = s;
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    double xm[kNB] = {0.0, 0.0, 0.0, 0.0};
+    if (dir == 0) {
+      // middle vertex: left Schur update from Wp/zp (if any vertex was eliminated on the left), right one
+      // from the record (if any on the right)
+      eliminate(m, m > 0, false, S - m > 0);
+      double* vr = vtx_rec(t, m);
+      // x_m = L^-T z
+#pragma unroll
+      for (int r = kNB - 1; r >= 0; --r) {
+        double s = z[r];
+#pragma unroll
+        for (int k = r + 1; k < kNB; ++k) s -= L[tri(k, r)] * xm[k];
+        xm[r] = s * Linv[r];
+      }
+#pragma unroll
+      for (int r = 0; r < kNB; ++r) {
+        vr[42 + (kSlot0 + r) * kD + dim] += xm[r];
+        vr[26 + r * kD + dim] = xm[r];  // x_m for the direction-1 lanes
+      }
+    }
+    double part = red;
+    part += __shfl_xor(part, kD, 64);  // the two directions of this dimension
+    double qf = 0.0;
+    if (dir == 0)
+      for (int i = 0; i < S; ++i) qf += seg_rec(t, i)[68 + dim];
+    double cst = (dir == 0) ? 0.5 * (qf - part) : 0.0;
+    cst += __shfl_xor(cst, 1, 64);
+    cst += __shfl_xor(cst, 2, 64);
+    if (dir == 0 && dim == 0) {
+      bool pos_ok = true;
+      for (int v = 0; v <= S; ++v) pos_ok = pos_ok && (vtx_rec(t, v)[63] != 0.0);
+      if (cost) cost[s_p[t]] = cst;
       if (status) status[s_p[t]] = merge_status(pos_ok, status_in, s_p[t]);
     }
-    // backward: x_v = L^-T (z - W x_{v+1}); the four lanes of a path run in lockstep, so the factors
-    // written by lane 0 above are visible here (same wavefront, program order)
-    double xn[kNB] = {0.0, 0.0, 0.0, 0.0};
-    for (int v = S; v >= 0; --v) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    // outward back-substitution: x_v = L_v^-T (z_v - W_v x_next), next = the neighbour towards the middle
+    double xn[kNB];
+    {
+      const double* vr = vtx_rec(t, m);
+#pragma unroll
+      for (int r = 0; r < kNB; ++r) xn[r] = vr[26 + r * kD + dim];
+    }
+    for (int s = len - 1; s >= 0; --s) {
+      const int v = dir ? (S - s) : s;
       double* vr = vtx_rec(t, v);
       double tv[kNB], x[kNB];
 #pragma unroll
       for (int r = 0; r < kNB; ++r) {
-        double s = vr[26 + r * kD + dim];
-        if (v < S) {
+        double sacc = vr[26 + r * kD + dim];
 #pragma unroll
-          for (int c = 0; c < kNB; ++c) s -= vr[10 + r * kNB + c] * xn[c];
-        }
-        tv[r] = s;
+        for (int c = 0; c < kNB; ++c) sacc -= vr[10 + r * kNB + c] * xn[c];
+        tv[r] = sacc;
       }
 #pragma unroll
       for (int r = kNB - 1; r >= 0; --r) {
-        double s = tv[r];
+        double sacc = tv[r];
 #pragma unroll
-        for (int m = r + 1; m < kNB; ++m) s -= vr[tri(m, r)] * x[m];
-        x[r] = s * vr[tri(r, r)];
+        for (int k = r + 1; k < kNB; ++k) sacc -= vr[tri(k, r)] * x[k];
+        x[r] = sacc * vr[tri(r, r)];
       }
 #pragma unroll
       for (int r = 0; r < kNB; ++r) {
@@ -320,7 +404,7 @@ hipError_t launch_solve_tile(const BatchView& b, int d, bool fused, const uint8_
                              int32_t* status, double* cost, const int32_t* status_in, hipStream_t stream) {
   const size_t per_path = (size_t)tile_path_doubles(b.max_segments) * sizeof(double);
   int TP = (int)(kTileLdsBudget / per_path);
-  if (TP > 16) TP = 16;
+  if (TP > 8) TP = 8;  // phase B runs eight lanes per path inside one wavefront
   // more, smaller tiles so that every CU gets work (256 CUs) and several tiles share a CU
   while (TP > 4 && (b.n_paths + TP - 1) / TP < 512) TP >>= 1;
   const size_t lds_bytes = per_path * (size_t)TP;
