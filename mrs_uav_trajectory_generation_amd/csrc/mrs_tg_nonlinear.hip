@@ -303,17 +303,30 @@ __device__ __forceinline__ double evaluate_objective(const uint8_t* __restrict__
 // the outer-loop kernel: optimiser ticks (one objective evaluation each).  On exit seg_times holds the
 // last evaluated point and opt_status the stopping reason (-2: start rejected, as NLopt would).
 
+// All bins of a plan run in ONE launch: blocks [block_begin, block_begin + n_blocks) of the grid belong to a
+// bin (paths sorted longest first, so the long paths are dispatched first and the short ones fill the tail).
+struct BinTable {
+  int n;
+  int group[5], q_begin[5], q_count[5], max_S[5], block_begin[5];
+};
+
 template <int DS>
-__global__ __launch_bounds__(64) void optimize_kernel(BatchView b, NonlinearParams prm, int G, int q_begin, int q_count,
-                                                      int Sb, const uint8_t* __restrict__ mask,
+__global__ __launch_bounds__(64) void optimize_kernel(BatchView b, NonlinearParams prm, BinTable bins,
+                                                      const uint8_t* __restrict__ mask,
                                                       const double* __restrict__ vals, double* __restrict__ seg_times,
                                                       int32_t* __restrict__ opt_status) {
   extern __shared__ double lds[];
+  int bin = 0;
+#pragma unroll
+  for (int i = 1; i < 5; ++i)
+    if (i < bins.n && (int)blockIdx.x >= bins.block_begin[i]) bin = i;
+  const int G = bins.group[bin], q_begin = bins.q_begin[bin], q_count = bins.q_count[bin], Sb = bins.max_S[bin];
+  const int block_in_bin = (int)blockIdx.x - bins.block_begin[bin];
   const int lane = threadIdx.x;
   const int g = lane & (G - 1);
   const int grp = lane / G;
   const int per_block = 64 / G;
-  const int qi = blockIdx.x * per_block + grp;
+  const int qi = block_in_bin * per_block + grp;
   const bool active = qi < q_count;
   const int q = q_begin + (active ? qi : 0);
   const PathRef pr = path_at(b, q);
@@ -640,18 +653,37 @@ hipError_t launch_nonlinear(NonlinearPlan& nl, const BatchView& b, const Nonline
   if (b.n_paths == 0) return hipSuccess;
   hipError_t e = ensure_buffers(nl, b);
   if (e != hipSuccess) return e;
-  // 1. outer loop
-  for (const NonlinearBin& bin : nl.bins) {
-    const int per_block = 64 / bin.group;
-    const size_t lds_bytes = (size_t)per_block * group_lds_doubles(bin.max_S) * sizeof(double);
+  // 1. outer loop: every bin in one launch
+  {
+    BinTable bt{};
+    bt.n = (int)nl.bins.size();
+    if (bt.n > 5) return hipErrorInvalidValue;
+    size_t lds_bytes = 0;
+    int blocks = 0;
+    for (int i = 0; i < bt.n; ++i) {
+      const NonlinearBin& bin = nl.bins[i];
+      const int per_block = 64 / bin.group;
+      bt.group[i] = bin.group;
+      bt.q_begin[i] = bin.q_begin;
+      bt.q_count[i] = bin.q_count;
+      bt.max_S[i] = bin.max_S;
+      bt.block_begin[i] = blocks;
+      blocks += (int)cdiv_u(bin.q_count, per_block);
+      const size_t need = (size_t)per_block * group_lds_doubles(bin.max_S) * sizeof(double);
+      if (need > lds_bytes) lds_bytes = need;
+    }
     if (lds_bytes > 160 * 1024) return hipErrorInvalidValue;
-    const dim3 grid(cdiv_u(bin.q_count, per_block));
+    if (lds_bytes > 64 * 1024) {
+      e = nl.dim_split == 4 ? hipFuncSetAttribute((const void*)optimize_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes)
+                            : hipFuncSetAttribute((const void*)optimize_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+      if (e != hipSuccess) return e;
+    }
     if (nl.dim_split == 4)
-      hipLaunchKernelGGL(optimize_kernel<4>, grid, dim3(64), lds_bytes, stream, b, prm, bin.group, bin.q_begin,
-                         bin.q_count, bin.max_S, mask, vals, seg_times, nl.d_opt_status);
+      hipLaunchKernelGGL(optimize_kernel<4>, dim3(blocks), dim3(64), lds_bytes, stream, b, prm, bt, mask, vals, seg_times,
+                         nl.d_opt_status);
     else
-      hipLaunchKernelGGL(optimize_kernel<1>, grid, dim3(64), lds_bytes, stream, b, prm, bin.group, bin.q_begin,
-                         bin.q_count, bin.max_S, mask, vals, seg_times, nl.d_opt_status);
+      hipLaunchKernelGGL(optimize_kernel<1>, dim3(blocks), dim3(64), lds_bytes, stream, b, prm, bt, mask, vals, seg_times,
+                         nl.d_opt_status);
     if ((e = hipGetLastError()) != hipSuccess) return e;
   }
   // 2. trajectory of the last evaluated point (scaleSegmentTimesWithViolation works on poly_opt_'s state)
