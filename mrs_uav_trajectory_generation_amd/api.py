@@ -20,6 +20,8 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libmrs_tg.so")
 
 TIME_ALLOC_NONE = -1
+TIME_ALLOC_SQUARED_TIME = 0
+TIME_ALLOC_RICHTER_TIME = 1
 TIME_ALLOC_MELLINGER = 2
 FLAG_FUSED_ASSEMBLY = 1
 
@@ -34,7 +36,9 @@ class Options(C.Structure):
     _fields_ = [("derivative_to_optimize", C.c_int32), ("time_alloc_method", C.c_int32),
                 ("estimate_times", C.c_int32), ("max_iterations", C.c_int32),
                 ("f_rel", C.c_double), ("f_abs", C.c_double), ("x_rel", C.c_double), ("x_abs", C.c_double),
-                ("sampling_dt", C.c_double), ("sample_capacity", C.c_int32), ("flags", C.c_int32)]
+                ("sampling_dt", C.c_double), ("sample_capacity", C.c_int32), ("flags", C.c_int32),
+                ("time_penalty", C.c_double), ("soft_constraint_weight", C.c_double),
+                ("use_soft_constraints", C.c_int32), ("reserved_", C.c_int32), ("initial_stepsize_rel", C.c_double)]
 
 
 class PolicyOptions(C.Structure):

@@ -114,9 +114,11 @@ int check_options(mrs_tg_ctx* ctx, const mrs_tg_options* opt) {
   if (!opt) return fail(ctx, MRS_TG_ERR_INVALID_ARG, "options is NULL");
   if (opt->derivative_to_optimize < 0 || opt->derivative_to_optimize > 4)
     return fail(ctx, MRS_TG_ERR_INVALID_ARG, "derivative_to_optimize %d outside [0, 4]", opt->derivative_to_optimize);
-  if (opt->time_alloc_method != MRS_TG_TIME_ALLOC_NONE && opt->time_alloc_method != MRS_TG_TIME_ALLOC_MELLINGER)
+  if (opt->time_alloc_method != MRS_TG_TIME_ALLOC_NONE && opt->time_alloc_method != MRS_TG_TIME_ALLOC_MELLINGER &&
+      opt->time_alloc_method != MRS_TG_TIME_ALLOC_SQUARED_TIME && opt->time_alloc_method != MRS_TG_TIME_ALLOC_RICHTER_TIME)
     return fail(ctx, MRS_TG_ERR_UNSUPPORTED,
-                "time_alloc_method %d is not implemented on the HIP path (supported: -1 fixed times, 2 Mellinger)",
+                "time_alloc_method %d is not implemented on the HIP path (supported: -1 fixed times, 0 / 1 time-only "
+                "gradient-free, 2 Mellinger)",
                 opt->time_alloc_method);
   if (opt->sampling_dt > 0 && opt->sample_capacity < 0)
     return fail(ctx, MRS_TG_ERR_INVALID_ARG, "negative sample_capacity");
@@ -178,6 +180,10 @@ void mrs_tg_default_options(mrs_tg_options* opt) {
   opt->sampling_dt = 0.0;
   opt->sample_capacity = 0;
   opt->flags = 0;
+  opt->time_penalty = 100.0;           // config/private/trajectory_generation.yaml:4
+  opt->soft_constraint_weight = 1.5;   // :6
+  opt->use_soft_constraints = 1;       // :5
+  opt->initial_stepsize_rel = 0.1;     // src/mrs_trajectory_generation.cpp:893
 }
 
 const char* mrs_tg_last_error(const mrs_tg_ctx* ctx) {
@@ -373,8 +379,8 @@ int mrs_tg_plan_solve(mrs_tg_plan* plan, const double* wp, const uint8_t* mask, 
   if (rc != MRS_TG_OK) return rc;
   if (!mask || !vals || !seg_times || !coeffs || !status)
     return fail(ctx, MRS_TG_ERR_INVALID_ARG, "fixed_mask, fixed_values, seg_times, coeffs_out and status_out are required");
-  if ((opt->estimate_times || opt->time_alloc_method == MRS_TG_TIME_ALLOC_MELLINGER) && !limits)
-    return fail(ctx, MRS_TG_ERR_INVALID_ARG, "limits are required for time estimation and for the Mellinger mode");
+  if ((opt->estimate_times || opt->time_alloc_method != MRS_TG_TIME_ALLOC_NONE) && !limits)
+    return fail(ctx, MRS_TG_ERR_INVALID_ARG, "limits are required for time estimation and for every time-allocation mode");
   if (opt->estimate_times && !wp) return fail(ctx, MRS_TG_ERR_INVALID_ARG, "waypoints are required when estimate_times is set");
   if (opt->sampling_dt > 0 && !n_samples) return fail(ctx, MRS_TG_ERR_INVALID_ARG, "n_samples_out is required when sampling");
   HIP_TRY(ctx, hipSetDevice(ctx->device));
@@ -382,7 +388,22 @@ int mrs_tg_plan_solve(mrs_tg_plan* plan, const double* wp, const uint8_t* mask, 
   const int d = opt->derivative_to_optimize;
   if (opt->estimate_times) HIP_TRY(ctx, mrs_tg::launch_estimate_times(b, wp, limits, seg_times, ctx->stream));
 
-  if (opt->time_alloc_method == MRS_TG_TIME_ALLOC_MELLINGER) {
+  if (opt->time_alloc_method == MRS_TG_TIME_ALLOC_SQUARED_TIME || opt->time_alloc_method == MRS_TG_TIME_ALLOC_RICHTER_TIME) {
+    mrs_tg::DfoParams prm;
+    prm.derivative = d;
+    prm.mode = opt->time_alloc_method;
+    prm.max_iterations = opt->max_iterations;
+    prm.f_rel = opt->f_rel;
+    prm.f_abs = opt->f_abs;
+    prm.x_rel = opt->x_rel;
+    prm.x_abs = opt->x_abs;
+    prm.time_penalty = opt->time_penalty;
+    prm.soft_weight = opt->soft_constraint_weight;
+    prm.use_soft = opt->use_soft_constraints;
+    prm.initial_stepsize_rel = opt->initial_stepsize_rel;
+    ProfileScope ps(ctx, 2);
+    HIP_TRY(ctx, mrs_tg::launch_dfo(plan->nl, b, prm, mask, vals, limits, seg_times, coeffs, status, cost, ctx->stream));
+  } else if (opt->time_alloc_method == MRS_TG_TIME_ALLOC_MELLINGER) {
     mrs_tg::NonlinearParams prm;
     prm.derivative = d;
     prm.max_iterations = opt->max_iterations;

@@ -18,6 +18,16 @@ struct NonlinearParams {
 // Paths are sorted by segment count (longest first), so every lane-group class is a contiguous range
 // of positions q.  A path with S segments uses a group of G = min(64, pow2ceil(S + 1)) lanes: lane k of
 // the group evaluates the cost at the k-th perturbed time vector (k = 0: unperturbed).
+struct DfoParams {
+  int derivative;
+  int mode;            // 0 squared time, 1 Richter time
+  int max_iterations;
+  double f_rel, f_abs, x_rel, x_abs;
+  double time_penalty, soft_weight;
+  int use_soft;
+  double initial_stepsize_rel;
+};
+
 struct NonlinearBin {
   int group;      // lanes per path: 4, 8, 16, 32 or 64
   int q_begin;    // first position of the bin
@@ -32,6 +42,9 @@ struct NonlinearPlan {
   size_t ws_doubles = 0;
   int32_t* d_opt_status = nullptr; // stopping reason of the outer loop per path
   double* d_maxima = nullptr;      // [n_segments][9] per-segment maxima
+  double* d_dfo_vec = nullptr;     // modes 0/1: x0 | best | h, 3 * n_segments doubles
+  double* d_dfo_f = nullptr;       // modes 0/1: fbest | f_sweep, 2 * n_paths doubles
+  int32_t* d_dfo_state = nullptr;  // modes 0/1: phase, i, sg, neval, improved, ret, done per path
 };
 
 int nonlinear_plan_build(NonlinearPlan& nl, const std::vector<int32_t>& seg_offsets, const std::vector<int32_t>& order);
@@ -40,6 +53,9 @@ void nonlinear_plan_free(NonlinearPlan& nl);
 hipError_t launch_nonlinear(NonlinearPlan& nl, const BatchView& b, const NonlinearParams& prm, const uint8_t* mask,
                             const double* vals, const double* limits, double* seg_times, double* coeffs,
                             int32_t* status, double* cost, hipStream_t stream);
+hipError_t launch_dfo(NonlinearPlan& nl, const BatchView& b, const DfoParams& prm, const uint8_t* mask, const double* vals,
+                      const double* limits, double* seg_times, double* coeffs, int32_t* status, double* cost,
+                      hipStream_t stream);
 hipError_t launch_cost_gradient(NonlinearPlan& nl, const BatchView& b, int d, const uint8_t* mask, const double* vals,
                                 const double* seg_times, double* cost, double* grad, hipStream_t stream);
 hipError_t launch_segment_maxima(const BatchView& b, const double* coeffs, const double* seg_times, double* maxima,

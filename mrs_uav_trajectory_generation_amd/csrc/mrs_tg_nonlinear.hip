@@ -586,6 +586,223 @@ __global__ __launch_bounds__(64) void cost_gradient_kernel(BatchView b, int d, i
 }
 
 // ---------------------------------------------------------------------------------------------
+// gradient-free modes 0 / 1 (objectiveFunctionTime, nonlinear_impl.h:568-614): per evaluation a fused solve,
+// the 4-D magnitude maxima of v, a, j (computeMaximumOfMagnitude, linear_impl.h:478-508: all four
+// dimensions in one norm, quirk B6) and one step of the search's state machine.  The search is this
+// project's own ("MRS-DFO"; CPU statement in oracle/mto_dfo.c): NLopt's BOBYQA is not reproduced.
+
+// maxima4[seg * 3 + (k-1)] = max over the segment of |p^(k)| over x, y, z, heading
+__global__ __launch_bounds__(64) void segment_maxima4_kernel(int n_segments, const double* __restrict__ coeffs,
+                                                             const double* __restrict__ seg_times,
+                                                             double* __restrict__ maxima4) {
+  const int s = blockIdx.x * 64 + threadIdx.x;
+  if (s >= n_segments) return;
+  const int k = blockIdx.y + 1;
+  const double* c = coeffs + (size_t)s * kD * kN;
+  const double T = seg_times[s];
+  double cb[kD][kN];
+  double tp = 1.0;
+#pragma unroll
+  for (int j = 0; j < kN; ++j) {
+#pragma unroll
+    for (int q = 0; q < kD; ++q) cb[q][j] = c[q * kN + j] * tp;
+    tp *= T;
+  }
+  const double ti = 1.0 / T;
+  double m2, scale;
+  if (k == 1) {
+    m2 = max_mag2<1, kD>(cb);
+    scale = ti;
+  } else if (k == 2) {
+    m2 = max_mag2<2, kD>(cb);
+    scale = ti * ti;
+  } else {
+    m2 = max_mag2<3, kD>(cb);
+    scale = ti * ti * ti;
+  }
+  maxima4[(size_t)s * 3 + (k - 1)] = sqrt(m2) * scale;
+}
+
+enum { kDfoFirst = -1, kDfoInitPlus = 0, kDfoInitMinus = 1, kDfoCompass = 2 };
+// per-path int state: [0] phase [1] i [2] sg [3] neval [4] improved [5] ret [6] done
+constexpr int kDfoInts = 7;
+
+__global__ __launch_bounds__(64) void dfo_init_kernel(BatchView b, DfoParams prm, const double* __restrict__ seg_times,
+                                                      double* __restrict__ vec, double* __restrict__ fvals,
+                                                      int32_t* __restrict__ state) {
+  const int p = blockIdx.x * 64 + threadIdx.x;
+  if (p >= b.n_paths) return;
+  const int s0 = b.seg_offsets[p], n = b.seg_offsets[p + 1] - s0;
+  const size_t nS = (size_t)b.n_segments;
+  bool bad = false;
+  for (int i = 0; i < n; ++i) {
+    const double t = seg_times[s0 + i];
+    if (t < kTimeLowerBound) bad = true;
+    vec[s0 + i] = t;                                    // x0
+    vec[nS + s0 + i] = t;                               // best
+    vec[2 * nS + s0 + i] = prm.initial_stepsize_rel * t;  // h
+  }
+  int32_t* st = state + (size_t)p * kDfoInts;
+  st[0] = kDfoFirst;
+  st[1] = 0;
+  st[2] = 0;
+  st[3] = 0;
+  st[4] = 0;
+  st[5] = bad ? -2 : -1;
+  st[6] = bad ? 1 : 0;
+  fvals[p] = 0.0;
+  fvals[b.n_paths + p] = 0.0;
+}
+
+// consume the objective of the trial currently in seg_times, write the next trial there
+__global__ __launch_bounds__(64) void dfo_step_kernel(BatchView b, DfoParams prm, const double* __restrict__ limits,
+                                                      const double* __restrict__ cost, const double* __restrict__ maxima4,
+                                                      double* __restrict__ seg_times, double* __restrict__ vec,
+                                                      double* __restrict__ fvals, int32_t* __restrict__ state) {
+  const int p = blockIdx.x * 64 + threadIdx.x;
+  if (p >= b.n_paths) return;
+  int32_t* st = state + (size_t)p * kDfoInts;
+  if (st[6]) return;
+  const int s0 = b.seg_offsets[p], n = b.seg_offsets[p + 1] - s0;
+  const size_t nS = (size_t)b.n_segments;
+  double* x = seg_times + s0;
+  double* x0 = vec + s0;
+  double* best = vec + nS + s0;
+  double* h = vec + 2 * nS + s0;
+  // objective = J_d + time penalty + soft constraints
+  double total = 0.0, mx[3] = {-DBL_MAX, -DBL_MAX, -DBL_MAX};
+  for (int i = 0; i < n; ++i) {
+    total += x[i];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) mx[k] = fmax(mx[k], maxima4[(size_t)(s0 + i) * 3 + k]);
+  }
+  double f = cost[p] + ((prm.mode == 1) ? total * prm.time_penalty : total * total * prm.time_penalty);
+  if (prm.use_soft) {
+    const double* lim = limits + (size_t)p * 9;
+    double soft = 0.0;
+#pragma unroll
+    for (int dim = 0; dim < 4; ++dim) {
+      const int grp = (dim <= 1) ? 0 : (dim == 2 ? 1 : 2);
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        const double value = lim[k * 3 + grp];
+        soft += fmin(1.0e12, exp((mx[k] - value) / value * prm.soft_weight));
+      }
+    }
+    f += soft;
+  }
+  // ---- state machine (same transitions as oracle/mto_dfo.c::dfo_step)
+  int phase = st[0], ci = st[1], sg = st[2], neval = st[3], improved = st[4];
+  double fbest = fvals[p], f_sweep = fvals[b.n_paths + p];
+  bool accepted = false;
+  ++neval;
+  if (phase == kDfoFirst) {
+    fbest = f;
+  } else if (f < fbest) {
+    fbest = f;
+    for (int k = 0; k < n; ++k) best[k] = x[k];
+    improved = 1;
+    accepted = true;
+  }
+  int ret = -1;
+  bool done = false;
+  if (prm.max_iterations > 0 && neval >= prm.max_iterations) {
+    ret = 5;
+    done = true;
+  }
+  while (!done) {
+    if (phase == kDfoFirst) {
+      phase = kDfoInitPlus;
+      ci = 0;
+    } else if (phase == kDfoInitPlus) {
+      if (++ci >= n) {
+        phase = kDfoInitMinus;
+        ci = 0;
+      }
+    } else if (phase == kDfoInitMinus) {
+      if (++ci >= n) {
+        phase = kDfoCompass;
+        for (int k = 0; k < n; ++k) h[k] *= 0.5;
+        ci = 0;
+        sg = 0;
+        f_sweep = fbest;
+        improved = 0;
+        accepted = false;
+      }
+    } else {
+      if (sg == 0 && !accepted) {
+        sg = 1;
+      } else {
+        sg = 0;
+        ++ci;
+      }
+      accepted = false;
+      if (ci >= n) {
+        if (improved) {
+          if (relstop(f_sweep, fbest, prm.f_rel, prm.f_abs)) {
+            ret = 3;
+            done = true;
+            break;
+          }
+        } else {
+          bool all_small = true;
+          for (int k = 0; k < n; ++k) {
+            h[k] *= 0.5;
+            if (!(h[k] < prm.x_abs || h[k] < prm.x_rel * fabs(best[k]))) all_small = false;
+          }
+          if (all_small) {
+            ret = 4;
+            done = true;
+            break;
+          }
+        }
+        f_sweep = fbest;
+        improved = 0;
+        ci = 0;
+        sg = 0;
+      }
+    }
+    if (phase == kDfoInitPlus) {
+      for (int k = 0; k < n; ++k) x[k] = x0[k];
+      x[ci] = x0[ci] + h[ci];
+      break;
+    }
+    if (phase == kDfoInitMinus) {
+      for (int k = 0; k < n; ++k) x[k] = x0[k];
+      x[ci] = (x0[ci] - h[ci] >= kTimeLowerBound) ? x0[ci] - h[ci] : x0[ci] + 2.0 * h[ci];
+      break;
+    }
+    double t = best[ci] + (sg == 0 ? h[ci] : -h[ci]);
+    if (t < kTimeLowerBound) t = kTimeLowerBound;
+    if (t == best[ci]) continue;
+    for (int k = 0; k < n; ++k) x[k] = best[k];
+    x[ci] = t;
+    break;
+  }
+  st[0] = phase;
+  st[1] = ci;
+  st[2] = sg;
+  st[3] = neval;
+  st[4] = improved;
+  if (done) {
+    st[5] = ret;
+    st[6] = 1;
+  }
+  fvals[p] = fbest;
+  fvals[b.n_paths + p] = f_sweep;
+}
+
+// final status: -2 stays (position-free vertex), a rejected start surfaces as FAILURE -1, else the stopping reason
+__global__ __launch_bounds__(64) void dfo_finalize_kernel(int n_paths, const int32_t* __restrict__ state,
+                                                          int32_t* __restrict__ status) {
+  const int p = blockIdx.x * 64 + threadIdx.x;
+  if (p >= n_paths) return;
+  if (status[p] == -2) return;
+  const int ret = state[(size_t)p * kDfoInts + 5];
+  status[p] = (ret == -2) ? -1 : ret;
+}
+
+// ---------------------------------------------------------------------------------------------
 // host side
 
 // split the four dimensions over lanes while the batch is too small to fill the machine otherwise
@@ -622,6 +839,12 @@ void nonlinear_plan_free(NonlinearPlan& nl) {
   if (nl.d_ws) (void)hipFree(nl.d_ws);
   if (nl.d_opt_status) (void)hipFree(nl.d_opt_status);
   if (nl.d_maxima) (void)hipFree(nl.d_maxima);
+  if (nl.d_dfo_vec) (void)hipFree(nl.d_dfo_vec);
+  if (nl.d_dfo_f) (void)hipFree(nl.d_dfo_f);
+  if (nl.d_dfo_state) (void)hipFree(nl.d_dfo_state);
+  nl.d_dfo_vec = nullptr;
+  nl.d_dfo_f = nullptr;
+  nl.d_dfo_state = nullptr;
   nl.d_ws = nullptr;
   nl.d_opt_status = nullptr;
   nl.d_maxima = nullptr;
@@ -700,6 +923,44 @@ hipError_t launch_nonlinear(NonlinearPlan& nl, const BatchView& b, const Nonline
   // 4. updateSegmentTimes + solveLinear with the scaled times (nonlinear_impl.h:405-408), final status
   return launch_solve_linear(b, prm.derivative, true, mask, vals, seg_times, nullptr, nullptr, nl.d_ws, coeffs, status,
                              cost, nl.d_opt_status, stream);
+}
+
+hipError_t launch_dfo(NonlinearPlan& nl, const BatchView& b, const DfoParams& prm, const uint8_t* mask, const double* vals,
+                      const double* limits, double* seg_times, double* coeffs, int32_t* status, double* cost,
+                      hipStream_t stream) {
+  if (b.n_paths == 0) return hipSuccess;
+  hipError_t e = ensure_buffers(nl, b);
+  if (e != hipSuccess) return e;
+  const size_t nS = (size_t)(b.n_segments > 0 ? b.n_segments : 1), P = (size_t)b.n_paths;
+  if (!nl.d_dfo_vec && (e = hipMalloc(&nl.d_dfo_vec, sizeof(double) * 3 * nS)) != hipSuccess) return e;
+  if (!nl.d_dfo_f && (e = hipMalloc(&nl.d_dfo_f, sizeof(double) * 2 * P)) != hipSuccess) return e;
+  if (!nl.d_dfo_state && (e = hipMalloc(&nl.d_dfo_state, sizeof(int32_t) * kDfoInts * P)) != hipSuccess) return e;
+  // the maxima buffer (9 doubles per segment) doubles as the 3-per-segment buffer of these modes
+  double* cost_buf = cost ? cost : nl.d_dfo_f;  // J_d per evaluation (needs a real buffer)
+  double* cost_eval = cost;
+  if (!cost_eval) return hipErrorInvalidValue;  // the ABI always passes one on this path
+  (void)cost_buf;
+  const unsigned pblocks = cdiv_u(b.n_paths, 64);
+  hipLaunchKernelGGL(dfo_init_kernel, dim3(pblocks), dim3(64), 0, stream, b, prm, seg_times, nl.d_dfo_vec, nl.d_dfo_f,
+                     nl.d_dfo_state);
+  if ((e = hipGetLastError()) != hipSuccess) return e;
+  // NLopt's maxeval <= 0 means "no limit"; the host loop needs one
+  const int rounds = prm.max_iterations > 0 ? prm.max_iterations : 1000;
+  for (int r = 0; r < rounds; ++r) {
+    if ((e = launch_solve_linear(b, prm.derivative, true, mask, vals, seg_times, nullptr, nullptr, nl.d_ws, coeffs, status,
+                                 cost_eval, nullptr, stream)) != hipSuccess)
+      return e;
+    hipLaunchKernelGGL(segment_maxima4_kernel, dim3(cdiv_u(b.n_segments, 64), 3), dim3(64), 0, stream, b.n_segments, coeffs,
+                       seg_times, nl.d_maxima);
+    if ((e = hipGetLastError()) != hipSuccess) return e;
+    hipLaunchKernelGGL(dfo_step_kernel, dim3(pblocks), dim3(64), 0, stream, b, prm, limits, cost_eval, nl.d_maxima, seg_times,
+                       nl.d_dfo_vec, nl.d_dfo_f, nl.d_dfo_state);
+    if ((e = hipGetLastError()) != hipSuccess) return e;
+  }
+  // paths that stopped early were re-solved at their final point every round; paths that used the whole budget
+  // hold the coefficients of their last trial: both are "the last evaluated point"
+  hipLaunchKernelGGL(dfo_finalize_kernel, dim3(pblocks), dim3(64), 0, stream, b.n_paths, nl.d_dfo_state, status);
+  return hipGetLastError();
 }
 
 hipError_t launch_cost_gradient(NonlinearPlan& nl, const BatchView& b, int d, const uint8_t* mask, const double* vals,

@@ -128,6 +128,10 @@ typedef struct {
   int estimate_times;         /* 1: seg_times from the Euclidean estimator, 0: as given */
   mto_nlopt_params nlopt;
   double sampling_dt;         /* <= 0: no sampling */
+  double time_penalty;        /* modes 0 / 1 */
+  int use_soft_constraints;
+  double soft_constraint_weight;
+  double initial_stepsize_rel;
 } mto_options;
 
 /* Batch driver in the C-ABI's CSR layout (include/mrs_tg.h). Single thread when n_threads<=1,
@@ -139,6 +143,28 @@ int mto_solve_batch(int n_paths, const int32_t* seg_offsets, const double* waypo
                     int32_t* status_out, double* cost_out, int32_t* n_samples_out, double* samples_out,
                     int sample_capacity, int n_threads);
 
+
+/* ---- gradient-free time-allocation modes 0 / 1 (mto_dfo.c) ---------------------------------- */
+typedef struct {
+  int time_alloc_method;        /* 0 kSquaredTime, 1 kRichterTime (nonlinear.h:92-100) */
+  mto_nlopt_params nlopt;
+  double time_penalty;          /* nonlinear.h:70; param time_penalty */
+  int use_soft_constraints;     /* param soft_constraints_enabled */
+  double soft_constraint_weight;
+  double initial_stepsize_rel;  /* 0.1, src/mrs_trajectory_generation.cpp:893 */
+} mto_dfo_params;
+
+/* computeMaximumOfMagnitude over all four dimensions (linear_impl.h:478-508) */
+double mto_max_of_magnitude(int n_seg, const double* coeffs, const double* seg_times, int derivative);
+/* evaluateMaximumMagnitudeAsSoftConstraint over the 12 registered constraints (nonlinear_impl.h:740-762,
+ * src/mrs_trajectory_generation.cpp:1067-1081); maxima[k-1] = 4-D maximum of derivative k */
+double mto_soft_constraint_cost(const double maxima[3], const double* limits9, double weight);
+/* objectiveFunctionTime nonlinear_impl.h:568-614; parts_out [3] = trajectory, time, soft (may be NULL) */
+double mto_objective_time(const mto_path* path, const double* seg_times, const double* limits9, const mto_dfo_params* prm,
+                          double* parts_out);
+/* own derivative-free search standing in for NLopt LN_BOBYQA; x in/out = last evaluated point */
+int mto_optimize_time_dfo(const mto_path* path, const double* limits9, const mto_dfo_params* prm, double* x,
+                          int* n_eval_out, double* f_last_out);
 
 /* ---- path-policy layer (SURVEY.md 8 f: the rows ranked "next") ------------------------------ */
 typedef struct {

@@ -1,0 +1,212 @@
+/*
+ * mto_dfo.c -- CPU ORACLE (test infrastructure): the gradient-free time-allocation modes 0 / 1
+ * (kSquaredTime, kRichterTime).  See mrs_tg_oracle.h for the rules that apply to oracle/.
+ *
+ * Follows (relative to /root/reference/include/eth_trajectory_generation/impl/):
+ *   polynomial_optimization_nonlinear_impl.h:121-157   optimizeTime (NLopt driver set-up: bounds, initial step)
+ *   polynomial_optimization_nonlinear_impl.h:568-614   objectiveFunctionTime
+ *   polynomial_optimization_nonlinear_impl.h:725-762   evaluateMaximumMagnitudeConstraint / ...AsSoftConstraint
+ *   polynomial_optimization_linear_impl.h:478-508      computeMaximumOfMagnitude
+ *   src/mrs_trajectory_generation.cpp:1067-1081        the 12 registered magnitude constraints
+ *
+ * The reference minimises this objective with NLopt's LN_BOBYQA (un-vendored).  BOBYQA is not restated; the
+ * driver below is this project's own deterministic derivative-free search ("MRS-DFO"),
+ * which the HIP path implements identically: Powell's initial interpolation sweep x0 +- h_i e_i (the only part
+ * BOBYQA reaches with the shipping max_iterations = 10), then a compass search with step halving.  As with
+ * mode 2 the point that is kept is the LAST EVALUATED one (the optimiser object's state), and there is no
+ * feasibility scaling in these modes.
+ */
+#include <float.h>
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "mrs_tg_oracle.h"
+
+#define N MTO_N
+#define DIM MTO_D
+
+double mto_max_of_magnitude(int n_seg, const double* coeffs, const double* seg_times, int derivative) {
+  /* computeMaximumOfMagnitude: per segment the candidates {0} + {t_start, t_end, real roots in range} of the
+   * 4-D norm, and finally the end of the last segment (linear_impl.h:478-508) */
+  static const int dims[4] = {0, 1, 2, 3};
+  double best = -DBL_MAX;
+  for (int s = 0; s < n_seg; ++s) {
+    /* mto_segment_max_magnitude covers {0, T} and the roots; the extra leading 0.0 candidate is a duplicate */
+    const double m = mto_segment_max_magnitude(coeffs + (size_t)s * DIM * N, seg_times[s], derivative, dims, 4);
+    if (m > best) best = m;
+  }
+  return best;
+}
+
+double mto_soft_constraint_cost(const double maxima[3], const double* limits9, double weight) {
+  /* 12 constraints: dimensions 0,1 -> horizontal limits, 2 -> vertical, 3 -> heading; every one of them is
+   * evaluated with the 4-D maximum of its derivative (quirk B6) */
+  double cost = 0.0;
+  for (int dim = 0; dim < 4; ++dim) {
+    const int grp = (dim <= 1) ? 0 : (dim == 2 ? 1 : 2);
+    for (int k = 0; k < 3; ++k) {
+      const double value = limits9[k * 3 + grp];
+      const double rel = (maxima[k] - value) / value;
+      const double c = exp(rel * weight);
+      cost += (c < 1.0e12) ? c : 1.0e12;
+    }
+  }
+  return cost;
+}
+
+double mto_objective_time(const mto_path* path, const double* seg_times, const double* limits9, const mto_dfo_params* prm,
+                          double* parts_out /* [3] trajectory, time, soft; may be NULL */) {
+  const int S = path->n_seg;
+  double* coeffs = (double*)malloc(sizeof(double) * (size_t)S * DIM * N);
+  mto_solve_linear(path, seg_times, coeffs);
+  const double cost_traj = mto_compute_cost(S, path->derivative_to_optimize, seg_times, coeffs);
+  double total = 0.0;
+  for (int i = 0; i < S; ++i) total += seg_times[i];
+  const double cost_time = (prm->time_alloc_method == 1) ? total * prm->time_penalty : total * total * prm->time_penalty;
+  double cost_soft = 0.0;
+  if (prm->use_soft_constraints) {
+    double mx[3];
+    for (int k = 1; k <= 3; ++k) mx[k - 1] = mto_max_of_magnitude(S, coeffs, seg_times, k);
+    cost_soft = mto_soft_constraint_cost(mx, limits9, prm->soft_constraint_weight);
+  }
+  free(coeffs);
+  if (parts_out) {
+    parts_out[0] = cost_traj;
+    parts_out[1] = cost_time;
+    parts_out[2] = cost_soft;
+  }
+  return cost_traj + cost_time + cost_soft;
+}
+
+static int relstop(double vold, double vnew, double reltol, double abstol) {
+  if (isinf(vold)) return 0;
+  const double dv = fabs(vnew - vold);
+  return dv < abstol || dv < reltol * (fabs(vnew) + fabs(vold)) * 0.5 || (reltol > 0 && vnew == vold);
+}
+
+/* ---- MRS-DFO as an explicit state machine: one objective evaluation per step -------------------------- */
+
+enum { DFO_FIRST = -1, DFO_INIT_PLUS = 0, DFO_INIT_MINUS = 1, DFO_COMPASS = 2 };
+
+typedef struct {
+  int phase, i, sg, neval, improved, ret, done;
+  double fbest, f_sweep;
+} dfo_state;
+
+/* consume the objective value f of the trial held in x (the last evaluated point); write the next trial into x.
+ * x0, best, h are the per-path vectors of the search. */
+static void dfo_step(dfo_state* st, int n, double f, double* x, double* x0, double* best, double* h,
+                     const mto_dfo_params* prm) {
+  const double lb = 0.01;
+  const int maxeval = prm->nlopt.max_iterations;
+  int accepted = 0;
+  st->neval++;
+  if (st->phase == DFO_FIRST) {
+    st->fbest = f;
+  } else if (f < st->fbest) {
+    st->fbest = f;
+    memcpy(best, x, sizeof(double) * (size_t)n);
+    st->improved = 1;
+    accepted = 1;
+  }
+  if (maxeval > 0 && st->neval >= maxeval) {
+    st->ret = MTO_MAXEVAL_REACHED;
+    st->done = 1;
+    return;
+  }
+  for (;;) {
+    if (st->phase == DFO_FIRST) {
+      st->phase = DFO_INIT_PLUS;
+      st->i = 0;
+    } else if (st->phase == DFO_INIT_PLUS) {
+      if (++st->i >= n) {
+        st->phase = DFO_INIT_MINUS;
+        st->i = 0;
+      }
+    } else if (st->phase == DFO_INIT_MINUS) {
+      if (++st->i >= n) {
+        st->phase = DFO_COMPASS;
+        for (int k = 0; k < n; ++k) h[k] *= 0.5;
+        st->i = 0;
+        st->sg = 0;
+        st->f_sweep = st->fbest;
+        st->improved = 0;
+        accepted = 0;
+      }
+    } else { /* compass: advance (coordinate, sign) */
+      if (st->sg == 0 && !accepted) {
+        st->sg = 1;
+      } else {
+        st->sg = 0;
+        ++st->i;
+      }
+      accepted = 0;
+      if (st->i >= n) { /* end of a sweep */
+        if (st->improved) {
+          if (relstop(st->f_sweep, st->fbest, prm->nlopt.f_rel, prm->nlopt.f_abs)) {
+            st->ret = MTO_FTOL_REACHED;
+            st->done = 1;
+            return;
+          }
+        } else {
+          int all_small = 1;
+          for (int k = 0; k < n; ++k) {
+            h[k] *= 0.5;
+            if (!(h[k] < prm->nlopt.x_abs || h[k] < prm->nlopt.x_rel * fabs(best[k]))) all_small = 0;
+          }
+          if (all_small) {
+            st->ret = MTO_XTOL_REACHED;
+            st->done = 1;
+            return;
+          }
+        }
+        st->f_sweep = st->fbest;
+        st->improved = 0;
+        st->i = 0;
+        st->sg = 0;
+      }
+    }
+    /* build the trial of the current (phase, i, sg) */
+    const int i = st->i;
+    if (st->phase == DFO_INIT_PLUS) {
+      memcpy(x, x0, sizeof(double) * (size_t)n);
+      x[i] = x0[i] + h[i];
+      return;
+    }
+    if (st->phase == DFO_INIT_MINUS) {
+      memcpy(x, x0, sizeof(double) * (size_t)n);
+      x[i] = (x0[i] - h[i] >= lb) ? x0[i] - h[i] : x0[i] + 2.0 * h[i];
+      return;
+    }
+    double t = best[i] + (st->sg == 0 ? h[i] : -h[i]);
+    if (t < lb) t = lb;
+    if (t == best[i]) continue; /* nothing to try in this direction */
+    memcpy(x, best, sizeof(double) * (size_t)n);
+    x[i] = t;
+    return;
+  }
+}
+
+int mto_optimize_time_dfo(const mto_path* path, const double* limits9, const mto_dfo_params* prm, double* x,
+                          int* n_eval_out, double* f_last_out) {
+  const int n = path->n_seg;
+  double x0[MTO_MAX_SEG], h[MTO_MAX_SEG], best[MTO_MAX_SEG];
+  for (int i = 0; i < n; ++i) {
+    if (x[i] < 0.01) { /* NLopt rejects a start outside the bounds */
+      if (n_eval_out) *n_eval_out = 0;
+      return MTO_INVALID_ARGS;
+    }
+    x0[i] = best[i] = x[i];
+    h[i] = prm->initial_stepsize_rel * x[i]; /* nonlinear_impl.h:127-130 */
+  }
+  dfo_state st = {DFO_FIRST, 0, 0, 0, 0, MTO_FAILURE, 0, 0.0, 0.0};
+  double f = 0.0;
+  while (!st.done) {
+    f = mto_objective_time(path, x, limits9, prm, NULL);
+    dfo_step(&st, n, f, x, x0, best, h, prm);
+  }
+  if (n_eval_out) *n_eval_out = st.neval;
+  if (f_last_out) *f_last_out = f;
+  return st.ret;
+}

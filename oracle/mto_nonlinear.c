@@ -540,6 +540,14 @@ static int solve_one(int S, const double* wp, const uint8_t* mask, const double*
       mto_scale_segment_times_to_meet_constraints(S, coeffs, times, lim, NULL);
       mto_solve_linear(&path, times, coeffs);
     }
+  } else if (opt->time_alloc_method == 0 || opt->time_alloc_method == 1) {
+    /* optimizeTime (nonlinear_impl.h:121-157): no feasibility scaling afterwards; the trajectory is the one
+     * of the last objective evaluation */
+    mto_dfo_params dp = {opt->time_alloc_method, opt->nlopt, opt->time_penalty, opt->use_soft_constraints,
+                         opt->soft_constraint_weight, opt->initial_stepsize_rel};
+    int rc = mto_optimize_time_dfo(&path, lim, &dp, times, NULL, NULL);
+    status = (rc == MTO_INVALID_ARGS) ? MTO_FAILURE : rc;
+    mto_solve_linear(&path, times, coeffs);
   } else {
     if (mto_solve_linear(&path, times, coeffs) != 0) status = MTO_FAILURE;
   }

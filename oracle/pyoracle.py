@@ -33,7 +33,14 @@ class NloptParams(C.Structure):
 
 class Options(C.Structure):
     _fields_ = [("derivative_to_optimize", C.c_int), ("time_alloc_method", C.c_int),
-                ("estimate_times", C.c_int), ("nlopt", NloptParams), ("sampling_dt", C.c_double)]
+                ("estimate_times", C.c_int), ("nlopt", NloptParams), ("sampling_dt", C.c_double),
+                ("time_penalty", C.c_double), ("use_soft_constraints", C.c_int), ("soft_constraint_weight", C.c_double),
+                ("initial_stepsize_rel", C.c_double)]
+
+
+class DfoParams(C.Structure):
+    _fields_ = [("time_alloc_method", C.c_int), ("nlopt", NloptParams), ("time_penalty", C.c_double),
+                ("use_soft_constraints", C.c_int), ("soft_constraint_weight", C.c_double), ("initial_stepsize_rel", C.c_double)]
 
 
 class PolicyParams(C.Structure):
@@ -92,6 +99,12 @@ def lib():
         L.mto_solve_batch.argtypes = [C.c_int, C.POINTER(C.c_int32), dp, C.POINTER(C.c_uint8), dp, dp,
                                       C.POINTER(Options), dp, dp, C.POINTER(C.c_int32), dp,
                                       C.POINTER(C.c_int32), dp, C.c_int, C.c_int]
+        L.mto_max_of_magnitude.restype = C.c_double
+        L.mto_max_of_magnitude.argtypes = [C.c_int, dp, dp, C.c_int]
+        L.mto_objective_time.restype = C.c_double
+        L.mto_objective_time.argtypes = [C.POINTER(_Path), dp, dp, C.POINTER(DfoParams), dp]
+        L.mto_optimize_time_dfo.restype = C.c_int
+        L.mto_optimize_time_dfo.argtypes = [C.POINTER(_Path), dp, C.POINTER(DfoParams), dp, C.POINTER(C.c_int), dp]
         L.mto_default_policy_params.argtypes = [C.POINTER(PolicyParams)]
         L.mto_dist_from_segment.restype = C.c_double
         L.mto_dist_from_segment.argtypes = [dp, dp, dp]
@@ -109,6 +122,13 @@ def lib():
                                         C.POINTER(C.c_int)]
         _lib = L
     return _lib
+
+
+def make_options(deriv, time_alloc_method, estimate_times, max_iterations, sampling_dt, time_penalty=100.0,
+                 use_soft_constraints=1, soft_constraint_weight=1.5, initial_stepsize_rel=0.1):
+    # time_penalty 100, soft weight 1.5: /root/reference/config/private/trajectory_generation.yaml:4-6
+    return Options(deriv, time_alloc_method, int(estimate_times), default_nlopt(max_iterations), float(sampling_dt),
+                   float(time_penalty), int(use_soft_constraints), float(soft_constraint_weight), float(initial_stepsize_rel))
 
 
 def default_policy(**overrides):
@@ -133,7 +153,7 @@ def optimize_path(waypoints, stop_at=None, initial_state=None, limits=None, rela
                                     initial_state["jerk"]]))
     lim = _f64(limits)
     pol = policy or default_policy()
-    opt = Options(deriv, time_alloc_method, 1, default_nlopt(max_iterations), float(sampling_dt))
+    opt = make_options(deriv, time_alloc_method, 1, max_iterations, sampling_dt)
     out = np.zeros((capacity, 4))
     ns, nw, it = C.c_int(0), C.c_int(0), C.c_int(0)
     md = C.c_double(0)
@@ -202,6 +222,34 @@ def optimize_times(deriv, fixed_mask, fixed_values, seg_times, params=None):
     return rc, t, ne.value, fc.value
 
 
+def objective_time(deriv, fixed_mask, fixed_values, seg_times, limits, mode=0, time_penalty=100.0, soft=1, weight=1.5):
+    t = _f64(seg_times)
+    p = _make_path(t.size, deriv, fixed_mask, fixed_values)
+    prm = DfoParams(mode, default_nlopt(), float(time_penalty), int(soft), float(weight), 0.1)
+    parts = np.zeros(3)
+    lim = _f64(limits)
+    f = lib().mto_objective_time(C.byref(p), _dp(t), _dp(lim), C.byref(prm), _dp(parts))
+    return f, parts
+
+
+def optimize_times_dfo(deriv, fixed_mask, fixed_values, seg_times, limits, mode=0, max_iterations=10, time_penalty=100.0,
+                       soft=1, weight=1.5):
+    t = _f64(seg_times).copy()
+    p = _make_path(t.size, deriv, fixed_mask, fixed_values)
+    prm = DfoParams(mode, default_nlopt(max_iterations), float(time_penalty), int(soft), float(weight), 0.1)
+    ne = C.c_int(0)
+    fl = C.c_double(0)
+    lim = _f64(limits)
+    rc = lib().mto_optimize_time_dfo(C.byref(p), _dp(lim), C.byref(prm), _dp(t), C.byref(ne), C.byref(fl))
+    return rc, t, ne.value, fl.value
+
+
+def max_of_magnitude(coeffs, seg_times, derivative):
+    c = _f64(coeffs)
+    t = _f64(seg_times)
+    return lib().mto_max_of_magnitude(t.size, _dp(c), _dp(t), derivative)
+
+
 def find_roots(coeffs_increasing):
     c = _f64(coeffs_increasing)
     re = np.zeros(128)
@@ -255,7 +303,7 @@ def unwrap_heading(what, frm):
 
 def solve_batch(seg_offsets, waypoints, fixed_mask, fixed_values, limits, seg_times, *, deriv=4,
                 time_alloc_method=-1, estimate_times=False, max_iterations=10, sampling_dt=0.0,
-                sample_capacity=0, n_threads=1):
+                sample_capacity=0, n_threads=1, time_penalty=100.0, use_soft_constraints=1, soft_constraint_weight=1.5):
     """Batch driver in the C-ABI's CSR layout. Returns dict(times, coeffs, status, cost, n_samples, samples)."""
     so = np.ascontiguousarray(seg_offsets, dtype=np.int32)
     P = so.size - 1
@@ -270,7 +318,8 @@ def solve_batch(seg_offsets, waypoints, fixed_mask, fixed_values, limits, seg_ti
     cost = np.zeros(P)
     ns = np.zeros(P, dtype=np.int32)
     samples = np.zeros((P, max(sample_capacity, 1), D))
-    opt = Options(deriv, time_alloc_method, int(estimate_times), default_nlopt(max_iterations), float(sampling_dt))
+    opt = make_options(deriv, time_alloc_method, estimate_times, max_iterations, sampling_dt, time_penalty,
+                       use_soft_constraints, soft_constraint_weight)
     lib().mto_solve_batch(P, so.ctypes.data_as(C.POINTER(C.c_int32)), _dp(w), m.ctypes.data_as(C.POINTER(C.c_uint8)),
                           _dp(v), _dp(lim), C.byref(opt), _dp(t), _dp(coeffs),
                           status.ctypes.data_as(C.POINTER(C.c_int32)), _dp(cost),

@@ -38,7 +38,8 @@ def test_abi_version_and_default_options(lib):
     # config/private/trajectory_generation.yaml:10)
     assert (opt.f_rel, opt.x_rel, opt.max_iterations) == (0.05, 0.1, 10)
     assert opt.f_abs == -1.0 and opt.x_abs == -1.0 and opt.time_alloc_method == -1
-    assert C.sizeof(api.Options) == 64
+    assert C.sizeof(api.Options) == 96
+    assert (opt.time_penalty, opt.soft_constraint_weight, opt.use_soft_constraints, opt.initial_stepsize_rel) == (100.0, 1.5, 1, 0.1)
 
 
 def test_no_device_is_a_loud_error(lib):

@@ -1,0 +1,106 @@
+"""Oracle-side tests of the gradient-free time-allocation modes 0 / 1 (kSquaredTime / kRichterTime,
+nonlinear_impl.h:121-157, 568-614, 725-762): the objective's three parts against independent numpy
+arithmetic, and the invariants of the derivative-free search that stands in for NLopt's BOBYQA
+(DESIGN.md 5b).  No GPU."""
+import math
+
+import numpy as np
+import pytest
+
+from mrs_uav_trajectory_generation_amd import problem as pr
+from oracle import pyoracle as po
+from tests import util
+
+
+def _path(n_seg, seed):
+    batch = pr.random_batch(1, n_seg, seed0=seed)
+    t = util.oracle_times(batch)
+    _, m, v = batch.path(0)
+    return batch, m, v, t
+
+
+def _dense_max(coeffs, times, k, n=4001):
+    """max over the trajectory of the 4-D norm of derivative k, by dense sampling"""
+    best = 0.0
+    for s in range(len(times)):
+        for x in np.linspace(0.0, times[s], n):
+            best = max(best, float(np.linalg.norm(util.eval_poly(coeffs[s], x, k))))
+    return best
+
+
+@pytest.mark.parametrize("mode", [0, 1])
+def test_objective_parts(mode):
+    batch, m, v, t = _path(4, 11)
+    lim = pr.DEFAULT_LIMITS
+    f, parts = po.objective_time(4, m, v, t, lim, mode=mode, time_penalty=100.0, soft=1, weight=1.5)
+    c = po.solve_linear(4, m, v, t)
+    assert parts[0] == pytest.approx(po.compute_cost(4, t, c), rel=1e-13)
+    total = float(np.sum(t))
+    assert parts[1] == pytest.approx(100.0 * (total if mode == 1 else total * total), rel=1e-14)
+    # soft constraints: 12 terms, every derivative's 4-D maximum against horizontal (x2), vertical, heading limits
+    soft = 0.0
+    for k in (1, 2, 3):
+        mk = po.max_of_magnitude(c, t, k)
+        dense = _dense_max(c, t, k, 801)
+        assert mk >= dense * (1 - 1e-12) and mk <= dense * (1 + 1e-3)
+        for grp, mult in ((0, 2), (1, 1), (2, 1)):
+            value = lim[(k - 1) * 3 + grp]
+            soft += mult * min(1e12, math.exp((mk - value) / value * 1.5))
+    assert parts[2] == pytest.approx(soft, rel=1e-12)
+    assert f == pytest.approx(parts.sum(), rel=1e-15)
+    f0, parts0 = po.objective_time(4, m, v, t, lim, mode=mode, soft=0)
+    assert parts0[2] == 0.0 and f0 == pytest.approx(parts[0] + parts[1], rel=1e-15)
+
+
+def test_soft_constraint_cost_is_capped():
+    _, m, v, t = _path(3, 5)
+    lim = pr.DEFAULT_LIMITS * 1e-3  # 1000x violation: exp() overflows the cap
+    _, parts = po.objective_time(4, m, v, t, lim, soft=1, weight=1.5)
+    assert parts[2] == 12e12
+
+
+@pytest.mark.parametrize("n_seg,mode", [(1, 0), (3, 0), (3, 1), (10, 0), (10, 1)])
+def test_dfo_first_evaluations_follow_the_initial_interpolation_sweep(n_seg, mode):
+    """the shipping budget (max_iterations = 10) never leaves x0 +- h e_i with h = 0.1 x0 for S >= 5"""
+    _, m, v, t = _path(n_seg, 21 + n_seg)
+    lim = pr.DEFAULT_LIMITS
+    for budget in range(1, 2 * n_seg + 2):
+        rc, x, ne, fl = po.optimize_times_dfo(4, m, v, t, lim, mode=mode, max_iterations=budget)
+        assert rc == 5 and ne == budget
+        exp = t.copy()
+        if budget >= 2:
+            i = (budget - 2) % n_seg
+            exp[i] = t[i] * (1.1 if budget - 2 < n_seg else 0.9)
+        assert np.allclose(x, exp, rtol=1e-15, atol=0)
+        assert fl == pytest.approx(po.objective_time(4, m, v, x, lim, mode=mode)[0], rel=1e-15)
+
+
+def test_dfo_converges_and_never_leaves_the_bounds():
+    _, m, v, t = _path(3, 8)
+    lim = pr.DEFAULT_LIMITS
+    f_start = po.objective_time(4, m, v, t, lim, mode=1)[0]
+    rc, x, ne, fl = po.optimize_times_dfo(4, m, v, t, lim, mode=1, max_iterations=400)
+    assert rc in (3, 4) and ne < 400
+    assert np.all(x >= 0.01)
+    # the last evaluated point is at most one compass step from the best point, whose value is <= f(x0)
+    rc2, x2, ne2, fl2 = po.optimize_times_dfo(4, m, v, t, lim, mode=1, max_iterations=ne)
+    assert np.array_equal(x, x2) and fl == fl2
+    best = min(po.optimize_times_dfo(4, m, v, t, lim, mode=1, max_iterations=k)[3] for k in range(1, ne + 1))
+    assert best < f_start
+
+
+def test_dfo_rejects_start_below_lower_bound():
+    _, m, v, t = _path(3, 8)
+    t[1] = 0.005
+    rc, x, ne, _ = po.optimize_times_dfo(4, m, v, t, pr.DEFAULT_LIMITS)
+    assert rc == -2 and ne == 0 and np.array_equal(x, t)
+
+
+def test_batch_driver_modes_0_1():
+    batch = pr.random_batch(6, "ragged", seed0=3)
+    for mode in (0, 1):
+        out = po.solve_batch(batch.seg_offsets, batch.waypoints, batch.fixed_mask, batch.fixed_values, batch.limits,
+                             np.zeros(batch.n_segments), deriv=4, time_alloc_method=mode, estimate_times=True)
+        assert np.all(out["status"] == 5)
+        assert util.continuity_defect(batch, out["coeffs"], out["times"]) < 1e-7
+        assert util.constraint_defect(batch, out["coeffs"], out["times"]) < 1e-7
