@@ -21,30 +21,30 @@ namespace mrs_tg {
 
 // ---------------------------------------------------------------------------------------------
 // K1: Hessian / mapping-block assembly.  HBM-write bound: 8 B read + 1600 B written per segment.
-// One thread per (segment, matrix row); blockIdx.y is the row so that the row's constants are
-// wave-uniform (scalar loads) and every store instruction writes 64 consecutive doubles.
+// One thread per (path position, matrix row, segment slot): blockIdx.z is the slot and blockIdx.y the
+// row, so there is no index arithmetic beyond one multiply-add, the row's constants are wave-uniform
+// (scalar loads) and every store instruction writes 64 consecutive doubles.  The H row is stored before
+// the A^-1 row (which needs the division) is computed, so the stores start one dependent load +
+// ~20 multiplies after the wave starts.  Launch shapes measured in scripts/k1_variants.hip
+// (1024 x 10: 4.8 us against 4.6 us for a pure fill of the same 16.5 MB and 5.2 us for the previous
+// two-paths-per-lane, 16-byte-store shape).
 
-// one matrix row (a) of H(T) and of A^-1(T)
-__device__ __forceinline__ void block_rows(double T, int d, int a, double (&hrow)[kN], double (&arow)[kN]) {
-  double w[kHalf];
-  w[0] = 1.0;
-#pragma unroll
-  for (int k = 1; k < kHalf; ++k) w[k] = w[k - 1] * T;
+// row a of H(T) = T^(1-2d) D_T HBAR_d D_T
+__device__ __forceinline__ void hessian_row(double T, int d, int a, double (&hrow)[kN]) {
+  const double t2 = T * T, t3 = t2 * T, t4 = t2 * t2;
+  const double w[kHalf] = {1.0, T, t2, t3, t4};
   const int pa = a % kHalf;
-  double td = 1.0;  // T^d
-  if (d == 1) td = w[1];
-  else if (d == 2) td = w[2];
-  else if (d == 3) td = w[3];
-  else if (d == 4) td = w[4];
-  double wa = 1.0;  // T^pa
-  if (pa == 1) wa = w[1];
-  else if (pa == 2) wa = w[2];
-  else if (pa == 3) wa = w[3];
-  else if (pa == 4) wa = w[4];
+  const double td = (d == 0) ? 1.0 : (d == 1) ? T : (d == 2) ? t2 : (d == 3) ? t3 : t4;
+  const double wa = (pa == 0) ? 1.0 : (pa == 1) ? T : (pa == 2) ? t2 : (pa == 3) ? t3 : t4;
   const double sa = (T / (td * td)) * wa;  // T^(1-2d) * T^pa
 #pragma unroll
   for (int c = 0; c < kN; ++c) hrow[c] = c_hbar[d][a][c] * sa * w[c % kHalf];
-  // A^-1(T)[a][c] = ABAR_INV[a][c] * T^(c%5) / T^a
+}
+
+// row a of A^-1(T): ABAR_INV[a][c] * T^(c%5) / T^a
+__device__ __forceinline__ void mapping_inverse_row(double T, int a, double (&arow)[kN]) {
+  const double t2 = T * T, t3 = t2 * T, t4 = t2 * t2;
+  const double w[kHalf] = {1.0, T, t2, t3, t4};
   const double ti = 1.0 / T;
   double tia = 1.0;
   for (int k = 0; k < a; ++k) tia *= ti;
@@ -52,56 +52,44 @@ __device__ __forceinline__ void block_rows(double T, int d, int a, double (&hrow
   for (int c = 0; c < kN; ++c) arow[c] = c_abar_inv[a][c] * w[c % kHalf] * tia;
 }
 
-__global__ __launch_bounds__(256) void assemble_blocks_kernel(BatchView b, int d, const double* __restrict__ seg_times,
-                                                              double* __restrict__ Hout, double* __restrict__ Aout) {
-  const int idx = blockIdx.x * 256 + threadIdx.x;
-  if (idx >= b.n_segments) return;
-  const int a = blockIdx.y;
-  // slot j such that slot_start[j] <= idx < slot_start[j+1]
-  int lo = 0, hi = b.max_segments;
-  while (hi - lo > 1) {
-    const int mid = (lo + hi) >> 1;
-    if (b.slot_start[mid] <= idx) lo = mid;
-    else hi = mid;
-  }
-  const int j = lo;
-  const int q = idx - b.slot_start[j];
-  const int p = b.order[q];
-  const double T = seg_times[b.seg_offsets[p] + j];
-  double hrow[kN], arow[kN];
-  block_rows(T, d, a, hrow, arow);
-  const size_t P = (size_t)b.n_paths;
-  const size_t base = ((size_t)j * 100 + (size_t)a * kN) * P + (size_t)q;
+__device__ __forceinline__ void store_block_rows(double T, int d, int a, size_t base, size_t P, double* __restrict__ Hout,
+                                                 double* __restrict__ Aout) {
+  double row[kN];
+  hessian_row(T, d, a, row);
 #pragma unroll
-  for (int c = 0; c < kN; ++c) Hout[base + (size_t)c * P] = hrow[c];
+  for (int c = 0; c < kN; ++c) Hout[base + (size_t)c * P] = row[c];
+  mapping_inverse_row(T, a, row);
 #pragma unroll
-  for (int c = 0; c < kN; ++c) Aout[base + (size_t)c * P] = arow[c];
+  for (int c = 0; c < kN; ++c) Aout[base + (size_t)c * P] = row[c];
 }
 
-// Uniform batches (every path has S segments, so position q == path q and segment (q, j) sits at q*S + j)
-// with an even number of paths: no indirection loads, and each lane owns two neighbouring positions so that
-// every store is 16 bytes per lane (1 KiB per wave instruction).
+// general (ragged) batches: slot j holds the first slot_start[j+1] - slot_start[j] positions of the
+// longest-first order; blocks beyond that count exit at once
+__global__ __launch_bounds__(256) void assemble_blocks_kernel(BatchView b, int d, const double* __restrict__ seg_times,
+                                                              double* __restrict__ Hout, double* __restrict__ Aout) {
+  const int q = blockIdx.x * 256 + threadIdx.x;
+  const int j = blockIdx.z;
+  if (q >= b.slot_start[j + 1] - b.slot_start[j]) return;
+  const int a = blockIdx.y;
+  const int p = b.order[q];
+  const double T = seg_times[b.seg_offsets[p] + j];
+  const size_t P = (size_t)b.n_paths;
+  store_block_rows(T, d, a, ((size_t)j * 100 + (size_t)a * kN) * P + (size_t)q, P, Hout, Aout);
+}
+
+// uniform batches (every path has S segments, so position q == path q and segment (q, j) sits at q*S + j):
+// no indirection loads
 __global__ __launch_bounds__(256) void assemble_blocks_uniform_kernel(int n_paths, int S, int d,
                                                                       const double* __restrict__ seg_times,
                                                                       double* __restrict__ Hout,
                                                                       double* __restrict__ Aout) {
-  const int half = n_paths >> 1;
-  const int idx = blockIdx.x * 256 + threadIdx.x;
-  if (idx >= half * S) return;
+  const int q = blockIdx.x * 256 + threadIdx.x;
+  if (q >= n_paths) return;
   const int a = blockIdx.y;
-  const int j = idx / half;
-  const int q = (idx - j * half) * 2;
-  const double T0 = seg_times[(size_t)q * S + j];
-  const double T1 = seg_times[(size_t)(q + 1) * S + j];
-  double h0[kN], a0[kN], h1[kN], a1[kN];
-  block_rows(T0, d, a, h0, a0);
-  block_rows(T1, d, a, h1, a1);
+  const int j = blockIdx.z;
+  const double T = seg_times[(size_t)q * S + j];
   const size_t P = (size_t)n_paths;
-  const size_t base = ((size_t)j * 100 + (size_t)a * kN) * P + (size_t)q;
-#pragma unroll
-  for (int c = 0; c < kN; ++c) *reinterpret_cast<double2*>(Hout + base + (size_t)c * P) = make_double2(h0[c], h1[c]);
-#pragma unroll
-  for (int c = 0; c < kN; ++c) *reinterpret_cast<double2*>(Aout + base + (size_t)c * P) = make_double2(a0[c], a1[c]);
+  store_block_rows(T, d, a, ((size_t)j * 100 + (size_t)a * kN) * P + (size_t)q, P, Hout, Aout);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -309,13 +297,12 @@ static inline unsigned cdiv(long long a, long long b) { return (unsigned)((a + b
 hipError_t launch_assemble(const BatchView& b, int d, const double* seg_times, double* H, double* Ainv,
                            hipStream_t stream) {
   if (b.n_segments == 0) return hipSuccess;
-  const bool aligned = (reinterpret_cast<uintptr_t>(H) % 16 == 0) && (reinterpret_cast<uintptr_t>(Ainv) % 16 == 0);
-  if (b.uniform_S > 0 && (b.n_paths % 2) == 0 && aligned) {
-    dim3 grid(cdiv((long long)(b.n_paths / 2) * b.uniform_S, 256), kN);
+  if (b.uniform_S > 0) {
+    dim3 grid(cdiv(b.n_paths, 256), kN, b.uniform_S);
     hipLaunchKernelGGL(assemble_blocks_uniform_kernel, grid, dim3(256), 0, stream, b.n_paths, b.uniform_S, d, seg_times,
                        H, Ainv);
   } else {
-    dim3 grid(cdiv(b.n_segments, 256), kN);
+    dim3 grid(cdiv(b.n_paths, 256), kN, b.max_segments);
     hipLaunchKernelGGL(assemble_blocks_kernel, grid, dim3(256), 0, stream, b, d, seg_times, H, Ainv);
   }
   return hipGetLastError();
