@@ -63,9 +63,11 @@ enum {
   MRS_TG_TIME_ALLOC_NONE = -1,         /* fixed segment times: PolynomialOptimization::solveLinear only */
   MRS_TG_TIME_ALLOC_SQUARED_TIME = 0,  /* kSquaredTime: J_d + time_penalty (sum T)^2 + soft constraints, gradient-free */
   MRS_TG_TIME_ALLOC_RICHTER_TIME = 1,  /* kRichterTime: J_d + time_penalty sum T + soft constraints, gradient-free */
-  MRS_TG_TIME_ALLOC_MELLINGER = 2      /* kMellingerOuterLoop, the shipping default
+  MRS_TG_TIME_ALLOC_MELLINGER = 2,     /* kMellingerOuterLoop, the shipping default
                                           (config/private/trajectory_generation.yaml:7) */
-  /* 3 / 4 (k*TimeAndConstraints) are not implemented: MRS_TG_ERR_UNSUPPORTED */
+  MRS_TG_TIME_ALLOC_SQUARED_TIME_AND_CONSTRAINTS = 3, /* kSquaredTimeAndConstraints: as 0, segment times and free
+                                          end-point derivatives are the variables (nonlinear_impl.h:429-536) */
+  MRS_TG_TIME_ALLOC_RICHTER_TIME_AND_CONSTRAINTS = 4  /* kRichterTimeAndConstraints: as 1, same variables */
 };
 
 enum {
@@ -84,7 +86,7 @@ typedef struct mrs_tg_options {
   double sampling_dt;             /* > 0: sample the result (sampleWholeTrajectory, src/...cpp:1169) */
   int32_t sample_capacity;        /* samples_out holds this many samples per path */
   int32_t flags;                  /* MRS_TG_FLAG_* */
-  /* gradient-free modes 0 / 1 only (objectiveFunctionTime, nonlinear_impl.h:568-614) */
+  /* gradient-free modes 0 / 1 / 3 / 4 only (objectiveFunctionTime[AndConstraints], nonlinear_impl.h:568-614, 651-722) */
   double time_penalty;            /* param time_penalty (config/private/trajectory_generation.yaml:4) */
   double soft_constraint_weight;  /* param soft_constraints_weight (:6) */
   int32_t use_soft_constraints;   /* param soft_constraints_enabled (:5) */

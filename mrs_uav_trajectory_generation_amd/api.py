@@ -23,6 +23,8 @@ TIME_ALLOC_NONE = -1
 TIME_ALLOC_SQUARED_TIME = 0
 TIME_ALLOC_RICHTER_TIME = 1
 TIME_ALLOC_MELLINGER = 2
+TIME_ALLOC_SQUARED_TIME_AND_CONSTRAINTS = 3
+TIME_ALLOC_RICHTER_TIME_AND_CONSTRAINTS = 4
 FLAG_FUSED_ASSEMBLY = 1
 
 KERNEL_ASSEMBLE, KERNEL_SOLVE_LINEAR, KERNEL_NONLINEAR = 0, 1, 2

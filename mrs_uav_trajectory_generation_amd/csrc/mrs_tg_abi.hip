@@ -114,11 +114,10 @@ int check_options(mrs_tg_ctx* ctx, const mrs_tg_options* opt) {
   if (!opt) return fail(ctx, MRS_TG_ERR_INVALID_ARG, "options is NULL");
   if (opt->derivative_to_optimize < 0 || opt->derivative_to_optimize > 4)
     return fail(ctx, MRS_TG_ERR_INVALID_ARG, "derivative_to_optimize %d outside [0, 4]", opt->derivative_to_optimize);
-  if (opt->time_alloc_method != MRS_TG_TIME_ALLOC_NONE && opt->time_alloc_method != MRS_TG_TIME_ALLOC_MELLINGER &&
-      opt->time_alloc_method != MRS_TG_TIME_ALLOC_SQUARED_TIME && opt->time_alloc_method != MRS_TG_TIME_ALLOC_RICHTER_TIME)
-    return fail(ctx, MRS_TG_ERR_UNSUPPORTED,
-                "time_alloc_method %d is not implemented on the HIP path (supported: -1 fixed times, 0 / 1 time-only "
-                "gradient-free, 2 Mellinger)",
+  if (opt->time_alloc_method < MRS_TG_TIME_ALLOC_NONE || opt->time_alloc_method > MRS_TG_TIME_ALLOC_RICHTER_TIME_AND_CONSTRAINTS)
+    return fail(ctx, MRS_TG_ERR_INVALID_ARG,
+                "time_alloc_method %d is not one of -1 (fixed times), 0 / 1 (time only, gradient-free), 2 (Mellinger), "
+                "3 / 4 (time and free constraints, gradient-free)",
                 opt->time_alloc_method);
   if (opt->sampling_dt > 0 && opt->sample_capacity < 0)
     return fail(ctx, MRS_TG_ERR_INVALID_ARG, "negative sample_capacity");
@@ -388,7 +387,7 @@ int mrs_tg_plan_solve(mrs_tg_plan* plan, const double* wp, const uint8_t* mask, 
   const int d = opt->derivative_to_optimize;
   if (opt->estimate_times) HIP_TRY(ctx, mrs_tg::launch_estimate_times(b, wp, limits, seg_times, ctx->stream));
 
-  if (opt->time_alloc_method == MRS_TG_TIME_ALLOC_SQUARED_TIME || opt->time_alloc_method == MRS_TG_TIME_ALLOC_RICHTER_TIME) {
+  if (opt->time_alloc_method != MRS_TG_TIME_ALLOC_NONE && opt->time_alloc_method != MRS_TG_TIME_ALLOC_MELLINGER) {
     mrs_tg::DfoParams prm;
     prm.derivative = d;
     prm.mode = opt->time_alloc_method;

@@ -20,7 +20,7 @@ struct NonlinearParams {
 // the group evaluates the cost at the k-th perturbed time vector (k = 0: unperturbed).
 struct DfoParams {
   int derivative;
-  int mode;            // 0 squared time, 1 Richter time
+  int mode;            // 0 squared time, 1 Richter time, 3 / 4 the same with the free constraints as variables
   int max_iterations;
   double f_rel, f_abs, x_rel, x_abs;
   double time_penalty, soft_weight;
@@ -42,9 +42,13 @@ struct NonlinearPlan {
   size_t ws_doubles = 0;
   int32_t* d_opt_status = nullptr; // stopping reason of the outer loop per path
   double* d_maxima = nullptr;      // [n_segments][9] per-segment maxima
-  double* d_dfo_vec = nullptr;     // modes 0/1: x0 | best | h, 3 * n_segments doubles
-  double* d_dfo_f = nullptr;       // modes 0/1: fbest | f_sweep, 2 * n_paths doubles
-  int32_t* d_dfo_state = nullptr;  // modes 0/1: phase, i, sg, neval, improved, ret, done per path
+  // gradient-free modes (0, 1, 3, 4), allocated on first use
+  double* d_dfo_vec = nullptr;       // x | x0 | best | h | lb | ub, each 21 n_segments + 20 n_paths doubles
+  double* d_dfo_f = nullptr;         // fbest | f_sweep | J_d scratch, 3 * n_paths doubles
+  int32_t* d_dfo_state = nullptr;    // phase, i, sg, neval, improved, ret, done, n_var per path
+  int32_t* d_dfo_fidx = nullptr;     // modes 3/4: free-constraint index of every (vertex, derivative), -1 if fixed
+  double* d_dfo_segcost = nullptr;   // modes 3/4: J_d share of every (segment, dimension)
+  int32_t* d_dfo_seg_path = nullptr; // modes 3/4: path of every segment
 };
 
 int nonlinear_plan_build(NonlinearPlan& nl, const std::vector<int32_t>& seg_offsets, const std::vector<int32_t>& order);

@@ -78,6 +78,13 @@ void mto_segment_hessian(int derivative, double T, double* Hout, double* Ainv_ou
 /* setupFromVertices + solveLinear (linear_impl.h:62-106,184-257,311-373).
  * coeffs_out [S][4][10] ascending powers. Returns 0 on success. */
 int mto_solve_linear(const mto_path* path, const double* seg_times, double* coeffs_out);
+/* number of free constraints n_free (every unconstrained (vertex, derivative 0..4), linear_impl.h:191-254) */
+int mto_count_free_constraints(const mto_path* path);
+/* as mto_solve_linear; free_out (may be NULL) receives getFreeConstraints: [4][n_free], ordered by (vertex, derivative) */
+int mto_solve_linear_free(const mto_path* path, const double* seg_times, double* coeffs_out, double* free_out);
+/* setFreeConstraints + updateSegmentsFromCompactConstraints (linear_impl.h:515-522, 264-282): coefficients
+ * from given free constraints without a solve */
+int mto_coeffs_from_free_constraints(const mto_path* path, const double* seg_times, const double* free_in, double* coeffs_out);
 /* computeCost linear_impl.h:128-141 */
 double mto_compute_cost(int n_seg, int derivative, const double* seg_times, const double* coeffs);
 
@@ -146,7 +153,7 @@ int mto_solve_batch(int n_paths, const int32_t* seg_offsets, const double* waypo
 
 /* ---- gradient-free time-allocation modes 0 / 1 (mto_dfo.c) ---------------------------------- */
 typedef struct {
-  int time_alloc_method;        /* 0 kSquaredTime, 1 kRichterTime (nonlinear.h:92-100) */
+  int time_alloc_method;        /* 0 kSquaredTime, 1 kRichterTime, 3 / 4 the same + free constraints (nonlinear.h:92-100) */
   mto_nlopt_params nlopt;
   double time_penalty;          /* nonlinear.h:70; param time_penalty */
   int use_soft_constraints;     /* param soft_constraints_enabled */
@@ -165,6 +172,17 @@ double mto_objective_time(const mto_path* path, const double* seg_times, const d
 /* own derivative-free search standing in for NLopt LN_BOBYQA; x in/out = last evaluated point */
 int mto_optimize_time_dfo(const mto_path* path, const double* limits9, const mto_dfo_params* prm, double* x,
                           int* n_eval_out, double* f_last_out);
+
+/* modes 3 / 4: x = [segment times, free constraints of dimension 0..3]; coeffs_out may be NULL
+ * (objectiveFunctionTimeAndConstraints nonlinear_impl.h:651-722) */
+double mto_objective_time_and_constraints(const mto_path* path, const double* x, const double* limits9,
+                                          const mto_dfo_params* prm, double* coeffs_out, double* parts_out);
+/* setFreeEndpointDerivativeHardConstraints nonlinear_impl.h:765-804; lower / upper [4 * n_free] */
+void mto_free_derivative_bounds(const mto_path* path, const double* limits9, double* lower, double* upper);
+/* optimizeTimeAndFreeConstraints nonlinear_impl.h:429-536 with the same search; seg_times in/out and coeffs_out
+ * are those of the last evaluated point */
+int mto_optimize_time_and_constraints_dfo(const mto_path* path, const double* limits9, const mto_dfo_params* prm,
+                                          double* seg_times, double* coeffs_out, int* n_eval_out, double* f_last_out);
 
 /* ---- path-policy layer (SURVEY.md 8 f: the rows ranked "next") ------------------------------ */
 typedef struct {

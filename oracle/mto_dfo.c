@@ -1,10 +1,14 @@
 /*
  * mto_dfo.c -- CPU ORACLE (test infrastructure): the gradient-free time-allocation modes 0 / 1
- * (kSquaredTime, kRichterTime).  See mrs_tg_oracle.h for the rules that apply to oracle/.
+ * (kSquaredTime, kRichterTime) and 3 / 4 (kSquaredTimeAndConstraints, kRichterTimeAndConstraints).
+ * See mrs_tg_oracle.h for the rules that apply to oracle/.
  *
  * Follows (relative to /root/reference/include/eth_trajectory_generation/impl/):
  *   polynomial_optimization_nonlinear_impl.h:121-157   optimizeTime (NLopt driver set-up: bounds, initial step)
  *   polynomial_optimization_nonlinear_impl.h:568-614   objectiveFunctionTime
+ *   polynomial_optimization_nonlinear_impl.h:429-536   optimizeTimeAndFreeConstraints (variables, bounds, steps)
+ *   polynomial_optimization_nonlinear_impl.h:651-722   objectiveFunctionTimeAndConstraints
+ *   polynomial_optimization_nonlinear_impl.h:765-804   setFreeEndpointDerivativeHardConstraints
  *   polynomial_optimization_nonlinear_impl.h:725-762   evaluateMaximumMagnitudeConstraint / ...AsSoftConstraint
  *   polynomial_optimization_linear_impl.h:478-508      computeMaximumOfMagnitude
  *   src/mrs_trajectory_generation.cpp:1067-1081        the 12 registered magnitude constraints
@@ -63,7 +67,7 @@ double mto_objective_time(const mto_path* path, const double* seg_times, const d
   const double cost_traj = mto_compute_cost(S, path->derivative_to_optimize, seg_times, coeffs);
   double total = 0.0;
   for (int i = 0; i < S; ++i) total += seg_times[i];
-  const double cost_time = (prm->time_alloc_method == 1) ? total * prm->time_penalty : total * total * prm->time_penalty;
+  const double cost_time = (prm->time_alloc_method == 1 || prm->time_alloc_method == 4) ? total * prm->time_penalty : total * total * prm->time_penalty;
   double cost_soft = 0.0;
   if (prm->use_soft_constraints) {
     double mx[3];
@@ -94,11 +98,12 @@ typedef struct {
   double fbest, f_sweep;
 } dfo_state;
 
+static double clampd(double t, double lo, double hi) { return t < lo ? lo : (t > hi ? hi : t); }
+
 /* consume the objective value f of the trial held in x (the last evaluated point); write the next trial into x.
- * x0, best, h are the per-path vectors of the search. */
-static void dfo_step(dfo_state* st, int n, double f, double* x, double* x0, double* best, double* h,
-                     const mto_dfo_params* prm) {
-  const double lb = 0.01;
+ * x0, best, h, lb, ub are the per-path vectors of the search (n variables). */
+static void dfo_step(dfo_state* st, int n, double f, double* x, double* x0, double* best, double* h, const double* lb,
+                     const double* ub, const mto_dfo_params* prm) {
   const int maxeval = prm->nlopt.max_iterations;
   int accepted = 0;
   st->neval++;
@@ -171,16 +176,15 @@ static void dfo_step(dfo_state* st, int n, double f, double* x, double* x0, doub
     const int i = st->i;
     if (st->phase == DFO_INIT_PLUS) {
       memcpy(x, x0, sizeof(double) * (size_t)n);
-      x[i] = x0[i] + h[i];
+      x[i] = clampd((x0[i] + h[i] <= ub[i]) ? x0[i] + h[i] : x0[i] - h[i], lb[i], ub[i]);
       return;
     }
     if (st->phase == DFO_INIT_MINUS) {
       memcpy(x, x0, sizeof(double) * (size_t)n);
-      x[i] = (x0[i] - h[i] >= lb) ? x0[i] - h[i] : x0[i] + 2.0 * h[i];
+      x[i] = clampd((x0[i] - h[i] >= lb[i]) ? x0[i] - h[i] : x0[i] + 2.0 * h[i], lb[i], ub[i]);
       return;
     }
-    double t = best[i] + (st->sg == 0 ? h[i] : -h[i]);
-    if (t < lb) t = lb;
+    const double t = clampd(best[i] + (st->sg == 0 ? h[i] : -h[i]), lb[i], ub[i]);
     if (t == best[i]) continue; /* nothing to try in this direction */
     memcpy(x, best, sizeof(double) * (size_t)n);
     x[i] = t;
@@ -191,7 +195,7 @@ static void dfo_step(dfo_state* st, int n, double f, double* x, double* x0, doub
 int mto_optimize_time_dfo(const mto_path* path, const double* limits9, const mto_dfo_params* prm, double* x,
                           int* n_eval_out, double* f_last_out) {
   const int n = path->n_seg;
-  double x0[MTO_MAX_SEG], h[MTO_MAX_SEG], best[MTO_MAX_SEG];
+  double x0[MTO_MAX_SEG], h[MTO_MAX_SEG], best[MTO_MAX_SEG], lb[MTO_MAX_SEG], ub[MTO_MAX_SEG];
   for (int i = 0; i < n; ++i) {
     if (x[i] < 0.01) { /* NLopt rejects a start outside the bounds */
       if (n_eval_out) *n_eval_out = 0;
@@ -199,14 +203,105 @@ int mto_optimize_time_dfo(const mto_path* path, const double* limits9, const mto
     }
     x0[i] = best[i] = x[i];
     h[i] = prm->initial_stepsize_rel * x[i]; /* nonlinear_impl.h:127-130 */
+    lb[i] = 0.01;                            /* kOptimizationTimeLowerBound, :134-135 */
+    ub[i] = DBL_MAX;
   }
   dfo_state st = {DFO_FIRST, 0, 0, 0, 0, MTO_FAILURE, 0, 0.0, 0.0};
   double f = 0.0;
   while (!st.done) {
     f = mto_objective_time(path, x, limits9, prm, NULL);
-    dfo_step(&st, n, f, x, x0, best, h, prm);
+    dfo_step(&st, n, f, x, x0, best, h, lb, ub, prm);
   }
   if (n_eval_out) *n_eval_out = st.neval;
   if (f_last_out) *f_last_out = f;
+  return st.ret;
+}
+
+/* ---- modes 3 / 4: segment times and free end-point derivatives ---------------------------------------- */
+
+double mto_objective_time_and_constraints(const mto_path* path, const double* x, const double* limits9,
+                                          const mto_dfo_params* prm, double* coeffs_out, double* parts_out) {
+  /* objectiveFunctionTimeAndConstraints nonlinear_impl.h:651-722: x = [T_0..T_{S-1}, free constraints of
+   * dimension 0, 1, 2, 3]; updateSegmentTimes + setFreeConstraints, no solve */
+  const int S = path->n_seg;
+  double* coeffs = coeffs_out ? coeffs_out : (double*)malloc(sizeof(double) * (size_t)S * DIM * N);
+  mto_coeffs_from_free_constraints(path, x, x + S, coeffs);
+  const double cost_traj = mto_compute_cost(S, path->derivative_to_optimize, x, coeffs);
+  double total = 0.0;
+  for (int i = 0; i < S; ++i) total += x[i];
+  const double cost_time = (prm->time_alloc_method == 4) ? total * prm->time_penalty : total * total * prm->time_penalty;
+  double cost_soft = 0.0;
+  if (prm->use_soft_constraints) {
+    double mx[3];
+    for (int k = 1; k <= 3; ++k) mx[k - 1] = mto_max_of_magnitude(S, coeffs, x, k);
+    cost_soft = mto_soft_constraint_cost(mx, limits9, prm->soft_constraint_weight);
+  }
+  if (!coeffs_out) free(coeffs);
+  if (parts_out) {
+    parts_out[0] = cost_traj;
+    parts_out[1] = cost_time;
+    parts_out[2] = cost_soft;
+  }
+  return cost_traj + cost_time + cost_soft;
+}
+
+void mto_free_derivative_bounds(const mto_path* path, const double* limits9, double* lower, double* upper) {
+  /* setFreeEndpointDerivativeHardConstraints nonlinear_impl.h:765-804 over the 12 constraints registered at
+   * src/mrs_trajectory_generation.cpp:1067-1081.  The counter walks derivatives 0..derivative_to_optimize only,
+   * while the free constraints cover derivatives 0..4: for derivative_to_optimize < 4 the bound lands on a
+   * different free constraint than the one it was meant for.  Replicated as written. */
+  const int V = path->n_seg + 1, n_free = mto_count_free_constraints(path), d = path->derivative_to_optimize;
+  for (int i = 0; i < DIM * n_free; ++i) {
+    lower[i] = -DBL_MAX; /* std::numeric_limits<double>::lowest() */
+    upper[i] = DBL_MAX;
+  }
+  for (int dim = 0; dim < DIM; ++dim) {
+    const int grp = (dim <= 1) ? 0 : (dim == 2 ? 1 : 2);
+    for (int k = 1; k <= 3; ++k) {
+      const double value = limits9[(k - 1) * 3 + grp];
+      int counter = 0;
+      for (int v = 0; v < V; ++v)
+        for (int deriv = 0; deriv <= d; ++deriv)
+          if (!path->fixed_mask[v * MTO_HALF + deriv]) {
+            if (deriv == k) {
+              lower[dim * n_free + counter] = -fabs(value);
+              upper[dim * n_free + counter] = fabs(value);
+            }
+            counter++;
+          }
+    }
+  }
+}
+
+int mto_optimize_time_and_constraints_dfo(const mto_path* path, const double* limits9, const mto_dfo_params* prm,
+                                          double* seg_times, double* coeffs_out, int* n_eval_out, double* f_last_out) {
+  /* optimizeTimeAndFreeConstraints nonlinear_impl.h:429-536 */
+  const int S = path->n_seg, n_free = mto_count_free_constraints(path), n = S + DIM * n_free;
+  double* buf = (double*)malloc(sizeof(double) * (size_t)n * 6);
+  double *x = buf, *x0 = buf + n, *best = buf + 2 * n, *h = buf + 3 * n, *lb = buf + 4 * n, *ub = buf + 5 * n;
+  memcpy(x, seg_times, sizeof(double) * (size_t)S);
+  mto_solve_linear_free(path, seg_times, coeffs_out, x + S); /* initial solution :436-438 */
+  for (int i = 0; i < S; ++i) {
+    lb[i] = 0.01;
+    ub[i] = DBL_MAX;
+  }
+  mto_free_derivative_bounds(path, limits9, lb + S, ub + S);
+  for (int i = 0; i < n; ++i) {
+    const double ax = fabs(x[i]);
+    h[i] = (ax <= DBL_EPSILON) ? 1e-13 : prm->initial_stepsize_rel * ax; /* :486-494 */
+    if (x[i] < lb[i]) lb[i] = x[i];                                       /* :496-501 */
+    else if (x[i] > ub[i]) ub[i] = x[i];
+    x0[i] = best[i] = x[i];
+  }
+  dfo_state st = {DFO_FIRST, 0, 0, 0, 0, MTO_FAILURE, 0, 0.0, 0.0};
+  double f = 0.0;
+  while (!st.done) {
+    f = mto_objective_time_and_constraints(path, x, limits9, prm, coeffs_out, NULL);
+    memcpy(seg_times, x, sizeof(double) * (size_t)S); /* the optimiser object holds the last evaluated point */
+    dfo_step(&st, n, f, x, x0, best, h, lb, ub, prm);
+  }
+  if (n_eval_out) *n_eval_out = st.neval;
+  if (f_last_out) *f_last_out = f;
+  free(buf);
   return st.ret;
 }

@@ -184,7 +184,49 @@ static int qr_solve(double* M, int n, double* B, int nrhs) {
   return 0;
 }
 
+int mto_count_free_constraints(const mto_path* path) {
+  /* n_free_constraints_: every (vertex, derivative 0..4) without a constraint (linear_impl.h:191-254) */
+  int n = 0;
+  for (int i = 0; i < HALF * (path->n_seg + 1); ++i) n += path->fixed_mask[i] ? 0 : 1;
+  return n;
+}
+
 int mto_solve_linear(const mto_path* path, const double* seg_times, double* coeffs_out) {
+  return mto_solve_linear_free(path, seg_times, coeffs_out, NULL);
+}
+
+int mto_coeffs_from_free_constraints(const mto_path* path, const double* seg_times, const double* free_in, double* coeffs_out) {
+  /* setFreeConstraints (linear_impl.h:515-522) + updateSegmentsFromCompactConstraints (:264-282):
+   * no solve, d = [d_f; d_p] with d_p given; free_in [4][n_free], free constraints ordered by (vertex, derivative) */
+  const int S = path->n_seg, V = S + 1;
+  if (S < 1 || S > MTO_MAX_SEG) return -1;
+  const int n_all = HALF * V, n_free = mto_count_free_constraints(path);
+  int* fidx = (int*)malloc(sizeof(int) * (size_t)n_all);
+  for (int i = 0, cp = 0; i < n_all; ++i) fidx[i] = path->fixed_mask[i] ? -1 : cp++;
+  for (int i = 0; i < S; ++i) {
+    double A[N * N], Ai[N * N];
+    mto_mapping_matrix(seg_times[i], A);
+    mto_invert_mapping_matrix(A, Ai);
+    for (int k = 0; k < DIM; ++k) {
+      double dseg[N];
+      for (int r = 0; r < N; ++r) {
+        const int u = (i + r / HALF) * HALF + r % HALF;
+        dseg[r] = path->fixed_mask[u] ? path->fixed_values[(size_t)u * DIM + k] : free_in[(size_t)k * n_free + fidx[u]];
+      }
+      double* c = coeffs_out + ((size_t)i * DIM + k) * N;
+      for (int r = 0; r < N; ++r) {
+        double acc = 0.0;
+        for (int q = 0; q < N; ++q) acc += Ai[r * N + q] * dseg[q];
+        c[r] = acc;
+      }
+    }
+  }
+  free(fidx);
+  return 0;
+}
+
+int mto_solve_linear_free(const mto_path* path, const double* seg_times, double* coeffs_out, double* free_out) {
+  /* free_out (may be NULL): getFreeConstraints, [4][n_free] (free_constraints_compact_, linear_impl.h:360-369) */
   const int S = path->n_seg, V = S + 1, d = path->derivative_to_optimize;
   if (S < 1 || S > MTO_MAX_SEG) return -1;
   const int n_all = HALF * V;
@@ -231,7 +273,10 @@ int mto_solve_linear(const mto_path* path, const double* seg_times, double* coef
     }
     rc = qr_solve(Rpp, n_free, rhs, DIM);
     for (int r = 0; r < n_free; ++r)
-      for (int k = 0; k < DIM; ++k) dall[(size_t)(n_fixed + r) * DIM + k] = rhs[(size_t)r * DIM + k];
+      for (int k = 0; k < DIM; ++k) {
+        dall[(size_t)(n_fixed + r) * DIM + k] = rhs[(size_t)r * DIM + k];
+        if (free_out) free_out[(size_t)k * n_free + r] = rhs[(size_t)r * DIM + k];
+      }
     free(Rpp);
     free(rhs);
   }

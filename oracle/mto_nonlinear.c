@@ -548,6 +548,12 @@ static int solve_one(int S, const double* wp, const uint8_t* mask, const double*
     int rc = mto_optimize_time_dfo(&path, lim, &dp, times, NULL, NULL);
     status = (rc == MTO_INVALID_ARGS) ? MTO_FAILURE : rc;
     mto_solve_linear(&path, times, coeffs);
+  } else if (opt->time_alloc_method == 3 || opt->time_alloc_method == 4) {
+    /* optimizeTimeAndFreeConstraints (nonlinear_impl.h:429-536): the trajectory is the one set by the last
+     * objective evaluation (setFreeConstraints), no solve and no feasibility scaling afterwards */
+    mto_dfo_params dp = {opt->time_alloc_method, opt->nlopt, opt->time_penalty, opt->use_soft_constraints,
+                         opt->soft_constraint_weight, opt->initial_stepsize_rel};
+    status = mto_optimize_time_and_constraints_dfo(&path, lim, &dp, times, coeffs, NULL, NULL);
   } else {
     if (mto_solve_linear(&path, times, coeffs) != 0) status = MTO_FAILURE;
   }

@@ -105,6 +105,15 @@ def lib():
         L.mto_objective_time.argtypes = [C.POINTER(_Path), dp, dp, C.POINTER(DfoParams), dp]
         L.mto_optimize_time_dfo.restype = C.c_int
         L.mto_optimize_time_dfo.argtypes = [C.POINTER(_Path), dp, C.POINTER(DfoParams), dp, C.POINTER(C.c_int), dp]
+        L.mto_count_free_constraints.argtypes = [C.POINTER(_Path)]
+        L.mto_solve_linear_free.argtypes = [C.POINTER(_Path), dp, dp, dp]
+        L.mto_coeffs_from_free_constraints.argtypes = [C.POINTER(_Path), dp, dp, dp]
+        L.mto_objective_time_and_constraints.restype = C.c_double
+        L.mto_objective_time_and_constraints.argtypes = [C.POINTER(_Path), dp, dp, C.POINTER(DfoParams), dp, dp]
+        L.mto_free_derivative_bounds.argtypes = [C.POINTER(_Path), dp, dp, dp]
+        L.mto_optimize_time_and_constraints_dfo.restype = C.c_int
+        L.mto_optimize_time_and_constraints_dfo.argtypes = [C.POINTER(_Path), dp, C.POINTER(DfoParams), dp, dp,
+                                                            C.POINTER(C.c_int), dp]
         L.mto_default_policy_params.argtypes = [C.POINTER(PolicyParams)]
         L.mto_dist_from_segment.restype = C.c_double
         L.mto_dist_from_segment.argtypes = [dp, dp, dp]
@@ -242,6 +251,64 @@ def optimize_times_dfo(deriv, fixed_mask, fixed_values, seg_times, limits, mode=
     lim = _f64(limits)
     rc = lib().mto_optimize_time_dfo(C.byref(p), _dp(lim), C.byref(prm), _dp(t), C.byref(ne), C.byref(fl))
     return rc, t, ne.value, fl.value
+
+
+def solve_linear_free(deriv, fixed_mask, fixed_values, seg_times):
+    """solveLinear + getFreeConstraints: (coeffs [S][4][10], free [4][n_free])"""
+    t = _f64(seg_times)
+    p = _make_path(t.size, deriv, fixed_mask, fixed_values)
+    nf = lib().mto_count_free_constraints(C.byref(p))
+    coeffs = np.zeros((t.size, D, N))
+    free = np.zeros((D, nf))
+    rc = lib().mto_solve_linear_free(C.byref(p), _dp(t), _dp(coeffs), _dp(free))
+    assert rc == 0
+    return coeffs, free
+
+
+def coeffs_from_free(deriv, fixed_mask, fixed_values, seg_times, free):
+    t = _f64(seg_times)
+    p = _make_path(t.size, deriv, fixed_mask, fixed_values)
+    f = _f64(free)
+    coeffs = np.zeros((t.size, D, N))
+    lib().mto_coeffs_from_free_constraints(C.byref(p), _dp(t), _dp(f), _dp(coeffs))
+    return coeffs
+
+
+def objective_time_and_constraints(deriv, fixed_mask, fixed_values, x, limits, mode=3, time_penalty=100.0, soft=1,
+                                   weight=1.5):
+    x = _f64(x)
+    n_seg = np.asarray(fixed_mask).reshape(-1, 5).shape[0] - 1
+    p = _make_path(n_seg, deriv, fixed_mask, fixed_values)
+    prm = DfoParams(mode, default_nlopt(), float(time_penalty), int(soft), float(weight), 0.1)
+    parts = np.zeros(3)
+    lim = _f64(limits)
+    f = lib().mto_objective_time_and_constraints(C.byref(p), _dp(x), _dp(lim), C.byref(prm), None, _dp(parts))
+    return f, parts
+
+
+def free_derivative_bounds(deriv, fixed_mask, fixed_values, limits):
+    n_seg = np.asarray(fixed_mask).reshape(-1, 5).shape[0] - 1
+    p = _make_path(n_seg, deriv, fixed_mask, fixed_values)
+    nf = lib().mto_count_free_constraints(C.byref(p))
+    lo = np.zeros((D, nf))
+    hi = np.zeros((D, nf))
+    lim = _f64(limits)
+    lib().mto_free_derivative_bounds(C.byref(p), _dp(lim), _dp(lo), _dp(hi))
+    return lo, hi
+
+
+def optimize_time_and_constraints_dfo(deriv, fixed_mask, fixed_values, seg_times, limits, mode=3, max_iterations=10,
+                                      time_penalty=100.0, soft=1, weight=1.5):
+    t = _f64(seg_times).copy()
+    p = _make_path(t.size, deriv, fixed_mask, fixed_values)
+    prm = DfoParams(mode, default_nlopt(max_iterations), float(time_penalty), int(soft), float(weight), 0.1)
+    ne = C.c_int(0)
+    fl = C.c_double(0)
+    lim = _f64(limits)
+    coeffs = np.zeros((t.size, D, N))
+    rc = lib().mto_optimize_time_and_constraints_dfo(C.byref(p), _dp(lim), C.byref(prm), _dp(t), _dp(coeffs),
+                                                     C.byref(ne), C.byref(fl))
+    return rc, t, coeffs, ne.value, fl.value
 
 
 def max_of_magnitude(coeffs, seg_times, derivative):

@@ -1,4 +1,5 @@
-"""GPU parity of the gradient-free time-allocation modes 0 / 1 (kSquaredTime / kRichterTime) through the C ABI,
+"""GPU parity of the gradient-free time-allocation modes 0 / 1 (kSquaredTime / kRichterTime) and 3 / 4
+(k*TimeAndConstraints) through the C ABI,
 against oracle/mto_dfo.c.
 
 Tolerances: the trial points of the search are exact functions of the start point and of the outcomes of the
@@ -65,8 +66,63 @@ def test_start_below_lower_bound_reports_failure(gpu_ctx):
     assert np.array_equal(out["times"][5:10], t[5:10])
 
 
-def test_modes_3_4_are_reported_unsupported(gpu_ctx):
+def test_unknown_mode_is_rejected(gpu_ctx):
     batch = pr.random_batch(2, 3, seed0=1)
-    for mode in (3, 4):
-        with pytest.raises(api.MrsTgError, match="not implemented"):
+    for mode in (-2, 5, 7):
+        with pytest.raises(api.MrsTgError, match="time_alloc_method"):
             gpu_ctx.solve_batch(batch, None, time_alloc_method=mode)
+
+
+# ---- modes 3 / 4: segment times and free end-point derivatives as variables ----
+# The start point's free constraints come from two different linear solvers (oracle: reference-style dense QR,
+# product: block Cholesky on exact constants), which agree to ~1e-9 of the end-point scale; the trial points
+# inherit that difference, so times / coefficients are compared to 1e-6 and statuses exactly.
+
+@pytest.mark.parametrize("mode", [api.TIME_ALLOC_SQUARED_TIME_AND_CONSTRAINTS, api.TIME_ALLOC_RICHTER_TIME_AND_CONSTRAINTS])
+@pytest.mark.parametrize("n_seg,n_paths,budget", [(10, 64, 10), (3, 40, 10), ("ragged", 48, 10), (1, 5, 10), (4, 32, 30),
+                                                  (4, 32, 45)])
+def test_time_and_constraints_matches_oracle(gpu_ctx, mode, n_seg, n_paths, budget):
+    batch = pr.random_batch(n_paths, n_seg, seed0=515)
+    out = gpu_ctx.solve_batch(batch, None, time_alloc_method=mode, max_iterations=budget)
+    ref = _oracle(batch, mode, budget)
+    assert np.array_equal(out["status"], ref["status"])
+    assert np.max(np.abs(out["times"] - ref["times"]) / ref["times"]) < 1e-9
+    assert util.coeff_error(out["coeffs"], ref["coeffs"], batch.seg_offsets) < 1e-6
+    assert np.max(np.abs(out["cost"] - ref["cost"]) / np.abs(ref["cost"])) < 1e-6
+    assert util.continuity_defect(batch, out["coeffs"], out["times"]) < 1e-9
+    assert util.constraint_defect(batch, out["coeffs"], out["times"]) < 1e-9
+
+
+def test_time_and_constraints_with_acceleration_objective_and_stop_vertices(gpu_ctx):
+    # derivative_to_optimize = 2 (the shipping default): jerk and snap are free at the ends, and the reference's
+    # bound walk lands on other free constraints than intended (oracle/mto_dfo.c::mto_free_derivative_bounds)
+    parts = []
+    for s in range(24):
+        wp = pr.random_box_waypoints(5, 900 + s)
+        stop = np.zeros(6, dtype=bool)
+        stop[2 + s % 2] = True
+        parts.append(pr.build_vertices(wp, 2, stop_at=stop))
+    batch = pr.assemble_batch(parts, np.tile(pr.DEFAULT_LIMITS, (len(parts), 1)), 2)
+    for mode, budget in ((3, 10), (4, 40)):
+        out = gpu_ctx.solve_batch(batch, None, time_alloc_method=mode, max_iterations=budget)
+        ref = _oracle(batch, mode, budget)
+        assert np.array_equal(out["status"], ref["status"])
+        assert np.max(np.abs(out["times"] - ref["times"]) / ref["times"]) < 1e-9
+        assert util.coeff_error(out["coeffs"], ref["coeffs"], batch.seg_offsets) < 1e-6
+        assert util.continuity_defect(batch, out["coeffs"], out["times"]) < 1e-9
+
+
+def test_time_and_constraints_long_budget(gpu_ctx):
+    batch = pr.random_batch(24, 2, seed0=77)
+    out = gpu_ctx.solve_batch(batch, None, time_alloc_method=4, max_iterations=200, time_penalty=20.0)
+    ref = _oracle(batch, 4, 200, time_penalty=20.0)
+    assert np.all(np.isin(out["status"], (3, 4, 5)))
+    same = 0
+    for p in range(batch.n_paths):
+        a, b = batch.seg_offsets[p], batch.seg_offsets[p + 1]
+        if out["status"][p] == ref["status"][p] and \
+                np.max(np.abs(out["times"][a:b] - ref["times"][a:b]) / ref["times"][a:b]) < 1e-6 and \
+                util.coeff_error(out["coeffs"][a:b], ref["coeffs"][a:b]) < 1e-5:
+            same += 1
+    assert same >= 0.8 * batch.n_paths, same
+    assert util.continuity_defect(batch, out["coeffs"], out["times"]) < 1e-9

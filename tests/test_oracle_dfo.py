@@ -104,3 +104,105 @@ def test_batch_driver_modes_0_1():
         assert np.all(out["status"] == 5)
         assert util.continuity_defect(batch, out["coeffs"], out["times"]) < 1e-7
         assert util.constraint_defect(batch, out["coeffs"], out["times"]) < 1e-7
+
+
+# ---- modes 3 / 4: segment times + free end-point derivatives (nonlinear_impl.h:429-536, 651-722, 765-804) ----
+
+def test_free_constraints_round_trip():
+    for n_seg, seed in ((1, 3), (4, 9), (10, 2)):
+        _, m, v, t = _path(n_seg, seed)
+        c, free = po.solve_linear_free(4, m, v, t)
+        assert free.shape == (4, 4 * (n_seg - 1))
+        assert np.array_equal(c, po.solve_linear(4, m, v, t))
+        c2 = po.coeffs_from_free(4, m, v, t, free)
+        assert util.coeff_error(c2, c) < 1e-13
+        # the free constraints are the derivatives of the solution at the interior vertices
+        for vert in range(1, n_seg):
+            for k in range(1, 5):
+                got = free[:, (vert - 1) * 4 + (k - 1)]
+                assert np.allclose(got, math.factorial(k) * c[vert, :, k], rtol=1e-9, atol=1e-12)
+
+
+@pytest.mark.parametrize("mode", [3, 4])
+def test_objective_with_free_constraints_equals_time_only_objective_at_the_linear_solution(mode):
+    _, m, v, t = _path(5, 17)
+    lim = pr.DEFAULT_LIMITS
+    _, free = po.solve_linear_free(4, m, v, t)
+    f, parts = po.objective_time_and_constraints(4, m, v, np.concatenate([t, free.ravel()]), lim, mode=mode)
+    f01, parts01 = po.objective_time(4, m, v, t, lim, mode=mode - 3)
+    assert np.allclose(parts, parts01, rtol=1e-9)
+    # moving a free constraint away from the minimiser of J_d raises J_d
+    x = np.concatenate([t, free.ravel()])
+    x[len(t) + 3] += 0.05
+    _, parts_moved = po.objective_time_and_constraints(4, m, v, x, lim, mode=mode)
+    assert parts_moved[0] > parts[0] and parts_moved[1] == parts[1]
+
+
+def test_free_derivative_bounds_snap_and_the_acceleration_quirk():
+    lim = pr.DEFAULT_LIMITS  # v 2/2/1, a 2/2/2, j 20/20/20 (horizontal, vertical, heading)
+    wp = pr.random_box_waypoints(3, 4)
+    # derivative_to_optimize = 4: every free constraint (v, a, j, s per interior vertex) is walked, bounds aligned
+    _, m, v = pr.build_vertices(wp, pr.SNAP)
+    lo, hi = po.free_derivative_bounds(4, m, v, lim)
+    big = np.finfo(float).max
+    for dim, grp in enumerate((0, 0, 1, 2)):
+        exp = [lim[grp], lim[3 + grp], lim[6 + grp], big] * 2
+        assert np.array_equal(hi[dim], exp) and np.array_equal(lo[dim], -np.array(exp))
+    # derivative_to_optimize = 2: ends fix p, v, a (jerk and snap free), the walk counts derivatives 0..2 only, so the
+    # velocity / acceleration bounds of the two interior vertices land on free constraints 0..3 = (v0 jerk, v0 snap,
+    # v1 velocity, v1 acceleration) instead of (v1 v, v1 a, v2 v, v2 a)
+    _, m2, v2 = pr.build_vertices(wp, 2)
+    assert m2.reshape(-1, 5).sum(axis=1).tolist() == [3, 1, 1, 3]
+    lo2, hi2 = po.free_derivative_bounds(2, m2, v2, lim)
+    assert hi2.shape == (4, 12)
+    for dim, grp in enumerate((0, 0, 1, 2)):
+        exp = [lim[grp], lim[3 + grp], lim[grp], lim[3 + grp]] + [big] * 8
+        assert np.array_equal(hi2[dim], exp) and np.array_equal(lo2[dim], -np.array(exp))
+
+
+@pytest.mark.parametrize("mode", [3, 4])
+def test_dfo_time_and_constraints_first_evaluations(mode):
+    _, m, v, t = _path(4, 6)
+    lim = pr.DEFAULT_LIMITS
+    c0, free = po.solve_linear_free(4, m, v, t)
+    rc, x, c, ne, fl = po.optimize_time_and_constraints_dfo(4, m, v, t, lim, mode=mode, max_iterations=1)
+    assert rc == 5 and ne == 1 and np.array_equal(x, t) and util.coeff_error(c, c0) < 1e-13
+    # second evaluation: T_0 + 10 % with the free constraints held (not re-solved)
+    rc, x, c, ne, fl = po.optimize_time_and_constraints_dfo(4, m, v, t, lim, mode=mode, max_iterations=2)
+    t1 = t.copy()
+    t1[0] *= 1.1
+    assert np.allclose(x, t1, rtol=1e-15)
+    assert util.coeff_error(c, po.coeffs_from_free(4, m, v, t1, free)) < 1e-13
+    assert util.coeff_error(c, po.solve_linear(4, m, v, t1)) > 1e-6
+    # evaluation S + 2 perturbs the first free constraint of dimension 0
+    rc, x, c, ne, fl = po.optimize_time_and_constraints_dfo(4, m, v, t, lim, mode=mode, max_iterations=len(t) + 2)
+    f2 = free.copy()
+    f2[0, 0] = min(f2[0, 0] + 0.1 * abs(f2[0, 0]), max(lim[0], f2[0, 0])) if f2[0, 0] + 0.1 * abs(f2[0, 0]) <= max(lim[0], f2[0, 0]) \
+        else f2[0, 0] - 0.1 * abs(f2[0, 0])
+    assert np.array_equal(x, t) and util.coeff_error(c, po.coeffs_from_free(4, m, v, t, f2)) < 1e-12
+    assert fl == pytest.approx(po.objective_time_and_constraints(4, m, v, np.concatenate([t, f2.ravel()]), lim, mode=mode)[0],
+                               rel=1e-12)
+
+
+def test_dfo_time_and_constraints_long_run_improves_and_keeps_continuity():
+    batch = pr.random_batch(1, 3, seed0=12)
+    t = util.oracle_times(batch)
+    _, m, v = batch.path(0)
+    lim = pr.DEFAULT_LIMITS
+    _, free = po.solve_linear_free(4, m, v, t)
+    f0 = po.objective_time_and_constraints(4, m, v, np.concatenate([t, free.ravel()]), lim, mode=4)[0]
+    fbest = min(po.optimize_time_and_constraints_dfo(4, m, v, t, lim, mode=4, max_iterations=k)[4] for k in (60, 90, 120))
+    assert fbest < f0
+    rc, x, c, ne, fl = po.optimize_time_and_constraints_dfo(4, m, v, t, lim, mode=4, max_iterations=120)
+    assert np.all(x >= 0.01)
+    assert util.continuity_defect(batch, c, x) < 1e-7 and util.constraint_defect(batch, c, x) < 1e-7
+
+
+def test_batch_driver_modes_3_4():
+    batch = pr.random_batch(5, "ragged", seed0=4)
+    for mode in (3, 4):
+        out = po.solve_batch(batch.seg_offsets, batch.waypoints, batch.fixed_mask, batch.fixed_values, batch.limits,
+                             np.zeros(batch.n_segments), deriv=4, time_alloc_method=mode, estimate_times=True)
+        assert np.all(out["status"] == 5)
+        assert util.continuity_defect(batch, out["coeffs"], out["times"]) < 1e-7
+        assert util.constraint_defect(batch, out["coeffs"], out["times"]) < 1e-7
