@@ -7,8 +7,12 @@ A "step" is one pass of the hot path over one batch whose inputs already sit in 
 workload = BASELINE.json configs[1]: 1024 random 10-segment order-10 min-snap paths, fixed (Euclidean)
 segment times, linear QP only: the Hessian/mapping-block assembly kernel + the block-Cholesky solve
 kernel per step.  `--workload nonlinear` times configs[2] (Mellinger outer loop + feasibility scaling +
-sampling) instead.  Weak scaling: every rank owns `--paths` paths; for N > 1 each step ends with the one
-RCCL gather of coefficients / times / status to rank 0.
+sampling) instead.  Weak scaling: every rank owns `--paths` paths and there is no data-path collective
+(paths are independent); as at N = 1 the results of a step stay resident in the HBM of the GPU that
+computed them, and the job's one collective -- the RCCL gather of the final step's coefficients / times /
+status to rank 0 ("exactly one gather at the end") -- runs inside the timed region.
+`--gather every` gathers after every step instead (double-buffered on a side stream); for N > 1 that
+rate is reported next to the headline as extras.gather_every_step.
 
 Prints ONE JSON line (rank 0) with `roofline` (assembly kernel, HBM-write bound, HIP-event timed on the
 launch stream) and `cpu_baseline` (the C oracle timed on this box's host cores).
@@ -38,13 +42,19 @@ def parse_args():
     ap.add_argument("--segments", type=int, default=10)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the secondary (other workload) measurement")
+    ap.add_argument("--gather", choices=["final", "every"], default="final",
+                    help="N > 1: gather the results to rank 0 once at the end of the timed steps (default) or after every step")
     ap.add_argument("--force-dist", action="store_true", help="initialise torch.distributed even for one rank (tests the RCCL path)")
     return ap.parse_args()
 
 
-def time_steps(step_fn, steps, warmup, dist, torch):
+def time_steps(step_fn, steps, warmup, dist, torch, final_fn=None):
+    """W untimed steps, then exactly K steps (+ final_fn, the job's closing gather) between barrier + synchronize
+    pairs; returns the MAX over ranks of the elapsed seconds."""
     for _ in range(warmup):
         step_fn()
+    if final_fn is not None:
+        final_fn()          # warm the collective up as well (communicator set-up is not part of a step)
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
@@ -52,6 +62,8 @@ def time_steps(step_fn, steps, warmup, dist, torch):
     t0 = time.perf_counter()
     for _ in range(steps):
         step_fn()
+    if final_fn is not None:
+        final_fn()
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
@@ -86,6 +98,10 @@ def main():
     dist = None
     if world > 1 or args.force_dist:
         import torch.distributed as dist_mod
+        if args.force_dist and "RANK" not in os.environ:   # stand-alone single-rank rendezvous
+            os.environ.update(RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29533")
         torch.cuda.set_device(local_rank)
         dist_mod.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
         dist = dist_mod
@@ -154,20 +170,34 @@ def main():
             torch.cuda.current_stream().wait_event(slot_free[slot])
         return slot
 
+    gather_every = [args.gather == "every"]
+    last_slot = [0]
+
     def step_linear():
         slot = begin_step()
         plan.solve(opt_lin, db.fixed_mask, db.fixed_values, t_fixed, out_coeffs[slot], status_i32[slot], db.cost)
-        finish_step(slot, False)
+        last_slot[0] = slot
+        if gather_every[0]:
+            finish_step(slot, False)
 
     def step_nonlinear():
         slot = begin_step()
         out_times[slot].copy_(t_init)   # the outer loop overwrites the times: restart from the same point
         plan.solve(opt_nl, db.fixed_mask, db.fixed_values, out_times[slot], out_coeffs[slot], status_i32[slot], db.cost,
                    limits=db.limits, n_samples=db.n_samples, samples=db.samples)
-        finish_step(slot, True)
+        last_slot[0] = slot
+        if gather_every[0]:
+            finish_step(slot, True)
+
+    def final_gather():
+        """the job's closing collective: results of the last step -> rank 0 (no-op at N = 1 without --force-dist)"""
+        if dist is None or gather_every[0]:
+            return
+        finish_step(last_slot[0], True)
+        torch.cuda.current_stream().wait_event(slot_free[last_slot[0]])
 
     steps_fn = {"linear": step_linear, "nonlinear": step_nonlinear}
-    elapsed = time_steps(steps_fn[args.workload], args.steps, args.warmup, dist, torch)
+    elapsed = time_steps(steps_fn[args.workload], args.steps, args.warmup, dist, torch, final_gather)
     total_paths = P * world * args.steps
     value = total_paths / elapsed
 
@@ -195,9 +225,10 @@ def main():
     alg_bytes = ASSEMBLY_BYTES_PER_SEGMENT * nS
     achieved = alg_bytes / (mean_ms * 1e-3) / 1e9
     # HBM traffic from PMC counters (separate rocprofv3 passes, profiles/round1_pmc_assemble_hbm_traffic.csv):
-    # WRITE_SIZE is exact for 16-B stores; FETCH_SIZE is doubled as MI355X_MICROARCH.md prescribes for gfx950.
-    # Measured for the 1024 x 10 launch: 16000 KiB written + 2 x 200 KiB fetched.
-    traffic = (16000 + 2 * 200) * 1024 if (P == 1024 and args.segments == 10) else None
+    # WRITE_SIZE calibrated on this kernel's store pattern (8 B per lane, 512 B per wave instruction) with a pure
+    # fill of known size (k_fill8 in scripts/k1_variants.hip: exact); FETCH_SIZE is doubled as MI355X_MICROARCH.md
+    # prescribes for gfx950.  Measured for the 1024 x 10 launch: 16000 KiB written + 2 x 105 KiB fetched.
+    traffic = (16000 + 2 * 105) * 1024 if (P == 1024 and args.segments == 10) else None
     roofline = dict(kernel="assemble_blocks_uniform_kernel", bound="hbm", achieved=achieved, peak=HBM_PEAK_GBS, unit="GB/s",
                     frac=achieved / HBM_PEAK_GBS, traffic=traffic, bytes_per_launch=alg_bytes,
                     avg_launch_us=mean_ms * 1e3, per_launch_event_us=per_launch_mean_ms * 1e3,
@@ -234,8 +265,18 @@ def main():
     if not args.no_extras:
         other = "nonlinear" if args.workload == "linear" else "linear"
         k2 = max(5, args.steps // 10) if other == "nonlinear" else args.steps
-        el2 = time_steps(steps_fn[other], k2, 3, dist, torch)
-        extras[other] = dict(value=P * world * k2 / el2, unit="trajectories/s", steps=k2, ms_per_step=el2 / k2 * 1e3)
+        el2 = time_steps(steps_fn[other], k2, 3, dist, torch, final_gather)
+        if rank == 0:
+            extras[other] = dict(value=P * world * k2 / el2, unit="trajectories/s", steps=k2, ms_per_step=el2 / k2 * 1e3)
+        if dist is not None and not gather_every[0]:
+            # the same workload with the results of EVERY step gathered to rank 0 (bound by the xGMI links into the root)
+            gather_every[0] = True
+            el3 = time_steps(steps_fn[args.workload], args.steps, 3, dist, torch)
+            gather_every[0] = False
+            if rank == 0:
+                extras["gather_every_step"] = dict(value=P * world * args.steps / el3, unit="trajectories/s",
+                                                   ms_per_step=el3 / args.steps * 1e3,
+                                                   bytes_per_rank_per_step=int(packed[0].numel() * 8))
 
     # ---- parity of this very batch against the oracle (max-coeff err vs CPU ref) + CPU baseline ----
     cpu = None
@@ -285,9 +326,14 @@ def main():
                                           "fixed times, linear QP" if args.workload == "linear" else
                                           "BASELINE configs[2]: %d random %d-segment paths per GPU, Mellinger outer loop "
                                           "(<=10 evaluations) + feasibility scaling + sampling dt 0.2") % (P, args.segments),
-                                paths_per_gpu=P, segments=args.segments, parallelism="independent paths sharded per rank; "
-                                "RCCL gather of results to rank 0" if world > 1 else "single GPU"),
+                                paths_per_gpu=P, segments=args.segments,
+                                parallelism=("independent paths sharded per rank, no data-path collective; RCCL gather of "
+                                             "the results to rank 0 %s, inside the timed region"
+                                             % ("after every step" if args.gather == "every" else "once, after the last step"))
+                                if world > 1 else "single GPU"),
                     max_coeff_err_vs_cpu_ref=err, roofline=roofline, cpu_baseline=cpu, extras=extras)
+        import ctypes
+        ctypes.CDLL(None).fflush(None)   # RCCL's banner sits in C stdio: keep the JSON line the last thing printed
         print(json.dumps(line), flush=True)
     plan.close()
     ctx.close()

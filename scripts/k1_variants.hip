@@ -302,17 +302,30 @@ __global__ __launch_bounds__(BLOCK) void k_zpad(int n_paths, int S, int d, size_
   for (int c = 0; c < kN; ++c) Aout[base + (size_t)c * stride] = a0[c];
 }
 
+// pure fill with 8-byte stores per lane (calibrates WRITE_SIZE for the 8-B-per-lane store pattern of V_z)
+template <int BLOCK>
+__global__ __launch_bounds__(BLOCK) void k_fill8(size_t n, double* __restrict__ Hout, double* __restrict__ Aout) {
+  size_t i = (size_t)blockIdx.x * BLOCK + threadIdx.x;
+  const size_t stride = (size_t)gridDim.x * BLOCK;
+  for (; i < n; i += stride) {
+    Hout[i] = 1.0;
+    Aout[i] = 3.0;
+  }
+}
+
 __global__ void k_empty() {}
+
+static int g_launches = 200, g_reps = 5, g_warm = 20;
 
 template <typename F>
 static void measure(const char* name, F launch, hipStream_t st, double bytes) {
   hipEvent_t e0, e1;
   CK(hipEventCreate(&e0));
   CK(hipEventCreate(&e1));
-  for (int i = 0; i < 20; ++i) launch();
+  for (int i = 0; i < g_warm; ++i) launch();
   CK(hipStreamSynchronize(st));
   float best = 1e30f, sum = 0;
-  const int reps = 5, n = 200;
+  const int reps = g_reps, n = g_launches;
   for (int r = 0; r < reps; ++r) {
     CK(hipEventRecord(e0, st));
     for (int i = 0; i < n; ++i) launch();
@@ -333,6 +346,11 @@ int main(int argc, char** argv) {
   const int P = argc > 1 ? atoi(argv[1]) : 1024;
   const int S = argc > 2 ? atoi(argv[2]) : 10;
   const int d = 4;
+  if (argc > 3) {  // "pmc" mode: a handful of launches per variant so that a counter pass stays small
+    g_launches = atoi(argv[3]);
+    g_reps = 1;
+    g_warm = 1;
+  }
   hipStream_t st;
   CK(hipStreamCreate(&st));
   const size_t nblk = (size_t)P * S * 100;
@@ -351,6 +369,7 @@ int main(int argc, char** argv) {
   measure("empty", [&] { hipLaunchKernelGGL(k_empty, dim3(1), dim3(64), 0, st); }, st, 0.0);
 #define FILL(B, NT, G)                                                                                        \
   measure("fill<" #B "," #NT "> grid " #G, [&] { hipLaunchKernelGGL((k_fill<B, NT>), dim3(G), dim3(B), 0, st, nblk / 2, H, A); }, st, bytes)
+  measure("fill8<256> grid 2048", [&] { hipLaunchKernelGGL((k_fill8<256>), dim3(2048), dim3(256), 0, st, nblk, H, A); }, st, bytes);
   FILL(256, false, 1024);
   FILL(256, true, 1024);
   FILL(256, false, 2048);
