@@ -53,18 +53,48 @@ __device__ __forceinline__ double perturbed_time(const double* xs, int i, int k,
   return T;
 }
 
+// The vertex constraints of a path do not change during the outer loop, and every objective evaluation walks all
+// of them on every lane: they are staged once per kernel in LDS (kVtxLds doubles per vertex: the 5 x 4 constrained
+// values, 0 where free, then the free mask).  Read from global memory inside the sweep, each segment step exposed
+// one L2 round trip on the only wavefront of its SIMD.
+constexpr int kVtxLds = 22;
+
+__device__ __forceinline__ void stage_vertices(const uint8_t* __restrict__ mask, const double* __restrict__ vals, int v0,
+                                               int S, double* vtx, int g, int G) {
+  for (int v = g; v <= S; v += G) {
+    double f[kHalf][kD];
+    bool pf;
+    const unsigned fb = load_vertex<kD>(mask, vals, v0 + v, 0, f, pf);
+    double* r = vtx + (size_t)v * kVtxLds;
+#pragma unroll
+    for (int k = 0; k < kHalf; ++k)
+#pragma unroll
+      for (int dd = 0; dd < kD; ++dd) r[k * kD + dd] = f[k][dd];
+    r[20] = (double)fb;
+    r[21] = pf ? 1.0 : 0.0;
+  }
+}
+
 template <int ND>
-__device__ __forceinline__ double forward_cost(const uint8_t* __restrict__ mask, const double* __restrict__ vals, int v0,
-                                               int S, int d, const double* xs, int k, int dim0) {
+__device__ __forceinline__ unsigned staged_vertex(const double* vtx, int v, int dim0, double (&f)[kHalf][ND]) {
+  const double* r = vtx + (size_t)v * kVtxLds;
+#pragma unroll
+  for (int k = 0; k < kHalf; ++k)
+#pragma unroll
+    for (int dd = 0; dd < ND; ++dd) f[k][dd] = r[k * kD + dim0 + dd];
+  return (unsigned)r[20];
+}
+
+template <int ND>
+__device__ __forceinline__ double forward_cost(const double* vtx, int S, int d, const double* xs, int k, int dim0) {
   Elim<ND> st;
   st.init();
   double fs[kHalf][ND], fe[kHalf][ND];
   double L[10], z[kNB][ND], W[kNB][kNB];
-  bool pf;
-  unsigned free_s = load_vertex<ND>(mask, vals, v0, dim0, fs, pf);
+  unsigned free_s = staged_vertex<ND>(vtx, 0, dim0, fs);
   const double corr = kGradStep / ((double)S - 1.0);
   for (int i = 0; i < S; ++i) {
-    const unsigned free_e = load_vertex<ND>(mask, vals, v0 + i + 1, dim0, fe, pf);
+    const unsigned free_e = staged_vertex<ND>(vtx, i + 1, dim0, fe);
     double Hs[kSym10];
     hessian_from_time(perturbed_time(xs, i, k, corr), d, Hs);
     st.absorb_segment(Hs, fs, fe, free_s, free_e, L, z, W);
@@ -270,16 +300,17 @@ __device__ __forceinline__ bool relstop(double vold, double vnew, double reltol,
   return dv < abstol || dv < reltol * (fabs(vnew) + fabs(vold)) * 0.5 || (reltol > 0 && vnew == vold);
 }
 
-// per-group LDS block (doubles): x, g, xn, gn, dir [5*Sb], s[M][Sb], y[M][Sb], rho[M]
-__host__ __device__ constexpr int group_lds_doubles(int Sb) { return (5 + 2 * kLbfgsM) * Sb + kLbfgsM; }
+// per-group LDS block (doubles): x, g, xn, gn, dir [5*Sb], s[M][Sb], y[M][Sb], rho[M], staged vertices [(Sb+1)*kVtxLds]
+__host__ __device__ constexpr int group_lds_doubles(int Sb) { return (5 + 2 * kLbfgsM) * Sb + kLbfgsM + (Sb + 1) * kVtxLds; }
+// cost_gradient_kernel: x, g [2*Sb], staged vertices
+__host__ __device__ constexpr int gradient_lds_doubles(int Sb) { return 2 * Sb + (Sb + 1) * kVtxLds; }
 
 // objective evaluation at `pt`: cost returned to every lane of the group, gradient to `grad` (LDS).
 // (objectiveFunctionTimeMellingerOuterLoop + getCostAndGradientMellinger)
 // DS lanes share one time vector (DS = 1: one lane, four dimensions; DS = 4: four lanes, one dimension each).
 template <int DS>
-__device__ __forceinline__ double evaluate_objective(const uint8_t* __restrict__ mask, const double* __restrict__ vals,
-                                                     int v0, int S, int d, const double* pt, double* grad, int g, int G,
-                                                     bool active) {
+__device__ __forceinline__ double evaluate_objective(const double* vtx, int S, int d, const double* pt, double* grad, int g,
+                                                     int G, bool active) {
   constexpr int ND = kD / DS;
   const int kl = G / DS;  // time vectors handled per round
   const int kk = g / DS, dim0 = (g % DS) * ND;
@@ -288,7 +319,7 @@ __device__ __forceinline__ double evaluate_objective(const uint8_t* __restrict__
   for (int r = 0; r < rounds; ++r) {
     const int k = kk + r * kl;
     double Jk = 0.0;
-    if (active && k <= S && (k == 0 || S > 1)) Jk = forward_cost<ND>(mask, vals, v0, S, d, pt, k, dim0);
+    if (active && k <= S && (k == 0 || S > 1)) Jk = forward_cost<ND>(vtx, S, d, pt, k, dim0);
     if (DS == 4) {
       Jk += __shfl_xor(Jk, 1, 64);
       Jk += __shfl_xor(Jk, 2, 64);
@@ -341,6 +372,8 @@ __global__ __launch_bounds__(64) void optimize_kernel(BatchView b, NonlinearPara
   double* sm = dir + Sb;            // [M][Sb]
   double* ym = sm + kLbfgsM * Sb;   // [M][Sb]
   double* rho = ym + kLbfgsM * Sb;  // [M]
+  double* vtx = rho + kLbfgsM;      // [(Sb + 1) * kVtxLds]
+  if (active) stage_vertices(mask, vals, pr.v0, S, vtx, g, G);
 
   // ---- start point; NLopt rejects a start below the lower bound (-> INVALID_ARGS)
   int ok = 1;
@@ -367,7 +400,7 @@ __global__ __launch_bounds__(64) void optimize_kernel(BatchView b, NonlinearPara
     if (!running) break;
 
     // (1) one objective evaluation at the trial point
-    const double fn = evaluate_objective<DS>(mask, vals, pr.v0, S, d, xn, gn, g, G, !done);
+    const double fn = evaluate_objective<DS>(vtx, S, d, xn, gn, g, G, !done);
     __syncthreads();
     bool new_dir = false;
     if (!done) {
@@ -572,12 +605,15 @@ __global__ __launch_bounds__(64) void cost_gradient_kernel(BatchView b, int d, i
   const int qi = blockIdx.x * (64 / G) + grp;
   const bool active = qi < q_count;
   const PathRef pr = path_at(b, q_begin + (active ? qi : 0));
-  double* x = lds + (size_t)grp * 2 * Sb;
+  double* x = lds + (size_t)grp * gradient_lds_doubles(Sb);
   double* gr = x + Sb;
-  if (active)
+  double* vtx = gr + Sb;
+  if (active) {
     for (int i = g; i < pr.S; i += G) x[i] = seg_times[pr.s0 + i];
+    stage_vertices(mask, vals, pr.v0, pr.S, vtx, g, G);
+  }
   __syncthreads();
-  const double J = evaluate_objective<DS>(mask, vals, pr.v0, pr.S, d, x, gr, g, G, active);
+  const double J = evaluate_objective<DS>(vtx, pr.S, d, x, gr, g, G, active);
   __syncthreads();
   if (active) {
     for (int i = g; i < pr.S; i += G) grad[pr.s0 + i] = gr[i];
@@ -1164,7 +1200,7 @@ hipError_t launch_cost_gradient(NonlinearPlan& nl, const BatchView& b, int d, co
                                 const double* seg_times, double* cost, double* grad, hipStream_t stream) {
   for (const NonlinearBin& bin : nl.bins) {
     const int per_block = 64 / bin.group;
-    const size_t lds_bytes = (size_t)per_block * 2 * bin.max_S * sizeof(double);
+    const size_t lds_bytes = (size_t)per_block * gradient_lds_doubles(bin.max_S) * sizeof(double);
     if (lds_bytes > 160 * 1024) return hipErrorInvalidValue;
     const dim3 grid(cdiv_u(bin.q_count, per_block));
     if (nl.dim_split == 4)

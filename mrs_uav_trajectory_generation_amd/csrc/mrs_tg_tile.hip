@@ -14,9 +14,14 @@
 //       LDS-resident 4x4 blocks, meeting at the middle vertex                                  (serial, S/2 deep)
 //   C   one lane per (segment, dimension): c = A^-1 d -> global coefficients                (parallel)
 // so the serial lanes execute only the chain (~1/3 of the instructions of the one-lane kernel).
+// Wavefront 0 of the 256-thread workgroup owns A0 and B; wavefronts 1-3 ("workers") own A1 and C.  The workers'
+// global loads never wait for a phase boundary: the blocks (or segment time) of a worker's first A1 item are
+// requested before A0 runs, and the A^-1 rows of its first C item before B runs, so both latencies hide behind
+// the other wavefront's phase.
 #include <hip/hip_runtime.h>
 
 #include <cstdint>
+#include <type_traits>
 
 #include "mrs_tg_device.hpp"
 #include "mrs_tg_solve.hpp"
@@ -29,18 +34,36 @@ constexpr int kVtxRec = 42 + 20 + 2;                 // L[10] W[16] z[4][4] | d[
 
 __host__ __device__ constexpr int tile_path_doubles(int S) { return S * kSegRec + (S + 1) * kVtxRec; }
 
+// optional phase clocks (scripts/tile_phases.hip defines MRS_TG_PHASE_CLOCKS; compiled out of the library)
+#ifdef MRS_TG_PHASE_CLOCKS
+__device__ long long g_phase_clock[8];
+#define MRS_TG_PHASE_MARK_T(i, thread)                                                          \
+  do {                                                                                          \
+    if (blockIdx.x == gridDim.x / 2 && threadIdx.x == (thread)) g_phase_clock[i] = clock64();   \
+  } while (0)
+#else
+#define MRS_TG_PHASE_MARK_T(i, thread)
+#endif
+#define MRS_TG_PHASE_MARK(i) MRS_TG_PHASE_MARK_T(i, 0)
+
+constexpr int kTileThreads = 256;
+constexpr int kTileWorkers = kTileThreads - 64;
+
 template <bool FUSED>
-__global__ __launch_bounds__(128) void solve_tile_kernel(BatchView b, int d, int TP, int Smax,
-                                                         const uint8_t* __restrict__ mask,
-                                                         const double* __restrict__ vals,
-                                                         const double* __restrict__ seg_times,
-                                                         const double* __restrict__ Hblk, const double* __restrict__ Ablk,
-                                                         double* __restrict__ coeffs, int32_t* __restrict__ status,
-                                                         double* __restrict__ cost,
-                                                         const int32_t* __restrict__ status_in) {
+__global__ __launch_bounds__(kTileThreads) void solve_tile_kernel(BatchView b, int d, int TP, int Smax,
+                                                                  const uint8_t* __restrict__ mask,
+                                                                  const double* __restrict__ vals,
+                                                                  const double* __restrict__ seg_times,
+                                                                  const double* __restrict__ Hblk,
+                                                                  const double* __restrict__ Ablk,
+                                                                  double* __restrict__ coeffs, int32_t* __restrict__ status,
+                                                                  double* __restrict__ cost,
+                                                                  const int32_t* __restrict__ status_in) {
   extern __shared__ double lds[];
   __shared__ int s_S[16], s_s0[16], s_v0[16], s_p[16];
   const int tid = threadIdx.x;
+  const int wtid = tid - 64;  // worker index; negative on wavefront 0
+  MRS_TG_PHASE_MARK(0);
   const int q0 = blockIdx.x * TP;
   const int n_here = min(TP, b.n_paths - q0);
   const int PS = tile_path_doubles(Smax);
@@ -53,13 +76,47 @@ __global__ __launch_bounds__(128) void solve_tile_kernel(BatchView b, int d, int
     s_v0[tid] = pr.v0;
     s_p[tid] = pr.p;
   }
-  __syncthreads();
-
   auto seg_rec = [&](int t, int i) { return lds + (size_t)t * PS + (size_t)i * kSegRec; };
   auto vtx_rec = [&](int t, int v) { return lds + (size_t)t * PS + (size_t)Smax * kSegRec + (size_t)v * kVtxRec; };
+  // an all-zero segment record stands in for "no segment on this side" (vertex 0 has no left segment, vertex S no
+  // right one), so that phase B loads both neighbours unconditionally: a branch per matrix entry around an LDS load
+  // serialises the load latencies (measured: 5300 -> 2500 shader cycles per elimination step)
+  double* zero_rec = lds + (size_t)TP * PS;
+  if (tid >= 64 && tid < 64 + kSegRec) zero_rec[tid - 64] = 0.0;
+  __syncthreads();
+  MRS_TG_PHASE_MARK(1);
 
-  // ---- A0: vertex constraints -> d (constrained values, 0 where free), free bits
-  for (int item = tid; item < n_here * (Smax + 1); item += 128) {
+  // item = (segment i, path t of the tile, dimension): the unit of the parallel phases A1 and C
+  const int n_items = n_here * Smax * kD;
+  auto item_valid = [&](int item, int& t, int& i, int& dim) {
+    dim = item % kD;
+    t = (item / kD) % n_here;
+    i = item / (kD * n_here);
+    return item < n_items && i < s_S[t];
+  };
+
+  // workers: request the inputs of their first A1 item now; they arrive while A0 runs
+  double Hs[kSym10];
+  double T_first = 1.0;
+  {
+    int t, i, dim;
+    if (wtid >= 0 && item_valid(wtid, t, i, dim)) {
+      if (FUSED) {
+        T_first = seg_times[s_s0[t] + i];
+      } else {
+        const BlockSource src{Hblk, Ablk, P, q0 + t};
+        load_H_blocks(src, i, Hs);
+      }
+    }
+  }
+
+  // ---- A0: vertex constraints -> d (constrained values, 0 where free), free bits; the hand-over area of every
+  // path's middle vertex is zeroed (phase B reads it even when nothing was handed over)
+  for (int e = tid; e < n_here * 42; e += kTileThreads) {
+    const int t = e / 42;
+    vtx_rec(t, s_S[t] / 2)[e % 42] = 0.0;
+  }
+  for (int item = tid; item < n_here * (Smax + 1); item += kTileThreads) {
     const int t = item % n_here, v = item / n_here;
     if (v > s_S[t]) continue;
     double f[kHalf][kD];
@@ -74,60 +131,70 @@ __global__ __launch_bounds__(128) void solve_tile_kernel(BatchView b, int d, int
     r[63] = pos_fixed ? 1.0 : 0.0;
   }
   __syncthreads();
+  MRS_TG_PHASE_MARK(2);
 
-  // ---- A1: per (segment, dimension): u = H [f_i; f_{i+1}], masked 4x4 blocks
-  for (int item = tid; item < n_here * Smax * kD; item += 128) {
-    const int dim = item % kD;
-    const int t = (item / kD) % n_here;
-    const int i = item / (kD * n_here);
-    if (i >= s_S[t]) continue;
-    double Hs[kSym10];
-    if (FUSED) {
-      hessian_from_time(seg_times[s_s0[t] + i], d, Hs);
-    } else {
-      const BlockSource src{Hblk, Ablk, P, q0 + t};
-      load_H_blocks(src, i, Hs);
-    }
-    const double* vs = vtx_rec(t, i);
-    const double* ve = vtx_rec(t, i + 1);
-    const unsigned free_s = (unsigned)vs[62], free_e = (unsigned)ve[62];
-    double f[kN];
+  // ---- A1 (workers): per (segment, dimension): u = H [f_i; f_{i+1}], masked 4x4 blocks
+  if (wtid >= 0) {
+    for (int item = wtid; item < n_items; item += kTileWorkers) {
+      int t, i, dim;
+      if (!item_valid(item, t, i, dim)) continue;
+      if (FUSED) {
+        hessian_from_time((item == wtid) ? T_first : seg_times[s_s0[t] + i], d, Hs);
+      } else if (item != wtid) {
+        const BlockSource src{Hblk, Ablk, P, q0 + t};
+        load_H_blocks(src, i, Hs);
+      }
+      const double* vs = vtx_rec(t, i);
+      const double* ve = vtx_rec(t, i + 1);
+      const unsigned free_s = (unsigned)vs[62], free_e = (unsigned)ve[62];
+      double f[kN];
 #pragma unroll
-    for (int k = 0; k < kHalf; ++k) {
-      f[k] = vs[42 + k * kD + dim];
-      f[kHalf + k] = ve[42 + k * kD + dim];
-    }
-    double* rec = seg_rec(t, i);
-    double qf = 0.0;
+      for (int k = 0; k < kHalf; ++k) {
+        f[k] = vs[42 + k * kD + dim];
+        f[kHalf + k] = ve[42 + k * kD + dim];
+      }
+      double* rec = seg_rec(t, i);
+      double qf = 0.0;
 #pragma unroll
-    for (int a = 0; a < kN; ++a) {
-      double u = 0.0;
+      for (int a = 0; a < kN; ++a) {
+        double u = 0.0;
 #pragma unroll
-      for (int c = 0; c < kN; ++c) u += Hs[sym10(a, c)] * f[c];
-      qf += f[a] * u;
-      if (a >= kSlot0 && a < kHalf) rec[36 + (a - kSlot0) * kD + dim] = ((free_s >> (a - kSlot0)) & 1u) ? u : 0.0;
-      if (a >= kHalf + kSlot0) rec[52 + (a - kHalf - kSlot0) * kD + dim] = ((free_e >> (a - kHalf - kSlot0)) & 1u) ? u : 0.0;
-    }
-    rec[68 + dim] = qf;
-    if (dim == 0) {
+        for (int c = 0; c < kN; ++c) u += Hs[sym10(a, c)] * f[c];
+        qf += f[a] * u;
+        if (a >= kSlot0 && a < kHalf) rec[36 + (a - kSlot0) * kD + dim] = ((free_s >> (a - kSlot0)) & 1u) ? u : 0.0;
+        if (a >= kHalf + kSlot0) rec[52 + (a - kHalf - kSlot0) * kD + dim] = ((free_e >> (a - kHalf - kSlot0)) & 1u) ? u : 0.0;
+      }
+      rec[68 + dim] = qf;
+      if (dim == 0) {
 #pragma unroll
-      for (int r = 0; r < kNB; ++r) {
-        const bool sr = (free_s >> r) & 1u, er = (free_e >> r) & 1u;
+        for (int r = 0; r < kNB; ++r) {
+          const bool sr = (free_s >> r) & 1u, er = (free_e >> r) & 1u;
 #pragma unroll
-        for (int c = 0; c <= r; ++c) {
-          const bool sc = (free_s >> c) & 1u, ec = (free_e >> c) & 1u;
-          rec[tri(r, c)] = (sr && sc) ? Hs[sym10(kSlot0 + r, kSlot0 + c)] : 0.0;
-          rec[26 + tri(r, c)] = (er && ec) ? Hs[sym10(kHalf + kSlot0 + r, kHalf + kSlot0 + c)] : 0.0;
-        }
+          for (int c = 0; c <= r; ++c) {
+            const bool sc = (free_s >> c) & 1u, ec = (free_e >> c) & 1u;
+            rec[tri(r, c)] = (sr && sc) ? Hs[sym10(kSlot0 + r, kSlot0 + c)] : 0.0;
+            rec[26 + tri(r, c)] = (er && ec) ? Hs[sym10(kHalf + kSlot0 + r, kHalf + kSlot0 + c)] : 0.0;
+          }
 #pragma unroll
-        for (int c = 0; c < kNB; ++c) {
-          const bool ec = (free_e >> c) & 1u;
-          rec[10 + r * kNB + c] = (sr && ec) ? Hs[sym10(kSlot0 + r, kHalf + kSlot0 + c)] : 0.0;
+          for (int c = 0; c < kNB; ++c) {
+            const bool ec = (free_e >> c) & 1u;
+            rec[10 + r * kNB + c] = (sr && ec) ? Hs[sym10(kSlot0 + r, kHalf + kSlot0 + c)] : 0.0;
+          }
         }
       }
     }
   }
+  // workers: request the A^-1 rows of their first C item; they arrive while wavefront 0 runs phase B
+  AinvRows ar_first;
+  if (!FUSED) {
+    int t, i, dim;
+    if (wtid >= 0 && item_valid(wtid, t, i, dim)) {
+      const BlockSource src{Hblk, Ablk, P, q0 + t};
+      load_A_blocks(src, i, ar_first);
+    }
+  }
   __syncthreads();
+  MRS_TG_PHASE_MARK(3);
 
   // ---- B: the vertex chain, eight lanes per path: lane = (direction, dimension).
   // Two-sided ("twisted") block elimination: direction 0 eliminates vertices 0, 1, ... from the left,
@@ -148,46 +215,54 @@ __global__ __launch_bounds__(128) void solve_tile_kernel(BatchView b, int d, int
 #pragma unroll
       for (int c = 0; c < kNB; ++c) Wp[r][c] = 0.0;
     }
-    // one elimination step at vertex v; `outer` = the already eliminated neighbour exists (Wp, zp valid);
-    // `inner` = there is a next vertex towards the middle to couple with
-    auto eliminate = [&](int v, bool outer, bool inner, bool middle) {
+    // One elimination step at vertex v.  INNER: there is a next vertex towards the middle to couple with;
+    // MIDDLE: v is the middle vertex, whose record holds the other side's Schur update (zero if there is none).
+    // Everything is loaded unconditionally up front (absent neighbours read the zero record, the first step
+    // subtracts the zero-initialised Wp / zp), so the step has one LDS round trip and no divergent branches.
+    auto eliminate = [&](int v, auto inner_tag, auto middle_tag) {
+      constexpr bool INNER = decltype(inner_tag)::value, MIDDLE = decltype(middle_tag)::value;
       double* vr = vtx_rec(t, v);
       const unsigned fb = (unsigned)vr[62];
-      const double* left = (v > 0) ? seg_rec(t, v - 1) : nullptr;   // segment v-1 ends at v
-      const double* right = (v < S) ? seg_rec(t, v) : nullptr;      // segment v starts at v
-      double Sm[10], y[kNB];
+      const double* left = (v > 0) ? seg_rec(t, v - 1) : zero_rec;   // segment v-1 ends at v
+      const double* right = (v < S) ? seg_rec(t, v) : zero_rec;      // segment v starts at v
+      const double* cb = dir ? left : right;                         // coupling towards the middle
+      double Sm[10], y[kNB], E[kNB][kNB];
+#pragma unroll
+      for (int e = 0; e < 10; ++e) Sm[e] = left[26 + e] + right[e];
+#pragma unroll
+      for (int r = 0; r < kNB; ++r) y[r] = -(left[52 + r * kD + dim] + right[36 + r * kD + dim]);
+      if (INNER) {
+        // direction 0: E~_v[r][c]; direction 1: E~_{v-1} transposed
+        double raw[kNB][kNB];
+#pragma unroll
+        for (int r = 0; r < kNB; ++r)
+#pragma unroll
+          for (int c = 0; c < kNB; ++c) raw[r][c] = cb[10 + r * kNB + c];
+#pragma unroll
+        for (int r = 0; r < kNB; ++r)
+#pragma unroll
+          for (int c = 0; c < kNB; ++c) E[r][c] = dir ? raw[c][r] : raw[r][c];
+      }
+      if (MIDDLE) {
+#pragma unroll
+        for (int e = 0; e < 10; ++e) Sm[e] -= vr[e];
+#pragma unroll
+        for (int r = 0; r < kNB; ++r) y[r] -= vr[26 + r * kD + dim];
+      }
 #pragma unroll
       for (int r = 0; r < kNB; ++r) {
-        const bool fr = (fb >> r) & 1u;
 #pragma unroll
         for (int c = 0; c <= r; ++c) {
-          double s = 0.0;
-          if (left) s += left[26 + tri(r, c)];
-          if (right) s += right[tri(r, c)];
-          if (outer) {
+          double s = Sm[tri(r, c)];
 #pragma unroll
-            for (int k = 0; k < kNB; ++k) s -= Wp[k][r] * Wp[k][c];
-          }
-          Sm[tri(r, c)] = (r == c && !fr) ? 1.0 : s;
+          for (int k = 0; k < kNB; ++k) s -= Wp[k][r] * Wp[k][c];
+          Sm[tri(r, c)] = s;
         }
-        double s = 0.0;
-        if (left) s -= left[52 + r * kD + dim];
-        if (right) s -= right[36 + r * kD + dim];
-        if (outer) {
+        double s = y[r];
 #pragma unroll
-          for (int k = 0; k < kNB; ++k) s -= Wp[k][r] * zp[k];
-        }
+        for (int k = 0; k < kNB; ++k) s -= Wp[k][r] * zp[k];
         y[r] = s;
-      }
-      if (middle) {
-        // the other side's Schur update and right-hand side, left in this vertex's record by direction 1
-#pragma unroll
-        for (int r = 0; r < kNB; ++r) {
-#pragma unroll
-          for (int c = 0; c <= r; ++c)
-            if (!(r == c && !((fb >> r) & 1u))) Sm[tri(r, c)] -= vr[tri(r, c)];
-          y[r] -= vr[26 + r * kD + dim];
-        }
+        if (!((fb >> r) & 1u)) Sm[tri(r, r)] = 1.0;  // constrained slot: identity row (its off-diagonals are masked to 0)
       }
 #pragma unroll
       for (int c = 0; c < kNB; ++c) {
@@ -213,27 +288,24 @@ __global__ __launch_bounds__(128) void solve_tile_kernel(BatchView b, int d, int
         z[r] = s * Linv[r];
         red += z[r] * z[r];
       }
-      if (inner) {
-        // coupling block between v (rows) and the next vertex towards the middle (columns):
-        // direction 0: E~_v[r][c]; direction 1: E~_{v-1} transposed
-        const double* cb = dir ? left : right;
+      if (INNER) {
 #pragma unroll
         for (int c = 0; c < kNB; ++c)
 #pragma unroll
           for (int r = 0; r < kNB; ++r) {
-            double s = dir ? cb[10 + c * kNB + r] : cb[10 + r * kNB + c];
+            double s = E[r][c];
 #pragma unroll
             for (int k = 0; k < r; ++k) s -= L[tri(r, k)] * W[k][c];
             W[r][c] = s * Linv[r];
           }
       }
-      // keep the factors for the backward sweep (reciprocal diagonal; W written by the dim-0 lane)
+      // keep the factors for the backward sweep (reciprocal diagonal; written by the dim-0 lane)
       if (dim == 0) {
 #pragma unroll
         for (int e = 0; e < 10; ++e) vr[e] = L[e];
 #pragma unroll
         for (int r = 0; r < kNB; ++r) vr[tri(r, r)] = Linv[r];
-        if (inner) {
+        if (INNER) {
 #pragma unroll
           for (int r = 0; r < kNB; ++r)
 #pragma unroll
@@ -242,17 +314,21 @@ __global__ __launch_bounds__(128) void solve_tile_kernel(BatchView b, int d, int
       }
 #pragma unroll
       for (int r = 0; r < kNB; ++r) vr[26 + r * kD + dim] = z[r];
+      if (INNER) {
 #pragma unroll
-      for (int r = 0; r < kNB; ++r) {
-        zp[r] = z[r];
+        for (int r = 0; r < kNB; ++r) {
+          zp[r] = z[r];
 #pragma unroll
-        for (int c = 0; c < kNB; ++c) Wp[r][c] = W[r][c];
+          for (int c = 0; c < kNB; ++c) Wp[r][c] = W[r][c];
+        }
       }
     };
+    using std::true_type;
+    using std::false_type;
 
     for (int s = 0; s < len; ++s) {
       const int v = dir ? (S - s) : s;
-      eliminate(v, s > 0, true, false);
+      eliminate(v, true_type{}, false_type{});
     }
     // direction 1 hands its Schur update W^T W and right-hand-side update W^T z for the middle vertex over
     // through that vertex's (still unused) record
@@ -284,7 +360,7 @@ __global__ __launch_bounds__(128) void solve_tile_kernel(BatchView b, int d, int
     if (dir == 0) {
       // middle vertex: left Schur update from Wp/zp (if any vertex was eliminated on the left), right one
       // from the record (if any on the right)
-      eliminate(m, m > 0, false, S - m > 0);
+      eliminate(m, false_type{}, true_type{});
       double* vr = vtx_rec(t, m);
       // x_m = L^-T z
 #pragma unroll
@@ -350,41 +426,44 @@ __global__ __launch_bounds__(128) void solve_tile_kernel(BatchView b, int d, int
     }
   }
   __syncthreads();
+  MRS_TG_PHASE_MARK(4);
 
-  // ---- C: coefficients c = A^-1 [d_i; d_{i+1}] per (segment, dimension)
-  for (int item = tid; item < n_here * Smax * kD; item += 128) {
-    const int dim = item % kD;
-    const int t = (item / kD) % n_here;
-    const int i = item / (kD * n_here);
-    if (i >= s_S[t]) continue;
-    const double* vs = vtx_rec(t, i);
-    const double* ve = vtx_rec(t, i + 1);
-    double dv[kN], c[kN];
-#pragma unroll
-    for (int k = 0; k < kHalf; ++k) {
-      dv[k] = vs[42 + k * kD + dim];
-      dv[kHalf + k] = ve[42 + k * kD + dim];
-    }
-    if (FUSED) {
-      coefficients_from_time(seg_times[s_s0[t] + i], dv, c);
-    } else {
-      const BlockSource src{Hblk, Ablk, P, q0 + t};
-      AinvRows ar;
-      load_A_blocks(src, i, ar);
-#pragma unroll
-      for (int k = 0; k < kHalf; ++k) c[k] = ar.diag[k] * dv[k];
+  // ---- C (workers): coefficients c = A^-1 [d_i; d_{i+1}] per (segment, dimension)
+  if (wtid >= 0) {
+    for (int item = wtid; item < n_items; item += kTileWorkers) {
+      int t, i, dim;
+      if (!item_valid(item, t, i, dim)) continue;
+      const double* vs = vtx_rec(t, i);
+      const double* ve = vtx_rec(t, i + 1);
+      double dv[kN], c[kN];
 #pragma unroll
       for (int k = 0; k < kHalf; ++k) {
-        double acc = 0.0;
-#pragma unroll
-        for (int s = 0; s < kN; ++s) acc += ar.low[k][s] * dv[s];
-        c[kHalf + k] = acc;
+        dv[k] = vs[42 + k * kD + dim];
+        dv[kHalf + k] = ve[42 + k * kD + dim];
       }
-    }
-    double* out = coeffs + ((size_t)(s_s0[t] + i) * kD + dim) * kN;
+      if (FUSED) {
+        coefficients_from_time((item == wtid) ? T_first : seg_times[s_s0[t] + i], dv, c);
+      } else {
+        if (item != wtid) {
+          const BlockSource src{Hblk, Ablk, P, q0 + t};
+          load_A_blocks(src, i, ar_first);
+        }
 #pragma unroll
-    for (int k = 0; k < kN; ++k) out[k] = c[k];
+        for (int k = 0; k < kHalf; ++k) c[k] = ar_first.diag[k] * dv[k];
+#pragma unroll
+        for (int k = 0; k < kHalf; ++k) {
+          double acc = 0.0;
+#pragma unroll
+          for (int s = 0; s < kN; ++s) acc += ar_first.low[k][s] * dv[s];
+          c[kHalf + k] = acc;
+        }
+      }
+      double* out = coeffs + ((size_t)(s_s0[t] + i) * kD + dim) * kN;
+#pragma unroll
+      for (int k = 0; k < kN; ++k) out[k] = c[k];
+    }
   }
+  MRS_TG_PHASE_MARK_T(5, 64);  // a worker's clock: wavefront 0 has nothing to do in phase C
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -396,30 +475,30 @@ bool tile_kernel_applies(const BatchView& b) {
   // measured on MI355X (10 segments): 47 vs 60 us at 1024 paths, but 154 vs 86 us at 8192 paths, where the
   // per-lane kernel already fills the machine and the tile kernel's serial phase leaves most lanes idle
   if (b.n_paths == 0 || b.n_paths > 2048) return false;
-  return (size_t)tile_path_doubles(b.max_segments) * sizeof(double) <= kTileLdsBudget;
+  return (size_t)tile_path_doubles(b.max_segments) * sizeof(double) + kSegRec * sizeof(double) <= kTileLdsBudget;
 }
 
 hipError_t launch_solve_tile(const BatchView& b, int d, bool fused, const uint8_t* mask, const double* vals,
                              const double* seg_times, const double* H, const double* Ainv, double* coeffs,
                              int32_t* status, double* cost, const int32_t* status_in, hipStream_t stream) {
   const size_t per_path = (size_t)tile_path_doubles(b.max_segments) * sizeof(double);
-  int TP = (int)(kTileLdsBudget / per_path);
-  if (TP > 8) TP = 8;  // phase B runs eight lanes per path inside one wavefront
+  int TP = (int)((kTileLdsBudget - kSegRec * sizeof(double)) / per_path);
+  if (TP > 8) TP = 8;  // phase B runs eight lanes per path inside wavefront 0
   // more, smaller tiles so that every CU gets work (256 CUs) and several tiles share a CU
   while (TP > 4 && (b.n_paths + TP - 1) / TP < 512) TP >>= 1;
-  const size_t lds_bytes = per_path * (size_t)TP;
+  const size_t lds_bytes = per_path * (size_t)TP + kSegRec * sizeof(double);  // + the all-zero segment record
   const unsigned grid = (unsigned)((b.n_paths + TP - 1) / TP);
   if (fused) {
     hipError_t e = hipFuncSetAttribute((const void*)solve_tile_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                        (int)kTileLdsBudget);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(solve_tile_kernel<true>, dim3(grid), dim3(128), lds_bytes, stream, b, d, TP, b.max_segments, mask,
+    hipLaunchKernelGGL(solve_tile_kernel<true>, dim3(grid), dim3(kTileThreads), lds_bytes, stream, b, d, TP, b.max_segments, mask,
                        vals, seg_times, H, Ainv, coeffs, status, cost, status_in);
   } else {
     hipError_t e = hipFuncSetAttribute((const void*)solve_tile_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                        (int)kTileLdsBudget);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(solve_tile_kernel<false>, dim3(grid), dim3(128), lds_bytes, stream, b, d, TP, b.max_segments, mask,
+    hipLaunchKernelGGL(solve_tile_kernel<false>, dim3(grid), dim3(kTileThreads), lds_bytes, stream, b, d, TP, b.max_segments, mask,
                        vals, seg_times, H, Ainv, coeffs, status, cost, status_in);
   }
   return hipGetLastError();

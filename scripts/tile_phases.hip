@@ -1,0 +1,92 @@
+// tile_phases.hip -- where the time of solve_tile_kernel goes: shader-clock stamps at the phase boundaries of
+// one workgroup (MRS_TG_PHASE_CLOCKS), plus the launch-to-launch time of the kernel.  Not part of the library.
+//
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -I mrs_uav_trajectory_generation_amd/csrc -I include \
+//         scripts/tile_phases.hip -o scripts/tile_phases.bin && scripts/tile_phases.bin [P] [S]
+#define MRS_TG_PHASE_CLOCKS 1
+#include "../mrs_uav_trajectory_generation_amd/csrc/mrs_tg_kernels.hip"
+#include "../mrs_uav_trajectory_generation_amd/csrc/mrs_tg_tile.hip"
+
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+
+#define CK(x)                                                                   \
+  do {                                                                          \
+    hipError_t e_ = (x);                                                        \
+    if (e_ != hipSuccess) {                                                     \
+      fprintf(stderr, "%s:%d %s\n", __FILE__, __LINE__, hipGetErrorString(e_)); \
+      exit(1);                                                                  \
+    }                                                                           \
+  } while (0)
+
+using namespace mrs_tg;
+
+template <typename T>
+static T* to_dev(const std::vector<T>& h) {
+  T* d;
+  CK(hipMalloc(&d, h.size() * sizeof(T)));
+  CK(hipMemcpy(d, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice));
+  return d;
+}
+
+int main(int argc, char** argv) {
+  const int P = argc > 1 ? atoi(argv[1]) : 1024, S = argc > 2 ? atoi(argv[2]) : 10, d = 4;
+  const int V = S + 1;
+  std::vector<int32_t> so(P + 1), order(P), slot(S + 1);
+  for (int p = 0; p <= P; ++p) so[p] = p * S;
+  for (int p = 0; p < P; ++p) order[p] = p;
+  for (int j = 0; j <= S; ++j) slot[j] = j * P;
+  std::vector<uint8_t> mask((size_t)P * V * 5, 0);
+  std::vector<double> vals((size_t)P * V * 5 * 4, 0.0), T((size_t)P * S);
+  unsigned rng = 12345u;
+  auto uni = [&] { rng = rng * 1664525u + 1013904223u; return (rng >> 8) * (1.0 / 16777216.0); };
+  for (int p = 0; p < P; ++p)
+    for (int v = 0; v < V; ++v) {
+      const size_t u = ((size_t)p * V + v) * 5;
+      const bool end = (v == 0 || v == S);
+      for (int k = 0; k < 5; ++k) mask[u + k] = (k == 0 || end) ? 1 : 0;
+      for (int dim = 0; dim < 4; ++dim) vals[u * 4 + dim] = uni() * 20.0 - 10.0;
+    }
+  for (auto& t : T) t = 0.5 + 4.5 * uni();
+  BatchView b{P, P * S, S, S, to_dev(so), to_dev(order), to_dev(slot)};
+  uint8_t* dmask = to_dev(mask);
+  double *dvals = to_dev(vals), *dT = to_dev(T), *H, *A, *coeffs, *cost;
+  int32_t* status;
+  CK(hipMalloc(&H, (size_t)P * S * 100 * 8));
+  CK(hipMalloc(&A, (size_t)P * S * 100 * 8));
+  CK(hipMalloc(&coeffs, (size_t)P * S * 40 * 8));
+  CK(hipMalloc(&cost, (size_t)P * 8));
+  CK(hipMalloc(&status, (size_t)P * 4));
+  hipStream_t st;
+  CK(hipStreamCreate(&st));
+  CK(launch_assemble(b, d, dT, H, A, st));
+  if (!tile_kernel_applies(b)) {
+    printf("tile kernel does not apply to P=%d S=%d\n", P, S);
+    return 0;
+  }
+  hipEvent_t e0, e1;
+  CK(hipEventCreate(&e0));
+  CK(hipEventCreate(&e1));
+  for (int fused = 0; fused < 2; ++fused) {
+    for (int i = 0; i < 10; ++i) CK(launch_solve_tile(b, d, fused, dmask, dvals, dT, H, A, coeffs, status, cost, nullptr, st));
+    CK(hipStreamSynchronize(st));
+    const int n = 200;
+    CK(hipEventRecord(e0, st));
+    for (int i = 0; i < n; ++i) CK(launch_solve_tile(b, d, fused, dmask, dvals, dT, H, A, coeffs, status, cost, nullptr, st));
+    CK(hipEventRecord(e1, st));
+    CK(hipEventSynchronize(e1));
+    float ms;
+    CK(hipEventElapsedTime(&ms, e0, e1));
+    long long clk[8];
+    CK(hipMemcpyFromSymbol(clk, HIP_SYMBOL(g_phase_clock), sizeof(clk)));
+    printf("P=%d S=%d %s: %.2f us per launch back to back; phase clocks (shader cycles since kernel entry of the "
+           "middle workgroup): setup %lld  A0 %lld  A1 %lld  B %lld  C %lld  total %lld\n",
+           P, S, fused ? "fused" : "blocks", ms * 1e3 / n, clk[1] - clk[0], clk[2] - clk[1], clk[3] - clk[2], clk[4] - clk[3],
+           clk[5] - clk[4], clk[5] - clk[0]);
+  }
+  std::vector<double> hc((size_t)P);
+  CK(hipMemcpy(hc.data(), cost, (size_t)P * 8, hipMemcpyDeviceToHost));
+  printf("cost[0..2] = %g %g %g\n", hc[0], hc[1], hc[2]);
+  return 0;
+}
