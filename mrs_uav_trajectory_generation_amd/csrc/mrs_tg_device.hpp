@@ -26,6 +26,19 @@ constexpr int kNB = 4;     // free-candidate slots per vertex (velocity..snap)
 constexpr int kSlot0 = 1;  // first free-candidate slot
 constexpr double kTimeLowerBound = 0.01;  // kOptimizationTimeLowerBound (polynomial_optimization_nonlinear.h:304)
 
+// optional phase clocks: the micro-benchmarks under scripts/ define MRS_TG_PHASE_CLOCKS and read g_phase_clock;
+// compiled out of the library
+#ifdef MRS_TG_PHASE_CLOCKS
+__device__ long long g_phase_clock[8];
+#define MRS_TG_PHASE_MARK_T(i, thread)                                                          \
+  do {                                                                                          \
+    if (blockIdx.x == gridDim.x / 2 && threadIdx.x == (thread)) g_phase_clock[i] = clock64();   \
+  } while (0)
+#else
+#define MRS_TG_PHASE_MARK_T(i, thread)
+#endif
+#define MRS_TG_PHASE_MARK(i) MRS_TG_PHASE_MARK_T(i, 0)
+
 static __constant__ double c_abar_inv[kN][kN] = MRS_TG_ABAR_INV_INIT;
 static __constant__ double c_hbar[kHalf][kN][kN] = MRS_TG_HBAR_INIT;
 

@@ -188,18 +188,19 @@ __global__ __launch_bounds__(256) void estimate_times_kernel(BatchView b, const 
 // The reference's sample times are defined by repeated floating-point addition
 // (time_in_segment += dt; accumulated += dt, with the remainder carried into the next segment), so the
 // sample count and the segment a boundary sample falls into depend on that exact rounding.  One wavefront
-// per path:
-//   1. lane 0 replays the recurrence in a register-only loop and records, per segment, the index of its
-//      first sample and the time_in_segment of that sample (S entries instead of one per sample);
-//   2. every lane takes samples n = lane, lane+64, ...: finds the segment, re-adds dt (n - first) times from
-//      the segment's start value -- the same additions in the same order, so bit-identical to the
-//      reference's running sum -- and evaluates the four polynomials.
+// per path walks the trajectory a chunk of up to 64 samples at a time: lane j adds dt to the chunk's start
+// values j times -- the same additions in the same order as the reference's running sums, so its
+// time_in_segment / accumulated values are bit-identical to those of the reference's j-th next sample -- a ballot
+// finds the first lane at which the walk stops (segment end, trajectory end or capacity), the lanes before it
+// evaluate the four polynomials of the current segment and store their sample, and the stopping lane's values
+// seed the next chunk.  A serial replay on one lane cost ~190 shader cycles per sample (divergent-branch
+// control flow around three compares); the chunked walk costs ~20.
 // The heading goes through the reference's quaternion round trip, atan2(2wz, 1-2z^2) with
 // w = cos(y/2), z = sin(y/2) (eth_mav_msgs/common.h:130-140), which is the wrap of y to (-pi, pi];
 // it is computed as y - 2 pi rint(y / 2 pi) (agreement 1e-15; same value at the +-pi seam).
 // A trajectory longer than the caller's capacity is reported as capacity + 1 samples ("too long": the
 // nodelet rejects such results by its length check, src/mrs_trajectory_generation.cpp:1178-1199); this
-// bounds the serial walk, which matters because a path whose outer loop ended on a rejected trial point
+// bounds the walk, which matters because a path whose outer loop ended on a rejected trial point
 // can come back with segment times of thousands of seconds.
 
 __device__ __forceinline__ double wrap_heading(double y) {
@@ -208,85 +209,102 @@ __device__ __forceinline__ double wrap_heading(double y) {
   return fma(-kf, two_pi_lo, fma(-kf, two_pi_hi, y));
 }
 
+__device__ __forceinline__ double lane_value(double v, int src) {
+  const int lo = __builtin_amdgcn_readlane(__double2loint(v), src), hi = __builtin_amdgcn_readlane(__double2hiint(v), src);
+  return __hiloint2double(hi, lo);
+}
+
 __global__ __launch_bounds__(64) void sample_kernel(BatchView b, const double* __restrict__ coeffs,
                                                     const double* __restrict__ seg_times, double dt, int capacity,
                                                     int32_t* __restrict__ n_samples, double* __restrict__ samples) {
-  extern __shared__ double s_mem[];  // [S] times | [S] first-sample tin | [S+1] first-sample index (as int)
+  extern __shared__ double s_T[];  // [max_segments] segment times | [S][4][10] coefficients of this path
   const int q = blockIdx.x;
   const PathRef pr = path_at(b, q);
   const int S = pr.S;
   const int lane = threadIdx.x;
-  double* s_T = s_mem;
-  double* s_tin0 = s_mem + b.max_segments;
-  int* s_first = reinterpret_cast<int*>(s_mem + 2 * b.max_segments);
+  double* s_c = s_T + b.max_segments;
+  MRS_TG_PHASE_MARK(0);
   for (int i = lane; i < S; i += 64) s_T[i] = seg_times[pr.s0 + i];
+  if (samples) {  // one coalesced pass instead of a global round trip per segment inside the walk
+    const double* __restrict__ cg = coeffs + (size_t)pr.s0 * kD * kN;
+    for (int e = lane; e < S * kD * kN; e += 64) s_c[e] = cg[e];
+  }
   __syncthreads();
-  if (lane == 0) {
-    double t_end = 0.0;
-    for (int i = 0; i < S; ++i) t_end += s_T[i];
-    // first segment whose accumulated time exceeds t_start = 0 (trajectory.cpp:108-120)
-    double acc = 0.0;
-    int i = 0;
-    for (i = 0; i < S; ++i) {
-      acc += s_T[i];
-      if (acc > 0.0) break;
-    }
-    int n = 0;
-    if (i < S) {
-      acc -= s_T[i];
-      double tin = 0.0 - acc;
-      double Ti = s_T[i];
-      for (int j = 0; j <= i; ++j) s_first[j] = 0;
-      s_tin0[i] = tin;
-      while (acc < t_end) {  // trajectory.cpp:131-150
-        if (tin > Ti) {
-          tin = tin - Ti;
-          ++i;
-          if (i >= S) break;
-          Ti = s_T[i];
-          s_first[i] = n;
-          s_tin0[i] = tin;
-          continue;
+  MRS_TG_PHASE_MARK(1);
+  // every lane carries the same walk state (i, Ti, tin, acc, n): t_end and the start segment as the reference
+  // computes them (trajectory.cpp:100-120, t_start = 0)
+  double t_end = 0.0;
+  for (int i = 0; i < S; ++i) t_end += s_T[i];
+  double acc = 0.0;
+  int i = 0;
+  for (i = 0; i < S; ++i) {
+    acc += s_T[i];
+    if (acc > 0.0) break;
+  }
+  int n = 0;
+  if (i < S) {
+    acc -= s_T[i];
+    double tin = 0.0 - acc;
+    double Ti = s_T[i];
+    double* out = samples ? samples + (size_t)pr.p * capacity * kD : nullptr;
+    while (true) {  // trajectory.cpp:131-150, one chunk per iteration
+      if (!(acc < t_end)) break;
+      bool past_end = false;
+      while (tin > Ti) {  // carry the remainder into the next segment(s)
+        tin = tin - Ti;
+        ++i;
+        if (i >= S) {
+          past_end = true;
+          break;
         }
-        ++n;
-        tin += dt;
-        acc += dt;
-        if (n > capacity) break;  // overflow: report capacity + 1, keep the serial walk bounded
+        Ti = s_T[i];
       }
-      for (int j = (i < S ? i + 1 : S); j <= S; ++j) s_first[j] = n;
-    } else {
-      for (int j = 0; j <= S; ++j) s_first[j] = 0;
+      if (past_end) break;
+      // lanes 0..last are computed in this chunk; `last` only has to be non-negative: an underestimate splits the
+      // segment into several chunks, an overestimate adds idle additions
+      const double room = (Ti - tin) / dt;
+      const int last = __builtin_amdgcn_readfirstlane((room < 61.0) ? (int)room + 2 : 63);
+      // lane j adds dt j times; past its own count a lane adds +0.0, which leaves the value unchanged, so the
+      // loop body is two independent dependent-add chains and a select that does not sit on them
+      double tj = tin, aj = acc;
+#pragma unroll 4
+      for (int r = 0; r < last; ++r) {
+        const double step = (lane > r) ? dt : 0.0;
+        tj += step;
+        aj += step;
+      }
+      const bool ok = (lane <= last) && (aj < t_end) && !(tj > Ti) && (n + lane <= capacity);
+      const unsigned long long okmask = __ballot(ok);
+      const int m = (~okmask == 0ull) ? 64 : __builtin_ctzll(~okmask);  // lanes [0, m) emit a sample
+      if (out && lane < m && n + lane < capacity) {
+        const double* c = s_c + __builtin_amdgcn_readfirstlane(i) * (kD * kN);
+        double v[kD];
+#pragma unroll
+        for (int dd = 0; dd < kD; ++dd) {
+          double accv = c[dd * kN + kN - 1];
+#pragma unroll
+          for (int k = kN - 2; k >= 0; --k) accv = accv * tj + c[dd * kN + k];
+          v[dd] = accv;
+        }
+        v[3] = wrap_heading(v[3]);
+#pragma unroll
+        for (int dd = 0; dd < kD; ++dd) out[(size_t)(n + lane) * kD + dd] = v[dd];
+      }
+      n += m;
+      if (m == last + 1) {  // every computed lane emitted: the chunk ran out before the walk stopped
+        tin = lane_value(tj, last) + dt;
+        acc = lane_value(aj, last) + dt;
+        if (n > capacity) break;
+        continue;
+      }
+      // lane m is the first that did not emit: its values are the walk's state at the stop
+      tin = lane_value(tj, m);
+      acc = lane_value(aj, m);
+      if (n > capacity) break;  // overflow: report capacity + 1
     }
-    if (n_samples) n_samples[pr.p] = n;
   }
-  __syncthreads();
-  const int N = s_first[S];
-  if (!samples) return;
-  double* out = samples + (size_t)pr.p * capacity * kD;
-  const int n_out = N < capacity ? N : capacity;
-  for (int n = lane; n < n_out; n += 64) {
-    // last segment whose first sample index is <= n
-    int lo = 0, hi = S;  // s_first[lo] <= n < s_first[hi] = N
-    while (hi - lo > 1) {
-      const int mid = (lo + hi) >> 1;
-      if (s_first[mid] <= n) lo = mid;
-      else hi = mid;
-    }
-    double t = s_tin0[lo];
-    for (int r = n - s_first[lo]; r > 0; --r) t += dt;
-    const double* c = coeffs + (size_t)(pr.s0 + lo) * kD * kN;
-    double v[kD];
-#pragma unroll
-    for (int dd = 0; dd < kD; ++dd) {
-      double accv = c[dd * kN + kN - 1];
-#pragma unroll
-      for (int k = kN - 2; k >= 0; --k) accv = accv * t + c[dd * kN + k];
-      v[dd] = accv;
-    }
-    v[3] = wrap_heading(v[3]);
-#pragma unroll
-    for (int dd = 0; dd < kD; ++dd) out[(size_t)n * kD + dd] = v[dd];
-  }
+  MRS_TG_PHASE_MARK(2);
+  if (lane == 0 && n_samples) n_samples[pr.p] = n;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -350,7 +368,12 @@ hipError_t launch_estimate_times(const BatchView& b, const double* wp, const dou
 hipError_t launch_sample(const BatchView& b, const double* coeffs, const double* seg_times, double dt, int capacity,
                          int32_t* n_samples, double* samples, hipStream_t stream) {
   if (b.n_paths == 0) return hipSuccess;
-  const size_t lds = sizeof(double) * (size_t)(3 * b.max_segments + 2);
+  const size_t lds = sizeof(double) * (size_t)b.max_segments * (1 + kD * kN);
+  if (lds > 160 * 1024) return hipErrorInvalidValue;
+  if (lds > 64 * 1024) {
+    hipError_t e = hipFuncSetAttribute((const void*)sample_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+  }
   hipLaunchKernelGGL(sample_kernel, dim3(b.n_paths), dim3(64), lds, stream, b, coeffs, seg_times, dt, capacity,
                      n_samples, samples);
   return hipGetLastError();

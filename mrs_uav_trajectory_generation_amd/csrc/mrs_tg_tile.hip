@@ -34,17 +34,6 @@ constexpr int kVtxRec = 42 + 20 + 2;                 // L[10] W[16] z[4][4] | d[
 
 __host__ __device__ constexpr int tile_path_doubles(int S) { return S * kSegRec + (S + 1) * kVtxRec; }
 
-// optional phase clocks (scripts/tile_phases.hip defines MRS_TG_PHASE_CLOCKS; compiled out of the library)
-#ifdef MRS_TG_PHASE_CLOCKS
-__device__ long long g_phase_clock[8];
-#define MRS_TG_PHASE_MARK_T(i, thread)                                                          \
-  do {                                                                                          \
-    if (blockIdx.x == gridDim.x / 2 && threadIdx.x == (thread)) g_phase_clock[i] = clock64();   \
-  } while (0)
-#else
-#define MRS_TG_PHASE_MARK_T(i, thread)
-#endif
-#define MRS_TG_PHASE_MARK(i) MRS_TG_PHASE_MARK_T(i, 0)
 
 constexpr int kTileThreads = 256;
 constexpr int kTileWorkers = kTileThreads - 64;

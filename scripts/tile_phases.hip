@@ -85,6 +85,29 @@ int main(int argc, char** argv) {
            P, S, fused ? "fused" : "blocks", ms * 1e3 / n, clk[1] - clk[0], clk[2] - clk[1], clk[3] - clk[2], clk[4] - clk[3],
            clk[5] - clk[4], clk[5] - clk[0]);
   }
+  // sampler: serial walk (lane 0) and parallel evaluation, dt 0.2, capacity 512
+  {
+    const int cap = 512;
+    double* samples;
+    int32_t* ns;
+    CK(hipMalloc(&samples, (size_t)P * cap * 4 * 8));
+    CK(hipMalloc(&ns, (size_t)P * 4));
+    for (int i = 0; i < 5; ++i) CK(launch_sample(b, coeffs, dT, 0.2, cap, ns, samples, st));
+    CK(hipStreamSynchronize(st));
+    const int n = 50;
+    CK(hipEventRecord(e0, st));
+    for (int i = 0; i < n; ++i) CK(launch_sample(b, coeffs, dT, 0.2, cap, ns, samples, st));
+    CK(hipEventRecord(e1, st));
+    CK(hipEventSynchronize(e1));
+    float ms;
+    CK(hipEventElapsedTime(&ms, e0, e1));
+    long long clk[8];
+    CK(hipMemcpyFromSymbol(clk, HIP_SYMBOL(g_phase_clock), sizeof(clk)));
+    std::vector<int32_t> hn(P);
+    CK(hipMemcpy(hn.data(), ns, (size_t)P * 4, hipMemcpyDeviceToHost));
+    printf("sample_kernel: %.2f us per launch; middle workgroup (%d samples): load %lld  walk + evaluate %lld cycles\n",
+           ms * 1e3 / n, hn[P / 2], clk[1] - clk[0], clk[2] - clk[1]);
+  }
   std::vector<double> hc((size_t)P);
   CK(hipMemcpy(hc.data(), cost, (size_t)P * 8, hipMemcpyDeviceToHost));
   printf("cost[0..2] = %g %g %g\n", hc[0], hc[1], hc[2]);
