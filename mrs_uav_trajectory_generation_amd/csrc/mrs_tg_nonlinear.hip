@@ -85,26 +85,224 @@ __device__ __forceinline__ unsigned staged_vertex(const double* vtx, int v, int 
   return (unsigned)r[20];
 }
 
+// ---- specialised segment steps of the forward sweep ---------------------------------------------------------
+// Almost every segment of almost every path is one of three shapes: both end vertices constrain their position
+// only (interior segment), the start vertex is fully constrained with zero derivatives (first segment, or the one
+// after a full stop), or the end vertex is (last segment, or the one before a full stop).  For these the general
+// masked step (Elim::absorb_segment: ~650 instructions per dimension-lane) collapses:
+//   * the right-hand-side terms u = H [f_s; f_e] involve only the two position columns, and
+//     H[a][0] f_s + H[a][5] f_e = T^(a%5 + 1 - 2d) * (HBAR[a][0] f_s + HBAR[a][5] f_e): the bracket does not depend
+//     on the segment time, so it is computed once per kernel and staged in LDS (kSegLds doubles per segment: per
+//     dimension the eight brackets of the derivative rows and the f^T HBAR f term of qf);
+//   * no masks, no materialised 10 x 10 block: the 4 x 4 blocks are HBAR constants times T^(r + c + 2 - 2d), fused
+//     into the accumulations that consume them;
+//   * a fully constrained vertex is not factorised at all.
+// ~230 instructions per interior step for one dimension per lane, ~360 for four.  Any other mask / value pattern
+// (initial state with non-zero derivatives, partially constrained stop vertices) takes the general step.
+constexpr int kSegLds = 38;
+enum { kSegGeneral = 0, kSegStart = 1, kSegInterior = 2, kSegEnd = 3 };
+
+__device__ __forceinline__ void stage_segments(const double* vtx, int S, int d, double* seg, int g, int G) {
+  const double (*hb)[kN] = c_hbar[d];
+  for (int i = g; i < S; i += G) {
+    const double* vs = vtx + (size_t)i * kVtxLds;
+    const double* ve = vs + kVtxLds;
+    const unsigned fs = (unsigned)vs[20], fe = (unsigned)ve[20];
+    bool plain = (vs[21] != 0.0) && (ve[21] != 0.0);
+#pragma unroll
+    for (int k = 1; k < kHalf; ++k)
+#pragma unroll
+      for (int q = 0; q < kD; ++q) plain = plain && (vs[k * kD + q] == 0.0) && (ve[k * kD + q] == 0.0);
+    int kind = kSegGeneral;
+    if (plain) {
+      if (fs == 0xFu && fe == 0xFu) kind = kSegInterior;
+      else if (fs == 0u && fe == 0xFu) kind = kSegStart;
+      else if (fs == 0xFu && fe == 0u) kind = kSegEnd;
+    }
+    double* r = seg + (size_t)i * kSegLds;
+#pragma unroll
+    for (int q = 0; q < kD; ++q) {
+      const double f0s = vs[q], f0e = ve[q];
+#pragma unroll
+      for (int k = 0; k < kNB; ++k) {
+        r[q * 9 + k] = hb[kSlot0 + k][0] * f0s + hb[kSlot0 + k][kHalf] * f0e;
+        r[q * 9 + kNB + k] = hb[kHalf + kSlot0 + k][0] * f0s + hb[kHalf + kSlot0 + k][kHalf] * f0e;
+      }
+      const double w0 = hb[0][0] * f0s + hb[0][kHalf] * f0e, w5 = hb[kHalf][0] * f0s + hb[kHalf][kHalf] * f0e;
+      r[q * 9 + 8] = f0s * w0 + f0e * w5;
+    }
+    r[36] = (double)kind;
+  }
+}
+
+// reciprocal: hardware estimate + two Newton steps (~1 ulp)
+__device__ __forceinline__ double rcp_refined(double x) {
+  double y = __builtin_amdgcn_rcp(x);
+  y = fma(fma(-x, y, 1.0), y, y);
+  y = fma(fma(-x, y, 1.0), y, y);
+  return y;
+}
+
+// p2[m] = T^(m + 1 - 2d) without the IEEE division sequence
+__device__ __forceinline__ void segment_powers(double T, int d, double (&p2)[9]) {
+  const double t2 = T * T;
+  const double td = (d == 0) ? 1.0 : (d == 1) ? T : (d == 2) ? t2 : (d == 3) ? t2 * T : t2 * t2;
+  p2[0] = T * rcp_refined(td * td);
+#pragma unroll
+  for (int m = 1; m < 9; ++m) p2[m] = p2[m - 1] * T;
+}
+
 template <int ND>
-__device__ __forceinline__ double forward_cost(const double* vtx, int S, int d, const double* xs, int k, int dim0) {
+struct FastStep {
+  // brackets of this (segment, dimension): w[q][0..3] start rows, [4..7] end rows, [8] qf term
+  double w[ND][9];
+
+  __device__ __forceinline__ void load(const double* seg, int dim0) {
+#pragma unroll
+    for (int q = 0; q < ND; ++q)
+#pragma unroll
+      for (int j = 0; j < 9; ++j) w[q][j] = seg[(dim0 + q) * 9 + j];
+  }
+
+  // start vertex fully constrained: nothing to eliminate; the state moves to the end vertex
+  __device__ __forceinline__ void start(Elim<ND>& st, const double (*hb)[kN], const double (&p2)[9]) const {
+#pragma unroll
+    for (int r = 0; r < kNB; ++r) {
+#pragma unroll
+      for (int c = 0; c <= r; ++c) st.Sm[tri(r, c)] = hb[kHalf + kSlot0 + r][kHalf + kSlot0 + c] * p2[r + c + 2];
+#pragma unroll
+      for (int q = 0; q < ND; ++q) st.y[r][q] = -(w[q][kNB + r] * p2[r + 1]);
+    }
+#pragma unroll
+    for (int q = 0; q < ND; ++q) st.qf = fma(p2[0], w[q][8], st.qf);
+  }
+
+  // Cholesky of st.Sm (all four slots free), z = L^-1 y, red += |z|^2
+  __device__ __forceinline__ void factor(Elim<ND>& st, double (&L)[10], double (&Linv)[kNB], double (&z)[kNB][ND]) const {
+#pragma unroll
+    for (int c = 0; c < kNB; ++c) {
+      double dsum = st.Sm[tri(c, c)];
+#pragma unroll
+      for (int m = 0; m < c; ++m) dsum = fma(-L[tri(c, m)], L[tri(c, m)], dsum);
+      const double inv = rsqrt_refined(dsum);
+      L[tri(c, c)] = dsum * inv;
+      Linv[c] = inv;
+#pragma unroll
+      for (int r = c + 1; r < kNB; ++r) {
+        double s = st.Sm[tri(r, c)];
+#pragma unroll
+        for (int m = 0; m < c; ++m) s = fma(-L[tri(r, m)], L[tri(c, m)], s);
+        L[tri(r, c)] = s * inv;
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < ND; ++q)
+#pragma unroll
+      for (int r = 0; r < kNB; ++r) {
+        double s = st.y[r][q];
+#pragma unroll
+        for (int m = 0; m < r; ++m) s = fma(-L[tri(r, m)], z[m][q], s);
+        z[r][q] = s * Linv[r];
+        st.red = fma(z[r][q], z[r][q], st.red);
+      }
+  }
+
+  // end vertex fully constrained: eliminate the start vertex, nothing is passed on
+  __device__ __forceinline__ void end(Elim<ND>& st, const double (*hb)[kN], const double (&p2)[9]) const {
+#pragma unroll
+    for (int r = 0; r < kNB; ++r) {
+#pragma unroll
+      for (int c = 0; c <= r; ++c) st.Sm[tri(r, c)] = fma(hb[kSlot0 + r][kSlot0 + c], p2[r + c + 2], st.Sm[tri(r, c)]);
+#pragma unroll
+      for (int q = 0; q < ND; ++q) st.y[r][q] = fma(-w[q][r], p2[r + 1], st.y[r][q]);
+    }
+#pragma unroll
+    for (int q = 0; q < ND; ++q) st.qf = fma(p2[0], w[q][8], st.qf);
+    double L[10], Linv[kNB], z[kNB][ND];
+    factor(st, L, Linv, z);
+  }
+
+  // both vertices constrain their position only
+  __device__ __forceinline__ void interior(Elim<ND>& st, const double (*hb)[kN], const double (&p2)[9]) const {
+#pragma unroll
+    for (int r = 0; r < kNB; ++r) {
+#pragma unroll
+      for (int c = 0; c <= r; ++c) st.Sm[tri(r, c)] = fma(hb[kSlot0 + r][kSlot0 + c], p2[r + c + 2], st.Sm[tri(r, c)]);
+#pragma unroll
+      for (int q = 0; q < ND; ++q) st.y[r][q] = fma(-w[q][r], p2[r + 1], st.y[r][q]);
+    }
+#pragma unroll
+    for (int q = 0; q < ND; ++q) st.qf = fma(p2[0], w[q][8], st.qf);
+    double L[10], Linv[kNB], z[kNB][ND], W[kNB][kNB];
+    factor(st, L, Linv, z);
+    // W = L^-1 E, E[r][c] = HBAR[1+r][6+c] T^(r+c+2-2d)
+#pragma unroll
+    for (int c = 0; c < kNB; ++c)
+#pragma unroll
+      for (int r = 0; r < kNB; ++r) {
+        double s = hb[kSlot0 + r][kHalf + kSlot0 + c] * p2[r + c + 2];
+#pragma unroll
+        for (int m = 0; m < r; ++m) s = fma(-L[tri(r, m)], W[m][c], s);
+        W[r][c] = s * Linv[r];
+      }
+    // next vertex: Sm = Hee - W^T W ; y = -u_e - W^T z
+#pragma unroll
+    for (int r = 0; r < kNB; ++r) {
+#pragma unroll
+      for (int c = 0; c <= r; ++c) {
+        double s = hb[kHalf + kSlot0 + r][kHalf + kSlot0 + c] * p2[r + c + 2];
+#pragma unroll
+        for (int m = 0; m < kNB; ++m) s = fma(-W[m][r], W[m][c], s);
+        st.Sm[tri(r, c)] = s;
+      }
+#pragma unroll
+      for (int q = 0; q < ND; ++q) {
+        double s = -(w[q][kNB + r] * p2[r + 1]);
+#pragma unroll
+        for (int m = 0; m < kNB; ++m) s = fma(-W[m][r], z[m][q], s);
+        st.y[r][q] = s;
+      }
+    }
+  }
+};
+
+template <int ND>
+__device__ __forceinline__ double forward_cost(const double* vtx, const double* seg, int S, int d, const double* xs, int k,
+                                               int dim0) {
   Elim<ND> st;
   st.init();
-  double fs[kHalf][ND], fe[kHalf][ND];
-  double L[10], z[kNB][ND], W[kNB][kNB];
-  unsigned free_s = staged_vertex<ND>(vtx, 0, dim0, fs);
+  const double (*hb)[kN] = c_hbar[d];
   const double corr = kGradStep / ((double)S - 1.0);
+  int last_kind = kSegGeneral;
   for (int i = 0; i < S; ++i) {
-    const unsigned free_e = staged_vertex<ND>(vtx, i + 1, dim0, fe);
-    double Hs[kSym10];
-    hessian_from_time(perturbed_time(xs, i, k, corr), d, Hs);
-    st.absorb_segment(Hs, fs, fe, free_s, free_e, L, z, W);
-#pragma unroll
-    for (int s = 0; s < kHalf; ++s)
-#pragma unroll
-      for (int dd = 0; dd < ND; ++dd) fs[s][dd] = fe[s][dd];
-    free_s = free_e;
+    const double T = perturbed_time(xs, i, k, corr);
+    const double* sr = seg + (size_t)i * kSegLds;
+    const int kind = (int)sr[36];
+    last_kind = kind;
+    if (kind == kSegGeneral) {
+      double fs[kHalf][ND], fe[kHalf][ND];
+      double L[10], z[kNB][ND], W[kNB][kNB];
+      const unsigned free_s = staged_vertex<ND>(vtx, i, dim0, fs);
+      const unsigned free_e = staged_vertex<ND>(vtx, i + 1, dim0, fe);
+      double Hs[kSym10];
+      hessian_from_time(T, d, Hs);
+      st.absorb_segment(Hs, fs, fe, free_s, free_e, L, z, W);
+    } else {
+      double p2[9];
+      segment_powers(T, d, p2);
+      FastStep<ND> fast;
+      fast.load(sr, dim0);
+      if (kind == kSegInterior) fast.interior(st, hb, p2);
+      else if (kind == kSegStart) fast.start(st, hb, p2);
+      else fast.end(st, hb, p2);
+    }
   }
-  st.factor_vertex(free_s, L, z);
+  if (last_kind != kSegEnd) {  // after an end-type segment the state stands on a fully constrained vertex: nothing left
+    double fl[kHalf][ND];
+    double L[10], z[kNB][ND];
+    const unsigned free_l = staged_vertex<ND>(vtx, S, dim0, fl);
+    st.factor_vertex(free_l, L, z);
+  }
   return 0.5 * (st.qf - st.red);
 }
 
@@ -300,17 +498,20 @@ __device__ __forceinline__ bool relstop(double vold, double vnew, double reltol,
   return dv < abstol || dv < reltol * (fabs(vnew) + fabs(vold)) * 0.5 || (reltol > 0 && vnew == vold);
 }
 
-// per-group LDS block (doubles): x, g, xn, gn, dir [5*Sb], s[M][Sb], y[M][Sb], rho[M], staged vertices [(Sb+1)*kVtxLds]
-__host__ __device__ constexpr int group_lds_doubles(int Sb) { return (5 + 2 * kLbfgsM) * Sb + kLbfgsM + (Sb + 1) * kVtxLds; }
+// per-group LDS block (doubles): x, g, xn, gn, dir [5*Sb], s[M][Sb], y[M][Sb], rho[M], staged vertices
+// [(Sb+1)*kVtxLds], staged segment records [Sb*kSegLds]
+__host__ __device__ constexpr int group_lds_doubles(int Sb) {
+  return (5 + 2 * kLbfgsM) * Sb + kLbfgsM + (Sb + 1) * kVtxLds + Sb * kSegLds;
+}
 // cost_gradient_kernel: x, g [2*Sb], staged vertices
-__host__ __device__ constexpr int gradient_lds_doubles(int Sb) { return 2 * Sb + (Sb + 1) * kVtxLds; }
+__host__ __device__ constexpr int gradient_lds_doubles(int Sb) { return 2 * Sb + (Sb + 1) * kVtxLds + Sb * kSegLds; }
 
 // objective evaluation at `pt`: cost returned to every lane of the group, gradient to `grad` (LDS).
 // (objectiveFunctionTimeMellingerOuterLoop + getCostAndGradientMellinger)
 // DS lanes share one time vector (DS = 1: one lane, four dimensions; DS = 4: four lanes, one dimension each).
 template <int DS>
-__device__ __forceinline__ double evaluate_objective(const double* vtx, int S, int d, const double* pt, double* grad, int g,
-                                                     int G, bool active) {
+__device__ __forceinline__ double evaluate_objective(const double* vtx, const double* seg, int S, int d, const double* pt,
+                                                     double* grad, int g, int G, bool active) {
   constexpr int ND = kD / DS;
   const int kl = G / DS;  // time vectors handled per round
   const int kk = g / DS, dim0 = (g % DS) * ND;
@@ -319,7 +520,7 @@ __device__ __forceinline__ double evaluate_objective(const double* vtx, int S, i
   for (int r = 0; r < rounds; ++r) {
     const int k = kk + r * kl;
     double Jk = 0.0;
-    if (active && k <= S && (k == 0 || S > 1)) Jk = forward_cost<ND>(vtx, S, d, pt, k, dim0);
+    if (active && k <= S && (k == 0 || S > 1)) Jk = forward_cost<ND>(vtx, seg, S, d, pt, k, dim0);
     if (DS == 4) {
       Jk += __shfl_xor(Jk, 1, 64);
       Jk += __shfl_xor(Jk, 2, 64);
@@ -373,7 +574,10 @@ __global__ __launch_bounds__(64) void optimize_kernel(BatchView b, NonlinearPara
   double* ym = sm + kLbfgsM * Sb;   // [M][Sb]
   double* rho = ym + kLbfgsM * Sb;  // [M]
   double* vtx = rho + kLbfgsM;      // [(Sb + 1) * kVtxLds]
+  double* seg = vtx + (size_t)(Sb + 1) * kVtxLds;  // [Sb * kSegLds]
   if (active) stage_vertices(mask, vals, pr.v0, S, vtx, g, G);
+  __syncthreads();
+  if (active) stage_segments(vtx, S, d, seg, g, G);
 
   // ---- start point; NLopt rejects a start below the lower bound (-> INVALID_ARGS)
   int ok = 1;
@@ -400,7 +604,7 @@ __global__ __launch_bounds__(64) void optimize_kernel(BatchView b, NonlinearPara
     if (!running) break;
 
     // (1) one objective evaluation at the trial point
-    const double fn = evaluate_objective<DS>(vtx, S, d, xn, gn, g, G, !done);
+    const double fn = evaluate_objective<DS>(vtx, seg, S, d, xn, gn, g, G, !done);
     __syncthreads();
     bool new_dir = false;
     if (!done) {
@@ -608,12 +812,15 @@ __global__ __launch_bounds__(64) void cost_gradient_kernel(BatchView b, int d, i
   double* x = lds + (size_t)grp * gradient_lds_doubles(Sb);
   double* gr = x + Sb;
   double* vtx = gr + Sb;
+  double* seg = vtx + (size_t)(Sb + 1) * kVtxLds;
   if (active) {
     for (int i = g; i < pr.S; i += G) x[i] = seg_times[pr.s0 + i];
     stage_vertices(mask, vals, pr.v0, pr.S, vtx, g, G);
   }
   __syncthreads();
-  const double J = evaluate_objective<DS>(vtx, pr.S, d, x, gr, g, G, active);
+  if (active) stage_segments(vtx, pr.S, d, seg, g, G);
+  __syncthreads();
+  const double J = evaluate_objective<DS>(vtx, seg, pr.S, d, x, gr, g, G, active);
   __syncthreads();
   if (active) {
     for (int i = g; i < pr.S; i += G) grad[pr.s0 + i] = gr[i];
