@@ -29,7 +29,7 @@ constexpr double kTimeLowerBound = 0.01;  // kOptimizationTimeLowerBound (polyno
 // optional phase clocks: the micro-benchmarks under scripts/ define MRS_TG_PHASE_CLOCKS and read g_phase_clock;
 // compiled out of the library
 #ifdef MRS_TG_PHASE_CLOCKS
-__device__ long long g_phase_clock[8];
+__device__ long long g_phase_clock[32];
 #define MRS_TG_PHASE_MARK_T(i, thread)                                                          \
   do {                                                                                          \
     if (blockIdx.x == gridDim.x / 2 && threadIdx.x == (thread)) g_phase_clock[i] = clock64();   \

@@ -108,11 +108,14 @@ __device__ __forceinline__ void stage_segments(const double* vtx, int S, int d, 
     const double* vs = vtx + (size_t)i * kVtxLds;
     const double* ve = vs + kVtxLds;
     const unsigned fs = (unsigned)vs[20], fe = (unsigned)ve[20];
-    bool plain = (vs[21] != 0.0) && (ve[21] != 0.0);
+    // "plain": both positions constrained, every constrained derivative value zero (bit-wise tests on values that
+    // are loaded unconditionally: a short-circuit chain would put each LDS load behind its own branch)
+    double nz = 0.0;
 #pragma unroll
     for (int k = 1; k < kHalf; ++k)
 #pragma unroll
-      for (int q = 0; q < kD; ++q) plain = plain && (vs[k * kD + q] == 0.0) && (ve[k * kD + q] == 0.0);
+      for (int q = 0; q < kD; ++q) nz += fabs(vs[k * kD + q]) + fabs(ve[k * kD + q]);
+    const bool plain = (nz == 0.0) & (vs[21] != 0.0) & (ve[21] != 0.0);
     int kind = kSegGeneral;
     if (plain) {
       if (fs == 0xFu && fe == 0xFu) kind = kSegInterior;
@@ -147,9 +150,40 @@ __device__ __forceinline__ double rcp_refined(double x) {
 __device__ __forceinline__ void segment_powers(double T, int d, double (&p2)[9]) {
   const double t2 = T * T;
   const double td = (d == 0) ? 1.0 : (d == 1) ? T : (d == 2) ? t2 : (d == 3) ? t2 * T : t2 * t2;
+  const double t4 = t2 * t2;
   p2[0] = T * rcp_refined(td * td);
-#pragma unroll
-  for (int m = 1; m < 9; ++m) p2[m] = p2[m - 1] * T;
+  p2[1] = p2[0] * T;   // depth-3 product tree instead of an 8-long dependent chain
+  p2[2] = p2[0] * t2;
+  p2[3] = p2[1] * t2;
+  p2[4] = p2[0] * t4;
+  p2[5] = p2[1] * t4;
+  p2[6] = p2[2] * t4;
+  p2[7] = p2[3] * t4;
+  p2[8] = p2[4] * t4;
+}
+
+// The 36 HBAR_d constants of the three 4 x 4 blocks (start-start packed | start-end | end-end packed) are staged in
+// LDS as well: addressed through the constant bank with a run-time d they were scalar loads inside the sweep, whose
+// latency stalled every step and whose SGPR footprint forced spills.
+constexpr int kBlockConsts = 36;
+
+__device__ __forceinline__ void stage_block_constants(int d, double* hc, int tid, int nthreads) {
+  const double (*hb)[kN] = c_hbar[d];
+  for (int e = tid; e < kBlockConsts; e += nthreads) {
+    double v;
+    if (e < 10) {
+      int r = 0;
+      while (tri(r + 1, 0) <= e) ++r;
+      v = hb[kSlot0 + r][kSlot0 + (e - tri(r, 0))];
+    } else if (e < 26) {
+      v = hb[kSlot0 + (e - 10) / kNB][kHalf + kSlot0 + (e - 10) % kNB];
+    } else {
+      int r = 0;
+      while (tri(r + 1, 0) <= e - 26) ++r;
+      v = hb[kHalf + kSlot0 + r][kHalf + kSlot0 + (e - 26 - tri(r, 0))];
+    }
+    hc[e] = v;
+  }
 }
 
 template <int ND>
@@ -165,11 +199,11 @@ struct FastStep {
   }
 
   // start vertex fully constrained: nothing to eliminate; the state moves to the end vertex
-  __device__ __forceinline__ void start(Elim<ND>& st, const double (*hb)[kN], const double (&p2)[9]) const {
+  __device__ __forceinline__ void start(Elim<ND>& st, const double* hc, const double (&p2)[9]) const {
 #pragma unroll
     for (int r = 0; r < kNB; ++r) {
 #pragma unroll
-      for (int c = 0; c <= r; ++c) st.Sm[tri(r, c)] = hb[kHalf + kSlot0 + r][kHalf + kSlot0 + c] * p2[r + c + 2];
+      for (int c = 0; c <= r; ++c) st.Sm[tri(r, c)] = hc[26 + tri(r, c)] * p2[r + c + 2];
 #pragma unroll
       for (int q = 0; q < ND; ++q) st.y[r][q] = -(w[q][kNB + r] * p2[r + 1]);
     }
@@ -208,11 +242,11 @@ struct FastStep {
   }
 
   // end vertex fully constrained: eliminate the start vertex, nothing is passed on
-  __device__ __forceinline__ void end(Elim<ND>& st, const double (*hb)[kN], const double (&p2)[9]) const {
+  __device__ __forceinline__ void end(Elim<ND>& st, const double* hc, const double (&p2)[9]) const {
 #pragma unroll
     for (int r = 0; r < kNB; ++r) {
 #pragma unroll
-      for (int c = 0; c <= r; ++c) st.Sm[tri(r, c)] = fma(hb[kSlot0 + r][kSlot0 + c], p2[r + c + 2], st.Sm[tri(r, c)]);
+      for (int c = 0; c <= r; ++c) st.Sm[tri(r, c)] = fma(hc[tri(r, c)], p2[r + c + 2], st.Sm[tri(r, c)]);
 #pragma unroll
       for (int q = 0; q < ND; ++q) st.y[r][q] = fma(-w[q][r], p2[r + 1], st.y[r][q]);
     }
@@ -223,11 +257,11 @@ struct FastStep {
   }
 
   // both vertices constrain their position only
-  __device__ __forceinline__ void interior(Elim<ND>& st, const double (*hb)[kN], const double (&p2)[9]) const {
+  __device__ __forceinline__ void interior(Elim<ND>& st, const double* hc, const double (&p2)[9]) const {
 #pragma unroll
     for (int r = 0; r < kNB; ++r) {
 #pragma unroll
-      for (int c = 0; c <= r; ++c) st.Sm[tri(r, c)] = fma(hb[kSlot0 + r][kSlot0 + c], p2[r + c + 2], st.Sm[tri(r, c)]);
+      for (int c = 0; c <= r; ++c) st.Sm[tri(r, c)] = fma(hc[tri(r, c)], p2[r + c + 2], st.Sm[tri(r, c)]);
 #pragma unroll
       for (int q = 0; q < ND; ++q) st.y[r][q] = fma(-w[q][r], p2[r + 1], st.y[r][q]);
     }
@@ -240,7 +274,7 @@ struct FastStep {
     for (int c = 0; c < kNB; ++c)
 #pragma unroll
       for (int r = 0; r < kNB; ++r) {
-        double s = hb[kSlot0 + r][kHalf + kSlot0 + c] * p2[r + c + 2];
+        double s = hc[10 + r * kNB + c] * p2[r + c + 2];
 #pragma unroll
         for (int m = 0; m < r; ++m) s = fma(-L[tri(r, m)], W[m][c], s);
         W[r][c] = s * Linv[r];
@@ -250,7 +284,7 @@ struct FastStep {
     for (int r = 0; r < kNB; ++r) {
 #pragma unroll
       for (int c = 0; c <= r; ++c) {
-        double s = hb[kHalf + kSlot0 + r][kHalf + kSlot0 + c] * p2[r + c + 2];
+        double s = hc[26 + tri(r, c)] * p2[r + c + 2];
 #pragma unroll
         for (int m = 0; m < kNB; ++m) s = fma(-W[m][r], W[m][c], s);
         st.Sm[tri(r, c)] = s;
@@ -267,11 +301,10 @@ struct FastStep {
 };
 
 template <int ND>
-__device__ __forceinline__ double forward_cost(const double* vtx, const double* seg, int S, int d, const double* xs, int k,
-                                               int dim0) {
+__device__ __forceinline__ double forward_cost(const double* vtx, const double* seg, const double* hc, int S, int d,
+                                               const double* xs, int k, int dim0) {
   Elim<ND> st;
   st.init();
-  const double (*hb)[kN] = c_hbar[d];
   const double corr = kGradStep / ((double)S - 1.0);
   int last_kind = kSegGeneral;
   for (int i = 0; i < S; ++i) {
@@ -292,9 +325,9 @@ __device__ __forceinline__ double forward_cost(const double* vtx, const double* 
       segment_powers(T, d, p2);
       FastStep<ND> fast;
       fast.load(sr, dim0);
-      if (kind == kSegInterior) fast.interior(st, hb, p2);
-      else if (kind == kSegStart) fast.start(st, hb, p2);
-      else fast.end(st, hb, p2);
+      if (kind == kSegInterior) fast.interior(st, hc, p2);
+      else if (kind == kSegStart) fast.start(st, hc, p2);
+      else fast.end(st, hc, p2);
     }
   }
   if (last_kind != kSegEnd) {  // after an end-type segment the state stands on a fully constrained vertex: nothing left
@@ -475,14 +508,40 @@ __device__ __forceinline__ double violation_scaling(const double* __restrict__ m
 // ---------------------------------------------------------------------------------------------
 // group helpers (G lanes, G a power of two <= 64, groups aligned to G)
 
+// The optimiser's bookkeeping is a chain of ~20 small reductions per tick.  Butterflies through ds_bpermute
+// (__shfl_xor) cost ~700 shader cycles per 64-lane reduction; DPP moves inside a row of 16 lanes and v_readlane
+// across rows cost ~150.  Every lane of a group receives the bit-identical sum (each step adds the same two partial
+// sums on both sides), which the control flow relies on.
+template <int CTRL>
+__device__ __forceinline__ double dpp_move(double v) {
+  const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xF, 0xF, false);
+  const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xF, 0xF, false);
+  return __hiloint2double(hi, lo);
+}
+
+__device__ __forceinline__ double row_value(double v, int src_lane) {
+  const int lo = __builtin_amdgcn_readlane(__double2loint(v), src_lane), hi = __builtin_amdgcn_readlane(__double2hiint(v), src_lane);
+  return __hiloint2double(hi, lo);
+}
+
 __device__ __forceinline__ double group_sum(double v, int G) {
-  for (int m = G >> 1; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
+  v += dpp_move<0xB1>(v);                 // quad_perm [1,0,3,2]: lane ^ 1
+  if (G >= 4) v += dpp_move<0x4E>(v);     // quad_perm [2,3,0,1]: lane ^ 2
+  if (G >= 8) v += dpp_move<0x141>(v);    // row_half_mirror: the other quad of each 8
+  if (G >= 16) v += dpp_move<0x140>(v);   // row_mirror: the other half of each row of 16
+  if (G >= 32) {
+    // every lane of a row now holds its row's sum.  Rows of a group that is masked off at this point deliver stale
+    // values, which only that group's (inactive) lanes would consume.
+    const double a = row_value(v, 0) + row_value(v, 16), b = row_value(v, 32) + row_value(v, 48);
+    v = (G == 64) ? a + b : ((threadIdx.x & 32) ? b : a);
+  }
   return v;
 }
 
 __device__ __forceinline__ int group_and(int v, int G) {
-  for (int m = G >> 1; m >= 1; m >>= 1) v &= __shfl_xor(v, m, 64);
-  return v;
+  const unsigned long long m = __ballot(v != 0);
+  const unsigned long long gm = (G == 64) ? ~0ull : (((1ull << G) - 1ull) << (threadIdx.x & ~(G - 1)));
+  return (m & gm) == gm;
 }
 
 __device__ __forceinline__ double group_dot(const double* a, const double* b, int S, int g, int G) {
@@ -510,8 +569,8 @@ __host__ __device__ constexpr int gradient_lds_doubles(int Sb) { return 2 * Sb +
 // (objectiveFunctionTimeMellingerOuterLoop + getCostAndGradientMellinger)
 // DS lanes share one time vector (DS = 1: one lane, four dimensions; DS = 4: four lanes, one dimension each).
 template <int DS>
-__device__ __forceinline__ double evaluate_objective(const double* vtx, const double* seg, int S, int d, const double* pt,
-                                                     double* grad, int g, int G, bool active) {
+__device__ __forceinline__ double evaluate_objective(const double* vtx, const double* seg, const double* hc, int S, int d,
+                                                     const double* pt, double* grad, int g, int G, bool active) {
   constexpr int ND = kD / DS;
   const int kl = G / DS;  // time vectors handled per round
   const int kk = g / DS, dim0 = (g % DS) * ND;
@@ -520,10 +579,10 @@ __device__ __forceinline__ double evaluate_objective(const double* vtx, const do
   for (int r = 0; r < rounds; ++r) {
     const int k = kk + r * kl;
     double Jk = 0.0;
-    if (active && k <= S && (k == 0 || S > 1)) Jk = forward_cost<ND>(vtx, seg, S, d, pt, k, dim0);
-    if (DS == 4) {
-      Jk += __shfl_xor(Jk, 1, 64);
-      Jk += __shfl_xor(Jk, 2, 64);
+    if (active && k <= S && (k == 0 || S > 1)) Jk = forward_cost<ND>(vtx, seg, hc, S, d, pt, k, dim0);
+    if (DS == 4) {  // the four dimensions of one time vector sit in one quad
+      Jk += dpp_move<0xB1>(Jk);
+      Jk += dpp_move<0x4E>(Jk);
     }
     if (r == 0) J0 = __shfl(Jk, (threadIdx.x & ~(G - 1)), 64);  // lane 0 of the group holds k = 0
     if (active && dim0 == 0 && k >= 1 && k <= S) grad[k - 1] = (S > 1) ? (Jk - J0) / kGradStep : 0.0;
@@ -548,6 +607,7 @@ __global__ __launch_bounds__(64) void optimize_kernel(BatchView b, NonlinearPara
                                                       const double* __restrict__ vals, double* __restrict__ seg_times,
                                                       int32_t* __restrict__ opt_status) {
   extern __shared__ double lds[];
+  MRS_TG_PHASE_MARK(0);
   int bin = 0;
 #pragma unroll
   for (int i = 1; i < 5; ++i)
@@ -564,7 +624,9 @@ __global__ __launch_bounds__(64) void optimize_kernel(BatchView b, NonlinearPara
   const PathRef pr = path_at(b, q);
   const int S = pr.S, d = prm.derivative;
 
-  double* base = lds + (size_t)grp * group_lds_doubles(Sb);
+  double* hc = lds;  // [kBlockConsts], shared by the groups of the block
+  stage_block_constants(d, hc, lane, 64);
+  double* base = lds + kBlockConsts + (size_t)grp * group_lds_doubles(Sb);
   double* x = base;
   double* gr = x + Sb;
   double* xn = gr + Sb;
@@ -590,6 +652,7 @@ __global__ __launch_bounds__(64) void optimize_kernel(BatchView b, NonlinearPara
     }
   const bool bad = active && !group_and(ok, G);
   __syncthreads();
+  MRS_TG_PHASE_MARK(1);
 
   const int maxeval = prm.max_iterations;
   int ret = -1;
@@ -599,13 +662,14 @@ __global__ __launch_bounds__(64) void optimize_kernel(BatchView b, NonlinearPara
   bool first = true;
 
   while (true) {
-    int running = done ? 0 : 1;
-    for (int m = 32; m >= 1; m >>= 1) running |= __shfl_xor(running, m, 64);
-    if (!running) break;
+    if (__ballot(!done) == 0ull) break;
 
     // (1) one objective evaluation at the trial point
-    const double fn = evaluate_objective<DS>(vtx, seg, S, d, xn, gn, g, G, !done);
+    const double fn = evaluate_objective<DS>(vtx, seg, hc, S, d, xn, gn, g, G, !done);
     __syncthreads();
+#ifdef MRS_TG_PHASE_CLOCKS
+    if (neval < 12) MRS_TG_PHASE_MARK(6 + 2 * neval);  // after evaluation #neval
+#endif
     bool new_dir = false;
     if (!done) {
       ++neval;
@@ -758,7 +822,11 @@ __global__ __launch_bounds__(64) void optimize_kernel(BatchView b, NonlinearPara
     if (!done)
       for (int i = g; i < S; i += G) xn[i] = fmax(x[i] + alpha * dir[i], kTimeLowerBound);
     __syncthreads();
+#ifdef MRS_TG_PHASE_CLOCKS
+    if (neval >= 1 && neval < 13) MRS_TG_PHASE_MARK(5 + 2 * neval);  // end of the tick that made evaluation #neval-1
+#endif
   }
+  MRS_TG_PHASE_MARK(5);
 
   if (active) {
     for (int i = g; i < S; i += G) seg_times[pr.s0 + i] = x[i];
@@ -809,7 +877,9 @@ __global__ __launch_bounds__(64) void cost_gradient_kernel(BatchView b, int d, i
   const int qi = blockIdx.x * (64 / G) + grp;
   const bool active = qi < q_count;
   const PathRef pr = path_at(b, q_begin + (active ? qi : 0));
-  double* x = lds + (size_t)grp * gradient_lds_doubles(Sb);
+  double* hc = lds;
+  stage_block_constants(d, hc, lane, 64);
+  double* x = lds + kBlockConsts + (size_t)grp * gradient_lds_doubles(Sb);
   double* gr = x + Sb;
   double* vtx = gr + Sb;
   double* seg = vtx + (size_t)(Sb + 1) * kVtxLds;
@@ -820,7 +890,7 @@ __global__ __launch_bounds__(64) void cost_gradient_kernel(BatchView b, int d, i
   __syncthreads();
   if (active) stage_segments(vtx, pr.S, d, seg, g, G);
   __syncthreads();
-  const double J = evaluate_objective<DS>(vtx, seg, pr.S, d, x, gr, g, G, active);
+  const double J = evaluate_objective<DS>(vtx, seg, hc, pr.S, d, x, gr, g, G, active);
   __syncthreads();
   if (active) {
     for (int i = g; i < pr.S; i += G) grad[pr.s0 + i] = gr[i];
@@ -1309,7 +1379,7 @@ hipError_t launch_nonlinear(NonlinearPlan& nl, const BatchView& b, const Nonline
       bt.max_S[i] = bin.max_S;
       bt.block_begin[i] = blocks;
       blocks += (int)cdiv_u(bin.q_count, per_block);
-      const size_t need = (size_t)per_block * group_lds_doubles(bin.max_S) * sizeof(double);
+      const size_t need = ((size_t)per_block * group_lds_doubles(bin.max_S) + kBlockConsts) * sizeof(double);
       if (need > lds_bytes) lds_bytes = need;
     }
     if (lds_bytes > 160 * 1024) return hipErrorInvalidValue;
@@ -1407,7 +1477,7 @@ hipError_t launch_cost_gradient(NonlinearPlan& nl, const BatchView& b, int d, co
                                 const double* seg_times, double* cost, double* grad, hipStream_t stream) {
   for (const NonlinearBin& bin : nl.bins) {
     const int per_block = 64 / bin.group;
-    const size_t lds_bytes = (size_t)per_block * gradient_lds_doubles(bin.max_S) * sizeof(double);
+    const size_t lds_bytes = ((size_t)per_block * gradient_lds_doubles(bin.max_S) + kBlockConsts) * sizeof(double);
     if (lds_bytes > 160 * 1024) return hipErrorInvalidValue;
     const dim3 grid(cdiv_u(bin.q_count, per_block));
     if (nl.dim_split == 4)

@@ -6,7 +6,9 @@
 #define MRS_TG_PHASE_CLOCKS 1
 #include "../mrs_uav_trajectory_generation_amd/csrc/mrs_tg_kernels.hip"
 #include "../mrs_uav_trajectory_generation_amd/csrc/mrs_tg_tile.hip"
+#include "../mrs_uav_trajectory_generation_amd/csrc/mrs_tg_nonlinear.hip"
 
+#include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <vector>
@@ -48,7 +50,17 @@ int main(int argc, char** argv) {
       for (int k = 0; k < 5; ++k) mask[u + k] = (k == 0 || end) ? 1 : 0;
       for (int dim = 0; dim < 4; ++dim) vals[u * 4 + dim] = uni() * 20.0 - 10.0;
     }
-  for (auto& t : T) t = 0.5 + 4.5 * uni();
+  // segment times as the Euclidean estimator would give them at 2 m/s (so that the outer loop runs a realistic
+  // number of ticks)
+  for (int p = 0; p < P; ++p)
+    for (int i = 0; i < S; ++i) {
+      double d2 = 0;
+      for (int dim = 0; dim < 3; ++dim) {
+        const double a = vals[(((size_t)p * V + i) * 5) * 4 + dim], bb = vals[(((size_t)p * V + i + 1) * 5) * 4 + dim];
+        d2 += (a - bb) * (a - bb);
+      }
+      T[(size_t)p * S + i] = fmax(0.5, sqrt(d2) / 2.0);
+    }
   BatchView b{P, P * S, S, S, to_dev(so), to_dev(order), to_dev(slot)};
   uint8_t* dmask = to_dev(mask);
   double *dvals = to_dev(vals), *dT = to_dev(T), *H, *A, *coeffs, *cost;
@@ -78,7 +90,7 @@ int main(int argc, char** argv) {
     CK(hipEventSynchronize(e1));
     float ms;
     CK(hipEventElapsedTime(&ms, e0, e1));
-    long long clk[8];
+    long long clk[32];
     CK(hipMemcpyFromSymbol(clk, HIP_SYMBOL(g_phase_clock), sizeof(clk)));
     printf("P=%d S=%d %s: %.2f us per launch back to back; phase clocks (shader cycles since kernel entry of the "
            "middle workgroup): setup %lld  A0 %lld  A1 %lld  B %lld  C %lld  total %lld\n",
@@ -101,12 +113,43 @@ int main(int argc, char** argv) {
     CK(hipEventSynchronize(e1));
     float ms;
     CK(hipEventElapsedTime(&ms, e0, e1));
-    long long clk[8];
+    long long clk[32];
     CK(hipMemcpyFromSymbol(clk, HIP_SYMBOL(g_phase_clock), sizeof(clk)));
     std::vector<int32_t> hn(P);
     CK(hipMemcpy(hn.data(), ns, (size_t)P * 4, hipMemcpyDeviceToHost));
     printf("sample_kernel: %.2f us per launch; middle workgroup (%d samples): load %lld  walk + evaluate %lld cycles\n",
            ms * 1e3 / n, hn[P / 2], clk[1] - clk[0], clk[2] - clk[1]);
+  }
+  // outer loop (mode 2): one optimiser tick = one objective evaluation (S + 1 forward sweeps) + bookkeeping
+  {
+    NonlinearPlan nl;
+    nonlinear_plan_build(nl, so, order);
+    NonlinearParams prm{d, 10, 0.05, -1.0, 0.1, -1.0};
+    std::vector<double> lim((size_t)P * 9);
+    const double l9[9] = {2, 2, 1, 2, 2, 2, 20, 20, 20};
+    for (size_t i = 0; i < lim.size(); ++i) lim[i] = l9[i % 9];
+    double* dlim = to_dev(lim);
+    double* Tw;
+    CK(hipMalloc(&Tw, (size_t)P * S * 8));
+    float total = 0;
+    const int n = 20;
+    for (int i = 0; i < n + 3; ++i) {
+      CK(hipMemcpyAsync(Tw, dT, (size_t)P * S * 8, hipMemcpyDeviceToDevice, st));
+      CK(hipEventRecord(e0, st));
+      CK(launch_nonlinear(nl, b, prm, dmask, dvals, dlim, Tw, coeffs, status, cost, st));
+      CK(hipEventRecord(e1, st));
+      CK(hipEventSynchronize(e1));
+      float ms;
+      CK(hipEventElapsedTime(&ms, e0, e1));
+      if (i >= 3) total += ms;
+    }
+    long long clk[32];
+    CK(hipMemcpyFromSymbol(clk, HIP_SYMBOL(g_phase_clock), sizeof(clk)));
+    printf("nonlinear pipeline (outer loop + 2 solves + maxima + scaling): %.2f us; optimize_kernel middle workgroup: staging %lld, whole kernel %lld cycles\n",
+           total * 1e3 / n, clk[1] - clk[0], clk[5] - clk[0]);
+    for (int t = 0; t < 6; ++t)
+      printf("  tick %d: evaluation %lld cycles, bookkeeping + direction %lld\n", t,
+             clk[6 + 2 * t] - (t == 0 ? clk[1] : clk[5 + 2 * t]), clk[7 + 2 * t] - clk[6 + 2 * t]);
   }
   std::vector<double> hc((size_t)P);
   CK(hipMemcpy(hc.data(), cost, (size_t)P * 8, hipMemcpyDeviceToHost));
