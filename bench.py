@@ -249,7 +249,7 @@ def main():
         torch.cuda.synchronize()
         m_big, _ = kernel_event_ms(lambda: plan_big.assemble(4, t_big, Hb, Ab), 20, torch)
         bytes_big = ASSEMBLY_BYTES_PER_SEGMENT * big_P * args.segments
-        extras["roofline_large"] = dict(kernel="assemble_blocks_kernel", paths=big_P, bytes_per_launch=bytes_big,
+        extras["roofline_large"] = dict(kernel="assemble_blocks_uniform_kernel", paths=big_P, bytes_per_launch=bytes_big,
                                         avg_launch_us=m_big * 1e3, achieved=bytes_big / (m_big * 1e-3) / 1e9,
                                         unit="GB/s", frac=bytes_big / (m_big * 1e-3) / 1e9 / HBM_PEAK_GBS)
         del Hb, Ab

@@ -55,6 +55,12 @@ def main():
     tag = sys.argv[1] if len(sys.argv) > 1 else "round1"
     ctx = api.Context(0)
     ctx.use_torch_stream()
+    if len(sys.argv) > 2:   # one config only, few repetitions: the command to put under rocprofv3
+        which = sys.argv[2]
+        batch = {"config3": lambda: pr.random_batch(1024, 10, seed0=0), "config4": lambda: pr.random_batch(8192, 10, seed0=0),
+                 "config5": lambda: pr.random_batch(8192, "ragged", seed0=0)}[which]()
+        print(which, measure(ctx, batch, True, 10))
+        return
     out = {}
     out["config1_single_4wp_path_linear"] = measure(ctx, pr.config1_batch(), False, 200)
     out["config2_1024x10_linear"] = measure(ctx, pr.random_batch(1024, 10, seed0=0), False, 200)
@@ -66,9 +72,10 @@ def main():
     big = pr.random_batch(65536, 10, seed0=0)
     out["config4_whole_65536x10_linear_one_gpu"] = measure(ctx, big, False, 10)
     out["config4_whole_65536x10_nonlinear_sampled_one_gpu"] = measure(ctx, big, True, 5)
-    path = os.path.join(ROOT, "profiles", "%s_configs.json" % tag)
-    with open(path, "w") as f:
-        json.dump(out, f, indent=1)
+    for folder in ("profiles", "gpurun_out"):   # gpurun_out/ is what travels back from the GPU box
+        if os.path.isdir(os.path.join(ROOT, folder)):
+            with open(os.path.join(ROOT, folder, "%s_configs.json" % tag), "w") as f:
+                json.dump(out, f, indent=1)
     for k, v in out.items():
         print("%-52s %10.3f ms/step %14.0f traj/s" % (k, v["ms_per_step"], v["trajectories_per_s"]))
 
