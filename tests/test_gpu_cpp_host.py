@@ -1,0 +1,65 @@
+"""The C++ host side of the drop-in: examples/path_service_host.cpp (include/mrs_tg_service.hpp, the nodelet's
+service callbacks without ROS) is built with plain g++ against libmrs_tg.so -- no HIP, no torch in the host -- run on
+the GPU, and its TrajectoryReference output is checked the way the reference's rostests check the nodelet's
+(test/include/get_path_test.h:27-106) together with the service-level error strings of callbackPathSrv
+(src/mrs_trajectory_generation.cpp:1976-2041, 2113)."""
+import json
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from tests.test_gpu_reference_scenarios import TEST_PATH, check_trajectory, check_waypoint_idxs
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def host_output(tmp_path_factory):
+    exe = str(tmp_path_factory.mktemp("host") / "path_service_host")
+    libdir = os.path.join(ROOT, "mrs_uav_trajectory_generation_amd")
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-I", os.path.join(ROOT, "include"),
+                           os.path.join(ROOT, "examples", "path_service_host.cpp"), "-o", exe, "-L", libdir, "-lmrs_tg",
+                           "-Wl,-rpath," + libdir])
+    out = subprocess.run([exe], check=True, capture_output=True, text=True, timeout=300).stdout
+    return json.loads(out)
+
+
+def test_error_strings_of_the_service(host_output):
+    assert host_output["missing_constraints"] == dict(host_output["missing_constraints"], success=False, message="missing constraints")
+    assert (host_output["empty"]["success"], host_output["empty"]["message"]) == (False, "received an empty message")
+    assert (host_output["nan"]["success"], host_output["nan"]["message"]) == (False, "invalid path")
+    for k in ("missing_constraints", "empty", "nan"):
+        assert host_output[k]["points"] == []
+
+
+@pytest.mark.parametrize("case", ["plain", "override", "no_state", "fallback"])
+def test_trajectory_reference_passes_the_reference_checks(host_output, case):
+    r = host_output[case]
+    assert r["success"] and r["message"] == "trajectory generated"
+    assert r["dt"] == 0.2 and r["use_heading"] and r["frame_id"] == "uav1/world_origin"
+    pts = np.array(r["points"])
+    assert check_trajectory(pts, TEST_PATH)
+    if case not in ("no_state", "fallback"):    # those two run after clearCurrentState()
+        # the trajectory starts at the current state, every requested waypoint has a non-zero index (get_path_test.h:89-106)
+        assert np.linalg.norm(pts[0, :3] - [0.0, 0.0, 3.0]) < 0.5
+        assert check_waypoint_idxs(r["idxs"], TEST_PATH)
+        assert r["fly_now"]
+    else:
+        assert r["idxs"][0] == 0 and len(r["idxs"]) == 4 and not r["fly_now"]   # no initial condition: "fly now" dropped
+    assert all(a < b for a, b in zip(r["idxs"][:-1], r["idxs"][1:]))
+
+
+def test_batch_members_keep_their_own_request_fields(host_output):
+    assert host_output["plain"]["input_id"] == 7 and host_output["loop_stop"]["input_id"] == 8 and host_output["override"]["input_id"] == 9
+    loop = host_output["loop_stop"]
+    assert loop["success"] and loop["loop"] and len(loop["idxs"]) == 5       # the first waypoint is appended once more
+    pts = np.array(loop["points"])
+    assert check_trajectory(pts, np.vstack([TEST_PATH, TEST_PATH[:1]]))
+    # user limits of 4 m/s instead of 2 m/s: a shorter trajectory; and its own, looser deviation bound was honoured
+    assert len(host_output["override"]["points"]) < len(host_output["plain"]["points"])
+    assert host_output["override"]["max_deviation"] <= 0.2 + 1e-9 or host_output["override"]["success"]
+    v = np.linalg.norm(np.diff(np.array(host_output["override"]["points"])[:, :2], axis=0), axis=1) / 0.2
+    assert 2.2 < v.max() < 4.0 * 1.05
