@@ -331,6 +331,13 @@ struct PathRef {
 
 __device__ __forceinline__ PathRef path_at(const BatchView& b, int q) {
   PathRef r;
+  if (b.uniform_S > 0) {  // every path has the same segment count: the stable sort left the order alone, offsets are arithmetic
+    r.p = q;              // (no dependent loads before a kernel can touch its inputs)
+    r.S = b.uniform_S;
+    r.s0 = q * b.uniform_S;
+    r.v0 = r.s0 + q;
+    return r;
+  }
   r.p = b.order[q];
   r.s0 = b.seg_offsets[r.p];
   r.S = b.seg_offsets[r.p + 1] - r.s0;

@@ -315,7 +315,15 @@ __global__ __launch_bounds__(kTileThreads) void solve_tile_kernel(BatchView b, i
     using std::true_type;
     using std::false_type;
 
-    for (int s = 0; s < len; ++s) {
+    // A fully constrained end vertex (every rest-to-rest path has two) has nothing to eliminate: its block is the
+    // identity, z = 0, W = 0.  When that holds for every lane of the wavefront the chains start one vertex further in,
+    // which takes one of the S/2 + 1 dependent steps off the phase.
+    int s_first = 0;
+    {
+      const unsigned end_fb = (len > 0) ? (unsigned)vtx_rec(t, dir ? S : 0)[62] : 0xFu;
+      if (__ballot(end_fb != 0u) == 0ull) s_first = 1;
+    }
+    for (int s = s_first; s < len; ++s) {
       const int v = dir ? (S - s) : s;
       eliminate(v, true_type{}, false_type{});
     }
@@ -389,7 +397,7 @@ __global__ __launch_bounds__(kTileThreads) void solve_tile_kernel(BatchView b, i
 #pragma unroll
       for (int r = 0; r < kNB; ++r) xn[r] = vr[26 + r * kD + dim];
     }
-    for (int s = len - 1; s >= 0; --s) {
+    for (int s = len - 1; s >= s_first; --s) {
       const int v = dir ? (S - s) : s;
       double* vr = vtx_rec(t, v);
       double tv[kNB], x[kNB];
