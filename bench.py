@@ -41,6 +41,7 @@ def parse_args():
     ap.add_argument("--paths", type=int, default=1024, help="paths per GPU")
     ap.add_argument("--segments", type=int, default=10)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=10.0, help="single-core work of the cpu_baseline sample")
     ap.add_argument("--no-extras", action="store_true", help="skip the secondary (other workload) measurement")
     ap.add_argument("--gather", choices=["final", "every"], default="final",
                     help="N > 1: gather the results to rank 0 once at the end of the timed steps (default) or after every step")
@@ -294,11 +295,19 @@ def main():
         t0 = time.perf_counter()
         ref = po.solve_batch(sub.seg_offsets, sub.waypoints, sub.fixed_mask, sub.fixed_values, sub.limits, sub_t, deriv=4)
         dt1 = time.perf_counter() - t0
-        cores = os.cpu_count() or 1
+        # bounded sample of ~10 s of single-core work: the same batch solved again and again
+        reps_cpu = max(1, min(2000, int(args.cpu_seconds / max(dt1, 1e-6))))
         t0 = time.perf_counter()
-        po.solve_batch(sub.seg_offsets, sub.waypoints, sub.fixed_mask, sub.fixed_values, sub.limits, sub_t, deriv=4,
-                       n_threads=cores)
-        dtn = time.perf_counter() - t0
+        for _ in range(reps_cpu):
+            po.solve_batch(sub.seg_offsets, sub.waypoints, sub.fixed_mask, sub.fixed_values, sub.limits, sub_t, deriv=4)
+        dt1 = (time.perf_counter() - t0) / reps_cpu
+        cores = os.cpu_count() or 1
+        reps_all = max(1, reps_cpu // 8)
+        t0 = time.perf_counter()
+        for _ in range(reps_all):
+            po.solve_batch(sub.seg_offsets, sub.waypoints, sub.fixed_mask, sub.fixed_values, sub.limits, sub_t, deriv=4,
+                           n_threads=cores)
+        dtn = (time.perf_counter() - t0) / reps_all
         gpu_c = db.coeffs.cpu().numpy()[:sub.n_segments]
         worst = 0.0
         for p in range(sub.n_paths):
@@ -306,17 +315,28 @@ def main():
             worst = max(worst, float(np.max(np.abs(gpu_c[a:b] - ref["coeffs"][a:b])) / np.max(np.abs(ref["coeffs"][a:b]))))
         err = worst
         cpu = dict(value=n_cpu / dt1, unit="trajectories/s", cores=1, kind="port",
-                   sample="%d of the %d paths of this batch, linear QP, C oracle (reference-style arithmetic, dense QR)"
-                          % (n_cpu, P),
+                   sample="%d x the first %d of the %d paths of this batch (%.1f s of one core), linear QP, C oracle "
+                          "(reference-style arithmetic, dense QR); all-core figure: %d x the same batch"
+                          % (reps_cpu, n_cpu, P, reps_cpu * dt1, reps_all),
                    value_all_cores=n_cpu / dtn, cores_all=cores)
         if args.workload == "nonlinear" or not args.no_extras:
             n_nl = min(P, 256)
             subn = batch.select(range(n_nl))
+
+            def cpu_nonlinear():
+                po.solve_batch(subn.seg_offsets, subn.waypoints, subn.fixed_mask, subn.fixed_values, subn.limits,
+                               times[:subn.n_segments], deriv=4, time_alloc_method=2, sampling_dt=0.2, sample_capacity=512)
             t0 = time.perf_counter()
-            po.solve_batch(subn.seg_offsets, subn.waypoints, subn.fixed_mask, subn.fixed_values, subn.limits,
-                           times[:subn.n_segments], deriv=4, time_alloc_method=2, sampling_dt=0.2, sample_capacity=512)
-            cpu["nonlinear_value"] = n_nl / (time.perf_counter() - t0)
-            cpu["nonlinear_sample"] = "%d paths, Mellinger outer loop + scaling + sampling, 1 thread" % n_nl
+            cpu_nonlinear()
+            dtnl = time.perf_counter() - t0
+            reps_nl = max(1, min(100, int(0.5 * args.cpu_seconds / max(dtnl, 1e-6))))
+            t0 = time.perf_counter()
+            for _ in range(reps_nl):
+                cpu_nonlinear()
+            dtnl = (time.perf_counter() - t0) / reps_nl
+            cpu["nonlinear_value"] = n_nl / dtnl
+            cpu["nonlinear_sample"] = ("%d x %d paths (%.1f s of one core), Mellinger outer loop + scaling + sampling, 1 thread"
+                                       % (reps_nl, n_nl, reps_nl * dtnl))
 
     if rank == 0:
         line = dict(metric="trajectories/sec (batch of N-seg min-snap paths)", value=value, unit="trajectories/s",
