@@ -36,6 +36,8 @@ extern "C" {
 #define MRS_TG_N_COEFF 10
 #define MRS_TG_N_DIM 4
 #define MRS_TG_N_SLOT 5 /* derivative slots per vertex: position .. snap */
+#define MRS_TG_MAX_SEGMENTS 256 /* longest path a plan accepts (per-path optimiser state lives in the 160 KB LDS of a CU;
+                                   the reference's deviation loop ends near 30 segments) */
 
 enum {
   MRS_TG_OK = 0,

@@ -277,6 +277,8 @@ int mrs_tg_plan_create(mrs_tg_ctx* ctx, int32_t n_paths, const int32_t* so, mrs_
   for (int p = 0; p < n_paths; ++p) {
     const int S = so[p + 1] - so[p];
     if (S < 1) return fail(ctx, MRS_TG_ERR_INVALID_ARG, "path %d has %d segments (need >= 1)", p, S);
+    if (S > MRS_TG_MAX_SEGMENTS)
+      return fail(ctx, MRS_TG_ERR_INVALID_ARG, "path %d has %d segments (at most %d)", p, S, MRS_TG_MAX_SEGMENTS);
     max_S = std::max(max_S, S);
     min_S = std::min(min_S, S);
   }

@@ -64,6 +64,16 @@ def test_long_paths_fall_back_to_per_lane_kernel(gpu_ctx):
     assert np.all(np.isin(nl["status"], (1, 3, 4, 5))) and np.all(np.isfinite(nl["coeffs"]))
 
 
+def test_longest_accepted_path_and_one_beyond(gpu_ctx):
+    batch = pr.random_batch(2, 256, seed0=8200)              # MRS_TG_MAX_SEGMENTS
+    out = gpu_ctx.solve_batch(batch, None, time_alloc_method=api.TIME_ALLOC_MELLINGER, max_iterations=3, sampling_dt=0.2,
+                              sample_capacity=64)
+    assert np.all(np.isin(out["status"], (1, 3, 4, 5))) and np.all(np.isfinite(out["coeffs"]))
+    assert util.continuity_defect(batch, out["coeffs"], out["times"]) < 1e-8
+    with pytest.raises(api.MrsTgError, match="at most 256"):
+        gpu_ctx.solve_batch(pr.random_batch(1, 257, seed0=1), None)
+
+
 def test_nonlinear_compact_mapping_matches_split_mapping(gpu_ctx):
     # P > 4096 switches the outer loop to one lane per time vector; the same paths in a small batch use four
     batch = pr.random_batch(4200, 10, seed0=9000)
