@@ -199,7 +199,7 @@ struct FastStep {
   }
 
   // start vertex fully constrained: nothing to eliminate; the state moves to the end vertex
-  __device__ __forceinline__ void start(Elim<ND>& st, const double* hc, const double (&p2)[9]) const {
+  __device__ __forceinline__ void start(Elim<ND>& st, const double (&hc)[kBlockConsts], const double (&p2)[9]) const {
 #pragma unroll
     for (int r = 0; r < kNB; ++r) {
 #pragma unroll
@@ -242,7 +242,7 @@ struct FastStep {
   }
 
   // end vertex fully constrained: eliminate the start vertex, nothing is passed on
-  __device__ __forceinline__ void end(Elim<ND>& st, const double* hc, const double (&p2)[9]) const {
+  __device__ __forceinline__ void end(Elim<ND>& st, const double (&hc)[kBlockConsts], const double (&p2)[9]) const {
 #pragma unroll
     for (int r = 0; r < kNB; ++r) {
 #pragma unroll
@@ -257,7 +257,7 @@ struct FastStep {
   }
 
   // both vertices constrain their position only
-  __device__ __forceinline__ void interior(Elim<ND>& st, const double* hc, const double (&p2)[9]) const {
+  __device__ __forceinline__ void interior(Elim<ND>& st, const double (&hc)[kBlockConsts], const double (&p2)[9]) const {
 #pragma unroll
     for (int r = 0; r < kNB; ++r) {
 #pragma unroll
@@ -305,6 +305,10 @@ __device__ __forceinline__ double forward_cost(const double* vtx, const double* 
                                                const double* xs, int k, int dim0) {
   Elim<ND> st;
   st.init();
+  // the 36 block constants stay in registers for the whole sweep (one LDS read per sweep instead of one per step)
+  double hcr[kBlockConsts];
+#pragma unroll
+  for (int e = 0; e < kBlockConsts; ++e) hcr[e] = hc[e];
   const double corr = kGradStep / ((double)S - 1.0);
   int last_kind = kSegGeneral;
   for (int i = 0; i < S; ++i) {
@@ -325,9 +329,9 @@ __device__ __forceinline__ double forward_cost(const double* vtx, const double* 
       segment_powers(T, d, p2);
       FastStep<ND> fast;
       fast.load(sr, dim0);
-      if (kind == kSegInterior) fast.interior(st, hc, p2);
-      else if (kind == kSegStart) fast.start(st, hc, p2);
-      else fast.end(st, hc, p2);
+      if (kind == kSegInterior) fast.interior(st, hcr, p2);
+      else if (kind == kSegStart) fast.start(st, hcr, p2);
+      else fast.end(st, hcr, p2);
     }
   }
   if (last_kind != kSegEnd) {  // after an end-type segment the state stands on a fully constrained vertex: nothing left
