@@ -85,6 +85,22 @@ __device__ __forceinline__ unsigned staged_vertex(const double* vtx, int v, int 
   return (unsigned)r[20];
 }
 
+// The sweep delivers the optimal cost as 0.5 (qf - red), a difference.  On an ordinary path it cancels 1-4 digits.  A
+// trial point that puts a segment on the 0.01 s lower bound next to 10 s neighbours makes qf ~ T^-7 |dp|^2 ~ 1e18 while the
+// true cost is ~1e4: all 16 digits cancel and the difference is noise of either sign -- and a negative "cost" passes the
+// Armijo test, after which the optimiser runs away (seen on 1 of 65536 random paths: times of 1e17 s).  The reference
+// evaluates 0.5 c^T Q c from the coefficients there (computeCost, linear_impl.h:128-141), a large positive number, and
+// its line search backtracks.  A difference that has lost more than nine digits is therefore reported as "very large":
+// the same decision (reject, backtrack) without claiming a value.
+constexpr double kUnreliableCost = 1.0e300;
+
+// J and qf are the sums over all four dimensions (a dimension whose waypoints do not move has qf = J = rounding noise
+// of either sign, so the test cannot be made per dimension); the absolute floor keeps a path that does not move at all
+// out of it.
+__device__ __forceinline__ double guarded_cost(double J, double qf) {
+  return (J >= 0.5e-9 * qf || qf < 1e-9) ? J : kUnreliableCost;
+}
+
 // ---- specialised segment steps of the forward sweep ---------------------------------------------------------
 // Almost every segment of almost every path is one of three shapes: both end vertices constrain their position
 // only (interior segment), the start vertex is fully constrained with zero derivatives (first segment, or the one
@@ -302,7 +318,7 @@ struct FastStep {
 
 template <int ND>
 __device__ __forceinline__ double forward_cost(const double* vtx, const double* seg, const double* hc, int S, int d,
-                                               const double* xs, int k, int dim0) {
+                                               const double* xs, int k, int dim0, double& qf_out) {
   Elim<ND> st;
   st.init();
   // the 36 block constants stay in registers for the whole sweep (one LDS read per sweep instead of one per step)
@@ -340,6 +356,7 @@ __device__ __forceinline__ double forward_cost(const double* vtx, const double* 
     const unsigned free_l = staged_vertex<ND>(vtx, S, dim0, fl);
     st.factor_vertex(free_l, L, z);
   }
+  qf_out = st.qf;
   return 0.5 * (st.qf - st.red);
 }
 
@@ -582,12 +599,15 @@ __device__ __forceinline__ double evaluate_objective(const double* vtx, const do
   const int rounds = (S + 1 + kl - 1) / kl;
   for (int r = 0; r < rounds; ++r) {
     const int k = kk + r * kl;
-    double Jk = 0.0;
-    if (active && k <= S && (k == 0 || S > 1)) Jk = forward_cost<ND>(vtx, seg, hc, S, d, pt, k, dim0);
+    double Jk = 0.0, qfk = 0.0;
+    if (active && k <= S && (k == 0 || S > 1)) Jk = forward_cost<ND>(vtx, seg, hc, S, d, pt, k, dim0, qfk);
     if (DS == 4) {  // the four dimensions of one time vector sit in one quad
       Jk += dpp_move<0xB1>(Jk);
       Jk += dpp_move<0x4E>(Jk);
+      qfk += dpp_move<0xB1>(qfk);
+      qfk += dpp_move<0x4E>(qfk);
     }
+    Jk = guarded_cost(Jk, qfk);
     if (r == 0) J0 = __shfl(Jk, (threadIdx.x & ~(G - 1)), 64);  // lane 0 of the group holds k = 0
     if (active && dim0 == 0 && k >= 1 && k <= S) grad[k - 1] = (S > 1) ? (Jk - J0) / kGradStep : 0.0;
   }

@@ -196,3 +196,26 @@ def test_sample_overflow_is_reported_as_capacity_plus_one(gpu_ctx):
     big = gpu_ctx.solve_batch(batch, None, sampling_dt=0.2, sample_capacity=4096)
     assert np.all(big["n_samples"] < 4096)
     assert np.array_equal(out["samples"][:, :16], big["samples"][:, :16])
+
+
+def test_trial_point_on_the_lower_bound_is_rejected_not_run_away_with(gpu_ctx):
+    """Path 27335 of the 65536-path benchmark batch: the third and fourth evaluations put segment 6 on the 0.01 s bound
+    between 5-10 s neighbours.  There 0.5 (qf - red) cancels completely (qf ~ 1e18, true cost ~ 3e4) and used to come
+    out negative, passed the Armijo test and sent the segment times to 1e17 s; the reference-style cost 0.5 c^T Q c is
+    large and positive and the line search backtracks.  The by-product cost is now reported as 'very large' when it has
+    lost more than nine digits (same decision), so the path must end where the oracle's does."""
+    batch = pr.random_batch(1, 10, seed0=27335)
+    out = gpu_ctx.solve_batch(batch, None, time_alloc_method=api.TIME_ALLOC_MELLINGER)
+    ref = po.solve_batch(batch.seg_offsets, batch.waypoints, batch.fixed_mask, batch.fixed_values, batch.limits,
+                         np.zeros(10), deriv=4, time_alloc_method=2, estimate_times=True)
+    assert out["status"][0] == ref["status"][0] == 3
+    assert np.max(np.abs(out["times"] - ref["times"]) / ref["times"]) < 1e-6
+    assert np.all(out["times"] < 30.0) and np.all(np.isfinite(out["coeffs"]))
+    # and the building block says so itself: at the oracle's third trial point the cost is flagged, not negative
+    t0 = util.oracle_times(batch)
+    _, m, v = batch.path(0)
+    _, t3, _, _ = po.optimize_times(4, m, v, t0, po.default_nlopt(3))
+    assert t3[6] == 0.01
+    J, _ = gpu_cost_gradient(gpu_ctx, batch, t3)
+    Jo, _ = po.cost_and_gradient(4, m, v, t3)
+    assert Jo > 1e4 and J[0] >= 1e299
