@@ -113,7 +113,8 @@ int mto_scale_segment_times_to_meet_constraints(int n_seg, double* coeffs, doubl
 /* ---- sampling --------------------------------------------------------------------------- */
 /* sampleWholeTrajectory -> Trajectory::evaluateRange (trajectory_sampling.cpp:49-124,
  * trajectory.cpp:93-151). Writes up to capacity samples of [x,y,z,heading_raw] for derivative
- * `derivative`; returns the number the reference would produce (may exceed capacity). */
+ * `derivative`; returns the number the reference would produce, or capacity + 1 if that is more than capacity
+ * (capacity 0: unbounded count). */
 int mto_sample_trajectory(int n_seg, const double* coeffs, const double* seg_times, double dt,
                           int derivative, double* out, int capacity);
 /* yaw after the quaternion round trip (eth_mav_msgs/common.h:130-140, eigen_mav_msgs.h setFromYaw/getYaw) */

@@ -386,6 +386,10 @@ int mto_sample_trajectory(int n_seg, const double* coeffs, const double* seg_tim
     ++count;
     time_in_segment += dt;
     accumulated += dt;
+    /* A trajectory whose outer loop ended on a rejected trial point can have segment times of 1e12 s after the
+     * feasibility scaling (the nodelet discards such results by its length check, src/...cpp:1178-1199); the
+     * reference would push 5e12 samples here.  Callers only distinguish "more than capacity", so stop there. */
+    if (capacity > 0 && count > capacity) break;
   }
   return count;
 }
