@@ -3,7 +3,10 @@
 // sequences.  No numerics live here and nothing falls back to the CPU: every failure is reported.
 #include <hip/hip_runtime.h>
 
+#include "mrs_tg_pool.h"
+
 #include <algorithm>
+#include <atomic>
 #include <cfloat>
 #include <cstdarg>
 #include <cstdio>
@@ -30,6 +33,8 @@ void set_global_error(const std::string& s) {
 }
 
 }  // namespace
+
+static std::atomic<int> g_live_contexts{0};
 
 struct mrs_tg_ctx {
   int device = -1;
@@ -94,10 +99,13 @@ struct ProfileScope {
 
 int ensure_ws(mrs_tg_plan* plan, size_t doubles) {
   if (plan->ws_doubles >= doubles) return MRS_TG_OK;
-  if (plan->d_ws) (void)hipFree(plan->d_ws);
+  if (plan->d_ws) {
+    (void)hipStreamSynchronize(plan->ctx->stream);  // pool contract: no work in flight on a block that is given back
+    mrs_tg::pool_free(plan->d_ws);
+  }
   plan->d_ws = nullptr;
   plan->ws_doubles = 0;
-  HIP_TRY(plan->ctx, hipMalloc(&plan->d_ws, doubles * sizeof(double)));
+  HIP_TRY(plan->ctx, mrs_tg::pool_alloc(&plan->d_ws, doubles * sizeof(double)));
   plan->ws_doubles = doubles;
   return MRS_TG_OK;
 }
@@ -105,8 +113,8 @@ int ensure_ws(mrs_tg_plan* plan, size_t doubles) {
 int ensure_blocks(mrs_tg_plan* plan) {
   if (plan->d_H) return MRS_TG_OK;
   const size_t bytes = mrs_tg_plan_block_bytes(plan);
-  HIP_TRY(plan->ctx, hipMalloc(&plan->d_H, bytes));
-  HIP_TRY(plan->ctx, hipMalloc(&plan->d_Ainv, bytes));
+  HIP_TRY(plan->ctx, mrs_tg::pool_alloc(&plan->d_H, bytes));
+  HIP_TRY(plan->ctx, mrs_tg::pool_alloc(&plan->d_Ainv, bytes));
   return MRS_TG_OK;
 }
 
@@ -130,9 +138,9 @@ namespace {
 struct DevBuf {
   void* p = nullptr;
   ~DevBuf() {
-    if (p) (void)hipFree(p);
+    if (p) (void)mrs_tg::pool_free(p);
   }
-  hipError_t alloc(size_t bytes) { return hipMalloc(&p, bytes ? bytes : 8); }
+  hipError_t alloc(size_t bytes) { return mrs_tg::pool_alloc(&p, bytes ? bytes : 8); }
   template <class T>
   T* as() {
     return static_cast<T*>(p);
@@ -216,6 +224,7 @@ int mrs_tg_create(int device_ordinal, mrs_tg_ctx** ctx_out) {
     (void)hipEventCreate(&ctx->ev_start[i]);
     (void)hipEventCreate(&ctx->ev_stop[i]);
   }
+  ++g_live_contexts;
   *ctx_out = ctx;
   return MRS_TG_OK;
 }
@@ -230,6 +239,7 @@ void mrs_tg_destroy(mrs_tg_ctx* ctx) {
   }
   if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
   delete ctx;
+  if (--g_live_contexts == 0) mrs_tg::pool_release_cached();  // the cached device blocks go with the last context
 }
 
 int mrs_tg_set_stream(mrs_tg_ctx* ctx, void* hip_stream) {
@@ -309,9 +319,9 @@ int mrs_tg_plan_create(mrs_tg_ctx* ctx, int32_t n_paths, const int32_t* so, mrs_
     return code;
   };
   hipError_t e;
-  if ((e = hipMalloc(&plan->d_seg_offsets, sizeof(int32_t) * (n_paths + 1))) != hipSuccess ||
-      (e = hipMalloc(&plan->d_order, sizeof(int32_t) * std::max(n_paths, 1))) != hipSuccess ||
-      (e = hipMalloc(&plan->d_slot_start, sizeof(int32_t) * (max_S + 1))) != hipSuccess ||
+  if ((e = mrs_tg::pool_alloc(&plan->d_seg_offsets, sizeof(int32_t) * (n_paths + 1))) != hipSuccess ||
+      (e = mrs_tg::pool_alloc(&plan->d_order, sizeof(int32_t) * std::max(n_paths, 1))) != hipSuccess ||
+      (e = mrs_tg::pool_alloc(&plan->d_slot_start, sizeof(int32_t) * (max_S + 1))) != hipSuccess ||
       (e = hipMemcpy(plan->d_seg_offsets, so, sizeof(int32_t) * (n_paths + 1), hipMemcpyHostToDevice)) != hipSuccess ||
       (n_paths > 0 && (e = hipMemcpy(plan->d_order, plan->order_host.data(), sizeof(int32_t) * n_paths,
                                      hipMemcpyHostToDevice)) != hipSuccess) ||
@@ -336,12 +346,12 @@ void mrs_tg_plan_destroy(mrs_tg_plan* plan) {
   (void)hipSetDevice(plan->ctx->device);
   (void)hipStreamSynchronize(plan->ctx->stream);
   mrs_tg::nonlinear_plan_free(plan->nl);
-  if (plan->d_seg_offsets) (void)hipFree(plan->d_seg_offsets);
-  if (plan->d_order) (void)hipFree(plan->d_order);
-  if (plan->d_slot_start) (void)hipFree(plan->d_slot_start);
-  if (plan->d_ws) (void)hipFree(plan->d_ws);
-  if (plan->d_H) (void)hipFree(plan->d_H);
-  if (plan->d_Ainv) (void)hipFree(plan->d_Ainv);
+  if (plan->d_seg_offsets) (void)mrs_tg::pool_free(plan->d_seg_offsets);
+  if (plan->d_order) (void)mrs_tg::pool_free(plan->d_order);
+  if (plan->d_slot_start) (void)mrs_tg::pool_free(plan->d_slot_start);
+  if (plan->d_ws) (void)mrs_tg::pool_free(plan->d_ws);
+  if (plan->d_H) (void)mrs_tg::pool_free(plan->d_H);
+  if (plan->d_Ainv) (void)mrs_tg::pool_free(plan->d_Ainv);
   delete plan;
 }
 
@@ -472,6 +482,10 @@ int mrs_tg_solve_batch(mrs_tg_ctx* ctx, int32_t n_paths, const int32_t* so, cons
   if (sampling && !n_samples) return fail(ctx, MRS_TG_ERR_INVALID_ARG, "n_samples_out is required when sampling");
   const size_t samp_doubles = sampling && samples ? (size_t)n_paths * (size_t)opt->sample_capacity * 4 : 0;
   DevBuf d_wp, d_mask, d_vals, d_lim, d_t, d_c, d_st, d_cost, d_ns, d_smp;
+  struct SyncOnExit {  // declared after the buffers, so it runs before they return to the pool (also on error paths)
+    hipStream_t s;
+    ~SyncOnExit() { (void)hipStreamSynchronize(s); }
+  } sync_on_exit{ctx->stream};
   HIP_TRY(ctx, d_wp.alloc(nV * 4 * sizeof(double)));
   HIP_TRY(ctx, d_mask.alloc(nV * 5));
   HIP_TRY(ctx, d_vals.alloc(nV * 20 * sizeof(double)));

@@ -33,6 +33,7 @@
 #include <cstdint>
 
 #include "mrs_tg_device.hpp"
+#include "mrs_tg_pool.h"
 #include "mrs_tg_solve.hpp"
 #include "mrs_tg_nonlinear.h"
 
@@ -1341,15 +1342,15 @@ int nonlinear_plan_build(NonlinearPlan& nl, const std::vector<int32_t>& so, cons
 }
 
 void nonlinear_plan_free(NonlinearPlan& nl) {
-  if (nl.d_ws) (void)hipFree(nl.d_ws);
-  if (nl.d_opt_status) (void)hipFree(nl.d_opt_status);
-  if (nl.d_maxima) (void)hipFree(nl.d_maxima);
-  if (nl.d_dfo_vec) (void)hipFree(nl.d_dfo_vec);
-  if (nl.d_dfo_f) (void)hipFree(nl.d_dfo_f);
-  if (nl.d_dfo_state) (void)hipFree(nl.d_dfo_state);
-  if (nl.d_dfo_fidx) (void)hipFree(nl.d_dfo_fidx);
-  if (nl.d_dfo_segcost) (void)hipFree(nl.d_dfo_segcost);
-  if (nl.d_dfo_seg_path) (void)hipFree(nl.d_dfo_seg_path);
+  if (nl.d_ws) (void)mrs_tg::pool_free(nl.d_ws);
+  if (nl.d_opt_status) (void)mrs_tg::pool_free(nl.d_opt_status);
+  if (nl.d_maxima) (void)mrs_tg::pool_free(nl.d_maxima);
+  if (nl.d_dfo_vec) (void)mrs_tg::pool_free(nl.d_dfo_vec);
+  if (nl.d_dfo_f) (void)mrs_tg::pool_free(nl.d_dfo_f);
+  if (nl.d_dfo_state) (void)mrs_tg::pool_free(nl.d_dfo_state);
+  if (nl.d_dfo_fidx) (void)mrs_tg::pool_free(nl.d_dfo_fidx);
+  if (nl.d_dfo_segcost) (void)mrs_tg::pool_free(nl.d_dfo_segcost);
+  if (nl.d_dfo_seg_path) (void)mrs_tg::pool_free(nl.d_dfo_seg_path);
   nl.d_dfo_fidx = nullptr;
   nl.d_dfo_segcost = nullptr;
   nl.d_dfo_seg_path = nullptr;
@@ -1368,15 +1369,15 @@ static hipError_t ensure_buffers(NonlinearPlan& nl, const BatchView& b) {
   hipError_t e;
   const size_t need = linear_workspace_doubles(b);
   if (nl.ws_doubles < need) {
-    if (nl.d_ws) (void)hipFree(nl.d_ws);
+    if (nl.d_ws) (void)mrs_tg::pool_free(nl.d_ws);
     nl.d_ws = nullptr;
     nl.ws_doubles = 0;
-    if ((e = hipMalloc(&nl.d_ws, need * sizeof(double))) != hipSuccess) return e;
+    if ((e = mrs_tg::pool_alloc(&nl.d_ws, need * sizeof(double))) != hipSuccess) return e;
     nl.ws_doubles = need;
   }
-  if (!nl.d_opt_status && (e = hipMalloc(&nl.d_opt_status, sizeof(int32_t) * (size_t)(b.n_paths > 0 ? b.n_paths : 1))) != hipSuccess)
+  if (!nl.d_opt_status && (e = mrs_tg::pool_alloc(&nl.d_opt_status, sizeof(int32_t) * (size_t)(b.n_paths > 0 ? b.n_paths : 1))) != hipSuccess)
     return e;
-  if (!nl.d_maxima && (e = hipMalloc(&nl.d_maxima, sizeof(double) * 9 * (size_t)(b.n_segments > 0 ? b.n_segments : 1))) != hipSuccess)
+  if (!nl.d_maxima && (e = mrs_tg::pool_alloc(&nl.d_maxima, sizeof(double) * 9 * (size_t)(b.n_segments > 0 ? b.n_segments : 1))) != hipSuccess)
     return e;
   return hipSuccess;
 }
@@ -1445,15 +1446,15 @@ hipError_t launch_dfo(NonlinearPlan& nl, const BatchView& b, const DfoParams& pr
   const size_t nS = (size_t)(b.n_segments > 0 ? b.n_segments : 1), P = (size_t)b.n_paths;
   const size_t NV = dfo_var_total(b.n_segments, b.n_paths);
   const bool with_free = prm.mode >= 3;
-  if (!nl.d_dfo_vec && (e = hipMalloc(&nl.d_dfo_vec, sizeof(double) * 6 * NV)) != hipSuccess) return e;
-  if (!nl.d_dfo_f && (e = hipMalloc(&nl.d_dfo_f, sizeof(double) * 3 * P)) != hipSuccess) return e;
+  if (!nl.d_dfo_vec && (e = mrs_tg::pool_alloc(&nl.d_dfo_vec, sizeof(double) * 6 * NV)) != hipSuccess) return e;
+  if (!nl.d_dfo_f && (e = mrs_tg::pool_alloc(&nl.d_dfo_f, sizeof(double) * 3 * P)) != hipSuccess) return e;
   if (!cost) cost = nl.d_dfo_f + 2 * P;  // J_d per evaluation needs a buffer even when the caller does not want it
-  if (!nl.d_dfo_state && (e = hipMalloc(&nl.d_dfo_state, sizeof(int32_t) * kDfoInts * P)) != hipSuccess) return e;
+  if (!nl.d_dfo_state && (e = mrs_tg::pool_alloc(&nl.d_dfo_state, sizeof(int32_t) * kDfoInts * P)) != hipSuccess) return e;
   if (with_free) {
-    if (!nl.d_dfo_fidx && (e = hipMalloc(&nl.d_dfo_fidx, sizeof(int32_t) * (nS + P) * kHalf)) != hipSuccess) return e;
-    if (!nl.d_dfo_segcost && (e = hipMalloc(&nl.d_dfo_segcost, sizeof(double) * nS * kD)) != hipSuccess) return e;
+    if (!nl.d_dfo_fidx && (e = mrs_tg::pool_alloc(&nl.d_dfo_fidx, sizeof(int32_t) * (nS + P) * kHalf)) != hipSuccess) return e;
+    if (!nl.d_dfo_segcost && (e = mrs_tg::pool_alloc(&nl.d_dfo_segcost, sizeof(double) * nS * kD)) != hipSuccess) return e;
     if (!nl.d_dfo_seg_path) {
-      if ((e = hipMalloc(&nl.d_dfo_seg_path, sizeof(int32_t) * nS)) != hipSuccess) return e;
+      if ((e = mrs_tg::pool_alloc(&nl.d_dfo_seg_path, sizeof(int32_t) * nS)) != hipSuccess) return e;
       hipLaunchKernelGGL(dfo_segment_path_kernel, dim3(cdiv_u(b.n_paths, 64)), dim3(64), 0, stream, b, nl.d_dfo_seg_path);
       if ((e = hipGetLastError()) != hipSuccess) return e;
     }

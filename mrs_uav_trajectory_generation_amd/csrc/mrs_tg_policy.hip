@@ -10,6 +10,7 @@
 // future", MPC prediction splicing, wall-clock overtime) have no counterpart.
 #include <hip/hip_runtime.h>
 
+
 #include <algorithm>
 #include <cfloat>
 #include <cmath>

@@ -1,0 +1,101 @@
+// mrs_tg_pool.hip -- caching device allocator (see mrs_tg_pool.h)
+#include "mrs_tg_pool.h"
+
+#include <map>
+#include <mutex>
+#include <unordered_map>
+
+namespace mrs_tg {
+
+namespace {
+
+struct Live {
+  size_t bytes;
+  int device;
+};
+
+std::mutex g_mutex;
+std::unordered_map<void*, Live> g_live;                    // handed out
+std::map<int, std::multimap<size_t, void*>> g_cached;      // per device, by rounded size
+size_t g_cached_bytes = 0;
+constexpr size_t kMaxCachedBytes = (size_t)8 << 30;        // beyond this, blocks go straight back to the driver
+
+size_t round_size(size_t bytes) {
+  if (bytes < 256) return 256;
+  if (bytes <= ((size_t)1 << 20)) {  // next power of two up to 1 MiB
+    size_t r = 256;
+    while (r < bytes) r <<= 1;
+    return r;
+  }
+  const size_t mib = (size_t)1 << 20;
+  return (bytes + mib - 1) / mib * mib;
+}
+
+}  // namespace
+
+hipError_t pool_alloc_bytes(void** p, size_t bytes) {
+  *p = nullptr;
+  int dev = 0;
+  hipError_t e = hipGetDevice(&dev);
+  if (e != hipSuccess) return e;
+  const size_t want = round_size(bytes);
+  {
+    std::lock_guard<std::mutex> lk(g_mutex);
+    auto& bucket = g_cached[dev];
+    auto it = bucket.lower_bound(want);
+    if (it != bucket.end() && it->first <= 4 * want) {
+      *p = it->second;
+      g_live[*p] = Live{it->first, dev};
+      g_cached_bytes -= it->first;
+      bucket.erase(it);
+      return hipSuccess;
+    }
+  }
+  e = hipMalloc(p, want);
+  if (e != hipSuccess) {  // give cached memory back to the driver and retry once
+    pool_release_cached();
+    e = hipMalloc(p, want);
+    if (e != hipSuccess) return e;
+  }
+  std::lock_guard<std::mutex> lk(g_mutex);
+  g_live[*p] = Live{want, dev};
+  return hipSuccess;
+}
+
+void pool_free(void* p) {
+  if (!p) return;
+  std::unique_lock<std::mutex> lk(g_mutex);
+  auto it = g_live.find(p);
+  if (it == g_live.end()) {  // not ours (should not happen): hand it to the driver
+    lk.unlock();
+    (void)hipFree(p);
+    return;
+  }
+  const Live info = it->second;
+  g_live.erase(it);
+  if (g_cached_bytes + info.bytes > kMaxCachedBytes) {
+    lk.unlock();
+    (void)hipFree(p);
+    return;
+  }
+  g_cached[info.device].emplace(info.bytes, p);
+  g_cached_bytes += info.bytes;
+}
+
+void pool_release_cached() {
+  std::map<int, std::multimap<size_t, void*>> take;
+  {
+    std::lock_guard<std::mutex> lk(g_mutex);
+    take.swap(g_cached);
+    g_cached_bytes = 0;
+  }
+  int cur = 0;
+  (void)hipGetDevice(&cur);
+  for (auto& [dev, bucket] : take) {
+    (void)hipSetDevice(dev);
+    for (auto& [bytes, ptr] : bucket) (void)hipFree(ptr);
+  }
+  (void)hipSetDevice(cur);
+}
+
+}  // namespace mrs_tg
