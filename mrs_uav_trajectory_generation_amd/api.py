@@ -83,6 +83,14 @@ def load_library():
     if not os.path.exists(LIB_PATH):
         raise MrsTgError("HIP extension %s is missing: run `python -m mrs_uav_trajectory_generation_amd.build` "
                          "(there is no CPU fallback)" % LIB_PATH)
+    # PyTorch wheels bundle their own libamdhip64.so.7 / libhsa-runtime64 pair.  The dynamic loader keeps ONE library per
+    # SONAME: if libmrs_tg.so pulled in the system libamdhip64.so.7 first, torch would later run its bundled HSA runtime
+    # under the system HIP runtime and one of the two fails with "no ROCm-capable device".  In a process that uses both,
+    # torch therefore has to be loaded first; a host without torch (the C++ hosts) simply uses the system runtime.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     L = C.CDLL(LIB_PATH)
     vp, dp, ip, bp = C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p  # raw addresses (host or device)
     L.mrs_tg_create.restype = C.c_int
