@@ -9,7 +9,8 @@
 //   src/eth_trajectory_generation/segment.cpp:113-212     magnitude extremum candidates
 //
 // Pipeline per bin of paths (host-orchestrated, one stream):
-//   optimize_kernel      the outer loop; every tick = one objective evaluation = S+1 forward cost sweeps
+//   optimize_split_kernel / optimize_compact_kernel   the outer loop (one dimension / four dimensions per lane);
+//                        every tick = one objective evaluation = S+1 cost sweeps
 //   solve (fused)        coefficients at the last evaluated times             (mrs_tg_kernels / mrs_tg_tile)
 //   segment_maxima9      max |p^(k)| per segment, one (k, group) per blockIdx.y so wavefronts stay uniform
 //   apply_scaling        T <- T * max(1, v, sqrt a, cbrt j)
@@ -215,17 +216,30 @@ struct FastStep {
       for (int j = 0; j < 9; ++j) w[q][j] = seg[(dim0 + q) * 9 + j];
   }
 
-  // start vertex fully constrained: nothing to eliminate; the state moves to the end vertex
-  __device__ __forceinline__ void start(Elim<ND>& st, const double (&hc)[kBlockConsts], const double (&p2)[9]) const {
+  // REV = false: the sweep runs left to right (a segment is entered at its start vertex); REV = true: right to left
+  // (entered at its end vertex): "near" / "far" blocks and brackets swap and the coupling block is transposed.
+  template <bool REV> static __device__ __forceinline__ constexpr int near_blk(int r, int c) { return (REV ? 26 : 0) + tri(r, c); }
+  template <bool REV> static __device__ __forceinline__ constexpr int far_blk(int r, int c) { return (REV ? 0 : 26) + tri(r, c); }
+  template <bool REV> static __device__ __forceinline__ constexpr int cpl_blk(int r, int c) { return 10 + (REV ? c * kNB + r : r * kNB + c); }
+  template <bool REV> static __device__ __forceinline__ constexpr int near_w(int r) { return REV ? kNB + r : r; }
+  template <bool REV> static __device__ __forceinline__ constexpr int far_w(int r) { return REV ? r : kNB + r; }
+
+  // entry vertex fully constrained: nothing to eliminate; the state moves to the far vertex
+  template <bool REV, class HC>
+  __device__ __forceinline__ void start_t(Elim<ND>& st, const HC& hc, const double (&p2)[9]) const {
 #pragma unroll
     for (int r = 0; r < kNB; ++r) {
 #pragma unroll
-      for (int c = 0; c <= r; ++c) st.Sm[tri(r, c)] = hc[26 + tri(r, c)] * p2[r + c + 2];
+      for (int c = 0; c <= r; ++c) st.Sm[tri(r, c)] = hc[far_blk<REV>(r, c)] * p2[r + c + 2];
 #pragma unroll
-      for (int q = 0; q < ND; ++q) st.y[r][q] = -(w[q][kNB + r] * p2[r + 1]);
+      for (int q = 0; q < ND; ++q) st.y[r][q] = -(w[q][far_w<REV>(r)] * p2[r + 1]);
     }
 #pragma unroll
     for (int q = 0; q < ND; ++q) st.qf = fma(p2[0], w[q][8], st.qf);
+  }
+  template <class HC>
+  __device__ __forceinline__ void start(Elim<ND>& st, const HC& hc, const double (&p2)[9]) const {
+    start_t<false>(st, hc, p2);
   }
 
   // Cholesky of st.Sm (all four slots free), z = L^-1 y, red += |z|^2
@@ -259,7 +273,8 @@ struct FastStep {
   }
 
   // end vertex fully constrained: eliminate the start vertex, nothing is passed on
-  __device__ __forceinline__ void end(Elim<ND>& st, const double (&hc)[kBlockConsts], const double (&p2)[9]) const {
+  template <class HC>
+  __device__ __forceinline__ void end(Elim<ND>& st, const HC& hc, const double (&p2)[9]) const {
 #pragma unroll
     for (int r = 0; r < kNB; ++r) {
 #pragma unroll
@@ -274,46 +289,51 @@ struct FastStep {
   }
 
   // both vertices constrain their position only
-  __device__ __forceinline__ void interior(Elim<ND>& st, const double (&hc)[kBlockConsts], const double (&p2)[9]) const {
+  template <bool REV, class HC>
+  __device__ __forceinline__ void interior_t(Elim<ND>& st, const HC& hc, const double (&p2)[9]) const {
 #pragma unroll
     for (int r = 0; r < kNB; ++r) {
 #pragma unroll
-      for (int c = 0; c <= r; ++c) st.Sm[tri(r, c)] = fma(hc[tri(r, c)], p2[r + c + 2], st.Sm[tri(r, c)]);
+      for (int c = 0; c <= r; ++c) st.Sm[tri(r, c)] = fma(hc[near_blk<REV>(r, c)], p2[r + c + 2], st.Sm[tri(r, c)]);
 #pragma unroll
-      for (int q = 0; q < ND; ++q) st.y[r][q] = fma(-w[q][r], p2[r + 1], st.y[r][q]);
+      for (int q = 0; q < ND; ++q) st.y[r][q] = fma(-w[q][near_w<REV>(r)], p2[r + 1], st.y[r][q]);
     }
 #pragma unroll
     for (int q = 0; q < ND; ++q) st.qf = fma(p2[0], w[q][8], st.qf);
     double L[10], Linv[kNB], z[kNB][ND], W[kNB][kNB];
     factor(st, L, Linv, z);
-    // W = L^-1 E, E[r][c] = HBAR[1+r][6+c] T^(r+c+2-2d)
+    // W = L^-1 E, E[r][c] = HBAR[1+r][6+c] T^(r+c+2-2d) (transposed when sweeping right to left)
 #pragma unroll
     for (int c = 0; c < kNB; ++c)
 #pragma unroll
       for (int r = 0; r < kNB; ++r) {
-        double s = hc[10 + r * kNB + c] * p2[r + c + 2];
+        double s = hc[cpl_blk<REV>(r, c)] * p2[r + c + 2];
 #pragma unroll
         for (int m = 0; m < r; ++m) s = fma(-L[tri(r, m)], W[m][c], s);
         W[r][c] = s * Linv[r];
       }
-    // next vertex: Sm = Hee - W^T W ; y = -u_e - W^T z
+    // next vertex: Sm = H_far - W^T W ; y = -u_far - W^T z
 #pragma unroll
     for (int r = 0; r < kNB; ++r) {
 #pragma unroll
       for (int c = 0; c <= r; ++c) {
-        double s = hc[26 + tri(r, c)] * p2[r + c + 2];
+        double s = hc[far_blk<REV>(r, c)] * p2[r + c + 2];
 #pragma unroll
         for (int m = 0; m < kNB; ++m) s = fma(-W[m][r], W[m][c], s);
         st.Sm[tri(r, c)] = s;
       }
 #pragma unroll
       for (int q = 0; q < ND; ++q) {
-        double s = -(w[q][kNB + r] * p2[r + 1]);
+        double s = -(w[q][far_w<REV>(r)] * p2[r + 1]);
 #pragma unroll
         for (int m = 0; m < kNB; ++m) s = fma(-W[m][r], z[m][q], s);
         st.y[r][q] = s;
       }
     }
+  }
+  template <class HC>
+  __device__ __forceinline__ void interior(Elim<ND>& st, const HC& hc, const double (&p2)[9]) const {
+    interior_t<false>(st, hc, p2);
   }
 };
 
@@ -322,10 +342,15 @@ __device__ __forceinline__ double forward_cost(const double* vtx, const double* 
                                                const double* xs, int k, int dim0, double& qf_out) {
   Elim<ND> st;
   st.init();
-  // the 36 block constants stay in registers for the whole sweep (one LDS read per sweep instead of one per step)
-  double hcr[kBlockConsts];
+  // one lane = four dimensions (big batches, throughput regime): the 36 block constants stay in registers for the whole
+  // sweep.  One lane = one dimension (small batches): they are read from LDS in every step, which keeps the kernel
+  // under 256 VGPRs so that the two wavefronts of a path share a SIMD.
+  constexpr int kRegConsts = (ND == 4) ? kBlockConsts : 1;
+  double hcr[kRegConsts];
+  if (ND == 4) {
 #pragma unroll
-  for (int e = 0; e < kBlockConsts; ++e) hcr[e] = hc[e];
+    for (int e = 0; e < kRegConsts; ++e) hcr[e] = hc[e];
+  }
   const double corr = kGradStep / ((double)S - 1.0);
   int last_kind = kSegGeneral;
   for (int i = 0; i < S; ++i) {
@@ -346,9 +371,15 @@ __device__ __forceinline__ double forward_cost(const double* vtx, const double* 
       segment_powers(T, d, p2);
       FastStep<ND> fast;
       fast.load(sr, dim0);
-      if (kind == kSegInterior) fast.interior(st, hcr, p2);
-      else if (kind == kSegStart) fast.start(st, hcr, p2);
-      else fast.end(st, hcr, p2);
+      if (ND == 4) {
+        if (kind == kSegInterior) fast.interior(st, hcr, p2);
+        else if (kind == kSegStart) fast.start(st, hcr, p2);
+        else fast.end(st, hcr, p2);
+      } else {
+        if (kind == kSegInterior) fast.interior(st, hc, p2);
+        else if (kind == kSegStart) fast.start(st, hc, p2);
+        else fast.end(st, hc, p2);
+      }
     }
   }
   if (last_kind != kSegEnd) {  // after an end-type segment the state stands on a fully constrained vertex: nothing left
@@ -359,6 +390,33 @@ __device__ __forceinline__ double forward_cost(const double* vtx, const double* 
   }
   qf_out = st.qf;
   return 0.5 * (st.qf - st.red);
+}
+
+// ---- two-sided evaluation for small batches ------------------------------------------------------------------
+// With one path per wavefront (DS = 4, 4 (S+1) <= 64 lanes) the machine holds one wavefront per SIMD and a tick is
+// a chain of S dependent segment steps.  A second wavefront per path runs the same elimination from the other end
+// (twisted factorisation: the two half sweeps meet at the middle vertex, whose block receives a Schur update from each
+// side); the chain per tick is S/2 steps + one join, and the two wavefronts of a path hide each other's latencies.
+// Only for "plain" paths (start, interior..., end segment kinds); anything else keeps the one-sided sweep.
+constexpr int kPairState = 16;  // Sm[10], y[4], qf, red handed from the backward to the forward wavefront, per lane
+
+template <bool REV>
+__device__ __forceinline__ void half_sweep(const double* seg, const double* hc, int S, int m, int d, const double* xs, int k,
+                                           int dim0, Elim<1>& st) {
+  st.init();
+  // the block constants are read from LDS in every step here: the two wavefronts of a path must fit one SIMD
+  // together (<= 256 VGPRs each), which the register-resident copy of the one-sided sweep would not allow
+  const double corr = kGradStep / ((double)S - 1.0);
+  const int n = REV ? S - m : m;
+  for (int s = 0; s < n; ++s) {
+    const int i = REV ? S - 1 - s : s;
+    double p2[9];
+    segment_powers(perturbed_time(xs, i, k, corr), d, p2);
+    FastStep<1> fast;
+    fast.load(seg + (size_t)i * kSegLds, dim0);
+    if (s == 0) fast.template start_t<REV>(st, hc, p2);
+    else fast.template interior_t<REV>(st, hc, p2);
+  }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -615,6 +673,41 @@ __device__ __forceinline__ double evaluate_objective(const double* vtx, const do
   return J0;
 }
 
+// Two-sided objective evaluation (forward wavefront's side): forward half sweep, barrier, join with the backward
+// half that the partner wavefront left in LDS, then the same reductions as evaluate_objective<4>.
+__device__ __forceinline__ double evaluate_pair(const double* seg, const double* hc, const double* pair_state, int S, int d,
+                                                const double* pt, double* grad, int g, bool active) {
+  const int k = g >> 2, dim0 = g & 3, m = S / 2;
+  const bool work = active && k <= S;
+  Elim<1> st;
+  st.init();
+  if (work) half_sweep<false>(seg, hc, S, m, d, pt, k, dim0, st);
+  __syncthreads();  // the partner's half sweeps are in LDS
+  double Jk = 0.0, qfk = 0.0;
+  if (work) {
+    const double* ps = pair_state + (size_t)g * kPairState;
+#pragma unroll
+    for (int e = 0; e < 10; ++e) st.Sm[e] += ps[e];
+#pragma unroll
+    for (int r = 0; r < kNB; ++r) st.y[r][0] += ps[10 + r];
+    st.qf += ps[14];
+    st.red += ps[15];
+    FastStep<1> fs;
+    double L[10], Linv[kNB], z[kNB][1];
+    fs.factor(st, L, Linv, z);
+    Jk = 0.5 * (st.qf - st.red);
+    qfk = st.qf;
+  }
+  Jk += dpp_move<0xB1>(Jk);
+  Jk += dpp_move<0x4E>(Jk);
+  qfk += dpp_move<0xB1>(qfk);
+  qfk += dpp_move<0x4E>(qfk);
+  Jk = guarded_cost(Jk, qfk);
+  const double J0 = row_value(Jk, 0);
+  if (work && dim0 == 0 && k >= 1) grad[k - 1] = (Jk - J0) / kGradStep;
+  return J0;
+}
+
 // ---------------------------------------------------------------------------------------------
 // the outer-loop kernel: optimiser ticks (one objective evaluation each).  On exit seg_times holds the
 // last evaluated point and opt_status the stopping reason (-2: start rejected, as NLopt would).
@@ -627,10 +720,9 @@ struct BinTable {
 };
 
 template <int DS>
-__global__ __launch_bounds__(64) void optimize_kernel(BatchView b, NonlinearParams prm, BinTable bins,
-                                                      const uint8_t* __restrict__ mask,
-                                                      const double* __restrict__ vals, double* __restrict__ seg_times,
-                                                      int32_t* __restrict__ opt_status) {
+__device__ __forceinline__ void optimize_body(const BatchView& b, const NonlinearParams& prm, const BinTable& bins,
+                                              const uint8_t* __restrict__ mask, const double* __restrict__ vals,
+                                              double* __restrict__ seg_times, int32_t* __restrict__ opt_status) {
   extern __shared__ double lds[];
   MRS_TG_PHASE_MARK(0);
   int bin = 0;
@@ -639,7 +731,11 @@ __global__ __launch_bounds__(64) void optimize_kernel(BatchView b, NonlinearPara
     if (i < bins.n && (int)blockIdx.x >= bins.block_begin[i]) bin = i;
   const int G = bins.group[bin], q_begin = bins.q_begin[bin], q_count = bins.q_count[bin], Sb = bins.max_S[bin];
   const int block_in_bin = (int)blockIdx.x - bins.block_begin[bin];
-  const int lane = threadIdx.x;
+  // 64 threads: the wavefront that runs everything.  128 threads (DS = 4, one path per block): wavefront 1 is the
+  // partner that runs the backward half sweeps of the two-sided evaluation and mirrors every barrier of wavefront 0.
+  const bool two_wave = (DS == 4) && blockDim.x == 128;  // compile-time false for DS = 1: none of the partner code is emitted there
+  const int wave = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63;
   const int g = lane & (G - 1);
   const int grp = lane / G;
   const int per_block = 64 / G;
@@ -650,8 +746,10 @@ __global__ __launch_bounds__(64) void optimize_kernel(BatchView b, NonlinearPara
   const int S = pr.S, d = prm.derivative;
 
   double* hc = lds;  // [kBlockConsts], shared by the groups of the block
-  stage_block_constants(d, hc, lane, 64);
+  if (wave == 0) stage_block_constants(d, hc, lane, 64);
   double* base = lds + kBlockConsts + (size_t)grp * group_lds_doubles(Sb);
+  double* pair_state = lds + kBlockConsts + (size_t)per_block * group_lds_doubles(Sb);  // [64 * kPairState] (two_wave only)
+  int* pair_flags = reinterpret_cast<int*>(pair_state + 64 * kPairState);              // [0] all done, [1] two-sided evaluation
   double* x = base;
   double* gr = x + Sb;
   double* xn = gr + Sb;
@@ -662,26 +760,59 @@ __global__ __launch_bounds__(64) void optimize_kernel(BatchView b, NonlinearPara
   double* rho = ym + kLbfgsM * Sb;  // [M]
   double* vtx = rho + kLbfgsM;      // [(Sb + 1) * kVtxLds]
   double* seg = vtx + (size_t)(Sb + 1) * kVtxLds;  // [Sb * kSegLds]
-  if (active) stage_vertices(mask, vals, pr.v0, S, vtx, g, G);
+  if (active && wave == 0) stage_vertices(mask, vals, pr.v0, S, vtx, g, G);
   __syncthreads();
-  if (active) stage_segments(vtx, S, d, seg, g, G);
+  if (active && wave == 0) stage_segments(vtx, S, d, seg, g, G);
 
   // ---- start point; NLopt rejects a start below the lower bound (-> INVALID_ARGS)
   int ok = 1;
-  if (active)
+  if (active && wave == 0)
     for (int i = g; i < S; i += G) {
       const double t = seg_times[pr.s0 + i];
       x[i] = t;
       xn[i] = t;
       if (t < kTimeLowerBound) ok = 0;
     }
-  const bool bad = active && !group_and(ok, G);
+  const bool bad = active && wave == 0 && !group_and(ok, G);
   __syncthreads();
   MRS_TG_PHASE_MARK(1);
 
   const int maxeval = prm.max_iterations;
   int ret = -1;
   bool done = !active || bad;
+  bool pair_ok = false;
+  if (two_wave) {
+    if (threadIdx.x == 0) {
+      bool plain = DS == 4 && G == 64 && active && S >= 4 && (int)seg[36] == kSegStart && (int)seg[(size_t)(S - 1) * kSegLds + 36] == kSegEnd;
+      for (int i = 1; plain && i < S - 1; ++i) plain = (int)seg[(size_t)i * kSegLds + 36] == kSegInterior;
+      pair_flags[0] = done ? 1 : 0;
+      pair_flags[1] = plain ? 1 : 0;
+    }
+    __syncthreads();
+    pair_ok = pair_flags[1] != 0;
+    if (wave == 1) {
+      // partner wavefront: backward half sweep of every tick, then the tick's other barriers
+      const int k = lane >> 2, dim0 = lane & 3;
+      while (pair_flags[0] == 0) {
+        if (pair_ok && k <= S) {
+          Elim<1> st;
+          half_sweep<true>(seg, hc, S, S / 2, d, xn, k, dim0, st);
+          double* ps = pair_state + (size_t)lane * kPairState;
+#pragma unroll
+          for (int e = 0; e < 10; ++e) ps[e] = st.Sm[e];
+#pragma unroll
+          for (int r = 0; r < kNB; ++r) ps[10 + r] = st.y[r][0];
+          ps[14] = st.qf;
+          ps[15] = st.red;
+        }
+        __syncthreads();  // hand-over
+        __syncthreads();  // after the evaluation
+        __syncthreads();  // after accept / reject
+        __syncthreads();  // after the next trial point (and the all-done flag)
+      }
+      return;
+    }
+  }
   int neval = 0, npairs = 0, head = 0;
   double f = 0.0, alpha = 1.0;
   bool first = true;
@@ -690,7 +821,13 @@ __global__ __launch_bounds__(64) void optimize_kernel(BatchView b, NonlinearPara
     if (__ballot(!done) == 0ull) break;
 
     // (1) one objective evaluation at the trial point
-    const double fn = evaluate_objective<DS>(vtx, seg, hc, S, d, xn, gn, g, G, !done);
+    double fn;
+    if (pair_ok) {
+      fn = evaluate_pair(seg, hc, pair_state, S, d, xn, gn, g, !done);
+    } else {
+      fn = evaluate_objective<DS>(vtx, seg, hc, S, d, xn, gn, g, G, !done);
+      if (two_wave) __syncthreads();  // the partner's hand-over barrier
+    }
     __syncthreads();
 #ifdef MRS_TG_PHASE_CLOCKS
     if (neval < 12) MRS_TG_PHASE_MARK(6 + 2 * neval);  // after evaluation #neval
@@ -846,6 +983,10 @@ __global__ __launch_bounds__(64) void optimize_kernel(BatchView b, NonlinearPara
     // (3) next trial point
     if (!done)
       for (int i = g; i < S; i += G) xn[i] = fmax(x[i] + alpha * dir[i], kTimeLowerBound);
+    if (two_wave) {
+      const bool all_done = __ballot(!done) == 0ull;
+      if (lane == 0) pair_flags[0] = all_done ? 1 : 0;
+    }
     __syncthreads();
 #ifdef MRS_TG_PHASE_CLOCKS
     if (neval >= 1 && neval < 13) MRS_TG_PHASE_MARK(5 + 2 * neval);  // end of the tick that made evaluation #neval-1
@@ -857,6 +998,23 @@ __global__ __launch_bounds__(64) void optimize_kernel(BatchView b, NonlinearPara
     for (int i = g; i < S; i += G) seg_times[pr.s0 + i] = x[i];
     if (g == 0) opt_status[pr.p] = bad ? -2 : ret;
   }
+}
+
+// One dimension per lane (small batches): up to two wavefronts per path, and at most 256 VGPRs so that both sit on one
+// SIMD.  Four dimensions per lane (large batches): one wavefront per 64 / G paths, registers as needed.
+__global__ __launch_bounds__(128, 2) void optimize_split_kernel(BatchView b, NonlinearParams prm, BinTable bins,
+                                                                const uint8_t* __restrict__ mask,
+                                                                const double* __restrict__ vals,
+                                                                double* __restrict__ seg_times,
+                                                                int32_t* __restrict__ opt_status) {
+  optimize_body<4>(b, prm, bins, mask, vals, seg_times, opt_status);
+}
+
+__global__ __launch_bounds__(64) void optimize_compact_kernel(BatchView b, NonlinearParams prm, BinTable bins,
+                                                              const uint8_t* __restrict__ mask,
+                                                              const double* __restrict__ vals, double* __restrict__ seg_times,
+                                                              int32_t* __restrict__ opt_status) {
+  optimize_body<1>(b, prm, bins, mask, vals, seg_times, opt_status);
 }
 
 // per-segment maxima, one (k, group) per blockIdx.y: maxima[seg * 9 + 3 (k-1) + group]
@@ -1395,6 +1553,7 @@ hipError_t launch_nonlinear(NonlinearPlan& nl, const BatchView& b, const Nonline
     if (bt.n > 5) return hipErrorInvalidValue;
     size_t lds_bytes = 0;
     int blocks = 0;
+    bool all_single = true;
     for (int i = 0; i < bt.n; ++i) {
       const NonlinearBin& bin = nl.bins[i];
       const int per_block = 64 / bin.group;
@@ -1406,18 +1565,22 @@ hipError_t launch_nonlinear(NonlinearPlan& nl, const BatchView& b, const Nonline
       blocks += (int)cdiv_u(bin.q_count, per_block);
       const size_t need = ((size_t)per_block * group_lds_doubles(bin.max_S) + kBlockConsts) * sizeof(double);
       if (need > lds_bytes) lds_bytes = need;
+      if (bin.group != 64) all_single = false;
     }
+    // one path per block and one dimension per lane: a partner wavefront runs the other half of every sweep
+    const unsigned threads = (nl.dim_split == 4 && all_single) ? 128u : 64u;
+    if (threads == 128u) lds_bytes += (64 * kPairState + 2) * sizeof(double);  // hand-over area + flags
     if (lds_bytes > 160 * 1024) return hipErrorInvalidValue;
     if (lds_bytes > 64 * 1024) {
-      e = nl.dim_split == 4 ? hipFuncSetAttribute((const void*)optimize_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes)
-                            : hipFuncSetAttribute((const void*)optimize_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+      e = nl.dim_split == 4 ? hipFuncSetAttribute((const void*)optimize_split_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes)
+                            : hipFuncSetAttribute((const void*)optimize_compact_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
       if (e != hipSuccess) return e;
     }
     if (nl.dim_split == 4)
-      hipLaunchKernelGGL(optimize_kernel<4>, dim3(blocks), dim3(64), lds_bytes, stream, b, prm, bt, mask, vals, seg_times,
+      hipLaunchKernelGGL(optimize_split_kernel, dim3(blocks), dim3(threads), lds_bytes, stream, b, prm, bt, mask, vals, seg_times,
                          nl.d_opt_status);
     else
-      hipLaunchKernelGGL(optimize_kernel<1>, dim3(blocks), dim3(64), lds_bytes, stream, b, prm, bt, mask, vals, seg_times,
+      hipLaunchKernelGGL(optimize_compact_kernel, dim3(blocks), dim3(64), lds_bytes, stream, b, prm, bt, mask, vals, seg_times,
                          nl.d_opt_status);
     if ((e = hipGetLastError()) != hipSuccess) return e;
   }
