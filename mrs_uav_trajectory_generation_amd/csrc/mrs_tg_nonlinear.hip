@@ -783,7 +783,8 @@ __device__ __forceinline__ void optimize_body(const BatchView& b, const Nonlinea
   bool pair_ok = false;
   if (two_wave) {
     if (threadIdx.x == 0) {
-      bool plain = DS == 4 && G == 64 && active && S >= 4 && (int)seg[36] == kSegStart && (int)seg[(size_t)(S - 1) * kSegLds + 36] == kSegEnd;
+      // every perturbation needs its own quad of lanes in one round: 4 (S + 1) <= 64
+      bool plain = DS == 4 && G == 64 && active && S >= 4 && 4 * (S + 1) <= 64 && (int)seg[36] == kSegStart && (int)seg[(size_t)(S - 1) * kSegLds + 36] == kSegEnd;
       for (int i = 1; plain && i < S - 1; ++i) plain = (int)seg[(size_t)i * kSegLds + 36] == kSegInterior;
       pair_flags[0] = done ? 1 : 0;
       pair_flags[1] = plain ? 1 : 0;

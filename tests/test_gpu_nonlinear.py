@@ -92,7 +92,8 @@ def _check_invariants(batch, out, limits_tol=1.05):
     assert np.all(np.isin(out["status"], (1, 3, 4, 5)))
 
 
-@pytest.mark.parametrize("n_seg,n_paths", [(10, 256), (3, 64), ("ragged", 96)])
+# (20, 24) and (15, 32): one path per wavefront with / without enough lanes for the two-sided evaluation in one round
+@pytest.mark.parametrize("n_seg,n_paths", [(10, 256), (3, 64), ("ragged", 96), (20, 24), (15, 32), (4, 16)])
 def test_nonlinear_end_to_end_vs_oracle(gpu_ctx, n_seg, n_paths):
     batch = pr.random_batch(n_paths, n_seg, seed0=4242)
     cap = 1024
