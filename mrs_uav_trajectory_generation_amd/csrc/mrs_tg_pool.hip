@@ -1,6 +1,7 @@
 // mrs_tg_pool.hip -- caching device allocator (see mrs_tg_pool.h)
 #include "mrs_tg_pool.h"
 
+#include <cstdlib>
 #include <map>
 #include <mutex>
 #include <unordered_map>
@@ -33,6 +34,16 @@ size_t round_size(size_t bytes) {
 
 }  // namespace
 
+// MRS_TG_POOL_POISON=1 fills every block handed out with 0xFF bytes (NaN as a double, -1 as an int): a test-suite run
+// under it shows any read of memory that this library did not write first.
+static hipError_t poison(void* p, size_t bytes) {
+  static const bool on = std::getenv("MRS_TG_POOL_POISON") != nullptr;
+  if (!on) return hipSuccess;
+  hipError_t e = hipMemset(p, 0xFF, bytes);
+  if (e == hipSuccess) e = hipDeviceSynchronize();
+  return e;
+}
+
 hipError_t pool_alloc_bytes(void** p, size_t bytes) {
   *p = nullptr;
   int dev = 0;
@@ -47,8 +58,9 @@ hipError_t pool_alloc_bytes(void** p, size_t bytes) {
       *p = it->second;
       g_live[*p] = Live{it->first, dev};
       g_cached_bytes -= it->first;
+      const size_t got = it->first;
       bucket.erase(it);
-      return hipSuccess;
+      return poison(*p, got);
     }
   }
   e = hipMalloc(p, want);
@@ -57,9 +69,11 @@ hipError_t pool_alloc_bytes(void** p, size_t bytes) {
     e = hipMalloc(p, want);
     if (e != hipSuccess) return e;
   }
-  std::lock_guard<std::mutex> lk(g_mutex);
-  g_live[*p] = Live{want, dev};
-  return hipSuccess;
+  {
+    std::lock_guard<std::mutex> lk(g_mutex);
+    g_live[*p] = Live{want, dev};
+  }
+  return poison(*p, want);
 }
 
 void pool_free(void* p) {
