@@ -32,6 +32,7 @@
 #include <cfloat>
 #include <cmath>
 #include <cstdint>
+#include <cstdlib>
 
 #include "mrs_tg_device.hpp"
 #include "mrs_tg_pool.h"
@@ -1471,7 +1472,10 @@ __global__ __launch_bounds__(64) void dfo_segment_path_kernel(BatchView b, int32
 // host side
 
 // split the four dimensions over lanes while the batch is too small to fill the machine otherwise
-static int dim_split_for(int n_paths) { return n_paths <= 4096 ? 4 : 1; }
+static int dim_split_for(int n_paths) {
+  if (const char* e = std::getenv("MRS_TG_DIM_SPLIT_MAX_PATHS")) return n_paths <= std::atoi(e) ? 4 : 1;  // tuning knob
+  return n_paths <= 3072 ? 4 : 1;  // measured cross-over (scripts/sweep_dim_split.sh): 3072 paths 319 vs 354 us, 4096 paths 382 vs 361 us
+}
 
 static int group_for(int S, int ds) {
   int G = 4;
