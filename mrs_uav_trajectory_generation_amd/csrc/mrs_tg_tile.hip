@@ -21,6 +21,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdint>
+#include <cstdlib>
 #include <type_traits>
 
 #include "mrs_tg_device.hpp"
@@ -469,9 +470,9 @@ __global__ __launch_bounds__(kTileThreads) void solve_tile_kernel(BatchView b, i
 static constexpr size_t kTileLdsBudget = 144 * 1024;
 
 bool tile_kernel_applies(const BatchView& b) {
-  // measured on MI355X (10 segments): 47 vs 60 us at 1024 paths, but 154 vs 86 us at 8192 paths, where the
-  // per-lane kernel already fills the machine and the tile kernel's serial phase leaves most lanes idle
-  if (b.n_paths == 0 || b.n_paths > 2048) return false;
+  int max_paths = 6144;  // measured (scripts/sweep_tile.sh, 10 segments): 4096 paths 51 vs 63 us, 6144 paths 73.6 vs 73.5 us, 8192 paths 96 vs 83 us
+  if (const char* e = std::getenv("MRS_TG_TILE_MAX_PATHS")) max_paths = std::atoi(e);  // tuning knob (scripts/sweep_tile.sh)
+  if (b.n_paths == 0 || b.n_paths > max_paths) return false;
   return (size_t)tile_path_doubles(b.max_segments) * sizeof(double) + kSegRec * sizeof(double) <= kTileLdsBudget;
 }
 

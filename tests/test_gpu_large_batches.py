@@ -1,6 +1,6 @@
 """Kernel variants that only engage on larger batches (the library picks the lane mapping from the batch
-size): one-lane-per-dimension solve (2048 < P <= 32768), one-lane-per-path solve (P > 32768), compact
-outer-loop mapping (P > 4096).  Parity is checked against the oracle on a strided subset (the oracle needs
+size): one-lane-per-dimension solve (6144 < P <= 32768), one-lane-per-path solve (P > 32768), compact
+outer-loop mapping (P > 3072).  Parity is checked against the oracle on a strided subset (the oracle needs
 ~30 us per linear path and ~2 ms per nonlinear path), and on every path through size-independent
 properties: continuity, constraints, linearity, agreement between the materialised-block and the fused
 pipelines, and agreement with the same paths solved in a small batch (different kernels, same answer)."""
@@ -22,7 +22,7 @@ def _subset_vs_oracle(batch, out, idx, tol):
     assert util.coeff_error(got, ref["coeffs"], sub.seg_offsets) < tol
 
 
-@pytest.mark.parametrize("n_paths", [2304, 33024])
+@pytest.mark.parametrize("n_paths", [2304, 6400, 33024])
 def test_linear_large_batches(gpu_ctx, n_paths):
     batch = pr.random_batch(n_paths, 10, seed0=7000)
     out = gpu_ctx.solve_batch(batch, None)
@@ -49,10 +49,14 @@ def test_linear_large_batches(gpu_ctx, n_paths):
 
 
 def test_linear_ragged_large_batch(gpu_ctx):
-    batch = pr.random_batch(4500, "ragged", seed0=8000)     # BASELINE config 5 shape, per-lane kernels
+    batch = pr.random_batch(7000, "ragged", seed0=8000)     # BASELINE config 5 shape, per-lane kernels
     out = gpu_ctx.solve_batch(batch, None)
     assert np.all(out["status"] == 1)
-    _subset_vs_oracle(batch, out, list(range(0, 4500, 41)), 1e-7)
+    _subset_vs_oracle(batch, out, list(range(0, 7000, 61)), 1e-7)
+    small = pr.random_batch(4500, "ragged", seed0=8000)     # same shape through the tile kernel
+    outs = gpu_ctx.solve_batch(small, None)
+    assert np.all(outs["status"] == 1)
+    _subset_vs_oracle(small, outs, list(range(0, 4500, 41)), 1e-7)
 
 
 def test_long_paths_fall_back_to_per_lane_kernel(gpu_ctx):
@@ -75,7 +79,7 @@ def test_longest_accepted_path_and_one_beyond(gpu_ctx):
 
 
 def test_nonlinear_compact_mapping_matches_split_mapping(gpu_ctx):
-    # P > 4096 switches the outer loop to one lane per time vector; the same paths in a small batch use four
+    # P > 3072 switches the outer loop to one lane per time vector; the same paths in a small batch use four
     batch = pr.random_batch(4200, 10, seed0=9000)
     out = gpu_ctx.solve_batch(batch, None, time_alloc_method=api.TIME_ALLOC_MELLINGER, sampling_dt=0.2, sample_capacity=64)
     assert np.all(np.isin(out["status"], (1, 3, 4, 5)))
