@@ -1,3 +1,5 @@
+"""Trace one benchmark path (seed = argv[1]) through the outer loop: the oracle's trial point after every evaluation
+budget next to the GPU pipeline's result, and J / gradient of both at those points (how the 65536-path runaway was found)."""
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
