@@ -63,3 +63,22 @@ def test_batch_members_keep_their_own_request_fields(host_output):
     assert host_output["override"]["max_deviation"] <= 0.2 + 1e-9 or host_output["override"]["success"]
     v = np.linalg.norm(np.diff(np.array(host_output["override"]["points"])[:, :2], axis=0), axis=1) / 0.2
     assert 2.2 < v.max() < 4.0 * 1.05
+
+
+def test_plain_c99_host(tmp_path):
+    """examples/solve_batch_host.c: the header is C (not C++), the library needs nothing but itself at link time"""
+    exe = str(tmp_path / "solve_batch_host")
+    libdir = os.path.join(ROOT, "mrs_uav_trajectory_generation_amd")
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-I", os.path.join(ROOT, "include"),
+                           os.path.join(ROOT, "examples", "solve_batch_host.c"), "-o", exe, "-L", libdir, "-lmrs_tg",
+                           "-Wl,-rpath," + libdir])
+    r = json.loads(subprocess.run([exe], check=True, capture_output=True, text=True, timeout=300).stdout)
+    assert r["abi"] == 1 and len(r["paths"]) == 2
+    for p, first, last in zip(r["paths"], ([-5, -5, 5], [0, 0, 2]), ([5, 5, 5], [20, 0, 2])):
+        assert p["status"] in (1, 3, 4, 5) and p["n_samples"] > 10 and p["cost"] > 0
+        assert np.allclose(p["first"], first, atol=1e-9)
+        assert np.linalg.norm(np.array(p["last"]) - last) < 0.5       # the last sample precedes the end by < dt
+        assert all(t >= 0.01 for t in p["times"])
+    # the straight line: symmetric segment times
+    t = r["paths"][1]["times"]
+    assert abs(t[0] - t[1]) < 1e-6 * t[0]
