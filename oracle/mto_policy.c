@@ -288,6 +288,7 @@ int mto_optimize_path(const double* wps_in, const uint8_t* stop_in, int n_in, co
   int n_wp = mto_preprocess_path(wps_in, stop_in, n_in, prm, wps, stop);
   if (n_waypoints_out) *n_waypoints_out = n_wp;
   int ok = 0, ns = 0;
+  double max_dev = 0;
   if (n_wp <= 1) goto done; /* "the path is empty (after postprocessing)" */
   if (prm->fallback_sampling) {
     ns = mto_fallback_sampling(wps, stop, n_wp, limits9, relax_heading, prm, sopt->sampling_dt, samples_out, capacity);
@@ -296,7 +297,6 @@ int mto_optimize_path(const double* wps_in, const uint8_t* stop_in, int n_in, co
     ok = find_trajectory(wps, stop, n_wp, initial_state, limits9, relax_heading, sopt, prm, samples_out, capacity, &ns);
   }
   if (!ok) goto done;
-  double max_dev = 0;
   for (int k = 0; k < prm->max_deviation_iterations; ++k) {
     const int is_safe = mto_validate_trajectory_spatial(samples_out, ns, wps, n_wp, prm, safe, &max_dev);
     if (prm->check_deviation_enabled && !is_safe) {
@@ -328,8 +328,6 @@ int mto_optimize_path(const double* wps_in, const uint8_t* stop_in, int n_in, co
       break;
     }
   }
-  if (max_deviation_out) *max_deviation_out = max_dev;
-  if (n_waypoints_out) *n_waypoints_out = n_wp;
   if (prm->override_heading_atan2) { /* getTrajectoryReference :1582-1597 */
     for (int it = 0; it < ns; ++it) {
       double* p = samples_out + (size_t)it * 4;
@@ -342,6 +340,9 @@ int mto_optimize_path(const double* wps_in, const uint8_t* stop_in, int n_in, co
     }
   }
 done:
+  /* bookkeeping of the state the loop ended in, for a failed request as well (the product reports the same) */
+  if (max_deviation_out) *max_deviation_out = max_dev;
+  if (n_waypoints_out) *n_waypoints_out = n_wp;
   *n_samples_out = ok ? ns : 0;
   free(wps);
   free(stop);
