@@ -220,3 +220,17 @@ def test_trial_point_on_the_lower_bound_is_rejected_not_run_away_with(gpu_ctx):
     J, _ = gpu_cost_gradient(gpu_ctx, batch, t3)
     Jo, _ = po.cost_and_gradient(4, m, v, t3)
     assert Jo > 1e4 and J[0] >= 1e299
+
+
+@pytest.mark.parametrize("dt,cap", [(0.01, 16384), (0.05, 4096), (0.5, 256), (1.0, 128), (0.3, 512)])
+def test_sampling_other_sampling_periods(gpu_ctx, dt, cap):
+    """the walk is defined by repeated addition of dt: every period has its own rounding pattern at the segment
+    boundaries (dt = 0.2 is the shipping value; futurised paths and user parameters give others)"""
+    batch = pr.random_batch(48, "ragged", seed0=77)
+    out = gpu_ctx.solve_batch(batch, None, sampling_dt=dt, sample_capacity=cap)
+    for p in range(batch.n_paths):
+        a, b = batch.seg_offsets[p], batch.seg_offsets[p + 1]
+        s, n = po.sample_trajectory(out["coeffs"][a:b], out["times"][a:b], dt, 0, cap)
+        assert min(n, cap + 1) == out["n_samples"][p], (p, n, out["n_samples"][p])
+        n = min(n, cap)
+        assert np.max(np.abs(out["samples"][p, :n, :3] - s[:n, :3])) < 1e-10
