@@ -174,3 +174,72 @@ def test_batch_driver_threads_agree():
                        sample_capacity=64, n_threads=4)
     for k in ("times", "coeffs", "status", "cost", "n_samples", "samples"):
         assert np.array_equal(a[k], b[k]), k
+
+
+def _textbook_min_derivative_qp(waypoints, mask, vals, times, deriv):
+    """Independent route to the same minimiser: the equality-constrained QP in COEFFICIENT space,
+        min  sum_seg 1/2 c^T Q_seg c   s.t.  p^(k)(vertex) = value for every constrained (vertex, k),
+                                            p_i^(k)(T_i) = p_{i+1}^(k)(0), k = 0..4, at every interior vertex,
+    solved by the null-space method with numpy / scipy (no mapping matrices, no reordering, no block elimination)."""
+    from math import factorial
+    from scipy.linalg import null_space
+    S, n = len(times), 10
+    def row(t, k):   # d^k/dt^k of [1, t, ..., t^9]
+        r = np.zeros(n)
+        for j in range(k, n):
+            r[j] = factorial(j) / factorial(j - k) * t ** (j - k)
+        return r
+    Q = np.zeros((S * n, S * n))
+    for s, T in enumerate(times):
+        for i in range(deriv, n):
+            for j in range(deriv, n):
+                e = i + j - 2 * deriv + 1
+                Q[s * n + i, s * n + j] = factorial(i) / factorial(i - deriv) * factorial(j) / factorial(j - deriv) * T ** e / e
+    sol = np.zeros((S, 4, n))
+    for dim in range(4):
+        rows, rhs = [], []
+        for v in range(S + 1):
+            for k in range(5):
+                seg, t = (v, 0.0) if v < S else (S - 1, times[S - 1])
+                if mask[v, k]:
+                    r = np.zeros(S * n)
+                    r[seg * n:(seg + 1) * n] = row(t, k)
+                    rows.append(r)
+                    rhs.append(vals[v, k, dim])
+                if 0 < v < S:   # continuity between segment v-1 (end) and segment v (start)
+                    r = np.zeros(S * n)
+                    r[(v - 1) * n:v * n] = row(times[v - 1], k)
+                    r[v * n:(v + 1) * n] = -row(0.0, k)
+                    rows.append(r)
+                    rhs.append(0.0)
+        # null-space method (constraints met to rounding, then an SPD reduced system): c = c_p + N z
+        E = np.array(rows)
+        r = np.array(rhs)
+        c_p = np.linalg.lstsq(E, r, rcond=None)[0]
+        N = null_space(E)
+        z = np.linalg.solve(N.T @ Q @ N, -N.T @ (Q @ c_p))
+        x = c_p + N @ z
+        sol[:, dim, :] = x[:S * n].reshape(S, n)
+    return sol
+
+
+@pytest.mark.parametrize("n_seg,deriv,seed", [(3, 4, 1), (4, 4, 2), (3, 2, 3), (5, 3, 4), (2, 4, 5)])
+def test_linear_solution_equals_the_textbook_kkt_solution(n_seg, deriv, seed):
+    """the reference's route (end-point derivative variables, A^-1, reordering, reduced system) and the textbook
+    coefficient-space QP describe the same minimiser; this pins the oracle's algebra to the problem statement
+    (Richter et al., ISRR 2013) rather than to its own formulas"""
+    rng = np.random.default_rng(seed)
+    wp = pr.random_box_waypoints(n_seg, 600 + seed)
+    stop = np.zeros(n_seg + 1, dtype=bool)
+    if n_seg >= 4:
+        stop[2] = True
+    _, m, v = pr.build_vertices(wp, deriv, stop_at=stop)
+    t = rng.uniform(0.8, 2.5, n_seg)
+    c = po.solve_linear(deriv, m, v, t)
+    ref = _textbook_min_derivative_qp(wp, m.reshape(-1, 5), v.reshape(-1, 5, 4), t, deriv)
+    # minimum acceleration with ten coefficients is nearly degenerate (smallest eigenvalue of R_pp ~ 6e-6, SURVEY.md A.4): the
+    # two routes agree on the cost to 1e-9 but on the coefficients only to cond * eps
+    assert util.coeff_error(c, ref) < (1e-5 if deriv == 2 else 1e-9)
+    J = po.compute_cost(deriv, t, c)
+    Jref = po.compute_cost(deriv, t, ref)
+    assert abs(J - Jref) <= 1e-8 * abs(Jref)
