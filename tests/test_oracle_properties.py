@@ -238,8 +238,8 @@ def test_linear_solution_equals_the_textbook_kkt_solution(n_seg, deriv, seed):
     c = po.solve_linear(deriv, m, v, t)
     ref = _textbook_min_derivative_qp(wp, m.reshape(-1, 5), v.reshape(-1, 5, 4), t, deriv)
     # minimum acceleration with ten coefficients is nearly degenerate (smallest eigenvalue of R_pp ~ 6e-6): the
-    # two routes agree on the cost to 1e-9 but on the coefficients only to cond * eps
-    assert util.coeff_error(c, ref) < (1e-5 if deriv == 2 else 1e-9)
+    # two routes agree on the cost to 1e-9 but on the coefficients only to cond * eps (minimum jerk sits in between)
+    assert util.coeff_error(c, ref) < {2: 1e-5, 3: 1e-7, 4: 1e-9}[deriv]
     J = po.compute_cost(deriv, t, c)
     Jref = po.compute_cost(deriv, t, ref)
     assert abs(J - Jref) <= 1e-8 * abs(Jref)
