@@ -93,15 +93,20 @@ __device__ __forceinline__ unsigned staged_vertex(const double* vtx, int v, int 
 // true cost is ~1e4: all 16 digits cancel and the difference is noise of either sign -- and a negative "cost" passes the
 // Armijo test, after which the optimiser runs away (seen on 1 of 65536 random paths: times of 1e17 s).  The reference
 // evaluates 0.5 c^T Q c from the coefficients there (computeCost, linear_impl.h:128-141), a large positive number, and
-// its line search backtracks.  A difference that has lost more than nine digits is therefore reported as "very large":
-// the same decision (reject, backtrack) without claiming a value.
+// its line search backtracks.  Measured, the difference carries an absolute error of about 1e-16 qf (2e-7 relative at
+// J = 0.5e-9 qf; up to ~100 times that through a long elimination chain), so a cost below 1e-12 qf -- fewer than two to
+// four digits left -- is reported as "very large": the same decision (reject, backtrack) without claiming a value.
+// The perturbed evaluations of the forward-difference gradient get one more decade: a sentinel there turns one
+// gradient component into 1e301 and wrecks the next direction, which is worse than a component with 1e-3 noise
+// (a first version used 0.5e-9 for both and stopped early on a path with a 0.11 s segment).
 constexpr double kUnreliableCost = 1.0e300;
+constexpr double kGuardBase = 1.0e-12, kGuardPerturbed = 1.0e-13;
 
 // J and qf are the sums over all four dimensions (a dimension whose waypoints do not move has qf = J = rounding noise
 // of either sign, so the test cannot be made per dimension); the absolute floor keeps a path that does not move at all
 // out of it.
-__device__ __forceinline__ double guarded_cost(double J, double qf) {
-  return (J >= 0.5e-9 * qf || qf < 1e-9) ? J : kUnreliableCost;
+__device__ __forceinline__ double guarded_cost(double J, double qf, bool base) {
+  return (J >= (base ? kGuardBase : kGuardPerturbed) * qf || qf < 1e-9) ? J : kUnreliableCost;
 }
 
 // ---- specialised segment steps of the forward sweep ---------------------------------------------------------
@@ -667,7 +672,7 @@ __device__ __forceinline__ double evaluate_objective(const double* vtx, const do
       qfk += dpp_move<0xB1>(qfk);
       qfk += dpp_move<0x4E>(qfk);
     }
-    Jk = guarded_cost(Jk, qfk);
+    Jk = guarded_cost(Jk, qfk, k == 0);
     if (r == 0) J0 = __shfl(Jk, (threadIdx.x & ~(G - 1)), 64);  // lane 0 of the group holds k = 0
     if (active && dim0 == 0 && k >= 1 && k <= S) grad[k - 1] = (S > 1) ? (Jk - J0) / kGradStep : 0.0;
   }
@@ -703,7 +708,7 @@ __device__ __forceinline__ double evaluate_pair(const double* seg, const double*
   Jk += dpp_move<0x4E>(Jk);
   qfk += dpp_move<0xB1>(qfk);
   qfk += dpp_move<0x4E>(qfk);
-  Jk = guarded_cost(Jk, qfk);
+  Jk = guarded_cost(Jk, qfk, k == 0);
   const double J0 = row_value(Jk, 0);
   if (work && dim0 == 0 && k >= 1) grad[k - 1] = (Jk - J0) / kGradStep;
   return J0;

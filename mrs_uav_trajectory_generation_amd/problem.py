@@ -189,6 +189,27 @@ def random_batch(n_paths, n_seg=10, *, seed0=0, derivative_to_optimize=SNAP, gen
     return assemble_batch(parts, lim, derivative_to_optimize)
 
 
+def random_mixed_batch(n_paths, derivative_to_optimize=SNAP, seed0=0):
+    """Every constraint pattern the adapter produces, mixed in one batch: 1..30 segments, both waypoint generators,
+    stop_at interior vertices (src/mrs_trajectory_generation.cpp:959-966), non-zero initial states (:946-957), limits
+    scaled by 0.3..3 per path."""
+    parts, lims = [], []
+    for p in range(seed0, seed0 + n_paths):
+        rng = SplitMix64(0xABCDEF + p)
+        S = 1 + rng.next_u64() % 30
+        wp = (random_box_waypoints if rng.next_u64() % 2 else random_walk_waypoints)(S, p)
+        stop = [rng.next_u64() % 4 == 0 for _ in range(S + 1)]
+        init = None
+        if rng.next_u64() % 2:
+            init = dict(heading=wp[0, 3] + rng.uniform(-0.5, 0.5),
+                        velocity=[rng.uniform(-2, 2), rng.uniform(-2, 2), rng.uniform(-1, 1), rng.uniform(-0.5, 0.5)],
+                        acceleration=[rng.uniform(-1, 1), rng.uniform(-1, 1), rng.uniform(-0.5, 0.5), rng.uniform(-0.3, 0.3)],
+                        jerk=[rng.uniform(-1, 1), rng.uniform(-1, 1), rng.uniform(-0.5, 0.5), rng.uniform(-0.3, 0.3)])
+        parts.append(build_vertices(wp, derivative_to_optimize, stop_at=stop, initial_state=init))
+        lims.append(DEFAULT_LIMITS * rng.uniform(0.3, 3.0))
+    return assemble_batch(parts, np.array(lims), derivative_to_optimize)
+
+
 def config1_batch(derivative_to_optimize=SNAP):
     """The reference tests' 4-waypoint path (BASELINE.json configs[0])."""
     return assemble_batch([build_vertices(CONFIG1_WAYPOINTS, derivative_to_optimize)], DEFAULT_LIMITS[None],

@@ -18,13 +18,20 @@ deriv = int(sys.argv[3]) if len(sys.argv) > 3 else 4
 gen = sys.argv[4] if len(sys.argv) > 4 else "box"
 mode = int(sys.argv[5]) if len(sys.argv) > 5 else 2
 ctx = api.Context(0)
-batch = pr.random_batch(P, n_seg, seed0=0, derivative_to_optimize=deriv, generator=gen)
+
+batch = pr.random_mixed_batch(P, deriv) if gen == "mixed" else pr.random_batch(P, n_seg, seed0=0, derivative_to_optimize=deriv, generator=gen)
 cap = 256
 out = ctx.solve_batch(batch, None, time_alloc_method=mode, sampling_dt=0.2, sample_capacity=cap)
 t0 = time.time()
-ref = po.solve_batch(batch.seg_offsets, batch.waypoints, batch.fixed_mask, batch.fixed_values, batch.limits,
-                     np.zeros(batch.n_segments), deriv=deriv, time_alloc_method=mode, estimate_times=True, sampling_dt=0.2,
-                     sample_capacity=cap, n_threads=os.cpu_count() or 8)
+cache = os.environ.get("PARITY_CACHE")  # oracle results of an identical earlier invocation (threshold experiments)
+if cache and os.path.exists(cache):
+    ref = dict(np.load(cache))
+else:
+    ref = po.solve_batch(batch.seg_offsets, batch.waypoints, batch.fixed_mask, batch.fixed_values, batch.limits,
+                         np.zeros(batch.n_segments), deriv=deriv, time_alloc_method=mode, estimate_times=True, sampling_dt=0.2,
+                         sample_capacity=cap, n_threads=os.cpu_count() or 8)
+    if cache:
+        np.savez(cache, **{k: v for k, v in ref.items() if k in ("status", "times", "coeffs", "n_samples")})
 print("oracle: %.1f s on %d threads" % (time.time() - t0, os.cpu_count() or 8))
 so = batch.seg_offsets
 same_status = out["status"] == ref["status"]

@@ -204,7 +204,7 @@ def test_trial_point_on_the_lower_bound_is_rejected_not_run_away_with(gpu_ctx):
     between 5-10 s neighbours.  There 0.5 (qf - red) cancels completely (qf ~ 1e18, true cost ~ 3e4) and used to come
     out negative, passed the Armijo test and sent the segment times to 1e17 s; the reference-style cost 0.5 c^T Q c is
     large and positive and the line search backtracks.  The by-product cost is now reported as 'very large' when it has
-    lost more than nine digits (same decision), so the path must end where the oracle's does."""
+    lost more than twelve digits (same decision), so the path must end where the oracle's does."""
     batch = pr.random_batch(1, 10, seed0=27335)
     out = gpu_ctx.solve_batch(batch, None, time_alloc_method=api.TIME_ALLOC_MELLINGER)
     ref = po.solve_batch(batch.seg_offsets, batch.waypoints, batch.fixed_mask, batch.fixed_values, batch.limits,
@@ -220,6 +220,47 @@ def test_trial_point_on_the_lower_bound_is_rejected_not_run_away_with(gpu_ctx):
     J, _ = gpu_cost_gradient(gpu_ctx, batch, t3)
     Jo, _ = po.cost_and_gradient(4, m, v, t3)
     assert Jo > 1e4 and J[0] >= 1e299
+
+
+def test_short_segment_is_evaluated_not_flagged(gpu_ctx):
+    """Path 35 of the mixed batch: the second evaluation lands on a 0.11 s segment between 2-6 s ones (J = 1.5e3,
+    qf = 3e12).  The by-product cost is good to 2e-7 there, but a first version of the guard (threshold 0.5e-9) flagged
+    the perturbed evaluations, the gradient came out as 1e301 and the next step collapsed to nothing (status 3 after
+    two evaluations; the oracle goes on to J = 889)."""
+    batch = pr.random_mixed_batch(1, 4, seed0=35)
+    S = batch.n_segments
+    out = gpu_ctx.solve_batch(batch, None, time_alloc_method=api.TIME_ALLOC_MELLINGER)
+    ref = po.solve_batch(batch.seg_offsets, batch.waypoints, batch.fixed_mask, batch.fixed_values, batch.limits,
+                         np.zeros(S), deriv=4, time_alloc_method=2, estimate_times=True)
+    assert out["status"][0] == ref["status"][0] == 3
+    assert np.max(np.abs(out["times"] - ref["times"]) / ref["times"]) < 1e-4
+    t0 = util.oracle_times(batch)
+    _, m, v = batch.path(0)
+    _, t2, _, _ = po.optimize_times(4, m, v, t0, po.default_nlopt(2))
+    assert 0.1 < t2[2] < 0.12
+    J, g = gpu_cost_gradient(gpu_ctx, batch, t2)
+    Jo, go = po.cost_and_gradient(4, m, v, t2)
+    assert abs(J[0] - Jo) < 1e-6 * Jo
+    assert np.max(np.abs(g - go)) < 1e-5 * np.max(np.abs(go))
+
+
+@pytest.mark.parametrize("deriv", [2, 3, 4])
+def test_mixed_constraint_patterns_vs_oracle(gpu_ctx, deriv):
+    """1-30 segments, stop_at vertices, non-zero initial states, both generators and per-path limits in one batch
+    (problem.random_mixed_batch; 16384 paths of it: scripts/parity_sweep.py, profiles/round1_parity_sweep.txt)."""
+    batch = pr.random_mixed_batch(768, deriv)
+    cap = 512
+    out = gpu_ctx.solve_batch(batch, None, time_alloc_method=api.TIME_ALLOC_MELLINGER, sampling_dt=0.2, sample_capacity=cap)
+    ref = po.solve_batch(batch.seg_offsets, batch.waypoints, batch.fixed_mask, batch.fixed_values, batch.limits,
+                         np.zeros(batch.n_segments), deriv=deriv, time_alloc_method=2, estimate_times=True,
+                         sampling_dt=0.2, sample_capacity=cap, n_threads=8)
+    assert np.all(np.isfinite(out["coeffs"])) and np.all(np.isfinite(out["times"]))
+    so = batch.seg_offsets
+    dt = np.array([np.max(np.abs(out["times"][a:b] - ref["times"][a:b]) / ref["times"][a:b]) for a, b in zip(so[:-1], so[1:])])
+    same = (out["status"] == ref["status"]) & (out["n_samples"] == np.minimum(ref["n_samples"], cap + 1))
+    assert same.mean() >= 0.99, same.mean()
+    assert (dt < 1e-6).mean() >= 0.95, (dt < 1e-6).mean()
+    assert (dt < 1e-3).mean() >= 0.99, (dt < 1e-3).mean()
 
 
 @pytest.mark.parametrize("dt,cap", [(0.01, 16384), (0.05, 4096), (0.5, 256), (1.0, 128), (0.3, 512)])
