@@ -39,14 +39,31 @@ __device__ long long g_phase_clock[32];
 #endif
 #define MRS_TG_PHASE_MARK(i) MRS_TG_PHASE_MARK_T(i, 0)
 
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() also drains the global-memory counter
+// (s_waitcnt vmcnt(0)), which turns a prefetch issued before the barrier into a wait at the barrier.
+__device__ __forceinline__ void lds_barrier() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+  __builtin_amdgcn_s_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+}
+
+// blockIdx -> work index such that the workgroups of one XCD (blockIdx % 8: round-robin dispatch over the eight XCDs of
+// an MI355X) own a contiguous range of work items and therefore share cache lines in that XCD's L2
+__device__ __forceinline__ int xcd_contiguous_index(unsigned bid, unsigned grid) {
+  constexpr unsigned kXcds = 8;
+  const unsigned xcd = bid % kXcds, idx = bid / kXcds, per = grid / kXcds, rem = grid % kXcds;
+  return (int)(xcd * per + (xcd < rem ? xcd : rem) + idx);
+}
+
 static __constant__ double c_abar_inv[kN][kN] = MRS_TG_ABAR_INV_INIT;
 static __constant__ double c_hbar[kHalf][kN][kN] = MRS_TG_HBAR_INIT;
 
 __device__ __forceinline__ double rsqrt_refined(double x) {
-  double y = __builtin_amdgcn_rsq(x);
-  y = y * fma(-0.5 * x * y, y, 1.5);
-  y = y * fma(-0.5 * x * y, y, 1.5);
-  return y;
+  // v_rsq_f64 is good to 5e-8; one third-order step y (1 + e/2 + 3 e^2/8), e = 1 - x y^2, leaves O(e^3) ~ 1e-21 and
+  // is four dependent operations (two Newton steps: six) -- scripts/rsq_accuracy.hip
+  const double y = __builtin_amdgcn_rsq(x);
+  const double e = fma(-(x * y), y, 1.0);
+  return fma(y * e, fma(e, 0.375, 0.5), y);
 }
 
 // index into a packed lower-triangular 4x4 (r >= c)

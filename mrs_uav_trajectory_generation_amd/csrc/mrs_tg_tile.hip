@@ -33,7 +33,14 @@ namespace mrs_tg {
 constexpr int kSegRec = 10 + 16 + 10 + 16 + 16 + 4;  // HssM, EM, HeeM, ustart[r][dim], uend[r][dim], qf[dim] = 72
 constexpr int kVtxRec = 42 + 20 + 2;                 // L[10] W[16] z[4][4] | d[5][4] | free bits, flags
 
-__host__ __device__ constexpr int tile_path_doubles(int S) { return S * kSegRec + (S + 1) * kVtxRec; }
+// Per-path LDS stride.  Both record sizes are multiples of 8 doubles, so the unpadded stride put every path of a
+// tile on the same banks ((a/4) mod 32 for ds_read2_b64 / ds_write*): the 16-lane groups of phase B (two paths x two
+// directions) then hit one bank with up to four distinct addresses.  A stride of 4 (mod 16) doubles shifts each
+// path by 8 banks.
+__host__ __device__ constexpr int tile_path_doubles(int S) {
+  const int base = S * kSegRec + (S + 1) * kVtxRec;
+  return base + ((4 - base % 16) + 16) % 16;
+}
 
 
 constexpr int kTileThreads = 256;
@@ -54,7 +61,10 @@ __global__ __launch_bounds__(kTileThreads) void solve_tile_kernel(BatchView b, i
   const int tid = threadIdx.x;
   const int wtid = tid - 64;  // worker index; negative on wavefront 0
   MRS_TG_PHASE_MARK(0);
-  const int q0 = blockIdx.x * TP;
+  // Workgroups are dispatched to the eight XCDs round-robin by blockIdx, and each XCD has its own L2.  In the blocks
+  // variant a 128-byte line of an SoA block row (one entry, 16 consecutive paths) is shared by the neighbouring tiles,
+  // so neighbouring tiles go to the same XCD: XCD x owns a contiguous range of tiles.
+  const int q0 = xcd_contiguous_index(blockIdx.x, gridDim.x) * TP;
   const int n_here = min(TP, b.n_paths - q0);
   const int PS = tile_path_doubles(Smax);
   const size_t P = (size_t)b.n_paths;
@@ -85,6 +95,16 @@ __global__ __launch_bounds__(kTileThreads) void solve_tile_kernel(BatchView b, i
     return item < n_items && i < s_S[t];
   };
 
+  // A0's own global loads go out first (one vertex per thread; further rounds, if any, follow below): they are the
+  // shortest path to the next barrier, and queued behind the workers' block prefetch they used to arrive last
+  // (phase A0 of the blocks variant: 5100 -> cycles measured in scripts/tile_phases.hip)
+  const int n_vertex_items = n_here * (Smax + 1);
+  double f_first[kHalf][kD];
+  unsigned fb_first = 0;
+  bool pos_first = false;
+  const bool vertex_first = tid < n_vertex_items && (tid / n_here) <= s_S[tid % n_here];
+  if (vertex_first) fb_first = load_vertex<kD>(mask, vals, s_v0[tid % n_here] + tid / n_here, 0, f_first, pos_first);
+
   // workers: request the inputs of their first A1 item now; they arrive while A0 runs
   double Hs[kSym10];
   double T_first = 1.0;
@@ -106,12 +126,7 @@ __global__ __launch_bounds__(kTileThreads) void solve_tile_kernel(BatchView b, i
     const int t = e / 42;
     vtx_rec(t, s_S[t] / 2)[e % 42] = 0.0;
   }
-  for (int item = tid; item < n_here * (Smax + 1); item += kTileThreads) {
-    const int t = item % n_here, v = item / n_here;
-    if (v > s_S[t]) continue;
-    double f[kHalf][kD];
-    bool pos_fixed;
-    const unsigned fb = load_vertex<kD>(mask, vals, s_v0[t] + v, 0, f, pos_fixed);
+  auto store_vertex = [&](int t, int v, const double (&f)[kHalf][kD], unsigned fb, bool pos_fixed) {
     double* r = vtx_rec(t, v);
 #pragma unroll
     for (int k = 0; k < kHalf; ++k)
@@ -119,8 +134,17 @@ __global__ __launch_bounds__(kTileThreads) void solve_tile_kernel(BatchView b, i
       for (int dd = 0; dd < kD; ++dd) r[42 + k * kD + dd] = f[k][dd];
     r[62] = (double)fb;
     r[63] = pos_fixed ? 1.0 : 0.0;
+  };
+  if (vertex_first) store_vertex(tid % n_here, tid / n_here, f_first, fb_first, pos_first);
+  for (int item = tid + kTileThreads; item < n_vertex_items; item += kTileThreads) {
+    const int t = item % n_here, v = item / n_here;
+    if (v > s_S[t]) continue;
+    double f[kHalf][kD];
+    bool pos_fixed;
+    const unsigned fb = load_vertex<kD>(mask, vals, s_v0[t] + v, 0, f, pos_fixed);
+    store_vertex(t, v, f, fb, pos_fixed);
   }
-  __syncthreads();
+  lds_barrier();  // not __syncthreads(): the workers' block loads stay in flight across it
   MRS_TG_PHASE_MARK(2);
 
   // ---- A1 (workers): per (segment, dimension): u = H [f_i; f_{i+1}], masked 4x4 blocks
@@ -156,6 +180,7 @@ __global__ __launch_bounds__(kTileThreads) void solve_tile_kernel(BatchView b, i
       }
       rec[68 + dim] = qf;
       if (dim == 0) {
+        const bool transposed = i >= s_S[t] / 2;
 #pragma unroll
         for (int r = 0; r < kNB; ++r) {
           const bool sr = (free_s >> r) & 1u, er = (free_e >> r) & 1u;
@@ -165,10 +190,13 @@ __global__ __launch_bounds__(kTileThreads) void solve_tile_kernel(BatchView b, i
             rec[tri(r, c)] = (sr && sc) ? Hs[sym10(kSlot0 + r, kSlot0 + c)] : 0.0;
             rec[26 + tri(r, c)] = (er && ec) ? Hs[sym10(kHalf + kSlot0 + r, kHalf + kSlot0 + c)] : 0.0;
           }
+          // the coupling block is stored the way its consumer reads it: segments left of the middle vertex belong to
+          // the forward direction of phase B (E[r][c]), the others to the backward direction (E transposed)
 #pragma unroll
           for (int c = 0; c < kNB; ++c) {
             const bool ec = (free_e >> c) & 1u;
-            rec[10 + r * kNB + c] = (sr && ec) ? Hs[sym10(kSlot0 + r, kHalf + kSlot0 + c)] : 0.0;
+            const double val = (sr && ec) ? Hs[sym10(kSlot0 + r, kHalf + kSlot0 + c)] : 0.0;
+            rec[10 + (transposed ? c * kNB + r : r * kNB + c)] = val;
           }
         }
       }
@@ -186,6 +214,7 @@ __global__ __launch_bounds__(kTileThreads) void solve_tile_kernel(BatchView b, i
   __syncthreads();
   MRS_TG_PHASE_MARK(3);
 
+  double red_both = 0.0;  // sum |z|^2 of this lane's dimension, both directions (phase B -> C)
   // ---- B: the vertex chain, eight lanes per path: lane = (direction, dimension).
   // Two-sided ("twisted") block elimination: direction 0 eliminates vertices 0, 1, ... from the left,
   // direction 1 eliminates S, S-1, ... from the right, both towards the middle vertex m = S/2; then the
@@ -207,32 +236,48 @@ __global__ __launch_bounds__(kTileThreads) void solve_tile_kernel(BatchView b, i
     }
     // One elimination step at vertex v.  INNER: there is a next vertex towards the middle to couple with;
     // MIDDLE: v is the middle vertex, whose record holds the other side's Schur update (zero if there is none).
-    // Everything is loaded unconditionally up front (absent neighbours read the zero record, the first step
-    // subtracts the zero-initialised Wp / zp), so the step has one LDS round trip and no divergent branches.
-    auto eliminate = [&](int v, auto inner_tag, auto middle_tag) {
-      constexpr bool INNER = decltype(inner_tag)::value, MIDDLE = decltype(middle_tag)::value;
-      double* vr = vtx_rec(t, v);
-      const unsigned fb = (unsigned)vr[62];
+    // The inputs of a step (StepIn) are loaded unconditionally up front (absent neighbours read the zero record, the
+    // first step subtracts the zero-initialised Wp / zp), so the step has one LDS round trip and no divergent branches.
+    // (Loading them one step ahead into a second register set changed nothing: the step is bound by its ~220
+    // in-order instructions, not by the LDS latency.)
+    struct StepIn {
+      double dl[10], dr[10], yl[kNB], yr[kNB], E[kNB][kNB];
+      unsigned fb;
+    };
+    auto load_step = [&](int v, StepIn& in, auto inner_tag) {
+      constexpr bool INNER = decltype(inner_tag)::value;
+      const double* vr = vtx_rec(t, v);
+      in.fb = (unsigned)vr[62];
       const double* left = (v > 0) ? seg_rec(t, v - 1) : zero_rec;   // segment v-1 ends at v
       const double* right = (v < S) ? seg_rec(t, v) : zero_rec;      // segment v starts at v
       const double* cb = dir ? left : right;                         // coupling towards the middle
-      double Sm[10], y[kNB], E[kNB][kNB];
 #pragma unroll
-      for (int e = 0; e < 10; ++e) Sm[e] = left[26 + e] + right[e];
-#pragma unroll
-      for (int r = 0; r < kNB; ++r) y[r] = -(left[52 + r * kD + dim] + right[36 + r * kD + dim]);
-      if (INNER) {
-        // direction 0: E~_v[r][c]; direction 1: E~_{v-1} transposed
-        double raw[kNB][kNB];
-#pragma unroll
-        for (int r = 0; r < kNB; ++r)
-#pragma unroll
-          for (int c = 0; c < kNB; ++c) raw[r][c] = cb[10 + r * kNB + c];
-#pragma unroll
-        for (int r = 0; r < kNB; ++r)
-#pragma unroll
-          for (int c = 0; c < kNB; ++c) E[r][c] = dir ? raw[c][r] : raw[r][c];
+      for (int e = 0; e < 10; ++e) {
+        in.dl[e] = left[26 + e];
+        in.dr[e] = right[e];
       }
+#pragma unroll
+      for (int r = 0; r < kNB; ++r) {
+        in.yl[r] = left[52 + r * kD + dim];
+        in.yr[r] = right[36 + r * kD + dim];
+      }
+      if (INNER) {
+        // direction 0: E~_v[r][c]; direction 1: E~_{v-1} transposed -- phase A1 stored it that way
+#pragma unroll
+        for (int r = 0; r < kNB; ++r)
+#pragma unroll
+          for (int c = 0; c < kNB; ++c) in.E[r][c] = cb[10 + r * kNB + c];
+      }
+    };
+    auto eliminate = [&](int v, const StepIn& in, auto inner_tag, auto middle_tag) {
+      constexpr bool INNER = decltype(inner_tag)::value, MIDDLE = decltype(middle_tag)::value;
+      double* vr = vtx_rec(t, v);
+      const unsigned fb = in.fb;
+      double Sm[10], y[kNB];
+#pragma unroll
+      for (int e = 0; e < 10; ++e) Sm[e] = in.dl[e] + in.dr[e];
+#pragma unroll
+      for (int r = 0; r < kNB; ++r) y[r] = -(in.yl[r] + in.yr[r]);
       if (MIDDLE) {
 #pragma unroll
         for (int e = 0; e < 10; ++e) Sm[e] -= vr[e];
@@ -279,11 +324,12 @@ __global__ __launch_bounds__(kTileThreads) void solve_tile_kernel(BatchView b, i
         red += z[r] * z[r];
       }
       if (INNER) {
+        // row by row, the four columns side by side: four independent chains for the scheduler
 #pragma unroll
-        for (int c = 0; c < kNB; ++c)
+        for (int r = 0; r < kNB; ++r)
 #pragma unroll
-          for (int r = 0; r < kNB; ++r) {
-            double s = E[r][c];
+          for (int c = 0; c < kNB; ++c) {
+            double s = in.E[r][c];
 #pragma unroll
             for (int k = 0; k < r; ++k) s -= L[tri(r, k)] * W[k][c];
             W[r][c] = s * Linv[r];
@@ -324,10 +370,14 @@ __global__ __launch_bounds__(kTileThreads) void solve_tile_kernel(BatchView b, i
       const unsigned end_fb = (len > 0) ? (unsigned)vtx_rec(t, dir ? S : 0)[62] : 0xFu;
       if (__ballot(end_fb != 0u) == 0ull) s_first = 1;
     }
+    MRS_TG_PHASE_MARK(10);
     for (int s = s_first; s < len; ++s) {
       const int v = dir ? (S - s) : s;
-      eliminate(v, true_type{}, false_type{});
+      StepIn in;
+      load_step(v, in, true_type{});
+      eliminate(v, in, true_type{}, false_type{});
     }
+    MRS_TG_PHASE_MARK(11);
     // direction 1 hands its Schur update W^T W and right-hand-side update W^T z for the middle vertex over
     // through that vertex's (still unused) record
     if (dir == 1 && len > 0) {
@@ -354,11 +404,14 @@ __global__ __launch_bounds__(kTileThreads) void solve_tile_kernel(BatchView b, i
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    MRS_TG_PHASE_MARK(12);
     double xm[kNB] = {0.0, 0.0, 0.0, 0.0};
     if (dir == 0) {
       // middle vertex: left Schur update from Wp/zp (if any vertex was eliminated on the left), right one
       // from the record (if any on the right)
-      eliminate(m, false_type{}, true_type{});
+      StepIn in;
+      load_step(m, in, false_type{});
+      eliminate(m, in, false_type{}, true_type{});
       double* vr = vtx_rec(t, m);
       // x_m = L^-T z
 #pragma unroll
@@ -374,23 +427,12 @@ __global__ __launch_bounds__(kTileThreads) void solve_tile_kernel(BatchView b, i
         vr[26 + r * kD + dim] = xm[r];  // x_m for the direction-1 lanes
       }
     }
-    double part = red;
-    part += __shfl_xor(part, kD, 64);  // the two directions of this dimension
-    double qf = 0.0;
-    if (dir == 0)
-      for (int i = 0; i < S; ++i) qf += seg_rec(t, i)[68 + dim];
-    double cst = (dir == 0) ? 0.5 * (qf - part) : 0.0;
-    cst += __shfl_xor(cst, 1, 64);
-    cst += __shfl_xor(cst, 2, 64);
-    if (dir == 0 && dim == 0) {
-      bool pos_ok = true;
-      for (int v = 0; v <= S; ++v) pos_ok = pos_ok && (vtx_rec(t, v)[63] != 0.0);
-      if (cost) cost[s_p[t]] = cst;
-      if (status) status[s_p[t]] = merge_status(pos_ok, status_in, s_p[t]);
-    }
+    MRS_TG_PHASE_MARK(13);
+    red_both = red + __shfl_xor(red, kD, 64);  // the two directions of this dimension; cost and status follow in phase C
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    MRS_TG_PHASE_MARK(14);
     // outward back-substitution: x_v = L_v^-T (z_v - W_v x_next), next = the neighbour towards the middle
     double xn[kNB];
     {
@@ -422,9 +464,38 @@ __global__ __launch_bounds__(kTileThreads) void solve_tile_kernel(BatchView b, i
         xn[r] = x[r];
       }
     }
+    MRS_TG_PHASE_MARK(15);
   }
   __syncthreads();
   MRS_TG_PHASE_MARK(4);
+
+  // ---- cost and status (wavefront 0, beside the workers' phase C): cost = 0.5 (f^T H f - sum |z|^2) summed over the
+  // dimensions; the eight lanes of a path share the loops over its segments and vertices
+  if (tid < n_here * 2 * kD) {
+    const int t = tid / (2 * kD), dir = (tid / kD) & 1, dim = tid % kD;
+    const int S = s_S[t];
+    const int half = S / 2, i0 = dir ? half : 0, i1 = dir ? S : half;
+    double qa = 0.0, qb = 0.0;
+    int i = i0;
+    for (; i + 1 < i1; i += 2) {
+      qa += seg_rec(t, i)[68 + dim];
+      qb += seg_rec(t, i + 1)[68 + dim];
+    }
+    if (i < i1) qa += seg_rec(t, i)[68 + dim];
+    double qf = qa + qb;
+    qf += __shfl_xor(qf, kD, 64);
+    double cst = 0.5 * (qf - red_both);
+    cst += __shfl_xor(cst, 1, 64);
+    cst += __shfl_xor(cst, 2, 64);
+    bool ok = true;
+    for (int v = tid % (2 * kD); v <= S; v += 2 * kD) ok = ok && (vtx_rec(t, v)[63] != 0.0);
+    const unsigned long long bal = __ballot(ok);
+    const bool pos_ok = ((bal >> (t * 2 * kD)) & 0xFFull) == 0xFFull;
+    if (dir == 0 && dim == 0) {
+      if (cost) cost[s_p[t]] = cst;
+      if (status) status[s_p[t]] = merge_status(pos_ok, status_in, s_p[t]);
+    }
+  }
 
   // ---- C (workers): coefficients c = A^-1 [d_i; d_{i+1}] per (segment, dimension)
   if (wtid >= 0) {

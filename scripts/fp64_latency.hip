@@ -10,6 +10,9 @@ __global__ __launch_bounds__(64) void k(double* out, long long* cyc, double a, d
   double acc[NSTREAM];
 #pragma unroll
   for (int i = 0; i < NSTREAM; ++i) acc[i] = a + i + threadIdx.x;
+  // per-lane values the compiler must keep in VGPRs
+  double va = a + 1e-9 * threadIdx.x, vb = b - 1e-9 * threadIdx.x;
+  asm volatile("" : "+v"(va), "+v"(vb));
   const long long t0 = clock64();
 #pragma unroll 1
   for (int it = 0; it < 64; ++it) {
@@ -24,6 +27,10 @@ __global__ __launch_bounds__(64) void k(double* out, long long* cyc, double a, d
         else if (OP == 4) acc[i] = __builtin_amdgcn_rcp(acc[i]);
         else if (OP == 5) acc[i] = 1.0 / acc[i];
         else if (OP == 6) acc[i] = sqrt(acc[i]);
+        else if (OP == 7) acc[i] = __builtin_fma(acc[i], vb, va);           // three VGPR-pair sources
+        else if (OP == 8) acc[i] = acc[i] * vb;                             // two VGPR-pair sources
+        else if (OP == 9) acc[i] = __builtin_fma(acc[i], vb, a);            // two VGPR pairs + one SGPR pair
+        else if (OP == 10) acc[i] = __builtin_fma(-acc[(i + 1) % NSTREAM], vb, acc[i]);  // as in a Schur update: three VGPR pairs, all different
       }
     }
   }
@@ -54,5 +61,9 @@ int main() {
   run<1, 4>("rcp"); run<4, 4>("rcp");
   run<1, 5>("div"); run<4, 5>("div");
   run<1, 6>("sqrt"); run<4, 6>("sqrt");
+  run<1, 7>("fma vvv"); run<2, 7>("fma vvv"); run<4, 7>("fma vvv"); run<8, 7>("fma vvv");
+  run<1, 8>("mul vv"); run<4, 8>("mul vv");
+  run<1, 9>("fma vvs"); run<4, 9>("fma vvs");
+  run<4, 10>("fma -v*v+v"); run<8, 10>("fma -v*v+v");
   return 0;
 }

@@ -5,7 +5,7 @@
 #include <cstdio>
 #include <vector>
 
-__global__ void k(const double* x, double* raw, double* n1, double* n2, double* gs_sqrt, double* gs_inv, int n) {
+__global__ void k(const double* x, double* raw, double* n1, double* n2, double* gs_sqrt, double* gs_inv, double* cubic, int n) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   const double v = x[i];
@@ -19,6 +19,9 @@ __global__ void k(const double* x, double* raw, double* n1, double* n2, double* 
   const double r = fma(-g, h, 0.5);
   gs_sqrt[i] = fma(g, r, g);
   gs_inv[i] = 2.0 * fma(h, r, h);
+  // one third-order step: y (1 + e/2 + 3 e^2 / 8), e = 1 - v y^2 (four dependent operations after v_rsq_f64)
+  const double e = fma(-(v * y), y, 1.0);
+  cubic[i] = fma(y * e, fma(e, 0.375, 0.5), y);
 }
 
 int main() {
@@ -30,14 +33,15 @@ int main() {
     const double m = 1.0 + (s >> 11) * (1.0 / 9007199254740992.0);
     x[i] = std::ldexp(m, (int)(s % 120) - 60);
   }
-  double *dx, *d[5];
+  double *dx, *d[6];
   hipMalloc(&dx, n * 8);
   for (auto& p : d) hipMalloc(&p, n * 8);
   hipMemcpy(dx, x.data(), n * 8, hipMemcpyHostToDevice);
-  hipLaunchKernelGGL(k, dim3(n / 256), dim3(256), 0, 0, dx, d[0], d[1], d[2], d[3], d[4], n);
-  const char* names[5] = {"v_rsq_f64 raw", "1 Newton step", "2 Newton steps", "coupled step: sqrt", "coupled step: 1/sqrt"};
+  hipLaunchKernelGGL(k, dim3(n / 256), dim3(256), 0, 0, dx, d[0], d[1], d[2], d[3], d[4], d[5], n);
+  const char* names[6] = {"v_rsq_f64 raw", "1 Newton step", "2 Newton steps", "coupled step: sqrt", "coupled step: 1/sqrt",
+                          "1 third-order step"};
   std::vector<double> h(n);
-  for (int kx = 0; kx < 5; ++kx) {
+  for (int kx = 0; kx < 6; ++kx) {
     hipMemcpy(h.data(), d[kx], n * 8, hipMemcpyDeviceToHost);
     long double worst = 0;
     for (int i = 0; i < n; ++i) {

@@ -97,6 +97,9 @@ int main(int argc, char** argv) {
            "middle workgroup): setup %lld  A0 %lld  A1 %lld  B %lld  C %lld  total %lld\n",
            P, S, fused ? "fused" : "blocks", ms * 1e3 / n, clk[1] - clk[0], clk[2] - clk[1], clk[3] - clk[2], clk[4] - clk[3],
            clk[5] - clk[4], clk[5] - clk[0]);
+    printf("   inside B: entry %lld  elimination loop %lld  hand-over %lld  middle %lld  fence %lld  back substitution %lld  exit %lld\n",
+           clk[10] - clk[3], clk[11] - clk[10], clk[12] - clk[11], clk[13] - clk[12], clk[14] - clk[13], clk[15] - clk[14],
+           clk[4] - clk[15]);
   }
   // sampler: serial walk (lane 0) and parallel evaluation, dt 0.2, capacity 512
   {
