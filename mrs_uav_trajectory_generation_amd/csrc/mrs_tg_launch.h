@@ -30,7 +30,7 @@ hipError_t launch_sample(const BatchView& b, const double* coeffs, const double*
                          int32_t* n_samples, double* samples, hipStream_t stream);
 size_t linear_workspace_doubles(const BatchView& b);
 // phase-split tile kernel (mrs_tg_tile.hip): small and medium batches whose per-path state fits in LDS
-bool tile_kernel_applies(const BatchView& b);
+bool tile_kernel_applies(const BatchView& b, bool fused);
 hipError_t launch_solve_tile(const BatchView& b, int d, bool fused, const uint8_t* mask, const double* vals,
                              const double* seg_times, const double* H, const double* Ainv, double* coeffs,
                              int32_t* status, double* cost, const int32_t* status_in, hipStream_t stream);

@@ -540,8 +540,12 @@ __global__ __launch_bounds__(kTileThreads) void solve_tile_kernel(BatchView b, i
 
 static constexpr size_t kTileLdsBudget = 144 * 1024;
 
-bool tile_kernel_applies(const BatchView& b) {
-  int max_paths = 6144;  // measured (scripts/sweep_tile.sh, 10 segments): 4096 paths 51 vs 63 us, 6144 paths 73.6 vs 73.5 us, 8192 paths 96 vs 83 us
+bool tile_kernel_applies(const BatchView& b, bool fused) {
+  // measured, 10 segments, linear step / nonlinear pipeline in us (tile vs one-lane-per-(path, dimension) kernel):
+  //   blocks: 4096 paths 46 vs 62, 6144 64 vs 74, 8192 82 vs 82, 12288 124 vs 146, 16384 164 vs 205, 32768 368 vs 386,
+  //           65536 736 vs 579 (beyond the Infinity Cache the tile's 32-64-byte pieces of every line cost more);
+  //   fused:  8192 570 vs 552, 16384 942 vs 884, 32768 1700 vs 1682 (no blocks to fetch: the lanes win earlier)
+  int max_paths = fused ? 6144 : 32768;
   if (const char* e = std::getenv("MRS_TG_TILE_MAX_PATHS")) max_paths = std::atoi(e);  // tuning knob (scripts/sweep_tile.sh)
   if (b.n_paths == 0 || b.n_paths > max_paths) return false;
   return (size_t)tile_path_doubles(b.max_segments) * sizeof(double) + kSegRec * sizeof(double) <= kTileLdsBudget;

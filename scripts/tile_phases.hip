@@ -74,7 +74,7 @@ int main(int argc, char** argv) {
   hipStream_t st;
   CK(hipStreamCreate(&st));
   CK(launch_assemble(b, d, dT, H, A, st));
-  if (!tile_kernel_applies(b)) {
+  if (!tile_kernel_applies(b, false)) {
     printf("tile kernel does not apply to P=%d S=%d\n", P, S);
     return 0;
   }

@@ -1,6 +1,7 @@
 """Kernel variants that only engage on larger batches (the library picks the lane mapping from the batch
-size): one-lane-per-dimension solve (6144 < P <= 32768), one-lane-per-path solve (P > 32768), compact
-outer-loop mapping (P > 3072).  Parity is checked against the oracle on a strided subset (the oracle needs
+size): one-lane-per-dimension solve (fused pipeline: 6144 < P <= 32768; materialised blocks: only when the tile does
+not fit the LDS, or forced with MRS_TG_TILE_MAX_PATHS), one-lane-per-path solve (P > 32768), compact outer-loop
+mapping (P > 3072).  Parity is checked against the oracle on a strided subset (the oracle needs
 ~30 us per linear path and ~2 ms per nonlinear path), and on every path through size-independent
 properties: continuity, constraints, linearity, agreement between the materialised-block and the fused
 pipelines, and agreement with the same paths solved in a small batch (different kernels, same answer)."""
@@ -22,8 +23,10 @@ def _subset_vs_oracle(batch, out, idx, tol):
     assert util.coeff_error(got, ref["coeffs"], sub.seg_offsets) < tol
 
 
-@pytest.mark.parametrize("n_paths", [2304, 6400, 33024])
-def test_linear_large_batches(gpu_ctx, n_paths):
+@pytest.mark.parametrize("n_paths,tile_max", [(2304, None), (6400, None), (6400, 0), (33024, None)])
+def test_linear_large_batches(gpu_ctx, monkeypatch, n_paths, tile_max):
+    if tile_max is not None:
+        monkeypatch.setenv("MRS_TG_TILE_MAX_PATHS", str(tile_max))  # read at every call: both pipelines on the lane kernels
     batch = pr.random_batch(n_paths, 10, seed0=7000)
     out = gpu_ctx.solve_batch(batch, None)
     fused = gpu_ctx.solve_batch(batch, out["times"], flags=api.FLAG_FUSED_ASSEMBLY)
@@ -37,6 +40,7 @@ def test_linear_large_batches(gpu_ctx, n_paths):
     idx = list(range(0, n_paths, n_paths // 97))
     _subset_vs_oracle(batch, out, idx, 1e-7)
     # the same paths in a small batch go through the tile kernel: same answer
+    monkeypatch.delenv("MRS_TG_TILE_MAX_PATHS", raising=False)
     small = batch.select(idx)
     ts = np.concatenate([out["times"][batch.seg_offsets[p]:batch.seg_offsets[p + 1]] for p in idx])
     sout = gpu_ctx.solve_batch(small, ts)
