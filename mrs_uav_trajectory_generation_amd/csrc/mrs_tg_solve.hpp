@@ -70,6 +70,32 @@ __device__ __forceinline__ void load_A_blocks(const BlockSource& src, int seg, A
     for (int c = 0; c < kN; ++c) a.low[k][c] = (blk + (size_t)((kHalf + k) * kN + c) * src.P)[q];
 }
 
+// The same loads for the tile kernel, whose lanes sit on different segments and paths: the row pointer depends only on
+// the block entry (wave-uniform, SGPRs), the lane contributes one 32-bit BYTE offset ((seg * 100 * P + q) * 8 -- the
+// tile kernel only runs when a block buffer is smaller than 4 GiB, tile_kernel_applies()), so each access is
+// global_load ... v_off, s[base] instead of a 64-bit VALU address computation per access and lane.
+__device__ __forceinline__ const double* at_byte_offset(const double* row, unsigned byte_off) {
+  return reinterpret_cast<const double*>(reinterpret_cast<const char*>(row) + byte_off);
+}
+
+__device__ __forceinline__ void load_H_blocks32(const BlockSource& src, int seg, double (&Hs)[kSym10]) {
+  const unsigned off = ((unsigned)seg * 100u * (unsigned)src.P + (unsigned)src.q) * 8u;
+#pragma unroll
+  for (int a = 0; a < kN; ++a)
+#pragma unroll
+    for (int c = a; c < kN; ++c) Hs[sym10(a, c)] = *at_byte_offset(src.H + (size_t)(a * kN + c) * src.P, off);
+}
+
+__device__ __forceinline__ void load_A_blocks32(const BlockSource& src, int seg, AinvRows& a) {
+  const unsigned off = ((unsigned)seg * 100u * (unsigned)src.P + (unsigned)src.q) * 8u;
+#pragma unroll
+  for (int k = 0; k < kHalf; ++k) a.diag[k] = *at_byte_offset(src.A + (size_t)(k * kN + k) * src.P, off);
+#pragma unroll
+  for (int k = 0; k < kHalf; ++k)
+#pragma unroll
+    for (int c = 0; c < kN; ++c) a.low[k][c] = *at_byte_offset(src.A + (size_t)((kHalf + k) * kN + c) * src.P, off);
+}
+
 template <int ND>
 struct SavedFactors {
   double L[10];

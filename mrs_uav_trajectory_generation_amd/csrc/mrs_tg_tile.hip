@@ -115,7 +115,7 @@ __global__ __launch_bounds__(kTileThreads) void solve_tile_kernel(BatchView b, i
         T_first = seg_times[s_s0[t] + i];
       } else {
         const BlockSource src{Hblk, Ablk, P, q0 + t};
-        load_H_blocks(src, i, Hs);
+        load_H_blocks32(src, i, Hs);
       }
     }
   }
@@ -156,8 +156,9 @@ __global__ __launch_bounds__(kTileThreads) void solve_tile_kernel(BatchView b, i
         hessian_from_time((item == wtid) ? T_first : seg_times[s_s0[t] + i], d, Hs);
       } else if (item != wtid) {
         const BlockSource src{Hblk, Ablk, P, q0 + t};
-        load_H_blocks(src, i, Hs);
+        load_H_blocks32(src, i, Hs);
       }
+      MRS_TG_PHASE_MARK_T(16, 64);
       const double* vs = vtx_rec(t, i);
       const double* ve = vtx_rec(t, i + 1);
       const unsigned free_s = (unsigned)vs[62], free_e = (unsigned)ve[62];
@@ -179,40 +180,49 @@ __global__ __launch_bounds__(kTileThreads) void solve_tile_kernel(BatchView b, i
         if (a >= kHalf + kSlot0) rec[52 + (a - kHalf - kSlot0) * kD + dim] = ((free_e >> (a - kHalf - kSlot0)) & 1u) ? u : 0.0;
       }
       rec[68 + dim] = qf;
+      MRS_TG_PHASE_MARK_T(17, 64);
       if (dim == 0) {
+        // masked blocks D_s H D_e with D = diag(free bits) as 0.0 / 1.0 factors: two multiplications per entry
+        // instead of bit tests and selects (this lane works alone here, the other three of its quad wait)
         const bool transposed = i >= s_S[t] / 2;
+        double ms[kNB], me[kNB];
 #pragma unroll
         for (int r = 0; r < kNB; ++r) {
-          const bool sr = (free_s >> r) & 1u, er = (free_e >> r) & 1u;
+          ms[r] = (double)((free_s >> r) & 1u);
+          me[r] = (double)((free_e >> r) & 1u);
+        }
+#pragma unroll
+        for (int r = 0; r < kNB; ++r) {
 #pragma unroll
           for (int c = 0; c <= r; ++c) {
-            const bool sc = (free_s >> c) & 1u, ec = (free_e >> c) & 1u;
-            rec[tri(r, c)] = (sr && sc) ? Hs[sym10(kSlot0 + r, kSlot0 + c)] : 0.0;
-            rec[26 + tri(r, c)] = (er && ec) ? Hs[sym10(kHalf + kSlot0 + r, kHalf + kSlot0 + c)] : 0.0;
+            rec[tri(r, c)] = (ms[r] * ms[c]) * Hs[sym10(kSlot0 + r, kSlot0 + c)];
+            rec[26 + tri(r, c)] = (me[r] * me[c]) * Hs[sym10(kHalf + kSlot0 + r, kHalf + kSlot0 + c)];
           }
           // the coupling block is stored the way its consumer reads it: segments left of the middle vertex belong to
           // the forward direction of phase B (E[r][c]), the others to the backward direction (E transposed)
 #pragma unroll
           for (int c = 0; c < kNB; ++c) {
-            const bool ec = (free_e >> c) & 1u;
-            const double val = (sr && ec) ? Hs[sym10(kSlot0 + r, kHalf + kSlot0 + c)] : 0.0;
+            const double val = (ms[r] * me[c]) * Hs[sym10(kSlot0 + r, kHalf + kSlot0 + c)];
             rec[10 + (transposed ? c * kNB + r : r * kNB + c)] = val;
           }
         }
       }
     }
   }
-  // workers: request the A^-1 rows of their first C item; they arrive while wavefront 0 runs phase B
+  MRS_TG_PHASE_MARK_T(18, 64);
+  lds_barrier();
+  MRS_TG_PHASE_MARK(3);
+  // workers: request the A^-1 rows of their first C item now -- after the barrier that starts phase B (issuing the 55
+  // loads takes a worker ~2600 cycles, which used to sit in front of that barrier); they arrive while wavefront 0 runs B
   AinvRows ar_first;
   if (!FUSED) {
     int t, i, dim;
     if (wtid >= 0 && item_valid(wtid, t, i, dim)) {
       const BlockSource src{Hblk, Ablk, P, q0 + t};
-      load_A_blocks(src, i, ar_first);
+      load_A_blocks32(src, i, ar_first);
     }
   }
-  __syncthreads();
-  MRS_TG_PHASE_MARK(3);
+  MRS_TG_PHASE_MARK_T(19, 64);
 
   double red_both = 0.0;  // sum |z|^2 of this lane's dimension, both directions (phase B -> C)
   // ---- B: the vertex chain, eight lanes per path: lane = (direction, dimension).
@@ -466,7 +476,7 @@ __global__ __launch_bounds__(kTileThreads) void solve_tile_kernel(BatchView b, i
     }
     MRS_TG_PHASE_MARK(15);
   }
-  __syncthreads();
+  lds_barrier();
   MRS_TG_PHASE_MARK(4);
 
   // ---- cost and status (wavefront 0, beside the workers' phase C): cost = 0.5 (f^T H f - sum |z|^2) summed over the
@@ -515,7 +525,7 @@ __global__ __launch_bounds__(kTileThreads) void solve_tile_kernel(BatchView b, i
       } else {
         if (item != wtid) {
           const BlockSource src{Hblk, Ablk, P, q0 + t};
-          load_A_blocks(src, i, ar_first);
+          load_A_blocks32(src, i, ar_first);
         }
 #pragma unroll
         for (int k = 0; k < kHalf; ++k) c[k] = ar_first.diag[k] * dv[k];
@@ -548,6 +558,8 @@ bool tile_kernel_applies(const BatchView& b, bool fused) {
   int max_paths = fused ? 6144 : 32768;
   if (const char* e = std::getenv("MRS_TG_TILE_MAX_PATHS")) max_paths = std::atoi(e);  // tuning knob (scripts/sweep_tile.sh)
   if (b.n_paths == 0 || b.n_paths > max_paths) return false;
+  // 32-bit byte offsets into the block buffers (load_H_blocks32)
+  if (!fused && (unsigned long long)b.max_segments * 800ull * (unsigned long long)b.n_paths > 0xFFFFFFFFull) return false;
   return (size_t)tile_path_doubles(b.max_segments) * sizeof(double) + kSegRec * sizeof(double) <= kTileLdsBudget;
 }
 

@@ -97,6 +97,8 @@ int main(int argc, char** argv) {
            "middle workgroup): setup %lld  A0 %lld  A1 %lld  B %lld  C %lld  total %lld\n",
            P, S, fused ? "fused" : "blocks", ms * 1e3 / n, clk[1] - clk[0], clk[2] - clk[1], clk[3] - clk[2], clk[4] - clk[3],
            clk[5] - clk[4], clk[5] - clk[0]);
+    printf("   worker 0 in A1 (cycles after the A0 barrier as seen by thread 0): item start %lld  u, qf done %lld  blocks stored %lld; A^-1 requested %lld cycles into phase B\n",
+           clk[16] - clk[2], clk[17] - clk[2], clk[18] - clk[2], clk[19] - clk[3]);
     printf("   inside B: entry %lld  elimination loop %lld  hand-over %lld  middle %lld  fence %lld  back substitution %lld  exit %lld\n",
            clk[10] - clk[3], clk[11] - clk[10], clk[12] - clk[11], clk[13] - clk[12], clk[14] - clk[13], clk[15] - clk[14],
            clk[4] - clk[15]);
