@@ -1,0 +1,16 @@
+#!/bin/bash
+# rocprofv3 kernel statistics behind the numbers in DESIGN.md / profiles/ (run on the GPU box; copies land in gpurun_out/)
+# usage: scripts/profile_round.sh <tag>   e.g. round1
+tag=${1:-round}
+cd "$(dirname "$0")/.." && export TMPDIR=/tmp
+run() {  # name, bench arguments...
+  name=$1; shift
+  rm -rf gpurun_out/prof_$name
+  rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_$name -- python3 bench.py "$@" > gpurun_out/prof_$name.log 2>&1
+  f=$(find gpurun_out/prof_$name -name '*kernel_stats.csv' | head -1)
+  [ -n "$f" ] && cp "$f" gpurun_out/${tag}_${name}_kernel_stats.csv
+}
+run bench_linear --steps 200 --warmup 20 --no-cpu-baseline --no-extras   # 1024 x 10 only: the roofline kernel at the bench size
+run bench_nonlinear_1024 --workload nonlinear --steps 50 --warmup 5 --no-cpu-baseline --no-extras
+run bench_nonlinear_8192 --workload nonlinear --paths 8192 --steps 30 --warmup 5 --no-cpu-baseline --no-extras
+python3 scripts/kstats.py gpurun_out/${tag}_*_kernel_stats.csv
