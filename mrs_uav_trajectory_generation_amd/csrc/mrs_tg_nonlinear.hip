@@ -624,6 +624,33 @@ __device__ __forceinline__ double group_sum(double v, int G) {
   return v;
 }
 
+// N sums at once: the levels (and their branches on G) are shared, the N dependent chains interleave.  Separate
+// group_sum calls cannot overlap, each carries its own control flow.
+template <int N>
+__device__ __forceinline__ void group_sum_n(double (&v)[N], int G) {
+#pragma unroll
+  for (int n = 0; n < N; ++n) v[n] += dpp_move<0xB1>(v[n]);
+  if (G >= 4) {
+#pragma unroll
+    for (int n = 0; n < N; ++n) v[n] += dpp_move<0x4E>(v[n]);
+  }
+  if (G >= 8) {
+#pragma unroll
+    for (int n = 0; n < N; ++n) v[n] += dpp_move<0x141>(v[n]);
+  }
+  if (G >= 16) {
+#pragma unroll
+    for (int n = 0; n < N; ++n) v[n] += dpp_move<0x140>(v[n]);
+  }
+  if (G >= 32) {
+#pragma unroll
+    for (int n = 0; n < N; ++n) {
+      const double a = row_value(v[n], 0) + row_value(v[n], 16), b = row_value(v[n], 32) + row_value(v[n], 48);
+      v[n] = (G == 64) ? a + b : ((threadIdx.x & 32) ? b : a);
+    }
+  }
+}
+
 __device__ __forceinline__ int group_and(int v, int G) {
   const unsigned long long m = __ballot(v != 0);
   const unsigned long long gm = (G == 64) ? ~0ull : (((1ull << G) - 1ull) << (threadIdx.x & ~(G - 1)));
@@ -643,10 +670,14 @@ __device__ __forceinline__ bool relstop(double vold, double vnew, double reltol,
   return dv < abstol || dv < reltol * (fabs(vnew) + fabs(vold)) * 0.5 || (reltol > 0 && vnew == vold);
 }
 
-// per-group LDS block (doubles): x, g, xn, gn, dir [5*Sb], s[M][Sb], y[M][Sb], rho[M], staged vertices
+// The optimiser's scalar state (f, alpha | neval, npairs, head, ret) is the same in every lane of a group; it is parked
+// in LDS while the objective is evaluated, so that it does not occupy registers there (the kernel sits on its 256-VGPR
+// cap and the compiler spilled exactly these to scratch memory, a global-memory round trip per reload).
+constexpr int kTickState = 4;  // doubles: f, alpha, then four ints
+// per-group LDS block (doubles): x, g, xn, gn, dir [5*Sb], s[M][Sb], y[M][Sb], rho[M + 1], tick state, staged vertices
 // [(Sb+1)*kVtxLds], staged segment records [Sb*kSegLds]
 __host__ __device__ constexpr int group_lds_doubles(int Sb) {
-  return (5 + 2 * kLbfgsM) * Sb + kLbfgsM + (Sb + 1) * kVtxLds + Sb * kSegLds;
+  return (5 + 2 * kLbfgsM) * Sb + (kLbfgsM + 1) + kTickState + (Sb + 1) * kVtxLds + Sb * kSegLds;
 }
 // cost_gradient_kernel: x, g [2*Sb], staged vertices
 __host__ __device__ constexpr int gradient_lds_doubles(int Sb) { return 2 * Sb + (Sb + 1) * kVtxLds + Sb * kSegLds; }
@@ -764,7 +795,9 @@ __device__ __forceinline__ void optimize_body(const BatchView& b, const Nonlinea
   double* sm = dir + Sb;            // [M][Sb]
   double* ym = sm + kLbfgsM * Sb;   // [M][Sb]
   double* rho = ym + kLbfgsM * Sb;  // [M]
-  double* vtx = rho + kLbfgsM;      // [(Sb + 1) * kVtxLds]
+  double* tick_f = rho + kLbfgsM + 1;                         // rho[kLbfgsM] = scaling from the newest pair (fast path)
+  int* tick_i = reinterpret_cast<int*>(tick_f + 2);
+  double* vtx = tick_f + kTickState;  // [(Sb + 1) * kVtxLds]
   double* seg = vtx + (size_t)(Sb + 1) * kVtxLds;  // [Sb * kSegLds]
   if (active && wave == 0) stage_vertices(mask, vals, pr.v0, S, vtx, g, G);
   __syncthreads();
@@ -784,6 +817,7 @@ __device__ __forceinline__ void optimize_body(const BatchView& b, const Nonlinea
   MRS_TG_PHASE_MARK(1);
 
   const int maxeval = prm.max_iterations;
+  const bool single = Sb <= G;  // uniform per workgroup
   int ret = -1;
   bool done = !active || bad;
   bool pair_ok = false;
@@ -826,6 +860,15 @@ __device__ __forceinline__ void optimize_body(const BatchView& b, const Nonlinea
 
   while (true) {
     if (__ballot(!done) == 0ull) break;
+    // park the scalar state (see kTickState)
+    if (g == 0) {
+      tick_f[0] = f;
+      tick_f[1] = alpha;
+      tick_i[0] = neval;
+      tick_i[1] = npairs;
+      tick_i[2] = head;
+      tick_i[3] = ret;
+    }
 
     // (1) one objective evaluation at the trial point
     double fn;
@@ -836,11 +879,102 @@ __device__ __forceinline__ void optimize_body(const BatchView& b, const Nonlinea
       if (two_wave) __syncthreads();  // the partner's hand-over barrier
     }
     __syncthreads();
+    f = tick_f[0];
+    alpha = tick_f[1];
+    neval = tick_i[0];
+    npairs = tick_i[1];
+    head = tick_i[2];
+    ret = tick_i[3];
+    first = neval == 0;
 #ifdef MRS_TG_PHASE_CLOCKS
     if (neval < 12) MRS_TG_PHASE_MARK(6 + 2 * neval);  // after evaluation #neval
 #endif
     bool new_dir = false;
-    if (!done) {
+    // Bookkeeping in registers when every lane of the group owns at most one element of the optimiser's vectors
+    // (Sb <= G: every path but the very long ones): x, g, dir live in LDS between ticks (the evaluation needs the
+    // registers) and are read / written once per tick; `xi_`, `gi_` carry them from the accept step to the direction.
+    double xi_ = 0.0, gi_ = 0.0;
+    const bool me = g < S;
+    if (single && !done) {
+      ++neval;
+      xi_ = me ? x[g] : 0.0;
+      gi_ = me ? gr[g] : 0.0;
+      const double xni = me ? xn[g] : 0.0, gni = me ? gn[g] : 0.0;
+      if (first) {
+        f = fn;
+        xi_ = xni;
+        gi_ = gni;
+        if (maxeval > 0 && neval >= maxeval) {
+          ret = 5;
+          done = true;
+        } else {
+          new_dir = true;
+        }
+      } else {
+        // slope and the curvature sums of the would-be pair in one batched reduction (the sums are wasted on a
+        // rejected step, which is cheaper than three more reductions on an accepted one)
+        const double si = xni - xi_, yi = gni - gi_;
+        double red4[4] = {gi_ * si, si * yi, si * si, yi * yi};
+        group_sum_n<4>(red4, G);
+        const double slope = red4[0];
+        if (fn <= f + 1e-4 * slope) {
+          int stop = 0;
+          if (relstop(f, fn, prm.f_rel, prm.f_abs)) {
+            stop = 3;
+          } else {
+            const int allx = me ? (relstop(xi_, xni, prm.x_rel, prm.x_abs) ? 1 : 0) : 1;
+            if (group_and(allx, G)) stop = 4;
+          }
+          const double sy = red4[1], ss = red4[2], yy = red4[3];
+          const bool budget_out = maxeval > 0 && neval >= maxeval;
+          int slot = -1;
+          if (!stop && !budget_out && sy > 1e-10 * sqrt(ss) * sqrt(yy)) {
+            if (npairs == kLbfgsM) {
+              slot = head;  // overwrite the oldest pair
+              head = (head + 1) % kLbfgsM;
+            } else {
+              slot = (head + npairs) % kLbfgsM;
+              ++npairs;
+            }
+          }
+          if (slot >= 0 && me) {
+            sm[slot * Sb + g] = si;
+            ym[slot * Sb + g] = yi;
+          }
+          if (slot >= 0 && g == 0) {
+            rho[slot] = 1.0 / sy;
+            rho[kLbfgsM] = sy / yy;  // the scaling of the initial Hessian, taken from the newest pair
+          }
+          xi_ = xni;
+          gi_ = gni;
+          f = fn;
+          if (stop) {
+            ret = stop;
+            done = true;
+          } else if (budget_out) {
+            ret = 5;
+            done = true;
+          } else {
+            new_dir = true;
+          }
+        } else if (maxeval > 0 && neval >= maxeval) {
+          xi_ = xni;  // budget ends on a rejected trial: the last evaluated point is what the reference keeps
+          ret = 5;
+          done = true;
+        } else {
+          alpha *= 0.5;
+          if (alpha < 1e-12) {
+            xi_ = xni;
+            ret = 4;
+            done = true;
+          }
+        }
+      }
+      if (me) {
+        x[g] = xi_;
+        gr[g] = gi_;
+      }
+    } else if (!done) {
       ++neval;
       if (first) {
         f = fn;
@@ -925,9 +1059,81 @@ __device__ __forceinline__ void optimize_body(const BatchView& b, const Nonlinea
       }
     }
     first = false;
+#ifdef MRS_TG_PHASE_CLOCKS
+    if (neval == 2) MRS_TG_PHASE_MARK(28);  // tick 1: accept step done
+#endif
     __syncthreads();
+#ifdef MRS_TG_PHASE_CLOCKS
+    if (neval == 2) MRS_TG_PHASE_MARK(29);
+#endif
 
     // (2) search direction: L-BFGS two-loop recursion, projected on the lower bound
+    if (single) {
+      double di = (me && !new_dir) ? dir[g] : 0.0;
+      if (new_dir) {
+        di = -gi_;
+        if (npairs > 0) {
+          // the pairs and their rho are read up front (independent of the recursion), the recursion runs in registers
+          double sk[kLbfgsM], yk[kLbfgsM], rk[kLbfgsM], al[kLbfgsM];
+#pragma unroll
+          for (int k = 0; k < kLbfgsM; ++k) {
+            const int id = (head + k) % kLbfgsM;
+            const bool have = k < npairs;
+            sk[k] = (have && me) ? sm[id * Sb + g] : 0.0;
+            yk[k] = (have && me) ? ym[id * Sb + g] : 0.0;
+            rk[k] = have ? rho[id] : 0.0;
+            al[k] = 0.0;
+          }
+#pragma unroll
+          for (int k = kLbfgsM - 1; k >= 0; --k)
+            if (k < npairs) {
+              al[k] = rk[k] * group_sum(sk[k] * di, G);
+              di -= al[k] * yk[k];
+            }
+          di *= rho[kLbfgsM];  // s^T y / y^T y of the newest pair, computed when it was stored
+#pragma unroll
+          for (int k = 0; k < kLbfgsM; ++k)
+            if (k < npairs) {
+              const double beta = rk[k] * group_sum(yk[k] * di, G);
+              di += (al[k] - beta) * sk[k];
+            }
+        }
+        if (xi_ <= kTimeLowerBound && di < 0.0) di = 0.0;
+        double red3[3] = {gi_ * di, xi_ * xi_, di * di};
+        group_sum_n<3>(red3, G);
+        double gd = red3[0];
+        const double nx = red3[1];
+        double nd = red3[2];
+        if (!(gd < 0.0)) {
+          // not a descent direction: projected steepest descent, forget the curvature pairs
+          double v = -gi_;
+          if (xi_ <= kTimeLowerBound && v < 0.0) v = 0.0;
+          di = v;
+          double red2[2] = {gi_ * v, v * v};
+          group_sum_n<2>(red2, G);
+          gd = red2[0];
+          nd = red2[1];
+          npairs = 0;
+          head = 0;
+          if (!(gd < 0.0)) {
+            ret = 1;
+            done = true;
+          }
+        }
+        alpha = 1.0;
+        if (!done && npairs == 0) {
+          // first trial step of a restart moves x by at most 10 % in norm
+          const double cap = 0.1 * sqrt(nx) / sqrt(nd);
+          if (cap < alpha) alpha = cap;
+        }
+        if (me) dir[g] = di;
+      }
+      // (3) next trial point
+      if (!done && me) {
+        if (!new_dir) xi_ = x[g];
+        xn[g] = fmax(xi_ + alpha * di, kTimeLowerBound);
+      }
+    } else {
     if (new_dir) {
       double al[kLbfgsM];
       for (int i = g; i < S; i += G) dir[i] = -gr[i];
@@ -990,6 +1196,10 @@ __device__ __forceinline__ void optimize_body(const BatchView& b, const Nonlinea
     // (3) next trial point
     if (!done)
       for (int i = g; i < S; i += G) xn[i] = fmax(x[i] + alpha * dir[i], kTimeLowerBound);
+    }
+#ifdef MRS_TG_PHASE_CLOCKS
+    if (neval == 2) MRS_TG_PHASE_MARK(30);  // tick 1: direction and trial point done
+#endif
     if (two_wave) {
       const bool all_done = __ballot(!done) == 0ull;
       if (lane == 0) pair_flags[0] = all_done ? 1 : 0;

@@ -153,6 +153,8 @@ int main(int argc, char** argv) {
     CK(hipMemcpyFromSymbol(clk, HIP_SYMBOL(g_phase_clock), sizeof(clk)));
     printf("nonlinear pipeline (outer loop + 2 solves + maxima + scaling): %.2f us; optimize_kernel middle workgroup: staging %lld, whole kernel %lld cycles\n",
            total * 1e3 / n, clk[1] - clk[0], clk[5] - clk[0]);
+    printf("  tick 1 in detail: accept step %lld, barrier %lld, direction + trial point %lld, flag + barrier %lld\n",
+           clk[28] - clk[8], clk[29] - clk[28], clk[30] - clk[29], clk[9] - clk[30]);
     for (int t = 0; t < 6; ++t)
       printf("  tick %d: evaluation %lld cycles, bookkeeping + direction %lld\n", t,
              clk[6 + 2 * t] - (t == 0 ? clk[1] : clk[5 + 2 * t]), clk[7 + 2 * t] - clk[6 + 2 * t]);
