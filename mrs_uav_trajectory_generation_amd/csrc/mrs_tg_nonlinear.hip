@@ -766,21 +766,23 @@ __device__ __forceinline__ void optimize_body(const BatchView& b, const Nonlinea
 #pragma unroll
   for (int i = 1; i < 5; ++i)
     if (i < bins.n && (int)blockIdx.x >= bins.block_begin[i]) bin = i;
-  const int G = bins.group[bin], q_begin = bins.q_begin[bin], q_count = bins.q_count[bin], Sb = bins.max_S[bin];
+  int G = bins.group[bin];  // not const: laundered at the top of every tick, see there
+  const int q_begin = bins.q_begin[bin], q_count = bins.q_count[bin], Sb = bins.max_S[bin];
   const int block_in_bin = (int)blockIdx.x - bins.block_begin[bin];
   // 64 threads: the wavefront that runs everything.  128 threads (DS = 4, one path per block): wavefront 1 is the
   // partner that runs the backward half sweeps of the two-sided evaluation and mirrors every barrier of wavefront 0.
   const bool two_wave = (DS == 4) && blockDim.x == 128;  // compile-time false for DS = 1: none of the partner code is emitted there
   const int wave = threadIdx.x >> 6;
   const int lane = threadIdx.x & 63;
-  const int g = lane & (G - 1);
+  int g = lane & (G - 1);
   const int grp = lane / G;
   const int per_block = 64 / G;
   const int qi = block_in_bin * per_block + grp;
   const bool active = qi < q_count;
   const int q = q_begin + (active ? qi : 0);
   const PathRef pr = path_at(b, q);
-  const int S = pr.S, d = prm.derivative;
+  int S = pr.S;
+  const int d = prm.derivative;
 
   double* hc = lds;  // [kBlockConsts], shared by the groups of the block
   if (wave == 0) stage_block_constants(d, hc, lane, 64);
@@ -870,7 +872,15 @@ __device__ __forceinline__ void optimize_body(const BatchView& b, const Nonlinea
       tick_i[3] = ret;
     }
 
-    // (1) one objective evaluation at the trial point
+    // (1) one objective evaluation at the trial point.  The lane coordinates go through an empty asm so that the
+    // dozens of lane predicates derived from them (k <= S, dim0 == 0, G >= 16, ...) are recomputed where they are
+    // used: hoisted out of the loop as 64-bit lane masks they overflowed the SGPR file (116 spilled SGPRs, each use
+    // two v_readlane_b32)
+    {
+      int Gv = G;
+      asm volatile("" : "+v"(g), "+v"(S), "+v"(Gv));
+      G = __builtin_amdgcn_readfirstlane(Gv);
+    }
     double fn;
     if (pair_ok) {
       fn = evaluate_pair(seg, hc, pair_state, S, d, xn, gn, g, !done);
