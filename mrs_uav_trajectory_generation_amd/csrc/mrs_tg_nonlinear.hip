@@ -148,15 +148,19 @@ __device__ __forceinline__ void stage_segments(const double* vtx, int S, int d, 
     }
     double* r = seg + (size_t)i * kSegLds;
 #pragma unroll
+    // A constant polynomial costs nothing, so HBAR[a][5] = -HBAR[a][0] (exactly, the constants are correctly rounded):
+    // the position terms depend on the difference of the two positions only.  Formed from the difference they carry
+    // a rounding error of eps |H dp| instead of eps |H p| -- at 10 m from the origin with 0.3 m between waypoints that
+    // is 30 times less noise in the right-hand sides and 1000 times less in f^T H f, the quantities whose difference is
+    // the cost.
     for (int q = 0; q < kD; ++q) {
-      const double f0s = vs[q], f0e = ve[q];
+      const double dp = vs[q] - ve[q];
 #pragma unroll
       for (int k = 0; k < kNB; ++k) {
-        r[q * 9 + k] = hb[kSlot0 + k][0] * f0s + hb[kSlot0 + k][kHalf] * f0e;
-        r[q * 9 + kNB + k] = hb[kHalf + kSlot0 + k][0] * f0s + hb[kHalf + kSlot0 + k][kHalf] * f0e;
+        r[q * 9 + k] = hb[kSlot0 + k][0] * dp;
+        r[q * 9 + kNB + k] = hb[kHalf + kSlot0 + k][0] * dp;
       }
-      const double w0 = hb[0][0] * f0s + hb[0][kHalf] * f0e, w5 = hb[kHalf][0] * f0s + hb[kHalf][kHalf] * f0e;
-      r[q * 9 + 8] = f0s * w0 + f0e * w5;
+      r[q * 9 + 8] = hb[0][0] * dp * dp;
     }
     r[36] = (double)kind;
   }
@@ -369,6 +373,12 @@ __device__ __forceinline__ double forward_cost(const double* vtx, const double* 
       double L[10], z[kNB][ND], W[kNB][kNB];
       const unsigned free_s = staged_vertex<ND>(vtx, i, dim0, fs);
       const unsigned free_e = staged_vertex<ND>(vtx, i + 1, dim0, fe);
+      // positions relative to the segment's start (see stage_segments): same cost, less cancellation noise
+#pragma unroll
+      for (int q = 0; q < ND; ++q) {
+        fe[0][q] -= fs[0][q];
+        fs[0][q] = 0.0;
+      }
       double Hs[kSym10];
       hessian_from_time(T, d, Hs);
       st.absorb_segment(Hs, fs, fe, free_s, free_e, L, z, W);

@@ -19,7 +19,8 @@ gen = sys.argv[4] if len(sys.argv) > 4 else "box"
 mode = int(sys.argv[5]) if len(sys.argv) > 5 else 2
 ctx = api.Context(0)
 
-batch = pr.random_mixed_batch(P, deriv) if gen == "mixed" else pr.random_batch(P, n_seg, seed0=0, derivative_to_optimize=deriv, generator=gen)
+seed0 = int(os.environ.get("SEED0", "0"))  # other seeds: other paths
+batch = pr.random_mixed_batch(P, deriv, seed0=seed0) if gen == "mixed" else pr.random_batch(P, n_seg, seed0=seed0, derivative_to_optimize=deriv, generator=gen)
 cap = 256
 out = ctx.solve_batch(batch, None, time_alloc_method=mode, sampling_dt=0.2, sample_capacity=cap)
 t0 = time.time()

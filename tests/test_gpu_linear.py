@@ -153,3 +153,20 @@ def test_full_size_properties_config2(gpu_ctx):
             snap = np.stack([util.eval_poly(out["coeffs"][s], x, 4) for x in tt])
             J += 0.5 * t[s] * np.sum(ws[:, None] * snap ** 2)
         assert abs(J - out["cost"][p]) < 1e-9 * abs(J)
+
+
+@pytest.mark.parametrize("n_paths", [64, 7000])
+def test_wild_segment_times_give_finite_output(gpu_ctx, n_paths):
+    """Segment times spread log-uniformly over 1e-2 .. 1e12 s inside one path (what a runaway feasibility scaling
+    leaves behind: path 8615 of the 65536-path benchmark batch has 2.7 s next to 9e11 s).  T^-7 then spans 1e98 within
+    one block-tridiagonal system, Schur complements come out <= 0 by rounding and 1/sqrt of one turned the whole path
+    into NaN.  Such pivots are now rejected (the variable stays 0, as with the reference's rank-revealing QR): every
+    output must be finite, in the tile kernel (64 paths) and the lane kernels (7000), blocks and fused."""
+    batch = pr.random_batch(n_paths, 10, seed0=31000)
+    rng = np.random.default_rng(5)
+    times = 10.0 ** rng.uniform(-2.0, 12.0, batch.n_segments)
+    for flags in (0, api.FLAG_FUSED_ASSEMBLY):
+        out = gpu_ctx.solve_batch(batch, times, flags=flags)
+        assert np.all(out["status"] == 1)
+        assert np.all(np.isfinite(out["coeffs"])), int((~np.isfinite(out["coeffs"])).sum())
+        assert np.all(np.isfinite(out["cost"]))
