@@ -14,6 +14,11 @@ status to rank 0 ("exactly one gather at the end") -- runs inside 
 `--gather every` gathers after every step instead (double-buffered on a side stream); for N > 1 that
 rate is reported next to the headline as extras.gather_every_step.
 
+Steps are independent batches, so `--in-flight` of them (default 2) are kept in flight per GPU, each on its own HIP
+stream with its own context and plan: a 1024-path batch leaves most of an MI355X idle (one wavefront per CU in the
+serial phase of the solve), and the assembly of batch k + 1 overlaps the solve of batch k.  Every step still does all
+of its work; `extras.one_batch_in_flight` is the same measurement with one stream (each step waits for the previous).
+
 Prints ONE JSON line (rank 0) with `roofline` (assembly kernel, HBM-write bound, HIP-event timed on the
 launch stream) and `cpu_baseline` (the C oracle timed on this box's host cores).
 """
@@ -46,6 +51,9 @@ def parse_args():
     ap.add_argument("--gather", choices=["final", "every"], default="final",
                     help="N > 1: gather the results to rank 0 once at the end of the timed steps (default) or after every step")
     ap.add_argument("--force-dist", action="store_true", help="initialise torch.distributed even for one rank (tests the RCCL path)")
+    ap.add_argument("--in-flight", type=int, default=2,
+                    help="independent batches in flight per GPU: steps are issued round-robin on this many HIP streams "
+                         "(one context + plan each); 1 = every step waits for the previous one")
     return ap.parse_args()
 
 
@@ -137,7 +145,17 @@ def main():
     # Output double buffer: results of step k are gathered to rank 0 on a side stream while step k+1 computes
     # (the gather is the job's only collective; RCCL over xGMI).  Coefficients, times and status share one
     # f64 buffer per slot so that the gather is a single collective.
-    n_slots = 2 if dist is not None else 1
+    n_lanes = max(1, args.in_flight)   # batches in flight: lane 0 = torch's current stream (ctx, plan), lanes 1.. = side streams
+    lane_stream = [torch.cuda.current_stream()] + [torch.cuda.Stream(device=dev) for _ in range(n_lanes - 1)]
+    lane_ctx, lane_plan = [ctx], [plan]
+    for st in lane_stream[1:]:
+        with torch.cuda.stream(st):
+            c = api.Context(dev.index)
+            c.use_torch_stream()
+            lane_ctx.append(c)
+            lane_plan.append(api.Plan(c, batch.seg_offsets))
+    n_slots = max(n_lanes, 2 if dist is not None else 1)   # slot s runs on lane s % n_lanes
+    active_lanes = [n_lanes]                               # extras.one_batch_in_flight sets this to 1
     packed = [torch.zeros(nS * 41 + P, dtype=torch.float64, device=dev) for _ in range(n_slots)]
     out_coeffs = [p[:nS * 40].view(nS, 4, 10) for p in packed]
     out_times = [p[nS * 40:nS * 41] for p in packed]
@@ -150,13 +168,31 @@ def main():
             for _ in range(n_slots)]
     slot_free = [None] * n_slots      # event: the gather that read this slot has finished
     step_no = [0]
+    # per-slot side outputs and the pre-bound solve calls (arguments converted once: a few us of host time per step)
+    slot_cost = [torch.zeros(P, dtype=torch.float64, device=dev) for _ in range(n_slots)]
+    slot_nsamp = [torch.zeros(P, dtype=torch.int32, device=dev) for _ in range(n_slots)]
+    slot_samples = [db.samples] + [torch.zeros_like(db.samples) for _ in range(n_slots - 1)]
+    bound = {}
 
-    def finish_step(slot, with_times):
+    def slot_call(kind, slot, lane):
+        key = (kind, slot, lane)
+        if key not in bound:
+            if kind == "linear":
+                bound[key] = lane_plan[lane].bind_solve(opt_lin, db.fixed_mask, db.fixed_values, t_fixed, out_coeffs[slot],
+                                                        status_i32[slot], slot_cost[slot])
+            else:
+                bound[key] = lane_plan[lane].bind_solve(opt_nl, db.fixed_mask, db.fixed_values, out_times[slot], out_coeffs[slot],
+                                                        status_i32[slot], slot_cost[slot], limits=db.limits,
+                                                        n_samples=slot_nsamp[slot], samples=slot_samples[slot])
+        return bound[key]
+
+    def finish_step(slot, lane):
         if dist is None:
             return
-        packed[slot][nS * 41:].copy_(status_i32[slot])          # int32 -> f64 tail of the packed buffer
-        ready = torch.cuda.Event()
-        ready.record()
+        with torch.cuda.stream(lane_stream[lane]):
+            packed[slot][nS * 41:].copy_(status_i32[slot])          # int32 -> f64 tail of the packed buffer
+            ready = torch.cuda.Event()
+            ready.record()
         with torch.cuda.stream(comm_stream):
             comm_stream.wait_event(ready)
             shard.gather_to_root(packed[slot], dist, bufs=recv[slot])
@@ -165,37 +201,42 @@ def main():
         slot_free[slot] = done
 
     def begin_step():
-        slot = step_no[0] % n_slots
+        """next slot and the lane (stream) it runs on; the lane waits until the gather that read the slot is done"""
+        lanes = active_lanes[0]
+        slots = max(lanes, 2 if dist is not None else 1)
+        slot = step_no[0] % slots
+        lane = slot % lanes
         step_no[0] += 1
         if slot_free[slot] is not None:
-            torch.cuda.current_stream().wait_event(slot_free[slot])
-        return slot
+            lane_stream[lane].wait_event(slot_free[slot])
+            slot_free[slot] = None
+        return slot, lane
 
     gather_every = [args.gather == "every"]
-    last_slot = [0]
+    last_slot = [(0, 0)]
 
     def step_linear():
-        slot = begin_step()
-        plan.solve(opt_lin, db.fixed_mask, db.fixed_values, t_fixed, out_coeffs[slot], status_i32[slot], db.cost)
-        last_slot[0] = slot
+        slot, lane = begin_step()
+        slot_call("linear", slot, lane)()
+        last_slot[0] = (slot, lane)
         if gather_every[0]:
-            finish_step(slot, False)
+            finish_step(slot, lane)
 
     def step_nonlinear():
-        slot = begin_step()
-        out_times[slot].copy_(t_init)   # the outer loop overwrites the times: restart from the same point
-        plan.solve(opt_nl, db.fixed_mask, db.fixed_values, out_times[slot], out_coeffs[slot], status_i32[slot], db.cost,
-                   limits=db.limits, n_samples=db.n_samples, samples=db.samples)
-        last_slot[0] = slot
+        slot, lane = begin_step()
+        with torch.cuda.stream(lane_stream[lane]):
+            out_times[slot].copy_(t_init)   # the outer loop overwrites the times: restart from the same point
+        slot_call("nonlinear", slot, lane)()
+        last_slot[0] = (slot, lane)
         if gather_every[0]:
-            finish_step(slot, True)
+            finish_step(slot, lane)
 
     def final_gather():
         """the job's closing collective: results of the last step -> rank 0 (no-op at N = 1 without --force-dist)"""
         if dist is None or gather_every[0]:
             return
-        finish_step(last_slot[0], True)
-        torch.cuda.current_stream().wait_event(slot_free[last_slot[0]])
+        finish_step(*last_slot[0])
+        torch.cuda.current_stream().wait_event(slot_free[last_slot[0][0]])
 
     steps_fn = {"linear": step_linear, "nonlinear": step_nonlinear}
     elapsed = time_steps(steps_fn[args.workload], args.steps, args.warmup, dist, torch, final_gather)
@@ -263,6 +304,17 @@ def main():
             ctx.solve_batch(batch, times_host)
         extras["host_buffer_call"] = dict(value=5 * P / (time.perf_counter() - t0), unit="trajectories/s",
                                           note="mrs_tg_solve_batch with host buffers, linear QP, includes PCIe copies")
+    if n_lanes > 1 and not args.no_extras:
+        # the same steps with one batch in flight: every step waits for the previous one (single stream)
+        torch.cuda.synchronize()
+        active_lanes[0] = 1
+        step_no[0] = 0
+        el1 = time_steps(steps_fn[args.workload], args.steps, 3, dist, torch, final_gather)
+        active_lanes[0] = n_lanes
+        step_no[0] = 0
+        if rank == 0:
+            extras["one_batch_in_flight"] = dict(value=P * world * args.steps / el1, unit="trajectories/s",
+                                                 ms_per_step=el1 / args.steps * 1e3)
     if not args.no_extras:
         other = "nonlinear" if args.workload == "linear" else "linear"
         k2 = max(5, args.steps // 10) if other == "nonlinear" else args.steps
@@ -346,7 +398,7 @@ def main():
                                           "fixed times, linear QP" if args.workload == "linear" else
                                           "BASELINE configs[2]: %d random %d-segment paths per GPU, Mellinger outer loop "
                                           "(<=10 evaluations) + feasibility scaling + sampling dt 0.2") % (P, args.segments),
-                                paths_per_gpu=P, segments=args.segments,
+                                paths_per_gpu=P, segments=args.segments, batches_in_flight=n_lanes,
                                 parallelism=("independent paths sharded per rank, no data-path collective; RCCL gather of "
                                              "the results to rank 0 %s, inside the timed region"
                                              % ("after every step" if args.gather == "every" else "once, after the last step"))
@@ -355,6 +407,10 @@ def main():
         import ctypes
         ctypes.CDLL(None).fflush(None)   # RCCL's banner sits in C stdio: keep the JSON line the last thing printed
         print(json.dumps(line), flush=True)
+    for pl in lane_plan[1:]:
+        pl.close()
+    for c in lane_ctx[1:]:
+        c.close()
     plan.close()
     ctx.close()
     if dist is not None:

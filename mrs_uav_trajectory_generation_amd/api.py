@@ -389,6 +389,23 @@ class Plan:
                                                   _t_ptr(status), _t_ptr(cost), _t_ptr(n_samples), _t_ptr(samples)),
                         "mrs_tg_plan_solve")
 
+    def bind_solve(self, opt, fixed_mask, fixed_values, seg_times, coeffs, status, cost=None, waypoints=None, limits=None,
+                   n_samples=None, samples=None):
+        """solve() with its arguments converted once: returns a callable that enqueues the same solve again (on the
+        context's stream) for a few microseconds of host time -- a server that keeps several batches in flight on
+        several streams issues steps faster than the GPU finishes them only if the per-call host cost is small.
+        The tensors must stay alive and in place for as long as the callable is used."""
+        keep = (opt, fixed_mask, fixed_values, seg_times, coeffs, status, cost, waypoints, limits, n_samples, samples)
+        args = (self._h, _t_ptr(waypoints), _t_ptr(fixed_mask), _t_ptr(fixed_values), _t_ptr(limits), C.byref(opt),
+                _t_ptr(seg_times), _t_ptr(coeffs), _t_ptr(status), _t_ptr(cost), _t_ptr(n_samples), _t_ptr(samples))
+        fn, check = self._L.mrs_tg_plan_solve, self.ctx._check
+
+        def enqueue(_keep=keep):
+            rc = fn(*args)
+            if rc:
+                check(rc, "mrs_tg_plan_solve")
+        return enqueue
+
     def cost_gradient(self, derivative, fixed_mask, fixed_values, seg_times, cost, grad):
         self.ctx._check(self._L.mrs_tg_plan_cost_gradient(self._h, int(derivative), _t_ptr(fixed_mask),
                                                           _t_ptr(fixed_values), _t_ptr(seg_times), _t_ptr(cost),
