@@ -55,6 +55,11 @@ __device__ __forceinline__ int xcd_contiguous_index(unsigned bid, unsigned grid)
   return (int)(xcd * per + (xcd < rem ? xcd : rem) + idx);
 }
 
+// LDS accumulation (ds_add_f64); the callers add exactly two terms per slot, so the result does not depend on the order
+__device__ __forceinline__ void lds_add(double* p, double v) {
+  __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+
 static __constant__ double c_abar_inv[kN][kN] = MRS_TG_ABAR_INV_INIT;
 static __constant__ double c_hbar[kHalf][kN][kN] = MRS_TG_HBAR_INIT;
 

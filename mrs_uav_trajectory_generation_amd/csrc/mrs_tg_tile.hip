@@ -29,16 +29,21 @@
 
 namespace mrs_tg {
 
-// LDS record sizes (doubles)
-constexpr int kSegRec = 10 + 16 + 10 + 16 + 16 + 4;  // HssM, EM, HeeM, ustart[r][dim], uend[r][dim], qf[dim] = 72
-constexpr int kVtxRec = 42 + 20 + 2;                 // L[10] W[16] z[4][4] | d[5][4] | free bits, flags
+// LDS record sizes (doubles).  A vertex's diagonal block D_v = Hee(segment v-1) + Hss(segment v) and right-hand side
+// Y_v = uend(v-1) + ustart(v) are accumulated into the vertex record by the segment lanes of phase A1 (LDS atomic
+// adds of two terms each: commutative, so bit-reproducible); phase B reads them from the slots it then overwrites
+// with L and z.  (An earlier layout kept the four pieces in the segment records and summed them inside the serial
+// chain: 11.4 KB per path instead of 7.5 KB, one workgroup per CU instead of two at eight paths per tile.)
+constexpr int kSegRec = 16 + 4;            // coupling block EM (as its consumer reads it), qf[dim]
+constexpr int kVtxRec = 42 + 20 + 2;       // D[10] -> L[10] | W[16] | Y[4][4] -> z[4][4] | d[5][4] | free bits, flags
+constexpr int kHandOver = 10 + 16;         // per path: the backward direction's Schur update for the middle vertex
 
 // Per-path LDS stride.  Both record sizes are multiples of 8 doubles, so the unpadded stride put every path of a
 // tile on the same banks ((a/4) mod 32 for ds_read2_b64 / ds_write*): the 16-lane groups of phase B (two paths x two
 // directions) then hit one bank with up to four distinct addresses.  A stride of 4 (mod 16) doubles shifts each
 // path by 8 banks.
 __host__ __device__ constexpr int tile_path_doubles(int S) {
-  const int base = S * kSegRec + (S + 1) * kVtxRec;
+  const int base = S * kSegRec + (S + 1) * kVtxRec + kHandOver;
   return base + ((4 - base % 16) + 16) % 16;
 }
 
@@ -78,11 +83,7 @@ __global__ __launch_bounds__(kTileThreads) void solve_tile_kernel(BatchView b, i
   }
   auto seg_rec = [&](int t, int i) { return lds + (size_t)t * PS + (size_t)i * kSegRec; };
   auto vtx_rec = [&](int t, int v) { return lds + (size_t)t * PS + (size_t)Smax * kSegRec + (size_t)v * kVtxRec; };
-  // an all-zero segment record stands in for "no segment on this side" (vertex 0 has no left segment, vertex S no
-  // right one), so that phase B loads both neighbours unconditionally: a branch per matrix entry around an LDS load
-  // serialises the load latencies (measured: 5300 -> 2500 shader cycles per elimination step)
-  double* zero_rec = lds + (size_t)TP * PS;
-  if (tid >= 64 && tid < 64 + kSegRec) zero_rec[tid - 64] = 0.0;
+  auto hand_over = [&](int t) { return lds + (size_t)t * PS + (size_t)Smax * kSegRec + (size_t)(Smax + 1) * kVtxRec; };
   __syncthreads();
   MRS_TG_PHASE_MARK(1);
 
@@ -120,14 +121,16 @@ __global__ __launch_bounds__(kTileThreads) void solve_tile_kernel(BatchView b, i
     }
   }
 
-  // ---- A0: vertex constraints -> d (constrained values, 0 where free), free bits; the hand-over area of every
-  // path's middle vertex is zeroed (phase B reads it even when nothing was handed over)
-  for (int e = tid; e < n_here * 42; e += kTileThreads) {
-    const int t = e / 42;
-    vtx_rec(t, s_S[t] / 2)[e % 42] = 0.0;
-  }
+  // ---- A0: vertex constraints -> d (constrained values, 0 where free), free bits; the vertex accumulators and the
+  // hand-over area of every path are zeroed (phase B reads the latter even when nothing was handed over)
+  for (int e = tid; e < n_here * kHandOver; e += kTileThreads) hand_over(e / kHandOver)[e % kHandOver] = 0.0;
   auto store_vertex = [&](int t, int v, const double (&f)[kHalf][kD], unsigned fb, bool pos_fixed) {
     double* r = vtx_rec(t, v);
+    // accumulators of phase A1
+#pragma unroll
+    for (int e = 0; e < 10; ++e) r[e] = 0.0;
+#pragma unroll
+    for (int e = 0; e < kNB * kD; ++e) r[26 + e] = 0.0;
 #pragma unroll
     for (int k = 0; k < kHalf; ++k)
 #pragma unroll
@@ -169,6 +172,8 @@ __global__ __launch_bounds__(kTileThreads) void solve_tile_kernel(BatchView b, i
         f[kHalf + k] = ve[42 + k * kD + dim];
       }
       double* rec = seg_rec(t, i);
+      double* acc_s = const_cast<double*>(vs);  // vertex records of the two ends (accumulators)
+      double* acc_e = const_cast<double*>(ve);
       double qf = 0.0;
 #pragma unroll
       for (int a = 0; a < kN; ++a) {
@@ -176,10 +181,12 @@ __global__ __launch_bounds__(kTileThreads) void solve_tile_kernel(BatchView b, i
 #pragma unroll
         for (int c = 0; c < kN; ++c) u += Hs[sym10(a, c)] * f[c];
         qf += f[a] * u;
-        if (a >= kSlot0 && a < kHalf) rec[36 + (a - kSlot0) * kD + dim] = ((free_s >> (a - kSlot0)) & 1u) ? u : 0.0;
-        if (a >= kHalf + kSlot0) rec[52 + (a - kHalf - kSlot0) * kD + dim] = ((free_e >> (a - kHalf - kSlot0)) & 1u) ? u : 0.0;
+        if (a >= kSlot0 && a < kHalf)
+          lds_add(acc_s + 26 + (a - kSlot0) * kD + dim, ((free_s >> (a - kSlot0)) & 1u) ? u : 0.0);
+        if (a >= kHalf + kSlot0)
+          lds_add(acc_e + 26 + (a - kHalf - kSlot0) * kD + dim, ((free_e >> (a - kHalf - kSlot0)) & 1u) ? u : 0.0);
       }
-      rec[68 + dim] = qf;
+      rec[16 + dim] = qf;
       MRS_TG_PHASE_MARK_T(17, 64);
       if (dim == 0) {
         // masked blocks D_s H D_e with D = diag(free bits) as 0.0 / 1.0 factors: two multiplications per entry
@@ -195,15 +202,15 @@ __global__ __launch_bounds__(kTileThreads) void solve_tile_kernel(BatchView b, i
         for (int r = 0; r < kNB; ++r) {
 #pragma unroll
           for (int c = 0; c <= r; ++c) {
-            rec[tri(r, c)] = (ms[r] * ms[c]) * Hs[sym10(kSlot0 + r, kSlot0 + c)];
-            rec[26 + tri(r, c)] = (me[r] * me[c]) * Hs[sym10(kHalf + kSlot0 + r, kHalf + kSlot0 + c)];
+            lds_add(acc_s + tri(r, c), (ms[r] * ms[c]) * Hs[sym10(kSlot0 + r, kSlot0 + c)]);
+            lds_add(acc_e + tri(r, c), (me[r] * me[c]) * Hs[sym10(kHalf + kSlot0 + r, kHalf + kSlot0 + c)]);
           }
           // the coupling block is stored the way its consumer reads it: segments left of the middle vertex belong to
           // the forward direction of phase B (E[r][c]), the others to the backward direction (E transposed)
 #pragma unroll
           for (int c = 0; c < kNB; ++c) {
             const double val = (ms[r] * me[c]) * Hs[sym10(kSlot0 + r, kHalf + kSlot0 + c)];
-            rec[10 + (transposed ? c * kNB + r : r * kNB + c)] = val;
+            rec[transposed ? c * kNB + r : r * kNB + c] = val;
           }
         }
       }
@@ -251,32 +258,25 @@ __global__ __launch_bounds__(kTileThreads) void solve_tile_kernel(BatchView b, i
     // (Loading them one step ahead into a second register set changed nothing: the step is bound by its ~220
     // in-order instructions, not by the LDS latency.)
     struct StepIn {
-      double dl[10], dr[10], yl[kNB], yr[kNB], E[kNB][kNB];
+      double D[10], Y[kNB], E[kNB][kNB];
       unsigned fb;
     };
     auto load_step = [&](int v, StepIn& in, auto inner_tag) {
       constexpr bool INNER = decltype(inner_tag)::value;
       const double* vr = vtx_rec(t, v);
       in.fb = (unsigned)vr[62];
-      const double* left = (v > 0) ? seg_rec(t, v - 1) : zero_rec;   // segment v-1 ends at v
-      const double* right = (v < S) ? seg_rec(t, v) : zero_rec;      // segment v starts at v
-      const double* cb = dir ? left : right;                         // coupling towards the middle
 #pragma unroll
-      for (int e = 0; e < 10; ++e) {
-        in.dl[e] = left[26 + e];
-        in.dr[e] = right[e];
-      }
+      for (int e = 0; e < 10; ++e) in.D[e] = vr[e];
 #pragma unroll
-      for (int r = 0; r < kNB; ++r) {
-        in.yl[r] = left[52 + r * kD + dim];
-        in.yr[r] = right[36 + r * kD + dim];
-      }
+      for (int r = 0; r < kNB; ++r) in.Y[r] = vr[26 + r * kD + dim];
       if (INNER) {
-        // direction 0: E~_v[r][c]; direction 1: E~_{v-1} transposed -- phase A1 stored it that way
+        // coupling towards the middle: direction 0 reads E~_v[r][c] of segment v, direction 1 E~_{v-1} transposed of
+        // segment v - 1 -- phase A1 stored it that way
+        const double* cb = seg_rec(t, dir ? v - 1 : v);
 #pragma unroll
         for (int r = 0; r < kNB; ++r)
 #pragma unroll
-          for (int c = 0; c < kNB; ++c) in.E[r][c] = cb[10 + r * kNB + c];
+          for (int c = 0; c < kNB; ++c) in.E[r][c] = cb[r * kNB + c];
       }
     };
     auto eliminate = [&](int v, const StepIn& in, auto inner_tag, auto middle_tag) {
@@ -285,14 +285,15 @@ __global__ __launch_bounds__(kTileThreads) void solve_tile_kernel(BatchView b, i
       const unsigned fb = in.fb;
       double Sm[10], y[kNB];
 #pragma unroll
-      for (int e = 0; e < 10; ++e) Sm[e] = in.dl[e] + in.dr[e];
+      for (int e = 0; e < 10; ++e) Sm[e] = in.D[e];
 #pragma unroll
-      for (int r = 0; r < kNB; ++r) y[r] = -(in.yl[r] + in.yr[r]);
+      for (int r = 0; r < kNB; ++r) y[r] = -in.Y[r];
       if (MIDDLE) {
+        const double* ho = hand_over(t);
 #pragma unroll
-        for (int e = 0; e < 10; ++e) Sm[e] -= vr[e];
+        for (int e = 0; e < 10; ++e) Sm[e] -= ho[e];
 #pragma unroll
-        for (int r = 0; r < kNB; ++r) y[r] -= vr[26 + r * kD + dim];
+        for (int r = 0; r < kNB; ++r) y[r] -= ho[10 + r * kD + dim];
       }
 #pragma unroll
       for (int r = 0; r < kNB; ++r) {
@@ -391,7 +392,7 @@ __global__ __launch_bounds__(kTileThreads) void solve_tile_kernel(BatchView b, i
     // direction 1 hands its Schur update W^T W and right-hand-side update W^T z for the middle vertex over
     // through that vertex's (still unused) record
     if (dir == 1 && len > 0) {
-      double* vm = vtx_rec(t, m);
+      double* vm = hand_over(t);
       if (dim == 0) {
 #pragma unroll
         for (int r = 0; r < kNB; ++r)
@@ -408,7 +409,7 @@ __global__ __launch_bounds__(kTileThreads) void solve_tile_kernel(BatchView b, i
         double s = 0.0;
 #pragma unroll
         for (int k = 0; k < kNB; ++k) s += Wp[k][r] * zp[k];
-        vm[26 + r * kD + dim] = s;
+        vm[10 + r * kD + dim] = s;
       }
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
@@ -488,10 +489,10 @@ __global__ __launch_bounds__(kTileThreads) void solve_tile_kernel(BatchView b, i
     double qa = 0.0, qb = 0.0;
     int i = i0;
     for (; i + 1 < i1; i += 2) {
-      qa += seg_rec(t, i)[68 + dim];
-      qb += seg_rec(t, i + 1)[68 + dim];
+      qa += seg_rec(t, i)[16 + dim];
+      qb += seg_rec(t, i + 1)[16 + dim];
     }
-    if (i < i1) qa += seg_rec(t, i)[68 + dim];
+    if (i < i1) qa += seg_rec(t, i)[16 + dim];
     double qf = qa + qb;
     qf += __shfl_xor(qf, kD, 64);
     double cst = 0.5 * (qf - red_both);
@@ -551,27 +552,30 @@ __global__ __launch_bounds__(kTileThreads) void solve_tile_kernel(BatchView b, i
 static constexpr size_t kTileLdsBudget = 144 * 1024;
 
 bool tile_kernel_applies(const BatchView& b, bool fused) {
-  // measured, 10 segments, linear step / nonlinear pipeline in us (tile vs one-lane-per-(path, dimension) kernel):
-  //   blocks: 4096 paths 46 vs 62, 6144 64 vs 74, 8192 82 vs 82, 12288 124 vs 146, 16384 164 vs 205, 32768 368 vs 386,
-  //           65536 736 vs 579 (beyond the Infinity Cache the tile's 32-64-byte pieces of every line cost more);
-  //   fused:  8192 570 vs 552, 16384 942 vs 884, 32768 1700 vs 1682 (no blocks to fetch: the lanes win earlier)
-  int max_paths = fused ? 6144 : 32768;
-  if (const char* e = std::getenv("MRS_TG_TILE_MAX_PATHS")) max_paths = std::atoi(e);  // tuning knob (scripts/sweep_tile.sh)
+  // measured, 10 segments, one batch in flight, us per linear step / nonlinear pipeline (tile vs lane kernels):
+  //   blocks: 8192 paths 61 vs 83, 32768 271 vs 385, 65536 516 vs 572;
+  //   fused:  4096 316 vs 343, 8192 513 vs 537, 16384 840 vs 886, 32768 1498 vs 1639, 65536 2861 vs 2872
+  // -- since the vertex-accumulator layout (two workgroups per CU at eight paths per tile) the tile kernel wins at
+  // every size tried on uniform batches.  Ragged batches (3..30 segments: every tile is sized and looped for the
+  // longest path of the batch) cross over earlier: blocks 4096 paths 130 vs 163, 8192 225 vs 234, 16384 478 vs 349;
+  // fused 2048 779 vs 857, 4096 744 vs 736, 8192 1070 vs 960 (scripts/ragged_tile_sweep.py).
+  long long max_paths = (b.uniform_S > 0) ? (1ll << 40) : (fused ? 4096 : 8192);
+  if (const char* e = std::getenv("MRS_TG_TILE_MAX_PATHS")) max_paths = std::atoll(e);  // tuning knob (scripts/sweep_tile.sh)
   if (b.n_paths == 0 || b.n_paths > max_paths) return false;
   // 32-bit byte offsets into the block buffers (load_H_blocks32)
   if (!fused && (unsigned long long)b.max_segments * 800ull * (unsigned long long)b.n_paths > 0xFFFFFFFFull) return false;
-  return (size_t)tile_path_doubles(b.max_segments) * sizeof(double) + kSegRec * sizeof(double) <= kTileLdsBudget;
+  return (size_t)tile_path_doubles(b.max_segments) * sizeof(double) <= kTileLdsBudget;
 }
 
 hipError_t launch_solve_tile(const BatchView& b, int d, bool fused, const uint8_t* mask, const double* vals,
                              const double* seg_times, const double* H, const double* Ainv, double* coeffs,
                              int32_t* status, double* cost, const int32_t* status_in, hipStream_t stream) {
   const size_t per_path = (size_t)tile_path_doubles(b.max_segments) * sizeof(double);
-  int TP = (int)((kTileLdsBudget - kSegRec * sizeof(double)) / per_path);
+  int TP = (int)(kTileLdsBudget / per_path);
   if (TP > 8) TP = 8;  // phase B runs eight lanes per path inside wavefront 0
   // more, smaller tiles so that every CU gets work (256 CUs) and several tiles share a CU
   while (TP > 4 && (b.n_paths + TP - 1) / TP < 512) TP >>= 1;
-  const size_t lds_bytes = per_path * (size_t)TP + kSegRec * sizeof(double);  // + the all-zero segment record
+  const size_t lds_bytes = per_path * (size_t)TP;
   const unsigned grid = (unsigned)((b.n_paths + TP - 1) / TP);
   if (fused) {
     hipError_t e = hipFuncSetAttribute((const void*)solve_tile_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize,

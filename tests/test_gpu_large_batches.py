@@ -1,6 +1,6 @@
 """Kernel variants that only engage on larger batches (the library picks the lane mapping from the batch
-size): one-lane-per-dimension solve (fused pipeline: 6144 < P <= 32768; materialised blocks: only when the tile does
-not fit the LDS, or forced with MRS_TG_TILE_MAX_PATHS), one-lane-per-path solve (P > 32768), compact outer-loop
+size, or that are forced): the lane solve kernels -- one lane per (path, dimension) up to 32768 paths, one lane per path
+beyond -- run when a path is too long for an LDS tile or when MRS_TG_TILE_MAX_PATHS forces them; compact outer-loop
 mapping (P > 3072).  Parity is checked against the oracle on a strided subset (the oracle needs
 ~30 us per linear path and ~2 ms per nonlinear path), and on every path through size-independent
 properties: continuity, constraints, linearity, agreement between the materialised-block and the fused
@@ -23,7 +23,7 @@ def _subset_vs_oracle(batch, out, idx, tol):
     assert util.coeff_error(got, ref["coeffs"], sub.seg_offsets) < tol
 
 
-@pytest.mark.parametrize("n_paths,tile_max", [(2304, None), (6400, None), (6400, 0), (33024, None)])
+@pytest.mark.parametrize("n_paths,tile_max", [(2304, None), (6400, None), (6400, 0), (33024, None), (33024, 0)])
 def test_linear_large_batches(gpu_ctx, monkeypatch, n_paths, tile_max):
     if tile_max is not None:
         monkeypatch.setenv("MRS_TG_TILE_MAX_PATHS", str(tile_max))  # read at every call: both pipelines on the lane kernels
