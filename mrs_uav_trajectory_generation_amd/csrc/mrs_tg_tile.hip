@@ -9,15 +9,17 @@
 // One-lane-per-path kernels run both on the serial lane.  Here a workgroup owns a tile of TP paths, stages
 // everything in LDS and runs
 //   A0  one lane per vertex:               constraints -> f, free masks                     (parallel)
-//   A1  one lane per (segment, dimension): blocks (from HBM or from T) -> u, masked blocks  (parallel)
+//   A1  one lane per (segment, dimension): blocks (from HBM or from T) -> u and masked blocks, added into the
+//       records of the segment's two end vertices (LDS atomic adds)                          (parallel)
 //   B   eight lanes per path (direction x dimension): two-sided elimination of the vertex chain on the
 //       LDS-resident 4x4 blocks, meeting at the middle vertex                                  (serial, S/2 deep)
 //   C   one lane per (segment, dimension): c = A^-1 d -> global coefficients                (parallel)
 // so the serial lanes execute only the chain (~1/3 of the instructions of the one-lane kernel).
-// Wavefront 0 of the 256-thread workgroup owns A0 and B; wavefronts 1-3 ("workers") own A1 and C.  The workers'
-// global loads never wait for a phase boundary: the blocks (or segment time) of a worker's first A1 item are
-// requested before A0 runs, and the A^-1 rows of its first C item before B runs, so both latencies hide behind
-// the other wavefront's phase.
+// Wavefront 0 of the 256-thread workgroup owns A0 and B (and, beside phase C, the cost and status of its paths);
+// wavefronts 1-3 ("workers") own A1 and C.  The workers' global loads never wait for a phase boundary: the blocks (or
+// segment time) of a worker's first A1 item are requested before A0 runs and the A^-1 rows of its first C item right
+// after the barrier that starts B, and the barriers order LDS traffic only, so both latencies hide behind the other
+// wavefront's phase.  Tiles are numbered so that each XCD owns a contiguous range of them.
 #include <hip/hip_runtime.h>
 
 #include <cstdint>
