@@ -53,8 +53,11 @@ __host__ __device__ constexpr int tile_path_doubles(int S) {
 constexpr int kTileThreads = 256;
 constexpr int kTileWorkers = kTileThreads - 64;
 
+// Two workgroups per CU (eight wavefronts, two per SIMD) need <= 256 VGPRs.  The blocks variant sits just below that
+// (248); the bound keeps it there -- a change that cost 14 more registers silently took the larger batches back to one
+// workgroup per CU (8192 x 10 linear 61 -> 76 us).
 template <bool FUSED>
-__global__ __launch_bounds__(kTileThreads) void solve_tile_kernel(BatchView b, int d, int TP, int Smax,
+__global__ __launch_bounds__(kTileThreads, 2) void solve_tile_kernel(BatchView b, int d, int TP, int Smax,
                                                                   const uint8_t* __restrict__ mask,
                                                                   const double* __restrict__ vals,
                                                                   const double* __restrict__ seg_times,
