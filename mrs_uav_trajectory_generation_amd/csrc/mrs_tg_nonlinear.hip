@@ -548,9 +548,13 @@ __device__ __forceinline__ double max_mag2(const double (&cb)[NDIM][kN]) {
       best = fmax(best, mm);
       if (gg > 0.0) lo = t;
       else hi = t;
-      double tn = (dd < 0.0) ? t - gg / dd : 0.5 * (lo + hi);
+      // Newton step with a refined reciprocal instead of the IEEE division sequence (a step that is off by an ulp is
+      // still a Newton step; the bracket test below safeguards it)
+      double tn = (dd < 0.0) ? fma(-gg, rcp_refined(dd), t) : 0.5 * (lo + hi);
       if (!(tn > lo && tn < hi)) tn = 0.5 * (lo + hi);
-      if (fabs(tn - t) < 1e-9) break;
+      // the last evaluated abscissa is within |tn - t| of the stationary point, and the value error is quadratic in it:
+      // 3e-7 leaves (m2''/m2) * 1e-13 / 2 < 1e-10 even for a peak as narrow as a grid cell (m2''/m2 ~ 1e3)
+      if (fabs(tn - t) < 3e-7) break;
       t = tn;
     }
   }
