@@ -94,10 +94,15 @@ __global__ __launch_bounds__(kTileThreads, 2) void solve_tile_kernel(BatchView b
 
   // item = (segment i, path t of the tile, dimension): the unit of the parallel phases A1 and C
   const int n_items = n_here * Smax * kD;
+  // q / n_here for q < 8192 without an integer division (~40 instructions each on this hardware, and every item of
+  // A1 and C started with two of them): floor(q * ceil(2^16 / n) / 2^16) is exact while q * n < 2^16
+  const unsigned inv_n = (65536u + (unsigned)n_here - 1u) / (unsigned)n_here;  // once per workgroup, wave-uniform
+  auto div_n = [&](int q) { return (int)(((unsigned)q * inv_n) >> 16); };
   auto item_valid = [&](int item, int& t, int& i, int& dim) {
     dim = item % kD;
-    t = (item / kD) % n_here;
-    i = item / (kD * n_here);
+    const int q = item / kD;  // (segment, path) index: path fastest
+    i = div_n(q);
+    t = q - i * n_here;
     return item < n_items && i < s_S[t];
   };
 
@@ -108,8 +113,9 @@ __global__ __launch_bounds__(kTileThreads, 2) void solve_tile_kernel(BatchView b
   double f_first[kHalf][kD];
   unsigned fb_first = 0;
   bool pos_first = false;
-  const bool vertex_first = tid < n_vertex_items && (tid / n_here) <= s_S[tid % n_here];
-  if (vertex_first) fb_first = load_vertex<kD>(mask, vals, s_v0[tid % n_here] + tid / n_here, 0, f_first, pos_first);
+  const int v_first = div_n(tid), t_first = tid - v_first * n_here;
+  const bool vertex_first = tid < n_vertex_items && v_first <= s_S[t_first];
+  if (vertex_first) fb_first = load_vertex<kD>(mask, vals, s_v0[t_first] + v_first, 0, f_first, pos_first);
 
   // workers: request the inputs of their first A1 item now; they arrive while A0 runs
   double Hs[kSym10];
@@ -143,9 +149,9 @@ __global__ __launch_bounds__(kTileThreads, 2) void solve_tile_kernel(BatchView b
     r[62] = (double)fb;
     r[63] = pos_fixed ? 1.0 : 0.0;
   };
-  if (vertex_first) store_vertex(tid % n_here, tid / n_here, f_first, fb_first, pos_first);
+  if (vertex_first) store_vertex(t_first, v_first, f_first, fb_first, pos_first);
   for (int item = tid + kTileThreads; item < n_vertex_items; item += kTileThreads) {
-    const int t = item % n_here, v = item / n_here;
+    const int v = div_n(item), t = item - v * n_here;
     if (v > s_S[t]) continue;
     double f[kHalf][kD];
     bool pos_fixed;
