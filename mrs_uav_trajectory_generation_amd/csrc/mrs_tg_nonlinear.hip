@@ -703,10 +703,11 @@ template <int DS>
 __device__ __forceinline__ double evaluate_objective(const double* vtx, const double* seg, const double* hc, int S, int d,
                                                      const double* pt, double* grad, int g, int G, bool active) {
   constexpr int ND = kD / DS;
-  const int kl = G / DS;  // time vectors handled per round
+  const int kl_shift = __builtin_ctz((unsigned)G) - (DS == 4 ? 2 : 0);  // G is a power of two >= DS: no integer division
+  const int kl = 1 << kl_shift;  // time vectors handled per round
   const int kk = g / DS, dim0 = (g % DS) * ND;
   double J0 = 0.0;
-  const int rounds = (S + 1 + kl - 1) / kl;
+  const int rounds = (S + kl) >> kl_shift;
   for (int r = 0; r < rounds; ++r) {
     const int k = kk + r * kl;
     double Jk = 0.0, qfk = 0.0;
@@ -789,8 +790,9 @@ __device__ __forceinline__ void optimize_body(const BatchView& b, const Nonlinea
   const int wave = threadIdx.x >> 6;
   const int lane = threadIdx.x & 63;
   int g = lane & (G - 1);
-  const int grp = lane / G;
-  const int per_block = 64 / G;
+  const int g_shift = __builtin_ctz((unsigned)G);  // G is a power of two
+  const int grp = lane >> g_shift;
+  const int per_block = 64 >> g_shift;
   const int qi = block_in_bin * per_block + grp;
   const bool active = qi < q_count;
   const int q = q_begin + (active ? qi : 0);
@@ -1297,8 +1299,9 @@ __global__ __launch_bounds__(64) void cost_gradient_kernel(BatchView b, int d, i
   extern __shared__ double lds[];
   const int lane = threadIdx.x;
   const int g = lane & (G - 1);
-  const int grp = lane / G;
-  const int qi = blockIdx.x * (64 / G) + grp;
+  const int g_shift = __builtin_ctz((unsigned)G);  // G is a power of two
+  const int grp = lane >> g_shift;
+  const int qi = blockIdx.x * (64 >> g_shift) + grp;
   const bool active = qi < q_count;
   const PathRef pr = path_at(b, q_begin + (active ? qi : 0));
   double* hc = lds;
