@@ -63,13 +63,29 @@ def test_linear_ragged_large_batch(gpu_ctx):
     _subset_vs_oracle(small, outs, list(range(0, 4500, 41)), 1e-7)
 
 
-def test_long_paths_fall_back_to_per_lane_kernel(gpu_ctx):
-    batch = pr.random_batch(6, 120, seed0=8100)             # 120 segments: too large for the LDS tile
+def test_long_paths_one_per_tile(gpu_ctx):
+    batch = pr.random_batch(6, 120, seed0=8100)             # 120 segments: one path per LDS tile
     out = gpu_ctx.solve_batch(batch, None)
     assert np.all(out["status"] == 1)
     _subset_vs_oracle(batch, out, list(range(6)), 1e-6)
     nl = gpu_ctx.solve_batch(batch.select([0, 1]), None, time_alloc_method=api.TIME_ALLOC_MELLINGER)
     assert np.all(np.isin(nl["status"], (1, 3, 4, 5))) and np.all(np.isfinite(nl["coeffs"]))
+
+
+@pytest.mark.parametrize("n_seg", [129, 200, 218, 219])
+def test_long_paths_tile_and_lane_kernels_agree(gpu_ctx, monkeypatch, n_seg):
+    """Beyond the oracle's 128 segments: an LDS tile holds a path of up to 218 segments (one path per workgroup);
+    longer ones go to the lane kernels.  Both must give the same trajectory, continuous and on its constraints."""
+    batch = pr.random_batch(3, n_seg, seed0=8300 + n_seg)
+    out = gpu_ctx.solve_batch(batch, None)
+    fused = gpu_ctx.solve_batch(batch, out["times"], flags=api.FLAG_FUSED_ASSEMBLY)
+    monkeypatch.setenv("MRS_TG_TILE_MAX_PATHS", "0")
+    lane = gpu_ctx.solve_batch(batch, out["times"])
+    assert np.all(out["status"] == 1) and np.all(lane["status"] == 1)
+    assert util.coeff_error(out["coeffs"], lane["coeffs"], batch.seg_offsets) < 1e-8
+    assert util.coeff_error(fused["coeffs"], lane["coeffs"], batch.seg_offsets) < 1e-8
+    assert util.continuity_defect(batch, out["coeffs"], out["times"]) < 1e-8
+    assert util.constraint_defect(batch, out["coeffs"], out["times"]) < 1e-8
 
 
 def test_longest_accepted_path_and_one_beyond(gpu_ctx):
