@@ -149,14 +149,19 @@ __global__ __launch_bounds__(256) void estimate_times_kernel(BatchView b, const 
                                                              double* __restrict__ seg_times) {
   const int idx = blockIdx.x * 256 + threadIdx.x;
   if (idx >= b.n_segments) return;
-  // path of CSR segment idx: binary search over seg_offsets
-  int lo = 0, hi = b.n_paths;
-  while (hi - lo > 1) {
-    const int mid = (lo + hi) >> 1;
-    if (b.seg_offsets[mid] <= idx) lo = mid;
-    else hi = mid;
+  // path of CSR segment idx: a division for uniform batches, binary search over seg_offsets otherwise
+  int p;
+  if (b.uniform_S > 0) {
+    p = idx / b.uniform_S;
+  } else {
+    int lo = 0, hi = b.n_paths;
+    while (hi - lo > 1) {
+      const int mid = (lo + hi) >> 1;
+      if (b.seg_offsets[mid] <= idx) lo = mid;
+      else hi = mid;
+    }
+    p = lo;
   }
-  const int p = lo;
   const int v = idx + p;  // vertex index of the segment's start
   const double* s = wp + (size_t)v * 4;
   const double* e = s + 4;
