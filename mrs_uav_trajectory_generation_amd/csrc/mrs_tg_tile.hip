@@ -37,7 +37,10 @@ namespace mrs_tg {
 // with L and z.  (An earlier layout kept the four pieces in the segment records and summed them inside the serial
 // chain: 11.4 KB per path instead of 7.5 KB, one workgroup per CU instead of two at eight paths per tile.)
 constexpr int kSegRec = 16 + 4;            // coupling block EM (as its consumer reads it), qf[dim]
-constexpr int kVtxRec = 42 + 20 + 2;       // D[10] -> L[10] | W[16] | Y[4][4] -> z[4][4] | d[5][4] | free bits, flags
+constexpr int kVtxRec = 42 + 20 + 2 + 2;   // D[10] -> L[10] | W[16] | Y[4][4] -> z[4][4] | d[5][4] | free bits, flags | pad
+// (the pad takes the record off a multiple of 16 doubles = the 32-bank period of ds_read2_b64 / ds_write: the two
+// directions of a path work on different vertices and met on the same banks at every access of phase B --
+// SQ_LDS_BANK_CONFLICT was 27 % of the kernel's LDS cycles, profiles/round1_pmc_sq_linear_step.csv)
 constexpr int kHandOver = 10 + 16;         // per path: the backward direction's Schur update for the middle vertex
 
 // Per-path LDS stride.  Both record sizes are multiples of 8 doubles, so the unpadded stride put every path of a
