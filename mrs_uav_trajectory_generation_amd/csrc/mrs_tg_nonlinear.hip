@@ -121,10 +121,19 @@ __device__ __forceinline__ double guarded_cost(double J, double qf, bool base) {
 //   * no masks, no materialised 10 x 10 block: the 4 x 4 blocks are HBAR constants times T^(r + c + 2 - 2d), fused
 //     into the accumulations that consume them;
 //   * a fully constrained vertex is not factorised at all.
-// ~230 instructions per interior step for one dimension per lane, ~360 for four.  Any other mask / value pattern
-// (initial state with non-zero derivatives, partially constrained stop vertices) takes the general step.
+// ~230 instructions per interior step for one dimension per lane, ~360 for four.  A first segment that starts from a
+// moving state has its own variant of the start step (kSegStartState below); any other mask / value pattern
+// (partially constrained stop vertices, a moving start straight into a stop) takes the general step.
 constexpr int kSegLds = 38;
-enum { kSegGeneral = 0, kSegStart = 1, kSegInterior = 2, kSegEnd = 3 };
+enum { kSegGeneral = 0, kSegStart = 1, kSegInterior = 2, kSegEnd = 3, kSegStartState = 4 };
+// kSegStartState: the first segment of a path that starts from a moving state (what the service layer sends: the
+// current velocity / acceleration / jerk as a fully constrained vertex with non-zero values).  As with kSegStart nothing
+// is eliminated at its start vertex, but the right-hand side of the far vertex is a polynomial in T -- row r gets
+// sum_c HBAR[6+r][c] f_c T^(r+1+c+1-2d) -- and so is f^T H f.  Their time-independent coefficients (per dimension 4 x 4
+// for the rows, 8 for the powers 1..8 of f^T H f; power 0 and the position bracket are the ordinary record) sit in
+// kStartExtra doubles in front of the segment records.
+constexpr int kStartExtraDim = 16 + 8;
+constexpr int kStartExtra = kD * kStartExtraDim;
 
 __device__ __forceinline__ void stage_segments(const double* vtx, int S, int d, double* seg, int g, int G) {
   const double (*hb)[kN] = c_hbar[d];
@@ -145,6 +154,34 @@ __device__ __forceinline__ void stage_segments(const double* vtx, int S, int d, 
       if (fs == 0xFu && fe == 0xFu) kind = kSegInterior;
       else if (fs == 0u && fe == 0xFu) kind = kSegStart;
       else if (fs == 0xFu && fe == 0u) kind = kSegEnd;
+    } else if (i == 0 && fs == 0u && fe == 0xFu && vs[21] != 0.0 && ve[21] != 0.0) {
+      double nze = 0.0;
+#pragma unroll
+      for (int k = 1; k < kHalf; ++k)
+#pragma unroll
+        for (int q = 0; q < kD; ++q) nze += fabs(ve[k * kD + q]);
+      if (nze == 0.0) {
+        kind = kSegStartState;
+        double* ex = seg - kStartExtra;
+#pragma unroll
+        for (int q = 0; q < kD; ++q) {
+          double* e = ex + q * kStartExtraDim;
+          const double dp = vs[q] - ve[q];
+#pragma unroll
+          for (int r = 0; r < kNB; ++r)
+#pragma unroll
+            for (int c = 1; c < kHalf; ++c) e[r * 4 + (c - 1)] = hb[kHalf + kSlot0 + r][c] * vs[c * kD + q];
+          double Q[9] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+          for (int c = 1; c < kHalf; ++c) {
+            Q[c] += 2.0 * vs[c * kD + q] * (hb[c][0] * dp);  // derivative x position (HBAR[c][5] = -HBAR[c][0])
+#pragma unroll
+            for (int c2 = 1; c2 < kHalf; ++c2) Q[c + c2] += vs[c * kD + q] * vs[c2 * kD + q] * hb[c][c2];
+          }
+#pragma unroll
+          for (int m = 1; m < 9; ++m) e[16 + (m - 1)] = Q[m];
+        }
+      }
     }
     double* r = seg + (size_t)i * kSegLds;
 #pragma unroll
@@ -250,6 +287,25 @@ struct FastStep {
   template <class HC>
   __device__ __forceinline__ void start(Elim<ND>& st, const HC& hc, const double (&p2)[9]) const {
     start_t<false>(st, hc, p2);
+  }
+  // kSegStartState (see there): the ordinary start step plus the terms of the start vertex's derivative values
+  template <class HC>
+  __device__ __forceinline__ void start_state(Elim<ND>& st, const HC& hc, const double (&p2)[9], const double* ex,
+                                              int dim0) const {
+    start_t<false>(st, hc, p2);
+#pragma unroll
+    for (int q = 0; q < ND; ++q) {
+      const double* e = ex + (dim0 + q) * kStartExtraDim;
+#pragma unroll
+      for (int r = 0; r < kNB; ++r) {
+        double u = 0.0;
+#pragma unroll
+        for (int c = 1; c < kHalf; ++c) u = fma(e[r * 4 + (c - 1)], p2[r + 1 + c], u);
+        st.y[r][q] -= u;
+      }
+#pragma unroll
+      for (int m = 1; m < 9; ++m) st.qf = fma(e[16 + (m - 1)], p2[m], st.qf);
+    }
   }
 
   // Cholesky of st.Sm (all four slots free), z = L^-1 y, red += |z|^2
@@ -390,10 +446,12 @@ __device__ __forceinline__ double forward_cost(const double* vtx, const double* 
       if (ND == 4) {
         if (kind == kSegInterior) fast.interior(st, hcr, p2);
         else if (kind == kSegStart) fast.start(st, hcr, p2);
+        else if (kind == kSegStartState) fast.start_state(st, hcr, p2, seg - kStartExtra, dim0);
         else fast.end(st, hcr, p2);
       } else {
         if (kind == kSegInterior) fast.interior(st, hc, p2);
         else if (kind == kSegStart) fast.start(st, hc, p2);
+        else if (kind == kSegStartState) fast.start_state(st, hc, p2, seg - kStartExtra, dim0);
         else fast.end(st, hc, p2);
       }
     }
@@ -430,8 +488,12 @@ __device__ __forceinline__ void half_sweep(const double* seg, const double* hc, 
     segment_powers(perturbed_time(xs, i, k, corr), d, p2);
     FastStep<1> fast;
     fast.load(seg + (size_t)i * kSegLds, dim0);
-    if (s == 0) fast.template start_t<REV>(st, hc, p2);
-    else fast.template interior_t<REV>(st, hc, p2);
+    if (s == 0) {
+      if (!REV && (int)seg[36] == kSegStartState) fast.start_state(st, hc, p2, seg - kStartExtra, dim0);
+      else fast.template start_t<REV>(st, hc, p2);
+    } else {
+      fast.template interior_t<REV>(st, hc, p2);
+    }
   }
 }
 
@@ -689,12 +751,14 @@ __device__ __forceinline__ bool relstop(double vold, double vnew, double reltol,
 // cap and the compiler spilled exactly these to scratch memory, a global-memory round trip per reload).
 constexpr int kTickState = 4;  // doubles: f, alpha, then four ints
 // per-group LDS block (doubles): x, g, xn, gn, dir [5*Sb], s[M][Sb], y[M][Sb], rho[M + 1], tick state, staged vertices
-// [(Sb+1)*kVtxLds], staged segment records [Sb*kSegLds]
+// [(Sb+1)*kVtxLds], moving-start extras [kStartExtra], staged segment records [Sb*kSegLds]
 __host__ __device__ constexpr int group_lds_doubles(int Sb) {
-  return (5 + 2 * kLbfgsM) * Sb + (kLbfgsM + 1) + kTickState + (Sb + 1) * kVtxLds + Sb * kSegLds;
+  return (5 + 2 * kLbfgsM) * Sb + (kLbfgsM + 1) + kTickState + (Sb + 1) * kVtxLds + kStartExtra + Sb * kSegLds;
 }
 // cost_gradient_kernel: x, g [2*Sb], staged vertices
-__host__ __device__ constexpr int gradient_lds_doubles(int Sb) { return 2 * Sb + (Sb + 1) * kVtxLds + Sb * kSegLds; }
+__host__ __device__ constexpr int gradient_lds_doubles(int Sb) {
+  return 2 * Sb + (Sb + 1) * kVtxLds + kStartExtra + Sb * kSegLds;
+}
 
 // objective evaluation at `pt`: cost returned to every lane of the group, gradient to `grad` (LDS).
 // (objectiveFunctionTimeMellingerOuterLoop + getCostAndGradientMellinger)
@@ -816,7 +880,7 @@ __device__ __forceinline__ void optimize_body(const BatchView& b, const Nonlinea
   double* tick_f = rho + kLbfgsM + 1;                         // rho[kLbfgsM] = scaling from the newest pair (fast path)
   int* tick_i = reinterpret_cast<int*>(tick_f + 2);
   double* vtx = tick_f + kTickState;  // [(Sb + 1) * kVtxLds]
-  double* seg = vtx + (size_t)(Sb + 1) * kVtxLds;  // [Sb * kSegLds]
+  double* seg = vtx + (size_t)(Sb + 1) * kVtxLds + kStartExtra;  // [Sb * kSegLds], the moving-start extras in front
   if (active && wave == 0) stage_vertices(mask, vals, pr.v0, S, vtx, g, G);
   __syncthreads();
   if (active && wave == 0) stage_segments(vtx, S, d, seg, g, G);
@@ -842,7 +906,8 @@ __device__ __forceinline__ void optimize_body(const BatchView& b, const Nonlinea
   if (two_wave) {
     if (threadIdx.x == 0) {
       // every perturbation needs its own quad of lanes in one round: 4 (S + 1) <= 64
-      bool plain = DS == 4 && G == 64 && active && S >= 4 && 4 * (S + 1) <= 64 && (int)seg[36] == kSegStart && (int)seg[(size_t)(S - 1) * kSegLds + 36] == kSegEnd;
+      bool plain = DS == 4 && G == 64 && active && S >= 4 && 4 * (S + 1) <= 64 && ((int)seg[36] == kSegStart || (int)seg[36] == kSegStartState) &&
+                   (int)seg[(size_t)(S - 1) * kSegLds + 36] == kSegEnd;
       for (int i = 1; plain && i < S - 1; ++i) plain = (int)seg[(size_t)i * kSegLds + 36] == kSegInterior;
       pair_flags[0] = done ? 1 : 0;
       pair_flags[1] = plain ? 1 : 0;
@@ -1314,7 +1379,7 @@ __global__ __launch_bounds__(64) void cost_gradient_kernel(BatchView b, int d, i
   double* x = lds + kBlockConsts + (size_t)grp * gradient_lds_doubles(Sb);
   double* gr = x + Sb;
   double* vtx = gr + Sb;
-  double* seg = vtx + (size_t)(Sb + 1) * kVtxLds;
+  double* seg = vtx + (size_t)(Sb + 1) * kVtxLds + kStartExtra;
   if (active) {
     for (int i = g; i < pr.S; i += G) x[i] = seg_times[pr.s0 + i];
     stage_vertices(mask, vals, pr.v0, pr.S, vtx, g, G);

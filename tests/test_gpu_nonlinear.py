@@ -63,6 +63,50 @@ def test_cost_gradient_vs_oracle(gpu_ctx, n_seg, n_paths):
         assert np.max(np.abs(g[a:b] - go)) <= 1e-6 * max(np.max(np.abs(go)), 1e-300)
 
 
+def _moving_start_batch(n_paths, n_seg, deriv=4):
+    parts = []
+    for p in range(n_paths):
+        rng = pr.SplitMix64(4100 + p)
+        wp = pr.random_box_waypoints(n_seg, 4100 + p)
+        init = dict(heading=wp[0, 3] + rng.uniform(-0.3, 0.3),
+                    velocity=[rng.uniform(-2, 2), rng.uniform(-2, 2), rng.uniform(-1, 1), rng.uniform(-0.5, 0.5)],
+                    acceleration=[rng.uniform(-1, 1), rng.uniform(-1, 1), rng.uniform(-0.5, 0.5), rng.uniform(-0.3, 0.3)],
+                    jerk=[rng.uniform(-1, 1), rng.uniform(-1, 1), rng.uniform(-0.5, 0.5), rng.uniform(-0.3, 0.3)])
+        parts.append(pr.build_vertices(wp, deriv, initial_state=init))
+    return pr.assemble_batch(parts, np.tile(pr.DEFAULT_LIMITS, (n_paths, 1)), deriv)
+
+
+@pytest.mark.parametrize("n_seg,n_paths,deriv", [(10, 64, 4), (3, 32, 4), (14, 16, 4), (20, 8, 4), (10, 32, 3), (10, 32, 2), (2, 8, 4)])
+def test_cost_gradient_moving_start_vs_oracle(gpu_ctx, n_seg, n_paths, deriv):
+    """Paths that start from a moving state (non-zero velocity / acceleration / jerk at the first vertex): the first
+    segment takes the kSegStartState step (snap; with d < 4 the start vertex keeps free slots and the general step runs)
+    in the one- and two-wavefront evaluations (10 and 14 segments fit the two-sided one, 20 do not)."""
+    batch = _moving_start_batch(n_paths, n_seg, deriv)
+    times = util.oracle_times(batch)
+    J, g = gpu_cost_gradient(gpu_ctx, batch, times)
+    for p in range(batch.n_paths):
+        _, m, v = batch.path(p)
+        a, b = batch.seg_offsets[p], batch.seg_offsets[p + 1]
+        Jo, go = po.cost_and_gradient(deriv, m, v, times[a:b])
+        assert abs(J[p] - Jo) <= 1e-7 * abs(Jo), (p, J[p], Jo)
+        assert np.max(np.abs(g[a:b] - go)) <= 1e-6 * max(np.max(np.abs(go)), 1e-300), p
+
+
+def test_nonlinear_moving_start_end_to_end_vs_oracle(gpu_ctx):
+    batch = _moving_start_batch(256, 10)
+    cap = 512
+    out = gpu_ctx.solve_batch(batch, None, time_alloc_method=api.TIME_ALLOC_MELLINGER, sampling_dt=0.2, sample_capacity=cap)
+    ref = po.solve_batch(batch.seg_offsets, batch.waypoints, batch.fixed_mask, batch.fixed_values, batch.limits,
+                         np.zeros(batch.n_segments), deriv=4, time_alloc_method=2, estimate_times=True,
+                         sampling_dt=0.2, sample_capacity=cap, n_threads=8)
+    _check_invariants(batch, out)
+    so = batch.seg_offsets
+    dt = np.array([np.max(np.abs(out["times"][a:b] - ref["times"][a:b]) / ref["times"][a:b]) for a, b in zip(so[:-1], so[1:])])
+    same = (out["status"] == ref["status"]) & (out["n_samples"] == np.minimum(ref["n_samples"], cap + 1))
+    assert same.mean() >= 0.98, same.mean()
+    assert (dt < 1e-6).mean() >= 0.95, (dt < 1e-6).mean()
+
+
 def test_segment_maxima_vs_oracle_and_exact(gpu_ctx, golden):
     groups = [[0, 1], [2], [3]]
     for case in golden["cases"]:
