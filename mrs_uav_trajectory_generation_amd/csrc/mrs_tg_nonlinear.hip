@@ -125,7 +125,12 @@ __device__ __forceinline__ double guarded_cost(double J, double qf, bool base) {
 // moving state has its own variant of the start step (kSegStartState below); any other mask / value pattern
 // (partially constrained stop vertices, a moving start straight into a stop) takes the general step.
 constexpr int kSegLds = 38;
-enum { kSegGeneral = 0, kSegStart = 1, kSegInterior = 2, kSegEnd = 3, kSegStartState = 4 };
+enum { kSegGeneral = 0, kSegStart = 1, kSegInterior = 2, kSegEnd = 3, kSegStartState = 4, kSegMasked = 5 };
+// kSegMasked: every constrained derivative value is zero (so the position brackets are the whole right-hand side) but
+// the free masks of the two vertices are not one of the three patterns above: the end vertices of a rest-to-rest path
+// under the minimum-acceleration or minimum-jerk objective (d = 2, the reference's shipping default, leaves jerk and
+// snap free there), stop_at vertices (snap free).  One masked variant of the interior step covers them, in either sweep
+// direction; record slot 37 holds the two masks (start | end << 4) for every non-general kind.
 // kSegStartState: the first segment of a path that starts from a moving state (what the service layer sends: the
 // current velocity / acceleration / jerk as a fully constrained vertex with non-zero values).  As with kSegStart nothing
 // is eliminated at its start vertex, but the right-hand side of the far vertex is a polynomial in T -- row r gets
@@ -154,6 +159,7 @@ __device__ __forceinline__ void stage_segments(const double* vtx, int S, int d, 
       if (fs == 0xFu && fe == 0xFu) kind = kSegInterior;
       else if (fs == 0u && fe == 0xFu) kind = kSegStart;
       else if (fs == 0xFu && fe == 0u) kind = kSegEnd;
+      else kind = kSegMasked;
     } else if (i == 0 && fs == 0u && fe == 0xFu && vs[21] != 0.0 && ve[21] != 0.0) {
       double nze = 0.0;
 #pragma unroll
@@ -200,6 +206,7 @@ __device__ __forceinline__ void stage_segments(const double* vtx, int S, int d, 
       r[q * 9 + 8] = hb[0][0] * dp * dp;
     }
     r[36] = (double)kind;
+    r[37] = (double)(fs | (fe << 4));
   }
 }
 
@@ -401,6 +408,69 @@ struct FastStep {
   __device__ __forceinline__ void interior(Elim<ND>& st, const HC& hc, const double (&p2)[9]) const {
     interior_t<false>(st, hc, p2);
   }
+
+  // constrained slots of the vertex the state stands on: identity row, zero right-hand side (as Elim::factor_vertex)
+  static __device__ __forceinline__ void apply_mask(Elim<ND>& st, unsigned free_mask) {
+#pragma unroll
+    for (int r = 0; r < kNB; ++r) {
+      const bool fr = (free_mask >> r) & 1u;
+#pragma unroll
+      for (int c = 0; c <= r; ++c) {
+        const bool fc = (free_mask >> c) & 1u;
+        const double v = st.Sm[tri(r, c)];
+        st.Sm[tri(r, c)] = (r == c) ? (fr ? v : 1.0) : ((fr && fc) ? v : 0.0);
+      }
+#pragma unroll
+      for (int q = 0; q < ND; ++q) st.y[r][q] = fr ? st.y[r][q] : 0.0;
+    }
+  }
+
+  // kSegMasked: the interior step with the free masks of the near (mn) and far (mf) vertex.  mn = 0 reduces it to the
+  // start step, mf = 0 to the end step, both 0xF to the plain interior step.
+  template <bool REV, class HC>
+  __device__ __forceinline__ void masked_t(Elim<ND>& st, const HC& hc, const double (&p2)[9], unsigned mn, unsigned mf) const {
+#pragma unroll
+    for (int r = 0; r < kNB; ++r) {
+#pragma unroll
+      for (int c = 0; c <= r; ++c) st.Sm[tri(r, c)] = fma(hc[near_blk<REV>(r, c)], p2[r + c + 2], st.Sm[tri(r, c)]);
+#pragma unroll
+      for (int q = 0; q < ND; ++q) st.y[r][q] = fma(-w[q][near_w<REV>(r)], p2[r + 1], st.y[r][q]);
+    }
+#pragma unroll
+    for (int q = 0; q < ND; ++q) st.qf = fma(p2[0], w[q][8], st.qf);
+    apply_mask(st, mn);
+    double L[10], Linv[kNB], z[kNB][ND], W[kNB][kNB];
+    factor(st, L, Linv, z);
+#pragma unroll
+    for (int c = 0; c < kNB; ++c)
+#pragma unroll
+      for (int r = 0; r < kNB; ++r) {
+        const bool on = ((mn >> r) & 1u) && ((mf >> c) & 1u);
+        double s = on ? hc[cpl_blk<REV>(r, c)] * p2[r + c + 2] : 0.0;
+#pragma unroll
+        for (int m = 0; m < r; ++m) s = fma(-L[tri(r, m)], W[m][c], s);
+        W[r][c] = s * Linv[r];
+      }
+#pragma unroll
+    for (int r = 0; r < kNB; ++r) {
+      const bool fr = (mf >> r) & 1u;
+#pragma unroll
+      for (int c = 0; c <= r; ++c) {
+        const bool fc = (mf >> c) & 1u;
+        double s = (fr && fc) ? hc[far_blk<REV>(r, c)] * p2[r + c + 2] : 0.0;
+#pragma unroll
+        for (int m = 0; m < kNB; ++m) s = fma(-W[m][r], W[m][c], s);
+        st.Sm[tri(r, c)] = s;
+      }
+#pragma unroll
+      for (int q = 0; q < ND; ++q) {
+        double s = fr ? -(w[q][far_w<REV>(r)] * p2[r + 1]) : 0.0;
+#pragma unroll
+        for (int m = 0; m < kNB; ++m) s = fma(-W[m][r], z[m][q], s);
+        st.y[r][q] = s;
+      }
+    }
+  }
 };
 
 template <int ND>
@@ -446,13 +516,15 @@ __device__ __forceinline__ double forward_cost(const double* vtx, const double* 
       if (ND == 4) {
         if (kind == kSegInterior) fast.interior(st, hcr, p2);
         else if (kind == kSegStart) fast.start(st, hcr, p2);
+        else if (kind == kSegEnd) fast.end(st, hcr, p2);
         else if (kind == kSegStartState) fast.start_state(st, hcr, p2, seg - kStartExtra, dim0);
-        else fast.end(st, hcr, p2);
+        else fast.template masked_t<false>(st, hcr, p2, (unsigned)sr[37] & 0xFu, (unsigned)sr[37] >> 4);
       } else {
         if (kind == kSegInterior) fast.interior(st, hc, p2);
         else if (kind == kSegStart) fast.start(st, hc, p2);
+        else if (kind == kSegEnd) fast.end(st, hc, p2);
         else if (kind == kSegStartState) fast.start_state(st, hc, p2, seg - kStartExtra, dim0);
-        else fast.end(st, hc, p2);
+        else fast.template masked_t<false>(st, hc, p2, (unsigned)sr[37] & 0xFu, (unsigned)sr[37] >> 4);
       }
     }
   }
@@ -474,9 +546,12 @@ __device__ __forceinline__ double forward_cost(const double* vtx, const double* 
 // Only for "plain" paths (start, interior..., end segment kinds); anything else keeps the one-sided sweep.
 constexpr int kPairState = 16;  // Sm[10], y[4], qf, red handed from the backward to the forward wavefront, per lane
 
-template <bool REV>
+// special: bit i set = segment i takes the masked step, bit 31 = the first segment is a moving start (wave-uniform,
+// worked out once per kernel).  The plain start | interior ... | end path is its own instantiation: even a never-taken
+// branch to the masked step inside its loop cost it 8 % (register allocation at the 256-VGPR cap).
+template <bool REV, int SPECIAL>  // 0: plain path, 1: moving start only, 2: masked segments (and possibly a moving start)
 __device__ __forceinline__ void half_sweep(const double* seg, const double* hc, int S, int m, int d, const double* xs, int k,
-                                           int dim0, Elim<1>& st) {
+                                           int dim0, unsigned special, Elim<1>& st) {
   st.init();
   // the block constants are read from LDS in every step here: the two wavefronts of a path must fit one SIMD
   // together (<= 256 VGPRs each), which the register-resident copy of the one-sided sweep would not allow
@@ -488,8 +563,12 @@ __device__ __forceinline__ void half_sweep(const double* seg, const double* hc, 
     segment_powers(perturbed_time(xs, i, k, corr), d, p2);
     FastStep<1> fast;
     fast.load(seg + (size_t)i * kSegLds, dim0);
-    if (s == 0) {
-      if (!REV && (int)seg[36] == kSegStartState) fast.start_state(st, hc, p2, seg - kStartExtra, dim0);
+    if (SPECIAL == 2 && ((special >> i) & 1u)) {
+      const unsigned masks = (unsigned)seg[(size_t)i * kSegLds + 37];
+      const unsigned ms = masks & 0xFu, me = masks >> 4;
+      fast.template masked_t<REV>(st, hc, p2, REV ? me : ms, REV ? ms : me);
+    } else if (s == 0) {
+      if (SPECIAL != 0 && !REV && (special >> 31)) fast.start_state(st, hc, p2, seg - kStartExtra, dim0);
       else fast.template start_t<REV>(st, hc, p2);
     } else {
       fast.template interior_t<REV>(st, hc, p2);
@@ -792,12 +871,16 @@ __device__ __forceinline__ double evaluate_objective(const double* vtx, const do
 // Two-sided objective evaluation (forward wavefront's side): forward half sweep, barrier, join with the backward
 // half that the partner wavefront left in LDS, then the same reductions as evaluate_objective<4>.
 __device__ __forceinline__ double evaluate_pair(const double* seg, const double* hc, const double* pair_state, int S, int d,
-                                                const double* pt, double* grad, int g, bool active) {
+                                                const double* pt, double* grad, int g, bool active, unsigned special) {
   const int k = g >> 2, dim0 = g & 3, m = S / 2;
   const bool work = active && k <= S;
   Elim<1> st;
   st.init();
-  if (work) half_sweep<false>(seg, hc, S, m, d, pt, k, dim0, st);
+  if (work) {
+    if (special & 0x7FFFFFFFu) half_sweep<false, 2>(seg, hc, S, m, d, pt, k, dim0, special, st);
+    else if (special) half_sweep<false, 1>(seg, hc, S, m, d, pt, k, dim0, special, st);
+    else half_sweep<false, 0>(seg, hc, S, m, d, pt, k, dim0, 0u, st);
+  }
   __syncthreads();  // the partner's half sweeps are in LDS
   double Jk = 0.0, qfk = 0.0;
   if (work) {
@@ -810,6 +893,8 @@ __device__ __forceinline__ double evaluate_pair(const double* seg, const double*
     st.red += ps[15];
     FastStep<1> fs;
     double L[10], Linv[kNB], z[kNB][1];
+    // free mask of the middle vertex = end mask of the segment in front of it
+    if (special & 0x7FFFFFFFu) FastStep<1>::apply_mask(st, (unsigned)seg[(size_t)(m - 1) * kSegLds + 37] >> 4);
     fs.factor(st, L, Linv, z);
     Jk = 0.5 * (st.qf - st.red);
     qfk = st.qf;
@@ -868,7 +953,7 @@ __device__ __forceinline__ void optimize_body(const BatchView& b, const Nonlinea
   if (wave == 0) stage_block_constants(d, hc, lane, 64);
   double* base = lds + kBlockConsts + (size_t)grp * group_lds_doubles(Sb);
   double* pair_state = lds + kBlockConsts + (size_t)per_block * group_lds_doubles(Sb);  // [64 * kPairState] (two_wave only)
-  int* pair_flags = reinterpret_cast<int*>(pair_state + 64 * kPairState);              // [0] all done, [1] two-sided evaluation
+  int* pair_flags = reinterpret_cast<int*>(pair_state + 64 * kPairState);              // [0] all done, [1] two-sided evaluation, [2] moving start / masked segments
   double* x = base;
   double* gr = x + Sb;
   double* xn = gr + Sb;
@@ -903,24 +988,36 @@ __device__ __forceinline__ void optimize_body(const BatchView& b, const Nonlinea
   int ret = -1;
   bool done = !active || bad;
   bool pair_ok = false;
+  unsigned pair_special = 0u;
   if (two_wave) {
     if (threadIdx.x == 0) {
       // every perturbation needs its own quad of lanes in one round: 4 (S + 1) <= 64
-      bool plain = DS == 4 && G == 64 && active && S >= 4 && 4 * (S + 1) <= 64 && ((int)seg[36] == kSegStart || (int)seg[36] == kSegStartState) &&
-                   (int)seg[(size_t)(S - 1) * kSegLds + 36] == kSegEnd;
-      for (int i = 1; plain && i < S - 1; ++i) plain = (int)seg[(size_t)i * kSegLds + 36] == kSegInterior;
+      // every segment must have a specialised step: a start-type (or masked) first one, an end-type (or masked) last
+      // one, interior or masked ones in between
+      auto kind_of = [&](int i) { return (int)seg[(size_t)i * kSegLds + 36]; };
+      bool plain = DS == 4 && G == 64 && active && S >= 4 && 4 * (S + 1) <= 64 &&
+                   (kind_of(0) == kSegStart || kind_of(0) == kSegStartState || kind_of(0) == kSegMasked) &&
+                   (kind_of(S - 1) == kSegEnd || kind_of(S - 1) == kSegMasked);
+      for (int i = 1; plain && i < S - 1; ++i) plain = kind_of(i) == kSegInterior || kind_of(i) == kSegMasked;
+      unsigned special = 0u;
+      for (int i = 0; plain && i < S; ++i)
+        if (kind_of(i) == kSegMasked) special |= 1u << i;
+      if (plain && kind_of(0) == kSegStartState) special |= 1u << 31;
+      pair_flags[2] = (int)special;
       pair_flags[0] = done ? 1 : 0;
       pair_flags[1] = plain ? 1 : 0;
     }
     __syncthreads();
     pair_ok = pair_flags[1] != 0;
+    pair_special = (unsigned)__builtin_amdgcn_readfirstlane(pair_flags[2]);
     if (wave == 1) {
       // partner wavefront: backward half sweep of every tick, then the tick's other barriers
       const int k = lane >> 2, dim0 = lane & 3;
       while (pair_flags[0] == 0) {
         if (pair_ok && k <= S) {
           Elim<1> st;
-          half_sweep<true>(seg, hc, S, S / 2, d, xn, k, dim0, st);
+          if (pair_special & 0x7FFFFFFFu) half_sweep<true, 2>(seg, hc, S, S / 2, d, xn, k, dim0, pair_special, st);
+          else half_sweep<true, 0>(seg, hc, S, S / 2, d, xn, k, dim0, 0u, st);  // a moving start is the forward half's business
           double* ps = pair_state + (size_t)lane * kPairState;
 #pragma unroll
           for (int e = 0; e < 10; ++e) ps[e] = st.Sm[e];
@@ -964,7 +1061,7 @@ __device__ __forceinline__ void optimize_body(const BatchView& b, const Nonlinea
     }
     double fn;
     if (pair_ok) {
-      fn = evaluate_pair(seg, hc, pair_state, S, d, xn, gn, g, !done);
+      fn = evaluate_pair(seg, hc, pair_state, S, d, xn, gn, g, !done, pair_special);
     } else {
       fn = evaluate_objective<DS>(vtx, seg, hc, S, d, xn, gn, g, G, !done);
       if (two_wave) __syncthreads();  // the partner's hand-over barrier

@@ -92,6 +92,30 @@ def test_cost_gradient_moving_start_vs_oracle(gpu_ctx, n_seg, n_paths, deriv):
         assert np.max(np.abs(g[a:b] - go)) <= 1e-6 * max(np.max(np.abs(go)), 1e-300), p
 
 
+@pytest.mark.parametrize("n_seg,n_paths,deriv,stops", [(10, 64, 2, False), (10, 64, 3, False), (14, 16, 2, False), (20, 8, 2, False),
+                                                       (3, 32, 2, False), (10, 64, 4, True), (12, 32, 2, True), (20, 8, 3, True)])
+def test_cost_gradient_masked_vertices_vs_oracle(gpu_ctx, n_seg, n_paths, deriv, stops):
+    """Vertices with a partial free mask and zero constrained values take the masked specialised step (kSegMasked): the
+    end vertices of rest-to-rest paths under the minimum-acceleration / minimum-jerk objective (jerk and / or snap stay
+    free there), stop_at vertices -- in the one- and the two-wavefront evaluation."""
+    parts = []
+    for p in range(n_paths):
+        rng = pr.SplitMix64(5200 + p)
+        wp = pr.random_box_waypoints(n_seg, 5200 + p)
+        stop = [rng.next_u64() % 3 == 0 for _ in range(n_seg + 1)] if stops else None
+        parts.append(pr.build_vertices(wp, deriv, stop_at=stop))
+    batch = pr.assemble_batch(parts, np.tile(pr.DEFAULT_LIMITS, (n_paths, 1)), deriv)
+    times = util.oracle_times(batch)
+    J, g = gpu_cost_gradient(gpu_ctx, batch, times)
+    tol = {4: 1e-7, 3: 1e-6, 2: 1e-5}[deriv]  # the oracle's own accuracy drops with the objective's order (R_pp conditioning)
+    for p in range(batch.n_paths):
+        _, m, v = batch.path(p)
+        a, b = batch.seg_offsets[p], batch.seg_offsets[p + 1]
+        Jo, go = po.cost_and_gradient(deriv, m, v, times[a:b])
+        assert abs(J[p] - Jo) <= tol * abs(Jo), (p, J[p], Jo)
+        assert np.max(np.abs(g[a:b] - go)) <= 10 * tol * max(np.max(np.abs(go)), 1e-300), p
+
+
 def test_nonlinear_moving_start_end_to_end_vs_oracle(gpu_ctx):
     batch = _moving_start_batch(256, 10)
     cap = 512
