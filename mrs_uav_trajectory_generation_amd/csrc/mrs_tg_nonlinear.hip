@@ -140,7 +140,7 @@ enum { kSegGeneral = 0, kSegStart = 1, kSegInterior = 2, kSegEnd = 3, kSegStartS
 constexpr int kStartExtraDim = 16 + 8;
 constexpr int kStartExtra = kD * kStartExtraDim;
 
-__device__ __forceinline__ void stage_segments(const double* vtx, int S, int d, double* seg, int g, int G) {
+__device__ __forceinline__ void stage_segments(const double* vtx, int S, int d, double* seg, int g, int G, bool extras) {
   const double (*hb)[kN] = c_hbar[d];
   for (int i = g; i < S; i += G) {
     const double* vs = vtx + (size_t)i * kVtxLds;
@@ -160,7 +160,7 @@ __device__ __forceinline__ void stage_segments(const double* vtx, int S, int d, 
       else if (fs == 0u && fe == 0xFu) kind = kSegStart;
       else if (fs == 0xFu && fe == 0u) kind = kSegEnd;
       else kind = kSegMasked;
-    } else if (i == 0 && fs == 0u && fe == 0xFu && vs[21] != 0.0 && ve[21] != 0.0) {
+    } else if (extras && i == 0 && fs == 0u && fe == 0xFu && vs[21] != 0.0 && ve[21] != 0.0) {
       double nze = 0.0;
 #pragma unroll
       for (int k = 1; k < kHalf; ++k)
@@ -494,7 +494,10 @@ __device__ __forceinline__ double forward_cost(const double* vtx, const double* 
     const double* sr = seg + (size_t)i * kSegLds;
     const int kind = (int)sr[36];
     last_kind = kind;
-    if (kind == kSegGeneral) {
+    // The four-dimensions-per-lane sweep (large batches) keeps the general step for moving starts and masked
+    // vertices: their specialised steps would sit in the same loop as the plain ones and cost those ~10 % (register
+    // allocation of a 440-VGPR kernel), which the BASELINE batches -- all plain -- would pay for nothing.
+    if (kind == kSegGeneral || (ND == 4 && kind >= kSegStartState)) {
       double fs[kHalf][ND], fe[kHalf][ND];
       double L[10], z[kNB][ND], W[kNB][kNB];
       const unsigned free_s = staged_vertex<ND>(vtx, i, dim0, fs);
@@ -516,9 +519,7 @@ __device__ __forceinline__ double forward_cost(const double* vtx, const double* 
       if (ND == 4) {
         if (kind == kSegInterior) fast.interior(st, hcr, p2);
         else if (kind == kSegStart) fast.start(st, hcr, p2);
-        else if (kind == kSegEnd) fast.end(st, hcr, p2);
-        else if (kind == kSegStartState) fast.start_state(st, hcr, p2, seg - kStartExtra, dim0);
-        else fast.template masked_t<false>(st, hcr, p2, (unsigned)sr[37] & 0xFu, (unsigned)sr[37] >> 4);
+        else fast.end(st, hcr, p2);
       } else {
         if (kind == kSegInterior) fast.interior(st, hc, p2);
         else if (kind == kSegStart) fast.start(st, hc, p2);
@@ -831,12 +832,14 @@ __device__ __forceinline__ bool relstop(double vold, double vnew, double reltol,
 constexpr int kTickState = 4;  // doubles: f, alpha, then four ints
 // per-group LDS block (doubles): x, g, xn, gn, dir [5*Sb], s[M][Sb], y[M][Sb], rho[M + 1], tick state, staged vertices
 // [(Sb+1)*kVtxLds], moving-start extras [kStartExtra], staged segment records [Sb*kSegLds]
-__host__ __device__ constexpr int group_lds_doubles(int Sb) {
-  return (5 + 2 * kLbfgsM) * Sb + (kLbfgsM + 1) + kTickState + (Sb + 1) * kVtxLds + kStartExtra + Sb * kSegLds;
+// extras: the moving-start area (only the one-dimension-per-lane kernels use it; in the four-dimensions-per-lane mapping
+// of large batches many groups share a workgroup and 96 doubles each cost a workgroup per CU)
+__host__ __device__ constexpr int group_lds_doubles(int Sb, bool extras) {
+  return (5 + 2 * kLbfgsM) * Sb + (kLbfgsM + 1) + kTickState + (Sb + 1) * kVtxLds + (extras ? kStartExtra : 0) + Sb * kSegLds;
 }
 // cost_gradient_kernel: x, g [2*Sb], staged vertices
-__host__ __device__ constexpr int gradient_lds_doubles(int Sb) {
-  return 2 * Sb + (Sb + 1) * kVtxLds + kStartExtra + Sb * kSegLds;
+__host__ __device__ constexpr int gradient_lds_doubles(int Sb, bool extras) {
+  return 2 * Sb + (Sb + 1) * kVtxLds + (extras ? kStartExtra : 0) + Sb * kSegLds;
 }
 
 // objective evaluation at `pt`: cost returned to every lane of the group, gradient to `grad` (LDS).
@@ -951,8 +954,9 @@ __device__ __forceinline__ void optimize_body(const BatchView& b, const Nonlinea
 
   double* hc = lds;  // [kBlockConsts], shared by the groups of the block
   if (wave == 0) stage_block_constants(d, hc, lane, 64);
-  double* base = lds + kBlockConsts + (size_t)grp * group_lds_doubles(Sb);
-  double* pair_state = lds + kBlockConsts + (size_t)per_block * group_lds_doubles(Sb);  // [64 * kPairState] (two_wave only)
+  constexpr bool kExtras = DS == 4;
+  double* base = lds + kBlockConsts + (size_t)grp * group_lds_doubles(Sb, kExtras);
+  double* pair_state = lds + kBlockConsts + (size_t)per_block * group_lds_doubles(Sb, kExtras);  // [64 * kPairState] (two_wave only)
   int* pair_flags = reinterpret_cast<int*>(pair_state + 64 * kPairState);              // [0] all done, [1] two-sided evaluation, [2] moving start / masked segments
   double* x = base;
   double* gr = x + Sb;
@@ -965,10 +969,10 @@ __device__ __forceinline__ void optimize_body(const BatchView& b, const Nonlinea
   double* tick_f = rho + kLbfgsM + 1;                         // rho[kLbfgsM] = scaling from the newest pair (fast path)
   int* tick_i = reinterpret_cast<int*>(tick_f + 2);
   double* vtx = tick_f + kTickState;  // [(Sb + 1) * kVtxLds]
-  double* seg = vtx + (size_t)(Sb + 1) * kVtxLds + kStartExtra;  // [Sb * kSegLds], the moving-start extras in front
+  double* seg = vtx + (size_t)(Sb + 1) * kVtxLds + (kExtras ? kStartExtra : 0);  // [Sb * kSegLds], the moving-start extras in front
   if (active && wave == 0) stage_vertices(mask, vals, pr.v0, S, vtx, g, G);
   __syncthreads();
-  if (active && wave == 0) stage_segments(vtx, S, d, seg, g, G);
+  if (active && wave == 0) stage_segments(vtx, S, d, seg, g, G, kExtras);
 
   // ---- start point; NLopt rejects a start below the lower bound (-> INVALID_ARGS)
   int ok = 1;
@@ -1473,16 +1477,17 @@ __global__ __launch_bounds__(64) void cost_gradient_kernel(BatchView b, int d, i
   const PathRef pr = path_at(b, q_begin + (active ? qi : 0));
   double* hc = lds;
   stage_block_constants(d, hc, lane, 64);
-  double* x = lds + kBlockConsts + (size_t)grp * gradient_lds_doubles(Sb);
+  constexpr bool kExtras = DS == 4;
+  double* x = lds + kBlockConsts + (size_t)grp * gradient_lds_doubles(Sb, kExtras);
   double* gr = x + Sb;
   double* vtx = gr + Sb;
-  double* seg = vtx + (size_t)(Sb + 1) * kVtxLds + kStartExtra;
+  double* seg = vtx + (size_t)(Sb + 1) * kVtxLds + (kExtras ? kStartExtra : 0);
   if (active) {
     for (int i = g; i < pr.S; i += G) x[i] = seg_times[pr.s0 + i];
     stage_vertices(mask, vals, pr.v0, pr.S, vtx, g, G);
   }
   __syncthreads();
-  if (active) stage_segments(vtx, pr.S, d, seg, g, G);
+  if (active) stage_segments(vtx, pr.S, d, seg, g, G, kExtras);
   __syncthreads();
   const double J = evaluate_objective<DS>(vtx, seg, hc, pr.S, d, x, gr, g, G, active);
   __syncthreads();
@@ -1977,7 +1982,7 @@ hipError_t launch_nonlinear(NonlinearPlan& nl, const BatchView& b, const Nonline
       bt.max_S[i] = bin.max_S;
       bt.block_begin[i] = blocks;
       blocks += (int)cdiv_u(bin.q_count, per_block);
-      const size_t need = ((size_t)per_block * group_lds_doubles(bin.max_S) + kBlockConsts) * sizeof(double);
+      const size_t need = ((size_t)per_block * group_lds_doubles(bin.max_S, nl.dim_split == 4) + kBlockConsts) * sizeof(double);
       if (need > lds_bytes) lds_bytes = need;
       if (bin.group != 64) all_single = false;
     }
@@ -2079,7 +2084,7 @@ hipError_t launch_cost_gradient(NonlinearPlan& nl, const BatchView& b, int d, co
                                 const double* seg_times, double* cost, double* grad, hipStream_t stream) {
   for (const NonlinearBin& bin : nl.bins) {
     const int per_block = 64 / bin.group;
-    const size_t lds_bytes = ((size_t)per_block * gradient_lds_doubles(bin.max_S) + kBlockConsts) * sizeof(double);
+    const size_t lds_bytes = ((size_t)per_block * gradient_lds_doubles(bin.max_S, nl.dim_split == 4) + kBlockConsts) * sizeof(double);
     if (lds_bytes > 160 * 1024) return hipErrorInvalidValue;
     const dim3 grid(cdiv_u(bin.q_count, per_block));
     if (nl.dim_split == 4)
