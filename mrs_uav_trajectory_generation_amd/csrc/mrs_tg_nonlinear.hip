@@ -473,7 +473,9 @@ struct FastStep {
   }
 };
 
-template <int ND>
+// MASKED4: the four-dimensions-per-lane sweep with the masked step compiled in (launches whose objective order d < 4
+// makes every rest-to-rest path end on masked vertices); see the comment at the general branch below
+template <int ND, bool MASKED4 = false>
 __device__ __forceinline__ double forward_cost(const double* vtx, const double* seg, const double* hc, int S, int d,
                                                const double* xs, int k, int dim0, double& qf_out) {
   Elim<ND> st;
@@ -497,7 +499,7 @@ __device__ __forceinline__ double forward_cost(const double* vtx, const double* 
     // The four-dimensions-per-lane sweep (large batches) keeps the general step for moving starts and masked
     // vertices: their specialised steps would sit in the same loop as the plain ones and cost those ~10 % (register
     // allocation of a 440-VGPR kernel), which the BASELINE batches -- all plain -- would pay for nothing.
-    if (kind == kSegGeneral || (ND == 4 && kind >= kSegStartState)) {
+    if (kind == kSegGeneral || (ND == 4 && (kind == kSegStartState || (kind == kSegMasked && !MASKED4)))) {
       double fs[kHalf][ND], fe[kHalf][ND];
       double L[10], z[kNB][ND], W[kNB][kNB];
       const unsigned free_s = staged_vertex<ND>(vtx, i, dim0, fs);
@@ -519,6 +521,7 @@ __device__ __forceinline__ double forward_cost(const double* vtx, const double* 
       if (ND == 4) {
         if (kind == kSegInterior) fast.interior(st, hcr, p2);
         else if (kind == kSegStart) fast.start(st, hcr, p2);
+        else if (MASKED4 && kind == kSegMasked) fast.template masked_t<false>(st, hcr, p2, (unsigned)sr[37] & 0xFu, (unsigned)sr[37] >> 4);
         else fast.end(st, hcr, p2);
       } else {
         if (kind == kSegInterior) fast.interior(st, hc, p2);
@@ -845,7 +848,7 @@ __host__ __device__ constexpr int gradient_lds_doubles(int Sb, bool extras) {
 // objective evaluation at `pt`: cost returned to every lane of the group, gradient to `grad` (LDS).
 // (objectiveFunctionTimeMellingerOuterLoop + getCostAndGradientMellinger)
 // DS lanes share one time vector (DS = 1: one lane, four dimensions; DS = 4: four lanes, one dimension each).
-template <int DS>
+template <int DS, bool MASKED4 = false>
 __device__ __forceinline__ double evaluate_objective(const double* vtx, const double* seg, const double* hc, int S, int d,
                                                      const double* pt, double* grad, int g, int G, bool active) {
   constexpr int ND = kD / DS;
@@ -857,7 +860,7 @@ __device__ __forceinline__ double evaluate_objective(const double* vtx, const do
   for (int r = 0; r < rounds; ++r) {
     const int k = kk + r * kl;
     double Jk = 0.0, qfk = 0.0;
-    if (active && k <= S && (k == 0 || S > 1)) Jk = forward_cost<ND>(vtx, seg, hc, S, d, pt, k, dim0, qfk);
+    if (active && k <= S && (k == 0 || S > 1)) Jk = forward_cost<ND, MASKED4>(vtx, seg, hc, S, d, pt, k, dim0, qfk);
     if (DS == 4) {  // the four dimensions of one time vector sit in one quad
       Jk += dpp_move<0xB1>(Jk);
       Jk += dpp_move<0x4E>(Jk);
@@ -923,7 +926,7 @@ struct BinTable {
   int group[5], q_begin[5], q_count[5], max_S[5], block_begin[5];
 };
 
-template <int DS>
+template <int DS, bool MASKED4 = false>
 __device__ __forceinline__ void optimize_body(const BatchView& b, const NonlinearParams& prm, const BinTable& bins,
                                               const uint8_t* __restrict__ mask, const double* __restrict__ vals,
                                               double* __restrict__ seg_times, int32_t* __restrict__ opt_status) {
@@ -1067,7 +1070,7 @@ __device__ __forceinline__ void optimize_body(const BatchView& b, const Nonlinea
     if (pair_ok) {
       fn = evaluate_pair(seg, hc, pair_state, S, d, xn, gn, g, !done, pair_special);
     } else {
-      fn = evaluate_objective<DS>(vtx, seg, hc, S, d, xn, gn, g, G, !done);
+      fn = evaluate_objective<DS, MASKED4>(vtx, seg, hc, S, d, xn, gn, g, G, !done);
       if (two_wave) __syncthreads();  // the partner's hand-over barrier
     }
     __syncthreads();
@@ -1419,11 +1422,12 @@ __global__ __launch_bounds__(128, 2) void optimize_split_kernel(BatchView b, Non
   optimize_body<4>(b, prm, bins, mask, vals, seg_times, opt_status);
 }
 
+template <bool MASKED4>
 __global__ __launch_bounds__(64) void optimize_compact_kernel(BatchView b, NonlinearParams prm, BinTable bins,
                                                               const uint8_t* __restrict__ mask,
                                                               const double* __restrict__ vals, double* __restrict__ seg_times,
                                                               int32_t* __restrict__ opt_status) {
-  optimize_body<1>(b, prm, bins, mask, vals, seg_times, opt_status);
+  optimize_body<1, MASKED4>(b, prm, bins, mask, vals, seg_times, opt_status);
 }
 
 // per-segment maxima, one (k, group) per blockIdx.y: maxima[seg * 9 + 3 (k-1) + group]
@@ -1990,17 +1994,25 @@ hipError_t launch_nonlinear(NonlinearPlan& nl, const BatchView& b, const Nonline
     const unsigned threads = (nl.dim_split == 4 && all_single) ? 128u : 64u;
     if (threads == 128u) lds_bytes += (64 * kPairState + 2) * sizeof(double);  // hand-over area + flags
     if (lds_bytes > 160 * 1024) return hipErrorInvalidValue;
+    // objective order below snap: the end vertices of rest-to-rest paths keep free slots, so the large-batch kernel is
+    // launched with the masked step compiled in (the min-snap instantiation stays free of it)
+    const bool masked4 = prm.derivative < 4;
     if (lds_bytes > 64 * 1024) {
-      e = nl.dim_split == 4 ? hipFuncSetAttribute((const void*)optimize_split_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes)
-                            : hipFuncSetAttribute((const void*)optimize_compact_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+      const void* fn = nl.dim_split == 4 ? (const void*)optimize_split_kernel
+                       : masked4         ? (const void*)optimize_compact_kernel<true>
+                                         : (const void*)optimize_compact_kernel<false>;
+      e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
       if (e != hipSuccess) return e;
     }
     if (nl.dim_split == 4)
       hipLaunchKernelGGL(optimize_split_kernel, dim3(blocks), dim3(threads), lds_bytes, stream, b, prm, bt, mask, vals, seg_times,
                          nl.d_opt_status);
+    else if (masked4)
+      hipLaunchKernelGGL(optimize_compact_kernel<true>, dim3(blocks), dim3(64), lds_bytes, stream, b, prm, bt, mask, vals,
+                         seg_times, nl.d_opt_status);
     else
-      hipLaunchKernelGGL(optimize_compact_kernel, dim3(blocks), dim3(64), lds_bytes, stream, b, prm, bt, mask, vals, seg_times,
-                         nl.d_opt_status);
+      hipLaunchKernelGGL(optimize_compact_kernel<false>, dim3(blocks), dim3(64), lds_bytes, stream, b, prm, bt, mask, vals,
+                         seg_times, nl.d_opt_status);
     if ((e = hipGetLastError()) != hipSuccess) return e;
   }
   // 2. trajectory of the last evaluated point (scaleSegmentTimesWithViolation works on poly_opt_'s state)
