@@ -79,14 +79,20 @@ __global__ __launch_bounds__(256) void assemble_blocks_kernel(BatchView b, int d
 
 // uniform batches (every path has S segments, so position q == path q and segment (q, j) sits at q*S + j):
 // no indirection loads
-__global__ __launch_bounds__(256) void assemble_blocks_uniform_kernel(int n_paths, int S, int d,
-                                                                      const double* __restrict__ seg_times,
-                                                                      double* __restrict__ Hout,
-                                                                      double* __restrict__ Aout) {
-  const int q = blockIdx.x * 256 + threadIdx.x;
+// One-dimensional grid of (path chunk, row, slot) workgroups, the chunk slowest, numbered so that each XCD owns a
+// contiguous range (xcd_contiguous_index): the XCD that writes the blocks of paths [128 c, 128 c + 128) is then the XCD
+// whose tiles of the solve kernel read them (same partition of the paths over the XCDs), and finds them in its own L2.
+constexpr int kAssembleChunk = 128;
+__global__ __launch_bounds__(kAssembleChunk) void assemble_blocks_uniform_kernel(int n_paths, int S, int d,
+                                                                                 const double* __restrict__ seg_times,
+                                                                                 double* __restrict__ Hout,
+                                                                                 double* __restrict__ Aout) {
+  const int logical = xcd_contiguous_index(blockIdx.x, gridDim.x);
+  const int per_chunk = kN * S;
+  const int chunk = logical / per_chunk, rem = logical - chunk * per_chunk;
+  const int j = rem / kN, a = rem - j * kN;
+  const int q = chunk * kAssembleChunk + threadIdx.x;
   if (q >= n_paths) return;
-  const int a = blockIdx.y;
-  const int j = blockIdx.z;
   const double T = seg_times[(size_t)q * S + j];
   const size_t P = (size_t)n_paths;
   store_block_rows(T, d, a, ((size_t)j * 100 + (size_t)a * kN) * P + (size_t)q, P, Hout, Aout);
@@ -321,9 +327,9 @@ hipError_t launch_assemble(const BatchView& b, int d, const double* seg_times, d
                            hipStream_t stream) {
   if (b.n_segments == 0) return hipSuccess;
   if (b.uniform_S > 0) {
-    dim3 grid(cdiv(b.n_paths, 256), kN, b.uniform_S);
-    hipLaunchKernelGGL(assemble_blocks_uniform_kernel, grid, dim3(256), 0, stream, b.n_paths, b.uniform_S, d, seg_times,
-                       H, Ainv);
+    dim3 grid(cdiv(b.n_paths, kAssembleChunk) * kN * b.uniform_S);
+    hipLaunchKernelGGL(assemble_blocks_uniform_kernel, grid, dim3(kAssembleChunk), 0, stream, b.n_paths, b.uniform_S, d,
+                       seg_times, H, Ainv);
   } else {
     dim3 grid(cdiv(b.n_paths, 256), kN, b.max_segments);
     hipLaunchKernelGGL(assemble_blocks_kernel, grid, dim3(256), 0, stream, b, d, seg_times, H, Ainv);
