@@ -14,9 +14,10 @@ status to rank 0 ("exactly one gather at the end") -- runs inside 
 `--gather every` gathers after every step instead (double-buffered on a side stream); for N > 1 that
 rate is reported next to the headline as extras.gather_every_step.
 
-Steps are independent batches, so `--in-flight` of them (default 2) are kept in flight per GPU, each on its own HIP
-stream with its own context and plan: a 1024-path batch leaves most of an MI355X idle (one wavefront per CU in the
-serial phase of the solve), and the assembly of batch k + 1 overlaps the solve of batch k.  Every step still does all
+Steps are independent batches, so `--in-flight` of them (default 4 = the HIP runtime's hardware queues per process)
+are kept in flight per GPU, each on its own HIP stream with its own context and plan: a 1024-path batch leaves most of
+an MI355X idle (one wavefront per CU in the serial phase of the solve), and the assembly of one batch overlaps the
+solves of the others.  Every step still does all
 of its work; `extras.one_batch_in_flight` is the same measurement with one stream (each step waits for the previous).
 
 Prints ONE JSON line (rank 0) with `roofline` (assembly kernel, HBM-write bound, HIP-event timed on the
@@ -51,7 +52,7 @@ def parse_args():
     ap.add_argument("--gather", choices=["final", "every"], default="final",
                     help="N > 1: gather the results to rank 0 once at the end of the timed steps (default) or after every step")
     ap.add_argument("--force-dist", action="store_true", help="initialise torch.distributed even for one rank (tests the RCCL path)")
-    ap.add_argument("--in-flight", type=int, default=2,
+    ap.add_argument("--in-flight", type=int, default=4,
                     help="independent batches in flight per GPU: steps are issued round-robin on this many HIP streams "
                          "(one context + plan each); 1 = every step waits for the previous one")
     return ap.parse_args()

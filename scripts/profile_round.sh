@@ -10,7 +10,7 @@ run() {  # name, bench arguments...
   f=$(find gpurun_out/prof_$name -name '*kernel_stats.csv' | head -1)
   [ -n "$f" ] && cp "$f" gpurun_out/${tag}_${name}_kernel_stats.csv
 }
-run bench_linear --steps 200 --warmup 20 --no-cpu-baseline --no-extras   # the bench command (two batches in flight: kernels of the two streams overlap)
+run bench_linear --steps 200 --warmup 20 --no-cpu-baseline --no-extras   # the bench command (four batches in flight: kernels of the streams overlap)
 run bench_linear_one_in_flight --in-flight 1 --steps 200 --warmup 20 --no-cpu-baseline --no-extras   # per-kernel durations without overlap
 run bench_nonlinear_1024 --workload nonlinear --in-flight 1 --steps 50 --warmup 5 --no-cpu-baseline --no-extras
 run bench_nonlinear_8192 --workload nonlinear --in-flight 1 --paths 8192 --steps 30 --warmup 5 --no-cpu-baseline --no-extras
