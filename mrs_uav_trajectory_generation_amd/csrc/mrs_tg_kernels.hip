@@ -346,6 +346,8 @@ hipError_t launch_solve_linear(const BatchView& b, int d, bool fused, const uint
                                double* coeffs, int32_t* status, double* cost, const int32_t* status_in,
                                hipStream_t stream) {
   if (b.n_paths == 0) return hipSuccess;
+  if (fused && rows_kernel_applies(b))
+    return launch_solve_rows(b, d, mask, vals, seg_times, coeffs, status, cost, status_in, stream);
   if (tile_kernel_applies(b, fused))
     return launch_solve_tile(b, d, fused, mask, vals, seg_times, H, Ainv, coeffs, status, cost, status_in, stream);
   if (use_split_dims(b.n_paths)) {

@@ -35,4 +35,9 @@ hipError_t launch_solve_tile(const BatchView& b, int d, bool fused, const uint8_
                              const double* seg_times, const double* H, const double* Ainv, double* coeffs,
                              int32_t* status, double* cost, const int32_t* status_in, hipStream_t stream);
 
+// one lane per unknown, no materialised blocks (mrs_tg_rows.hip): the fused linear solve of every path that fits its LDS record
+bool rows_kernel_applies(const BatchView& b);
+hipError_t launch_solve_rows(const BatchView& b, int d, const uint8_t* mask, const double* vals, const double* seg_times,
+                             double* coeffs, int32_t* status, double* cost, const int32_t* status_in, hipStream_t stream);
+
 }  // namespace mrs_tg

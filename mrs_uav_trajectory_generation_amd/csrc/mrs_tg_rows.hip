@@ -1,0 +1,548 @@
+// mrs_tg_rows.hip -- linear QP solve with one lane per unknown (the latency-optimised solve kernel for fixed times).
+//
+// What it replaces: PolynomialOptimization::updateSegmentTimes + constructR + solveLinear +
+// updateSegmentsFromCompactConstraints + computeCost for every path of a batch
+// (/root/reference/include/eth_trajectory_generation/impl/polynomial_optimization_linear_impl.h:289-304, 311-373,
+// 264-282, 128-141).
+//
+// A wavefront owns two paths (one for small batches) from their constraints to their coefficients; no workgroup
+// barrier, no other wavefront involved:
+//   stage    one lane per vertex / segment: constraints -> LDS (constrained values, free factors); per segment the
+//            powers of T the matrix entries need and the position difference of its end vertices;
+//   build    one lane per unknown (vertex, slot): the lane forms ITS column of the reduced matrix R_pp and its four
+//            right-hand sides directly from the time-normalised constants (mrs_tg_constants.h): column entries are
+//            HBAR * T^p, the right-hand sides -H (p_start - p_end) (a constant polynomial costs nothing, so the position
+//            columns of H differ by their sign only) -- nothing is assembled in memory;
+//   solve    two-sided elimination, 16 lanes per (path, direction), rank-one updates as v_fmac_f64_dpp row broadcasts
+//            (mrs_tg_rowelim.hpp); the four outermost vertices of a side are built by all quads at once, further
+//            vertices (and the middle one) when their quad becomes free;
+//   recover  one lane per (segment, dimension): c = A^-1 d, and the cost as the reference computes it, 0.5 c^T Q c
+//            (no cancellation, unlike the elimination by-product 0.5 (f^T H f - sum y^2 / pivot)).
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <cstdlib>
+
+#include "mrs_tg_device.hpp"
+#include "mrs_tg_rowelim.hpp"
+
+namespace mrs_tg {
+
+// LDS records (doubles)
+//   vertex : f[5][4] constrained end-point derivatives (0 where free) | free factors of the slots 1..4 (0.0 / 1.0) |
+//            x[4][4] the solution of the slots 1..4 (exactly 0 on a constrained slot: identity row, zero right-hand side)
+//            | parking space for the four eliminated columns of a long path (12 each)
+//   segment: q[k] = T^(2 + k - 2d), k = 0..3 | T | pad | p_i - p_{i+1} per dimension
+//   cost   : one partial per (segment, dimension)
+constexpr int kRVtxDer = 0, kRVtxFree = 20, kRVtxX = 24, kRVtxPark = 40, kRVtxRec = 88;
+constexpr int kRSegPow = 0, kRSegT = 4, kRSegDp = 6, kRSegRec = 10;
+
+__host__ __device__ constexpr int rows_path_doubles(int S) {
+  const int base = (S + 1) * kRVtxRec + S * kRSegRec + S * kD;
+  return base + (base & 1) + 2;  // 16-byte aligned records, paths of a wavefront off each other's banks
+}
+
+__device__ __forceinline__ void wave_lds_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
+
+// B[D][i] B[D][j] / (i + j - 2D + 1): 0.5 c^T Q c = T^(1-2D) sum_ij G_ij (c_i T^i)(c_j T^j)
+// (computeQuadraticCostJacobian, linear_impl.h:606-618, with the factor 2 of Q against the 0.5 of the cost)
+template <int D>
+__device__ __forceinline__ double cost_quadratic_form(const double (&cb)[kN]) {
+  double total = 0.0;
+#pragma unroll
+  for (int i = D; i < kN; ++i) {
+    double bi = 1.0;
+#pragma unroll
+    for (int n = 0; n < D; ++n) bi *= (double)(i - n);
+    double inner = 0.0;
+#pragma unroll
+    for (int j = D; j < kN; ++j) {
+      double bj = 1.0;
+#pragma unroll
+      for (int n = 0; n < D; ++n) bj *= (double)(j - n);
+      inner = fma(bi * bj / (double)(i + j - 2 * D + 1), cb[j], inner);
+    }
+    total = fma(cb[i], inner, total);
+  }
+  return total;
+}
+
+#ifdef MRS_TG_ROWS_DEBUG
+__device__ double g_rows_debug[64 * 24 * 2];
+#endif
+
+struct RowSolve : RowCore {
+  int S, mid, nact;
+  bool store_ok;   // false for the spare rows of a wavefront that holds one path
+  bool general;    // some constrained derivative value of the path is non-zero (initial state): full right-hand sides
+  int d;
+  double* vtx0;
+  double* seg0;
+  // per-lane constants of the column (depend on slot and direction only)
+  double cOwnN[4], cNext[4], cOwnP[4], cPrev[4], cRhsN, cRhsP;
+  // the column being built
+  double own[4], nxt[4], prv[4], rhs[4];
+
+  __device__ __forceinline__ double* vtx_rec(int v) const { return vtx0 + v * kRVtxRec; }
+  __device__ __forceinline__ double* seg_rec(int i) const { return seg0 + i * kRSegRec; }
+  __device__ __forceinline__ int vertex_at(int w) const { return dir ? mid + w : mid - w; }
+
+  // H(a, b) = HBAR_d[a][b] T^((a%5) + (b%5) + 1 - 2d).  The unknown (v, k) sits in row 1 + k of the segment that starts at
+  // v and in row 6 + k of the segment that ends there; "N" is the segment towards the middle, "P" the one towards the
+  // end this row started from.
+  __device__ __forceinline__ void load_constants() {
+    const double* hb = &c_hbar[d][0][0];
+    const int row_s = 1 + k, row_e = 6 + k;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int ss = (1 + j) * kN + row_s, ee = (6 + j) * kN + row_e;  // diagonal blocks: start half, end half
+      const int fwd = row_s * kN + 6 + j;                                // (v, k) with slot j of the following vertex
+      const int bwd = (1 + j) * kN + row_e;                              // (v, k) with slot j of the preceding vertex
+      cOwnN[j] = hb[dir ? ee : ss];
+      cOwnP[j] = hb[dir ? ss : ee];
+      cNext[j] = hb[dir ? bwd : fwd];
+      cPrev[j] = hb[dir ? fwd : bwd];
+    }
+    cRhsN = hb[(dir ? row_e : row_s) * kN];
+    cRhsP = hb[(dir ? row_s : row_e) * kN];
+  }
+
+  // column of the unknown (vertex at distance w, slot k) -> own / nxt / prv / rhs
+  __device__ __forceinline__ void build(int w) {
+    const int v = min(max(vertex_at(w), 0), S);  // (a shorter path that shares the wavefront builds out of turn; unused)
+    const int iN = dir ? v - 1 : v, iP = dir ? v : v - 1;
+    const bool hasN = iN >= 0 && iN < S, hasP = iP >= 0 && iP < S;
+    const double* sn = seg_rec(min(max(iN, 0), S - 1));
+    const double* sp = seg_rec(min(max(iP, 0), S - 1));
+    const double* vo = vtx_rec(v);
+    const double* vn = vtx_rec(min(max(dir ? v - 1 : v + 1, 0), S));
+    const double* vp = vtx_rec(min(max(dir ? v + 1 : v - 1, 0), S));
+    double qN = sn[kRSegPow + k], qP = sp[kRSegPow + k];
+    const double TN = sn[kRSegT], TP = sp[kRSegT];
+    const double2 dN01 = *reinterpret_cast<const double2*>(sn + kRSegDp), dN23 = *reinterpret_cast<const double2*>(sn + kRSegDp + 2);
+    const double2 dP01 = *reinterpret_cast<const double2*>(sp + kRSegDp), dP23 = *reinterpret_cast<const double2*>(sp + kRSegDp + 2);
+    const double2 mo01 = *reinterpret_cast<const double2*>(vo + kRVtxFree), mo23 = *reinterpret_cast<const double2*>(vo + kRVtxFree + 2);
+    const double2 mn01 = *reinterpret_cast<const double2*>(vn + kRVtxFree), mn23 = *reinterpret_cast<const double2*>(vn + kRVtxFree + 2);
+    const double2 mp01 = *reinterpret_cast<const double2*>(vp + kRVtxFree), mp23 = *reinterpret_cast<const double2*>(vp + kRVtxFree + 2);
+    const double mk = vo[kRVtxFree + k];
+    qN = hasN ? qN : 0.0;  // a segment that does not exist contributes nothing
+    qP = hasP ? qP : 0.0;
+    const double mo[4] = {mo01.x, mo01.y, mo23.x, mo23.y}, mn[4] = {mn01.x, mn01.y, mn23.x, mn23.y},
+                 mp[4] = {mp01.x, mp01.y, mp23.x, mp23.y};
+    const double dN[4] = {dN01.x, dN01.y, dN23.x, dN23.y}, dP[4] = {dP01.x, dP01.y, dP23.x, dP23.y};
+    double pN[4], pP[4];
+    pN[0] = qN * TN;
+    pP[0] = qP * TP;
+#pragma unroll
+    for (int j = 1; j < 4; ++j) {
+      pN[j] = pN[j - 1] * TN;
+      pP[j] = pP[j - 1] * TP;
+    }
+    // the backward direction brings only its Schur update to the middle vertex: its copy starts from zero
+    const bool zero = (w == 0 && dir == 1);
+    const double mkz = zero ? 0.0 : mk;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const double both = fma(cOwnN[j], pN[j], cOwnP[j] * pP[j]);
+      double o = (mkz * mo[j]) * both;
+      if (j == k) o += zero ? 0.0 : 1.0 - mk;  // constrained slot: identity row (everything else in it is masked to zero)
+      own[j] = o;
+      nxt[j] = (mk * mn[j]) * (cNext[j] * pN[j]);
+      prv[j] = (mk * mp[j]) * (cPrev[j] * pP[j]);
+    }
+    const double gN = -mkz * (cRhsN * qN), gP = -mkz * (cRhsP * qP);
+#pragma unroll
+    for (int dd = 0; dd < 4; ++dd) rhs[dd] = fma(gN, dN[dd], gP * dP[dd]);
+    if (general && !zero) {
+      // constrained derivative values that are not zero (the initial state of a path that starts in motion,
+      // src/mrs_trajectory_generation.cpp:946-957): the remaining columns of H f
+      const int rowN = dir ? 6 + k : 1 + k, rowP = dir ? 1 + k : 6 + k;
+      const int ownN = dir ? 5 : 0, othN = dir ? 0 : 5, ownP = dir ? 0 : 5, othP = dir ? 5 : 0;
+      double acc[4] = {0.0, 0.0, 0.0, 0.0};
+      for (int bb = 1; bb <= 4; ++bb) {
+        const double hNo = c_hbar[d][rowN][ownN + bb] * pN[bb - 1], hNn = c_hbar[d][rowN][othN + bb] * pN[bb - 1];
+        const double hPo = c_hbar[d][rowP][ownP + bb] * pP[bb - 1], hPp = c_hbar[d][rowP][othP + bb] * pP[bb - 1];
+        for (int dd = 0; dd < 4; ++dd) {
+          const double fo = vo[kRVtxDer + bb * kD + dd], fn = vn[kRVtxDer + bb * kD + dd], fp = vp[kRVtxDer + bb * kD + dd];
+          acc[dd] += (hNo + hPo) * fo + hNn * fn + hPp * fp;
+        }
+      }
+#pragma unroll
+      for (int dd = 0; dd < 4; ++dd) rhs[dd] -= mk * acc[dd];
+    }
+  }
+
+  template <int Q>
+  __device__ __forceinline__ void place(bool mine) {
+    if (mine) {
+      constexpr int N = 4 * ((Q + 3) % 4), P = 4 * ((Q + 1) % 4);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        A[4 * Q + j] = own[j];
+        A[N + j] = nxt[j];
+        A[P + j] = prv[j];
+      }
+#pragma unroll
+      for (int dd = 0; dd < 4; ++dd) B[dd] = rhs[dd];
+    }
+  }
+
+  template <int Q>
+  __device__ __forceinline__ void park(int w, bool mine) {
+    if (mine && store_ok) {
+      constexpr int N = 4 * ((Q + 3) % 4);
+      double2* fr = reinterpret_cast<double2*>(vtx_rec(vertex_at(w)) + kRVtxPark + 12 * k);
+      fr[0] = make_double2(A[4 * Q], A[4 * Q + 1]);
+      fr[1] = make_double2(A[4 * Q + 2], A[4 * Q + 3]);
+      fr[2] = make_double2(A[N], A[N + 1]);
+      fr[3] = make_double2(A[N + 2], A[N + 3]);
+      fr[4] = make_double2(B[0], B[1]);
+      fr[5] = make_double2(B[2], B[3]);
+    }
+  }
+
+  template <int Q>
+  __device__ __forceinline__ void restore(int w, bool mine) {
+    if (mine) {
+      constexpr int N = 4 * ((Q + 3) % 4);
+      const double2* fr = reinterpret_cast<const double2*>(vtx_rec(vertex_at(w)) + kRVtxPark + 12 * k);
+      const double2 a = fr[0], b = fr[1], c = fr[2], e = fr[3], f = fr[4], g = fr[5];
+      A[4 * Q] = a.x, A[4 * Q + 1] = a.y, A[4 * Q + 2] = b.x, A[4 * Q + 3] = b.y;
+      A[N] = c.x, A[N + 1] = c.y, A[N + 2] = e.x, A[N + 3] = e.y;
+      B[0] = f.x, B[1] = f.y, B[2] = g.x, B[3] = g.y;
+    }
+  }
+
+  // forward step at distance w >= 1 (quad Q = w % 4).  REFILL (w >= 4): the quad is needed again for the vertex four
+  // steps further in (the middle vertex at w = 4): its columns are parked and the new vertex is built in their place.
+  template <int Q, bool REFILL>
+  __device__ __forceinline__ void forward_step(int w) {
+    const bool act = w <= nact;
+    const bool mine = quad == Q && act;
+    eliminate_vertex<Q>(act);
+    scale_columns<Q>(mine);
+    if (REFILL) {
+      park<Q>(w, mine);
+      build(w - 4);
+      place<Q>(mine);
+    }
+  }
+
+  // backward step at distance w (quad Q): hand this vertex's solution to the vertex one further out and to the own
+  // lower slots; RESTORE: that vertex was parked.  Then x goes to LDS (the recover phase forms d = f + x).
+  template <int Q, bool RESTORE>
+  __device__ __forceinline__ void backward_step(int w) {
+    if (RESTORE) restore<(Q + 1) % 4>(w + 1, quad == (Q + 1) % 4 && w + 1 <= nact);
+    back_vertex<Q>();
+    if (quad == Q && w <= nact && store_ok && (w > 0 || dir == 0)) {
+      double2* xr = reinterpret_cast<double2*>(vtx_rec(vertex_at(w)) + kRVtxX + k * kD);
+      xr[0] = make_double2(B[0], B[1]);
+      xr[1] = make_double2(B[2], B[3]);
+    }
+  }
+
+  template <bool REFILL>
+  __device__ __forceinline__ void forward_dispatch(int w) {
+    switch (w & 3) {
+      case 0: forward_step<0, REFILL>(w); break;
+      case 1: forward_step<1, REFILL>(w); break;
+      case 2: forward_step<2, REFILL>(w); break;
+      default: forward_step<3, REFILL>(w); break;
+    }
+  }
+
+  // wmax = largest nact of the wavefront (wave-uniform)
+  __device__ __forceinline__ void run(int wmax) {
+#pragma unroll
+    for (int j = 0; j < 16; ++j) A[j] = 0.0;
+#pragma unroll
+    for (int dd = 0; dd < 4; ++dd) B[dd] = 0.0;
+    own_inv = 0.0;
+    // every quad builds the outermost vertex it is responsible for, all at once
+    {
+      int w0 = -1;
+      if (quad <= nact) w0 = nact - ((nact - quad) & 3);  // largest w <= nact with w % 4 == quad
+      if (quad == 0 && nact < 4) w0 = 0;                  // quad 0 starts with the middle vertex on a short side
+      build(w0 < 0 ? 0 : w0);
+      const bool have = w0 >= 0;
+      place<0>(have && quad == 0);
+      place<1>(have && quad == 1);
+      place<2>(have && quad == 2);
+      place<3>(have && quad == 3);
+    }
+    MRS_TG_PHASE_MARK(10);
+#ifdef MRS_TG_ROWS_DEBUG
+    if (blockIdx.x == 0) {
+      for (int j = 0; j < 16; ++j) g_rows_debug[threadIdx.x * 24 + j] = A[j];
+      for (int j = 0; j < 4; ++j) g_rows_debug[threadIdx.x * 24 + 16 + j] = B[j];
+      g_rows_debug[threadIdx.x * 24 + 20] = nact;
+      g_rows_debug[threadIdx.x * 24 + 21] = cOwnN[0];
+      g_rows_debug[threadIdx.x * 24 + 22] = cNext[0];
+      g_rows_debug[threadIdx.x * 24 + 23] = cRhsN;
+    }
+#endif
+    for (int w = wmax; w > 4; --w) forward_dispatch<true>(w);
+    if (wmax >= 4) forward_step<0, true>(4);
+    if (wmax >= 3) forward_step<3, false>(3);
+    if (wmax >= 2) forward_step<2, false>(2);
+    if (wmax >= 1) forward_step<1, false>(1);
+    MRS_TG_PHASE_MARK(11);
+    middle();
+    MRS_TG_PHASE_MARK(12);
+#ifdef MRS_TG_ROWS_DEBUG
+    if (blockIdx.x == 0) {
+      for (int j = 0; j < 16; ++j) g_rows_debug[64 * 24 + threadIdx.x * 24 + j] = A[j];
+      for (int j = 0; j < 4; ++j) g_rows_debug[64 * 24 + threadIdx.x * 24 + 16 + j] = B[j];
+    }
+#endif
+    backward_step<0, false>(0);
+    if (wmax >= 1) backward_step<1, false>(1);
+    if (wmax >= 2) backward_step<2, false>(2);
+    if (wmax >= 3) {
+      if (wmax >= 4) backward_step<3, true>(3);
+      else backward_step<3, false>(3);
+    }
+    for (int w = 4; w <= wmax; ++w) {
+      if (w < wmax) {
+        switch (w & 3) {
+          case 0: backward_step<0, true>(w); break;
+          case 1: backward_step<1, true>(w); break;
+          case 2: backward_step<2, true>(w); break;
+          default: backward_step<3, true>(w); break;
+        }
+      } else {
+        switch (w & 3) {
+          case 0: backward_step<0, false>(w); break;
+          case 1: backward_step<1, false>(w); break;
+          case 2: backward_step<2, false>(w); break;
+          default: backward_step<3, false>(w); break;
+        }
+      }
+    }
+  }
+};
+
+__global__ __launch_bounds__(64) void solve_rows_kernel(BatchView b, int d, int ppw, int Smax,
+                                                        const uint8_t* __restrict__ mask, const double* __restrict__ vals,
+                                                        const double* __restrict__ seg_times, double* __restrict__ coeffs,
+                                                        int32_t* __restrict__ status, double* __restrict__ cost,
+                                                        const int32_t* __restrict__ status_in) {
+  extern __shared__ double lds[];
+  const int lane = threadIdx.x;
+  const int q0 = blockIdx.x * ppw;
+  const int n_here = min(ppw, b.n_paths - q0);
+  const int PS = rows_path_doubles(Smax);
+  MRS_TG_PHASE_MARK(0);
+
+  // row = (path of the wavefront, direction)
+  const int pl = (lane >> 4) & 1;
+  const int t = pl < n_here ? pl : n_here - 1;
+  const PathRef pr = path_at(b, q0 + t);
+  double* base = lds + (size_t)t * PS;
+  double* vtx0 = base;
+  double* seg0 = base + (size_t)(Smax + 1) * kRVtxRec;
+  double* pc0 = seg0 + (size_t)Smax * kRSegRec;
+
+  // the per-lane constants of the build are requested first: their latency hides behind the staging pass
+  RowSolve rs;
+  rs.dir = lane >> 5;
+  rs.quad = (lane >> 2) & 3;
+  rs.k = lane & 3;
+  rs.d = d;
+  rs.load_constants();
+
+  // ---- stage: constraints and segment data of the wavefront's paths -> LDS
+  bool pos_ok_lane = true, nonzero_lane = false;
+  unsigned long long pos_bad[2] = {0ull, 0ull}, gen_any[2] = {0ull, 0ull};
+#pragma unroll
+  for (int tt = 0; tt < 2; ++tt) {
+    if (tt >= n_here) break;
+    const int S_t = __builtin_amdgcn_readlane(pr.S, tt * 16), s0_t = __builtin_amdgcn_readlane(pr.s0, tt * 16),
+              v0_t = __builtin_amdgcn_readlane(pr.v0, tt * 16);
+    double* vb = lds + (size_t)tt * PS;
+    double* sb = vb + (size_t)(Smax + 1) * kRVtxRec;
+    pos_ok_lane = true;
+    nonzero_lane = false;
+    for (int v = lane; v <= S_t; v += 64) {
+      double f[kHalf][kD];
+      bool pos_fixed;
+      const unsigned fb = load_vertex<kD>(mask, vals, v0_t + v, 0, f, pos_fixed);
+      double* r = vb + (size_t)v * kRVtxRec;
+#pragma unroll
+      for (int kk = 0; kk < kHalf; ++kk)
+#pragma unroll
+        for (int dd = 0; dd < kD; ++dd) {
+          r[kRVtxDer + kk * kD + dd] = f[kk][dd];
+          if (kk >= 1) nonzero_lane = nonzero_lane || (f[kk][dd] != 0.0);
+        }
+#pragma unroll
+      for (int j = 0; j < kNB; ++j) r[kRVtxFree + j] = (double)((fb >> j) & 1u);
+#pragma unroll
+      for (int e = 0; e < kNB * kD; ++e) r[kRVtxX + e] = 0.0;  // stays for a fully constrained end vertex, which nobody solves
+      pos_ok_lane = pos_ok_lane && pos_fixed;
+    }
+    for (int i = lane; i < S_t; i += 64) {
+      const double T = seg_times[s0_t + i];
+      const double* ps = vals + (size_t)(v0_t + i) * kHalf * kD;  // constrained position of vertex i, then of i + 1
+      double* r = sb + (size_t)i * kRSegRec;
+      // T^(2 - 2d) as the assembly kernel forms it: T / (T^d)^2 ... times T
+      const double t2 = T * T;
+      double td = 1.0;
+      if (d == 1) td = T;
+      else if (d == 2) td = t2;
+      else if (d == 3) td = t2 * T;
+      else if (d == 4) td = t2 * t2;
+      double qk = t2 / (td * td);
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk) {
+        r[kRSegPow + kk] = qk;
+        qk *= T;
+      }
+      r[kRSegT] = T;
+#pragma unroll
+      for (int dd = 0; dd < kD; ++dd) r[kRSegDp + dd] = ps[dd] - ps[kHalf * kD + dd];
+    }
+    pos_bad[tt] = __ballot(!pos_ok_lane);
+    gen_any[tt] = __ballot(nonzero_lane);
+  }
+  wave_lds_sync();
+  MRS_TG_PHASE_MARK(1);
+
+  // ---- build + solve
+  {
+    rs.store_ok = pl < n_here;
+    rs.general = (t ? gen_any[1] : gen_any[0]) != 0ull;
+    rs.S = pr.S;
+    rs.mid = pr.S / 2;
+    rs.vtx0 = vtx0;
+    rs.seg0 = seg0;
+    // vertices a side eliminates: [0, m) or (m, S]; a fully constrained end vertex (every rest-to-rest path has two)
+    // has nothing to eliminate -- its rows are identity rows, its couplings are masked -- and is left out
+    {
+      const int len = rs.dir ? pr.S - rs.mid : rs.mid;
+      const double* ef = vtx0 + (size_t)(rs.dir ? pr.S : 0) * kRVtxRec + kRVtxFree;
+      const bool end_fixed = (ef[0] + ef[1] + ef[2] + ef[3]) == 0.0;
+      rs.nact = (len > 0 && end_fixed) ? len - 1 : len;
+    }
+    int wmax = max(max(__builtin_amdgcn_readlane(rs.nact, 0), __builtin_amdgcn_readlane(rs.nact, 16)),
+                   max(__builtin_amdgcn_readlane(rs.nact, 32), __builtin_amdgcn_readlane(rs.nact, 48)));
+    rs.run(wmax);
+  }
+  wave_lds_sync();
+  MRS_TG_PHASE_MARK(4);
+
+  // ---- recover: coefficients c = A^-1 [d_i; d_{i+1}] and the cost share 0.5 c^T Q c per (segment, dimension)
+  const int per_path = Smax * kD;
+  for (int item = lane; item < n_here * per_path; item += 64) {
+    const int tt = item >= per_path ? 1 : 0;
+    const int r = item - tt * per_path;
+    const int i = r >> 2, dim = r & 3;
+    const int S_t = __builtin_amdgcn_readlane(pr.S, 0);
+    const int S_u = __builtin_amdgcn_readlane(pr.S, 16);
+    if (i >= (tt ? S_u : S_t)) continue;
+    const int s0_t = tt ? __builtin_amdgcn_readlane(pr.s0, 16) : __builtin_amdgcn_readlane(pr.s0, 0);
+    const double* vb = lds + (size_t)tt * PS;
+    const double* sb = vb + (size_t)(Smax + 1) * kRVtxRec;
+    double* pcb = const_cast<double*>(sb) + (size_t)Smax * kRSegRec;
+    const double* vs = vb + (size_t)i * kRVtxRec;
+    const double* ve = vs + kRVtxRec;
+    const double T = sb[(size_t)i * kRSegRec + kRSegT];
+    double dv[kN];
+#pragma unroll
+    for (int kk = 0; kk < kHalf; ++kk) {
+      dv[kk] = vs[kRVtxDer + kk * kD + dim];
+      dv[kHalf + kk] = ve[kRVtxDer + kk * kD + dim];
+      if (kk >= kSlot0) {
+        dv[kk] += vs[kRVtxX + (kk - kSlot0) * kD + dim];
+        dv[kHalf + kk] += ve[kRVtxX + (kk - kSlot0) * kD + dim];
+      }
+    }
+    // c_k = T^-k sum_j ABAR_INV[k][j] T^(j%5) d_j ; cb_k = c_k T^k is what the cost needs
+    double w[kHalf];
+    w[0] = 1.0;
+#pragma unroll
+    for (int kk = 1; kk < kHalf; ++kk) w[kk] = w[kk - 1] * T;
+    double db[kN], cb[kN], c[kN];
+#pragma unroll
+    for (int j = 0; j < kN; ++j) db[j] = dv[j] * w[j % kHalf];
+    const double ti = 1.0 / T;
+    double tik = 1.0;
+#pragma unroll
+    for (int kk = 0; kk < kN; ++kk) {
+      double s = 0.0;
+      if (kk < kHalf) {
+        s = c_abar_inv[kk][kk] * db[kk];  // the upper half of ABAR_INV is diag(1/k!)
+      } else {
+#pragma unroll
+        for (int j = 0; j < kN; ++j) s += c_abar_inv[kk][j] * db[j];
+      }
+      cb[kk] = s;
+      c[kk] = s * tik;
+      tik *= ti;
+    }
+    double* out = coeffs + ((size_t)(s0_t + i) * kD + dim) * kN;
+#pragma unroll
+    for (int kk = 0; kk < kN; ++kk) out[kk] = c[kk];
+    double quad_form;
+    switch (d) {
+      case 0: quad_form = cost_quadratic_form<0>(cb); break;
+      case 1: quad_form = cost_quadratic_form<1>(cb); break;
+      case 2: quad_form = cost_quadratic_form<2>(cb); break;
+      case 3: quad_form = cost_quadratic_form<3>(cb); break;
+      default: quad_form = cost_quadratic_form<4>(cb); break;
+    }
+    // T^(1 - 2d) = q[0] / T
+    pcb[r] = quad_form * (sb[(size_t)i * kRSegRec + kRSegPow] * ti);
+  }
+  wave_lds_sync();
+
+  // ---- cost and status: the 16 lanes of a path's first row add its partial costs in a fixed order
+  if ((lane >> 5) == 0 && pl < n_here) {
+    const int l16 = lane & 15;
+    double s = 0.0;
+    for (int e = l16; e < pr.S * kD; e += 16) s += pc0[e];
+    s += __shfl_xor(s, 8, 64);
+    s += __shfl_xor(s, 4, 64);
+    s += __shfl_xor(s, 2, 64);
+    s += __shfl_xor(s, 1, 64);
+    if (l16 == 0) {
+      if (cost) cost[pr.p] = s;
+      if (status) status[pr.p] = merge_status((pl ? pos_bad[1] : pos_bad[0]) == 0ull, status_in, pr.p);
+    }
+  }
+  MRS_TG_PHASE_MARK(5);
+}
+
+// ---------------------------------------------------------------------------------------------
+// launcher
+
+static constexpr size_t kRowsLdsBudget = 144 * 1024;
+
+bool rows_kernel_applies(const BatchView& b) {
+  if (b.n_paths == 0) return false;
+  if (const char* e = std::getenv("MRS_TG_ROWS_KERNEL"))
+    if (std::atoi(e) == 0) return false;  // tuning / test knob: fall back to the tile and lane kernels
+  return (size_t)rows_path_doubles(b.max_segments) * sizeof(double) <= kRowsLdsBudget;
+}
+
+hipError_t launch_solve_rows(const BatchView& b, int d, const uint8_t* mask, const double* vals, const double* seg_times,
+                             double* coeffs, int32_t* status, double* cost, const int32_t* status_in, hipStream_t stream) {
+  const size_t per_path = (size_t)rows_path_doubles(b.max_segments) * sizeof(double);
+  // one path per wavefront while that still leaves SIMDs idle (256 CUs x 4); two paths per wavefront otherwise
+  int ppw = (b.n_paths <= 2048) ? 1 : 2;
+  if (const char* e = std::getenv("MRS_TG_ROWS_PPW")) ppw = std::atoi(e) == 1 ? 1 : 2;
+  if (per_path * 2 > kRowsLdsBudget) ppw = 1;
+  const size_t lds_bytes = per_path * (size_t)ppw;
+  hipError_t e = hipFuncSetAttribute((const void*)solve_rows_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kRowsLdsBudget);
+  if (e != hipSuccess) return e;
+  const unsigned grid = (unsigned)((b.n_paths + ppw - 1) / ppw);
+  hipLaunchKernelGGL(solve_rows_kernel, dim3(grid), dim3(64), lds_bytes, stream, b, d, ppw, b.max_segments, mask, vals,
+                     seg_times, coeffs, status, cost, status_in);
+  return hipGetLastError();
+}
+
+}  // namespace mrs_tg

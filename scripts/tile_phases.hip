@@ -6,6 +6,7 @@
 #define MRS_TG_PHASE_CLOCKS 1
 #include "../mrs_uav_trajectory_generation_amd/csrc/mrs_tg_kernels.hip"
 #include "../mrs_uav_trajectory_generation_amd/csrc/mrs_tg_tile.hip"
+#include "../mrs_uav_trajectory_generation_amd/csrc/mrs_tg_rows.hip"
 #include "../mrs_uav_trajectory_generation_amd/csrc/mrs_tg_nonlinear.hip"
 #include "../mrs_uav_trajectory_generation_amd/csrc/mrs_tg_pool.hip"
 
@@ -102,6 +103,25 @@ int main(int argc, char** argv) {
     printf("   inside B: entry %lld  elimination loop %lld  hand-over %lld  middle %lld  fence %lld  back substitution %lld  exit %lld\n",
            clk[10] - clk[3], clk[11] - clk[10], clk[12] - clk[11], clk[13] - clk[12], clk[14] - clk[13], clk[15] - clk[14],
            clk[4] - clk[15]);
+  }
+  // the rows kernel (one lane per unknown): the library's fused linear solve
+  for (int ppw = 1; ppw <= 2; ++ppw) {
+    setenv("MRS_TG_ROWS_PPW", ppw == 1 ? "1" : "2", 1);
+    for (int i = 0; i < 10; ++i) CK(launch_solve_rows(b, d, dmask, dvals, dT, coeffs, status, cost, nullptr, st));
+    CK(hipStreamSynchronize(st));
+    const int n = 200;
+    CK(hipEventRecord(e0, st));
+    for (int i = 0; i < n; ++i) CK(launch_solve_rows(b, d, dmask, dvals, dT, coeffs, status, cost, nullptr, st));
+    CK(hipEventRecord(e1, st));
+    CK(hipEventSynchronize(e1));
+    float ms;
+    CK(hipEventElapsedTime(&ms, e0, e1));
+    long long clk[32];
+    CK(hipMemcpyFromSymbol(clk, HIP_SYMBOL(g_phase_clock), sizeof(clk)));
+    printf("P=%d S=%d rows kernel, %d path(s) per wavefront: %.2f us per launch back to back; middle wavefront (shader cycles): stage %lld  "
+           "build %lld  forward %lld  middle vertex %lld  backward %lld  recover %lld  total %lld\n",
+           P, S, ppw, ms * 1e3 / n, clk[1] - clk[0], clk[10] - clk[1], clk[11] - clk[10], clk[12] - clk[11], clk[4] - clk[12],
+           clk[5] - clk[4], clk[5] - clk[0]);
   }
   // sampler: serial walk (lane 0) and parallel evaluation, dt 0.2, capacity 512
   {
