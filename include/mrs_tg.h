@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define MRS_TG_ABI_VERSION 1
+#define MRS_TG_ABI_VERSION 2
 #define MRS_TG_N_COEFF 10
 #define MRS_TG_N_DIM 4
 #define MRS_TG_N_SLOT 5 /* derivative slots per vertex: position .. snap */
@@ -51,7 +51,10 @@ enum {
 /* per-path status values (nlopt.h result codes, as consumed by the nodelet) */
 enum {
   MRS_TG_STATUS_FAILURE = -1,
-  MRS_TG_STATUS_INVALID_ARGS = -2,
+  MRS_TG_STATUS_INVALID_ARGS = -2, /* also: a vertex of the path leaves its POSITION unconstrained.  Every caller of the
+                                      reference constrains the position of every vertex (src/...cpp:944, 963, 967); the
+                                      general fixed / free patterns of setupConstraintReorderingMatrix
+                                      (linear_impl.h:184-257) are supported for the derivatives 1..4 only */
   MRS_TG_STATUS_SUCCESS = 1,
   MRS_TG_STATUS_FTOL_REACHED = 3,
   MRS_TG_STATUS_XTOL_REACHED = 4,
@@ -73,8 +76,12 @@ enum {
 };
 
 enum {
-  MRS_TG_FLAG_FUSED_ASSEMBLY = 1 /* linear mode: recompute the per-segment blocks inside the solve
-                                    kernel instead of reading the materialised ones */
+  MRS_TG_FLAG_FUSED_ASSEMBLY = 1,     /* the default since ABI 2 (kept so that ABI-1 callers still say what they mean): every
+                                         lane of the solve kernel forms its column of the reduced system straight from the
+                                         segment times; no block is written to memory */
+  MRS_TG_FLAG_MATERIALIZED_BLOCKS = 2 /* linear mode: run the assembly kernel (mrs_tg_plan_assemble: full H_i and A_i^-1 of
+                                         every segment in HBM, the reference's updateSegmentTimes + constructR products) and
+                                         solve from the materialised blocks */
 };
 
 typedef struct mrs_tg_options {
@@ -94,6 +101,12 @@ typedef struct mrs_tg_options {
   int32_t use_soft_constraints;   /* param soft_constraints_enabled (:5) */
   int32_t reserved_;
   double initial_stepsize_rel;    /* 0.1 (src/...cpp:893) */
+  double max_time_s;              /* nlopt maxtime (src/...cpp:899: 2 * 0.95 * timeLeft()); <= 0: none.  The time-allocation
+                                     search of a path that is still running when the budget has passed stops at its last
+                                     evaluated point with MRS_TG_STATUS_MAXTIME_REACHED (checked once per objective
+                                     evaluation against the device's constant-rate clock; the budget starts when the
+                                     search kernel starts, for mrs_tg_solve_batch minus the host time already spent in
+                                     the call) */
 } mrs_tg_options;
 
 typedef struct mrs_tg_ctx mrs_tg_ctx;
@@ -116,6 +129,30 @@ void mrs_tg_default_options(mrs_tg_options* opt);
 int mrs_tg_set_stream(mrs_tg_ctx* ctx, void* hip_stream);
 int mrs_tg_reset_stream(mrs_tg_ctx* ctx);
 int mrs_tg_synchronize(mrs_tg_ctx* ctx);
+
+/* ---- several devices -------------------------------------------------------------------------- */
+
+/* A set of contexts, one per entry of `device_ordinals` (an ordinal may repeat: two contexts on one GPU), for
+ * mrs_tg_multi_solve_batch.  The reference handles one path per request on one worker thread
+ * (src/mrs_trajectory_generation.cpp:1064-1083, 1513); paths are independent, so a batch shards over the devices with no
+ * exchange between them. */
+typedef struct mrs_tg_multi mrs_tg_multi;
+int mrs_tg_create_multi(const int* device_ordinals, int n_devices, mrs_tg_multi** multi_out);
+void mrs_tg_destroy_multi(mrs_tg_multi* multi);
+int mrs_tg_multi_n_devices(const mrs_tg_multi* multi);
+mrs_tg_ctx* mrs_tg_multi_context(mrs_tg_multi* multi, int index); /* the context of device `index` (owned by `multi`) */
+/* Which device solves which path: shard_out[p] in [0, n_devices).  Uniform batches are cut into contiguous ranges whose
+ * sizes differ by at most one; ragged batches are balanced on the segment count (longest path first onto the least
+ * loaded device). */
+int mrs_tg_multi_shard(const mrs_tg_multi* multi, int32_t n_paths, const int32_t* seg_offsets, int32_t* shard_out);
+/* mrs_tg_solve_batch over all devices of `multi`: same arguments, same results (every path is solved by exactly the
+ * kernels a single-device call would run on it).  One host thread per device solves its shard from / into the caller's
+ * buffers; returns the first error of any shard (mrs_tg_multi_last_error). */
+int mrs_tg_multi_solve_batch(mrs_tg_multi* multi, int32_t n_paths, const int32_t* seg_offsets, const double* waypoints,
+                             const uint8_t* fixed_mask, const double* fixed_values, const double* limits,
+                             const mrs_tg_options* opt, double* seg_times_inout, double* coeffs_out, int32_t* status_out,
+                             double* cost_out, int32_t* n_samples_out, double* samples_out);
+const char* mrs_tg_multi_last_error(const mrs_tg_multi* multi);
 
 /* ---- one-call host interface ---------------------------------------------------------------- */
 
@@ -188,9 +225,10 @@ int mrs_tg_plan_cost_gradient(mrs_tg_plan* plan, int32_t derivative_to_optimize,
 int mrs_tg_plan_segment_maxima(mrs_tg_plan* plan, const double* coeffs_dev, const double* seg_times_dev,
                                double* maxima_out_dev);
 
-/* Duration in milliseconds of the most recent launch of a kernel family, measured with HIP events on
- * the launch stream (requires mrs_tg_set_profiling(ctx, 1)); kernel_id: 0 assemble, 1 linear solve,
- * 2 nonlinear outer loop.  Blocks until that launch has finished. */
+/* Duration in milliseconds of the most recent launch of a kernel, from the start and end time stamps of that very dispatch
+ * (the events are attached to the kernel launch itself, hipExtLaunchKernelGGL: what rocprofv3 --kernel-trace reports for
+ * it) -- requires mrs_tg_set_profiling(ctx, 1).  kernel_id: 0 block assembly, 1 linear solve, 2 nonlinear outer loop.
+ * Blocks until that launch has finished. */
 int mrs_tg_set_profiling(mrs_tg_ctx* ctx, int enabled);
 int mrs_tg_last_kernel_ms(mrs_tg_ctx* ctx, int kernel_id, float* ms_out);
 
@@ -234,6 +272,11 @@ typedef struct mrs_tg_policy_options {
   int32_t fallback_sampling;           /* use findTrajectoryFallback (:1215-1395) instead of the optimiser */
   double fallback_speed_factor, fallback_accel_factor, fallback_stopping_time;
   int32_t override_heading_atan2;      /* getTrajectoryReference (:1582-1597) */
+  int32_t reserved_;
+  double max_execution_time_s;         /* max_execution_time (:2008-2033); <= 0: none.  Checked before every round: the
+                                          solver's max_time_s becomes 2 * 0.95 * time left (:899) and a path that is still
+                                          active when the time is up fails, as overtime() makes the nodelet give up
+                                          (:1085, 1156, 1171, 1516-1522) */
 } mrs_tg_policy_options;
 
 void mrs_tg_default_policy_options(mrs_tg_policy_options* opt);

@@ -25,7 +25,8 @@ TIME_ALLOC_RICHTER_TIME = 1
 TIME_ALLOC_MELLINGER = 2
 TIME_ALLOC_SQUARED_TIME_AND_CONSTRAINTS = 3
 TIME_ALLOC_RICHTER_TIME_AND_CONSTRAINTS = 4
-FLAG_FUSED_ASSEMBLY = 1
+FLAG_FUSED_ASSEMBLY = 1        # the default since ABI 2
+FLAG_MATERIALIZED_BLOCKS = 2   # assembly kernel + solve from the materialised H / A^-1 blocks
 
 KERNEL_ASSEMBLE, KERNEL_SOLVE_LINEAR, KERNEL_NONLINEAR = 0, 1, 2
 
@@ -40,7 +41,8 @@ class Options(C.Structure):
                 ("f_rel", C.c_double), ("f_abs", C.c_double), ("x_rel", C.c_double), ("x_abs", C.c_double),
                 ("sampling_dt", C.c_double), ("sample_capacity", C.c_int32), ("flags", C.c_int32),
                 ("time_penalty", C.c_double), ("soft_constraint_weight", C.c_double),
-                ("use_soft_constraints", C.c_int32), ("reserved_", C.c_int32), ("initial_stepsize_rel", C.c_double)]
+                ("use_soft_constraints", C.c_int32), ("reserved_", C.c_int32), ("initial_stepsize_rel", C.c_double),
+                ("max_time_s", C.c_double)]
 
 
 class PolicyOptions(C.Structure):
@@ -51,7 +53,7 @@ class PolicyOptions(C.Structure):
                 ("max_trajectory_len_factor", C.c_double), ("min_trajectory_len_factor", C.c_double),
                 ("fallback_sampling", C.c_int32), ("fallback_speed_factor", C.c_double),
                 ("fallback_accel_factor", C.c_double), ("fallback_stopping_time", C.c_double),
-                ("override_heading_atan2", C.c_int32)]
+                ("override_heading_atan2", C.c_int32), ("reserved_", C.c_int32), ("max_execution_time_s", C.c_double)]
 
 
 class Waypoint(C.Structure):
@@ -70,6 +72,8 @@ EXPORTED_SYMBOLS = [
     "mrs_tg_plan_assemble", "mrs_tg_plan_block_bytes", "mrs_tg_plan_solve", "mrs_tg_plan_cost_gradient",
     "mrs_tg_plan_segment_maxima", "mrs_tg_set_profiling", "mrs_tg_last_kernel_ms", "mrs_tg_find_trajectory",
     "mrs_tg_default_policy_options", "mrs_tg_optimize_paths", "mrs_tg_waypoint_trajectory_idxs",
+    "mrs_tg_create_multi", "mrs_tg_destroy_multi", "mrs_tg_multi_n_devices", "mrs_tg_multi_context", "mrs_tg_multi_shard",
+    "mrs_tg_multi_solve_batch", "mrs_tg_multi_last_error",
 ]
 
 _lib = None
@@ -143,6 +147,20 @@ def load_library():
                                         C.POINTER(PolicyOptions), C.c_int32, ip, ip, dp, dp, ip, ip]
     L.mrs_tg_waypoint_trajectory_idxs.restype = C.c_int32
     L.mrs_tg_waypoint_trajectory_idxs.argtypes = [dp, C.c_int32, C.POINTER(Waypoint), C.c_int32, ip]
+    L.mrs_tg_create_multi.restype = C.c_int
+    L.mrs_tg_create_multi.argtypes = [C.POINTER(C.c_int), C.c_int, C.POINTER(vp)]
+    L.mrs_tg_destroy_multi.restype = None
+    L.mrs_tg_destroy_multi.argtypes = [vp]
+    L.mrs_tg_multi_n_devices.restype = C.c_int
+    L.mrs_tg_multi_n_devices.argtypes = [vp]
+    L.mrs_tg_multi_context.restype = vp
+    L.mrs_tg_multi_context.argtypes = [vp, C.c_int]
+    L.mrs_tg_multi_shard.restype = C.c_int
+    L.mrs_tg_multi_shard.argtypes = [vp, C.c_int32, ip, ip]
+    L.mrs_tg_multi_solve_batch.restype = C.c_int
+    L.mrs_tg_multi_solve_batch.argtypes = [vp, C.c_int32, ip, dp, bp, dp, dp, C.POINTER(Options), dp, dp, ip, dp, ip, dp]
+    L.mrs_tg_multi_last_error.restype = C.c_char_p
+    L.mrs_tg_multi_last_error.argtypes = [vp]
     _lib = L
     return L
 
@@ -281,6 +299,62 @@ class Context:
         self._check(rc, "mrs_tg_find_trajectory")
         return dict(times=times, coeffs=coeffs, status=status.value, n_samples=ns.value,
                     samples=samples[:min(ns.value, sample_capacity)])
+
+
+class MultiContext:
+    """Several devices (mrs_tg_multi): a batch is sharded over them, one host thread per device."""
+
+    def __init__(self, devices):
+        self._L = load_library()
+        arr = (C.c_int * len(devices))(*[int(d) for d in devices])
+        h = C.c_void_p()
+        rc = self._L.mrs_tg_create_multi(arr, len(devices), C.byref(h))
+        if rc != 0:
+            raise MrsTgError("mrs_tg_create_multi failed (%d): %s" % (rc, self._L.mrs_tg_last_error(None).decode()))
+        self._h = h
+        self.n_devices = self._L.mrs_tg_multi_n_devices(h)
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._L.mrs_tg_destroy_multi(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def shard(self, seg_offsets):
+        so = np.ascontiguousarray(seg_offsets, dtype=np.int32)
+        out = np.zeros(so.size - 1, dtype=np.int32)
+        rc = self._L.mrs_tg_multi_shard(self._h, so.size - 1, _np_ptr(so), _np_ptr(out))
+        if rc != 0:
+            raise MrsTgError("mrs_tg_multi_shard failed (%d)" % rc)
+        return out
+
+    def solve_batch(self, batch: Batch, seg_times=None, **opts):
+        """Context.solve_batch over all devices (mrs_tg_multi_solve_batch)."""
+        opt = default_options(derivative_to_optimize=batch.derivative_to_optimize, **opts)
+        nS, P = batch.n_segments, batch.n_paths
+        if seg_times is None:
+            opt.estimate_times = 1
+            t = np.zeros(nS)
+        else:
+            t = np.ascontiguousarray(seg_times, dtype=np.float64).copy()
+        coeffs = np.zeros((nS, N_DIM, N_COEFF))
+        status = np.zeros(P, dtype=np.int32)
+        cost = np.zeros(P)
+        sampling = opt.sampling_dt > 0
+        n_samples = np.zeros(P, dtype=np.int32) if sampling else None
+        samples = np.zeros((P, max(opt.sample_capacity, 1), N_DIM)) if sampling else None
+        rc = self._L.mrs_tg_multi_solve_batch(self._h, P, _np_ptr(batch.seg_offsets), _np_ptr(batch.waypoints),
+                                              _np_ptr(batch.fixed_mask), _np_ptr(batch.fixed_values), _np_ptr(batch.limits),
+                                              C.byref(opt), _np_ptr(t), _np_ptr(coeffs), _np_ptr(status), _np_ptr(cost),
+                                              _np_ptr(n_samples), _np_ptr(samples))
+        if rc != 0:
+            raise MrsTgError("mrs_tg_multi_solve_batch failed (%d): %s" % (rc, self._L.mrs_tg_multi_last_error(self._h).decode()))
+        return dict(times=t, coeffs=coeffs, status=status, cost=cost, n_samples=n_samples, samples=samples)
 
 
 def _waypoint_array(paths, stop_flags=None):

@@ -7,6 +7,7 @@
 
 #include <algorithm>
 #include <atomic>
+#include <chrono>
 #include <cfloat>
 #include <cstdarg>
 #include <cstdio>
@@ -46,6 +47,10 @@ struct mrs_tg_ctx {
   hipEvent_t ev_stop[3] = {nullptr, nullptr, nullptr};
   bool ev_valid[3] = {false, false, false};
   hipDeviceProp_t prop;
+  double wall_clock_hz = 1.0e8;  // rate of s_memrealtime (hipDeviceAttributeWallClockRate)
+  // plan of the most recent mrs_tg_solve_batch: a caller that sends the same batch shape again (the nodelet's
+  // deviation loop, a server's fixed batch size) skips the analysis, the uploads and the device allocations
+  mrs_tg_plan* cached_plan = nullptr;
 };
 
 struct mrs_tg_plan {
@@ -77,22 +82,33 @@ int fail(mrs_tg_ctx* ctx, int code, const char* fmt, ...) {
   return code;
 }
 
+long long budget_ticks(const mrs_tg_ctx* ctx, double seconds_left) {
+  // a budget that is already spent still lets every path evaluate its start point once (nlopt checks after an evaluation)
+  const double t = seconds_left * ctx->wall_clock_hz;
+  return t < 1.0 ? 1ll : (t > 9.0e18 ? (long long)9.0e18 : (long long)t);
+}
+
 #define HIP_TRY(ctx, expr)                                                                        \
   do {                                                                                            \
     hipError_t e__ = (expr);                                                                      \
     if (e__ != hipSuccess) return fail((ctx), MRS_TG_ERR_HIP, "%s failed: %s", #expr, hipGetErrorString(e__)); \
   } while (0)
 
+// Arms the per-dispatch timer for the next timed launch of this thread (the main kernel of the family `kernel_id`):
+// the events ride on the kernel launch itself, so their difference is that dispatch's own duration.
 struct ProfileScope {
   mrs_tg_ctx* ctx;
   int id;
   ProfileScope(mrs_tg_ctx* c, int kernel_id) : ctx(c), id(kernel_id) {
-    if (ctx->profiling) (void)hipEventRecord(ctx->ev_start[id], ctx->stream);
+    if (ctx->profiling) {
+      mrs_tg::set_kernel_timer(ctx->ev_start[id], ctx->ev_stop[id]);
+      ctx->ev_valid[id] = false;
+    }
   }
   ~ProfileScope() {
     if (ctx->profiling) {
-      (void)hipEventRecord(ctx->ev_stop[id], ctx->stream);
-      ctx->ev_valid[id] = true;
+      const mrs_tg::KernelTimer left = mrs_tg::take_kernel_timer();  // consumed <=> a timed kernel was launched
+      ctx->ev_valid[id] = left.start == nullptr;
     }
   }
 };
@@ -134,6 +150,17 @@ int check_options(mrs_tg_ctx* ctx, const mrs_tg_options* opt) {
 
 }  // namespace
 
+namespace mrs_tg {
+int report_error(mrs_tg_ctx* ctx, int code, const char* fmt, ...) {
+  char buf[512];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof(buf), fmt, ap);
+  va_end(ap);
+  return fail(ctx, code, "%s", buf);
+}
+}  // namespace mrs_tg
+
 namespace {
 struct DevBuf {
   void* p = nullptr;
@@ -145,10 +172,6 @@ struct DevBuf {
   T* as() {
     return static_cast<T*>(p);
   }
-};
-struct PlanGuard {
-  mrs_tg_plan* p = nullptr;
-  ~PlanGuard() { mrs_tg_plan_destroy(p); }
 };
 }  // namespace
 
@@ -191,6 +214,7 @@ void mrs_tg_default_options(mrs_tg_options* opt) {
   opt->soft_constraint_weight = 1.5;   // :6
   opt->use_soft_constraints = 1;       // :5
   opt->initial_stepsize_rel = 0.1;     // src/mrs_trajectory_generation.cpp:893
+  opt->max_time_s = 0.0;               // no deadline (the nodelet sets 2 * 0.95 * timeLeft(), :899)
 }
 
 const char* mrs_tg_last_error(const mrs_tg_ctx* ctx) {
@@ -220,6 +244,11 @@ int mrs_tg_create(int device_ordinal, mrs_tg_ctx** ctx_out) {
     return fail(nullptr, MRS_TG_ERR_HIP, "device setup failed: %s", hipGetErrorString(e));
   }
   ctx->stream = ctx->own_stream;
+  {
+    int khz = 0;
+    if (hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, device_ordinal) == hipSuccess && khz > 0)
+      ctx->wall_clock_hz = 1.0e3 * (double)khz;
+  }
   for (int i = 0; i < 3; ++i) {
     (void)hipEventCreate(&ctx->ev_start[i]);
     (void)hipEventCreate(&ctx->ev_stop[i]);
@@ -233,6 +262,11 @@ void mrs_tg_destroy(mrs_tg_ctx* ctx) {
   if (!ctx) return;
   (void)hipSetDevice(ctx->device);
   (void)hipStreamSynchronize(ctx->stream);
+  if (ctx->cached_plan) {
+    mrs_tg_plan* p = ctx->cached_plan;
+    ctx->cached_plan = nullptr;
+    mrs_tg_plan_destroy(p);
+  }
   for (int i = 0; i < 3; ++i) {
     if (ctx->ev_start[i]) (void)hipEventDestroy(ctx->ev_start[i]);
     if (ctx->ev_stop[i]) (void)hipEventDestroy(ctx->ev_stop[i]);
@@ -270,7 +304,7 @@ int mrs_tg_set_profiling(mrs_tg_ctx* ctx, int enabled) {
 int mrs_tg_last_kernel_ms(mrs_tg_ctx* ctx, int kernel_id, float* ms_out) {
   if (!ctx || !ms_out) return fail(ctx, MRS_TG_ERR_INVALID_ARG, "NULL argument");
   if (kernel_id < 0 || kernel_id > 2 || !ctx->ev_valid[kernel_id])
-    return fail(ctx, MRS_TG_ERR_INVALID_ARG, "no timed launch recorded for kernel id %d", kernel_id);
+    return fail(ctx, MRS_TG_ERR_INVALID_ARG, "no timed launch recorded for kernel id %d (mrs_tg_set_profiling, then a call that runs that kernel)", kernel_id);
   HIP_TRY(ctx, hipEventSynchronize(ctx->ev_stop[kernel_id]));
   HIP_TRY(ctx, hipEventElapsedTime(ms_out, ctx->ev_start[kernel_id], ctx->ev_stop[kernel_id]));
   return MRS_TG_OK;
@@ -412,7 +446,7 @@ int mrs_tg_plan_solve(mrs_tg_plan* plan, const double* wp, const uint8_t* mask, 
     prm.soft_weight = opt->soft_constraint_weight;
     prm.use_soft = opt->use_soft_constraints;
     prm.initial_stepsize_rel = opt->initial_stepsize_rel;
-    ProfileScope ps(ctx, 2);
+    prm.time_budget_ticks = opt->max_time_s > 0 ? budget_ticks(ctx, opt->max_time_s) : 0;
     HIP_TRY(ctx, mrs_tg::launch_dfo(plan->nl, b, prm, mask, vals, limits, seg_times, coeffs, status, cost, ctx->stream));
   } else if (opt->time_alloc_method == MRS_TG_TIME_ALLOC_MELLINGER) {
     mrs_tg::NonlinearParams prm;
@@ -422,11 +456,12 @@ int mrs_tg_plan_solve(mrs_tg_plan* plan, const double* wp, const uint8_t* mask, 
     prm.f_abs = opt->f_abs;
     prm.x_rel = opt->x_rel;
     prm.x_abs = opt->x_abs;
+    prm.time_budget_ticks = opt->max_time_s > 0 ? budget_ticks(ctx, opt->max_time_s) : 0;
     ProfileScope ps(ctx, 2);
     HIP_TRY(ctx, mrs_tg::launch_nonlinear(plan->nl, b, prm, mask, vals, limits, seg_times, coeffs, status, cost,
                                           ctx->stream));
   } else {
-    const bool fused = (opt->flags & MRS_TG_FLAG_FUSED_ASSEMBLY) != 0;
+    const bool fused = (opt->flags & MRS_TG_FLAG_MATERIALIZED_BLOCKS) == 0;  // the default since ABI 2
     if ((rc = ensure_ws(plan, mrs_tg::linear_workspace_doubles(b))) != MRS_TG_OK) return rc;
     if (!fused) {
       if ((rc = ensure_blocks(plan)) != MRS_TG_OK) return rc;
@@ -475,8 +510,20 @@ int mrs_tg_solve_batch(mrs_tg_ctx* ctx, int32_t n_paths, const int32_t* so, cons
   if (!so || !mask || !vals || !seg_times || !coeffs || !status)
     return fail(ctx, MRS_TG_ERR_INVALID_ARG, "seg_offsets, fixed_mask, fixed_values, seg_times, coeffs_out, status_out are required");
   if (n_paths == 0) return MRS_TG_OK;
-  PlanGuard pg;
-  if ((rc = mrs_tg_plan_create(ctx, n_paths, so, &pg.p)) != MRS_TG_OK) return rc;
+  const auto t_call = std::chrono::steady_clock::now();
+  // the plan of the previous call is kept: the same batch shape again (a server's fixed batch, the re-solves of the
+  // nodelet's deviation loop) costs no analysis, no structure upload and no workspace allocation
+  mrs_tg_plan* plan = ctx->cached_plan;
+  if (plan && (plan->view.n_paths != n_paths ||
+               std::memcmp(plan->seg_offsets_host.data(), so, sizeof(int32_t) * ((size_t)n_paths + 1)) != 0)) {
+    ctx->cached_plan = nullptr;
+    mrs_tg_plan_destroy(plan);
+    plan = nullptr;
+  }
+  if (!plan) {
+    if ((rc = mrs_tg_plan_create(ctx, n_paths, so, &plan)) != MRS_TG_OK) return rc;
+    ctx->cached_plan = plan;
+  }
   const size_t nS = (size_t)so[n_paths], nV = nS + (size_t)n_paths;
   const bool sampling = opt->sampling_dt > 0;
   if (sampling && !n_samples) return fail(ctx, MRS_TG_ERR_INVALID_ARG, "n_samples_out is required when sampling");
@@ -502,8 +549,13 @@ int mrs_tg_solve_batch(mrs_tg_ctx* ctx, int32_t n_paths, const int32_t* so, cons
   HIP_TRY(ctx, hipMemcpyAsync(d_vals.p, vals, nV * 20 * sizeof(double), hipMemcpyHostToDevice, s));
   if (limits) HIP_TRY(ctx, hipMemcpyAsync(d_lim.p, limits, (size_t)n_paths * 9 * sizeof(double), hipMemcpyHostToDevice, s));
   HIP_TRY(ctx, hipMemcpyAsync(d_t.p, seg_times, nS * sizeof(double), hipMemcpyHostToDevice, s));
-  rc = mrs_tg_plan_solve(pg.p, wp ? d_wp.as<double>() : nullptr, d_mask.as<uint8_t>(), d_vals.as<double>(),
-                         limits ? d_lim.as<double>() : nullptr, opt, d_t.as<double>(), d_c.as<double>(),
+  mrs_tg_options local = *opt;
+  if (local.max_time_s > 0) {  // what is left of the caller's budget when the kernels start
+    const double spent = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_call).count();
+    local.max_time_s = local.max_time_s - spent > 1.0e-9 ? local.max_time_s - spent : 1.0e-9;
+  }
+  rc = mrs_tg_plan_solve(plan, wp ? d_wp.as<double>() : nullptr, d_mask.as<uint8_t>(), d_vals.as<double>(),
+                         limits ? d_lim.as<double>() : nullptr, &local, d_t.as<double>(), d_c.as<double>(),
                          d_st.as<int32_t>(), d_cost.as<double>(), sampling ? d_ns.as<int32_t>() : nullptr,
                          samp_doubles ? d_smp.as<double>() : nullptr);
   if (rc != MRS_TG_OK) return rc;

@@ -328,11 +328,11 @@ hipError_t launch_assemble(const BatchView& b, int d, const double* seg_times, d
   if (b.n_segments == 0) return hipSuccess;
   if (b.uniform_S > 0) {
     dim3 grid(cdiv(b.n_paths, kAssembleChunk) * kN * b.uniform_S);
-    hipLaunchKernelGGL(assemble_blocks_uniform_kernel, grid, dim3(kAssembleChunk), 0, stream, b.n_paths, b.uniform_S, d,
-                       seg_times, H, Ainv);
+    MRS_TG_LAUNCH_TIMED(assemble_blocks_uniform_kernel, grid, dim3(kAssembleChunk), 0, stream, b.n_paths, b.uniform_S, d,
+                        seg_times, H, Ainv);
   } else {
     dim3 grid(cdiv(b.n_paths, 256), kN, b.max_segments);
-    hipLaunchKernelGGL(assemble_blocks_kernel, grid, dim3(256), 0, stream, b, d, seg_times, H, Ainv);
+    MRS_TG_LAUNCH_TIMED(assemble_blocks_kernel, grid, dim3(256), 0, stream, b, d, seg_times, H, Ainv);
   }
   return hipGetLastError();
 }
@@ -353,18 +353,18 @@ hipError_t launch_solve_linear(const BatchView& b, int d, bool fused, const uint
   if (use_split_dims(b.n_paths)) {
     dim3 grid(cdiv((long long)b.n_paths * 4, 64));
     if (fused)
-      hipLaunchKernelGGL((solve_linear_kernel<1, true>), grid, dim3(64), 0, stream, b, d, mask, vals, seg_times, H, Ainv,
+      MRS_TG_LAUNCH_TIMED((solve_linear_kernel<1, true>), grid, dim3(64), 0, stream, b, d, mask, vals, seg_times, H, Ainv,
                          ws, coeffs, status, cost, status_in);
     else
-      hipLaunchKernelGGL((solve_linear_kernel<1, false>), grid, dim3(64), 0, stream, b, d, mask, vals, seg_times, H,
+      MRS_TG_LAUNCH_TIMED((solve_linear_kernel<1, false>), grid, dim3(64), 0, stream, b, d, mask, vals, seg_times, H,
                          Ainv, ws, coeffs, status, cost, status_in);
   } else {
     dim3 grid(cdiv(b.n_paths, 64));
     if (fused)
-      hipLaunchKernelGGL((solve_linear_kernel<4, true>), grid, dim3(64), 0, stream, b, d, mask, vals, seg_times, H, Ainv,
+      MRS_TG_LAUNCH_TIMED((solve_linear_kernel<4, true>), grid, dim3(64), 0, stream, b, d, mask, vals, seg_times, H, Ainv,
                          ws, coeffs, status, cost, status_in);
     else
-      hipLaunchKernelGGL((solve_linear_kernel<4, false>), grid, dim3(64), 0, stream, b, d, mask, vals, seg_times, H,
+      MRS_TG_LAUNCH_TIMED((solve_linear_kernel<4, false>), grid, dim3(64), 0, stream, b, d, mask, vals, seg_times, H,
                          Ainv, ws, coeffs, status, cost, status_in);
   }
   return hipGetLastError();

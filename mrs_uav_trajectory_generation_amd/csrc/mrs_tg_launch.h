@@ -1,11 +1,31 @@
 // mrs_tg_launch.h -- host-visible view of a batch and the kernel launchers (internal to the library).
 #pragma once
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 
 #include <cstddef>
 #include <cstdint>
 
+struct mrs_tg_ctx;
+
 namespace mrs_tg {
+
+// Per-dispatch timing (mrs_tg_set_profiling): the next launch of the kernel family a ProfileScope names carries these
+// events on the launch itself (hipExtLaunchKernelGGL), so their difference is the dispatch's own start-to-end time.
+struct KernelTimer {
+  hipEvent_t start = nullptr, stop = nullptr;
+};
+KernelTimer take_kernel_timer();  // the pending pair (null events when nothing is pending); consumed by the call
+void set_kernel_timer(hipEvent_t start, hipEvent_t stop);  // arms the next timed launch of this thread
+// launch with the pending timer, if any
+#define MRS_TG_LAUNCH_TIMED(kernel, grid, block, lds, stream, ...)                                           \
+  do {                                                                                                       \
+    const ::mrs_tg::KernelTimer kt__ = ::mrs_tg::take_kernel_timer();                                        \
+    hipExtLaunchKernelGGL(kernel, grid, block, lds, stream, kt__.start, kt__.stop, 0, __VA_ARGS__);          \
+  } while (0)
+
+// records `message` as the context's (and the global) last error and returns `code`
+int report_error(mrs_tg_ctx* ctx, int code, const char* fmt, ...);
 
 // Device-resident structure of a batch (built once per plan).
 struct BatchView {

@@ -13,6 +13,7 @@ struct NonlinearParams {
   int derivative;
   int max_iterations;
   double f_rel, f_abs, x_rel, x_abs;
+  long long time_budget_ticks = 0;  // nlopt maxtime in ticks of the device's constant wall clock (s_memrealtime); 0 = none
 };
 
 // Paths are sorted by segment count (longest first), so every lane-group class is a contiguous range
@@ -26,6 +27,7 @@ struct DfoParams {
   double time_penalty, soft_weight;
   int use_soft;
   double initial_stepsize_rel;
+  long long time_budget_ticks = 0;  // as NonlinearParams
 };
 
 struct NonlinearBin {
@@ -49,6 +51,7 @@ struct NonlinearPlan {
   int32_t* d_dfo_fidx = nullptr;     // modes 3/4: free-constraint index of every (vertex, derivative), -1 if fixed
   double* d_dfo_segcost = nullptr;   // modes 3/4: J_d share of every (segment, dimension)
   int32_t* d_dfo_seg_path = nullptr; // modes 3/4: path of every segment
+  long long* d_dfo_deadline = nullptr; // wall-clock deadline of the running search (0 = none), written by its first kernel
 };
 
 int nonlinear_plan_build(NonlinearPlan& nl, const std::vector<int32_t>& seg_offsets, const std::vector<int32_t>& order);

@@ -991,6 +991,13 @@ __device__ __forceinline__ void optimize_body(const BatchView& b, const Nonlinea
   MRS_TG_PHASE_MARK(1);
 
   const int maxeval = prm.max_iterations;
+  // nlopt maxtime (src/mrs_trajectory_generation.cpp:899): the constant-rate wall clock of the device, read once per
+  // evaluation; a path that is still running when it passes stops with MAXTIME_REACHED (6) at its last evaluated point
+  const long long t_deadline = prm.time_budget_ticks > 0 ? (long long)wall_clock64() + prm.time_budget_ticks : 0ll;
+  bool timed_out = false;
+  // nlopt checks the evaluation count first, then the clock (nlopt_stop_evals, nlopt_stop_time)
+  auto budget_spent = [&](int n) { return (maxeval > 0 && n >= maxeval) || timed_out; };
+  auto budget_code = [&](int n) { return (maxeval > 0 && n >= maxeval) ? 5 : 6; };
   const bool single = Sb <= G;  // uniform per workgroup
   int ret = -1;
   bool done = !active || bad;
@@ -1081,6 +1088,7 @@ __device__ __forceinline__ void optimize_body(const BatchView& b, const Nonlinea
     head = tick_i[2];
     ret = tick_i[3];
     first = neval == 0;
+    timed_out = t_deadline != 0ll && (long long)wall_clock64() > t_deadline;
 #ifdef MRS_TG_PHASE_CLOCKS
     if (neval < 12) MRS_TG_PHASE_MARK(6 + 2 * neval);  // after evaluation #neval
 #endif
@@ -1099,8 +1107,8 @@ __device__ __forceinline__ void optimize_body(const BatchView& b, const Nonlinea
         f = fn;
         xi_ = xni;
         gi_ = gni;
-        if (maxeval > 0 && neval >= maxeval) {
-          ret = 5;
+        if (budget_spent(neval)) {
+          ret = budget_code(neval);
           done = true;
         } else {
           new_dir = true;
@@ -1121,7 +1129,7 @@ __device__ __forceinline__ void optimize_body(const BatchView& b, const Nonlinea
             if (group_and(allx, G)) stop = 4;
           }
           const double sy = red4[1], ss = red4[2], yy = red4[3];
-          const bool budget_out = maxeval > 0 && neval >= maxeval;
+          const bool budget_out = budget_spent(neval);
           int slot = -1;
           if (!stop && !budget_out && sy > 1e-10 * sqrt(ss) * sqrt(yy)) {
             if (npairs == kLbfgsM) {
@@ -1147,14 +1155,14 @@ __device__ __forceinline__ void optimize_body(const BatchView& b, const Nonlinea
             ret = stop;
             done = true;
           } else if (budget_out) {
-            ret = 5;
+            ret = budget_code(neval);
             done = true;
           } else {
             new_dir = true;
           }
-        } else if (maxeval > 0 && neval >= maxeval) {
+        } else if (budget_spent(neval)) {
           xi_ = xni;  // budget ends on a rejected trial: the last evaluated point is what the reference keeps
-          ret = 5;
+          ret = budget_code(neval);
           done = true;
         } else {
           alpha *= 0.5;
@@ -1177,8 +1185,8 @@ __device__ __forceinline__ void optimize_body(const BatchView& b, const Nonlinea
           x[i] = xn[i];
           gr[i] = gn[i];
         }
-        if (maxeval > 0 && neval >= maxeval) {
-          ret = 5;
+        if (budget_spent(neval)) {
+          ret = budget_code(neval);
           done = true;
         } else {
           new_dir = true;
@@ -1208,7 +1216,7 @@ __device__ __forceinline__ void optimize_body(const BatchView& b, const Nonlinea
           sy = group_sum(sy, G);
           ss = group_sum(ss, G);
           yy = group_sum(yy, G);
-          const bool budget_out = maxeval > 0 && neval >= maxeval;
+          const bool budget_out = budget_spent(neval);
           int slot = -1;
           if (!stop && !budget_out && sy > 1e-10 * sqrt(ss) * sqrt(yy)) {
             if (npairs == kLbfgsM) {
@@ -1233,15 +1241,15 @@ __device__ __forceinline__ void optimize_body(const BatchView& b, const Nonlinea
             ret = stop;
             done = true;
           } else if (budget_out) {
-            ret = 5;
+            ret = budget_code(neval);
             done = true;
           } else {
             new_dir = true;
           }
-        } else if (maxeval > 0 && neval >= maxeval) {
+        } else if (budget_spent(neval)) {
           // budget ends on a rejected trial: the last evaluated point is what the reference keeps
           for (int i = g; i < S; i += G) x[i] = xn[i];
-          ret = 5;
+          ret = budget_code(neval);
           done = true;
         } else {
           alpha *= 0.5;
@@ -1582,8 +1590,9 @@ __global__ __launch_bounds__(64) void dfo_init_kernel(BatchView b, DfoParams prm
                                                       const double* __restrict__ seg_times,
                                                       const double* __restrict__ coeffs, double* __restrict__ vec,
                                                       double* __restrict__ fvals, int32_t* __restrict__ state,
-                                                      int32_t* __restrict__ fidx) {
+                                                      int32_t* __restrict__ fidx, long long* __restrict__ deadline) {
   const int p = blockIdx.x * 64 + threadIdx.x;
+  if (p == 0) *deadline = prm.time_budget_ticks > 0 ? (long long)wall_clock64() + prm.time_budget_ticks : 0ll;
   if (p >= b.n_paths) return;
   const int s0 = b.seg_offsets[p], n = b.seg_offsets[p + 1] - s0, v0 = s0 + p, V = n + 1;
   const size_t NV = dfo_var_total(b.n_segments, b.n_paths);
@@ -1718,7 +1727,8 @@ __global__ __launch_bounds__(64) void dfo_step_kernel(BatchView b, DfoParams prm
                                                       const double* __restrict__ cost, const double* __restrict__ segcost,
                                                       const double* __restrict__ maxima4, double* __restrict__ seg_times,
                                                       double* __restrict__ vec, double* __restrict__ fvals,
-                                                      int32_t* __restrict__ state) {
+                                                      int32_t* __restrict__ state,
+                                                      const long long* __restrict__ deadline) {
   const int p = blockIdx.x * 64 + threadIdx.x;
   if (p >= b.n_paths) return;
   int32_t* st = state + (size_t)p * kDfoInts;
@@ -1772,6 +1782,9 @@ __global__ __launch_bounds__(64) void dfo_step_kernel(BatchView b, DfoParams prm
   bool done = false;
   if (prm.max_iterations > 0 && neval >= prm.max_iterations) {
     ret = 5;
+    done = true;
+  } else if (deadline && *deadline != 0ll && (long long)wall_clock64() > *deadline) {
+    ret = 6;  // nlopt maxtime
     done = true;
   }
   while (!done) {
@@ -1932,6 +1945,8 @@ void nonlinear_plan_free(NonlinearPlan& nl) {
   if (nl.d_dfo_fidx) (void)mrs_tg::pool_free(nl.d_dfo_fidx);
   if (nl.d_dfo_segcost) (void)mrs_tg::pool_free(nl.d_dfo_segcost);
   if (nl.d_dfo_seg_path) (void)mrs_tg::pool_free(nl.d_dfo_seg_path);
+  if (nl.d_dfo_deadline) (void)mrs_tg::pool_free(nl.d_dfo_deadline);
+  nl.d_dfo_deadline = nullptr;
   nl.d_dfo_fidx = nullptr;
   nl.d_dfo_segcost = nullptr;
   nl.d_dfo_seg_path = nullptr;
@@ -2005,14 +2020,14 @@ hipError_t launch_nonlinear(NonlinearPlan& nl, const BatchView& b, const Nonline
       if (e != hipSuccess) return e;
     }
     if (nl.dim_split == 4)
-      hipLaunchKernelGGL(optimize_split_kernel, dim3(blocks), dim3(threads), lds_bytes, stream, b, prm, bt, mask, vals, seg_times,
-                         nl.d_opt_status);
+      MRS_TG_LAUNCH_TIMED(optimize_split_kernel, dim3(blocks), dim3(threads), lds_bytes, stream, b, prm, bt, mask, vals,
+                          seg_times, nl.d_opt_status);
     else if (masked4)
-      hipLaunchKernelGGL(optimize_compact_kernel<true>, dim3(blocks), dim3(64), lds_bytes, stream, b, prm, bt, mask, vals,
-                         seg_times, nl.d_opt_status);
+      MRS_TG_LAUNCH_TIMED(optimize_compact_kernel<true>, dim3(blocks), dim3(64), lds_bytes, stream, b, prm, bt, mask, vals,
+                          seg_times, nl.d_opt_status);
     else
-      hipLaunchKernelGGL(optimize_compact_kernel<false>, dim3(blocks), dim3(64), lds_bytes, stream, b, prm, bt, mask, vals,
-                         seg_times, nl.d_opt_status);
+      MRS_TG_LAUNCH_TIMED(optimize_compact_kernel<false>, dim3(blocks), dim3(64), lds_bytes, stream, b, prm, bt, mask, vals,
+                          seg_times, nl.d_opt_status);
     if ((e = hipGetLastError()) != hipSuccess) return e;
   }
   // 2. trajectory of the last evaluated point (scaleSegmentTimesWithViolation works on poly_opt_'s state)
@@ -2044,6 +2059,7 @@ hipError_t launch_dfo(NonlinearPlan& nl, const BatchView& b, const DfoParams& pr
   if (!nl.d_dfo_f && (e = mrs_tg::pool_alloc(&nl.d_dfo_f, sizeof(double) * 3 * P)) != hipSuccess) return e;
   if (!cost) cost = nl.d_dfo_f + 2 * P;  // J_d per evaluation needs a buffer even when the caller does not want it
   if (!nl.d_dfo_state && (e = mrs_tg::pool_alloc(&nl.d_dfo_state, sizeof(int32_t) * kDfoInts * P)) != hipSuccess) return e;
+  if (!nl.d_dfo_deadline && (e = mrs_tg::pool_alloc(&nl.d_dfo_deadline, sizeof(long long))) != hipSuccess) return e;
   if (with_free) {
     if (!nl.d_dfo_fidx && (e = mrs_tg::pool_alloc(&nl.d_dfo_fidx, sizeof(int32_t) * (nS + P) * kHalf)) != hipSuccess) return e;
     if (!nl.d_dfo_segcost && (e = mrs_tg::pool_alloc(&nl.d_dfo_segcost, sizeof(double) * nS * kD)) != hipSuccess) return e;
@@ -2060,7 +2076,7 @@ hipError_t launch_dfo(NonlinearPlan& nl, const BatchView& b, const DfoParams& pr
                                cost, nullptr, stream)) != hipSuccess)
     return e;
   hipLaunchKernelGGL(dfo_init_kernel, dim3(pblocks), dim3(64), 0, stream, b, prm, mask, limits, seg_times, coeffs,
-                     nl.d_dfo_vec, nl.d_dfo_f, nl.d_dfo_state, nl.d_dfo_fidx);
+                     nl.d_dfo_vec, nl.d_dfo_f, nl.d_dfo_state, nl.d_dfo_fidx, nl.d_dfo_deadline);
   if ((e = hipGetLastError()) != hipSuccess) return e;
   // NLopt's maxeval <= 0 means "no limit"; the host loop needs one
   const int rounds = prm.max_iterations > 0 ? prm.max_iterations : 1000;
@@ -2079,7 +2095,7 @@ hipError_t launch_dfo(NonlinearPlan& nl, const BatchView& b, const DfoParams& pr
                        nl.d_maxima);
     if ((e = hipGetLastError()) != hipSuccess) return e;
     hipLaunchKernelGGL(dfo_step_kernel, dim3(pblocks), dim3(64), 0, stream, b, prm, limits, cost, nl.d_dfo_segcost,
-                       nl.d_maxima, seg_times, nl.d_dfo_vec, nl.d_dfo_f, nl.d_dfo_state);
+                       nl.d_maxima, seg_times, nl.d_dfo_vec, nl.d_dfo_f, nl.d_dfo_state, nl.d_dfo_deadline);
     if ((e = hipGetLastError()) != hipSuccess) return e;
   }
   // paths that stopped early were re-evaluated at their final point every round; paths that used the whole budget

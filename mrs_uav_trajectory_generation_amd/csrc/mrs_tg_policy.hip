@@ -17,7 +17,10 @@
 #include <cstring>
 #include <vector>
 
+#include <chrono>
+
 #include "../../include/mrs_tg.h"
+#include "mrs_tg_launch.h"
 
 namespace {
 
@@ -297,6 +300,8 @@ void mrs_tg_default_policy_options(mrs_tg_policy_options* o) {
   o->fallback_accel_factor = 1.0;
   o->fallback_stopping_time = 2.0;
   o->override_heading_atan2 = 0;
+  o->reserved_ = 0;
+  o->max_execution_time_s = 0.0;
 }
 
 int mrs_tg_optimize_paths(mrs_tg_ctx* ctx, int32_t n_paths, const int32_t* wp_offsets, const mrs_tg_waypoint* waypoints,
@@ -304,14 +309,23 @@ int mrs_tg_optimize_paths(mrs_tg_ctx* ctx, int32_t n_paths, const int32_t* wp_of
                           const uint8_t* relax_heading, const mrs_tg_policy_options* opt, int32_t sample_capacity,
                           int32_t* success_out, int32_t* n_samples_out, double* samples_out, double* max_deviation_out,
                           int32_t* n_waypoints_out, int32_t* iterations_out) {
-  if (!ctx || !wp_offsets || !waypoints || !limits || !opt || !success_out || !n_samples_out || !samples_out || n_paths < 0 ||
-      sample_capacity <= 0)
-    return MRS_TG_ERR_INVALID_ARG;
+  if (!ctx) return mrs_tg::report_error(nullptr, MRS_TG_ERR_INVALID_ARG, "ctx is NULL");
+  if (!wp_offsets || !waypoints || !limits || !opt || !success_out || !n_samples_out || !samples_out)
+    return mrs_tg::report_error(ctx, MRS_TG_ERR_INVALID_ARG,
+                                "wp_offsets, waypoints, limits, options, success_out, n_samples_out and samples_out are required");
+  if (n_paths < 0 || sample_capacity <= 0)
+    return mrs_tg::report_error(ctx, MRS_TG_ERR_INVALID_ARG, "n_paths %d / sample_capacity %d: need >= 0 / > 0", n_paths,
+                                sample_capacity);
   const mrs_tg_policy_options& o = *opt;
   const int d = o.solver.derivative_to_optimize;
-  if (d < 2 || d > 4) return MRS_TG_ERR_INVALID_ARG;
+  if (d < 2 || d > 4)
+    return mrs_tg::report_error(ctx, MRS_TG_ERR_INVALID_ARG, "derivative_to_optimize must be 2, 3 or 4 (got %d)", d);
   const double dt = o.solver.sampling_dt;
-  if (!(dt > 0)) return MRS_TG_ERR_INVALID_ARG;
+  if (!(dt > 0)) return mrs_tg::report_error(ctx, MRS_TG_ERR_INVALID_ARG, "the policy layer needs sampling_dt > 0 (got %g)", dt);
+  const auto t_begin = std::chrono::steady_clock::now();
+  auto time_left = [&]() {
+    return o.max_execution_time_s - std::chrono::duration<double>(std::chrono::steady_clock::now() - t_begin).count();
+  };
   std::vector<PathState> st((size_t)n_paths);
   for (int p = 0; p < n_paths; ++p) {
     preprocess(waypoints + wp_offsets[p], wp_offsets[p + 1] - wp_offsets[p], o, st[p]);
@@ -326,6 +340,35 @@ int mrs_tg_optimize_paths(mrs_tg_ctx* ctx, int32_t n_paths, const int32_t* wp_of
     for (int p = 0; p < n_paths; ++p)
       if (!st[p].done) active.push_back(p);
     if (active.empty()) break;
+    // the requests are independent: one that cannot be solved (its deviation loop has subdivided it beyond the longest
+    // path a plan takes; the reference has no such limit) fails on its own and leaves the others alone
+    if (!o.fallback_sampling) {
+      size_t kept = 0;
+      for (int p : active) {
+        if (st[p].n_wp - 1 > MRS_TG_MAX_SEGMENTS) {
+          st[p].done = true;
+          st[p].ok = false;
+          st[p].n_samples = 0;
+        } else {
+          active[kept++] = p;
+        }
+      }
+      active.resize(kept);
+      if (active.empty()) break;
+    }
+    // overtime() (:1085, 1156, 1171, 1516-1522): out of time, every request that is still being worked on is given up
+    double budget_left = 0.0;
+    if (o.max_execution_time_s > 0) {
+      budget_left = time_left();
+      if (budget_left <= 0) {
+        for (int p : active) {
+          st[p].done = true;
+          st[p].ok = false;
+          st[p].n_samples = 0;
+        }
+        break;
+      }
+    }
     // ---- solve every active path (one batched GPU call, or the fallback sampler on the host)
     if (o.fallback_sampling) {
       for (int p : active) {
@@ -384,6 +427,7 @@ int mrs_tg_optimize_paths(mrs_tg_ctx* ctx, int32_t n_paths, const int32_t* wp_of
       mrs_tg_options so_opt = o.solver;
       so_opt.estimate_times = 1;
       so_opt.sample_capacity = sample_capacity;
+      if (o.max_execution_time_s > 0) so_opt.max_time_s = 2.0 * 0.95 * budget_left;  // :899
       const int rc = mrs_tg_solve_batch(ctx, (int32_t)active.size(), so.data(), wp.data(), mask.data(), vals.data(), lim.data(),
                                         &so_opt, times.data(), coeffs.data(), status.data(), cost.data(), ns.data(), smp.data());
       if (rc != MRS_TG_OK) return rc;

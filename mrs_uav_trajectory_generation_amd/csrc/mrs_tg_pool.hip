@@ -1,5 +1,7 @@
-// mrs_tg_pool.hip -- caching device allocator (see mrs_tg_pool.h)
+// mrs_tg_pool.hip -- caching device allocator (see mrs_tg_pool.h) and the per-thread kernel timer of the launchers
 #include "mrs_tg_pool.h"
+
+#include "mrs_tg_launch.h"
 
 #include <cstdlib>
 #include <map>
@@ -110,6 +112,21 @@ void pool_release_cached() {
     for (auto& [bytes, ptr] : bucket) (void)hipFree(ptr);
   }
   (void)hipSetDevice(cur);
+}
+
+// ---- per-dispatch timing (mrs_tg_launch.h): armed by the ABI layer for the kernel it wants timed, consumed by the
+// launcher of that kernel; per thread, because contexts are driven from one thread each
+static thread_local KernelTimer t_kernel_timer;
+
+void set_kernel_timer(hipEvent_t start, hipEvent_t stop) {
+  t_kernel_timer.start = start;
+  t_kernel_timer.stop = stop;
+}
+
+KernelTimer take_kernel_timer() {
+  const KernelTimer k = t_kernel_timer;
+  t_kernel_timer = KernelTimer{};
+  return k;
 }
 
 }  // namespace mrs_tg

@@ -24,6 +24,7 @@
 #include <cstdlib>
 
 #include "mrs_tg_device.hpp"
+#include "mrs_tg_launch.h"
 #include "mrs_tg_rowelim.hpp"
 
 namespace mrs_tg {
@@ -540,7 +541,7 @@ hipError_t launch_solve_rows(const BatchView& b, int d, const uint8_t* mask, con
   hipError_t e = hipFuncSetAttribute((const void*)solve_rows_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kRowsLdsBudget);
   if (e != hipSuccess) return e;
   const unsigned grid = (unsigned)((b.n_paths + ppw - 1) / ppw);
-  hipLaunchKernelGGL(solve_rows_kernel, dim3(grid), dim3(64), lds_bytes, stream, b, d, ppw, b.max_segments, mask, vals,
+  MRS_TG_LAUNCH_TIMED(solve_rows_kernel, dim3(grid), dim3(64), lds_bytes, stream, b, d, ppw, b.max_segments, mask, vals,
                      seg_times, coeffs, status, cost, status_in);
   return hipGetLastError();
 }

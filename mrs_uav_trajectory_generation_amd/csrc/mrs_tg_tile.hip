@@ -595,13 +595,13 @@ hipError_t launch_solve_tile(const BatchView& b, int d, bool fused, const uint8_
     hipError_t e = hipFuncSetAttribute((const void*)solve_tile_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                        (int)kTileLdsBudget);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(solve_tile_kernel<true>, dim3(grid), dim3(kTileThreads), lds_bytes, stream, b, d, TP, b.max_segments, mask,
+    MRS_TG_LAUNCH_TIMED(solve_tile_kernel<true>, dim3(grid), dim3(kTileThreads), lds_bytes, stream, b, d, TP, b.max_segments, mask,
                        vals, seg_times, H, Ainv, coeffs, status, cost, status_in);
   } else {
     hipError_t e = hipFuncSetAttribute((const void*)solve_tile_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                        (int)kTileLdsBudget);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(solve_tile_kernel<false>, dim3(grid), dim3(kTileThreads), lds_bytes, stream, b, d, TP, b.max_segments, mask,
+    MRS_TG_LAUNCH_TIMED(solve_tile_kernel<false>, dim3(grid), dim3(kTileThreads), lds_bytes, stream, b, d, TP, b.max_segments, mask,
                        vals, seg_times, H, Ainv, coeffs, status, cost, status_in);
   }
   return hipGetLastError();

@@ -1,0 +1,150 @@
+"""Boundary features added for ABI 2, through the C ABI on the GPU: several devices, the nlopt-style time budget
+(MAXTIME_REACHED), the cached plan of the one-call interface, per-dispatch kernel timing, and the policy layer's handling
+of one unsolvable request next to healthy ones."""
+import time
+
+import numpy as np
+import pytest
+import torch
+
+from mrs_uav_trajectory_generation_amd import api, problem as pr
+from tests import util
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("n_seg,n_paths,n_dev", [(10, 37, 2), ("ragged", 41, 3), (6, 5, 4)])
+def test_multi_device_solve_equals_single_device(gpu_ctx, n_seg, n_paths, n_dev):
+    """mrs_tg_multi_solve_batch (here: several contexts on the one GPU of the box, one host thread each) returns, path
+    for path, exactly what mrs_tg_solve_batch returns: same kernels per path, so bit-identical."""
+    batch = pr.random_batch(n_paths, n_seg, seed0=4200)
+    multi = api.MultiContext([0] * n_dev)
+    assert multi.n_devices == n_dev
+    shard = multi.shard(batch.seg_offsets)
+    counts = np.diff(batch.seg_offsets)
+    assert set(shard.tolist()) == set(range(n_dev))
+    if n_seg == "ragged":  # balanced on the segment count: no shard carries more than the lightest one + the longest path
+        load = np.array([counts[shard == r].sum() for r in range(n_dev)])
+        assert load.max() - load.min() <= counts.max()
+    else:  # contiguous ranges whose sizes differ by at most one
+        assert np.all(np.diff(shard) >= 0)
+        sizes = np.bincount(shard, minlength=n_dev)
+        assert sizes.max() - sizes.min() <= 1
+    for kwargs in (dict(), dict(time_alloc_method=api.TIME_ALLOC_MELLINGER, sampling_dt=0.2, sample_capacity=512)):
+        one = gpu_ctx.solve_batch(batch, None, **kwargs)
+        many = multi.solve_batch(batch, None, **kwargs)
+        for key in ("times", "coeffs", "status", "cost"):
+            assert np.array_equal(one[key], many[key]), key
+        if kwargs:
+            assert np.array_equal(one["n_samples"], many["n_samples"])
+            for p in range(n_paths):
+                n = min(one["n_samples"][p], 512)
+                assert np.array_equal(one["samples"][p, :n], many["samples"][p, :n])
+    multi.close()
+
+
+def test_multi_device_reports_the_failing_shard(gpu_ctx):
+    batch = pr.random_batch(6, 4, seed0=1)
+    multi = api.MultiContext([0, 0])
+    with pytest.raises(api.MrsTgError, match="device"):
+        multi.solve_batch(batch, None, time_alloc_method=9)
+    multi.close()
+
+
+def test_time_budget_stops_the_outer_loop_with_maxtime(gpu_ctx):
+    """max_time_s is nlopt's maxtime (src/mrs_trajectory_generation.cpp:899): a search that is still running when it has
+    passed stops at its last evaluated point with code 6, which the nodelet rejects (:1138-1149).  A generous budget
+    changes nothing."""
+    batch = pr.random_batch(64, 10, seed0=910)
+    free = gpu_ctx.solve_batch(batch, None, time_alloc_method=api.TIME_ALLOC_MELLINGER)
+    roomy = gpu_ctx.solve_batch(batch, None, time_alloc_method=api.TIME_ALLOC_MELLINGER, max_time_s=30.0)
+    assert np.array_equal(free["status"], roomy["status"]) and np.array_equal(free["times"], roomy["times"])
+    tight = gpu_ctx.solve_batch(batch, None, time_alloc_method=api.TIME_ALLOC_MELLINGER, max_time_s=1e-7)
+    assert np.all(tight["status"] == 6), tight["status"]
+    assert np.all(np.isfinite(tight["coeffs"])) and np.all(tight["times"] >= 0.01)
+    # the trajectory that comes back is still a valid solve of the linear QP at the returned times
+    assert util.continuity_defect(batch, tight["coeffs"], tight["times"]) < 1e-7
+    for mode in (api.TIME_ALLOC_RICHTER_TIME, api.TIME_ALLOC_SQUARED_TIME_AND_CONSTRAINTS):
+        t2 = gpu_ctx.solve_batch(batch, None, time_alloc_method=mode, max_time_s=1e-7)
+        assert np.all(t2["status"] == 6), (mode, t2["status"])
+    # findTrajectory's gate turns code 6 into "no trajectory"
+    wp = pr.random_box_waypoints(6, 3)
+    out = gpu_ctx.find_trajectory(wp, max_time_s=1e-7)
+    assert out["status"] == 6 and out["n_samples"] == 0
+
+
+def test_policy_gives_up_when_out_of_time(gpu_ctx):
+    paths = [pr.random_walk_waypoints(6, 70 + i) for i in range(4)]
+    ok = api.optimize_paths(gpu_ctx, paths, sample_capacity=2048)
+    assert ok["success"].sum() >= 3
+    pol = api.default_policy_options(max_execution_time_s=1e-9)
+    late = api.optimize_paths(gpu_ctx, paths, policy=pol, sample_capacity=2048)
+    assert late["success"].sum() == 0 and late["n_samples"].sum() == 0
+
+
+def test_one_oversized_request_does_not_fail_the_batch(gpu_ctx):
+    """A request whose waypoint list is longer than the longest path a plan accepts fails on its own
+    (the reference treats requests independently); its neighbours are solved."""
+    long_path = np.zeros((300, 4))
+    long_path[:, 0] = np.arange(300) * 0.7
+    long_path[:, 1] = np.sin(np.arange(300) * 0.3)
+    long_path[:, 2] = 3.0
+    healthy = pr.random_walk_waypoints(6, 11)
+    out = api.optimize_paths(gpu_ctx, [healthy, long_path, healthy], sample_capacity=4096)
+    assert out["success"].tolist() == [1, 0, 1]
+    assert out["n_samples"][1] == 0 and out["n_samples"][0] == out["n_samples"][2] > 0
+    assert np.array_equal(out["samples"][0], out["samples"][2])
+
+
+def test_policy_reports_why_it_refused(gpu_ctx):
+    pol = api.default_policy_options(solver=dict(derivative_to_optimize=1))
+    with pytest.raises(api.MrsTgError, match="derivative_to_optimize must be 2, 3 or 4"):
+        api.optimize_paths(gpu_ctx, [pr.random_walk_waypoints(5, 1)], policy=pol)
+
+
+def test_one_call_interface_reuses_its_plan(gpu_ctx):
+    """Same batch shape again: no analysis, no structure upload, no workspace allocation; another shape in between
+    replaces the cached plan; results never depend on which of the two happened."""
+    a = pr.random_batch(256, 10, seed0=60)
+    b = pr.random_batch(100, 7, seed0=61)
+    first = gpu_ctx.solve_batch(a, None)
+    t0 = time.perf_counter()
+    for _ in range(20):
+        again = gpu_ctx.solve_batch(a, None)
+    warm = (time.perf_counter() - t0) / 20
+    assert np.array_equal(first["coeffs"], again["coeffs"])
+    other = gpu_ctx.solve_batch(b, None)
+    back = gpu_ctx.solve_batch(a, None)
+    assert np.array_equal(first["coeffs"], back["coeffs"]) and np.all(other["status"] == 1)
+    assert warm < 5e-3, warm  # a 256-path call is a fraction of a millisecond once the plan exists
+
+
+def test_per_dispatch_kernel_timing(gpu_ctx):
+    """mrs_tg_last_kernel_ms reads the time stamps of the kernel dispatch itself: positive, and far below the
+    launch-to-synchronise wall time of the call that made it."""
+    batch = pr.random_batch(1024, 10, seed0=0)
+    plan = api.Plan(gpu_ctx, batch.seg_offsets)
+    db = api.DeviceBatch(batch, "cuda:0", sample_capacity=256)
+    est = api.default_options(estimate_times=1)
+    plan.solve(est, db.fixed_mask, db.fixed_values, db.seg_times, db.coeffs, db.status, db.cost, waypoints=db.waypoints,
+               limits=db.limits)
+    torch.cuda.synchronize()
+    gpu_ctx.set_profiling(True)
+    try:
+        with pytest.raises(api.MrsTgError):
+            gpu_ctx.last_kernel_ms(api.KERNEL_NONLINEAR)  # nothing of that family has run under profiling yet
+        H = torch.empty(plan.block_doubles, dtype=torch.float64, device="cuda")
+        A = torch.empty(plan.block_doubles, dtype=torch.float64, device="cuda")
+        plan.assemble(4, db.seg_times, H, A)
+        ms_asm = gpu_ctx.last_kernel_ms(api.KERNEL_ASSEMBLE)
+        plan.solve(api.default_options(), db.fixed_mask, db.fixed_values, db.seg_times, db.coeffs, db.status, db.cost)
+        ms_solve = gpu_ctx.last_kernel_ms(api.KERNEL_SOLVE_LINEAR)
+        nl = api.default_options(time_alloc_method=api.TIME_ALLOC_MELLINGER)
+        plan.solve(nl, db.fixed_mask, db.fixed_values, db.seg_times, db.coeffs, db.status, db.cost, limits=db.limits)
+        ms_outer = gpu_ctx.last_kernel_ms(api.KERNEL_NONLINEAR)
+    finally:
+        gpu_ctx.set_profiling(False)
+    assert 1e-3 < ms_asm < 0.1, ms_asm        # ~5 us for 16 MB
+    assert 1e-3 < ms_solve < 0.2, ms_solve    # ~8 us
+    assert 5e-3 < ms_outer < 2.0, ms_outer    # ~80 us
+    plan.close()

@@ -27,9 +27,10 @@ def _subset_vs_oracle(batch, out, idx, tol):
 def test_linear_large_batches(gpu_ctx, monkeypatch, n_paths, tile_max):
     if tile_max is not None:
         monkeypatch.setenv("MRS_TG_TILE_MAX_PATHS", str(tile_max))  # read at every call: both pipelines on the lane kernels
+        monkeypatch.setenv("MRS_TG_ROWS_KERNEL", "0")                # (and not on the rows kernel, the default fused solve)
     batch = pr.random_batch(n_paths, 10, seed0=7000)
-    out = gpu_ctx.solve_batch(batch, None)
-    fused = gpu_ctx.solve_batch(batch, out["times"], flags=api.FLAG_FUSED_ASSEMBLY)
+    out = gpu_ctx.solve_batch(batch, None, flags=api.FLAG_MATERIALIZED_BLOCKS)
+    fused = gpu_ctx.solve_batch(batch, out["times"])
     assert np.all(out["status"] == 1) and np.all(fused["status"] == 1)
     # The two pipelines round the block entries differently (1 ulp); the solution moves by cond(R_pp) * eps,
     # and among tens of thousands of random paths a few have a 0.05 s segment next to 10 s ones (cond ~1e9).
@@ -77,10 +78,11 @@ def test_long_paths_tile_and_lane_kernels_agree(gpu_ctx, monkeypatch, n_seg):
     """Beyond the oracle's 128 segments: an LDS tile holds a path of up to 218 segments (one path per workgroup);
     longer ones go to the lane kernels.  Both must give the same trajectory, continuous and on its constraints."""
     batch = pr.random_batch(3, n_seg, seed0=8300 + n_seg)
-    out = gpu_ctx.solve_batch(batch, None)
-    fused = gpu_ctx.solve_batch(batch, out["times"], flags=api.FLAG_FUSED_ASSEMBLY)
+    out = gpu_ctx.solve_batch(batch, None, flags=api.FLAG_MATERIALIZED_BLOCKS)
+    fused = gpu_ctx.solve_batch(batch, out["times"])
     monkeypatch.setenv("MRS_TG_TILE_MAX_PATHS", "0")
-    lane = gpu_ctx.solve_batch(batch, out["times"])
+    monkeypatch.setenv("MRS_TG_ROWS_KERNEL", "0")
+    lane = gpu_ctx.solve_batch(batch, out["times"], flags=api.FLAG_MATERIALIZED_BLOCKS)
     assert np.all(out["status"] == 1) and np.all(lane["status"] == 1)
     assert util.coeff_error(out["coeffs"], lane["coeffs"], batch.seg_offsets) < 1e-8
     assert util.coeff_error(fused["coeffs"], lane["coeffs"], batch.seg_offsets) < 1e-8

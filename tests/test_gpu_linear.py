@@ -50,7 +50,7 @@ def test_assemble_blocks_match_exact_and_oracle(gpu_ctx, golden):
 def test_linear_golden_cases(gpu_ctx, golden, fused):
     for case in golden["cases"]:
         batch, t = util.case_batch(case)
-        out = gpu_ctx.solve_batch(batch, t, flags=api.FLAG_FUSED_ASSEMBLY if fused else 0)
+        out = gpu_ctx.solve_batch(batch, t, flags=api.FLAG_FUSED_ASSEMBLY if fused else api.FLAG_MATERIALIZED_BLOCKS)
         exact = np.array(case["coeffs"])
         err = util.coeff_error(out["coeffs"], exact)
         assert err < TOL_EXACT, (case["name"], err)
@@ -80,7 +80,7 @@ def test_linear_random_batches_vs_oracle(gpu_ctx, n_seg, n_paths):
     batch = pr.random_batch(n_paths, n_seg, seed0=1000)
     t = util.oracle_times(batch)
     ref = util.oracle_linear(batch, t)
-    for flags in (0, api.FLAG_FUSED_ASSEMBLY):
+    for flags in (api.FLAG_MATERIALIZED_BLOCKS, api.FLAG_FUSED_ASSEMBLY):
         out = gpu_ctx.solve_batch(batch, t, flags=flags)
         assert util.coeff_error(out["coeffs"], ref["coeffs"], batch.seg_offsets) < TOL_ORACLE
         assert np.max(np.abs(out["cost"] - ref["cost"]) / np.abs(ref["cost"]).clip(1e-300)) < 1e-7
@@ -91,7 +91,7 @@ def test_linear_ragged_batch_vs_oracle(gpu_ctx):
     batch = pr.random_batch(257, "ragged", seed0=5)
     t = util.oracle_times(batch)
     ref = util.oracle_linear(batch, t)
-    for flags in (0, api.FLAG_FUSED_ASSEMBLY):
+    for flags in (api.FLAG_MATERIALIZED_BLOCKS, api.FLAG_FUSED_ASSEMBLY):
         out = gpu_ctx.solve_batch(batch, t, flags=flags)
         assert util.coeff_error(out["coeffs"], ref["coeffs"], batch.seg_offsets) < TOL_ORACLE
 
@@ -165,7 +165,7 @@ def test_wild_segment_times_give_finite_output(gpu_ctx, n_paths):
     batch = pr.random_batch(n_paths, 10, seed0=31000)
     rng = np.random.default_rng(5)
     times = 10.0 ** rng.uniform(-2.0, 12.0, batch.n_segments)
-    for flags in (0, api.FLAG_FUSED_ASSEMBLY):
+    for flags in (api.FLAG_MATERIALIZED_BLOCKS, api.FLAG_FUSED_ASSEMBLY):
         out = gpu_ctx.solve_batch(batch, times, flags=flags)
         assert np.all(out["status"] == 1)
         assert np.all(np.isfinite(out["coeffs"])), int((~np.isfinite(out["coeffs"])).sum())
