@@ -1,44 +1,59 @@
 #!/usr/bin/env python3
 """bench.py -- headline benchmark: trajectories/s for a batch of 10-segment min-snap paths.
 
-    python bench.py --gpus N --steps K --warmup W        (N > 1: launched by torch.distributed.run)
+    python bench.py --gpus N --steps K --warmup W
 
-A "step" is one pass of the hot path over one batch whose inputs already sit in HBM.  Default
-workload = BASELINE.json configs[1]: 1024 random 10-segment order-10 min-snap paths, fixed (Euclidean)
-segment times, linear QP only: the Hessian/mapping-block assembly kernel + the block-Cholesky solve
-kernel per step.  `--workload nonlinear` times configs[2] (Mellinger outer loop + feasibility scaling +
-sampling) instead.  Weak scaling: every rank owns `--paths` paths and there is no data-path collective
-(paths are independent); as at N = 1 the results of a step stay resident in the HBM of the GPU that
-computed them, and the job's one collective -- the RCCL gather of the final step's coefficients / times /
-status to rank 0 ("exactly one gather at the end") -- runs inside the timed region.
-`--gather every` gathers after every step instead (double-buffered on a side stream); for N > 1 that
-rate is reported next to the headline as extras.gather_every_step.
+N = 1 runs in this process.  N > 1 without a torch.distributed environment starts N ranks itself:
+`python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py <same arguments>`
+as a CHILD process, before this process has imported torch or touched the GPU, and relays the child's JSON line and
+exit code.  Launched by torch.distributed.run (RANK / WORLD_SIZE in the environment) it is one of the ranks.
 
-Steps are independent batches, so `--in-flight` of them (default 4 = the HIP runtime's hardware queues per process)
-are kept in flight per GPU, each on its own HIP stream with its own context and plan: a 1024-path batch leaves most of
-an MI355X idle (one wavefront per CU in the serial phase of the solve), and the assembly of one batch overlaps the
-solves of the others.  Every step still does all
-of its work; `extras.one_batch_in_flight` is the same measurement with one stream (each step waits for the previous).
+A "step" is one pass of the hot path over one batch whose inputs already sit in HBM.  Headline workload = BASELINE.json
+configs[1]: 1024 random 10-segment order-10 min-snap paths per GPU, fixed (Euclidean) segment times, linear QP only, solved
+by the library's default linear solve (mrs_tg_plan_solve, flags 0: every lane forms its column of the reduced system from
+the segment times in registers -- no block is written to memory).  The Hessian / mapping-block ASSEMBLY kernel
+(mrs_tg_plan_assemble, 1608 B per segment into HBM) is the `roofline` object; the step that runs it and then solves from
+the materialised blocks is timed as extras.materialized_blocks_step.  `--workload nonlinear` times configs[2] (Mellinger
+outer loop + feasibility scaling + sampling) instead.
 
-Prints ONE JSON line (rank 0) with `roofline` (assembly kernel, HBM-write bound, HIP-event timed on the
-launch stream) and `cpu_baseline` (the C oracle timed on this box's host cores).
+Weak scaling: every rank owns `--paths` paths and there is no data-path collective (paths are independent); as at N = 1 the
+results of a step stay resident in the HBM of the GPU that computed them, and the job's one collective -- the RCCL gather of
+the final step's coefficients / times / status to rank 0 ("exactly one gather at the end") -- runs inside the
+timed region.  BASELINE configs[3] in its own terms -- ONE batch of 65536 nonlinear-time paths cut into contiguous shards
+over the N ranks, results gathered to rank 0 -- is measured in the same run at every N and reported as extras.config3
+(strong scaling of a fixed batch).
+
+Steps are independent batches, so `--in-flight` of them (default 4 = the HIP runtime's hardware queues per process) are kept
+in flight per GPU, each on its own HIP stream with its own context and plan; extras.one_batch_in_flight is the same
+measurement with one stream (each step waits for the previous).
+
+Prints ONE JSON line (rank 0): `roofline` (assembly kernel, HBM-write bound; `achieved` uses the PER-DISPATCH duration --
+events attached to the kernel launch itself, what rocprofv3 --kernel-trace reports for the dispatch; the back-to-back
+launch interval is given beside it and labelled), `roofline_solve` / `roofline_outer_loop` (FP64, flop model of SURVEY.md 8d
+over the per-dispatch duration), and `cpu_baseline` (the C oracle on this box's host cores: one core, and all cores through
+its persistent thread pool on the configs[3]-sized batch).
 """
 import argparse
+import glob
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
-
-import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+FP64_VECTOR_PEAK_TFLOPS = 78.6  # 256 CUs x 4 SIMDs x 16 lanes x 2 flop x 2.4 GHz; scripts/dpp_probe.hip measures it (sustained)
 ASSEMBLY_BYTES_PER_SEGMENT = 8 + 800 + 800   # read T, write full 10x10 f64 H and A^-1
+SOLVE_FLOP_PER_SEGMENT = 6.0e3               # linear solve ~6e3 S flop per path (6e4 at S = 10)
+NONLINEAR_FLOP_PER_PATH_S10 = 7.0e6          # mode 2, <= 121 linear solves at S = 10
+CONFIG3_PATHS = 65536
 
 
-def parse_args():
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
@@ -48,15 +63,58 @@ def parse_args():
     ap.add_argument("--segments", type=int, default=10)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=10.0, help="single-core work of the cpu_baseline sample")
-    ap.add_argument("--no-extras", action="store_true", help="skip the secondary (other workload) measurement")
+    ap.add_argument("--no-extras", action="store_true", help="skip the secondary measurements")
     ap.add_argument("--gather", choices=["final", "every"], default="final",
                     help="N > 1: gather the results to rank 0 once at the end of the timed steps (default) or after every step")
     ap.add_argument("--force-dist", action="store_true", help="initialise torch.distributed even for one rank (tests the RCCL path)")
+    ap.add_argument("--dist-backend", choices=["nccl", "gloo"], default="nccl",
+                    help="gloo: the collectives go through host memory (lets several ranks share one GPU in a test)")
     ap.add_argument("--in-flight", type=int, default=4,
                     help="independent batches in flight per GPU: steps are issued round-robin on this many HIP streams "
                          "(one context + plan each); 1 = every step waits for the previous one")
-    return ap.parse_args()
+    ap.add_argument("--config3-paths", type=int, default=CONFIG3_PATHS, help="size of the fixed batch of extras.config3")
+    return ap.parse_args(argv)
 
+
+# ---------------------------------------------------------------------------------------------------------------------
+# self-launch (N > 1)
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def launcher_command(n_gpus, argv, port, python=sys.executable, script=os.path.abspath(__file__)):
+    """The torch.distributed.run command that starts `n_gpus` ranks of this script with the caller's own arguments."""
+    return [python, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n_gpus), "--master-addr", "127.0.0.1",
+            "--master-port", str(port), script] + list(argv)
+
+
+def self_launch(args, argv):
+    """Start the ranks as a child process (this process has not initialised the GPU), relay the JSON line, return its rc."""
+    cmd = launcher_command(args.gpus, argv, _free_port())
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    proc = subprocess.run(cmd, stdout=subprocess.PIPE, env=env, text=True)
+    line = None
+    for ln in proc.stdout.splitlines():
+        if ln.startswith('{"metric"'):
+            line = ln
+        elif ln.strip():
+            print(ln, file=sys.stderr)
+    if line is not None:
+        print(line, flush=True)
+    elif proc.returncode == 0:
+        print("bench.py: the ranks printed no result line", file=sys.stderr)
+        return 1
+    return proc.returncode
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# helpers (run inside a rank)
 
 def time_steps(step_fn, steps, warmup, dist, torch, final_fn=None):
     """W untimed steps, then exactly K steps (+ final_fn, the job's closing gather) between barrier + synchronize
@@ -81,45 +139,94 @@ def time_steps(step_fn, steps, warmup, dist, torch, final_fn=None):
     elapsed = time.perf_counter() - t0
     if dist is not None:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        if dist.get_backend() == "gloo":
+            t = t.cpu()
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     return elapsed
 
 
-def kernel_event_ms(launch_fn, reps, torch):
-    """Average duration of one launch, HIP events on the launch stream around every single launch."""
-    starts = [torch.cuda.Event(enable_timing=True) for _ in range(reps)]
-    stops = [torch.cuda.Event(enable_timing=True) for _ in range(reps)]
-    for i in range(reps):
-        starts[i].record()
-        launch_fn()
-        stops[i].record()
+def dispatch_stats(ctx, kernel_id, launch_fn, reps, torch):
+    """Per-dispatch durations of `reps` QUEUED launches of one kernel: the library attaches a pair of timing events to every
+    kernel launch itself (mrs_tg_set_profiling / mrs_tg_kernel_ms_history), so each value is that dispatch's own start-to-end
+    time -- what rocprofv3 --kernel-trace reports for the same launches of the same command.  Returns (mean, median, min) ms."""
     torch.cuda.synchronize()
-    per = sorted(s.elapsed_time(e) for s, e in zip(starts, stops))
-    return float(np.mean(per)), float(per[len(per) // 2])
+    ctx.set_profiling(True)
+    try:
+        for _ in range(reps):
+            launch_fn()
+        vals = ctx.kernel_ms_history(kernel_id, min(reps, 512))
+    finally:
+        ctx.set_profiling(False)
+    torch.cuda.synchronize()
+    vals.sort()
+    return sum(vals) / len(vals), vals[len(vals) // 2], vals[0]
+
+
+def back_to_back_ms(launch_fn, reps, torch):
+    """(two events around `reps` back-to-back launches) / reps: the launch-to-launch interval, in which the tail of one
+    dispatch overlaps the ramp of the next -- NOT a kernel duration."""
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        launch_fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / reps
+
+
+def measured_traffic(n_paths, n_seg):
+    """HBM traffic of the assembly kernel from the newest committed PMC summary (separate rocprofv3 --pmc passes,
+    scripts/pmc_assemble.py; MI355X_MICROARCH.md corrections applied there).  Not measured in this run."""
+    best = None
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "round*_pmc_assemble_hbm_traffic.json"))):
+        try:
+            with open(f) as fh:
+                d = json.load(fh)
+        except (OSError, ValueError):
+            continue
+        if d.get("paths") == n_paths and d.get("segments") == n_seg:
+            best = (d, os.path.relpath(f, ROOT))
+    return best
 
 
 def main():
-    args = parse_args()
+    argv = sys.argv[1:]
+    args = parse_args(argv)
+    if args.gpus > 1 and "RANK" not in os.environ:
+        sys.exit(self_launch(args, argv))   # nothing below has run: no torch import, no GPU call in this process
+
+    import numpy as np
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     import torch
+    n_dev = torch.cuda.device_count()
+    dev_index = local_rank if local_rank < n_dev else local_rank % max(n_dev, 1)   # gloo test: ranks share the GPU
     dist = None
     if world > 1 or args.force_dist:
         import torch.distributed as dist_mod
         if args.force_dist and "RANK" not in os.environ:   # stand-alone single-rank rendezvous
             os.environ.update(RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-            os.environ.setdefault("MASTER_PORT", "29533")
-        torch.cuda.set_device(local_rank)
-        dist_mod.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+            os.environ.setdefault("MASTER_PORT", str(_free_port()))
+        torch.cuda.set_device(dev_index)
+        if args.dist_backend == "nccl":
+            dist_mod.init_process_group("nccl", device_id=torch.device("cuda", dev_index))
+        else:
+            dist_mod.init_process_group("gloo")
         dist = dist_mod
+        ranks_seen = dist.get_world_size()
+        if ranks_seen != max(args.gpus, 1) and not args.force_dist:
+            raise SystemExit("bench.py: --gpus %d but torch.distributed reports %d ranks" % (args.gpus, ranks_seen))
     else:
         torch.cuda.set_device(0)
-    dev = torch.device("cuda", local_rank if dist is not None else 0)
+        dev_index = 0
+        ranks_seen = 1
+    dev = torch.device("cuda", dev_index)
+    gloo = dist is not None and args.dist_backend == "gloo"
 
-    from mrs_uav_trajectory_generation_amd import api, problem as pr
+    from mrs_uav_trajectory_generation_amd import api, problem as pr, shard
 
     # every rank generates its own shard: path p of rank r is seeded with r * paths + p
     batch = pr.random_batch(args.paths, args.segments, seed0=rank * args.paths)
@@ -138,10 +245,16 @@ def main():
     t_fixed = t_init.clone()   # linear mode never writes the times
 
     opt_lin = api.default_options(derivative_to_optimize=4)
+    opt_blocks = api.default_options(derivative_to_optimize=4, flags=api.FLAG_MATERIALIZED_BLOCKS)
     opt_nl = api.default_options(derivative_to_optimize=4, time_alloc_method=api.TIME_ALLOC_MELLINGER,
                                  sampling_dt=0.2, sample_capacity=512)
 
-    from mrs_uav_trajectory_generation_amd import shard
+    def gather(tensor, bufs):
+        """the job's one collective: equally shaped per-rank results -> rank 0"""
+        if gloo:
+            shard.gather_to_root(tensor.cpu(), dist)
+        else:
+            shard.gather_to_root(tensor, dist, bufs=bufs)
 
     # Output double buffer: results of step k are gathered to rank 0 on a side stream while step k+1 computes
     # (the gather is the job's only collective; RCCL over xGMI).  Coefficients, times and status share one
@@ -165,7 +278,7 @@ def main():
         tt.copy_(t_init)
     db.coeffs, db.seg_times, db.status = out_coeffs[0], out_times[0], status_i32[0]
     comm_stream = torch.cuda.Stream(device=dev) if dist is not None else None
-    recv = [[torch.empty_like(packed[0]) for _ in range(world)] if (dist is not None and rank == 0) else None
+    recv = [[torch.empty_like(packed[0]) for _ in range(world)] if (dist is not None and rank == 0 and not gloo) else None
             for _ in range(n_slots)]
     slot_free = [None] * n_slots      # event: the gather that read this slot has finished
     step_no = [0]
@@ -178,9 +291,9 @@ def main():
     def slot_call(kind, slot, lane):
         key = (kind, slot, lane)
         if key not in bound:
-            if kind == "linear":
-                bound[key] = lane_plan[lane].bind_solve(opt_lin, db.fixed_mask, db.fixed_values, t_fixed, out_coeffs[slot],
-                                                        status_i32[slot], slot_cost[slot])
+            if kind in ("linear", "blocks"):
+                bound[key] = lane_plan[lane].bind_solve(opt_lin if kind == "linear" else opt_blocks, db.fixed_mask, db.fixed_values,
+                                                        t_fixed, out_coeffs[slot], status_i32[slot], slot_cost[slot])
             else:
                 bound[key] = lane_plan[lane].bind_solve(opt_nl, db.fixed_mask, db.fixed_values, out_times[slot], out_coeffs[slot],
                                                         status_i32[slot], slot_cost[slot], limits=db.limits,
@@ -196,7 +309,7 @@ def main():
             ready.record()
         with torch.cuda.stream(comm_stream):
             comm_stream.wait_event(ready)
-            shard.gather_to_root(packed[slot], dist, bufs=recv[slot])
+            gather(packed[slot], recv[slot])
             done = torch.cuda.Event()
             done.record()
         slot_free[slot] = done
@@ -216,12 +329,14 @@ def main():
     gather_every = [args.gather == "every"]
     last_slot = [(0, 0)]
 
-    def step_linear():
-        slot, lane = begin_step()
-        slot_call("linear", slot, lane)()
-        last_slot[0] = (slot, lane)
-        if gather_every[0]:
-            finish_step(slot, lane)
+    def make_linear_step(kind):
+        def step():
+            slot, lane = begin_step()
+            slot_call(kind, slot, lane)()
+            last_slot[0] = (slot, lane)
+            if gather_every[0]:
+                finish_step(slot, lane)
+        return step
 
     def step_nonlinear():
         slot, lane = begin_step()
@@ -239,44 +354,85 @@ def main():
         finish_step(*last_slot[0])
         torch.cuda.current_stream().wait_event(slot_free[last_slot[0][0]])
 
-    steps_fn = {"linear": step_linear, "nonlinear": step_nonlinear}
+    steps_fn = {"linear": make_linear_step("linear"), "blocks": make_linear_step("blocks"), "nonlinear": step_nonlinear}
+
+    # The clocks of an idle MI355X take a few milliseconds of work to come up, and the driver's default run is 5 warm-up
+    # + 20 timed steps of ~10 us: an untimed ramp of the same step keeps the timed region from measuring the ramp.
+    for _ in range(300):
+        steps_fn[args.workload]()
+    torch.cuda.synchronize()
+    step_no[0] = 0
+
     elapsed = time_steps(steps_fn[args.workload], args.steps, args.warmup, dist, torch, final_gather)
     total_paths = P * world * args.steps
     value = total_paths / elapsed
 
-    # ---- roofline of the assembly kernel (rank 0's device; HIP events on the launch stream) ----
+    # ---- roofline of the assembly kernel (rank 0's device) ----
     Hbuf = torch.empty(plan.block_doubles, dtype=torch.float64, device=dev)
     Abuf = torch.empty(plan.block_doubles, dtype=torch.float64, device=dev)
 
     def launch_assemble():
         plan.assemble(4, t_init, Hbuf, Abuf)
 
-    for _ in range(10):
+    for _ in range(20):
         launch_assemble()
     torch.cuda.synchronize()
-    # (a) two events around a run of back-to-back launches: mean launch duration without per-launch event cost
-    reps = 200
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record()
-    for _ in range(reps):
-        launch_assemble()
-    e1.record()
-    torch.cuda.synchronize()
-    mean_ms = e0.elapsed_time(e1) / reps
-    # (b) an event pair around every single launch (adds the event packets' own time to each sample)
-    per_launch_mean_ms, per_launch_med_ms = kernel_event_ms(launch_assemble, 200, torch)
+    asm_mean, asm_med, asm_min = dispatch_stats(ctx, api.KERNEL_ASSEMBLE, launch_assemble, 300, torch)
+    asm_b2b = back_to_back_ms(launch_assemble, 200, torch)
     alg_bytes = ASSEMBLY_BYTES_PER_SEGMENT * nS
-    achieved = alg_bytes / (mean_ms * 1e-3) / 1e9
-    # HBM traffic from PMC counters (separate rocprofv3 passes, profiles/round1_pmc_assemble_hbm_traffic.csv):
-    # WRITE_SIZE calibrated on this kernel's store pattern (8 B per lane, 512 B per wave instruction) with a pure
-    # fill of known size (k_fill8 in scripts/k1_variants.hip: exact); FETCH_SIZE is doubled as MI355X_MICROARCH.md
-    # prescribes for gfx950.  Measured for the 1024 x 10 launch: 16000 KiB written + 2 x 105 KiB fetched.
-    traffic = (16000 + 2 * 105) * 1024 if (P == 1024 and args.segments == 10) else None
+    achieved = alg_bytes / (asm_mean * 1e-3) / 1e9
+    traffic, traffic_source = None, "no PMC summary for this batch shape under profiles/"
+    tm = measured_traffic(P, args.segments)
+    if tm is not None:
+        traffic = tm[0]["hbm_bytes_per_launch"]
+        traffic_source = "%s (separate rocprofv3 --pmc passes; from profiles/, not this run)" % tm[1]
     roofline = dict(kernel="assemble_blocks_uniform_kernel", bound="hbm", achieved=achieved, peak=HBM_PEAK_GBS, unit="GB/s",
-                    frac=achieved / HBM_PEAK_GBS, traffic=traffic, bytes_per_launch=alg_bytes,
-                    avg_launch_us=mean_ms * 1e3, per_launch_event_us=per_launch_mean_ms * 1e3,
-                    per_launch_event_median_us=per_launch_med_ms * 1e3,
+                    frac=achieved / HBM_PEAK_GBS, traffic=traffic, traffic_source=traffic_source, bytes_per_launch=alg_bytes,
+                    avg_launch_us=asm_mean * 1e3, median_launch_us=asm_med * 1e3, min_launch_us=asm_min * 1e3,
+                    timing="per dispatch: a pair of events attached to each of 300 queued launches (what rocprofv3 --kernel-trace "
+                           "reports for the same launches)",
+                    back_to_back_interval_us=asm_b2b * 1e3,
+                    back_to_back_note="launch-to-launch interval of 200 queued launches; one dispatch's tail overlaps the "
+                                      "next one's ramp, so this is NOT a kernel duration (%.3f of peak if it were)"
+                                      % (alg_bytes / (asm_b2b * 1e-3) / 1e9 / HBM_PEAK_GBS),
                     note="16 MB per launch: launch-ramp bound, see extras.roofline_large for the same kernel at 1 GB")
+
+    # ---- FP64 rooflines of the solve kernel and of the outer-loop kernel (per dispatch, flop model of SURVEY.md 8d) ----
+    db.coeffs, db.seg_times, db.status = out_coeffs[0], out_times[0], status_i32[0]
+
+    def launch_solve():
+        plan.solve(opt_lin, db.fixed_mask, db.fixed_values, t_fixed, out_coeffs[0], status_i32[0], slot_cost[0])
+
+    def launch_nl():
+        out_times[0].copy_(t_init)
+        plan.solve(opt_nl, db.fixed_mask, db.fixed_values, out_times[0], out_coeffs[0], status_i32[0], slot_cost[0],
+                   limits=db.limits, n_samples=slot_nsamp[0], samples=slot_samples[0])
+
+    for _ in range(10):
+        launch_solve()
+    torch.cuda.synchronize()
+    sol_mean, sol_med, sol_min = dispatch_stats(ctx, api.KERNEL_SOLVE_LINEAR, launch_solve, 200, torch)
+    solve_flop = SOLVE_FLOP_PER_SEGMENT * nS
+    roofline_solve = dict(kernel="solve_rows_kernel", bound="fp64 vector", unit="TFLOP/s", peak=FP64_VECTOR_PEAK_TFLOPS,
+                          flop_per_launch=solve_flop, avg_launch_us=sol_mean * 1e3, median_launch_us=sol_med * 1e3,
+                          achieved=solve_flop / (sol_mean * 1e-3) / 1e12,
+                          frac=solve_flop / (sol_mean * 1e-3) / 1e12 / FP64_VECTOR_PEAK_TFLOPS,
+                          note="flop model of SURVEY.md 8d (6e3 flop per segment, which counts the reference's two dense "
+                               "10^3 products per segment; the kernel forms the blocks from exact constants and executes "
+                               "roughly a quarter of that); the kernel is bound by one dependent chain per path, not by "
+                               "FP64 issue: see DESIGN.md")
+    for _ in range(3):
+        launch_nl()
+    torch.cuda.synchronize()
+    nl_mean, nl_med, nl_min = dispatch_stats(ctx, api.KERNEL_NONLINEAR, launch_nl, 50, torch)
+    nl_flop = NONLINEAR_FLOP_PER_PATH_S10 * (args.segments / 10.0) ** 2 * P
+    roofline_outer = dict(kernel="optimize_split_kernel / optimize_compact_kernel", bound="fp64 vector", unit="TFLOP/s",
+                          peak=FP64_VECTOR_PEAK_TFLOPS, flop_per_launch=nl_flop, avg_launch_us=nl_mean * 1e3,
+                          median_launch_us=nl_med * 1e3, achieved=nl_flop / (nl_mean * 1e-3) / 1e12,
+                          frac=nl_flop / (nl_mean * 1e-3) / 1e12 / FP64_VECTOR_PEAK_TFLOPS,
+                          note="flop model of SURVEY.md 8d for mode 2 (7e6 flop per 10-segment path = 121 reference-style "
+                               "linear solves, an upper bound: the kernel runs forward-only cost sweeps and stops early on "
+                               "ftol / xtol)")
 
     extras = {}
     if not args.no_extras and rank == 0:
@@ -290,32 +446,44 @@ def main():
         for _ in range(3):
             plan_big.assemble(4, t_big, Hb, Ab)
         torch.cuda.synchronize()
-        m_big, _ = kernel_event_ms(lambda: plan_big.assemble(4, t_big, Hb, Ab), 20, torch)
+        m_big, _, _ = dispatch_stats(ctx, api.KERNEL_ASSEMBLE, lambda: plan_big.assemble(4, t_big, Hb, Ab), 20, torch)
         bytes_big = ASSEMBLY_BYTES_PER_SEGMENT * big_P * args.segments
         extras["roofline_large"] = dict(kernel="assemble_blocks_uniform_kernel", paths=big_P, bytes_per_launch=bytes_big,
                                         avg_launch_us=m_big * 1e3, achieved=bytes_big / (m_big * 1e-3) / 1e9,
-                                        unit="GB/s", frac=bytes_big / (m_big * 1e-3) / 1e9 / HBM_PEAK_GBS)
+                                        unit="GB/s", frac=bytes_big / (m_big * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                        timing="per dispatch, 20 queued launches")
         del Hb, Ab
         plan_big.close()
-        # PCIe-inclusive rate of the one-call host interface (plan creation + H2D + kernels + D2H); never the headline
+        # PCIe-inclusive rate of the one-call host interface (H2D + kernels + D2H; the plan is cached after the first call)
         times_host = t_init.cpu().numpy()
         ctx.solve_batch(batch, times_host)
         t0 = time.perf_counter()
-        for _ in range(5):
+        for _ in range(20):
             ctx.solve_batch(batch, times_host)
-        extras["host_buffer_call"] = dict(value=5 * P / (time.perf_counter() - t0), unit="trajectories/s",
+        extras["host_buffer_call"] = dict(value=20 * P / (time.perf_counter() - t0), unit="trajectories/s",
                                           note="mrs_tg_solve_batch with host buffers, linear QP, includes PCIe copies")
+    if not args.no_extras and args.workload == "linear":
+        # the step that materialises the blocks: assembly kernel + solve from the blocks in HBM
+        elb = time_steps(steps_fn["blocks"], args.steps, 3, dist, torch, final_gather)
+        if rank == 0:
+            extras["materialized_blocks_step"] = dict(value=P * world * args.steps / elb, unit="trajectories/s",
+                                                      ms_per_step=elb / args.steps * 1e3,
+                                                      note="MRS_TG_FLAG_MATERIALIZED_BLOCKS: assemble_blocks kernel (16.5 MB to "
+                                                           "HBM) + solve_tile_kernel reading the blocks back; %d in flight" % n_lanes)
     if n_lanes > 1 and not args.no_extras:
         # the same steps with one batch in flight: every step waits for the previous one (single stream)
         torch.cuda.synchronize()
         active_lanes[0] = 1
         step_no[0] = 0
         el1 = time_steps(steps_fn[args.workload], args.steps, 3, dist, torch, final_gather)
+        el1b = time_steps(steps_fn["blocks"], args.steps, 3, dist, torch, final_gather) if args.workload == "linear" else None
         active_lanes[0] = n_lanes
         step_no[0] = 0
         if rank == 0:
             extras["one_batch_in_flight"] = dict(value=P * world * args.steps / el1, unit="trajectories/s",
                                                  ms_per_step=el1 / args.steps * 1e3)
+            if el1b is not None:
+                extras["one_batch_in_flight"]["materialized_blocks_ms_per_step"] = el1b / args.steps * 1e3
     if not args.no_extras:
         other = "nonlinear" if args.workload == "linear" else "linear"
         k2 = max(5, args.steps // 10) if other == "nonlinear" else args.steps
@@ -332,11 +500,59 @@ def main():
                                                    ms_per_step=el3 / args.steps * 1e3,
                                                    bytes_per_rank_per_step=int(packed[0].numel() * 8))
 
+    # ---- BASELINE configs[3]: ONE batch of 65536 nonlinear-time paths, contiguous shards over the ranks, gather to rank 0
+    if not args.no_extras:
+        total3 = args.config3_paths
+        a3, b3 = shard.contiguous_shard(total3, rank, world)
+        n3 = b3 - a3
+        # path p of the batch is seeded with p, whatever the number of ranks: the same 65536 paths at every N
+        batch3 = pr.random_batch(n3, args.segments, seed0=a3)
+        plan3 = api.Plan(ctx, batch3.seg_offsets)
+        db3 = api.DeviceBatch(batch3, dev, sample_capacity=512)
+        plan3.solve(est, db3.fixed_mask, db3.fixed_values, db3.seg_times, db3.coeffs, db3.status, db3.cost,
+                    waypoints=db3.waypoints, limits=db3.limits)
+        torch.cuda.synchronize()
+        t3 = db3.seg_times.clone()
+        nS3 = batch3.n_segments
+        pk3 = torch.zeros(nS3 * 41 + n3, dtype=torch.float64, device=dev)
+        c3, tt3 = pk3[:nS3 * 40].view(nS3, 4, 10), pk3[nS3 * 40:nS3 * 41]
+        st3 = torch.zeros(n3, dtype=torch.int32, device=dev)
+        # equal shards gather in one collective; the (rare) uneven cut pads to the largest shard
+        cap3 = (total3 + world - 1) // world
+        pad3 = torch.zeros(cap3 * args.segments * 41 + cap3, dtype=torch.float64, device=dev) if dist is not None else None
+        recv3 = ([torch.empty_like(pad3) for _ in range(world)] if (dist is not None and rank == 0 and not gloo) else None)
+        call3 = plan3.bind_solve(opt_nl, db3.fixed_mask, db3.fixed_values, tt3, c3, st3, db3.cost, limits=db3.limits,
+                                 n_samples=db3.n_samples, samples=db3.samples)
+
+        def step3():
+            tt3.copy_(t3)
+            call3()
+
+        def gather3():
+            if dist is None:
+                return
+            pk3[nS3 * 41:].copy_(st3)
+            pad3[:pk3.numel()].copy_(pk3)
+            gather(pad3, recv3)
+
+        k3 = max(3, min(10, args.steps // 20))
+        el4 = time_steps(step3, k3, 2, dist, torch, gather3)
+        if rank == 0:
+            extras["config3"] = dict(workload="BASELINE configs[3]: one batch of %d random %d-segment paths, Mellinger outer loop + "
+                                              "feasibility scaling + sampling, contiguous shards over %d rank(s), results gathered "
+                                              "to rank 0 after the last step (inside the timed region)" % (total3, args.segments, world),
+                                     value=total3 * k3 / el4, unit="trajectories/s", scaling="strong", steps=k3,
+                                     ms_per_step=el4 / k3 * 1e3, paths_per_rank=n3, n_gpus=world,
+                                     gather_bytes_per_rank=int(pk3.numel() * 8))
+        plan3.close()
+        del db3, pk3, pad3, recv3
+
     # ---- parity of this very batch against the oracle (max-coeff err vs CPU ref) + CPU baseline ----
     cpu = None
     err = None
     if rank == 0 and not args.no_cpu_baseline:
         from oracle import pyoracle as po
+        active_lanes[0] = n_lanes
         step_no[0] = 0
         steps_fn["linear"]()
         torch.cuda.synchronize()
@@ -354,57 +570,86 @@ def main():
         for _ in range(reps_cpu):
             po.solve_batch(sub.seg_offsets, sub.waypoints, sub.fixed_mask, sub.fixed_values, sub.limits, sub_t, deriv=4)
         dt1 = (time.perf_counter() - t0) / reps_cpu
-        cores = os.cpu_count() or 1
-        reps_all = max(1, reps_cpu // 8)
-        t0 = time.perf_counter()
-        for _ in range(reps_all):
-            po.solve_batch(sub.seg_offsets, sub.waypoints, sub.fixed_mask, sub.fixed_values, sub.limits, sub_t, deriv=4,
-                           n_threads=cores)
-        dtn = (time.perf_counter() - t0) / reps_all
         gpu_c = db.coeffs.cpu().numpy()[:sub.n_segments]
         worst = 0.0
         for p in range(sub.n_paths):
             a, b = sub.seg_offsets[p], sub.seg_offsets[p + 1]
             worst = max(worst, float(np.max(np.abs(gpu_c[a:b] - ref["coeffs"][a:b])) / np.max(np.abs(ref["coeffs"][a:b]))))
         err = worst
+        # all cores: the oracle's persistent thread pool on a configs[3]-sized batch (the 1024 paths tiled 64 times)
+        cores = os.cpu_count() or 1
+        tile = max(1, CONFIG3_PATHS // n_cpu)
+        parts = [sub.path(p) for p in range(sub.n_paths)] * tile
+        big = pr.assemble_batch(parts, np.tile(sub.limits, (tile, 1)))
+        big_t = np.tile(sub_t, tile)
+        po.solve_batch(big.seg_offsets, big.waypoints, big.fixed_mask, big.fixed_values, big.limits, big_t, deriv=4,
+                       n_threads=cores)   # creates the pool, touches the memory
+        t0 = time.perf_counter()
+        reps_all = 0
+        while reps_all < 3 or (time.perf_counter() - t0 < 0.3 * args.cpu_seconds and reps_all < 50):
+            po.solve_batch(big.seg_offsets, big.waypoints, big.fixed_mask, big.fixed_values, big.limits, big_t, deriv=4,
+                           n_threads=cores)
+            reps_all += 1
+        dtn = (time.perf_counter() - t0) / reps_all
         cpu = dict(value=n_cpu / dt1, unit="trajectories/s", cores=1, kind="port",
                    sample="%d x the first %d of the %d paths of this batch (%.1f s of one core), linear QP, C oracle "
-                          "(reference-style arithmetic, dense QR); all-core figure: %d x the same batch"
-                          % (reps_cpu, n_cpu, P, reps_cpu * dt1, reps_all),
-                   value_all_cores=n_cpu / dtn, cores_all=cores)
+                          "(reference-style arithmetic, dense QR)" % (reps_cpu, n_cpu, P, reps_cpu * dt1),
+                   value_all_cores=big.n_paths / dtn, cores_all=cores,
+                   sample_all_cores="%d x a batch of %d paths (the same %d paths tiled), %d threads of the oracle's "
+                                    "persistent pool, dynamic chunks" % (reps_all, big.n_paths, n_cpu, cores))
         if args.workload == "nonlinear" or not args.no_extras:
             n_nl = min(P, 256)
             subn = batch.select(range(n_nl))
 
-            def cpu_nonlinear():
-                po.solve_batch(subn.seg_offsets, subn.waypoints, subn.fixed_mask, subn.fixed_values, subn.limits,
-                               times[:subn.n_segments], deriv=4, time_alloc_method=2, sampling_dt=0.2, sample_capacity=512)
+            def cpu_nonlinear(b_, t_, threads):
+                po.solve_batch(b_.seg_offsets, b_.waypoints, b_.fixed_mask, b_.fixed_values, b_.limits, t_, deriv=4,
+                               time_alloc_method=2, sampling_dt=0.2, sample_capacity=512, n_threads=threads)
+            tn = times[:subn.n_segments]
             t0 = time.perf_counter()
-            cpu_nonlinear()
+            cpu_nonlinear(subn, tn, 1)
             dtnl = time.perf_counter() - t0
             reps_nl = max(1, min(100, int(0.5 * args.cpu_seconds / max(dtnl, 1e-6))))
             t0 = time.perf_counter()
             for _ in range(reps_nl):
-                cpu_nonlinear()
+                cpu_nonlinear(subn, tn, 1)
             dtnl = (time.perf_counter() - t0) / reps_nl
             cpu["nonlinear_value"] = n_nl / dtnl
             cpu["nonlinear_sample"] = ("%d x %d paths (%.1f s of one core), Mellinger outer loop + scaling + sampling, 1 thread"
                                        % (reps_nl, n_nl, reps_nl * dtnl))
+            tile_n = max(1, 8192 // n_nl)
+            bign = pr.assemble_batch([subn.path(p) for p in range(n_nl)] * tile_n, np.tile(subn.limits, (tile_n, 1)))
+            bign_t = np.tile(tn, tile_n)
+            cpu_nonlinear(bign, bign_t, cores)
+            t0 = time.perf_counter()
+            reps_na = 0
+            while reps_na < 2 or (time.perf_counter() - t0 < 0.3 * args.cpu_seconds and reps_na < 20):
+                cpu_nonlinear(bign, bign_t, cores)
+                reps_na += 1
+            cpu["nonlinear_value_all_cores"] = bign.n_paths * reps_na / (time.perf_counter() - t0)
+            cpu["nonlinear_sample_all_cores"] = "%d x %d paths, %d threads" % (reps_na, bign.n_paths, cores)
 
     if rank == 0:
+        lin_desc = ("BASELINE configs[1]: %d random %d-segment order-10 min-snap paths per GPU, fixed times, linear QP"
+                    % (P, args.segments))
+        nl_desc = ("BASELINE configs[2]: %d random %d-segment paths per GPU, Mellinger outer loop (<=10 evaluations) + "
+                   "feasibility scaling + sampling dt 0.2" % (P, args.segments))
         line = dict(metric="trajectories/sec (batch of N-seg min-snap paths)", value=value, unit="trajectories/s",
-                    n_gpus=world, steps=args.steps, warmup=args.warmup, ms_per_step=elapsed / args.steps * 1e3,
+                    n_gpus=world, ranks_seen=ranks_seen, steps=args.steps, warmup=args.warmup,
+                    ms_per_step=elapsed / args.steps * 1e3,
                     higher_is_better=True, scaling="weak", vs_baseline=None, dtype="f64", data="synthetic",
-                    config=dict(workload=("BASELINE configs[1]: %d random %d-segment order-10 min-snap paths per GPU, "
-                                          "fixed times, linear QP" if args.workload == "linear" else
-                                          "BASELINE configs[2]: %d random %d-segment paths per GPU, Mellinger outer loop "
-                                          "(<=10 evaluations) + feasibility scaling + sampling dt 0.2") % (P, args.segments),
+                    config=dict(workload=lin_desc if args.workload == "linear" else nl_desc,
                                 paths_per_gpu=P, segments=args.segments, batches_in_flight=n_lanes,
-                                parallelism=("independent paths sharded per rank, no data-path collective; RCCL gather of "
+                                linear_solve="default of mrs_tg_plan_solve: solve_rows_kernel, blocks formed in registers "
+                                             "(nothing materialised); the assembly kernel is timed on its own (roofline) and "
+                                             "inside extras.materialized_blocks_step",
+                                clock_ramp_steps=300,
+                                parallelism=("independent paths sharded per rank, no data-path collective; %s gather of "
                                              "the results to rank 0 %s, inside the timed region"
-                                             % ("after every step" if args.gather == "every" else "once, after the last step"))
+                                             % ("gloo (host)" if gloo else "RCCL",
+                                                "after every step" if args.gather == "every" else "once, after the last step"))
                                 if world > 1 else "single GPU"),
-                    max_coeff_err_vs_cpu_ref=err, roofline=roofline, cpu_baseline=cpu, extras=extras)
+                    max_coeff_err_vs_cpu_ref=err, roofline=roofline, roofline_solve=roofline_solve,
+                    roofline_outer_loop=roofline_outer, cpu_baseline=cpu, extras=extras)
         import ctypes
         ctypes.CDLL(None).fflush(None)   # RCCL's banner sits in C stdio: keep the JSON line the last thing printed
         print(json.dumps(line), flush=True)
@@ -415,6 +660,7 @@ def main():
     plan.close()
     ctx.close()
     if dist is not None:
+        dist.barrier()
         dist.destroy_process_group()
 
 

@@ -229,8 +229,12 @@ int mrs_tg_plan_segment_maxima(mrs_tg_plan* plan, const double* coeffs_dev, cons
  * (the events are attached to the kernel launch itself, hipExtLaunchKernelGGL: what rocprofv3 --kernel-trace reports for
  * it) -- requires mrs_tg_set_profiling(ctx, 1).  kernel_id: 0 block assembly, 1 linear solve, 2 nonlinear outer loop.
  * Blocks until that launch has finished. */
-int mrs_tg_set_profiling(mrs_tg_ctx* ctx, int enabled);
+int mrs_tg_set_profiling(mrs_tg_ctx* ctx, int enabled); /* switching it on starts a new series */
 int mrs_tg_last_kernel_ms(mrs_tg_ctx* ctx, int kernel_id, float* ms_out);
+/* The durations of the newest timed launches of the series (at most 512 are kept, oldest first; launches may be queued
+ * back to back, every one carries its own pair of events).  Returns the number written (<= capacity) or a negative
+ * MRS_TG_ERR_*.  Blocks until those launches have finished. */
+int mrs_tg_kernel_ms_history(mrs_tg_ctx* ctx, int kernel_id, float* ms_out, int capacity);
 
 /* ---- single-path convenience mirroring findTrajectory()'s signature ------------------------- */
 

@@ -70,7 +70,8 @@ EXPORTED_SYMBOLS = [
     "mrs_tg_set_stream", "mrs_tg_reset_stream", "mrs_tg_synchronize", "mrs_tg_solve_batch", "mrs_tg_plan_create", "mrs_tg_plan_destroy",
     "mrs_tg_plan_n_paths", "mrs_tg_plan_n_segments", "mrs_tg_plan_max_segments", "mrs_tg_plan_get_order",
     "mrs_tg_plan_assemble", "mrs_tg_plan_block_bytes", "mrs_tg_plan_solve", "mrs_tg_plan_cost_gradient",
-    "mrs_tg_plan_segment_maxima", "mrs_tg_set_profiling", "mrs_tg_last_kernel_ms", "mrs_tg_find_trajectory",
+    "mrs_tg_plan_segment_maxima", "mrs_tg_set_profiling", "mrs_tg_last_kernel_ms", "mrs_tg_kernel_ms_history",
+    "mrs_tg_find_trajectory",
     "mrs_tg_default_policy_options", "mrs_tg_optimize_paths", "mrs_tg_waypoint_trajectory_idxs",
     "mrs_tg_create_multi", "mrs_tg_destroy_multi", "mrs_tg_multi_n_devices", "mrs_tg_multi_context", "mrs_tg_multi_shard",
     "mrs_tg_multi_solve_batch", "mrs_tg_multi_last_error",
@@ -137,6 +138,8 @@ def load_library():
     L.mrs_tg_set_profiling.argtypes = [vp, C.c_int]
     L.mrs_tg_last_kernel_ms.restype = C.c_int
     L.mrs_tg_last_kernel_ms.argtypes = [vp, C.c_int, C.POINTER(C.c_float)]
+    L.mrs_tg_kernel_ms_history.restype = C.c_int
+    L.mrs_tg_kernel_ms_history.argtypes = [vp, C.c_int, C.POINTER(C.c_float), C.c_int]
     L.mrs_tg_find_trajectory.restype = C.c_int
     L.mrs_tg_find_trajectory.argtypes = [vp, C.POINTER(Waypoint), C.c_int32, C.POINTER(InitialState), dp,
                                          C.POINTER(Options), C.c_int32, dp, dp, ip, ip, dp]
@@ -239,6 +242,14 @@ class Context:
         ms = C.c_float(0)
         self._check(self._L.mrs_tg_last_kernel_ms(self._h, int(kernel_id), C.byref(ms)), "last_kernel_ms")
         return ms.value
+
+    def kernel_ms_history(self, kernel_id, capacity=512):
+        """Per-dispatch durations (ms) of the newest timed launches since set_profiling(True), oldest first."""
+        buf = (C.c_float * capacity)()
+        n = self._L.mrs_tg_kernel_ms_history(self._h, int(kernel_id), buf, capacity)
+        if n < 0:
+            self._check(n, "kernel_ms_history")
+        return [buf[i] for i in range(n)]
 
     def solve_batch(self, batch: Batch, seg_times=None, **opts):
         """Host arrays in, host arrays out (mrs_tg_solve_batch).  seg_times None => estimate_times."""

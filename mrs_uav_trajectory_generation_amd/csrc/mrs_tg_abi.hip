@@ -43,9 +43,11 @@ struct mrs_tg_ctx {
   hipStream_t stream = nullptr;
   std::string last_error;
   bool profiling = false;
-  hipEvent_t ev_start[3] = {nullptr, nullptr, nullptr};
-  hipEvent_t ev_stop[3] = {nullptr, nullptr, nullptr};
-  bool ev_valid[3] = {false, false, false};
+  // per-dispatch timing: a ring of event pairs per kernel family, one pair per timed launch (kTimerRing launches can be
+  // queued before the oldest is overwritten)
+  static constexpr int kTimerRing = 512;
+  std::vector<hipEvent_t> ev_start[3], ev_stop[3];
+  long long ev_count[3] = {0, 0, 0};   // timed launches since profiling was switched on
   hipDeviceProp_t prop;
   double wall_clock_hz = 1.0e8;  // rate of s_memrealtime (hipDeviceAttributeWallClockRate)
   // plan of the most recent mrs_tg_solve_batch: a caller that sends the same batch shape again (the nodelet's
@@ -99,17 +101,24 @@ long long budget_ticks(const mrs_tg_ctx* ctx, double seconds_left) {
 struct ProfileScope {
   mrs_tg_ctx* ctx;
   int id;
+  bool armed = false;
   ProfileScope(mrs_tg_ctx* c, int kernel_id) : ctx(c), id(kernel_id) {
-    if (ctx->profiling) {
-      mrs_tg::set_kernel_timer(ctx->ev_start[id], ctx->ev_stop[id]);
-      ctx->ev_valid[id] = false;
+    if (!ctx->profiling) return;
+    if (ctx->ev_start[id].empty()) {
+      ctx->ev_start[id].assign(mrs_tg_ctx::kTimerRing, nullptr);
+      ctx->ev_stop[id].assign(mrs_tg_ctx::kTimerRing, nullptr);
     }
+    const int slot = (int)(ctx->ev_count[id] % mrs_tg_ctx::kTimerRing);
+    if (!ctx->ev_start[id][slot]) {
+      if (hipEventCreate(&ctx->ev_start[id][slot]) != hipSuccess || hipEventCreate(&ctx->ev_stop[id][slot]) != hipSuccess) return;
+    }
+    mrs_tg::set_kernel_timer(ctx->ev_start[id][slot], ctx->ev_stop[id][slot]);
+    armed = true;
   }
   ~ProfileScope() {
-    if (ctx->profiling) {
-      const mrs_tg::KernelTimer left = mrs_tg::take_kernel_timer();  // consumed <=> a timed kernel was launched
-      ctx->ev_valid[id] = left.start == nullptr;
-    }
+    if (!armed) return;
+    const mrs_tg::KernelTimer left = mrs_tg::take_kernel_timer();  // consumed <=> a timed kernel was launched
+    if (left.start == nullptr) ++ctx->ev_count[id];
   }
 };
 
@@ -249,10 +258,6 @@ int mrs_tg_create(int device_ordinal, mrs_tg_ctx** ctx_out) {
     if (hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, device_ordinal) == hipSuccess && khz > 0)
       ctx->wall_clock_hz = 1.0e3 * (double)khz;
   }
-  for (int i = 0; i < 3; ++i) {
-    (void)hipEventCreate(&ctx->ev_start[i]);
-    (void)hipEventCreate(&ctx->ev_stop[i]);
-  }
   ++g_live_contexts;
   *ctx_out = ctx;
   return MRS_TG_OK;
@@ -268,8 +273,10 @@ void mrs_tg_destroy(mrs_tg_ctx* ctx) {
     mrs_tg_plan_destroy(p);
   }
   for (int i = 0; i < 3; ++i) {
-    if (ctx->ev_start[i]) (void)hipEventDestroy(ctx->ev_start[i]);
-    if (ctx->ev_stop[i]) (void)hipEventDestroy(ctx->ev_stop[i]);
+    for (hipEvent_t e : ctx->ev_start[i])
+      if (e) (void)hipEventDestroy(e);
+    for (hipEvent_t e : ctx->ev_stop[i])
+      if (e) (void)hipEventDestroy(e);
   }
   if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
   delete ctx;
@@ -298,16 +305,32 @@ int mrs_tg_synchronize(mrs_tg_ctx* ctx) {
 int mrs_tg_set_profiling(mrs_tg_ctx* ctx, int enabled) {
   if (!ctx) return fail(nullptr, MRS_TG_ERR_INVALID_ARG, "ctx is NULL");
   ctx->profiling = enabled != 0;
+  if (ctx->profiling)
+    for (int i = 0; i < 3; ++i) ctx->ev_count[i] = 0;  // a new series
   return MRS_TG_OK;
+}
+
+int mrs_tg_kernel_ms_history(mrs_tg_ctx* ctx, int kernel_id, float* ms_out, int capacity) {
+  if (!ctx || (capacity > 0 && !ms_out)) return fail(ctx, MRS_TG_ERR_INVALID_ARG, "NULL argument");
+  if (kernel_id < 0 || kernel_id > 2) return fail(ctx, MRS_TG_ERR_INVALID_ARG, "kernel id %d outside [0, 2]", kernel_id);
+  const long long total = ctx->ev_count[kernel_id];
+  long long n = total < mrs_tg_ctx::kTimerRing ? total : mrs_tg_ctx::kTimerRing;
+  if (n > capacity) n = capacity;
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  for (long long i = 0; i < n; ++i) {  // the newest n launches, oldest first
+    const int slot = (int)((total - n + i) % mrs_tg_ctx::kTimerRing);
+    HIP_TRY(ctx, hipEventSynchronize(ctx->ev_stop[kernel_id][slot]));
+    HIP_TRY(ctx, hipEventElapsedTime(&ms_out[i], ctx->ev_start[kernel_id][slot], ctx->ev_stop[kernel_id][slot]));
+  }
+  return (int)n;
 }
 
 int mrs_tg_last_kernel_ms(mrs_tg_ctx* ctx, int kernel_id, float* ms_out) {
   if (!ctx || !ms_out) return fail(ctx, MRS_TG_ERR_INVALID_ARG, "NULL argument");
-  if (kernel_id < 0 || kernel_id > 2 || !ctx->ev_valid[kernel_id])
+  if (kernel_id < 0 || kernel_id > 2 || ctx->ev_count[kernel_id] == 0)
     return fail(ctx, MRS_TG_ERR_INVALID_ARG, "no timed launch recorded for kernel id %d (mrs_tg_set_profiling, then a call that runs that kernel)", kernel_id);
-  HIP_TRY(ctx, hipEventSynchronize(ctx->ev_stop[kernel_id]));
-  HIP_TRY(ctx, hipEventElapsedTime(ms_out, ctx->ev_start[kernel_id], ctx->ev_stop[kernel_id]));
-  return MRS_TG_OK;
+  const int n = mrs_tg_kernel_ms_history(ctx, kernel_id, ms_out, 1);
+  return n == 1 ? MRS_TG_OK : n;
 }
 
 // ---- plan ------------------------------------------------------------------------------------

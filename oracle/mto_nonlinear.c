@@ -24,6 +24,7 @@
 #include <float.h>
 #include <math.h>
 #include <pthread.h>
+#include <stdint.h>
 #include <stdlib.h>
 #include <string.h>
 
@@ -590,9 +591,8 @@ typedef struct {
   int capacity;
 } batch_job;
 
-static void* batch_worker(void* arg) {
-  batch_job* j = (batch_job*)arg;
-  for (int p = j->p0; p < j->p1; ++p) {
+static void run_paths(const batch_job* j, int p0, int p1) {
+  for (int p = p0; p < p1; ++p) {
     const int s0 = j->seg_offsets[p], S = j->seg_offsets[p + 1] - s0, v0 = s0 + p;
     const int st = solve_one(S, j->waypoints + (size_t)v0 * 4, j->fixed_mask + (size_t)v0 * 5,
                              j->fixed_values + (size_t)v0 * 5 * 4, j->limits + (size_t)p * 9, j->opt, j->seg_times + s0,
@@ -600,6 +600,51 @@ static void* batch_worker(void* arg) {
                              j->n_samples ? j->n_samples + p : NULL,
                              j->samples ? j->samples + (size_t)p * j->capacity * DIM : NULL, j->capacity);
     if (j->status) j->status[p] = st;
+  }
+}
+
+/* Persistent worker pool (bench.py's all-core CPU baseline): the workers are created once and parked on a condition
+ * variable; a batch is handed out in chunks of paths from a shared counter, so the nonlinear path (whose cost per path
+ * varies with the number of evaluations) balances itself and a call costs no thread creation. */
+static struct {
+  pthread_mutex_t mu;
+  pthread_cond_t wake, idle;
+  pthread_t* th;
+  int n_threads;          /* workers alive */
+  long long generation;   /* bumped once per batch */
+  const batch_job* job;
+  int next, chunk, busy, want; /* `want` workers (the lowest ids) take part in the current batch */
+} g_pool = {PTHREAD_MUTEX_INITIALIZER, PTHREAD_COND_INITIALIZER, PTHREAD_COND_INITIALIZER, NULL, 0, 0, NULL, 0, 1, 0, 0};
+
+static int pool_take(int* p0, int* p1) {
+  pthread_mutex_lock(&g_pool.mu);
+  const int total = g_pool.job->p1;
+  int ok = 0;
+  if (g_pool.next < total) {
+    *p0 = g_pool.next;
+    *p1 = g_pool.next + g_pool.chunk < total ? g_pool.next + g_pool.chunk : total;
+    g_pool.next = *p1;
+    ok = 1;
+  }
+  pthread_mutex_unlock(&g_pool.mu);
+  return ok;
+}
+
+static void* pool_worker(void* arg) {
+  const int id = (int)(intptr_t)arg;
+  long long seen = 0;
+  for (;;) {
+    pthread_mutex_lock(&g_pool.mu);
+    while (g_pool.generation == seen) pthread_cond_wait(&g_pool.wake, &g_pool.mu);
+    seen = g_pool.generation;
+    const int take_part = id < g_pool.want;
+    pthread_mutex_unlock(&g_pool.mu);
+    if (!take_part) continue;
+    int p0, p1;
+    while (pool_take(&p0, &p1)) run_paths(g_pool.job, p0, p1);
+    pthread_mutex_lock(&g_pool.mu);
+    if (--g_pool.busy == 0) pthread_cond_signal(&g_pool.idle);
+    pthread_mutex_unlock(&g_pool.mu);
   }
   return NULL;
 }
@@ -610,21 +655,43 @@ int mto_solve_batch(int n_paths, const int32_t* seg_offsets, const double* waypo
                     int sample_capacity, int n_threads) {
   if (n_threads < 1) n_threads = 1;
   if (n_threads > n_paths) n_threads = n_paths > 0 ? n_paths : 1;
-  batch_job* jobs = (batch_job*)malloc(sizeof(batch_job) * (size_t)n_threads);
-  pthread_t* th = (pthread_t*)malloc(sizeof(pthread_t) * (size_t)n_threads);
-  for (int t = 0; t < n_threads; ++t) {
-    batch_job j = {(int)((long long)n_paths * t / n_threads), (int)((long long)n_paths * (t + 1) / n_threads),
-                   seg_offsets, waypoints, fixed_mask, fixed_values, limits, opt, seg_times_inout, coeffs_out,
-                   status_out, cost_out, n_samples_out, samples_out, sample_capacity};
-    jobs[t] = j;
-  }
+  const batch_job job = {0, n_paths, seg_offsets, waypoints, fixed_mask, fixed_values, limits, opt, seg_times_inout,
+                         coeffs_out, status_out, cost_out, n_samples_out, samples_out, sample_capacity};
   if (n_threads == 1) {
-    batch_worker(&jobs[0]);
-  } else {
-    for (int t = 0; t < n_threads; ++t) pthread_create(&th[t], NULL, batch_worker, &jobs[t]);
-    for (int t = 0; t < n_threads; ++t) pthread_join(th[t], NULL);
+    run_paths(&job, 0, n_paths);
+    return 0;
   }
-  free(jobs);
-  free(th);
+  static pthread_mutex_t call_mu = PTHREAD_MUTEX_INITIALIZER; /* one batch at a time through the pool */
+  pthread_mutex_lock(&call_mu);
+  pthread_mutex_lock(&g_pool.mu);
+  if (g_pool.n_threads < n_threads) { /* grow the pool (never shrinks) */
+    g_pool.th = (pthread_t*)realloc(g_pool.th, sizeof(pthread_t) * (size_t)n_threads);
+    for (int t = g_pool.n_threads; t < n_threads; ++t) {
+      if (pthread_create(&g_pool.th[t], NULL, pool_worker, (void*)(intptr_t)t) != 0) {
+        n_threads = t; /* the system refuses more threads: go on with what exists */
+        break;
+      }
+      pthread_detach(g_pool.th[t]);
+    }
+    if (n_threads > g_pool.n_threads) g_pool.n_threads = n_threads;
+  }
+  if (n_threads < 1) { /* not a single worker could be created */
+    pthread_mutex_unlock(&g_pool.mu);
+    pthread_mutex_unlock(&call_mu);
+    run_paths(&job, 0, n_paths);
+    return 0;
+  }
+  g_pool.job = &job;
+  g_pool.next = 0;
+  /* ~8 chunks per worker: small enough to balance, large enough that the shared counter is not contended */
+  g_pool.chunk = n_paths / (8 * n_threads) > 0 ? n_paths / (8 * n_threads) : 1;
+  g_pool.want = n_threads;
+  g_pool.busy = n_threads;
+  ++g_pool.generation;
+  pthread_cond_broadcast(&g_pool.wake);
+  while (g_pool.busy > 0) pthread_cond_wait(&g_pool.idle, &g_pool.mu);
+  g_pool.job = NULL;
+  pthread_mutex_unlock(&g_pool.mu);
+  pthread_mutex_unlock(&call_mu);
   return 0;
 }

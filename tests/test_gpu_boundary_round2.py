@@ -135,8 +135,12 @@ def test_per_dispatch_kernel_timing(gpu_ctx):
             gpu_ctx.last_kernel_ms(api.KERNEL_NONLINEAR)  # nothing of that family has run under profiling yet
         H = torch.empty(plan.block_doubles, dtype=torch.float64, device="cuda")
         A = torch.empty(plan.block_doubles, dtype=torch.float64, device="cuda")
-        plan.assemble(4, db.seg_times, H, A)
+        for _ in range(40):  # queued back to back: every launch carries its own pair of events
+            plan.assemble(4, db.seg_times, H, A)
+        hist = gpu_ctx.kernel_ms_history(api.KERNEL_ASSEMBLE)
+        assert len(hist) == 40 and all(1e-3 < v < 0.1 for v in hist), hist
         ms_asm = gpu_ctx.last_kernel_ms(api.KERNEL_ASSEMBLE)
+        assert ms_asm == hist[-1]
         plan.solve(api.default_options(), db.fixed_mask, db.fixed_values, db.seg_times, db.coeffs, db.status, db.cost)
         ms_solve = gpu_ctx.last_kernel_ms(api.KERNEL_SOLVE_LINEAR)
         nl = api.default_options(time_alloc_method=api.TIME_ALLOC_MELLINGER)
