@@ -351,6 +351,41 @@ __device__ __forceinline__ double poly_eval(const double* c, double t, int deriv
   return acc;
 }
 
+// B[D][i] B[D][j] / (i + j - 2D + 1): 0.5 c^T Q c = T^(1-2D) sum_ij G_ij (c_i T^i)(c_j T^j)
+// (computeQuadraticCostJacobian, linear_impl.h:606-618, with the factor 2 of Q against the 0.5 of the cost)
+template <int D>
+__device__ __forceinline__ double cost_quadratic_form(const double (&cb)[kN]) {
+  double total = 0.0;
+#pragma unroll
+  for (int i = D; i < kN; ++i) {
+    double bi = 1.0;
+#pragma unroll
+    for (int n = 0; n < D; ++n) bi *= (double)(i - n);
+    double inner = 0.0;
+#pragma unroll
+    for (int j = D; j < kN; ++j) {
+      double bj = 1.0;
+#pragma unroll
+      for (int n = 0; n < D; ++n) bj *= (double)(j - n);
+      inner = fma(bi * bj / (double)(i + j - 2 * D + 1), cb[j], inner);
+    }
+    total = fma(cb[i], inner, total);
+  }
+  return total;
+}
+
+// cb_k = c_k T^k of one polynomial -> its cost 0.5 c^T Q c = T^(1-2d) * form (the reference's computeCost,
+// linear_impl.h:128-141, for one segment and dimension)
+__device__ __forceinline__ double cost_quadratic_form_d(int d, const double (&cb)[kN]) {
+  switch (d) {
+    case 0: return cost_quadratic_form<0>(cb);
+    case 1: return cost_quadratic_form<1>(cb);
+    case 2: return cost_quadratic_form<2>(cb);
+    case 3: return cost_quadratic_form<3>(cb);
+    default: return cost_quadratic_form<4>(cb);
+  }
+}
+
 // ---------------------------------------------------------------------------------------------
 // batch addressing shared by all kernels
 

@@ -49,29 +49,6 @@ __device__ __forceinline__ void wave_lds_sync() {
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 }
 
-// B[D][i] B[D][j] / (i + j - 2D + 1): 0.5 c^T Q c = T^(1-2D) sum_ij G_ij (c_i T^i)(c_j T^j)
-// (computeQuadraticCostJacobian, linear_impl.h:606-618, with the factor 2 of Q against the 0.5 of the cost)
-template <int D>
-__device__ __forceinline__ double cost_quadratic_form(const double (&cb)[kN]) {
-  double total = 0.0;
-#pragma unroll
-  for (int i = D; i < kN; ++i) {
-    double bi = 1.0;
-#pragma unroll
-    for (int n = 0; n < D; ++n) bi *= (double)(i - n);
-    double inner = 0.0;
-#pragma unroll
-    for (int j = D; j < kN; ++j) {
-      double bj = 1.0;
-#pragma unroll
-      for (int n = 0; n < D; ++n) bj *= (double)(j - n);
-      inner = fma(bi * bj / (double)(i + j - 2 * D + 1), cb[j], inner);
-    }
-    total = fma(cb[i], inner, total);
-  }
-  return total;
-}
-
 #ifdef MRS_TG_ROWS_DEBUG
 __device__ double g_rows_debug[64 * 24 * 2];
 #endif
@@ -488,14 +465,7 @@ __global__ __launch_bounds__(64) void solve_rows_kernel(BatchView b, int d, int 
     double* out = coeffs + ((size_t)(s0_t + i) * kD + dim) * kN;
 #pragma unroll
     for (int kk = 0; kk < kN; ++kk) out[kk] = c[kk];
-    double quad_form;
-    switch (d) {
-      case 0: quad_form = cost_quadratic_form<0>(cb); break;
-      case 1: quad_form = cost_quadratic_form<1>(cb); break;
-      case 2: quad_form = cost_quadratic_form<2>(cb); break;
-      case 3: quad_form = cost_quadratic_form<3>(cb); break;
-      default: quad_form = cost_quadratic_form<4>(cb); break;
-    }
+    const double quad_form = cost_quadratic_form_d(d, cb);
     // T^(1 - 2d) = q[0] / T
     pcb[r] = quad_form * (sb[(size_t)i * kRSegRec + kRSegPow] * ti);
   }
