@@ -1,5 +1,6 @@
 /* solve_batch_host.c -- the C ABI from plain C99 (no C++, no HIP headers, no torch): two rest-to-rest paths, minimum snap,
- * Mellinger time allocation, sampled at 0.2 s.  tests/test_gpu_cpp_host.py builds it with gcc and checks the output.
+ * Mellinger time allocation, sampled at 0.2 s -- on one device, then sharded over a device list.
+ * tests/test_gpu_cpp_host.py builds it with gcc and checks the output.
  *
  *   gcc -std=c99 -I include examples/solve_batch_host.c -o solve_batch_host -L mrs_uav_trajectory_generation_amd -lmrs_tg
  */
@@ -59,7 +60,35 @@ int main(void) {
     printf("], \"first\": [%.9g, %.9g, %.9g], \"last\": [%.9g, %.9g, %.9g]}", samples[(size_t)p * CAP * 4], samples[(size_t)p * CAP * 4 + 1],
            samples[(size_t)p * CAP * 4 + 2], last[0], last[1], last[2]);
   }
-  printf("]}\n");
+  printf("]");
   mrs_tg_destroy(ctx);
+
+  /* the same batch over a device list (here: device 0 twice -- on an 8-GPU node {0, 1, .., 7}): every device solves its
+   * shard on its own host thread, the results land in the caller's buffers; same numbers as the single-device call */
+  {
+    const int devices[2] = {0, 0};
+    mrs_tg_multi* multi = NULL;
+    double seg_times2[5] = {0}, coeffs2[5 * 4 * 10], cost2[N_PATHS];
+    static double samples2[N_PATHS * CAP * 4];
+    int32_t status2[N_PATHS], n_samples2[N_PATHS], shard[N_PATHS];
+    if (mrs_tg_create_multi(devices, 2, &multi) != MRS_TG_OK) {
+      fprintf(stderr, "mrs_tg_create_multi: %s\n", mrs_tg_last_error(NULL));
+      return 1;
+    }
+    mrs_tg_multi_shard(multi, N_PATHS, seg_offsets, shard);
+    if (mrs_tg_multi_solve_batch(multi, N_PATHS, seg_offsets, wp, mask, vals, limits, &opt, seg_times2, coeffs2, status2, cost2,
+                                 n_samples2, samples2) != MRS_TG_OK) {
+      fprintf(stderr, "mrs_tg_multi_solve_batch: %s\n", mrs_tg_multi_last_error(multi));
+      mrs_tg_destroy_multi(multi);
+      return 1;
+    }
+    printf(", \"multi\": {\"devices\": %d, \"shard\": [%d, %d], \"identical\": %s}", mrs_tg_multi_n_devices(multi), shard[0], shard[1],
+           (memcmp(coeffs, coeffs2, sizeof(coeffs)) == 0 && memcmp(seg_times, seg_times2, sizeof(seg_times)) == 0 &&
+            memcmp(status, status2, sizeof(status)) == 0 && memcmp(n_samples, n_samples2, sizeof(n_samples)) == 0)
+               ? "true"
+               : "false");
+    mrs_tg_destroy_multi(multi);
+  }
+  printf("}\n");
   return 0;
 }

@@ -73,7 +73,10 @@ def test_plain_c99_host(tmp_path):
                            os.path.join(ROOT, "examples", "solve_batch_host.c"), "-o", exe, "-L", libdir, "-lmrs_tg",
                            "-Wl,-rpath," + libdir])
     r = json.loads(subprocess.run([exe], check=True, capture_output=True, text=True, timeout=300).stdout)
-    assert r["abi"] == 1 and len(r["paths"]) == 2
+    assert r["abi"] == 2 and len(r["paths"]) == 2
+    # the device-list call (two contexts on this box's one GPU): a ragged batch is balanced on the segment count, and the
+    # results are bit-identical to the single-device call
+    assert r["multi"] == {"devices": 2, "shard": [0, 1], "identical": True}
     for p, first, last in zip(r["paths"], ([-5, -5, 5], [0, 0, 2]), ([5, 5, 5], [20, 0, 2])):
         assert p["status"] in (1, 3, 4, 5) and p["n_samples"] > 10 and p["cost"] > 0
         assert np.allclose(p["first"], first, atol=1e-9)

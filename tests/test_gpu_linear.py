@@ -19,7 +19,19 @@ from tests import util
 pytestmark = pytest.mark.gpu
 
 TOL_EXACT = 1e-11
-TOL_ORACLE = 1e-7  # random batches contain short segments where the reference-style oracle itself is ~3e-8 off
+TOL_ORACLE = 1e-8        # <= 1e-8 against the reference-style restatement ...
+TOL_ORACLE_SHORT = 1e-7  # ... except on paths with a segment shorter than 0.5 s next to much longer ones, where the ORACLE is
+#                          the inaccurate side: fixture bench1024_path74_short_segment (a 0.23 s segment between 8.9 s and
+#                          4.4 s ones) has the oracle 2.5e-8 off the 60-digit solution and the HIP path 2e-9 .. 4e-9
+#                          (test_linear_golden_cases, tests/test_oracle_golden.py)
+
+
+def assert_close_to_oracle(batch, t, got, ref):
+    for p in range(batch.n_paths):
+        a, b = batch.seg_offsets[p], batch.seg_offsets[p + 1]
+        tol = TOL_ORACLE_SHORT if np.min(t[a:b]) < 0.5 else TOL_ORACLE
+        err = util.coeff_error(got[a:b], ref[a:b])
+        assert err < tol, (p, err, np.min(t[a:b]))
 
 
 def test_assemble_blocks_match_exact_and_oracle(gpu_ctx, golden):
@@ -53,12 +65,44 @@ def test_linear_golden_cases(gpu_ctx, golden, fused):
         out = gpu_ctx.solve_batch(batch, t, flags=api.FLAG_FUSED_ASSEMBLY if fused else api.FLAG_MATERIALIZED_BLOCKS)
         exact = np.array(case["coeffs"])
         err = util.coeff_error(out["coeffs"], exact)
-        assert err < TOL_EXACT, (case["name"], err)
-        assert abs(out["cost"][0] - case["cost"]) <= 1e-10 * abs(case["cost"]), case["name"]
-        assert out["status"][0] == 1
-        # against the oracle the distance is bounded by the oracle's own error to the exact answer
         oc = po.solve_linear(case["derivative_to_optimize"], batch.fixed_mask, batch.fixed_values, t)
-        assert util.coeff_error(out["coeffs"], oc) <= 1.01 * util.coeff_error(oc, exact) + 10 * TOL_EXACT, case["name"]
+        err_oracle = util.coeff_error(oc, exact)
+        assert out["status"][0] == 1
+        if case["name"] == "bench1024_path74_short_segment":
+            # (cost: the fused kernel evaluates 0.5 c^T Q c, 1e-10 here; the blocks kernel's elimination by-product
+            # 0.5 (f^T H f - sum |z|^2) loses the digits the conditioning takes, 1e-8)
+            assert abs(out["cost"][0] - case["cost"]) <= (1e-9 if fused else 1e-7) * abs(case["cost"])
+            # The path behind bench.py's max_coeff_err_vs_cpu_ref: a 0.23 s segment between 8.9 s and 4.4 s ones puts
+            # (8.9 / 0.23)^7 = 1e11 between neighbouring blocks of R_pp, and no double-precision route reaches 1e-11 here.
+            # Measured against the 60-digit solution: HIP 2e-9 (fused) / 4e-9 (materialised blocks), oracle 2.5e-8 -- the
+            # 2.5e-8 that bench.py reports between the two is the ORACLE's error.
+            assert err < 1e-8 and err < 0.25 * err_oracle, (err, err_oracle)
+            assert util.coeff_error(out["coeffs"], oc) <= 1.2 * err_oracle
+            continue
+        assert abs(out["cost"][0] - case["cost"]) <= 1e-10 * abs(case["cost"]), case["name"]
+        assert err < TOL_EXACT, (case["name"], err)
+        # against the oracle the distance is bounded by the oracle's own error to the exact answer
+        assert util.coeff_error(out["coeffs"], oc) <= 1.01 * err_oracle + 10 * TOL_EXACT, case["name"]
+
+
+def test_supported_fixed_free_patterns_of_row_a10(gpu_ctx, golden):
+    """setupConstraintReorderingMatrix (linear_impl.h:184-257) takes any fixed / free pattern; this library takes every pattern
+    over the derivatives 1..4 and requires the position of every vertex to be constrained (as every caller of the reference
+    does; a position-free vertex is refused with status -2, test_gpu_abi_errors.py).  SURVEY.md A.4's example -- the shipping
+    minimum-acceleration objective with an initial state at vertex 0 and a stop_at at vertex 3: free slots per vertex
+    [1, 4, 4, 1, 4, 4, 2] -- against the 60-digit solution and the oracle."""
+    case = [c for c in golden["cases"] if c["name"] == "mixed6_d2"][0]
+    mask = np.array(case["fixed_mask"])
+    assert (5 - mask.sum(axis=1)).tolist() == [1, 4, 4, 1, 4, 4, 2] and np.all(mask[:, 0] == 1)
+    batch, t = util.case_batch(case)
+    exact = np.array(case["coeffs"])
+    oc = po.solve_linear(2, batch.fixed_mask, batch.fixed_values, t)
+    for flags in (api.FLAG_MATERIALIZED_BLOCKS, 0):
+        out = gpu_ctx.solve_batch(batch, t, flags=flags)
+        assert out["status"][0] == 1
+        assert util.coeff_error(out["coeffs"], exact) < TOL_EXACT
+        assert util.coeff_error(out["coeffs"], oc) <= 1.01 * util.coeff_error(oc, exact) + 10 * TOL_EXACT
+        assert util.constraint_defect(batch, out["coeffs"], t) < 1e-9
 
 
 def test_closed_form_rest_to_rest(gpu_ctx):
@@ -82,7 +126,7 @@ def test_linear_random_batches_vs_oracle(gpu_ctx, n_seg, n_paths):
     ref = util.oracle_linear(batch, t)
     for flags in (api.FLAG_MATERIALIZED_BLOCKS, api.FLAG_FUSED_ASSEMBLY):
         out = gpu_ctx.solve_batch(batch, t, flags=flags)
-        assert util.coeff_error(out["coeffs"], ref["coeffs"], batch.seg_offsets) < TOL_ORACLE
+        assert_close_to_oracle(batch, t, out["coeffs"], ref["coeffs"])
         assert np.max(np.abs(out["cost"] - ref["cost"]) / np.abs(ref["cost"]).clip(1e-300)) < 1e-7
         assert np.all(out["status"] == 1)
 
@@ -93,7 +137,7 @@ def test_linear_ragged_batch_vs_oracle(gpu_ctx):
     ref = util.oracle_linear(batch, t)
     for flags in (api.FLAG_MATERIALIZED_BLOCKS, api.FLAG_FUSED_ASSEMBLY):
         out = gpu_ctx.solve_batch(batch, t, flags=flags)
-        assert util.coeff_error(out["coeffs"], ref["coeffs"], batch.seg_offsets) < TOL_ORACLE
+        assert_close_to_oracle(batch, t, out["coeffs"], ref["coeffs"])
 
 
 @pytest.mark.parametrize("deriv", [2, 3, 4])

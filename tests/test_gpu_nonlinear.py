@@ -6,10 +6,10 @@ Tolerances:
     to its max-norm (the reference-style oracle loses digits on short segments and in the difference
     quotient); vs the exact fixtures: 1e-10 and 1e-8;
   * per-segment maxima: 1e-9 relative (different root finder, same maxima);
-  * end to end (optimiser + scaling + final solve): segment times 1e-6 relative, coefficients
-    1e-6 (err metric of SURVEY.md 8d), sampled positions 1e-6 m -- for at least 95 % of the paths
-    (measured: 100 % on the uniform 10-segment batches, 97-99 % on ragged ones), and 1e-3 on the
-    times of every path that ends with the same status.
+  * end to end (optimiser + scaling + final solve): the stopping reason and the sample count of EVERY path; segment times
+    1e-6 relative, coefficients 1e-6 (err metric of SURVEY.md 8d), sampled positions 1e-6 m -- for every path of the uniform
+    batches, >= 98 % of the ragged one and >= 98.5 % of the mixed-constraint batches (measured 99.0 % and 99.1-99.5 %,
+    scripts/agreement_rates.py), and 1e-3 on the times of every path that ends with the same status.
     An optimiser is a chain of comparisons; a path whose comparison flips on a 1e-9 difference in J
     takes a different branch on the two arithmetic routes.  Such paths must still satisfy every
     invariant (status, continuity, constraints, limits), which is asserted for 100 % of them.
@@ -127,8 +127,8 @@ def test_nonlinear_moving_start_end_to_end_vs_oracle(gpu_ctx):
     so = batch.seg_offsets
     dt = np.array([np.max(np.abs(out["times"][a:b] - ref["times"][a:b]) / ref["times"][a:b]) for a, b in zip(so[:-1], so[1:])])
     same = (out["status"] == ref["status"]) & (out["n_samples"] == np.minimum(ref["n_samples"], cap + 1))
-    assert same.mean() >= 0.98, same.mean()
-    assert (dt < 1e-6).mean() >= 0.95, (dt < 1e-6).mean()
+    assert same.all(), same.mean()
+    assert (dt < 1e-6).mean() >= 0.99, (dt < 1e-6).mean()
 
 
 def test_segment_maxima_vs_oracle_and_exact(gpu_ctx, golden):
@@ -185,7 +185,11 @@ def test_nonlinear_end_to_end_vs_oracle(gpu_ctx, n_seg, n_paths):
             good += 1
         if out["status"][p] == ref["status"][p]:
             worst_dt = max(worst_dt, dt)
-    assert good >= 0.95 * batch.n_paths, (good, batch.n_paths)
+    # measured: 100 % on every uniform batch, 94 of 96 on the ragged one (two paths take another branch of the line search on
+    # a 1e-9 difference in J); the stopping reason and the sample count agree on ALL paths
+    assert good >= (0.97 if n_seg == "ragged" else 1.0) * batch.n_paths, (good, batch.n_paths)
+    assert np.array_equal(out["status"], ref["status"])
+    assert np.array_equal(out["n_samples"], np.minimum(ref["n_samples"], cap + 1))
     # paths that took the same branches but sit on badly conditioned time vectors (a 0.7 s segment between
     # 15 s ones) still agree to 1e-3: the forward-difference gradient of the reference-style oracle is only
     # good to ~1e-7 there (tests/test_oracle_golden.py) and L-BFGS amplifies it
@@ -326,9 +330,13 @@ def test_mixed_constraint_patterns_vs_oracle(gpu_ctx, deriv):
     so = batch.seg_offsets
     dt = np.array([np.max(np.abs(out["times"][a:b] - ref["times"][a:b]) / ref["times"][a:b]) for a, b in zip(so[:-1], so[1:])])
     same = (out["status"] == ref["status"]) & (out["n_samples"] == np.minimum(ref["n_samples"], cap + 1))
-    assert same.mean() >= 0.99, same.mean()
-    assert (dt < 1e-6).mean() >= 0.95, (dt < 1e-6).mean()
-    assert (dt < 1e-3).mean() >= 0.99, (dt < 1e-3).mean()
+    # measured (scripts/agreement_rates.py, 768 paths per objective): stopping reason and sample count 100 %; times to 1e-6 on
+    # 99.5 % / 99.1 % / 99.3 % (d = 2 / 3 / 4), to 1e-3 on 100 % / 100 % / 99.9 %.  What is left are the trial points on the 0.01 s
+    # bound, where the by-product cost has lost its digits and the kernel rejects what the oracle's 0.5 c^T Q c may accept
+    # 
+    assert same.all(), same.mean()
+    assert (dt < 1e-6).mean() >= 0.985, (dt < 1e-6).mean()
+    assert (dt < 1e-3).mean() >= 0.995, (dt < 1e-3).mean()
 
 
 @pytest.mark.parametrize("dt,cap", [(0.01, 16384), (0.05, 4096), (0.5, 256), (1.0, 128), (0.3, 512)])
