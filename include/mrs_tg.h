@@ -213,6 +213,17 @@ int mrs_tg_plan_solve(mrs_tg_plan* plan, const double* waypoints_dev, const uint
                       double* seg_times_inout_dev, double* coeffs_out_dev, int32_t* status_out_dev,
                       double* cost_out_dev, int32_t* n_samples_out_dev, double* samples_out_dev);
 
+/* A solve with its arguments fixed once: mrs_tg_bound_solve_launch(b) enqueues what mrs_tg_plan_solve would with the
+ * arguments given here (options copied; the device buffers must stay where they are).  For a server that keeps several
+ * batches in flight and re-issues the same solve step after step: the per-step host cost is one pointer. */
+typedef struct mrs_tg_bound_solve mrs_tg_bound_solve;
+int mrs_tg_plan_bind_solve(mrs_tg_plan* plan, const double* waypoints_dev, const uint8_t* fixed_mask_dev,
+                           const double* fixed_values_dev, const double* limits_dev, const mrs_tg_options* opt,
+                           double* seg_times_inout_dev, double* coeffs_out_dev, int32_t* status_out_dev, double* cost_out_dev,
+                           int32_t* n_samples_out_dev, double* samples_out_dev, mrs_tg_bound_solve** bound_out);
+int mrs_tg_bound_solve_launch(mrs_tg_bound_solve* bound);
+void mrs_tg_bound_solve_destroy(mrs_tg_bound_solve* bound);
+
 /* Building blocks of the outer loop, exposed for parity tests (device pointers, asynchronous):
  * J_d and the h = 0.1 forward-difference gradient at the given times
  * (getCostAndGradientMellinger, nonlinear_impl.h:257-333): cost_out_dev [n_paths], grad_out_dev [sum S]. */

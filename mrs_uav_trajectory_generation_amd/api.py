@@ -69,7 +69,8 @@ EXPORTED_SYMBOLS = [
     "mrs_tg_create", "mrs_tg_destroy", "mrs_tg_last_error", "mrs_tg_abi_version", "mrs_tg_default_options",
     "mrs_tg_set_stream", "mrs_tg_reset_stream", "mrs_tg_synchronize", "mrs_tg_solve_batch", "mrs_tg_plan_create", "mrs_tg_plan_destroy",
     "mrs_tg_plan_n_paths", "mrs_tg_plan_n_segments", "mrs_tg_plan_max_segments", "mrs_tg_plan_get_order",
-    "mrs_tg_plan_assemble", "mrs_tg_plan_block_bytes", "mrs_tg_plan_solve", "mrs_tg_plan_cost_gradient",
+    "mrs_tg_plan_assemble", "mrs_tg_plan_block_bytes", "mrs_tg_plan_solve", "mrs_tg_plan_bind_solve",
+    "mrs_tg_bound_solve_launch", "mrs_tg_bound_solve_destroy", "mrs_tg_plan_cost_gradient",
     "mrs_tg_plan_segment_maxima", "mrs_tg_set_profiling", "mrs_tg_last_kernel_ms", "mrs_tg_kernel_ms_history",
     "mrs_tg_find_trajectory",
     "mrs_tg_default_policy_options", "mrs_tg_optimize_paths", "mrs_tg_waypoint_trajectory_idxs",
@@ -130,6 +131,12 @@ def load_library():
     L.mrs_tg_plan_block_bytes.argtypes = [vp]
     L.mrs_tg_plan_solve.restype = C.c_int
     L.mrs_tg_plan_solve.argtypes = [vp, dp, bp, dp, dp, C.POINTER(Options), dp, dp, ip, dp, ip, dp]
+    L.mrs_tg_plan_bind_solve.restype = C.c_int
+    L.mrs_tg_plan_bind_solve.argtypes = [vp, dp, bp, dp, dp, C.POINTER(Options), dp, dp, ip, dp, ip, dp, C.POINTER(vp)]
+    L.mrs_tg_bound_solve_launch.restype = C.c_int
+    L.mrs_tg_bound_solve_launch.argtypes = [vp]
+    L.mrs_tg_bound_solve_destroy.restype = None
+    L.mrs_tg_bound_solve_destroy.argtypes = [vp]
     L.mrs_tg_plan_cost_gradient.restype = C.c_int
     L.mrs_tg_plan_cost_gradient.argtypes = [vp, C.c_int32, bp, dp, dp, dp, dp]
     L.mrs_tg_plan_segment_maxima.restype = C.c_int
@@ -436,9 +443,13 @@ class Plan:
         order = np.zeros(max(self.n_paths, 1), dtype=np.int32)
         ctx._check(self._L.mrs_tg_plan_get_order(h, _np_ptr(order)), "mrs_tg_plan_get_order")
         self.order = order[:self.n_paths]
+        self._bound = []
 
     def close(self):
         if getattr(self, "_h", None):
+            for b in self._bound:
+                self._L.mrs_tg_bound_solve_destroy(b)
+            self._bound = []
             self._L.mrs_tg_plan_destroy(self._h)
             self._h = None
 
@@ -476,19 +487,23 @@ class Plan:
 
     def bind_solve(self, opt, fixed_mask, fixed_values, seg_times, coeffs, status, cost=None, waypoints=None, limits=None,
                    n_samples=None, samples=None):
-        """solve() with its arguments converted once: returns a callable that enqueues the same solve again (on the
-        context's stream) for a few microseconds of host time -- a server that keeps several batches in flight on
-        several streams issues steps faster than the GPU finishes them only if the per-call host cost is small.
+        """solve() with its arguments fixed once (mrs_tg_plan_bind_solve): returns a callable that enqueues the same solve
+        again on the context's stream for one foreign call with one pointer -- a server that keeps several batches in flight
+        on several streams issues steps faster than the GPU finishes them only if the per-call host cost is small.
         The tensors must stay alive and in place for as long as the callable is used."""
         keep = (opt, fixed_mask, fixed_values, seg_times, coeffs, status, cost, waypoints, limits, n_samples, samples)
-        args = (self._h, _t_ptr(waypoints), _t_ptr(fixed_mask), _t_ptr(fixed_values), _t_ptr(limits), C.byref(opt),
-                _t_ptr(seg_times), _t_ptr(coeffs), _t_ptr(status), _t_ptr(cost), _t_ptr(n_samples), _t_ptr(samples))
-        fn, check = self._L.mrs_tg_plan_solve, self.ctx._check
+        h = C.c_void_p()
+        self.ctx._check(self._L.mrs_tg_plan_bind_solve(self._h, _t_ptr(waypoints), _t_ptr(fixed_mask), _t_ptr(fixed_values),
+                                                       _t_ptr(limits), C.byref(opt), _t_ptr(seg_times), _t_ptr(coeffs),
+                                                       _t_ptr(status), _t_ptr(cost), _t_ptr(n_samples), _t_ptr(samples),
+                                                       C.byref(h)), "mrs_tg_plan_bind_solve")
+        self._bound.append(h)
+        fn, check = self._L.mrs_tg_bound_solve_launch, self.ctx._check
 
-        def enqueue(_keep=keep):
-            rc = fn(*args)
+        def enqueue(_keep=keep, _h=h):
+            rc = fn(_h)
             if rc:
-                check(rc, "mrs_tg_plan_solve")
+                check(rc, "mrs_tg_bound_solve_launch")
         return enqueue
 
     def cost_gradient(self, derivative, fixed_mask, fixed_values, seg_times, cost, grad):

@@ -122,6 +122,13 @@ struct ProfileScope {
   }
 };
 
+// hipSetDevice on every call costs more than asking which device is current
+hipError_t use_device(int device) {
+  int current = -1;
+  if (hipGetDevice(&current) == hipSuccess && current == device) return hipSuccess;  // (another library on this thread may
+  return hipSetDevice(device);                                                        // have switched: ask, do not remember)
+}
+
 int ensure_ws(mrs_tg_plan* plan, size_t doubles) {
   if (plan->ws_doubles >= doubles) return MRS_TG_OK;
   if (plan->d_ws) {
@@ -247,7 +254,7 @@ int mrs_tg_create(int device_ordinal, mrs_tg_ctx** ctx_out) {
   mrs_tg_ctx* ctx = new (std::nothrow) mrs_tg_ctx();
   if (!ctx) return fail(nullptr, MRS_TG_ERR_NOMEM, "out of host memory");
   ctx->device = device_ordinal;
-  if ((e = hipSetDevice(device_ordinal)) != hipSuccess || (e = hipGetDeviceProperties(&ctx->prop, device_ordinal)) != hipSuccess ||
+  if ((e = use_device(device_ordinal)) != hipSuccess || (e = hipGetDeviceProperties(&ctx->prop, device_ordinal)) != hipSuccess ||
       (e = hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking)) != hipSuccess) {
     delete ctx;
     return fail(nullptr, MRS_TG_ERR_HIP, "device setup failed: %s", hipGetErrorString(e));
@@ -265,7 +272,7 @@ int mrs_tg_create(int device_ordinal, mrs_tg_ctx** ctx_out) {
 
 void mrs_tg_destroy(mrs_tg_ctx* ctx) {
   if (!ctx) return;
-  (void)hipSetDevice(ctx->device);
+  (void)use_device(ctx->device);
   (void)hipStreamSynchronize(ctx->stream);
   if (ctx->cached_plan) {
     mrs_tg_plan* p = ctx->cached_plan;
@@ -297,7 +304,7 @@ int mrs_tg_reset_stream(mrs_tg_ctx* ctx) {
 
 int mrs_tg_synchronize(mrs_tg_ctx* ctx) {
   if (!ctx) return fail(nullptr, MRS_TG_ERR_INVALID_ARG, "ctx is NULL");
-  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  HIP_TRY(ctx, use_device(ctx->device));
   HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
   return MRS_TG_OK;
 }
@@ -316,7 +323,7 @@ int mrs_tg_kernel_ms_history(mrs_tg_ctx* ctx, int kernel_id, float* ms_out, int 
   const long long total = ctx->ev_count[kernel_id];
   long long n = total < mrs_tg_ctx::kTimerRing ? total : mrs_tg_ctx::kTimerRing;
   if (n > capacity) n = capacity;
-  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  HIP_TRY(ctx, use_device(ctx->device));
   for (long long i = 0; i < n; ++i) {  // the newest n launches, oldest first
     const int slot = (int)((total - n + i) % mrs_tg_ctx::kTimerRing);
     HIP_TRY(ctx, hipEventSynchronize(ctx->ev_stop[kernel_id][slot]));
@@ -349,7 +356,7 @@ int mrs_tg_plan_create(mrs_tg_ctx* ctx, int32_t n_paths, const int32_t* so, mrs_
     max_S = std::max(max_S, S);
     min_S = std::min(min_S, S);
   }
-  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  HIP_TRY(ctx, use_device(ctx->device));
   mrs_tg_plan* plan = new (std::nothrow) mrs_tg_plan();
   if (!plan) return fail(ctx, MRS_TG_ERR_NOMEM, "out of host memory");
   plan->ctx = ctx;
@@ -400,7 +407,7 @@ int mrs_tg_plan_create(mrs_tg_ctx* ctx, int32_t n_paths, const int32_t* so, mrs_
 
 void mrs_tg_plan_destroy(mrs_tg_plan* plan) {
   if (!plan) return;
-  (void)hipSetDevice(plan->ctx->device);
+  (void)use_device(plan->ctx->device);
   (void)hipStreamSynchronize(plan->ctx->stream);
   mrs_tg::nonlinear_plan_free(plan->nl);
   if (plan->d_seg_offsets) (void)mrs_tg::pool_free(plan->d_seg_offsets);
@@ -432,7 +439,7 @@ int mrs_tg_plan_assemble(mrs_tg_plan* plan, int32_t d, const double* seg_times_d
     return fail(plan ? plan->ctx : nullptr, MRS_TG_ERR_INVALID_ARG, "NULL argument");
   mrs_tg_ctx* ctx = plan->ctx;
   if (d < 0 || d > 4) return fail(ctx, MRS_TG_ERR_INVALID_ARG, "derivative_to_optimize %d outside [0, 4]", d);
-  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  HIP_TRY(ctx, use_device(ctx->device));
   ProfileScope ps(ctx, 0);
   HIP_TRY(ctx, mrs_tg::launch_assemble(plan->view, d, seg_times_dev, H_dev, Ainv_dev, ctx->stream));
   return MRS_TG_OK;
@@ -451,7 +458,7 @@ int mrs_tg_plan_solve(mrs_tg_plan* plan, const double* wp, const uint8_t* mask, 
     return fail(ctx, MRS_TG_ERR_INVALID_ARG, "limits are required for time estimation and for every time-allocation mode");
   if (opt->estimate_times && !wp) return fail(ctx, MRS_TG_ERR_INVALID_ARG, "waypoints are required when estimate_times is set");
   if (opt->sampling_dt > 0 && !n_samples) return fail(ctx, MRS_TG_ERR_INVALID_ARG, "n_samples_out is required when sampling");
-  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  HIP_TRY(ctx, use_device(ctx->device));
   const mrs_tg::BatchView& b = plan->view;
   const int d = opt->derivative_to_optimize;
   if (opt->estimate_times) HIP_TRY(ctx, mrs_tg::launch_estimate_times(b, wp, limits, seg_times, ctx->stream));
@@ -501,13 +508,50 @@ int mrs_tg_plan_solve(mrs_tg_plan* plan, const double* wp, const uint8_t* mask, 
   return MRS_TG_OK;
 }
 
+struct mrs_tg_bound_solve {
+  mrs_tg_plan* plan;
+  const double* wp;
+  const uint8_t* mask;
+  const double* vals;
+  const double* limits;
+  mrs_tg_options opt;
+  double* seg_times;
+  double* coeffs;
+  int32_t* status;
+  double* cost;
+  int32_t* n_samples;
+  double* samples;
+};
+
+int mrs_tg_plan_bind_solve(mrs_tg_plan* plan, const double* wp, const uint8_t* mask, const double* vals, const double* limits,
+                           const mrs_tg_options* opt, double* seg_times, double* coeffs, int32_t* status, double* cost,
+                           int32_t* n_samples, double* samples, mrs_tg_bound_solve** bound_out) {
+  if (!plan || !bound_out) return fail(plan ? plan->ctx : nullptr, MRS_TG_ERR_INVALID_ARG, "NULL argument");
+  *bound_out = nullptr;
+  const int rc = check_options(plan->ctx, opt);
+  if (rc != MRS_TG_OK) return rc;
+  mrs_tg_bound_solve* b = new (std::nothrow) mrs_tg_bound_solve{plan, wp, mask, vals, limits, *opt, seg_times, coeffs, status, cost,
+                                                                n_samples, samples};
+  if (!b) return fail(plan->ctx, MRS_TG_ERR_NOMEM, "out of host memory");
+  *bound_out = b;
+  return MRS_TG_OK;
+}
+
+int mrs_tg_bound_solve_launch(mrs_tg_bound_solve* b) {
+  if (!b) return fail(nullptr, MRS_TG_ERR_INVALID_ARG, "bound solve is NULL");
+  return mrs_tg_plan_solve(b->plan, b->wp, b->mask, b->vals, b->limits, &b->opt, b->seg_times, b->coeffs, b->status, b->cost,
+                           b->n_samples, b->samples);
+}
+
+void mrs_tg_bound_solve_destroy(mrs_tg_bound_solve* b) { delete b; }
+
 int mrs_tg_plan_cost_gradient(mrs_tg_plan* plan, int32_t d, const uint8_t* mask, const double* vals,
                               const double* seg_times, double* cost, double* grad) {
   if (!plan || !mask || !vals || !seg_times || !cost || !grad)
     return fail(plan ? plan->ctx : nullptr, MRS_TG_ERR_INVALID_ARG, "NULL argument");
   mrs_tg_ctx* ctx = plan->ctx;
   if (d < 0 || d > 4) return fail(ctx, MRS_TG_ERR_INVALID_ARG, "derivative_to_optimize %d outside [0, 4]", d);
-  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  HIP_TRY(ctx, use_device(ctx->device));
   HIP_TRY(ctx, mrs_tg::launch_cost_gradient(plan->nl, plan->view, d, mask, vals, seg_times, cost, grad, ctx->stream));
   return MRS_TG_OK;
 }
@@ -516,7 +560,7 @@ int mrs_tg_plan_segment_maxima(mrs_tg_plan* plan, const double* coeffs, const do
   if (!plan || !coeffs || !seg_times || !maxima)
     return fail(plan ? plan->ctx : nullptr, MRS_TG_ERR_INVALID_ARG, "NULL argument");
   mrs_tg_ctx* ctx = plan->ctx;
-  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  HIP_TRY(ctx, use_device(ctx->device));
   HIP_TRY(ctx, mrs_tg::launch_segment_maxima(plan->view, coeffs, seg_times, maxima, ctx->stream));
   return MRS_TG_OK;
 }

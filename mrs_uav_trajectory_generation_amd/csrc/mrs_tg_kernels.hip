@@ -225,15 +225,25 @@ __device__ __forceinline__ double lane_value(double v, int src) {
   return __hiloint2double(hi, lo);
 }
 
+// The walk and the evaluation are separate passes.  The walk produces, chunk by chunk, the time in its segment of every
+// sample (lane j of a chunk holds the j-th one) and parks it with its segment index in an LDS buffer; nothing else sits
+// on the walk's dependent chain.  When the buffer is full (or the walk has ended) all buffered samples are evaluated at
+// once, one lane per sample whatever its segment -- with the evaluation inside the chunk loop (one segment per chunk,
+// ~30 of 64 lanes busy, 40 broadcast LDS reads and the Horner chains in front of the next chunk's additions) the kernel
+// took 25 us for 1024 paths of ~300 samples; 1024 x 10 nonlinear 147 -> us.
+constexpr int kSampleBuffer = 1024;  // samples parked per flush (8 KB of times + 2 KB of segment indices)
+
 __global__ __launch_bounds__(64) void sample_kernel(BatchView b, const double* __restrict__ coeffs,
                                                     const double* __restrict__ seg_times, double dt, int capacity,
                                                     int32_t* __restrict__ n_samples, double* __restrict__ samples) {
-  extern __shared__ double s_T[];  // [max_segments] segment times | [S][4][10] coefficients of this path
+  extern __shared__ double s_T[];  // [max_segments] segment times | [S][4][10] coefficients of this path | sample buffer
   const int q = blockIdx.x;
   const PathRef pr = path_at(b, q);
   const int S = pr.S;
   const int lane = threadIdx.x;
   double* s_c = s_T + b.max_segments;
+  double* s_t = s_c + (size_t)b.max_segments * kD * kN;                         // [kSampleBuffer] time in segment
+  unsigned short* s_seg = reinterpret_cast<unsigned short*>(s_t + kSampleBuffer);  // [kSampleBuffer] segment index
   MRS_TG_PHASE_MARK(0);
   for (int i = lane; i < S; i += 64) s_T[i] = seg_times[pr.s0 + i];
   if (samples) {  // one coalesced pass instead of a global round trip per segment inside the walk
@@ -253,11 +263,37 @@ __global__ __launch_bounds__(64) void sample_kernel(BatchView b, const double* _
     if (acc > 0.0) break;
   }
   int n = 0;
+  double* out = samples ? samples + (size_t)pr.p * capacity * kD : nullptr;
+  int n_flushed = 0;  // samples [n_flushed, n) are parked in the buffer
+  auto flush = [&](int upto) {
+    if (!out) return;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    for (int e = n_flushed + lane; e < upto; e += 64) {
+      if (e >= capacity) break;
+      const double tj = s_t[e - n_flushed];
+      const double* c = s_c + (size_t)s_seg[e - n_flushed] * (kD * kN);
+      double v[kD];
+#pragma unroll
+      for (int dd = 0; dd < kD; ++dd) {
+        double accv = c[dd * kN + kN - 1];
+#pragma unroll
+        for (int k = kN - 2; k >= 0; --k) accv = accv * tj + c[dd * kN + k];
+        v[dd] = accv;
+      }
+      v[3] = wrap_heading(v[3]);
+#pragma unroll
+      for (int dd = 0; dd < kD; ++dd) out[(size_t)e * kD + dd] = v[dd];
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+  };
   if (i < S) {
     acc -= s_T[i];
     double tin = 0.0 - acc;
     double Ti = s_T[i];
-    double* out = samples ? samples + (size_t)pr.p * capacity * kD : nullptr;
     while (true) {  // trajectory.cpp:131-150, one chunk per iteration
       if (!(acc < t_end)) break;
       bool past_end = false;
@@ -275,31 +311,47 @@ __global__ __launch_bounds__(64) void sample_kernel(BatchView b, const double* _
       // segment into several chunks, an overestimate adds idle additions
       const double room = (Ti - tin) / dt;
       const int last = __builtin_amdgcn_readfirstlane((room < 61.0) ? (int)room + 2 : 63);
-      // lane j adds dt j times; past its own count a lane adds +0.0, which leaves the value unchanged, so the
-      // loop body is two independent dependent-add chains and a select that does not sit on them
+      // lane j adds dt j times: in iteration r the lanes above r add.  EXEC starts as "lanes 1..63" and is shifted left by
+      // one lane per iteration, so an iteration is two additions (two independent dependent chains) and one scalar shift;
+      // as a lane compare and two selects per iteration the walk was three times as long
       double tj = tin, aj = acc;
-#pragma unroll 4
-      for (int r = 0; r < last; ++r) {
-        const double step = (lane > r) ? dt : 0.0;
-        tj += step;
-        aj += step;
+      {
+        unsigned long long saved_exec;
+        int counter;
+        const double dtv = dt;
+        // (iterations beyond `last` only touch lanes above `last`, which are not used: the count is rounded up to the unrolling)
+#define MRS_TG_WALK_STEP "v_add_f64 %[tj], %[tj], %[dt]\n\tv_add_f64 %[aj], %[aj], %[dt]\n\ts_lshl_b64 exec, exec, 1\n\t"
+        asm volatile(
+            "s_mov_b64 %[save], exec\n\t"
+            "s_add_u32 %[cnt], %[n], 7\n\t"
+            "s_lshr_b32 %[cnt], %[cnt], 3\n\t"
+            "s_cmp_eq_u32 %[cnt], 0\n\t"
+            "s_cbranch_scc1 .Lwalk_done_%=\n\t"
+            "s_mov_b64 exec, -2\n"
+            ".Lwalk_loop_%=:\n\t" MRS_TG_WALK_STEP MRS_TG_WALK_STEP MRS_TG_WALK_STEP MRS_TG_WALK_STEP MRS_TG_WALK_STEP
+                MRS_TG_WALK_STEP MRS_TG_WALK_STEP MRS_TG_WALK_STEP
+            "s_sub_u32 %[cnt], %[cnt], 1\n\t"
+            "s_cmp_lg_u32 %[cnt], 0\n\t"
+            "s_cbranch_scc1 .Lwalk_loop_%=\n"
+            ".Lwalk_done_%=:\n\t"
+            "s_mov_b64 exec, %[save]"
+            : [tj] "+v"(tj), [aj] "+v"(aj), [save] "=&s"(saved_exec), [cnt] "=&s"(counter)
+            : [dt] "v"(dtv), [n] "s"(last)
+            : "scc");
+#undef MRS_TG_WALK_STEP
       }
       const bool ok = (lane <= last) && (aj < t_end) && !(tj > Ti) && (n + lane <= capacity);
       const unsigned long long okmask = __ballot(ok);
       const int m = (~okmask == 0ull) ? 64 : __builtin_ctzll(~okmask);  // lanes [0, m) emit a sample
-      if (out && lane < m && n + lane < capacity) {
-        const double* c = s_c + __builtin_amdgcn_readfirstlane(i) * (kD * kN);
-        double v[kD];
-#pragma unroll
-        for (int dd = 0; dd < kD; ++dd) {
-          double accv = c[dd * kN + kN - 1];
-#pragma unroll
-          for (int k = kN - 2; k >= 0; --k) accv = accv * tj + c[dd * kN + k];
-          v[dd] = accv;
+      if (out) {
+        if (n + m - n_flushed > kSampleBuffer) {  // the chunk does not fit: evaluate what is parked first
+          flush(n);
+          n_flushed = n;
         }
-        v[3] = wrap_heading(v[3]);
-#pragma unroll
-        for (int dd = 0; dd < kD; ++dd) out[(size_t)(n + lane) * kD + dd] = v[dd];
+        if (lane < m) {
+          s_t[n - n_flushed + lane] = tj;
+          s_seg[n - n_flushed + lane] = (unsigned short)i;
+        }
       }
       n += m;
       if (m == last + 1) {  // every computed lane emitted: the chunk ran out before the walk stopped
@@ -314,6 +366,7 @@ __global__ __launch_bounds__(64) void sample_kernel(BatchView b, const double* _
       if (n > capacity) break;  // overflow: report capacity + 1
     }
   }
+  flush(n);
   MRS_TG_PHASE_MARK(2);
   if (lane == 0 && n_samples) n_samples[pr.p] = n;
 }
@@ -381,7 +434,7 @@ hipError_t launch_estimate_times(const BatchView& b, const double* wp, const dou
 hipError_t launch_sample(const BatchView& b, const double* coeffs, const double* seg_times, double dt, int capacity,
                          int32_t* n_samples, double* samples, hipStream_t stream) {
   if (b.n_paths == 0) return hipSuccess;
-  const size_t lds = sizeof(double) * (size_t)b.max_segments * (1 + kD * kN);
+  const size_t lds = sizeof(double) * ((size_t)b.max_segments * (1 + kD * kN) + kSampleBuffer) + sizeof(unsigned short) * kSampleBuffer;
   if (lds > 160 * 1024) return hipErrorInvalidValue;
   if (lds > 64 * 1024) {
     hipError_t e = hipFuncSetAttribute((const void*)sample_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);

@@ -508,8 +508,10 @@ hipError_t launch_solve_rows(const BatchView& b, int d, const uint8_t* mask, con
   if (const char* e = std::getenv("MRS_TG_ROWS_PPW")) ppw = std::atoi(e) == 1 ? 1 : 2;
   if (per_path * 2 > kRowsLdsBudget) ppw = 1;
   const size_t lds_bytes = per_path * (size_t)ppw;
-  hipError_t e = hipFuncSetAttribute((const void*)solve_rows_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kRowsLdsBudget);
-  if (e != hipSuccess) return e;
+  if (lds_bytes > 64 * 1024) {  // beyond the default limit of a launch: raise it (a driver call, so only when needed)
+    hipError_t e = hipFuncSetAttribute((const void*)solve_rows_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kRowsLdsBudget);
+    if (e != hipSuccess) return e;
+  }
   const unsigned grid = (unsigned)((b.n_paths + ppw - 1) / ppw);
   MRS_TG_LAUNCH_TIMED(solve_rows_kernel, dim3(grid), dim3(64), lds_bytes, stream, b, d, ppw, b.max_segments, mask, vals,
                      seg_times, coeffs, status, cost, status_in);
