@@ -23,6 +23,7 @@
 #include <cmath>
 #include <cstdint>
 #include <limits>
+#include <chrono>
 #include <map>
 #include <optional>
 #include <stdexcept>
@@ -47,6 +48,7 @@ struct Path {  // mrs_msgs::Path, the fields read at src/...cpp:2061-2095
   double override_max_acceleration_horizontal = 0, override_max_acceleration_vertical = 0;
   double override_max_jerk_horizontal = 0, override_max_jerk_vertical = 0;
   double max_deviation_from_path = 0;
+  double max_execution_time = 0;  // > 0: this request's budget (:1862-1866); else the max_time parameter
   bool dont_prepend_current_state = false;
 };
 
@@ -82,6 +84,7 @@ struct CurrentState {  // the mrs_msgs::TrackerCommand fields used as the initia
 struct ServiceParams {  // config/{public,private}/trajectory_generation.yaml
   int n_attempts = 3;                    // n_attempts
   bool fallback_sampling_enabled = true; // fallback_sampling/enabled
+  double max_time = 0.5;                 // max_time [s] (config/public/trajectory_generation.yaml:4); <= 0: no deadline
   int sample_capacity = 8192;            // capacity of one trajectory in samples (host buffer size, not a reference parameter)
   mrs_tg_policy_options policy{};        // everything optimize() / findTrajectory() read
   ServiceParams() {
@@ -156,9 +159,11 @@ public:
       }
       job.limits = limits_for(path, job.has_initial_state ? &job.initial_state : nullptr);
       job.max_deviation = path.max_deviation_from_path > 0 ? path.max_deviation_from_path : params_.policy.max_deviation;  // :2085-2089
+      job.max_execution_time = path.max_execution_time > 0 ? path.max_execution_time : params_.max_time;                   // :1862-1872
       jobs.push_back(std::move(job));
     }
 
+    const auto t_start = std::chrono::steady_clock::now();  // start_time_total_ (:2008)
     std::vector<size_t> pending(jobs.size());
     for (size_t j = 0; j < jobs.size(); ++j) pending[j] = j;
     const int attempts = params_.n_attempts > 0 ? params_.n_attempts : 1;
@@ -169,7 +174,15 @@ public:
       for (size_t j : pending) by_deviation[jobs[j].max_deviation].push_back(j);
       std::vector<size_t> still;
       for (auto& [max_deviation, group] : by_deviation) {
-        solve_group(jobs, group, max_deviation, fallback);
+        // the requests of a GPU call share its clock: the tightest budget of the group, minus what the call has used
+        double budget = 0;
+        for (size_t j : group)
+          if (jobs[j].max_execution_time > 0 && (budget <= 0 || jobs[j].max_execution_time < budget)) budget = jobs[j].max_execution_time;
+        if (budget > 0) {
+          budget -= std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count();
+          if (budget <= 0) budget = 1e-9;  // already late: the policy layer gives these requests up (overtime(), :1730-1743)
+        }
+        solve_group(jobs, group, max_deviation, fallback, budget);
         for (size_t j : group)
           if (!jobs[j].success) still.push_back(j);
       }
@@ -216,6 +229,7 @@ private:
     mrs_tg_initial_state initial_state{};
     std::array<double, 9> limits{};
     double max_deviation = 0, max_deviation_out = 0;
+    double max_execution_time = 0;  // this request's budget [s], <= 0: none
     bool success = false;
     std::string message;
     std::vector<Reference> samples;
@@ -262,7 +276,7 @@ private:
     return {vh, vv, c.heading_speed, ah, av, c.heading_acceleration, jh, jv, c.heading_jerk};
   }
 
-  void solve_group(std::vector<Job>& jobs, const std::vector<size_t>& group, double max_deviation, bool fallback) {
+  void solve_group(std::vector<Job>& jobs, const std::vector<size_t>& group, double max_deviation, bool fallback, double budget_s) {
     const int32_t P = static_cast<int32_t>(group.size());
     std::vector<int32_t> off(P + 1, 0);
     std::vector<mrs_tg_waypoint> wps;
@@ -281,6 +295,7 @@ private:
     mrs_tg_policy_options pol = params_.policy;
     pol.max_deviation = max_deviation;
     pol.fallback_sampling = fallback ? 1 : pol.fallback_sampling;
+    pol.max_execution_time_s = budget_s;
     const int cap = params_.sample_capacity;
     std::vector<int32_t> success(P), n_samples(P);
     std::vector<double> samples(static_cast<size_t>(P) * cap * 4), max_dev(P);

@@ -323,9 +323,7 @@ int mrs_tg_optimize_paths(mrs_tg_ctx* ctx, int32_t n_paths, const int32_t* wp_of
   const double dt = o.solver.sampling_dt;
   if (!(dt > 0)) return mrs_tg::report_error(ctx, MRS_TG_ERR_INVALID_ARG, "the policy layer needs sampling_dt > 0 (got %g)", dt);
   const auto t_begin = std::chrono::steady_clock::now();
-  auto time_left = [&]() {
-    return o.max_execution_time_s - std::chrono::duration<double>(std::chrono::steady_clock::now() - t_begin).count();
-  };
+  auto elapsed = [&]() { return std::chrono::duration<double>(std::chrono::steady_clock::now() - t_begin).count(); };
   std::vector<PathState> st((size_t)n_paths);
   for (int p = 0; p < n_paths; ++p) {
     preprocess(waypoints + wp_offsets[p], wp_offsets[p + 1] - wp_offsets[p], o, st[p]);
@@ -357,10 +355,11 @@ int mrs_tg_optimize_paths(mrs_tg_ctx* ctx, int32_t n_paths, const int32_t* wp_of
       if (active.empty()) break;
     }
     // overtime() (:1085, 1156, 1171, 1516-1522): out of time, every request that is still being worked on is given up
-    double budget_left = 0.0;
+    double budget_left = 0.0;  // timeLeft() :1749-1761
     if (o.max_execution_time_s > 0) {
-      budget_left = time_left();
-      if (budget_left <= 0) {
+      const double spent = elapsed();
+      budget_left = spent >= o.max_execution_time_s ? 0.0 : o.max_execution_time_s - spent;
+      if (spent > 0.95 * o.max_execution_time_s - 0.01) {  // overtime() :1730-1743 (OVERTIME_SAFETY_FACTOR, _OFFSET)
         for (int p : active) {
           st[p].done = true;
           st[p].ok = false;
