@@ -461,6 +461,7 @@ int mrs_tg_plan_solve(mrs_tg_plan* plan, const double* wp, const uint8_t* mask, 
   HIP_TRY(ctx, use_device(ctx->device));
   const mrs_tg::BatchView& b = plan->view;
   const int d = opt->derivative_to_optimize;
+  bool sampled = false;  // the sampling rode on the final solve's launch
   if (opt->estimate_times) HIP_TRY(ctx, mrs_tg::launch_estimate_times(b, wp, limits, seg_times, ctx->stream));
 
   if (opt->time_alloc_method != MRS_TG_TIME_ALLOC_NONE && opt->time_alloc_method != MRS_TG_TIME_ALLOC_MELLINGER) {
@@ -488,8 +489,8 @@ int mrs_tg_plan_solve(mrs_tg_plan* plan, const double* wp, const uint8_t* mask, 
     prm.x_abs = opt->x_abs;
     prm.time_budget_ticks = opt->max_time_s > 0 ? budget_ticks(ctx, opt->max_time_s) : 0;
     ProfileScope ps(ctx, 2);
-    HIP_TRY(ctx, mrs_tg::launch_nonlinear(plan->nl, b, prm, mask, vals, limits, seg_times, coeffs, status, cost,
-                                          ctx->stream));
+    HIP_TRY(ctx, mrs_tg::launch_nonlinear(plan->nl, b, prm, mask, vals, limits, seg_times, coeffs, status, cost, ctx->stream,
+                                          opt->sampling_dt, opt->sample_capacity, n_samples, samples, &sampled));
   } else {
     const bool fused = (opt->flags & MRS_TG_FLAG_MATERIALIZED_BLOCKS) == 0;  // the default since ABI 2
     if ((rc = ensure_ws(plan, mrs_tg::linear_workspace_doubles(b))) != MRS_TG_OK) return rc;
@@ -499,10 +500,20 @@ int mrs_tg_plan_solve(mrs_tg_plan* plan, const double* wp, const uint8_t* mask, 
       HIP_TRY(ctx, mrs_tg::launch_assemble(b, d, seg_times, plan->d_H, plan->d_Ainv, ctx->stream));
     }
     ProfileScope ps(ctx, 1);
-    HIP_TRY(ctx, mrs_tg::launch_solve_linear(b, d, fused, mask, vals, seg_times, plan->d_H, plan->d_Ainv, plan->d_ws,
-                                             coeffs, status, cost, nullptr, ctx->stream));
+    if (fused && opt->sampling_dt > 0 && mrs_tg::rows_tail_sampling_pays(b)) {  // solve and sample in one launch
+      mrs_tg::RowsTail tail;
+      tail.sampling_dt = opt->sampling_dt;
+      tail.sample_capacity = opt->sample_capacity;
+      tail.n_samples = n_samples;
+      tail.samples = samples;
+      HIP_TRY(ctx, mrs_tg::launch_solve_rows(b, d, mask, vals, seg_times, coeffs, status, cost, nullptr, ctx->stream, tail));
+      sampled = true;
+    } else {
+      HIP_TRY(ctx, mrs_tg::launch_solve_linear(b, d, fused, mask, vals, seg_times, plan->d_H, plan->d_Ainv, plan->d_ws,
+                                               coeffs, status, cost, nullptr, ctx->stream));
+    }
   }
-  if (opt->sampling_dt > 0)
+  if (opt->sampling_dt > 0 && !sampled)
     HIP_TRY(ctx, mrs_tg::launch_sample(b, coeffs, seg_times, opt->sampling_dt, opt->sample_capacity, n_samples, samples,
                                        ctx->stream));
   return MRS_TG_OK;

@@ -386,6 +386,19 @@ __device__ __forceinline__ double cost_quadratic_form_d(int d, const double (&cb
   }
 }
 
+// violation scaling of one segment: max(1, v, sqrt(a), cbrt(j))  (trajectory.cpp:625-642)
+__device__ __forceinline__ double violation_scaling(const double* __restrict__ mx, const double* __restrict__ lim) {
+  double viol[3];
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    const double h = mx[k * 3 + 0] / lim[k * 3 + 0];
+    const double v = mx[k * 3 + 1] / lim[k * 3 + 1];
+    const double y = mx[k * 3 + 2] / lim[k * 3 + 2];
+    viol[k] = fmax(fmax(h, v), y);
+  }
+  return fmax(1.0, fmax(fmax(viol[0], sqrt(viol[1])), cbrt(viol[2])));
+}
+
 // ---------------------------------------------------------------------------------------------
 // batch addressing shared by all kernels
 

@@ -55,9 +55,30 @@ hipError_t launch_solve_tile(const BatchView& b, int d, bool fused, const uint8_
                              const double* seg_times, const double* H, const double* Ainv, double* coeffs,
                              int32_t* status, double* cost, const int32_t* status_in, hipStream_t stream);
 
+// What the rows kernel can do around its solve for the same path, in the same launch:
+//   before: the feasibility scaling of the segment times (scaleSegmentTimesWithViolation's T_i <- s_i T_i from the
+//           per-segment maxima, written back to seg_times) -- the last stage before the final solve of the Mellinger pipeline;
+//   after:  the sampling of the solved trajectory (sampleWholeTrajectory).
+// All-null / zero = the plain solve.
+struct RowsTail {
+  const double* maxima = nullptr;        // [n_segments][9]; with limits and opt_status: scale the times first
+  const double* limits = nullptr;        // [n_paths][9]
+  const int32_t* opt_status = nullptr;   // paths whose search was refused (-2) keep their times
+  double* seg_times_out = nullptr;       // the (scaled) times are written here (the caller's seg_times)
+  double sampling_dt = 0.0;              // > 0: sample
+  int sample_capacity = 0;
+  int32_t* n_samples = nullptr;
+  double* samples = nullptr;
+};
+
 // one lane per unknown, no materialised blocks (mrs_tg_rows.hip): the fused linear solve of every path that fits its LDS record
-bool rows_kernel_applies(const BatchView& b);
+bool rows_kernel_applies(const BatchView& b, bool with_sampling = false);
+// sampling on the solve's launch pays while a wavefront holds one path (small batches: one launch and one staging pass
+// less, 1024 x 10 nonlinear 138 -> 132 us); with two paths per wavefront the walks of the two run one after the other and
+// the separate sampler (one wavefront per path) is faster (8192 x 10: 483 vs 548 us)
+bool rows_tail_sampling_pays(const BatchView& b);
 hipError_t launch_solve_rows(const BatchView& b, int d, const uint8_t* mask, const double* vals, const double* seg_times,
-                             double* coeffs, int32_t* status, double* cost, const int32_t* status_in, hipStream_t stream);
+                             double* coeffs, int32_t* status, double* cost, const int32_t* status_in, hipStream_t stream,
+                             const RowsTail& tail = RowsTail());
 
 }  // namespace mrs_tg

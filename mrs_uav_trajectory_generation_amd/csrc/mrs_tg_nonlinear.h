@@ -57,9 +57,13 @@ struct NonlinearPlan {
 int nonlinear_plan_build(NonlinearPlan& nl, const std::vector<int32_t>& seg_offsets, const std::vector<int32_t>& order);
 void nonlinear_plan_free(NonlinearPlan& nl);
 
+// sampling_dt > 0: the caller wants the result sampled; when the final solve runs on the rows kernel the sampling rides
+// on that launch (*sampled_out = true) and the caller must not launch the sampler again
 hipError_t launch_nonlinear(NonlinearPlan& nl, const BatchView& b, const NonlinearParams& prm, const uint8_t* mask,
                             const double* vals, const double* limits, double* seg_times, double* coeffs,
-                            int32_t* status, double* cost, hipStream_t stream);
+                            int32_t* status, double* cost, hipStream_t stream, double sampling_dt = 0.0,
+                            int sample_capacity = 0, int32_t* n_samples = nullptr, double* samples = nullptr,
+                            bool* sampled_out = nullptr);
 hipError_t launch_dfo(NonlinearPlan& nl, const BatchView& b, const DfoParams& prm, const uint8_t* mask, const double* vals,
                       const double* limits, double* seg_times, double* coeffs, int32_t* status, double* cost,
                       hipStream_t stream);

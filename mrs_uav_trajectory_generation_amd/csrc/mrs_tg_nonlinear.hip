@@ -737,19 +737,6 @@ __device__ __forceinline__ double segment_maximum(const double* __restrict__ c, 
   return sqrt(m2) * scale;
 }
 
-// violation scaling of one segment: max(1, v, sqrt(a), cbrt(j))  (trajectory.cpp:625-642)
-__device__ __forceinline__ double violation_scaling(const double* __restrict__ mx, const double* __restrict__ lim) {
-  double viol[3];
-#pragma unroll
-  for (int k = 0; k < 3; ++k) {
-    const double h = mx[k * 3 + 0] / lim[k * 3 + 0];
-    const double v = mx[k * 3 + 1] / lim[k * 3 + 1];
-    const double y = mx[k * 3 + 2] / lim[k * 3 + 2];
-    viol[k] = fmax(fmax(h, v), y);
-  }
-  return fmax(1.0, fmax(fmax(viol[0], sqrt(viol[1])), cbrt(viol[2])));
-}
-
 // ---------------------------------------------------------------------------------------------
 // group helpers (G lanes, G a power of two <= 64, groups aligned to G)
 
@@ -1980,7 +1967,9 @@ static hipError_t ensure_buffers(NonlinearPlan& nl, const BatchView& b) {
 
 hipError_t launch_nonlinear(NonlinearPlan& nl, const BatchView& b, const NonlinearParams& prm, const uint8_t* mask,
                             const double* vals, const double* limits, double* seg_times, double* coeffs,
-                            int32_t* status, double* cost, hipStream_t stream) {
+                            int32_t* status, double* cost, hipStream_t stream, double sampling_dt, int sample_capacity,
+                            int32_t* n_samples, double* samples, bool* sampled_out) {
+  if (sampled_out) *sampled_out = false;
   if (b.n_paths == 0) return hipSuccess;
   hipError_t e = ensure_buffers(nl, b);
   if (e != hipSuccess) return e;
@@ -2038,6 +2027,23 @@ hipError_t launch_nonlinear(NonlinearPlan& nl, const BatchView& b, const Nonline
   hipLaunchKernelGGL(segment_maxima9_kernel, dim3(cdiv_u(b.n_segments, 64), 9), dim3(64), 0, stream, b.n_segments, coeffs,
                      seg_times, nl.d_maxima);
   if ((e = hipGetLastError()) != hipSuccess) return e;
+  // 3b + 4 in one launch where the rows kernel applies: its staging pass scales the times of its own path, its tail samples
+  const bool want_samples = sampling_dt > 0.0 && n_samples != nullptr && rows_tail_sampling_pays(b);
+  if (rows_kernel_applies(b, want_samples)) {
+    RowsTail tail;
+    tail.maxima = nl.d_maxima;
+    tail.limits = limits;
+    tail.opt_status = nl.d_opt_status;
+    tail.seg_times_out = seg_times;
+    if (want_samples) {
+      tail.sampling_dt = sampling_dt;
+      tail.sample_capacity = sample_capacity;
+      tail.n_samples = n_samples;
+      tail.samples = samples;
+      if (sampled_out) *sampled_out = true;
+    }
+    return launch_solve_rows(b, prm.derivative, mask, vals, seg_times, coeffs, status, cost, nl.d_opt_status, stream, tail);
+  }
   hipLaunchKernelGGL(apply_scaling_kernel, dim3(cdiv_u(b.n_segments, 256)), dim3(256), 0, stream, b, nl.d_maxima, limits,
                      nl.d_opt_status, seg_times);
   if ((e = hipGetLastError()) != hipSuccess) return e;

@@ -26,6 +26,7 @@
 #include "mrs_tg_device.hpp"
 #include "mrs_tg_launch.h"
 #include "mrs_tg_rowelim.hpp"
+#include "mrs_tg_sampling.hpp"
 
 namespace mrs_tg {
 
@@ -306,9 +307,9 @@ struct RowSolve : RowCore {
 
 __global__ __launch_bounds__(64) void solve_rows_kernel(BatchView b, int d, int ppw, int Smax,
                                                         const uint8_t* __restrict__ mask, const double* __restrict__ vals,
-                                                        const double* __restrict__ seg_times, double* __restrict__ coeffs,
+                                                        const double* seg_times /* may be tail.seg_times_out */, double* __restrict__ coeffs,
                                                         int32_t* __restrict__ status, double* __restrict__ cost,
-                                                        const int32_t* __restrict__ status_in) {
+                                                        const int32_t* __restrict__ status_in, RowsTail tail) {
   extern __shared__ double lds[];
   const int lane = threadIdx.x;
   const int q0 = blockIdx.x * ppw;
@@ -363,8 +364,13 @@ __global__ __launch_bounds__(64) void solve_rows_kernel(BatchView b, int d, int 
       for (int e = 0; e < kNB * kD; ++e) r[kRVtxX + e] = 0.0;  // stays for a fully constrained end vertex, which nobody solves
       pos_ok_lane = pos_ok_lane && pos_fixed;
     }
+    const int p_t = __builtin_amdgcn_readlane(pr.p, tt * 16);
     for (int i = lane; i < S_t; i += 64) {
-      const double T = seg_times[s0_t + i];
+      double T = seg_times[s0_t + i];
+      if (tail.maxima) {  // feasibility scaling of this segment (trajectory.cpp:625-657), then the solve at the scaled times
+        if (tail.opt_status[p_t] != -2) T *= violation_scaling(tail.maxima + (size_t)(s0_t + i) * 9, tail.limits + (size_t)p_t * 9);
+        tail.seg_times_out[s0_t + i] = T;
+      }
       const double* ps = vals + (size_t)(v0_t + i) * kHalf * kD;  // constrained position of vertex i, then of i + 1
       double* r = sb + (size_t)i * kRSegRec;
       // T^(2 - 2d) as the assembly kernel forms it: T / (T^d)^2 ... times T
@@ -465,6 +471,11 @@ __global__ __launch_bounds__(64) void solve_rows_kernel(BatchView b, int d, int 
     double* out = coeffs + ((size_t)(s0_t + i) * kD + dim) * kN;
 #pragma unroll
     for (int kk = 0; kk < kN; ++kk) out[kk] = c[kk];
+    if (tail.sampling_dt > 0.0 && tail.samples) {  // the sampler of this launch reads them from LDS
+      double* sc = lds + (size_t)ppw * PS + (size_t)tt * ((size_t)Smax * (kD * kN + 1)) + Smax + (size_t)r * kN;
+#pragma unroll
+      for (int kk = 0; kk < kN; ++kk) sc[kk] = c[kk];
+    }
     const double quad_form = cost_quadratic_form_d(d, cb);
     // T^(1 - 2d) = q[0] / T
     pcb[r] = quad_form * (sb[(size_t)i * kRSegRec + kRSegPow] * ti);
@@ -486,6 +497,24 @@ __global__ __launch_bounds__(64) void solve_rows_kernel(BatchView b, int d, int 
     }
   }
   MRS_TG_PHASE_MARK(5);
+
+  // ---- sample (sampleWholeTrajectory): the wavefront walks its paths one after the other
+  if (tail.sampling_dt > 0.0) {
+    double* samp = lds + (size_t)ppw * PS;                       // per path: [Smax] times | [Smax][4][10] coefficients
+    double* s_t = samp + (size_t)ppw * ((size_t)Smax * (kD * kN + 1));   // sample buffer of the wavefront
+    unsigned short* s_seg = reinterpret_cast<unsigned short*>(s_t + kSampleBuffer);
+    for (int tt = 0; tt < n_here; ++tt) {
+      const int S_t = __builtin_amdgcn_readlane(pr.S, tt * 16), p_t = __builtin_amdgcn_readlane(pr.p, tt * 16);
+      double* sT = samp + (size_t)tt * ((size_t)Smax * (kD * kN + 1));
+      const double* sb = lds + (size_t)tt * PS + (size_t)(Smax + 1) * kRVtxRec;
+      for (int i = lane; i < S_t; i += 64) sT[i] = sb[(size_t)i * kRSegRec + kRSegT];
+      wave_lds_sync();
+      double* out = tail.samples ? tail.samples + (size_t)p_t * tail.sample_capacity * kD : nullptr;
+      const int n = sample_path_walk(sT, sT + Smax, s_t, s_seg, S_t, tail.sampling_dt, tail.sample_capacity, out);
+      if (lane == 0 && tail.n_samples) tail.n_samples[p_t] = n;
+      wave_lds_sync();
+    }
+  }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -493,28 +522,39 @@ __global__ __launch_bounds__(64) void solve_rows_kernel(BatchView b, int d, int 
 
 static constexpr size_t kRowsLdsBudget = 144 * 1024;
 
-bool rows_kernel_applies(const BatchView& b) {
+// LDS of one wavefront: the records of its paths, and for a launch that samples the times and coefficients of those paths
+// plus one sample buffer
+static size_t rows_lds_bytes(int Smax, int ppw, bool sampling) {
+  size_t doubles = (size_t)ppw * rows_path_doubles(Smax);
+  if (sampling) doubles += (size_t)ppw * (size_t)Smax * (kD * kN + 1) + kSampleBuffer + kSampleBuffer / 4 + 2;
+  return doubles * sizeof(double);
+}
+
+bool rows_kernel_applies(const BatchView& b, bool with_sampling) {
   if (b.n_paths == 0) return false;
   if (const char* e = std::getenv("MRS_TG_ROWS_KERNEL"))
     if (std::atoi(e) == 0) return false;  // tuning / test knob: fall back to the tile and lane kernels
-  return (size_t)rows_path_doubles(b.max_segments) * sizeof(double) <= kRowsLdsBudget;
+  return rows_lds_bytes(b.max_segments, 1, with_sampling) <= kRowsLdsBudget;
 }
 
+bool rows_tail_sampling_pays(const BatchView& b) { return b.n_paths <= 2048 && rows_kernel_applies(b, true); }
+
 hipError_t launch_solve_rows(const BatchView& b, int d, const uint8_t* mask, const double* vals, const double* seg_times,
-                             double* coeffs, int32_t* status, double* cost, const int32_t* status_in, hipStream_t stream) {
-  const size_t per_path = (size_t)rows_path_doubles(b.max_segments) * sizeof(double);
+                             double* coeffs, int32_t* status, double* cost, const int32_t* status_in, hipStream_t stream,
+                             const RowsTail& tail) {
+  const bool sampling = tail.sampling_dt > 0.0;
   // one path per wavefront while that still leaves SIMDs idle (256 CUs x 4); two paths per wavefront otherwise
   int ppw = (b.n_paths <= 2048) ? 1 : 2;
   if (const char* e = std::getenv("MRS_TG_ROWS_PPW")) ppw = std::atoi(e) == 1 ? 1 : 2;
-  if (per_path * 2 > kRowsLdsBudget) ppw = 1;
-  const size_t lds_bytes = per_path * (size_t)ppw;
+  if (rows_lds_bytes(b.max_segments, 2, sampling) > kRowsLdsBudget) ppw = 1;
+  const size_t lds_bytes = rows_lds_bytes(b.max_segments, ppw, sampling);
   if (lds_bytes > 64 * 1024) {  // beyond the default limit of a launch: raise it (a driver call, so only when needed)
     hipError_t e = hipFuncSetAttribute((const void*)solve_rows_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kRowsLdsBudget);
     if (e != hipSuccess) return e;
   }
   const unsigned grid = (unsigned)((b.n_paths + ppw - 1) / ppw);
   MRS_TG_LAUNCH_TIMED(solve_rows_kernel, dim3(grid), dim3(64), lds_bytes, stream, b, d, ppw, b.max_segments, mask, vals,
-                     seg_times, coeffs, status, cost, status_in);
+                      seg_times, coeffs, status, cost, status_in, tail);
   return hipGetLastError();
 }
 

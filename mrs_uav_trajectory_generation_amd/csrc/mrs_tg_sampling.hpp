@@ -1,0 +1,154 @@
+// mrs_tg_sampling.hpp -- the sampler's walk over one path whose segment times and coefficients sit in LDS (shared by
+// sample_kernel and by the tail of solve_rows_kernel).
+//
+// Trajectory::evaluateRange's accumulate-and-carry walk
+// (/root/reference/src/eth_trajectory_generation/trajectory.cpp:93-151), positions + wrapped heading (the only fields the
+// nodelet reads, src/mrs_trajectory_generation.cpp:1582-1599); see the comment in mrs_tg_kernels.hip.
+#pragma once
+#include "mrs_tg_device.hpp"
+
+namespace mrs_tg {
+
+__device__ __forceinline__ double wrap_heading(double y) {
+  const double two_pi_hi = 6.283185307179586232e+00, two_pi_lo = 2.449293598294706414e-16;
+  const double kf = rint(y * 1.591549430918953456e-01);
+  return fma(-kf, two_pi_lo, fma(-kf, two_pi_hi, y));
+}
+
+__device__ __forceinline__ double lane_value(double v, int src) {
+  const int lo = __builtin_amdgcn_readlane(__double2loint(v), src), hi = __builtin_amdgcn_readlane(__double2hiint(v), src);
+  return __hiloint2double(hi, lo);
+}
+
+// The walk and the evaluation are separate passes.  The walk produces, chunk by chunk, the time in its segment of every
+// sample (lane j of a chunk holds the j-th one) and parks it with its segment index in an LDS buffer; nothing else sits
+// on the walk's dependent chain.  When the buffer is full (or the walk has ended) all buffered samples are evaluated at
+// once, one lane per sample whatever its segment -- with the evaluation inside the chunk loop (one segment per chunk,
+// ~30 of 64 lanes busy, 40 broadcast LDS reads and the Horner chains in front of the next chunk's additions) the kernel
+// took 25 us for 1024 paths of ~300 samples; 1024 x 10 nonlinear 147 -> us.
+constexpr int kSampleBuffer = 1024;  // samples parked per flush (8 KB of times + 2 KB of segment indices)
+
+// One wavefront (all 64 lanes, wave-uniform control flow).  s_T [S] segment times, s_c [S][4][10] coefficients, s_t / s_seg
+// the sample buffer (kSampleBuffer entries each); out: the path's [capacity][4] samples or nullptr (count only).
+// Returns the number of samples (capacity + 1 = "more than fit").
+__device__ __forceinline__ int sample_path_walk(const double* s_T, const double* s_c, double* s_t, unsigned short* s_seg, int S,
+                                                double dt, int capacity, double* out) {
+  const int lane = threadIdx.x & 63;
+  // every lane carries the same walk state (i, Ti, tin, acc, n): t_end and the start segment as the reference
+  // computes them (trajectory.cpp:100-120, t_start = 0)
+  double t_end = 0.0;
+  for (int i = 0; i < S; ++i) t_end += s_T[i];
+  double acc = 0.0;
+  int i = 0;
+  for (i = 0; i < S; ++i) {
+    acc += s_T[i];
+    if (acc > 0.0) break;
+  }
+  int n = 0;
+  int n_flushed = 0;  // samples [n_flushed, n) are parked in the buffer
+  auto flush = [&](int upto) {
+    if (!out) return;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    for (int e = n_flushed + lane; e < upto; e += 64) {
+      if (e >= capacity) break;
+      const double tj = s_t[e - n_flushed];
+      const double* c = s_c + (size_t)s_seg[e - n_flushed] * (kD * kN);
+      double v[kD];
+#pragma unroll
+      for (int dd = 0; dd < kD; ++dd) {
+        double accv = c[dd * kN + kN - 1];
+#pragma unroll
+        for (int k = kN - 2; k >= 0; --k) accv = accv * tj + c[dd * kN + k];
+        v[dd] = accv;
+      }
+      v[3] = wrap_heading(v[3]);
+#pragma unroll
+      for (int dd = 0; dd < kD; ++dd) out[(size_t)e * kD + dd] = v[dd];
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+  };
+  if (i < S) {
+    acc -= s_T[i];
+    double tin = 0.0 - acc;
+    double Ti = s_T[i];
+    while (true) {  // trajectory.cpp:131-150, one chunk per iteration
+      if (!(acc < t_end)) break;
+      bool past_end = false;
+      while (tin > Ti) {  // carry the remainder into the next segment(s)
+        tin = tin - Ti;
+        ++i;
+        if (i >= S) {
+          past_end = true;
+          break;
+        }
+        Ti = s_T[i];
+      }
+      if (past_end) break;
+      // lanes 0..last are computed in this chunk; `last` only has to be non-negative: an underestimate splits the
+      // segment into several chunks, an overestimate adds idle additions
+      const double room = (Ti - tin) / dt;
+      const int last = __builtin_amdgcn_readfirstlane((room < 61.0) ? (int)room + 2 : 63);
+      // lane j adds dt j times: in iteration r the lanes above r add.  EXEC starts as "lanes 1..63" and is shifted left by
+      // one lane per iteration, so an iteration is two additions (two independent dependent chains) and one scalar shift;
+      // as a lane compare and two selects per iteration the walk was three times as long
+      double tj = tin, aj = acc;
+      {
+        unsigned long long saved_exec;
+        int counter;
+        const double dtv = dt;
+        // (iterations beyond `last` only touch lanes above `last`, which are not used: the count is rounded up to the unrolling)
+#define MRS_TG_WALK_STEP "v_add_f64 %[tj], %[tj], %[dt]\n\tv_add_f64 %[aj], %[aj], %[dt]\n\ts_lshl_b64 exec, exec, 1\n\t"
+        asm volatile(
+            "s_mov_b64 %[save], exec\n\t"
+            "s_add_u32 %[cnt], %[n], 7\n\t"
+            "s_lshr_b32 %[cnt], %[cnt], 3\n\t"
+            "s_cmp_eq_u32 %[cnt], 0\n\t"
+            "s_cbranch_scc1 .Lwalk_done_%=\n\t"
+            "s_mov_b64 exec, -2\n"
+            ".Lwalk_loop_%=:\n\t" MRS_TG_WALK_STEP MRS_TG_WALK_STEP MRS_TG_WALK_STEP MRS_TG_WALK_STEP MRS_TG_WALK_STEP
+                MRS_TG_WALK_STEP MRS_TG_WALK_STEP MRS_TG_WALK_STEP
+            "s_sub_u32 %[cnt], %[cnt], 1\n\t"
+            "s_cmp_lg_u32 %[cnt], 0\n\t"
+            "s_cbranch_scc1 .Lwalk_loop_%=\n"
+            ".Lwalk_done_%=:\n\t"
+            "s_mov_b64 exec, %[save]"
+            : [tj] "+v"(tj), [aj] "+v"(aj), [save] "=&s"(saved_exec), [cnt] "=&s"(counter)
+            : [dt] "v"(dtv), [n] "s"(last)
+            : "scc");
+#undef MRS_TG_WALK_STEP
+      }
+      const bool ok = (lane <= last) && (aj < t_end) && !(tj > Ti) && (n + lane <= capacity);
+      const unsigned long long okmask = __ballot(ok);
+      const int m = (~okmask == 0ull) ? 64 : __builtin_ctzll(~okmask);  // lanes [0, m) emit a sample
+      if (out) {
+        if (n + m - n_flushed > kSampleBuffer) {  // the chunk does not fit: evaluate what is parked first
+          flush(n);
+          n_flushed = n;
+        }
+        if (lane < m) {
+          s_t[n - n_flushed + lane] = tj;
+          s_seg[n - n_flushed + lane] = (unsigned short)i;
+        }
+      }
+      n += m;
+      if (m == last + 1) {  // every computed lane emitted: the chunk ran out before the walk stopped
+        tin = lane_value(tj, last) + dt;
+        acc = lane_value(aj, last) + dt;
+        if (n > capacity) break;
+        continue;
+      }
+      // lane m is the first that did not emit: its values are the walk's state at the stop
+      tin = lane_value(tj, m);
+      acc = lane_value(aj, m);
+      if (n > capacity) break;  // overflow: report capacity + 1
+    }
+  }
+  flush(n);
+  return n;
+}
+
+}  // namespace mrs_tg
