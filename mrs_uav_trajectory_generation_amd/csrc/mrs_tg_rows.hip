@@ -305,6 +305,9 @@ struct RowSolve : RowCore {
   }
 };
 
+// TAIL: the launch scales the segment times first and / or samples afterwards (RowsTail); the plain solve is its own
+// instantiation, which the tail's code would otherwise cost 0.4 us at 1024 x 10
+template <bool TAIL>
 __global__ __launch_bounds__(64) void solve_rows_kernel(BatchView b, int d, int ppw, int Smax,
                                                         const uint8_t* __restrict__ mask, const double* __restrict__ vals,
                                                         const double* seg_times /* may be tail.seg_times_out */, double* __restrict__ coeffs,
@@ -367,7 +370,7 @@ __global__ __launch_bounds__(64) void solve_rows_kernel(BatchView b, int d, int 
     const int p_t = __builtin_amdgcn_readlane(pr.p, tt * 16);
     for (int i = lane; i < S_t; i += 64) {
       double T = seg_times[s0_t + i];
-      if (tail.maxima) {  // feasibility scaling of this segment (trajectory.cpp:625-657), then the solve at the scaled times
+      if (TAIL && tail.maxima) {  // feasibility scaling of this segment (trajectory.cpp:625-657), then the solve at the scaled times
         if (tail.opt_status[p_t] != -2) T *= violation_scaling(tail.maxima + (size_t)(s0_t + i) * 9, tail.limits + (size_t)p_t * 9);
         tail.seg_times_out[s0_t + i] = T;
       }
@@ -471,7 +474,7 @@ __global__ __launch_bounds__(64) void solve_rows_kernel(BatchView b, int d, int 
     double* out = coeffs + ((size_t)(s0_t + i) * kD + dim) * kN;
 #pragma unroll
     for (int kk = 0; kk < kN; ++kk) out[kk] = c[kk];
-    if (tail.sampling_dt > 0.0 && tail.samples) {  // the sampler of this launch reads them from LDS
+    if (TAIL && tail.sampling_dt > 0.0 && tail.samples) {  // the sampler of this launch reads them from LDS
       double* sc = lds + (size_t)ppw * PS + (size_t)tt * ((size_t)Smax * (kD * kN + 1)) + Smax + (size_t)r * kN;
 #pragma unroll
       for (int kk = 0; kk < kN; ++kk) sc[kk] = c[kk];
@@ -499,7 +502,7 @@ __global__ __launch_bounds__(64) void solve_rows_kernel(BatchView b, int d, int 
   MRS_TG_PHASE_MARK(5);
 
   // ---- sample (sampleWholeTrajectory): the wavefront walks its paths one after the other
-  if (tail.sampling_dt > 0.0) {
+  if (TAIL && tail.sampling_dt > 0.0) {
     double* samp = lds + (size_t)ppw * PS;                       // per path: [Smax] times | [Smax][4][10] coefficients
     double* s_t = samp + (size_t)ppw * ((size_t)Smax * (kD * kN + 1));   // sample buffer of the wavefront
     unsigned short* s_seg = reinterpret_cast<unsigned short*>(s_t + kSampleBuffer);
@@ -548,13 +551,19 @@ hipError_t launch_solve_rows(const BatchView& b, int d, const uint8_t* mask, con
   if (const char* e = std::getenv("MRS_TG_ROWS_PPW")) ppw = std::atoi(e) == 1 ? 1 : 2;
   if (rows_lds_bytes(b.max_segments, 2, sampling) > kRowsLdsBudget) ppw = 1;
   const size_t lds_bytes = rows_lds_bytes(b.max_segments, ppw, sampling);
+  const bool with_tail = sampling || tail.maxima != nullptr;
   if (lds_bytes > 64 * 1024) {  // beyond the default limit of a launch: raise it (a driver call, so only when needed)
-    hipError_t e = hipFuncSetAttribute((const void*)solve_rows_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kRowsLdsBudget);
+    hipError_t e = hipFuncSetAttribute(with_tail ? (const void*)solve_rows_kernel<true> : (const void*)solve_rows_kernel<false>,
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)kRowsLdsBudget);
     if (e != hipSuccess) return e;
   }
   const unsigned grid = (unsigned)((b.n_paths + ppw - 1) / ppw);
-  MRS_TG_LAUNCH_TIMED(solve_rows_kernel, dim3(grid), dim3(64), lds_bytes, stream, b, d, ppw, b.max_segments, mask, vals,
-                      seg_times, coeffs, status, cost, status_in, tail);
+  if (with_tail)
+    MRS_TG_LAUNCH_TIMED(solve_rows_kernel<true>, dim3(grid), dim3(64), lds_bytes, stream, b, d, ppw, b.max_segments, mask, vals,
+                        seg_times, coeffs, status, cost, status_in, tail);
+  else
+    MRS_TG_LAUNCH_TIMED(solve_rows_kernel<false>, dim3(grid), dim3(64), lds_bytes, stream, b, d, ppw, b.max_segments, mask, vals,
+                        seg_times, coeffs, status, cost, status_in, tail);
   return hipGetLastError();
 }
 
