@@ -413,7 +413,28 @@ def main():
     torch.cuda.synchronize()
     sol_mean, sol_med, sol_min = dispatch_stats(ctx, api.KERNEL_SOLVE_LINEAR, launch_solve, 200, torch)
     solve_flop = SOLVE_FLOP_PER_SEGMENT * nS
+    sq = None   # SQ counters of this kernel at this batch shape from the committed PMC passes (scripts/pmc_sq.sh)
+    try:
+        with open(os.path.join(ROOT, "profiles", "round2_pmc_sq_solve_rows.json")) as fh:
+            sq = json.load(fh)
+        if sq.get("paths") != P or sq.get("segments") != args.segments:
+            sq = None
+    except (OSError, ValueError):
+        sq = None
+    issue_peak = 256 * 4 * 2.4e9 / 4.0   # wavefront VALU instructions per second: one per 4 cycles per SIMD
+    counted = None
+    if sq is not None:
+        c = sq["counters"]
+        counted = dict(source=sq["source"] + " (separate rocprofv3 --pmc passes; from profiles/, not this run)",
+                       valu_instructions_per_launch=c["SQ_INSTS_VALU"], lds_instructions_per_launch=c["SQ_INSTS_LDS"],
+                       valu_issue_rate_ginst_s=c["SQ_INSTS_VALU"] / (sol_mean * 1e-3) / 1e9,
+                       valu_issue_peak_ginst_s=issue_peak / 1e9,
+                       valu_issue_frac=c["SQ_INSTS_VALU"] / (sol_mean * 1e-3) / issue_peak,
+                       executed_fp64_tflops_upper_bound=2.0 * 64 * c["SQ_INSTS_VALU"] / (sol_mean * 1e-3) / 1e12,
+                       wait_share_of_wave_cycles=c["SQ_WAIT_ANY"] / c["SQ_WAVE_CYCLES"],
+                       valu_active_share_of_wave_cycles=c["SQ_ACTIVE_INST_VALU"] / c["SQ_WAVE_CYCLES"])
     roofline_solve = dict(kernel="solve_rows_kernel", bound="fp64 vector", unit="TFLOP/s", peak=FP64_VECTOR_PEAK_TFLOPS,
+                          counted=counted,
                           flop_per_launch=solve_flop, avg_launch_us=sol_mean * 1e3, median_launch_us=sol_med * 1e3,
                           achieved=solve_flop / (sol_mean * 1e-3) / 1e12,
                           frac=solve_flop / (sol_mean * 1e-3) / 1e12 / FP64_VECTOR_PEAK_TFLOPS,
