@@ -447,13 +447,39 @@ def main():
     torch.cuda.synchronize()
     nl_mean, nl_med, nl_min = dispatch_stats(ctx, api.KERNEL_NONLINEAR, launch_nl, 50, torch)
     nl_flop = NONLINEAR_FLOP_PER_PATH_S10 * (args.segments / 10.0) ** 2 * P
-    roofline_outer = dict(kernel="optimize_split_kernel / optimize_compact_kernel", bound="fp64 vector", unit="TFLOP/s",
-                          peak=FP64_VECTOR_PEAK_TFLOPS, flop_per_launch=nl_flop, avg_launch_us=nl_mean * 1e3,
-                          median_launch_us=nl_med * 1e3, achieved=nl_flop / (nl_mean * 1e-3) / 1e12,
-                          frac=nl_flop / (nl_mean * 1e-3) / 1e12 / FP64_VECTOR_PEAK_TFLOPS,
-                          note="flop model of SURVEY.md 8d for mode 2 (7e6 flop per 10-segment path = 121 reference-style "
-                               "linear solves, an upper bound: the kernel runs forward-only cost sweeps and stops early on "
-                               "ftol / xtol)")
+    sq_nl = None   # SQ counters of the outer-loop kernel at this batch shape (scripts/pmc_sq.sh, committed)
+    try:
+        with open(os.path.join(ROOT, "profiles", "round2_pmc_sq_outer_loop.json")) as fh:
+            sq_nl = json.load(fh)
+        if sq_nl.get("paths") != P or sq_nl.get("segments") != args.segments:
+            sq_nl = None
+    except (OSError, ValueError):
+        sq_nl = None
+    if sq_nl is not None:
+        # executed work: every VALU instruction counted as a 64-lane FP64 FMA -- an upper bound of the flops the kernel ran
+        c = sq_nl["counters"]
+        nl_exec = 2.0 * 64 * c["SQ_INSTS_VALU"]
+        roofline_outer = dict(kernel=sq_nl["kernel"], bound="fp64 vector", unit="TFLOP/s", peak=FP64_VECTOR_PEAK_TFLOPS,
+                              flop_per_launch=nl_exec, avg_launch_us=nl_mean * 1e3, median_launch_us=nl_med * 1e3,
+                              achieved=nl_exec / (nl_mean * 1e-3) / 1e12,
+                              frac=nl_exec / (nl_mean * 1e-3) / 1e12 / FP64_VECTOR_PEAK_TFLOPS,
+                              counted=dict(source=sq_nl["source"] + " (separate rocprofv3 --pmc passes; from profiles/, not this run)",
+                                           valu_instructions_per_launch=c["SQ_INSTS_VALU"],
+                                           lds_instructions_per_launch=c["SQ_INSTS_LDS"],
+                                           valu_issue_frac=c["SQ_INSTS_VALU"] / (nl_mean * 1e-3) / issue_peak,
+                                           wait_share_of_wave_cycles=c["SQ_WAIT_ANY"] / c["SQ_WAVE_CYCLES"],
+                                           valu_active_share_of_wave_cycles=c["SQ_ACTIVE_INST_VALU"] / c["SQ_WAVE_CYCLES"]),
+                              reference_work_flop=nl_flop,
+                              note="flop_per_launch = 2 x 64 x counted VALU instructions (upper bound of the executed FP64 work); "
+                                   "reference_work_flop is SURVEY.md 8d's model of what the reference would execute for the same "
+                                   "batch (7e6 flop per 10-segment path = 121 linear solves), which the kernel undercuts by running "
+                                   "forward-only cost sweeps on exact constants and stopping on ftol / xtol -- not a rate")
+    else:
+        roofline_outer = dict(kernel="optimize_split_kernel / optimize_compact_kernel", bound="fp64 vector", unit="TFLOP/s",
+                              peak=FP64_VECTOR_PEAK_TFLOPS, flop_per_launch=None, avg_launch_us=nl_mean * 1e3,
+                              median_launch_us=nl_med * 1e3, achieved=None, frac=None, reference_work_flop=nl_flop,
+                              note="no committed SQ counters for this batch shape (scripts/pmc_sq.sh); reference_work_flop is "
+                                   "SURVEY.md 8d's model of the reference's work, not what the kernel executes")
 
     extras = {}
     if not args.no_extras and rank == 0:
