@@ -235,6 +235,18 @@ int mrs_tg_plan_cost_gradient(mrs_tg_plan* plan, int32_t derivative_to_optimize,
  * [segment][k-1][group]. */
 int mrs_tg_plan_segment_maxima(mrs_tg_plan* plan, const double* coeffs_dev, const double* seg_times_dev,
                                double* maxima_out_dev);
+/* sampleWholeTrajectory with every field of the sampled state (sampleTrajectoryInRange, trajectory_sampling.cpp:49-104:
+ * five evaluateRange passes over the same accumulate-and-carry walk, trajectory.cpp:93-151): for the trajectories given by
+ * coeffs_dev [sum S][4][10] and seg_times_dev [sum S], states_out_dev [n_paths][sample_capacity][MRS_TG_STATE_ORDERS][4]
+ * holds per sample the derivative orders 0..4 of (x, y, z, heading) -- position_W / velocity_W / acceleration_W / jerk_W /
+ * snap_W in the first three columns, yaw (wrapped to (-pi, pi] as setFromYaw's quaternion round trip does), yaw rate and
+ * yaw acceleration in the fourth; time_from_start of sample i is i * sampling_dt.  n_samples_out_dev [n_paths] as for the
+ * solve calls (capacity + 1 = more samples than fit).  The solve calls' own samples_out (positions and heading, all the
+ * nodelet reads: src/mrs_trajectory_generation.cpp:1582-1599) are order 0 of this, bit for bit.  Device pointers,
+ * asynchronous on the context's stream. */
+#define MRS_TG_STATE_ORDERS 5
+int mrs_tg_plan_sample_states(mrs_tg_plan* plan, const double* coeffs_dev, const double* seg_times_dev, double sampling_dt,
+                              int32_t sample_capacity, int32_t* n_samples_out_dev, double* states_out_dev);
 
 /* Duration in milliseconds of the most recent launch of a kernel, from the start and end time stamps of that very dispatch
  * (the events are attached to the kernel launch itself, hipExtLaunchKernelGGL: what rocprofv3 --kernel-trace reports for

@@ -28,6 +28,7 @@ TIME_ALLOC_RICHTER_TIME_AND_CONSTRAINTS = 4
 FLAG_FUSED_ASSEMBLY = 1        # the default since ABI 2
 FLAG_MATERIALIZED_BLOCKS = 2   # assembly kernel + solve from the materialised H / A^-1 blocks
 
+STATE_ORDERS = 5   # derivative orders 0..4 per sample of Plan.sample_states (MRS_TG_STATE_ORDERS)
 KERNEL_ASSEMBLE, KERNEL_SOLVE_LINEAR, KERNEL_NONLINEAR = 0, 1, 2
 
 
@@ -71,7 +72,7 @@ EXPORTED_SYMBOLS = [
     "mrs_tg_plan_n_paths", "mrs_tg_plan_n_segments", "mrs_tg_plan_max_segments", "mrs_tg_plan_get_order",
     "mrs_tg_plan_assemble", "mrs_tg_plan_block_bytes", "mrs_tg_plan_solve", "mrs_tg_plan_bind_solve",
     "mrs_tg_bound_solve_launch", "mrs_tg_bound_solve_destroy", "mrs_tg_plan_cost_gradient",
-    "mrs_tg_plan_segment_maxima", "mrs_tg_set_profiling", "mrs_tg_last_kernel_ms", "mrs_tg_kernel_ms_history",
+    "mrs_tg_plan_segment_maxima", "mrs_tg_plan_sample_states", "mrs_tg_set_profiling", "mrs_tg_last_kernel_ms", "mrs_tg_kernel_ms_history",
     "mrs_tg_find_trajectory",
     "mrs_tg_default_policy_options", "mrs_tg_optimize_paths", "mrs_tg_waypoint_trajectory_idxs",
     "mrs_tg_create_multi", "mrs_tg_destroy_multi", "mrs_tg_multi_n_devices", "mrs_tg_multi_context", "mrs_tg_multi_shard",
@@ -141,6 +142,8 @@ def load_library():
     L.mrs_tg_plan_cost_gradient.argtypes = [vp, C.c_int32, bp, dp, dp, dp, dp]
     L.mrs_tg_plan_segment_maxima.restype = C.c_int
     L.mrs_tg_plan_segment_maxima.argtypes = [vp, dp, dp, dp]
+    L.mrs_tg_plan_sample_states.restype = C.c_int
+    L.mrs_tg_plan_sample_states.argtypes = [vp, dp, dp, C.c_double, C.c_int32, ip, dp]
     L.mrs_tg_set_profiling.restype = C.c_int
     L.mrs_tg_set_profiling.argtypes = [vp, C.c_int]
     L.mrs_tg_last_kernel_ms.restype = C.c_int
@@ -515,9 +518,16 @@ class Plan:
         self.ctx._check(self._L.mrs_tg_plan_segment_maxima(self._h, _t_ptr(coeffs), _t_ptr(seg_times), _t_ptr(maxima)),
                         "mrs_tg_plan_segment_maxima")
 
+    def sample_states(self, coeffs, seg_times, sampling_dt, sample_capacity, n_samples, states):
+        """sampleWholeTrajectory with all fields: states [n_paths][capacity][STATE_ORDERS][4] (device tensors)."""
+        self.ctx._check(self._L.mrs_tg_plan_sample_states(self._h, _t_ptr(coeffs), _t_ptr(seg_times), float(sampling_dt),
+                                                          int(sample_capacity), _t_ptr(n_samples), _t_ptr(states)),
+                        "mrs_tg_plan_sample_states")
+
 
 class DeviceBatch:
     """A Batch uploaded to HBM as torch tensors, plus output tensors, for the plan interface."""
+
 
     def __init__(self, batch: Batch, device="cuda:0", sample_capacity=0):
         import torch

@@ -576,6 +576,19 @@ int mrs_tg_plan_segment_maxima(mrs_tg_plan* plan, const double* coeffs, const do
   return MRS_TG_OK;
 }
 
+int mrs_tg_plan_sample_states(mrs_tg_plan* plan, const double* coeffs, const double* seg_times, double sampling_dt,
+                              int32_t sample_capacity, int32_t* n_samples, double* states) {
+  if (!plan || !coeffs || !seg_times || !n_samples)
+    return fail(plan ? plan->ctx : nullptr, MRS_TG_ERR_INVALID_ARG, "NULL argument");
+  mrs_tg_ctx* ctx = plan->ctx;
+  if (!(sampling_dt > 0.0) || sample_capacity < 0 || (sample_capacity > 0 && !states))
+    return fail(ctx, MRS_TG_ERR_INVALID_ARG, "sampling_dt must be positive and states_out_dev given for a positive capacity");
+  HIP_TRY(ctx, use_device(ctx->device));
+  HIP_TRY(ctx, mrs_tg::launch_sample_states(plan->view, coeffs, seg_times, sampling_dt, sample_capacity, n_samples,
+                                            sample_capacity > 0 ? states : nullptr, ctx->stream));
+  return MRS_TG_OK;
+}
+
 // ---- one-call host interface ------------------------------------------------------------------
 
 

@@ -215,6 +215,7 @@ __global__ __launch_bounds__(256) void estimate_times_kernel(BatchView b, const 
 // bounds the walk, which matters because a path whose outer loop ended on a rejected trial point
 // can come back with segment times of thousands of seconds.
 
+template <int NDER>
 __global__ __launch_bounds__(64) void sample_kernel(BatchView b, const double* __restrict__ coeffs,
                                                     const double* __restrict__ seg_times, double dt, int capacity,
                                                     int32_t* __restrict__ n_samples, double* __restrict__ samples) {
@@ -234,8 +235,8 @@ __global__ __launch_bounds__(64) void sample_kernel(BatchView b, const double* _
   }
   __syncthreads();
   MRS_TG_PHASE_MARK(1);
-  double* out = samples ? samples + (size_t)pr.p * capacity * kD : nullptr;
-  const int n = sample_path_walk(s_T, s_c, s_t, s_seg, S, dt, capacity, out);
+  double* out = samples ? samples + (size_t)pr.p * capacity * (NDER + 1) * kD : nullptr;
+  const int n = sample_path_walk<NDER>(s_T, s_c, s_t, s_seg, S, dt, capacity, out);
   MRS_TG_PHASE_MARK(2);
   if (lane == 0 && n_samples) n_samples[pr.p] = n;
 }
@@ -300,18 +301,30 @@ hipError_t launch_estimate_times(const BatchView& b, const double* wp, const dou
   return hipGetLastError();
 }
 
-hipError_t launch_sample(const BatchView& b, const double* coeffs, const double* seg_times, double dt, int capacity,
-                         int32_t* n_samples, double* samples, hipStream_t stream) {
-  if (b.n_paths == 0) return hipSuccess;
+template <int NDER>
+static hipError_t launch_sample_n(const BatchView& b, const double* coeffs, const double* seg_times, double dt, int capacity,
+                                  int32_t* n_samples, double* samples, hipStream_t stream) {
   const size_t lds = sizeof(double) * ((size_t)b.max_segments * (1 + kD * kN) + kSampleBuffer) + sizeof(unsigned short) * kSampleBuffer;
   if (lds > 160 * 1024) return hipErrorInvalidValue;
   if (lds > 64 * 1024) {
-    hipError_t e = hipFuncSetAttribute((const void*)sample_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipError_t e = hipFuncSetAttribute((const void*)sample_kernel<NDER>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
   }
-  hipLaunchKernelGGL(sample_kernel, dim3(b.n_paths), dim3(64), lds, stream, b, coeffs, seg_times, dt, capacity,
+  hipLaunchKernelGGL(sample_kernel<NDER>, dim3(b.n_paths), dim3(64), lds, stream, b, coeffs, seg_times, dt, capacity,
                      n_samples, samples);
   return hipGetLastError();
+}
+
+hipError_t launch_sample(const BatchView& b, const double* coeffs, const double* seg_times, double dt, int capacity,
+                         int32_t* n_samples, double* samples, hipStream_t stream) {
+  if (b.n_paths == 0) return hipSuccess;
+  return launch_sample_n<0>(b, coeffs, seg_times, dt, capacity, n_samples, samples, stream);
+}
+
+hipError_t launch_sample_states(const BatchView& b, const double* coeffs, const double* seg_times, double dt, int capacity,
+                                int32_t* n_samples, double* states, hipStream_t stream) {
+  if (b.n_paths == 0) return hipSuccess;
+  return launch_sample_n<kSampleStateOrders - 1>(b, coeffs, seg_times, dt, capacity, n_samples, states, stream);
 }
 
 size_t linear_workspace_doubles(const BatchView& b) {

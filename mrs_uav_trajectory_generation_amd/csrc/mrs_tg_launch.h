@@ -48,6 +48,10 @@ hipError_t launch_estimate_times(const BatchView& b, const double* wp, const dou
                                  hipStream_t stream);
 hipError_t launch_sample(const BatchView& b, const double* coeffs, const double* seg_times, double dt, int capacity,
                          int32_t* n_samples, double* samples, hipStream_t stream);
+// the same walk, every sample with its derivative orders 0..4: states [n_paths][capacity][kSampleStateOrders][4]
+constexpr int kSampleStateOrders = 5;
+hipError_t launch_sample_states(const BatchView& b, const double* coeffs, const double* seg_times, double dt, int capacity,
+                                int32_t* n_samples, double* states, hipStream_t stream);
 size_t linear_workspace_doubles(const BatchView& b);
 // phase-split tile kernel (mrs_tg_tile.hip): small and medium batches whose per-path state fits in LDS
 bool tile_kernel_applies(const BatchView& b, bool fused);

@@ -15,6 +15,13 @@ __device__ __forceinline__ double wrap_heading(double y) {
   return fma(-kf, two_pi_lo, fma(-kf, two_pi_hi, y));
 }
 
+// j!/(j-k)!, a compile-time constant wherever j and k are
+__host__ __device__ constexpr double falling_factorial(int j, int k) {
+  double v = 1.0;
+  for (int n = 0; n < k; ++n) v *= (double)(j - n);
+  return v;
+}
+
 __device__ __forceinline__ double lane_value(double v, int src) {
   const int lo = __builtin_amdgcn_readlane(__double2loint(v), src), hi = __builtin_amdgcn_readlane(__double2hiint(v), src);
   return __hiloint2double(hi, lo);
@@ -31,6 +38,11 @@ constexpr int kSampleBuffer = 1024;  // samples parked per flush (8 KB of times 
 // One wavefront (all 64 lanes, wave-uniform control flow).  s_T [S] segment times, s_c [S][4][10] coefficients, s_t / s_seg
 // the sample buffer (kSampleBuffer entries each); out: the path's [capacity][4] samples or nullptr (count only).
 // Returns the number of samples (capacity + 1 = "more than fit").
+// NDER = 0: out[sample][4] positions + wrapped heading (what the nodelet reads).  NDER = 4: out[sample][5][4], the
+// derivative orders 0..4 of every dimension -- sampleTrajectoryInRange's position / velocity / acceleration / jerk / snap
+// and yaw / yaw rate / yaw acceleration (trajectory_sampling.cpp:49-104), each evaluated as Polynomial::evaluate(t, k)
+// does: Horner over j!/(j-k)! c_j (polynomial.h:150-163).
+template <int NDER = 0>
 __device__ __forceinline__ int sample_path_walk(const double* s_T, const double* s_c, double* s_t, unsigned short* s_seg, int S,
                                                 double dt, int capacity, double* out) {
   const int lane = threadIdx.x & 63;
@@ -55,17 +67,20 @@ __device__ __forceinline__ int sample_path_walk(const double* s_T, const double*
       if (e >= capacity) break;
       const double tj = s_t[e - n_flushed];
       const double* c = s_c + (size_t)s_seg[e - n_flushed] * (kD * kN);
-      double v[kD];
 #pragma unroll
-      for (int dd = 0; dd < kD; ++dd) {
-        double accv = c[dd * kN + kN - 1];
+      for (int k = 0; k <= NDER; ++k) {
+        double v[kD];
 #pragma unroll
-        for (int k = kN - 2; k >= 0; --k) accv = accv * tj + c[dd * kN + k];
-        v[dd] = accv;
+        for (int dd = 0; dd < kD; ++dd) {
+          double accv = falling_factorial(kN - 1, k) * c[dd * kN + kN - 1];
+#pragma unroll
+          for (int j = kN - 2; j >= k; --j) accv = accv * tj + falling_factorial(j, k) * c[dd * kN + j];
+          v[dd] = accv;
+        }
+        if (k == 0) v[3] = wrap_heading(v[3]);
+#pragma unroll
+        for (int dd = 0; dd < kD; ++dd) out[((size_t)e * (NDER + 1) + k) * kD + dd] = v[dd];
       }
-      v[3] = wrap_heading(v[3]);
-#pragma unroll
-      for (int dd = 0; dd < kD; ++dd) out[(size_t)e * kD + dd] = v[dd];
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     __builtin_amdgcn_wave_barrier();
