@@ -116,11 +116,19 @@ def self_launch(args, argv):
 # ---------------------------------------------------------------------------------------------------------------------
 # helpers (run inside a rank)
 
-def time_steps(step_fn, steps, warmup, dist, torch, final_fn=None):
+def time_steps(step_fn, steps, warmup, dist, torch, final_fn=None, block_fn=None):
     """W untimed steps, then exactly K steps (+ final_fn, the job's closing gather) between barrier + synchronize
-    pairs; returns the MAX over ranks of the elapsed seconds."""
-    for _ in range(warmup):
-        step_fn()
+    pairs; returns the MAX over ranks of the elapsed seconds.  block_fn(n), when given, issues n steps (the host's
+    issue loop in C, mrs_tg_bound_solve_launch_many) and replaces n calls of step_fn."""
+    if block_fn is not None:
+        def run(n):
+            if n > 0:
+                block_fn(n)
+    else:
+        def run(n):
+            for _ in range(n):
+                step_fn()
+    run(warmup)
     if final_fn is not None:
         final_fn()          # warm the collective up as well (communicator set-up is not part of a step)
     torch.cuda.synchronize()
@@ -128,8 +136,7 @@ def time_steps(step_fn, steps, warmup, dist, torch, final_fn=None):
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for _ in range(steps):
-        step_fn()
+    run(steps)
     if final_fn is not None:
         final_fn()
     torch.cuda.synchronize()
@@ -244,10 +251,12 @@ def main():
     t_init = db.seg_times.clone()
     t_fixed = t_init.clone()   # linear mode never writes the times
 
-    opt_lin = api.default_options(derivative_to_optimize=4)
-    opt_blocks = api.default_options(derivative_to_optimize=4, flags=api.FLAG_MATERIALIZED_BLOCKS)
-    opt_nl = api.default_options(derivative_to_optimize=4, time_alloc_method=api.TIME_ALLOC_MELLINGER,
-                                 sampling_dt=0.2, sample_capacity=512)
+    # [0]: the batch has the device to itself; [1]: several batches in flight (MRS_TG_FLAG_SHARED_DEVICE, a launch-shape hint)
+    opt_lin = [api.default_options(derivative_to_optimize=4, flags=f) for f in (0, api.FLAG_SHARED_DEVICE)]
+    opt_blocks = [api.default_options(derivative_to_optimize=4, flags=api.FLAG_MATERIALIZED_BLOCKS | f)
+                  for f in (0, api.FLAG_SHARED_DEVICE)]
+    opt_nl = [api.default_options(derivative_to_optimize=4, time_alloc_method=api.TIME_ALLOC_MELLINGER,
+                                  sampling_dt=0.2, sample_capacity=512, flags=f) for f in (0, api.FLAG_SHARED_DEVICE)]
 
     def gather(tensor, bufs):
         """the job's one collective: equally shaped per-rank results -> rank 0"""
@@ -289,13 +298,15 @@ def main():
     bound = {}
 
     def slot_call(kind, slot, lane):
-        key = (kind, slot, lane)
+        sh = 1 if active_lanes[0] > 1 else 0
+        key = (kind, slot, lane, sh)
         if key not in bound:
             if kind in ("linear", "blocks"):
-                bound[key] = lane_plan[lane].bind_solve(opt_lin if kind == "linear" else opt_blocks, db.fixed_mask, db.fixed_values,
-                                                        t_fixed, out_coeffs[slot], status_i32[slot], slot_cost[slot])
+                bound[key] = lane_plan[lane].bind_solve(opt_lin[sh] if kind == "linear" else opt_blocks[sh], db.fixed_mask,
+                                                        db.fixed_values, t_fixed, out_coeffs[slot], status_i32[slot],
+                                                        slot_cost[slot])
             else:
-                bound[key] = lane_plan[lane].bind_solve(opt_nl, db.fixed_mask, db.fixed_values, out_times[slot], out_coeffs[slot],
+                bound[key] = lane_plan[lane].bind_solve(opt_nl[sh], db.fixed_mask, db.fixed_values, out_times[slot], out_coeffs[slot],
                                                         status_i32[slot], slot_cost[slot], limits=db.limits,
                                                         n_samples=slot_nsamp[slot], samples=slot_samples[slot])
         return bound[key]
@@ -338,6 +349,26 @@ def main():
                 finish_step(slot, lane)
         return step
 
+    round_robin = {}
+
+    def make_linear_block(kind):
+        """n steps of a fixed-times workload through the library's own issue loop (mrs_tg_bound_solve_launch_many): step k
+        runs slot k % slots on lane slot % lanes.  Not for --gather every (a collective follows every step there)."""
+        def block(n):
+            lanes = active_lanes[0]
+            slots = max(lanes, 2 if dist is not None else 1)
+            for slot in range(slots):       # a slot whose last result is still being gathered: its lane waits for that
+                if slot_free[slot] is not None:
+                    lane_stream[slot % lanes].wait_event(slot_free[slot])
+                    slot_free[slot] = None
+            key = (kind, lanes, slots)
+            if key not in round_robin:
+                round_robin[key] = api.RoundRobin([slot_call(kind, sl, sl % lanes) for sl in range(slots)])
+            round_robin[key](n)
+            step_no[0] = n
+            last_slot[0] = ((n - 1) % slots, ((n - 1) % slots) % lanes)
+        return block
+
     def step_nonlinear():
         slot, lane = begin_step()
         with torch.cuda.stream(lane_stream[lane]):
@@ -355,6 +386,10 @@ def main():
         torch.cuda.current_stream().wait_event(slot_free[last_slot[0][0]])
 
     steps_fn = {"linear": make_linear_step("linear"), "blocks": make_linear_step("blocks"), "nonlinear": step_nonlinear}
+    blocks_fn = {"linear": make_linear_block("linear"), "blocks": make_linear_block("blocks")}
+
+    def block_for(kind):
+        return None if (gather_every[0] or kind not in blocks_fn) else blocks_fn[kind]
 
     # The clocks of an idle MI355X take a few milliseconds of work to come up, and the driver's default run is 5 warm-up
     # + 20 timed steps of ~10 us: an untimed ramp of the same step keeps the timed region from measuring the ramp.
@@ -363,7 +398,8 @@ def main():
     torch.cuda.synchronize()
     step_no[0] = 0
 
-    elapsed = time_steps(steps_fn[args.workload], args.steps, args.warmup, dist, torch, final_gather)
+    elapsed = time_steps(steps_fn[args.workload], args.steps, args.warmup, dist, torch, final_gather,
+                         block_fn=block_for(args.workload))
     total_paths = P * world * args.steps
     value = total_paths / elapsed
 
@@ -401,11 +437,11 @@ def main():
     db.coeffs, db.seg_times, db.status = out_coeffs[0], out_times[0], status_i32[0]
 
     def launch_solve():
-        plan.solve(opt_lin, db.fixed_mask, db.fixed_values, t_fixed, out_coeffs[0], status_i32[0], slot_cost[0])
+        plan.solve(opt_lin[0], db.fixed_mask, db.fixed_values, t_fixed, out_coeffs[0], status_i32[0], slot_cost[0])
 
     def launch_nl():
         out_times[0].copy_(t_init)
-        plan.solve(opt_nl, db.fixed_mask, db.fixed_values, out_times[0], out_coeffs[0], status_i32[0], slot_cost[0],
+        plan.solve(opt_nl[0], db.fixed_mask, db.fixed_values, out_times[0], out_coeffs[0], status_i32[0], slot_cost[0],
                    limits=db.limits, n_samples=slot_nsamp[0], samples=slot_samples[0])
 
     for _ in range(10):
@@ -511,7 +547,7 @@ def main():
                                           note="mrs_tg_solve_batch with host buffers, linear QP, includes PCIe copies")
     if not args.no_extras and args.workload == "linear":
         # the step that materialises the blocks: assembly kernel + solve from the blocks in HBM
-        elb = time_steps(steps_fn["blocks"], args.steps, 3, dist, torch, final_gather)
+        elb = time_steps(steps_fn["blocks"], args.steps, 3, dist, torch, final_gather, block_fn=block_for("blocks"))
         if rank == 0:
             extras["materialized_blocks_step"] = dict(value=P * world * args.steps / elb, unit="trajectories/s",
                                                       ms_per_step=elb / args.steps * 1e3,
@@ -522,8 +558,8 @@ def main():
         torch.cuda.synchronize()
         active_lanes[0] = 1
         step_no[0] = 0
-        el1 = time_steps(steps_fn[args.workload], args.steps, 3, dist, torch, final_gather)
-        el1b = time_steps(steps_fn["blocks"], args.steps, 3, dist, torch, final_gather) if args.workload == "linear" else None
+        el1 = time_steps(steps_fn[args.workload], args.steps, 3, dist, torch, final_gather, block_fn=block_for(args.workload))
+        el1b = time_steps(steps_fn["blocks"], args.steps, 3, dist, torch, final_gather, block_fn=block_for("blocks")) if args.workload == "linear" else None
         active_lanes[0] = n_lanes
         step_no[0] = 0
         if rank == 0:
@@ -534,7 +570,7 @@ def main():
     if not args.no_extras:
         other = "nonlinear" if args.workload == "linear" else "linear"
         k2 = max(5, args.steps // 10) if other == "nonlinear" else args.steps
-        el2 = time_steps(steps_fn[other], k2, 3, dist, torch, final_gather)
+        el2 = time_steps(steps_fn[other], k2, 3, dist, torch, final_gather, block_fn=block_for(other))
         if rank == 0:
             extras[other] = dict(value=P * world * k2 / el2, unit="trajectories/s", steps=k2, ms_per_step=el2 / k2 * 1e3)
         if dist is not None and not gather_every[0]:
@@ -568,7 +604,7 @@ def main():
         cap3 = (total3 + world - 1) // world
         pad3 = torch.zeros(cap3 * args.segments * 41 + cap3, dtype=torch.float64, device=dev) if dist is not None else None
         recv3 = ([torch.empty_like(pad3) for _ in range(world)] if (dist is not None and rank == 0 and not gloo) else None)
-        call3 = plan3.bind_solve(opt_nl, db3.fixed_mask, db3.fixed_values, tt3, c3, st3, db3.cost, limits=db3.limits,
+        call3 = plan3.bind_solve(opt_nl[0], db3.fixed_mask, db3.fixed_values, tt3, c3, st3, db3.cost, limits=db3.limits,
                                  n_samples=db3.n_samples, samples=db3.samples)
 
         def step3():
@@ -690,6 +726,11 @@ def main():
                                              "(nothing materialised); the assembly kernel is timed on its own (roofline) and "
                                              "inside extras.materialized_blocks_step",
                                 clock_ramp_steps=300,
+                                step_issue=("mrs_tg_bound_solve_launch_many: the K steps are issued round-robin over the "
+                                            "streams by the library's C loop" if block_for(args.workload) is not None
+                                            else "one Python call per step"),
+                                launch_hint=("MRS_TG_FLAG_SHARED_DEVICE (several batches in flight: two paths per wavefront "
+                                             "so that four launches fit the SIMDs side by side)" if n_lanes > 1 else "none"),
                                 parallelism=("independent paths sharded per rank, no data-path collective; %s gather of "
                                              "the results to rank 0 %s, inside the timed region"
                                              % ("gloo (host)" if gloo else "RCCL",

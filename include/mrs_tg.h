@@ -79,9 +79,13 @@ enum {
   MRS_TG_FLAG_FUSED_ASSEMBLY = 1,     /* the default since ABI 2 (kept so that ABI-1 callers still say what they mean): every
                                          lane of the solve kernel forms its column of the reduced system straight from the
                                          segment times; no block is written to memory */
-  MRS_TG_FLAG_MATERIALIZED_BLOCKS = 2 /* linear mode: run the assembly kernel (mrs_tg_plan_assemble: full H_i and A_i^-1 of
+  MRS_TG_FLAG_MATERIALIZED_BLOCKS = 2,/* linear mode: run the assembly kernel (mrs_tg_plan_assemble: full H_i and A_i^-1 of
                                          every segment in HBM, the reference's updateSegmentTimes + constructR products) and
                                          solve from the materialised blocks */
+  MRS_TG_FLAG_SHARED_DEVICE = 4       /* a hint, results are unaffected: the caller keeps several batches in flight on this
+                                         device (one context + stream each), so small batches are launched in shapes that
+                                         leave wavefront slots to the other streams instead of minimising the latency of
+                                         this one launch */
 };
 
 typedef struct mrs_tg_options {
@@ -223,6 +227,10 @@ int mrs_tg_plan_bind_solve(mrs_tg_plan* plan, const double* waypoints_dev, const
                            int32_t* n_samples_out_dev, double* samples_out_dev, mrs_tg_bound_solve** bound_out);
 int mrs_tg_bound_solve_launch(mrs_tg_bound_solve* bound);
 void mrs_tg_bound_solve_destroy(mrs_tg_bound_solve* bound);
+/* The issue loop of a host that keeps several batches in flight: launch k = 0 .. n_launches-1 goes to bound[k % n_bound]
+ * (one bound solve per context + stream).  Stops at the first error and returns its code (mrs_tg_last_error of that
+ * solve's context has the text). */
+int mrs_tg_bound_solve_launch_many(mrs_tg_bound_solve* const* bound, int32_t n_bound, int32_t n_launches);
 
 /* Building blocks of the outer loop, exposed for parity tests (device pointers, asynchronous):
  * J_d and the h = 0.1 forward-difference gradient at the given times

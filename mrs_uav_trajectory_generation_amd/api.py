@@ -27,6 +27,7 @@ TIME_ALLOC_SQUARED_TIME_AND_CONSTRAINTS = 3
 TIME_ALLOC_RICHTER_TIME_AND_CONSTRAINTS = 4
 FLAG_FUSED_ASSEMBLY = 1        # the default since ABI 2
 FLAG_MATERIALIZED_BLOCKS = 2   # assembly kernel + solve from the materialised H / A^-1 blocks
+FLAG_SHARED_DEVICE = 4         # hint: several batches are in flight on this device (results unaffected)
 
 STATE_ORDERS = 5   # derivative orders 0..4 per sample of Plan.sample_states (MRS_TG_STATE_ORDERS)
 KERNEL_ASSEMBLE, KERNEL_SOLVE_LINEAR, KERNEL_NONLINEAR = 0, 1, 2
@@ -71,7 +72,7 @@ EXPORTED_SYMBOLS = [
     "mrs_tg_set_stream", "mrs_tg_reset_stream", "mrs_tg_synchronize", "mrs_tg_solve_batch", "mrs_tg_plan_create", "mrs_tg_plan_destroy",
     "mrs_tg_plan_n_paths", "mrs_tg_plan_n_segments", "mrs_tg_plan_max_segments", "mrs_tg_plan_get_order",
     "mrs_tg_plan_assemble", "mrs_tg_plan_block_bytes", "mrs_tg_plan_solve", "mrs_tg_plan_bind_solve",
-    "mrs_tg_bound_solve_launch", "mrs_tg_bound_solve_destroy", "mrs_tg_plan_cost_gradient",
+    "mrs_tg_bound_solve_launch", "mrs_tg_bound_solve_launch_many", "mrs_tg_bound_solve_destroy", "mrs_tg_plan_cost_gradient",
     "mrs_tg_plan_segment_maxima", "mrs_tg_plan_sample_states", "mrs_tg_set_profiling", "mrs_tg_last_kernel_ms", "mrs_tg_kernel_ms_history",
     "mrs_tg_find_trajectory",
     "mrs_tg_default_policy_options", "mrs_tg_optimize_paths", "mrs_tg_waypoint_trajectory_idxs",
@@ -136,6 +137,8 @@ def load_library():
     L.mrs_tg_plan_bind_solve.argtypes = [vp, dp, bp, dp, dp, C.POINTER(Options), dp, dp, ip, dp, ip, dp, C.POINTER(vp)]
     L.mrs_tg_bound_solve_launch.restype = C.c_int
     L.mrs_tg_bound_solve_launch.argtypes = [vp]
+    L.mrs_tg_bound_solve_launch_many.restype = C.c_int
+    L.mrs_tg_bound_solve_launch_many.argtypes = [C.POINTER(vp), C.c_int32, C.c_int32]
     L.mrs_tg_bound_solve_destroy.restype = None
     L.mrs_tg_bound_solve_destroy.argtypes = [vp]
     L.mrs_tg_plan_cost_gradient.restype = C.c_int
@@ -507,6 +510,8 @@ class Plan:
             rc = fn(_h)
             if rc:
                 check(rc, "mrs_tg_bound_solve_launch")
+        enqueue.handle = h
+        enqueue.ctx = self.ctx
         return enqueue
 
     def cost_gradient(self, derivative, fixed_mask, fixed_values, seg_times, cost, grad):
@@ -523,6 +528,22 @@ class Plan:
         self.ctx._check(self._L.mrs_tg_plan_sample_states(self._h, _t_ptr(coeffs), _t_ptr(seg_times), float(sampling_dt),
                                                           int(sample_capacity), _t_ptr(n_samples), _t_ptr(states)),
                         "mrs_tg_plan_sample_states")
+
+
+class RoundRobin:
+    """The issue loop of a host that keeps several batches in flight, in C (mrs_tg_bound_solve_launch_many): launch k goes to
+    calls[k % len(calls)], each a callable returned by Plan.bind_solve (one per context + stream)."""
+
+    def __init__(self, calls):
+        self._calls = list(calls)
+        self._arr = (C.c_void_p * len(self._calls))(*[c.handle for c in self._calls])
+        self._fn = load_library().mrs_tg_bound_solve_launch_many
+
+    def __call__(self, n_launches):
+        rc = self._fn(self._arr, len(self._calls), int(n_launches))
+        if rc:
+            for c in self._calls:
+                c.ctx._check(rc, "mrs_tg_bound_solve_launch_many")
 
 
 class DeviceBatch:

@@ -461,6 +461,10 @@ int mrs_tg_plan_solve(mrs_tg_plan* plan, const double* wp, const uint8_t* mask, 
   HIP_TRY(ctx, use_device(ctx->device));
   const mrs_tg::BatchView& b = plan->view;
   const int d = opt->derivative_to_optimize;
+  struct SharedDeviceScope {
+    explicit SharedDeviceScope(bool on) { mrs_tg::set_shared_device_hint(on); }
+    ~SharedDeviceScope() { mrs_tg::set_shared_device_hint(false); }
+  } shared_scope((opt->flags & MRS_TG_FLAG_SHARED_DEVICE) != 0);
   bool sampled = false;  // the sampling rode on the final solve's launch
   if (opt->estimate_times) HIP_TRY(ctx, mrs_tg::launch_estimate_times(b, wp, limits, seg_times, ctx->stream));
 
@@ -555,6 +559,15 @@ int mrs_tg_bound_solve_launch(mrs_tg_bound_solve* b) {
 }
 
 void mrs_tg_bound_solve_destroy(mrs_tg_bound_solve* b) { delete b; }
+
+int mrs_tg_bound_solve_launch_many(mrs_tg_bound_solve* const* bound, int32_t n_bound, int32_t n_launches) {
+  if (!bound || n_bound < 1 || n_launches < 0) return fail(nullptr, MRS_TG_ERR_INVALID_ARG, "bound solves are required");
+  for (int32_t k = 0; k < n_launches; ++k) {
+    const int rc = mrs_tg_bound_solve_launch(bound[k % n_bound]);
+    if (rc != MRS_TG_OK) return rc;
+  }
+  return MRS_TG_OK;
+}
 
 int mrs_tg_plan_cost_gradient(mrs_tg_plan* plan, int32_t d, const uint8_t* mask, const double* vals,
                               const double* seg_times, double* cost, double* grad) {

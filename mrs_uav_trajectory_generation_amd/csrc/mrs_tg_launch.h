@@ -15,6 +15,10 @@ namespace mrs_tg {
 struct KernelTimer {
   hipEvent_t start = nullptr, stop = nullptr;
 };
+// Hint of the calling thread's current ABI call (MRS_TG_FLAG_SHARED_DEVICE): other batches are in flight on the device, so
+// launch shapes that leave wavefront slots free are preferred over the lowest latency of this launch alone.
+void set_shared_device_hint(bool on);
+bool shared_device_hint();
 KernelTimer take_kernel_timer();  // the pending pair (null events when nothing is pending); consumed by the call
 void set_kernel_timer(hipEvent_t start, hipEvent_t stop);  // arms the next timed launch of this thread
 // launch with the pending timer, if any

@@ -117,6 +117,11 @@ void pool_release_cached() {
 // ---- per-dispatch timing (mrs_tg_launch.h): armed by the ABI layer for the kernel it wants timed, consumed by the
 // launcher of that kernel; per thread, because contexts are driven from one thread each
 static thread_local KernelTimer t_kernel_timer;
+static thread_local bool t_shared_device = false;
+
+void set_shared_device_hint(bool on) { t_shared_device = on; }
+bool shared_device_hint() { return t_shared_device; }
+
 
 void set_kernel_timer(hipEvent_t start, hipEvent_t stop) {
   t_kernel_timer.start = start;

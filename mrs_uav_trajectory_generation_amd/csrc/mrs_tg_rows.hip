@@ -546,8 +546,11 @@ hipError_t launch_solve_rows(const BatchView& b, int d, const uint8_t* mask, con
                              double* coeffs, int32_t* status, double* cost, const int32_t* status_in, hipStream_t stream,
                              const RowsTail& tail) {
   const bool sampling = tail.sampling_dt > 0.0;
-  // one path per wavefront while that still leaves SIMDs idle (256 CUs x 4); two paths per wavefront otherwise
-  int ppw = (b.n_paths <= 2048) ? 1 : 2;
+  // one path per wavefront while that still leaves SIMDs idle (256 CUs x 4); two paths per wavefront otherwise -- and
+  // when the caller says other batches share the device: at 255 VGPRs a SIMD holds two wavefronts, so 1024 one-path
+  // wavefronts per launch let two launches run side by side, 512 two-path wavefronts four (1024 x 10, four streams:
+  // 4.9 -> 4.1 us per step; alone on the device the two-path launch is 0.9 us slower)
+  int ppw = (b.n_paths <= 2048 && !(shared_device_hint() && !sampling)) ? 1 : 2;
   if (const char* e = std::getenv("MRS_TG_ROWS_PPW")) ppw = std::atoi(e) == 1 ? 1 : 2;
   if (rows_lds_bytes(b.max_segments, 2, sampling) > kRowsLdsBudget) ppw = 1;
   const size_t lds_bytes = rows_lds_bytes(b.max_segments, ppw, sampling);

@@ -152,3 +152,52 @@ def test_per_dispatch_kernel_timing(gpu_ctx):
     assert 1e-3 < ms_solve < 0.2, ms_solve    # ~8 us
     assert 5e-3 < ms_outer < 2.0, ms_outer    # ~80 us
     plan.close()
+
+
+def test_shared_device_hint_changes_the_launch_shape_not_the_result(gpu_ctx):
+    """MRS_TG_FLAG_SHARED_DEVICE packs two paths into a wavefront for small batches; every path's arithmetic is the same."""
+    batch = pr.random_batch(1024, 10, seed0=0)
+    ragged = pr.random_batch(300, "ragged", seed0=3)
+    for bt in (batch, ragged):
+        alone = gpu_ctx.solve_batch(bt, None)
+        shared = gpu_ctx.solve_batch(bt, None, flags=api.FLAG_SHARED_DEVICE)
+        for key in ("coeffs", "status", "cost", "times"):
+            assert np.array_equal(alone[key], shared[key]), key
+    nl = dict(time_alloc_method=api.TIME_ALLOC_MELLINGER, sampling_dt=0.2, sample_capacity=512)
+    alone = gpu_ctx.solve_batch(ragged, None, **nl)
+    shared = gpu_ctx.solve_batch(ragged, None, flags=api.FLAG_SHARED_DEVICE, **nl)
+    for key in ("coeffs", "status", "times", "n_samples", "samples"):
+        assert np.array_equal(alone[key], shared[key]), key
+
+
+def test_issue_loop_in_c_round_robin_over_streams(gpu_ctx):
+    """mrs_tg_bound_solve_launch_many: launch k goes to bound[k % n]; the same results as one launch per call, and the
+    first failing solve's code comes back."""
+    batch = pr.random_batch(128, 7, seed0=12)
+    streams = [torch.cuda.Stream() for _ in range(3)]
+    ctxs, plans, dbs, calls = [], [], [], []
+    est = api.default_options(estimate_times=1)
+    lin = api.default_options(flags=api.FLAG_SHARED_DEVICE)
+    for st in streams:
+        with torch.cuda.stream(st):
+            c = api.Context(0)
+            c.use_torch_stream()
+            pl = api.Plan(c, batch.seg_offsets)
+            db = api.DeviceBatch(batch, "cuda:0", sample_capacity=16)
+            pl.solve(est, db.fixed_mask, db.fixed_values, db.seg_times, db.coeffs, db.status, db.cost, waypoints=db.waypoints,
+                     limits=db.limits)
+            ctxs.append(c), plans.append(pl), dbs.append(db)
+            calls.append(pl.bind_solve(lin, db.fixed_mask, db.fixed_values, db.seg_times, db.coeffs, db.status, db.cost))
+    torch.cuda.synchronize()
+    for db in dbs:
+        db.coeffs.zero_()
+    api.RoundRobin(calls)(7)   # 7 launches over 3 streams: every stream has run at least twice
+    torch.cuda.synchronize()
+    ref = gpu_ctx.solve_batch(batch, None)
+    for db in dbs:
+        assert np.array_equal(db.coeffs.cpu().numpy().reshape(ref["coeffs"].shape), ref["coeffs"])
+        assert np.all(db.status.cpu().numpy() == 1)
+    for pl in plans:
+        pl.close()
+    for c in ctxs:
+        c.close()
