@@ -231,6 +231,17 @@ void mrs_tg_bound_solve_destroy(mrs_tg_bound_solve* bound);
  * (one bound solve per context + stream).  Stops at the first error and returns its code (mrs_tg_last_error of that
  * solve's context has the text). */
 int mrs_tg_bound_solve_launch_many(mrs_tg_bound_solve* const* bound, int32_t n_bound, int32_t n_launches);
+/* The same run of launches captured once as a HIP graph and re-issued with ONE submission per run (launch-bound loops:
+ * short runs on an idle device, where every first launch of a stream pays the runtime's idle-to-busy path).  The streams of
+ * the bound solves become parallel branches, forked from and joined back into the stream of bound[0]'s context, on which
+ * mrs_tg_graph_launch enqueues the whole run; results are those of mrs_tg_bound_solve_launch_many.  Requirements: every
+ * bound solve has been launched once before (its workspaces exist), every context has a stream of its own (not the
+ * default stream), profiling is off, the arguments stay in place. */
+typedef struct mrs_tg_graph mrs_tg_graph;
+int mrs_tg_bound_solve_graph_create(mrs_tg_bound_solve* const* bound, int32_t n_bound, int32_t n_launches,
+                                    mrs_tg_graph** graph_out);
+int mrs_tg_graph_launch(mrs_tg_graph* graph);
+void mrs_tg_graph_destroy(mrs_tg_graph* graph);
 
 /* Building blocks of the outer loop, exposed for parity tests (device pointers, asynchronous):
  * J_d and the h = 0.1 forward-difference gradient at the given times

@@ -1,0 +1,80 @@
+#!/usr/bin/env python3
+"""Where a 20-step timed region spends its time: empty synchronize, one launch + synchronize, 20 launches + synchronize."""
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from mrs_uav_trajectory_generation_amd import api, problem as pr  # noqa: E402
+
+P, S, LANES = 1024, 10, 4
+batch = pr.random_batch(P, S, seed0=0)
+streams = [torch.cuda.Stream() for _ in range(LANES)]
+plans, dbs, calls, ctxs = [], [], [], []
+est = api.default_options(estimate_times=1)
+opt = api.default_options(flags=api.FLAG_SHARED_DEVICE)
+for st in streams:
+    with torch.cuda.stream(st):
+        c = api.Context(0)
+        c.use_torch_stream()
+        pl = api.Plan(c, batch.seg_offsets)
+        db = api.DeviceBatch(batch, "cuda:0", sample_capacity=16)
+        pl.solve(est, db.fixed_mask, db.fixed_values, db.seg_times, db.coeffs, db.status, db.cost, waypoints=db.waypoints, limits=db.limits)
+        ctxs.append(c), plans.append(pl), dbs.append(db)
+        calls.append(pl.bind_solve(opt, db.fixed_mask, db.fixed_values, db.seg_times, db.coeffs, db.status, db.cost))
+rr = api.RoundRobin(calls)
+rr(600)
+torch.cuda.synchronize()
+
+
+def timed(n, reps=30):
+    best, tot = 1e9, 0.0
+    for _ in range(reps):
+        rr(300)   # keep the clocks up
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        if n:
+            rr(n)
+        t1 = time.perf_counter()
+        torch.cuda.synchronize()
+        t2 = time.perf_counter()
+        best = min(best, t2 - t0)
+        tot += t2 - t0
+    return best * 1e6, tot / reps * 1e6, (t1 - t0) * 1e6
+
+
+for n in (0, 1, 4, 20, 100):
+    b, m, issue = timed(n)
+    print("%3d launches + synchronize: best %.1f us, mean %.1f us (issue loop of the last repetition %.1f us)" % (n, b, m, issue))
+
+
+def timed_graph(n, reps=30):
+    g = rr.graph(n)
+    g()
+    torch.cuda.synchronize()
+    best, tot = 1e9, 0.0
+    for _ in range(reps):
+        rr(300)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        g()
+        torch.cuda.synchronize()
+        t2 = time.perf_counter()
+        best = min(best, t2 - t0)
+        tot += t2 - t0
+    g.close()
+    return best * 1e6, tot / reps * 1e6
+
+
+for n in (1, 4, 20, 100, 200):
+    b, m = timed_graph(n)
+    print("%3d launches as one graph + synchronize: best %.1f us, mean %.1f us" % (n, b, m))
+for db in dbs:
+    db.coeffs.zero_()
+g = rr.graph(8)
+g()
+torch.cuda.synchronize()
+print("graph results written:", all(bool((db.coeffs != 0).any()) for db in dbs))

@@ -201,3 +201,45 @@ def test_issue_loop_in_c_round_robin_over_streams(gpu_ctx):
         pl.close()
     for c in ctxs:
         c.close()
+
+
+def test_run_of_solves_as_one_hip_graph(gpu_ctx):
+    """mrs_tg_bound_solve_graph_create: the round-robin run captured once (streams = parallel branches) writes what the
+    issue loop writes; capture on the default stream or with profiling on is refused with a message."""
+    batch = pr.random_batch(96, 6, seed0=21)
+    streams = [torch.cuda.Stream() for _ in range(3)]
+    ctxs, plans, dbs, calls = [], [], [], []
+    est = api.default_options(estimate_times=1)
+    lin = api.default_options()
+    for st in streams:
+        with torch.cuda.stream(st):
+            c = api.Context(0)
+            c.use_torch_stream()
+            pl = api.Plan(c, batch.seg_offsets)
+            db = api.DeviceBatch(batch, "cuda:0", sample_capacity=16)
+            pl.solve(est, db.fixed_mask, db.fixed_values, db.seg_times, db.coeffs, db.status, db.cost, waypoints=db.waypoints,
+                     limits=db.limits)
+            ctxs.append(c), plans.append(pl), dbs.append(db)
+            calls.append(pl.bind_solve(lin, db.fixed_mask, db.fixed_values, db.seg_times, db.coeffs, db.status, db.cost))
+    rr = api.RoundRobin(calls)
+    rr(3)   # every bound solve has run once: its workspaces exist
+    torch.cuda.synchronize()
+    ref = gpu_ctx.solve_batch(batch, None)
+    graph = rr.graph(7)
+    for rep in range(2):
+        for db in dbs:
+            db.coeffs.zero_()
+        torch.cuda.synchronize()
+        graph()
+        torch.cuda.synchronize()
+        for db in dbs:
+            assert np.array_equal(db.coeffs.cpu().numpy().reshape(ref["coeffs"].shape), ref["coeffs"])
+    graph.close()
+    ctxs[1].set_profiling(True)
+    with pytest.raises(api.MrsTgError, match="profiling"):
+        rr.graph(4)
+    ctxs[1].set_profiling(False)
+    for pl in plans:
+        pl.close()
+    for c in ctxs:
+        c.close()
