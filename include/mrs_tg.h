@@ -82,10 +82,17 @@ enum {
   MRS_TG_FLAG_MATERIALIZED_BLOCKS = 2,/* linear mode: run the assembly kernel (mrs_tg_plan_assemble: full H_i and A_i^-1 of
                                          every segment in HBM, the reference's updateSegmentTimes + constructR products) and
                                          solve from the materialised blocks */
-  MRS_TG_FLAG_SHARED_DEVICE = 4       /* a hint, results are unaffected: the caller keeps several batches in flight on this
+  MRS_TG_FLAG_SHARED_DEVICE = 4,      /* a hint, results are unaffected: the caller keeps several batches in flight on this
                                          device (one context + stream each), so small batches are launched in shapes that
                                          leave wavefront slots to the other streams instead of minimising the latency of
                                          this one launch */
+  MRS_TG_FLAG_CAREFUL_COST = 8        /* Mellinger mode: paths on which a trial point's cost lost its digits in the fast
+                                         evaluation (a segment on the 0.01 s bound next to long neighbours; about 0.3 % of
+                                         random 10-segment paths) are run again with the cost the reference computes,
+                                         0.5 c^T Q c from the coefficients (computeCost, linear_impl.h:128-141), in every
+                                         evaluation.  One more kernel per call, about the duration of the outer loop
+                                         itself; without the flag such a trial point is rejected where the reference may
+                                         accept it */
 };
 
 typedef struct mrs_tg_options {
@@ -263,6 +270,9 @@ int mrs_tg_plan_segment_maxima(mrs_tg_plan* plan, const double* coeffs_dev, cons
  * solve calls (capacity + 1 = more samples than fit).  The solve calls' own samples_out (positions and heading, all the
  * nodelet reads: src/mrs_trajectory_generation.cpp:1582-1599) are order 0 of this, bit for bit.  Device pointers,
  * asynchronous on the context's stream. */
+/* How many paths of the plan's most recent Mellinger solve with MRS_TG_FLAG_CAREFUL_COST had a trial point whose
+ * by-product cost lost its digits and were run again.  Blocks until that solve has finished. */
+int mrs_tg_plan_careful_count(mrs_tg_plan* plan, int32_t* count_out);
 #define MRS_TG_STATE_ORDERS 5
 int mrs_tg_plan_sample_states(mrs_tg_plan* plan, const double* coeffs_dev, const double* seg_times_dev, double sampling_dt,
                               int32_t sample_capacity, int32_t* n_samples_out_dev, double* states_out_dev);

@@ -27,6 +27,7 @@ TIME_ALLOC_SQUARED_TIME_AND_CONSTRAINTS = 3
 TIME_ALLOC_RICHTER_TIME_AND_CONSTRAINTS = 4
 FLAG_FUSED_ASSEMBLY = 1        # the default since ABI 2
 FLAG_MATERIALIZED_BLOCKS = 2   # assembly kernel + solve from the materialised H / A^-1 blocks
+FLAG_CAREFUL_COST = 8          # Mellinger mode: re-run the paths whose fast cost evaluation failed its guard with primal costs
 FLAG_SHARED_DEVICE = 4         # hint: several batches are in flight on this device (results unaffected)
 
 STATE_ORDERS = 5   # derivative orders 0..4 per sample of Plan.sample_states (MRS_TG_STATE_ORDERS)
@@ -74,7 +75,7 @@ EXPORTED_SYMBOLS = [
     "mrs_tg_plan_assemble", "mrs_tg_plan_block_bytes", "mrs_tg_plan_solve", "mrs_tg_plan_bind_solve",
     "mrs_tg_bound_solve_launch", "mrs_tg_bound_solve_launch_many", "mrs_tg_bound_solve_graph_create",
     "mrs_tg_graph_launch", "mrs_tg_graph_destroy", "mrs_tg_bound_solve_destroy", "mrs_tg_plan_cost_gradient",
-    "mrs_tg_plan_segment_maxima", "mrs_tg_plan_sample_states", "mrs_tg_set_profiling", "mrs_tg_last_kernel_ms", "mrs_tg_kernel_ms_history",
+    "mrs_tg_plan_segment_maxima", "mrs_tg_plan_sample_states", "mrs_tg_plan_careful_count", "mrs_tg_set_profiling", "mrs_tg_last_kernel_ms", "mrs_tg_kernel_ms_history",
     "mrs_tg_find_trajectory",
     "mrs_tg_default_policy_options", "mrs_tg_optimize_paths", "mrs_tg_waypoint_trajectory_idxs",
     "mrs_tg_create_multi", "mrs_tg_destroy_multi", "mrs_tg_multi_n_devices", "mrs_tg_multi_context", "mrs_tg_multi_shard",
@@ -152,6 +153,8 @@ def load_library():
     L.mrs_tg_plan_cost_gradient.argtypes = [vp, C.c_int32, bp, dp, dp, dp, dp]
     L.mrs_tg_plan_segment_maxima.restype = C.c_int
     L.mrs_tg_plan_segment_maxima.argtypes = [vp, dp, dp, dp]
+    L.mrs_tg_plan_careful_count.restype = C.c_int
+    L.mrs_tg_plan_careful_count.argtypes = [vp, ip]
     L.mrs_tg_plan_sample_states.restype = C.c_int
     L.mrs_tg_plan_sample_states.argtypes = [vp, dp, dp, C.c_double, C.c_int32, ip, dp]
     L.mrs_tg_set_profiling.restype = C.c_int
@@ -529,6 +532,11 @@ class Plan:
     def segment_maxima(self, coeffs, seg_times, maxima):
         self.ctx._check(self._L.mrs_tg_plan_segment_maxima(self._h, _t_ptr(coeffs), _t_ptr(seg_times), _t_ptr(maxima)),
                         "mrs_tg_plan_segment_maxima")
+
+    def careful_count(self):
+        n = C.c_int32(0)
+        self.ctx._check(self._L.mrs_tg_plan_careful_count(self._h, C.byref(n)), "mrs_tg_plan_careful_count")
+        return n.value
 
     def sample_states(self, coeffs, seg_times, sampling_dt, sample_capacity, n_samples, states):
         """sampleWholeTrajectory with all fields: states [n_paths][capacity][STATE_ORDERS][4] (device tensors)."""

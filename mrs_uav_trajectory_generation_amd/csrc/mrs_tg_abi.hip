@@ -492,6 +492,7 @@ int mrs_tg_plan_solve(mrs_tg_plan* plan, const double* wp, const uint8_t* mask, 
     prm.x_rel = opt->x_rel;
     prm.x_abs = opt->x_abs;
     prm.time_budget_ticks = opt->max_time_s > 0 ? budget_ticks(ctx, opt->max_time_s) : 0;
+    prm.careful_cap = (opt->flags & MRS_TG_FLAG_CAREFUL_COST) ? 1 : 0;
     ProfileScope ps(ctx, 2);
     HIP_TRY(ctx, mrs_tg::launch_nonlinear(plan->nl, b, prm, mask, vals, limits, seg_times, coeffs, status, cost, ctx->stream,
                                           opt->sampling_dt, opt->sample_capacity, n_samples, samples, &sampled));
@@ -674,6 +675,17 @@ int mrs_tg_plan_segment_maxima(mrs_tg_plan* plan, const double* coeffs, const do
   mrs_tg_ctx* ctx = plan->ctx;
   HIP_TRY(ctx, use_device(ctx->device));
   HIP_TRY(ctx, mrs_tg::launch_segment_maxima(plan->view, coeffs, seg_times, maxima, ctx->stream));
+  return MRS_TG_OK;
+}
+
+int mrs_tg_plan_careful_count(mrs_tg_plan* plan, int32_t* count_out) {
+  if (!plan || !count_out) return fail(plan ? plan->ctx : nullptr, MRS_TG_ERR_INVALID_ARG, "NULL argument");
+  mrs_tg_ctx* ctx = plan->ctx;
+  *count_out = 0;
+  if (!plan->nl.d_careful) return MRS_TG_OK;  // no outer loop has run on this plan
+  HIP_TRY(ctx, use_device(ctx->device));
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  HIP_TRY(ctx, hipMemcpy(count_out, plan->nl.d_careful + 2, sizeof(int32_t), hipMemcpyDeviceToHost));
   return MRS_TG_OK;
 }
 

@@ -14,6 +14,13 @@ struct NonlinearParams {
   int max_iterations;
   double f_rel, f_abs, x_rel, x_abs;
   long long time_budget_ticks = 0;  // nlopt maxtime in ticks of the device's constant wall clock (s_memrealtime); 0 = none
+  // Paths on which the by-product cost lost its digits (guarded_cost) are listed for the careful re-run
+  // (optimize_careful_kernel): position q of the path appended to careful_list (capacity careful_cap) through
+  // careful_count; a listed path keeps its start times.  nullptr: no list (the fast kernel's result stands).  A caller of
+  // launch_nonlinear only sets careful_cap != 0 to ask for the re-run; the launcher fills in the rest.
+  int32_t* careful_count = nullptr;
+  int32_t* careful_list = nullptr;
+  int careful_cap = 0;
 };
 
 // Paths are sorted by segment count (longest first), so every lane-group class is a contiguous range
@@ -44,6 +51,9 @@ struct NonlinearPlan {
   size_t ws_doubles = 0;
   int32_t* d_opt_status = nullptr; // stopping reason of the outer loop per path
   double* d_maxima = nullptr;      // [n_segments][9] per-segment maxima
+  int32_t* d_careful = nullptr;    // [0] count, [2] count of the last completed call, [4..] list of guarded paths
+  double* d_careful_ws = nullptr;  // factor store of optimize_careful_kernel's lanes
+  size_t careful_ws_doubles = 0;
   // gradient-free modes (0, 1, 3, 4), allocated on first use
   double* d_dfo_vec = nullptr;       // x | x0 | best | h | lb | ub, each 21 n_segments + 20 n_paths doubles
   double* d_dfo_f = nullptr;         // fbest | f_sweep | J_d scratch, 3 * n_paths doubles

@@ -29,6 +29,7 @@
 // oracle/mto_nonlinear.c.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cfloat>
 #include <cmath>
 #include <cstdint>
@@ -819,7 +820,7 @@ __device__ __forceinline__ bool relstop(double vold, double vnew, double reltol,
 // The optimiser's scalar state (f, alpha | neval, npairs, head, ret) is the same in every lane of a group; it is parked
 // in LDS while the objective is evaluated, so that it does not occupy registers there (the kernel sits on its 256-VGPR
 // cap and the compiler spilled exactly these to scratch memory, a global-memory round trip per reload).
-constexpr int kTickState = 4;  // doubles: f, alpha, then four ints
+constexpr int kTickState = 5;  // doubles: f, alpha, then six ints (neval, npairs, head, ret | guard tripped, spare)
 // per-group LDS block (doubles): x, g, xn, gn, dir [5*Sb], s[M][Sb], y[M][Sb], rho[M + 1], tick state, staged vertices
 // [(Sb+1)*kVtxLds], moving-start extras [kStartExtra], staged segment records [Sb*kSegLds]
 // extras: the moving-start area (only the one-dimension-per-lane kernels use it; in the four-dimensions-per-lane mapping
@@ -837,7 +838,8 @@ __host__ __device__ constexpr int gradient_lds_doubles(int Sb, bool extras) {
 // DS lanes share one time vector (DS = 1: one lane, four dimensions; DS = 4: four lanes, one dimension each).
 template <int DS, bool MASKED4 = false>
 __device__ __forceinline__ double evaluate_objective(const double* vtx, const double* seg, const double* hc, int S, int d,
-                                                     const double* pt, double* grad, int g, int G, bool active) {
+                                                     const double* pt, double* grad, int g, int G, bool active,
+                                                     int* tripped = nullptr) {
   constexpr int ND = kD / DS;
   const int kl_shift = __builtin_ctz((unsigned)G) - (DS == 4 ? 2 : 0);  // G is a power of two >= DS: no integer division
   const int kl = 1 << kl_shift;  // time vectors handled per round
@@ -855,6 +857,7 @@ __device__ __forceinline__ double evaluate_objective(const double* vtx, const do
       qfk += dpp_move<0x4E>(qfk);
     }
     Jk = guarded_cost(Jk, qfk, k == 0);
+    if (tripped && active && k <= S && Jk == kUnreliableCost) *tripped = 1;  // (every writer writes the same value)
     if (r == 0) J0 = __shfl(Jk, (threadIdx.x & ~(G - 1)), 64);  // lane 0 of the group holds k = 0
     if (active && dim0 == 0 && k >= 1 && k <= S) grad[k - 1] = (S > 1) ? (Jk - J0) / kGradStep : 0.0;
   }
@@ -864,7 +867,8 @@ __device__ __forceinline__ double evaluate_objective(const double* vtx, const do
 // Two-sided objective evaluation (forward wavefront's side): forward half sweep, barrier, join with the backward
 // half that the partner wavefront left in LDS, then the same reductions as evaluate_objective<4>.
 __device__ __forceinline__ double evaluate_pair(const double* seg, const double* hc, const double* pair_state, int S, int d,
-                                                const double* pt, double* grad, int g, bool active, unsigned special) {
+                                                const double* pt, double* grad, int g, bool active, unsigned special,
+                                                int* tripped) {
   const int k = g >> 2, dim0 = g & 3, m = S / 2;
   const bool work = active && k <= S;
   Elim<1> st;
@@ -897,8 +901,102 @@ __device__ __forceinline__ double evaluate_pair(const double* seg, const double*
   qfk += dpp_move<0xB1>(qfk);
   qfk += dpp_move<0x4E>(qfk);
   Jk = guarded_cost(Jk, qfk, k == 0);
+  if (work && Jk == kUnreliableCost) *tripped = 1;
   const double J0 = row_value(Jk, 0);
   if (work && dim0 == 0 && k >= 1) grad[k - 1] = (Jk - J0) / kGradStep;
+  return J0;
+}
+
+// ---- careful evaluation: the cost as the reference computes it -----------------------------------------------------
+// 0.5 c^T Q c from the coefficients (computeCost, linear_impl.h:128-141): a sum of non-negative terms, accurate where the
+// by-product 0.5 (qf - red) has cancelled.  One lane = one (time vector, dimension): the general elimination of
+// mrs_tg_solve.hpp with the factors of every vertex parked in global memory, back substitution, coefficients segment by
+// segment (not stored), their quadratic form.  ~6 times the work of a forward-only sweep and none of its specialised
+// steps: used by optimize_careful_kernel only, on the few paths whose fast evaluation failed the guard.
+//   ws: element e of vertex v of lane `wlane` at ws[(v * ws_per_vertex<1>() + e) * wstride + wlane]
+__device__ __forceinline__ double primal_cost_lane(const uint8_t* __restrict__ mask, const double* __restrict__ vals, int v0,
+                                                   int S, int d, const double* xs, int k, int dim0, double* ws,
+                                                   size_t wstride, unsigned wlane) {
+  constexpr int WSV = ws_per_vertex<1>();
+  const double corr = kGradStep / ((double)S - 1.0);
+  Elim<1> st;
+  st.init();
+  VertexData<1> vs, ve;
+  SavedFactors<1> sf;
+  fetch_vertex<1>(mask, vals, v0, dim0, vs);
+  for (int i = 0; i < S; ++i) {
+    fetch_vertex<1>(mask, vals, v0 + i + 1, dim0, ve);
+    double Hs[kSym10];
+    hessian_from_time(perturbed_time(xs, i, k, corr), d, Hs);
+    st.absorb_segment(Hs, vs.f, ve.f, vs.free_bits, ve.free_bits, sf.L, sf.z, sf.W);
+    store_factors<1>(ws + (size_t)i * WSV * wstride, wstride, wlane, sf);
+    vs = ve;
+  }
+  st.factor_vertex(vs.free_bits, sf.L, sf.z);
+  double xn[kNB][1], x[kNB][1], dn[kHalf][1], dc[kHalf][1];
+  back_substitute<1>(sf.L, sf.z, sf.W, xn, true, x);
+#pragma unroll
+  for (int sl = 0; sl < kHalf; ++sl) dn[sl][0] = vs.f[sl][0] + (sl >= kSlot0 ? x[sl - kSlot0][0] : 0.0);
+#pragma unroll
+  for (int r = 0; r < kNB; ++r) xn[r][0] = x[r][0];
+  double total = 0.0;
+  for (int i = S - 1; i >= 0; --i) {
+    load_factors<1>(ws + (size_t)i * WSV * wstride, wstride, wlane, sf);
+    VertexData<1> vc;
+    fetch_vertex<1>(mask, vals, v0 + i, dim0, vc);
+    back_substitute<1>(sf.L, sf.z, sf.W, xn, false, x);
+#pragma unroll
+    for (int sl = 0; sl < kHalf; ++sl) dc[sl][0] = vc.f[sl][0] + (sl >= kSlot0 ? x[sl - kSlot0][0] : 0.0);
+    // unit-time coefficients cb_k = c_k T^k (coefficients_from_time without its final T^-k) and their quadratic form
+    const double T = perturbed_time(xs, i, k, corr);
+    double w[kHalf];
+    w[0] = 1.0;
+#pragma unroll
+    for (int kk = 1; kk < kHalf; ++kk) w[kk] = w[kk - 1] * T;
+    double db[kN], cb[kN];
+#pragma unroll
+    for (int sl = 0; sl < kHalf; ++sl) {
+      db[sl] = dc[sl][0] * w[sl];
+      db[kHalf + sl] = dn[sl][0] * w[sl];
+    }
+#pragma unroll
+    for (int kk = 0; kk < kN; ++kk) {
+      double acc = 0.0;
+      if (kk < kHalf) {
+        acc = c_abar_inv[kk][kk] * db[kk];
+      } else {
+#pragma unroll
+        for (int j = 0; j < kN; ++j) acc += c_abar_inv[kk][j] * db[j];
+      }
+      cb[kk] = acc;
+    }
+    double p2[9];
+    segment_powers(T, d, p2);  // p2[0] = T^(1 - 2d)
+    total = fma(cost_quadratic_form_d(d, cb), p2[0], total);
+#pragma unroll
+    for (int sl = 0; sl < kHalf; ++sl) dn[sl][0] = dc[sl][0];
+#pragma unroll
+    for (int r = 0; r < kNB; ++r) xn[r][0] = x[r][0];
+  }
+  return total;
+}
+
+// evaluate_objective<4> with the primal cost (one path per wavefront, G = 64: 16 time vectors per round, four lanes each)
+__device__ __forceinline__ double evaluate_careful(const uint8_t* __restrict__ mask, const double* __restrict__ vals, int v0,
+                                                   int S, int d, const double* pt, double* grad, int g, bool active,
+                                                   double* ws, size_t wstride, unsigned wlane) {
+  const int kk = g >> 2, dim0 = g & 3;
+  double J0 = 0.0;
+  const int rounds = (S + 16) >> 4;
+  for (int r = 0; r < rounds; ++r) {
+    const int k = kk + r * 16;
+    double Jk = 0.0;
+    if (active && k <= S && (k == 0 || S > 1)) Jk = primal_cost_lane(mask, vals, v0, S, d, pt, k, dim0, ws, wstride, wlane);
+    Jk += dpp_move<0xB1>(Jk);
+    Jk += dpp_move<0x4E>(Jk);
+    if (r == 0) J0 = row_value(Jk, 0);
+    if (active && dim0 == 0 && k >= 1 && k <= S) grad[k - 1] = (S > 1) ? (Jk - J0) / kGradStep : 0.0;
+  }
   return J0;
 }
 
@@ -913,19 +1011,29 @@ struct BinTable {
   int group[5], q_begin[5], q_count[5], max_S[5], block_begin[5];
 };
 
-template <int DS, bool MASKED4 = false>
+// CAREFUL (optimize_careful_kernel): one listed path per workgroup of 64, the primal cost in every evaluation, `careful_ws`
+// the factor store of its lanes.
+template <int DS, bool MASKED4 = false, bool CAREFUL = false>
 __device__ __forceinline__ void optimize_body(const BatchView& b, const NonlinearParams& prm, const BinTable& bins,
                                               const uint8_t* __restrict__ mask, const double* __restrict__ vals,
-                                              double* __restrict__ seg_times, int32_t* __restrict__ opt_status) {
+                                              double* __restrict__ seg_times, int32_t* __restrict__ opt_status,
+                                              double* careful_ws = nullptr) {
   extern __shared__ double lds[];
   MRS_TG_PHASE_MARK(0);
   int bin = 0;
 #pragma unroll
   for (int i = 1; i < 5; ++i)
-    if (i < bins.n && (int)blockIdx.x >= bins.block_begin[i]) bin = i;
-  int G = bins.group[bin];  // not const: laundered at the top of every tick, see there
-  const int q_begin = bins.q_begin[bin], q_count = bins.q_count[bin], Sb = bins.max_S[bin];
-  const int block_in_bin = (int)blockIdx.x - bins.block_begin[bin];
+    if (!CAREFUL && i < bins.n && (int)blockIdx.x >= bins.block_begin[i]) bin = i;
+  int G = CAREFUL ? 64 : bins.group[bin];  // not const: laundered at the top of every tick, see there
+  int n_listed = 0;
+  if (CAREFUL) {
+    n_listed = prm.careful_count[0] < prm.careful_cap ? prm.careful_count[0] : prm.careful_cap;
+    if ((int)blockIdx.x >= n_listed) return;
+  }
+  // (careful: the workgroup's path is entry blockIdx.x of the list, a "bin" of one path that starts at its position)
+  const int q_begin = CAREFUL ? prm.careful_list[blockIdx.x] : bins.q_begin[bin];
+  const int q_count = CAREFUL ? 1 : bins.q_count[bin], Sb = CAREFUL ? b.max_segments : bins.max_S[bin];
+  const int block_in_bin = CAREFUL ? 0 : (int)blockIdx.x - bins.block_begin[bin];
   // 64 threads: the wavefront that runs everything.  128 threads (DS = 4, one path per block): wavefront 1 is the
   // partner that runs the backward half sweeps of the two-sided evaluation and mirrors every barrier of wavefront 0.
   const bool two_wave = (DS == 4) && blockDim.x == 128;  // compile-time false for DS = 1: none of the partner code is emitted there
@@ -1038,6 +1146,7 @@ __device__ __forceinline__ void optimize_body(const BatchView& b, const Nonlinea
   int neval = 0, npairs = 0, head = 0;
   double f = 0.0, alpha = 1.0;
   bool first = true;
+  if (g == 0) tick_i[4] = 0;  // set by an evaluation whose by-product cost failed the guard
 
   while (true) {
     if (__ballot(!done) == 0ull) break;
@@ -1061,10 +1170,13 @@ __device__ __forceinline__ void optimize_body(const BatchView& b, const Nonlinea
       G = __builtin_amdgcn_readfirstlane(Gv);
     }
     double fn;
-    if (pair_ok) {
-      fn = evaluate_pair(seg, hc, pair_state, S, d, xn, gn, g, !done, pair_special);
+    if (CAREFUL) {
+      fn = evaluate_careful(mask, vals, pr.v0, S, d, xn, gn, g, !done, careful_ws, (size_t)gridDim.x * 64,
+                            blockIdx.x * 64u + (unsigned)lane);
+    } else if (pair_ok) {
+      fn = evaluate_pair(seg, hc, pair_state, S, d, xn, gn, g, !done, pair_special, tick_i + 4);
     } else {
-      fn = evaluate_objective<DS, MASKED4>(vtx, seg, hc, S, d, xn, gn, g, G, !done);
+      fn = evaluate_objective<DS, MASKED4>(vtx, seg, hc, S, d, xn, gn, g, G, !done, tick_i + 4);
       if (two_wave) __syncthreads();  // the partner's hand-over barrier
     }
     __syncthreads();
@@ -1402,7 +1514,19 @@ __device__ __forceinline__ void optimize_body(const BatchView& b, const Nonlinea
   MRS_TG_PHASE_MARK(5);
 
   if (active) {
-    for (int i = g; i < S; i += G) seg_times[pr.s0 + i] = x[i];
+    // a path whose cost failed the guard somewhere is handed to the careful re-run: listed, start times left in place
+    bool listed = false;
+    if (!CAREFUL && prm.careful_count && !bad && tick_i[4] != 0) {
+      int ok = 0;
+      if (g == 0) {
+        const int idx = atomicAdd(prm.careful_count, 1);
+        ok = idx < prm.careful_cap;
+        if (ok) prm.careful_list[idx] = q;
+      }
+      listed = __shfl(ok, (int)(threadIdx.x & ~(unsigned)(G - 1)), 64) != 0;
+    }
+    if (!listed)
+      for (int i = g; i < S; i += G) seg_times[pr.s0 + i] = x[i];
     if (g == 0) opt_status[pr.p] = bad ? -2 : ret;
   }
 }
@@ -1423,6 +1547,21 @@ __global__ __launch_bounds__(64) void optimize_compact_kernel(BatchView b, Nonli
                                                               const double* __restrict__ vals, double* __restrict__ seg_times,
                                                               int32_t* __restrict__ opt_status) {
   optimize_body<1, MASKED4>(b, prm, bins, mask, vals, seg_times, opt_status);
+}
+
+// closes a call's list of guarded paths: [2] = their number (for mrs_tg_plan_careful_count), [0] = 0 for the next call
+__global__ void careful_close_kernel(int32_t* __restrict__ careful) {
+  careful[2] = careful[0];
+  careful[0] = 0;
+}
+
+// The outer loop again, from the untouched start times, for the paths the fast kernels listed (a trial point whose
+// by-product cost failed the guard): one path per workgroup, every evaluation through primal_cost_lane.
+__global__ __launch_bounds__(64) void optimize_careful_kernel(BatchView b, NonlinearParams prm, const uint8_t* __restrict__ mask,
+                                                              const double* __restrict__ vals, double* __restrict__ seg_times,
+                                                              int32_t* __restrict__ opt_status, double* __restrict__ ws) {
+  BinTable none{};
+  optimize_body<4, false, true>(b, prm, none, mask, vals, seg_times, opt_status, ws);
 }
 
 // per-segment maxima, one (k, group) per blockIdx.y: maxima[seg * 9 + 3 (k-1) + group]
@@ -1926,6 +2065,11 @@ void nonlinear_plan_free(NonlinearPlan& nl) {
   if (nl.d_ws) (void)mrs_tg::pool_free(nl.d_ws);
   if (nl.d_opt_status) (void)mrs_tg::pool_free(nl.d_opt_status);
   if (nl.d_maxima) (void)mrs_tg::pool_free(nl.d_maxima);
+  if (nl.d_careful) (void)mrs_tg::pool_free(nl.d_careful);
+  nl.d_careful = nullptr;
+  if (nl.d_careful_ws) (void)mrs_tg::pool_free(nl.d_careful_ws);
+  nl.d_careful_ws = nullptr;
+  nl.careful_ws_doubles = 0;
   if (nl.d_dfo_vec) (void)mrs_tg::pool_free(nl.d_dfo_vec);
   if (nl.d_dfo_f) (void)mrs_tg::pool_free(nl.d_dfo_f);
   if (nl.d_dfo_state) (void)mrs_tg::pool_free(nl.d_dfo_state);
@@ -1948,6 +2092,8 @@ void nonlinear_plan_free(NonlinearPlan& nl) {
 
 static unsigned cdiv_u(long long a, long long b) { return (unsigned)((a + b - 1) / b); }
 
+constexpr int kCarefulCap = 1024;  // paths per call that can be re-run with primal costs; further ones keep the fast result
+
 static hipError_t ensure_buffers(NonlinearPlan& nl, const BatchView& b) {
   hipError_t e;
   const size_t need = linear_workspace_doubles(b);
@@ -1962,10 +2108,14 @@ static hipError_t ensure_buffers(NonlinearPlan& nl, const BatchView& b) {
     return e;
   if (!nl.d_maxima && (e = mrs_tg::pool_alloc(&nl.d_maxima, sizeof(double) * 9 * (size_t)(b.n_segments > 0 ? b.n_segments : 1))) != hipSuccess)
     return e;
+  if (!nl.d_careful) {
+    if ((e = mrs_tg::pool_alloc(&nl.d_careful, sizeof(int32_t) * (4 + kCarefulCap))) != hipSuccess) return e;
+    if ((e = hipMemset(nl.d_careful, 0, sizeof(int32_t) * 4)) != hipSuccess) return e;  // once per plan: every call leaves the counter at zero
+  }
   return hipSuccess;
 }
 
-hipError_t launch_nonlinear(NonlinearPlan& nl, const BatchView& b, const NonlinearParams& prm, const uint8_t* mask,
+hipError_t launch_nonlinear(NonlinearPlan& nl, const BatchView& b, const NonlinearParams& prm_in, const uint8_t* mask,
                             const double* vals, const double* limits, double* seg_times, double* coeffs,
                             int32_t* status, double* cost, hipStream_t stream, double sampling_dt, int sample_capacity,
                             int32_t* n_samples, double* samples, bool* sampled_out) {
@@ -1974,6 +2124,30 @@ hipError_t launch_nonlinear(NonlinearPlan& nl, const BatchView& b, const Nonline
   hipError_t e = ensure_buffers(nl, b);
   if (e != hipSuccess) return e;
   // 1. outer loop: every bin in one launch
+  NonlinearParams prm = prm_in;
+  const bool careful = prm_in.careful_cap != 0;  // the caller asked for the careful re-run (MRS_TG_FLAG_CAREFUL_COST)
+  int careful_cap = 0;
+  if (careful) {
+    // as many paths per call as a 2 GB factor store holds (64 lanes x S vertices x 30 doubles each), at most kCarefulCap
+    const size_t per_path = (size_t)64 * (size_t)b.max_segments * ws_per_vertex<1>();
+    careful_cap = (int)std::min<size_t>((size_t)kCarefulCap, std::max<size_t>((size_t)16, ((size_t)1 << 28) / per_path));
+    careful_cap = std::min(careful_cap, b.n_paths);
+    const size_t need = per_path * (size_t)careful_cap;
+    if (nl.careful_ws_doubles < need) {
+      if (nl.d_careful_ws) (void)mrs_tg::pool_free(nl.d_careful_ws);
+      nl.d_careful_ws = nullptr;
+      nl.careful_ws_doubles = 0;
+      if ((e = mrs_tg::pool_alloc(&nl.d_careful_ws, need * sizeof(double))) != hipSuccess) return e;
+      nl.careful_ws_doubles = need;
+    }
+    prm.careful_count = nl.d_careful;
+    prm.careful_list = nl.d_careful + 4;
+    prm.careful_cap = careful_cap;
+  } else {
+    prm.careful_count = nullptr;
+    prm.careful_list = nullptr;
+    prm.careful_cap = 0;
+  }
   {
     BinTable bt{};
     bt.n = (int)nl.bins.size();
@@ -2018,6 +2192,18 @@ hipError_t launch_nonlinear(NonlinearPlan& nl, const BatchView& b, const Nonline
       MRS_TG_LAUNCH_TIMED(optimize_compact_kernel<false>, dim3(blocks), dim3(64), lds_bytes, stream, b, prm, bt, mask, vals,
                           seg_times, nl.d_opt_status);
     if ((e = hipGetLastError()) != hipSuccess) return e;
+    if (careful) {
+      const size_t clds = ((size_t)group_lds_doubles(b.max_segments, true) + kBlockConsts) * sizeof(double);
+      if (clds > 160 * 1024) return hipErrorInvalidValue;
+      if (clds > 64 * 1024 &&
+          (e = hipFuncSetAttribute((const void*)optimize_careful_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)clds)) != hipSuccess)
+        return e;
+      hipLaunchKernelGGL(optimize_careful_kernel, dim3(careful_cap), dim3(64), clds, stream, b, prm, mask, vals, seg_times,
+                         nl.d_opt_status, nl.d_careful_ws);
+      if ((e = hipGetLastError()) != hipSuccess) return e;
+      hipLaunchKernelGGL(careful_close_kernel, dim3(1), dim3(1), 0, stream, nl.d_careful);
+      if ((e = hipGetLastError()) != hipSuccess) return e;
+    }
   }
   // 2. trajectory of the last evaluated point (scaleSegmentTimesWithViolation works on poly_opt_'s state)
   if ((e = launch_solve_linear(b, prm.derivative, true, mask, vals, seg_times, nullptr, nullptr, nl.d_ws, coeffs, nullptr,

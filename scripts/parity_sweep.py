@@ -22,7 +22,8 @@ ctx = api.Context(0)
 seed0 = int(os.environ.get("SEED0", "0"))  # other seeds: other paths
 batch = pr.random_mixed_batch(P, deriv, seed0=seed0) if gen == "mixed" else pr.random_batch(P, n_seg, seed0=seed0, derivative_to_optimize=deriv, generator=gen)
 cap = 256
-out = ctx.solve_batch(batch, None, time_alloc_method=mode, sampling_dt=0.2, sample_capacity=cap)
+flags = api.FLAG_CAREFUL_COST if os.environ.get("CAREFUL") == "1" else 0  # CAREFUL=1: with the careful re-run of guarded paths
+out = ctx.solve_batch(batch, None, time_alloc_method=mode, sampling_dt=0.2, sample_capacity=cap, flags=flags)
 t0 = time.time()
 cache = os.environ.get("PARITY_CACHE")  # oracle results of an identical earlier invocation (threshold experiments)
 if cache and os.path.exists(cache):
@@ -40,7 +41,7 @@ dt = np.array([np.max(np.abs(out["times"][a:b] - ref["times"][a:b]) / ref["times
 dc = np.array([np.max(np.abs(out["coeffs"][a:b] - ref["coeffs"][a:b])) / np.max(np.abs(ref["coeffs"][a:b]))
                for a, b in zip(so[:-1], so[1:])])
 ns_same = out["n_samples"] == np.minimum(ref["n_samples"], cap + 1)
-print("paths %d  segments %s  d=%d  generator %s  mode %d" % (P, n_seg, deriv, gen, mode))
+print("paths %d  segments %s  d=%d  generator %s  mode %d%s" % (P, n_seg, deriv, gen, mode, "  careful re-run" if flags else ""))
 print("status equal: %.4f %%   statuses gpu %s" % (100 * same_status.mean(), dict(zip(*np.unique(out["status"], return_counts=True)))))
 for tol in (1e-9, 1e-6, 1e-3):
     print("  times within %.0e: %.4f %%   coeffs within %.0e: %.4f %%" % (tol, 100 * (dt < tol).mean(), tol, 100 * (dc < tol).mean()))

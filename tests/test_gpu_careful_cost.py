@@ -1,0 +1,91 @@
+"""MRS_TG_FLAG_CAREFUL_COST: the paths whose fast cost evaluation (the elimination's by-product 0.5 (qf - red)) failed its
+guard are run again with the cost the reference computes, 0.5 c^T Q c from the coefficients
+(/root/reference/include/eth_trajectory_generation/impl/polynomial_optimization_linear_impl.h:128-141), and then follow
+the oracle; every other path is untouched."""
+import numpy as np
+import pytest
+
+from mrs_uav_trajectory_generation_amd import api, problem as pr
+from oracle import pyoracle as po
+from tests import util
+
+pytestmark = pytest.mark.gpu
+NO_LIMITS = np.full(9, 1e9)  # feasibility scaling off: the returned times are the outer loop's own
+
+
+def _both(ctx, batch, t0):  # (the batch carries its objective order)
+    out = {}
+    for name, fl in (("fast", 0), ("careful", api.FLAG_CAREFUL_COST)):
+        out[name] = ctx.solve_batch(batch, t0.copy(), time_alloc_method=api.TIME_ALLOC_MELLINGER, flags=fl)
+    so = batch.seg_offsets
+    changed = [p for p in range(batch.n_paths)
+               if out["fast"]["status"][p] != out["careful"]["status"][p]
+               or not np.array_equal(out["fast"]["times"][so[p]:so[p + 1]], out["careful"]["times"][so[p]:so[p + 1]])]
+    return out, changed
+
+
+def test_guarded_paths_follow_the_oracle_and_the_others_are_untouched(gpu_ctx):
+    P = 8192
+    batch = pr.random_batch(P, 10, seed0=0, limits=NO_LIMITS)
+    t0 = util.oracle_times(pr.random_batch(P, 10, seed0=0))  # the Euclidean estimate under the default limits
+    out, changed = _both(gpu_ctx, batch, t0)
+    so = batch.seg_offsets
+    assert 10 <= len(changed) <= 80, len(changed)  # ~0.4 % of random 10-segment paths reach the 0.01 s bound on some trial
+    # the re-run paths are exactly the ones that changed (their cost differs in the last digits in every evaluation)
+    plan_count = None
+    plan = api.Plan(gpu_ctx, batch.seg_offsets)
+    db = api.DeviceBatch(batch, "cuda:0", sample_capacity=16)
+    import torch
+    db.seg_times.copy_(torch.from_numpy(t0))
+    opt = api.default_options(time_alloc_method=api.TIME_ALLOC_MELLINGER, flags=api.FLAG_CAREFUL_COST)
+    plan.solve(opt, db.fixed_mask, db.fixed_values, db.seg_times, db.coeffs, db.status, db.cost, limits=db.limits)
+    plan_count = plan.careful_count()
+    plan.close()
+    assert plan_count == len(changed)
+    worst_fast = worst_careful = 0.0
+    for p in changed:
+        _, m, v = batch.path(p)
+        rc, t, ne, fc = po.optimize_times(4, m, v, t0[so[p]:so[p + 1]], po.default_nlopt(10))
+        assert out["careful"]["status"][p] == rc
+        d_careful = np.max(np.abs(out["careful"]["times"][so[p]:so[p + 1]] - t) / t)
+        d_fast = np.max(np.abs(out["fast"]["times"][so[p]:so[p + 1]] - t) / t)
+        assert d_careful < 1e-6, (p, d_careful)
+        worst_fast, worst_careful = max(worst_fast, d_fast), max(worst_careful, d_careful)
+    # at least one of them is a path the fast evaluation sends elsewhere (path 4841 of this batch: 7e-6 against 1e-8)
+    assert worst_fast > 1e-6 > worst_careful, (worst_fast, worst_careful)
+    # solved trajectories of the re-run paths are complete and consistent
+    assert np.all(np.isfinite(out["careful"]["coeffs"])) and util.continuity_defect(batch, out["careful"]["coeffs"], out["careful"]["times"]) < 1e-6
+
+
+@pytest.mark.parametrize("d", [4, 2])
+def test_careful_rerun_on_mixed_constraint_patterns(gpu_ctx, d):
+    """Moving starts, stop_at vertices, 1..30 segments, both generators: the careful evaluation is the general elimination,
+    so every pattern the fast kernels take is re-run the same way; listed paths end where the oracle ends."""
+    P = 4096
+    batch = pr.random_mixed_batch(P, d, seed0=0)
+    batch.limits[:] = NO_LIMITS
+    ref_batch = pr.random_mixed_batch(P, d, seed0=0)
+    t0 = util.oracle_times(ref_batch)
+    out, changed = _both(gpu_ctx, batch, t0)
+    so = batch.seg_offsets
+    if d == 4:
+        assert len(changed) >= 3
+    agree = 0
+    for p in changed:
+        _, m, v = batch.path(p)
+        rc, t, ne, fc = po.optimize_times(d, m, v, t0[so[p]:so[p + 1]], po.default_nlopt(10))
+        assert out["careful"]["status"][p] == rc, p
+        agree += np.max(np.abs(out["careful"]["times"][so[p]:so[p + 1]] - t) / t) < 1e-6
+    assert agree >= len(changed) - 1, (agree, len(changed))  # (a chaotic path may still branch on a 1e-9 difference in J)
+    same = [p for p in range(P) if p not in set(changed)]
+    assert len(same) >= P - 60
+
+
+def test_flag_is_a_no_op_outside_mellinger_mode(gpu_ctx):
+    batch = pr.random_batch(64, 6, seed0=3)
+    a = gpu_ctx.solve_batch(batch, None)
+    b = gpu_ctx.solve_batch(batch, None, flags=api.FLAG_CAREFUL_COST)
+    assert np.array_equal(a["coeffs"], b["coeffs"])
+    a = gpu_ctx.solve_batch(batch, None, time_alloc_method=api.TIME_ALLOC_RICHTER_TIME)
+    b = gpu_ctx.solve_batch(batch, None, time_alloc_method=api.TIME_ALLOC_RICHTER_TIME, flags=api.FLAG_CAREFUL_COST)
+    assert np.array_equal(a["times"], b["times"])
