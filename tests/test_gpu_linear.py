@@ -8,6 +8,8 @@ time-normalised constants and is closer to the exact answer than the reference-s
                                 reaches 3.4e-8 on the short-time golden case), and within the oracle's own
                                 distance to the exact answer on every golden case
 """
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -71,7 +73,8 @@ def test_linear_golden_cases(gpu_ctx, golden, fused):
         if case["name"] == "bench1024_path74_short_segment":
             # (cost: the fused kernel evaluates 0.5 c^T Q c, 1e-10 here; the blocks kernel's elimination by-product
             # 0.5 (f^T H f - sum |z|^2) loses the digits the conditioning takes, 1e-8)
-            assert abs(out["cost"][0] - case["cost"]) <= (1e-9 if fused else 1e-7) * abs(case["cost"])
+            primal = fused and os.environ.get("MRS_TG_ROWS_KERNEL") != "0"  # (the diagnostic knob sends "fused" to the tile kernel)
+            assert abs(out["cost"][0] - case["cost"]) <= (1e-9 if primal else 1e-7) * abs(case["cost"])
             # The path behind bench.py's max_coeff_err_vs_cpu_ref: a 0.23 s segment between 8.9 s and 4.4 s ones puts
             # (8.9 / 0.23)^7 = 1e11 between neighbouring blocks of R_pp, and no double-precision route reaches 1e-11 here.
             # Measured against the 60-digit solution: HIP 2e-9 (fused) / 4e-9 (materialised blocks), oracle 2.5e-8 -- the
