@@ -18,6 +18,7 @@ struct NonlinearParams {
   // (optimize_careful_kernel): position q of the path appended to careful_list (capacity careful_cap) through
   // careful_count; a listed path keeps its start times.  nullptr: no list (the fast kernel's result stands).  A caller of
   // launch_nonlinear only sets careful_cap != 0 to ask for the re-run; the launcher fills in the rest.
+  const int32_t* only_flagged = nullptr;  // sweeping kernels: run the paths whose entry (by position) is non-zero only
   int32_t* careful_count = nullptr;
   int32_t* careful_list = nullptr;
   int careful_cap = 0;
@@ -51,6 +52,7 @@ struct NonlinearPlan {
   size_t ws_doubles = 0;
   int32_t* d_opt_status = nullptr; // stopping reason of the outer loop per path
   double* d_maxima = nullptr;      // [n_segments][9] per-segment maxima
+  int32_t* d_fallback = nullptr;   // [n_paths] by position: 1 = the prefix / suffix kernel left the path to the sweeping kernel
   int32_t* d_careful = nullptr;    // [0] count, [2] count of the last completed call, [4..] list of guarded paths
   double* d_careful_ws = nullptr;  // factor store of optimize_careful_kernel's lanes
   size_t careful_ws_doubles = 0;
