@@ -1787,6 +1787,56 @@ __global__ void careful_close_kernel(int32_t* __restrict__ careful) {
   careful[0] = 0;
 }
 
+// ---- lean sweeps (large batches of plain paths) --------------------------------------------------------------------
+// The sweeping evaluation of evaluate_objective<1> for plain paths only (start | interior ... | end): the block constants
+// come from the LDS table, the brackets from dp on the fly, and nothing of the general step is compiled in -- which is what
+// keeps the kernel at <= 256 VGPRs, i.e. TWO wavefronts per SIMD where optimize_compact_kernel (436 VGPRs) has one.  The
+// kernels are bound by the dependent chain of a step, not by issue: the second wavefront runs in
+// the first one's idle issue slots.  Lane k of a group of G sweeps time vector k (k, k + G, ... when S + 1 > G).
+__host__ __device__ constexpr int lean_eval_doubles(int Sb) { return 4 * Sb + 4 * (Sb + 1); }  // dp, staging area
+
+__device__ __forceinline__ double evaluate_lean(const double* tabs, const double* ev, int S, int d, const double* pt,
+                                                double* grad, int g, int G, bool active, int* tripped) {
+  const double* dp = ev;
+  const double* tab = tabs;  // left-to-right table
+  const double corr = kGradStep / ((double)S - 1.0);
+  double J0 = 0.0;
+  const int g_shift = __builtin_ctz((unsigned)G);  // G is a power of two
+  const int rounds = (S + G) >> g_shift;
+  for (int r = 0; r < rounds; ++r) {
+    const int k = g + (r << g_shift);
+    double Jk = 0.0, qfk = 0.0;
+    if (active && k <= S && (k == 0 || S > 1)) {
+      Elim<4> st;
+      st.init();
+      // (the brackets as a 36-double array per step: forming them where they are consumed instead brings the kernel from
+      // 256 VGPRs + 41 spilled to 204 without spills and makes it 5 % slower -- measured, 65536 x 10: 848 vs 896 us)
+      for (int i = 0; i < S; ++i) {
+        double p2[9];
+        segment_powers(perturbed_time(pt, i, k, corr), d, p2);
+        FastStep<4> fast;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const double dq = dp[i * 4 + q];
+#pragma unroll
+          for (int j = 0; j < 8; ++j) fast.w[q][j] = tab[36 + j] * dq;
+          fast.w[q][8] = tab[44] * dq * dq;
+        }
+        if (i == 0) fast.template start_t<false>(st, tab, p2);
+        else if (i < S - 1) fast.template interior_t<false>(st, tab, p2);
+        else fast.end(st, tab, p2);
+      }
+      Jk = 0.5 * (st.qf - st.red);
+      qfk = st.qf;
+    }
+    Jk = guarded_cost(Jk, qfk, k == 0);
+    if (tripped && active && k <= S && Jk == kUnreliableCost) *tripped = 1;
+    if (r == 0) J0 = __shfl(Jk, (int)(threadIdx.x & ~(unsigned)(G - 1)), 64);
+    if (active && k >= 1 && k <= S) grad[k - 1] = (S > 1) ? (Jk - J0) / kGradStep : 0.0;
+  }
+  return J0;
+}
+
 // ---- the outer loop on the prefix / suffix evaluation -----------------------------------------------------------
 // Groups of 8 lanes, 8 paths per wavefront.  The optimiser's vectors live in LDS and a lane owns the elements g, g + 8, ...
 // (the general bookkeeping of optimize_body, same arithmetic).  A path the evaluation does not take (not plain, S < 4) is
@@ -1795,15 +1845,18 @@ __global__ void careful_close_kernel(int32_t* __restrict__ careful) {
 __host__ __device__ constexpr int ps_group_doubles(int Sb) {
   return (5 + 2 * kLbfgsM) * Sb + (kLbfgsM + 1) + kTickState + ps_eval_doubles(Sb);
 }
+__host__ __device__ constexpr int lean_group_doubles(int Sb) {
+  return (5 + 2 * kLbfgsM) * Sb + (kLbfgsM + 1) + kTickState + lean_eval_doubles(Sb);
+}
 
 // positions -> dp of every segment; returns whether the path is one the evaluation takes (group-uniform)
 __device__ __forceinline__ bool stage_ps(const uint8_t* __restrict__ mask, const double* __restrict__ vals, int v0, int S,
-                                         int Sb, double* ev, int g, bool active) {
+                                         int Sb, double* ev, int g, int G, bool active, int min_segments) {
   double* dp = ev;
   double* tmp = ev + 4 * (size_t)Sb;  // the record area, not in use yet
-  int ok = (S >= 4) ? 1 : 0;
+  int ok = (S >= min_segments) ? 1 : 0;
   if (active)
-    for (int v = g; v <= S; v += kPsGroup) {
+    for (int v = g; v <= S; v += G) {
       double f[kHalf][kD];
       bool pf;
       const unsigned fb = load_vertex<kD>(mask, vals, v0 + v, 0, f, pf);
@@ -1817,25 +1870,27 @@ __device__ __forceinline__ bool stage_ps(const uint8_t* __restrict__ mask, const
 #pragma unroll
       for (int q = 0; q < kD; ++q) tmp[v * 4 + q] = f[0][q];
     }
-  const bool all_ok = group_and(ok, kPsGroup) != 0;
+  const bool all_ok = group_and(ok, G) != 0;
   ps_wave_sync();
   if (active)
-    for (int i = g; i < S; i += kPsGroup)
+    for (int i = g; i < S; i += G)
 #pragma unroll
       for (int q = 0; q < kD; ++q) dp[i * 4 + q] = tmp[i * 4 + q] - tmp[(i + 1) * 4 + q];
   ps_wave_sync();
   return all_ok;
 }
 
-__global__ __launch_bounds__(64) void optimize_ps_kernel(BatchView b, NonlinearParams prm, int q_begin, int q_count, int Sb,
-                                                         const uint8_t* __restrict__ mask, const double* __restrict__ vals,
-                                                         double* __restrict__ seg_times, int32_t* __restrict__ opt_status,
-                                                         int32_t* __restrict__ fallback) {
+// ROLES: the prefix / suffix evaluation (G = 8); otherwise the lean sweeps (G = the bin's group size)
+template <bool ROLES>
+__device__ __forceinline__ void plain_body(const BatchView& b, const NonlinearParams& prm, int G, int q_begin, int q_count, int Sb,
+                                           int block_in_bin, const uint8_t* __restrict__ mask, const double* __restrict__ vals,
+                                           double* __restrict__ seg_times, int32_t* __restrict__ opt_status,
+                                           int32_t* __restrict__ fallback) {
   extern __shared__ double lds[];
-  constexpr int G = kPsGroup;
   const int lane = threadIdx.x;
-  const int g = lane & (G - 1), grp = lane >> 3;
-  const int qi = (int)blockIdx.x * (64 / G) + grp;
+  const int g_shift = __builtin_ctz((unsigned)G);  // G is a power of two
+  const int g = lane & (G - 1), grp = lane >> g_shift;
+  const int qi = block_in_bin * (64 >> g_shift) + grp;
   bool active = qi < q_count;
   const int q = q_begin + (active ? qi : 0);
   const PathRef pr = path_at(b, q);
@@ -1843,7 +1898,7 @@ __global__ __launch_bounds__(64) void optimize_ps_kernel(BatchView b, NonlinearP
   const int d = prm.derivative;
   double* tabs = lds;
   stage_ps_tables(d, tabs, lane, 64);
-  double* base = lds + 2 * kPsTable + (size_t)grp * ps_group_doubles(Sb);
+  double* base = lds + 2 * kPsTable + (size_t)grp * (ROLES ? ps_group_doubles(Sb) : lean_group_doubles(Sb));
   double* x = base;
   double* gr = x + Sb;
   double* xn = gr + Sb;
@@ -1860,7 +1915,7 @@ __global__ __launch_bounds__(64) void optimize_ps_kernel(BatchView b, NonlinearP
 #pragma unroll
   for (int off = 32; off >= 1; off >>= 1) Smax = max(Smax, __shfl_xor(Smax, off, 64));
   Smax = __builtin_amdgcn_readfirstlane(Smax);
-  const bool takes = stage_ps(mask, vals, pr.v0, S, Sb, ev, g, active);
+  const bool takes = stage_ps(mask, vals, pr.v0, S, Sb, ev, g, G, active, ROLES ? 4 : 2);
   if (active && g == 0) fallback[q] = takes ? 0 : 1;
   active = active && takes;
 
@@ -1889,7 +1944,8 @@ __global__ __launch_bounds__(64) void optimize_ps_kernel(BatchView b, NonlinearP
 
   while (true) {
     if (__ballot(!done) == 0ull) break;
-    const double fn = evaluate_ps(tabs, ev, S, Sb, Smax, d, xn, gn, g, !done, tick_i + 4);
+    const double fn = ROLES ? evaluate_ps(tabs, ev, S, Sb, Smax, d, xn, gn, g, !done, tick_i + 4)
+                            : evaluate_lean(tabs, ev, S, d, xn, gn, g, G, !done, tick_i + 4);
     ps_wave_sync();
     timed_out = t_deadline != 0ll && (long long)wall_clock64() > t_deadline;
     bool new_dir = false;
@@ -2054,6 +2110,26 @@ __global__ __launch_bounds__(64) void optimize_ps_kernel(BatchView b, NonlinearP
   }
 }
 
+__global__ __launch_bounds__(64, 2) void optimize_ps_kernel(BatchView b, NonlinearParams prm, int q_begin, int q_count, int Sb,
+                                                            const uint8_t* __restrict__ mask, const double* __restrict__ vals,
+                                                            double* __restrict__ seg_times, int32_t* __restrict__ opt_status,
+                                                            int32_t* __restrict__ fallback) {
+  plain_body<true>(b, prm, kPsGroup, q_begin, q_count, Sb, (int)blockIdx.x, mask, vals, seg_times, opt_status, fallback);
+}
+
+// every bin in one launch, as the sweeping kernels
+__global__ __launch_bounds__(64, 2) void optimize_lean_kernel(BatchView b, NonlinearParams prm, BinTable bins,
+                                                              const uint8_t* __restrict__ mask, const double* __restrict__ vals,
+                                                              double* __restrict__ seg_times, int32_t* __restrict__ opt_status,
+                                                              int32_t* __restrict__ fallback) {
+  int bin = 0;
+#pragma unroll
+  for (int i = 1; i < 5; ++i)
+    if (i < bins.n && (int)blockIdx.x >= bins.block_begin[i]) bin = i;
+  plain_body<false>(b, prm, bins.group[bin], bins.q_begin[bin], bins.q_count[bin], bins.max_S[bin],
+                    (int)blockIdx.x - bins.block_begin[bin], mask, vals, seg_times, opt_status, fallback);
+}
+
 // The outer loop again, from the untouched start times, for the paths the fast kernels listed (a trial point whose
 // by-product cost failed the guard): one path per workgroup, every evaluation through primal_cost_lane.
 __global__ __launch_bounds__(64) void optimize_careful_kernel(BatchView b, NonlinearParams prm, const uint8_t* __restrict__ mask,
@@ -2160,7 +2236,7 @@ __global__ __launch_bounds__(64) void cost_gradient_ps_kernel(BatchView b, int d
 #pragma unroll
   for (int off = 32; off >= 1; off >>= 1) Smax = max(Smax, __shfl_xor(Smax, off, 64));
   Smax = __builtin_amdgcn_readfirstlane(Smax);
-  const bool takes = stage_ps(mask, vals, pr.v0, pr.S, Sb, ev, g, active);
+  const bool takes = stage_ps(mask, vals, pr.v0, pr.S, Sb, ev, g, kPsGroup, active, 4);
   if (active && g == 0) fallback[q] = takes ? 0 : 1;
   active = active && takes;
   if (active)
@@ -2570,7 +2646,9 @@ __global__ __launch_bounds__(64) void dfo_segment_path_kernel(BatchView b, int32
 // split the four dimensions over lanes while the batch is too small to fill the machine otherwise
 static int dim_split_for(int n_paths) {
   if (const char* e = std::getenv("MRS_TG_DIM_SPLIT_MAX_PATHS")) return n_paths <= std::atoi(e) ? 4 : 1;  // tuning knob
-  return n_paths <= 3072 ? 4 : 1;  // measured cross-over (scripts/sweep_dim_split.sh): 3072 paths 319 vs 354 us, 4096 paths 382 vs 361 us
+  // measured cross-over against the lean kernel of large batches (scripts/ps_step.py with MRS_TG_DIM_SPLIT_MAX_PATHS=0):
+  // outer-loop kernel 2048 paths 122 vs 143 us, 3072 paths 160 vs 150 us
+  return n_paths <= 2560 ? 4 : 1;
 }
 
 static int group_for(int S, int ds) {
@@ -2664,6 +2742,12 @@ static bool ps_applies(const NonlinearPlan&) {
   return false;
 }
 
+// Lean sweeps for plain paths (optimize_lean_kernel): two wavefronts per SIMD where the general sweeping kernel has one.  Tuning / test knob: MRS_TG_LEAN=0|1.
+static bool lean_applies(const NonlinearPlan& nl) {
+  if (const char* e = std::getenv("MRS_TG_LEAN")) return std::atoi(e) != 0;
+  return nl.dim_split == 1;
+}
+
 static hipError_t ensure_fallback(NonlinearPlan& nl, const BatchView& b) {
   if (nl.d_fallback) return hipSuccess;
   return mrs_tg::pool_alloc(&nl.d_fallback, sizeof(int32_t) * (size_t)(b.n_paths > 0 ? b.n_paths : 1));
@@ -2702,15 +2786,21 @@ hipError_t launch_nonlinear(NonlinearPlan& nl, const BatchView& b, const Nonline
     prm.careful_list = nullptr;
     prm.careful_cap = 0;
   }
-  // 1a. the prefix / suffix kernel takes every path it can (plain, S >= 4) and flags the others for the sweeping kernel
-  bool ps = ps_applies(nl);
-  if (ps)
+  // 1a. a plain-path kernel (lean sweeps, or the prefix / suffix evaluation) takes every path it can and flags the others
+  // for the sweeping kernel below
+  int plain_mode = ps_applies(nl) ? 1 : (lean_applies(nl) ? 2 : 0);
+  if ((int)nl.bins.size() > 5) plain_mode = 0;
+  auto plain_lds = [&](const NonlinearBin& bin) {
+    return plain_mode == 1 ? ((size_t)(64 / kPsGroup) * ps_group_doubles(bin.max_S) + 2 * kPsTable) * sizeof(double)
+                           : ((size_t)(64 / bin.group) * lean_group_doubles(bin.max_S) + 2 * kPsTable) * sizeof(double);
+  };
+  if (plain_mode)
     for (const NonlinearBin& bin : nl.bins)
-      if (((size_t)(64 / kPsGroup) * ps_group_doubles(bin.max_S) + 2 * kPsTable) * sizeof(double) > 160 * 1024) ps = false;
-  if (ps) {
+      if (plain_lds(bin) > 160 * 1024) plain_mode = 0;
+  if (plain_mode == 1) {
     if ((e = ensure_fallback(nl, b)) != hipSuccess) return e;
     for (const NonlinearBin& bin : nl.bins) {
-      const size_t plds = ((size_t)(64 / kPsGroup) * ps_group_doubles(bin.max_S) + 2 * kPsTable) * sizeof(double);
+      const size_t plds = plain_lds(bin);
       if (plds > 64 * 1024 &&
           (e = hipFuncSetAttribute((const void*)optimize_ps_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)plds)) != hipSuccess)
         return e;
@@ -2718,6 +2808,29 @@ hipError_t launch_nonlinear(NonlinearPlan& nl, const BatchView& b, const Nonline
                           bin.q_begin, bin.q_count, bin.max_S, mask, vals, seg_times, nl.d_opt_status, nl.d_fallback);
       if ((e = hipGetLastError()) != hipSuccess) return e;
     }
+    prm.only_flagged = nl.d_fallback;
+  } else if (plain_mode == 2) {
+    if ((e = ensure_fallback(nl, b)) != hipSuccess) return e;
+    BinTable bt{};
+    bt.n = (int)nl.bins.size();
+    size_t plds = 0;
+    int blocks = 0;
+    for (int i = 0; i < bt.n; ++i) {
+      const NonlinearBin& bin = nl.bins[i];
+      bt.group[i] = bin.group;
+      bt.q_begin[i] = bin.q_begin;
+      bt.q_count[i] = bin.q_count;
+      bt.max_S[i] = bin.max_S;
+      bt.block_begin[i] = blocks;
+      blocks += (int)cdiv_u(bin.q_count, 64 / bin.group);
+      plds = std::max(plds, plain_lds(bin));
+    }
+    if (plds > 64 * 1024 &&
+        (e = hipFuncSetAttribute((const void*)optimize_lean_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)plds)) != hipSuccess)
+      return e;
+    MRS_TG_LAUNCH_TIMED(optimize_lean_kernel, dim3(blocks), dim3(64), plds, stream, b, prm, bt, mask, vals, seg_times,
+                        nl.d_opt_status, nl.d_fallback);
+    if ((e = hipGetLastError()) != hipSuccess) return e;
     prm.only_flagged = nl.d_fallback;
   }
   {
