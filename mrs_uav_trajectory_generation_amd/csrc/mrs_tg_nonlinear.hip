@@ -592,6 +592,19 @@ __device__ __forceinline__ void half_sweep(const double* seg, const double* hc, 
 // largest of {end points, grid points, polished maxima}.  Every candidate is a true value of the
 // function, so the result never exceeds the exact maximum.
 
+// cross-lane moves (DPP within a row of 16, v_readlane across rows)
+template <int CTRL>
+__device__ __forceinline__ double dpp_move(double v) {
+  const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xF, 0xF, false);
+  const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xF, 0xF, false);
+  return __hiloint2double(hi, lo);
+}
+
+__device__ __forceinline__ double row_value(double v, int src_lane) {
+  const int lo = __builtin_amdgcn_readlane(__double2loint(v), src_lane), hi = __builtin_amdgcn_readlane(__double2hiint(v), src_lane);
+  return __hiloint2double(hi, lo);
+}
+
 constexpr int kGridCells = 32;
 constexpr int kPolishIters = 17;
 
@@ -661,18 +674,24 @@ struct MagPoly {
 // maximum inside).  Pass 2 polishes the recorded cells.  Keeping the two apart matters on a 64-wide
 // wavefront: lanes hold different polynomials, and polishing inside the grid loop would make every lane
 // wait for a Newton loop in almost every cell.
-template <int K, int NDIM>
-__device__ __forceinline__ double max_mag2(const double (&cb)[NDIM][kN]) {
-  static_assert(kGridCells <= 32, "cell mask is 32 bits");
+// PARTS lanes share one polynomial: lane `part` takes the grid cells [part * 32 / PARTS, (part + 1) * 32 / PARTS) -- the same
+// grid points and the same polished cells as one lane walking all 32, so the maximum over the PARTS lanes (taken by the
+// caller) is the same number; the dependent work of a lane, and with it the time a wavefront waits for its slowest lane's
+// Newton loops, is PARTS times shorter.
+template <int K, int NDIM, int PARTS = 1>
+__device__ __forceinline__ double max_mag2(const double (&cb)[NDIM][kN], int part = 0) {
+  static_assert(kGridCells <= 32 && kGridCells % PARTS == 0, "cell mask is 32 bits");
+  constexpr int kCells = kGridCells / PARTS;
   MagPoly<K, NDIM> mp;
   mp.init(cb);
+  const double h = 1.0 / kGridCells;
+  const int i0 = part * kCells;
   double m2, g;
-  mp.eval(0.0, m2, g);
+  mp.eval(i0 * h, m2, g);  // (i0 = 0: tau = 0 exactly)
   double best = m2;
   double g_prev = g;
-  const double h = 1.0 / kGridCells;
   unsigned cells = 0u;
-  for (int i = 1; i <= kGridCells; ++i) {
+  for (int i = i0 + 1; i <= i0 + kCells; ++i) {
     const double tau = (i == kGridCells) ? 1.0 : i * h;
     mp.eval(tau, m2, g);
     best = fmax(best, m2);
@@ -708,7 +727,8 @@ __device__ __forceinline__ double max_mag2(const double (&cb)[NDIM][kN]) {
 }
 
 // which = 3*(k-1) + group: maximum of |p^(k)| over [0, T] for one (k, group) of one segment
-__device__ __forceinline__ double segment_maximum(const double* __restrict__ c, double T, int which) {
+template <int PARTS = 1>
+__device__ __forceinline__ double segment_maximum(const double* __restrict__ c, double T, int which, int part = 0) {
   const int k = which / 3 + 1, grp = which % 3;
   double tp = 1.0;
   const double ti = 1.0 / T;
@@ -724,7 +744,7 @@ __device__ __forceinline__ double segment_maximum(const double* __restrict__ c, 
       cb[1][j] = c[1 * kN + j] * tp;
       tp *= T;
     }
-    m2 = (k == 1) ? max_mag2<1, 2>(cb) : (k == 2) ? max_mag2<2, 2>(cb) : max_mag2<3, 2>(cb);
+    m2 = (k == 1) ? max_mag2<1, 2, PARTS>(cb, part) : (k == 2) ? max_mag2<2, 2, PARTS>(cb, part) : max_mag2<3, 2, PARTS>(cb, part);
   } else {
     double cb[1][kN];
     const int dim = (grp == 1) ? 2 : 3;
@@ -733,7 +753,11 @@ __device__ __forceinline__ double segment_maximum(const double* __restrict__ c, 
       cb[0][j] = c[dim * kN + j] * tp;
       tp *= T;
     }
-    m2 = (k == 1) ? max_mag2<1, 1>(cb) : (k == 2) ? max_mag2<2, 1>(cb) : max_mag2<3, 1>(cb);
+    m2 = (k == 1) ? max_mag2<1, 1, PARTS>(cb, part) : (k == 2) ? max_mag2<2, 1, PARTS>(cb, part) : max_mag2<3, 1, PARTS>(cb, part);
+  }
+  if (PARTS == 4) {  // the four lanes of a quad share the polynomial
+    m2 = fmax(m2, dpp_move<0xB1>(m2));
+    m2 = fmax(m2, dpp_move<0x4E>(m2));
   }
   return sqrt(m2) * scale;
 }
@@ -745,18 +769,6 @@ __device__ __forceinline__ double segment_maximum(const double* __restrict__ c, 
 // (__shfl_xor) cost ~700 shader cycles per 64-lane reduction; DPP moves inside a row of 16 lanes and v_readlane
 // across rows cost ~150.  Every lane of a group receives the bit-identical sum (each step adds the same two partial
 // sums on both sides), which the control flow relies on.
-template <int CTRL>
-__device__ __forceinline__ double dpp_move(double v) {
-  const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xF, 0xF, false);
-  const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xF, 0xF, false);
-  return __hiloint2double(hi, lo);
-}
-
-__device__ __forceinline__ double row_value(double v, int src_lane) {
-  const int lo = __builtin_amdgcn_readlane(__double2loint(v), src_lane), hi = __builtin_amdgcn_readlane(__double2hiint(v), src_lane);
-  return __hiloint2double(hi, lo);
-}
-
 __device__ __forceinline__ double group_sum(double v, int G) {
   v += dpp_move<0xB1>(v);                 // quad_perm [1,0,3,2]: lane ^ 1
   if (G >= 4) v += dpp_move<0x4E>(v);     // quad_perm [2,3,0,1]: lane ^ 2
@@ -1277,7 +1289,10 @@ __device__ __forceinline__ void optimize_body(const BatchView& b, const Nonlinea
   const int qi = block_in_bin * per_block + grp;
   bool active = qi < q_count;
   const int q = q_begin + (active ? qi : 0);
-  if (!CAREFUL && prm.only_flagged) active = active && prm.only_flagged[q] != 0;  // the prefix / suffix kernel took the others
+  if (!CAREFUL && prm.only_flagged) {  // the plain-path kernel in front of this launch took the other paths
+    active = active && prm.only_flagged[q] != 0;
+    if (!__syncthreads_or(active ? 1 : 0)) return;  // (an all-plain batch: every workgroup ends here)
+  }
   const PathRef pr = path_at(b, q);
   int S = pr.S;
   const int d = prm.derivative;
@@ -2143,10 +2158,14 @@ __global__ __launch_bounds__(64) void optimize_careful_kernel(BatchView b, Nonli
 __global__ __launch_bounds__(64) void segment_maxima9_kernel(int n_segments, const double* __restrict__ coeffs,
                                                              const double* __restrict__ seg_times,
                                                              double* __restrict__ maxima) {
-  const int s = blockIdx.x * 64 + threadIdx.x;
-  if (s >= n_segments) return;
+  // a quad of lanes per segment, each a quarter of the grid (max_mag2)
+  const int t = blockIdx.x * 64 + threadIdx.x;
+  const int s = t >> 2;
+  const bool live = s < n_segments;
+  const int sc = live ? s : n_segments - 1;  // (the lanes of the tail quads compute, so that the quad exchange is defined)
   const int which = blockIdx.y;
-  maxima[(size_t)s * 9 + which] = segment_maximum(coeffs + (size_t)s * kD * kN, seg_times[s], which);
+  const double m = segment_maximum<4>(coeffs + (size_t)sc * kD * kN, seg_times[sc], which, t & 3);
+  if (live && (t & 3) == 0) maxima[(size_t)s * 9 + which] = m;
 }
 
 // scaleSegmentTimesToMeetConstraints' per-segment step (trajectory.cpp:610-658): T <- T * max(1, v, sqrt a, cbrt j).
@@ -2895,8 +2914,8 @@ hipError_t launch_nonlinear(NonlinearPlan& nl, const BatchView& b, const Nonline
                                nullptr, nullptr, stream)) != hipSuccess)
     return e;
   // 3. per-segment maxima and time scaling
-  hipLaunchKernelGGL(segment_maxima9_kernel, dim3(cdiv_u(b.n_segments, 64), 9), dim3(64), 0, stream, b.n_segments, coeffs,
-                     seg_times, nl.d_maxima);
+  hipLaunchKernelGGL(segment_maxima9_kernel, dim3(cdiv_u(4 * (long long)b.n_segments, 64), 9), dim3(64), 0, stream, b.n_segments,
+                     coeffs, seg_times, nl.d_maxima);
   if ((e = hipGetLastError()) != hipSuccess) return e;
   // 3b + 4 in one launch where the rows kernel applies: its staging pass scales the times of its own path, its tail samples
   const bool want_samples = sampling_dt > 0.0 && n_samples != nullptr && rows_tail_sampling_pays(b);
@@ -3022,7 +3041,7 @@ hipError_t launch_cost_gradient(NonlinearPlan& nl, const BatchView& b, int d, co
 hipError_t launch_segment_maxima(const BatchView& b, const double* coeffs, const double* seg_times, double* maxima,
                                  hipStream_t stream) {
   if (b.n_segments == 0) return hipSuccess;
-  hipLaunchKernelGGL(segment_maxima9_kernel, dim3(cdiv_u(b.n_segments, 64), 9), dim3(64), 0, stream, b.n_segments, coeffs,
+  hipLaunchKernelGGL(segment_maxima9_kernel, dim3(cdiv_u(4 * (long long)b.n_segments, 64), 9), dim3(64), 0, stream, b.n_segments, coeffs,
                      seg_times, maxima);
   return hipGetLastError();
 }
