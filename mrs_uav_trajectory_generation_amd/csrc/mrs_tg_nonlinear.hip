@@ -2158,14 +2158,12 @@ __global__ __launch_bounds__(64) void optimize_careful_kernel(BatchView b, Nonli
 __global__ __launch_bounds__(64) void segment_maxima9_kernel(int n_segments, const double* __restrict__ coeffs,
                                                              const double* __restrict__ seg_times,
                                                              double* __restrict__ maxima) {
-  // a quad of lanes per segment, each a quarter of the grid (max_mag2)
-  const int t = blockIdx.x * 64 + threadIdx.x;
-  const int s = t >> 2;
-  const bool live = s < n_segments;
-  const int sc = live ? s : n_segments - 1;  // (the lanes of the tail quads compute, so that the quad exchange is defined)
+  // One lane per (segment, which).  A quad of lanes per polynomial, each a quarter of the grid (max_mag2's PARTS = 4), was
+  // measured: 12.8 -> 11.1 us at 1024 x 10, 39 -> 64 us at 8192 x 10 (every lane repeats the polynomial's set-up) -- not kept.
+  const int s = blockIdx.x * 64 + threadIdx.x;
+  if (s >= n_segments) return;
   const int which = blockIdx.y;
-  const double m = segment_maximum<4>(coeffs + (size_t)sc * kD * kN, seg_times[sc], which, t & 3);
-  if (live && (t & 3) == 0) maxima[(size_t)s * 9 + which] = m;
+  maxima[(size_t)s * 9 + which] = segment_maximum(coeffs + (size_t)s * kD * kN, seg_times[s], which);
 }
 
 // scaleSegmentTimesToMeetConstraints' per-segment step (trajectory.cpp:610-658): T <- T * max(1, v, sqrt a, cbrt j).
@@ -2914,7 +2912,7 @@ hipError_t launch_nonlinear(NonlinearPlan& nl, const BatchView& b, const Nonline
                                nullptr, nullptr, stream)) != hipSuccess)
     return e;
   // 3. per-segment maxima and time scaling
-  hipLaunchKernelGGL(segment_maxima9_kernel, dim3(cdiv_u(4 * (long long)b.n_segments, 64), 9), dim3(64), 0, stream, b.n_segments,
+  hipLaunchKernelGGL(segment_maxima9_kernel, dim3(cdiv_u(b.n_segments, 64), 9), dim3(64), 0, stream, b.n_segments,
                      coeffs, seg_times, nl.d_maxima);
   if ((e = hipGetLastError()) != hipSuccess) return e;
   // 3b + 4 in one launch where the rows kernel applies: its staging pass scales the times of its own path, its tail samples
@@ -3041,7 +3039,7 @@ hipError_t launch_cost_gradient(NonlinearPlan& nl, const BatchView& b, int d, co
 hipError_t launch_segment_maxima(const BatchView& b, const double* coeffs, const double* seg_times, double* maxima,
                                  hipStream_t stream) {
   if (b.n_segments == 0) return hipSuccess;
-  hipLaunchKernelGGL(segment_maxima9_kernel, dim3(cdiv_u(4 * (long long)b.n_segments, 64), 9), dim3(64), 0, stream, b.n_segments, coeffs,
+  hipLaunchKernelGGL(segment_maxima9_kernel, dim3(cdiv_u(b.n_segments, 64), 9), dim3(64), 0, stream, b.n_segments, coeffs,
                      seg_times, maxima);
   return hipGetLastError();
 }
