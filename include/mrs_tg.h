@@ -51,10 +51,11 @@ enum {
 /* per-path status values (nlopt.h result codes, as consumed by the nodelet) */
 enum {
   MRS_TG_STATUS_FAILURE = -1,
-  MRS_TG_STATUS_INVALID_ARGS = -2, /* also: a vertex of the path leaves its POSITION unconstrained.  Every caller of the
-                                      reference constrains the position of every vertex (src/...cpp:944, 963, 967); the
-                                      general fixed / free patterns of setupConstraintReorderingMatrix
-                                      (linear_impl.h:184-257) are supported for the derivatives 1..4 only */
+  MRS_TG_STATUS_INVALID_ARGS = -2, /* also: a vertex of the path leaves its POSITION unconstrained and the general solver
+                                      was not asked for.  Every caller of the reference constrains the position of every
+                                      vertex (src/...cpp:944, 963, 967) and the fast kernels rely on it; the general
+                                      fixed / free patterns of setupConstraintReorderingMatrix (linear_impl.h:184-257)
+                                      are solved in fixed-times mode under MRS_TG_FLAG_GENERAL_PATTERNS */
   MRS_TG_STATUS_SUCCESS = 1,
   MRS_TG_STATUS_FTOL_REACHED = 3,
   MRS_TG_STATUS_XTOL_REACHED = 4,
@@ -86,6 +87,13 @@ enum {
                                          device (one context + stream each), so small batches are launched in shapes that
                                          leave wavefront slots to the other streams instead of minimising the latency of
                                          this one launch */
+  MRS_TG_FLAG_GENERAL_PATTERNS = 16,  /* fixed-times mode: some vertices may leave their POSITION free (setupFromVertices takes
+                                         any fixed / free pattern, linear_impl.h:184-257; the nodelet never builds such a
+                                         vertex).  The fast kernels return those paths with status -2; with this flag a
+                                         general kernel (5 x 5 vertex blocks, mrs_tg_general.hip) solves them afterwards.
+                                         mrs_tg_solve_batch sets it by itself when its host copy of fixed_mask shows such a
+                                         vertex; callers of the device-pointer interface say so.  The time-allocation modes
+                                         do not take such paths (status -2 stays) */
   MRS_TG_FLAG_CAREFUL_COST = 8        /* Mellinger mode: paths on which a trial point's cost lost its digits in the fast
                                          evaluation (a segment on the 0.01 s bound next to long neighbours; about 0.3 % of
                                          random 10-segment paths) are run again with the cost the reference computes,

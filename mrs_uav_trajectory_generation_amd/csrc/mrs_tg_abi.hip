@@ -498,14 +498,17 @@ int mrs_tg_plan_solve(mrs_tg_plan* plan, const double* wp, const uint8_t* mask, 
                                           opt->sampling_dt, opt->sample_capacity, n_samples, samples, &sampled));
   } else {
     const bool fused = (opt->flags & MRS_TG_FLAG_MATERIALIZED_BLOCKS) == 0;  // the default since ABI 2
-    if ((rc = ensure_ws(plan, mrs_tg::linear_workspace_doubles(b))) != MRS_TG_OK) return rc;
+    const bool general = (opt->flags & MRS_TG_FLAG_GENERAL_PATTERNS) != 0;   // position-free vertices may occur
+    if ((rc = ensure_ws(plan, general ? std::max(mrs_tg::linear_workspace_doubles(b), mrs_tg::general_workspace_doubles(b))
+                                      : mrs_tg::linear_workspace_doubles(b))) != MRS_TG_OK)
+      return rc;
     if (!fused) {
       if ((rc = ensure_blocks(plan)) != MRS_TG_OK) return rc;
       ProfileScope ps(ctx, 0);
       HIP_TRY(ctx, mrs_tg::launch_assemble(b, d, seg_times, plan->d_H, plan->d_Ainv, ctx->stream));
     }
     ProfileScope ps(ctx, 1);
-    if (fused && opt->sampling_dt > 0 && mrs_tg::rows_tail_sampling_pays(b)) {  // solve and sample in one launch
+    if (fused && !general && opt->sampling_dt > 0 && mrs_tg::rows_tail_sampling_pays(b)) {  // solve and sample in one launch
       mrs_tg::RowsTail tail;
       tail.sampling_dt = opt->sampling_dt;
       tail.sample_capacity = opt->sample_capacity;
@@ -517,6 +520,9 @@ int mrs_tg_plan_solve(mrs_tg_plan* plan, const double* wp, const uint8_t* mask, 
       HIP_TRY(ctx, mrs_tg::launch_solve_linear(b, d, fused, mask, vals, seg_times, plan->d_H, plan->d_Ainv, plan->d_ws,
                                                coeffs, status, cost, nullptr, ctx->stream));
     }
+    // the paths the fast kernels sent back with status -2 (a vertex without a position constraint): 5 x 5 vertex blocks
+    if (general)
+      HIP_TRY(ctx, mrs_tg::launch_solve_general(b, d, mask, vals, seg_times, plan->d_ws, coeffs, status, cost, ctx->stream));
   }
   if (opt->sampling_dt > 0 && !sampled)
     HIP_TRY(ctx, mrs_tg::launch_sample(b, coeffs, seg_times, opt->sampling_dt, opt->sample_capacity, n_samples, samples,
@@ -754,6 +760,14 @@ int mrs_tg_solve_batch(mrs_tg_ctx* ctx, int32_t n_paths, const int32_t* so, cons
   if (limits) HIP_TRY(ctx, hipMemcpyAsync(d_lim.p, limits, (size_t)n_paths * 9 * sizeof(double), hipMemcpyHostToDevice, s));
   HIP_TRY(ctx, hipMemcpyAsync(d_t.p, seg_times, nS * sizeof(double), hipMemcpyHostToDevice, s));
   mrs_tg_options local = *opt;
+  if (local.time_alloc_method == MRS_TG_TIME_ALLOC_NONE && !(local.flags & MRS_TG_FLAG_GENERAL_PATTERNS)) {
+    // the masks are in host memory here: a vertex without a position constraint switches the general solver on
+    for (size_t v = 0; v < nV; ++v)
+      if (mask[v * 5] == 0) {
+        local.flags |= MRS_TG_FLAG_GENERAL_PATTERNS;
+        break;
+      }
+  }
   if (local.max_time_s > 0) {  // what is left of the caller's budget when the kernels start
     const double spent = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_call).count();
     local.max_time_s = local.max_time_s - spent > 1.0e-9 ? local.max_time_s - spent : 1.0e-9;

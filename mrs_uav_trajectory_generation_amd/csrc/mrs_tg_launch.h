@@ -57,6 +57,10 @@ constexpr int kSampleStateOrders = 5;
 hipError_t launch_sample_states(const BatchView& b, const double* coeffs, const double* seg_times, double dt, int capacity,
                                 int32_t* n_samples, double* states, hipStream_t stream);
 size_t linear_workspace_doubles(const BatchView& b);
+// any fixed / free pattern, position-free vertices included (mrs_tg_general.hip): solves the paths whose status is -2
+size_t general_workspace_doubles(const BatchView& b);
+hipError_t launch_solve_general(const BatchView& b, int d, const uint8_t* mask, const double* vals, const double* seg_times,
+                                double* ws, double* coeffs, int32_t* status, double* cost, hipStream_t stream);
 // phase-split tile kernel (mrs_tg_tile.hip): small and medium batches whose per-path state fits in LDS
 bool tile_kernel_applies(const BatchView& b, bool fused);
 hipError_t launch_solve_tile(const BatchView& b, int d, bool fused, const uint8_t* mask, const double* vals,

@@ -171,12 +171,19 @@ def test_estimated_times_match_oracle(gpu_ctx):
     assert np.max(np.abs(out["times"] - t) / t) < 1e-13
 
 
-def test_position_free_vertex_is_rejected_loudly(gpu_ctx):
+def test_position_free_vertex_takes_the_general_solver(gpu_ctx):
+    """A vertex without a position constraint is outside the fast kernels (status -2 from them, see
+    tests/test_gpu_general_patterns.py for the device-pointer interface); the host interface sees the mask and has the
+    general kernel solve the path.  The time-allocation modes still refuse it."""
     wp, m, v = pr.build_vertices(pr.random_box_waypoints(4, 3), pr.SNAP)
-    m[2, 0] = 0  # no position constraint on an interior vertex: outside what the HIP path supports
+    m[2, 0] = 0
     batch = pr.assemble_batch([(wp, m, v)], pr.DEFAULT_LIMITS[None])
     out = gpu_ctx.solve_batch(batch, np.ones(4))
-    assert out["status"][0] == -2
+    assert out["status"][0] == 1
+    oc = po.solve_linear(4, m, v, np.ones(4))
+    assert util.coeff_error(out["coeffs"], oc) < 1e-8
+    out = gpu_ctx.solve_batch(batch, np.ones(4), time_alloc_method=api.TIME_ALLOC_MELLINGER)
+    assert out["status"][0] < 0
 
 
 def test_full_size_properties_config2(gpu_ctx):
