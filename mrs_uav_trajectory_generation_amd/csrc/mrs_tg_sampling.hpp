@@ -33,7 +33,8 @@ __device__ __forceinline__ double lane_value(double v, int src) {
 // once, one lane per sample whatever its segment -- with the evaluation inside the chunk loop (one segment per chunk,
 // ~30 of 64 lanes busy, 40 broadcast LDS reads and the Horner chains in front of the next chunk's additions) the kernel
 // took 25 us for 1024 paths of ~300 samples; 1024 x 10 nonlinear 147 -> us.
-constexpr int kSampleBuffer = 1024;  // samples parked per flush (8 KB of times + 2 KB of segment indices)
+constexpr int kSampleBuffer = 192;  // samples parked per flush.  1024 made the LDS block of a 10-segment path 13.5 KB (11 wavefronts
+                                    // per CU); 192: 5.2 KB, 30 per CU -- 8192 x 10: 50 -> 40 us (scripts/tile_phases.hip), 1024 x 10 unchanged
 
 // One wavefront (all 64 lanes, wave-uniform control flow).  s_T [S] segment times, s_c [S][4][10] coefficients, s_t / s_seg
 // the sample buffer (kSampleBuffer entries each); out: the path's [capacity][4] samples or nullptr (count only).
