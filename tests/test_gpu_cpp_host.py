@@ -85,3 +85,20 @@ def test_plain_c99_host(tmp_path):
     # the straight line: symmetric segment times
     t = r["paths"][1]["times"]
     assert abs(t[0] - t[1]) < 1e-6 * t[0]
+
+
+def test_cpp_stream_server_keeps_batches_in_flight(tmp_path):
+    """examples/stream_server_host.cpp: a g++-built host with four contexts / streams, bound solves issued by
+    mrs_tg_bound_solve_launch_many under MRS_TG_FLAG_SHARED_DEVICE; every lane ends with the one-call interface's result
+    bit for bit (the program's exit code says so) and the JSON line carries the throughput."""
+    exe = str(tmp_path / "stream_server_host")
+    libdir = os.path.join(ROOT, "mrs_uav_trajectory_generation_amd")
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-D__HIP_PLATFORM_AMD__", "-I", os.path.join(ROOT, "include"),
+                           "-I", "/opt/rocm/include", os.path.join(ROOT, "examples", "stream_server_host.cpp"), "-o", exe,
+                           "-L", libdir, "-lmrs_tg", "-L", "/opt/rocm/lib", "-lamdhip64", "-Wl,-rpath," + libdir,
+                           "-Wl,-rpath,/opt/rocm/lib"])
+    out = subprocess.run([exe, "1024", "4", "400"], check=True, capture_output=True, text=True, timeout=300).stdout
+    r = json.loads(out.strip().splitlines()[-1])
+    assert r["paths"] == 1024 and r["in_flight"] == 4 and r["steps"] == 400
+    assert r["max_abs_diff_vs_one_call_interface"] == 0.0
+    assert r["trajectories_per_s"] > 2.0e7   # (hundreds of millions on an idle MI355X; a loose floor for a shared box)
