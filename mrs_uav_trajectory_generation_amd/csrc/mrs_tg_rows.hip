@@ -349,6 +349,19 @@ __global__ __launch_bounds__(64) void solve_rows_kernel(BatchView b, int d, int 
     double* sb = vb + (size_t)(Smax + 1) * kRVtxRec;
     pos_ok_lane = true;
     nonzero_lane = false;
+    // the first round of the segment loop's loads (time, the two positions) is requested before the vertex loop: the
+    // compiler otherwise issues them after the vertex loop's stores, and the time after the positions -- three trips to
+    // memory in a row
+    double T_first = 1.0, ps_first[2 * kD] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+    if (lane < S_t) {
+      T_first = seg_times[s0_t + lane];
+      const double* ps = vals + (size_t)(v0_t + lane) * kHalf * kD;
+#pragma unroll
+      for (int dd = 0; dd < kD; ++dd) {
+        ps_first[dd] = ps[dd];
+        ps_first[kD + dd] = ps[kHalf * kD + dd];
+      }
+    }
     for (int v = lane; v <= S_t; v += 64) {
       double f[kHalf][kD];
       bool pos_fixed;
@@ -369,7 +382,7 @@ __global__ __launch_bounds__(64) void solve_rows_kernel(BatchView b, int d, int 
     }
     const int p_t = __builtin_amdgcn_readlane(pr.p, tt * 16);
     for (int i = lane; i < S_t; i += 64) {
-      double T = seg_times[s0_t + i];
+      double T = (i == lane) ? T_first : seg_times[s0_t + i];
       if (TAIL && tail.maxima) {  // feasibility scaling of this segment (trajectory.cpp:625-657), then the solve at the scaled times
         if (tail.opt_status[p_t] != -2) T *= violation_scaling(tail.maxima + (size_t)(s0_t + i) * 9, tail.limits + (size_t)p_t * 9);
         tail.seg_times_out[s0_t + i] = T;
@@ -391,7 +404,8 @@ __global__ __launch_bounds__(64) void solve_rows_kernel(BatchView b, int d, int 
       }
       r[kRSegT] = T;
 #pragma unroll
-      for (int dd = 0; dd < kD; ++dd) r[kRSegDp + dd] = ps[dd] - ps[kHalf * kD + dd];
+      for (int dd = 0; dd < kD; ++dd)
+        r[kRSegDp + dd] = (i == lane) ? ps_first[dd] - ps_first[kD + dd] : ps[dd] - ps[kHalf * kD + dd];
     }
     pos_bad[tt] = __ballot(!pos_ok_lane);
     gen_any[tt] = __ballot(nonzero_lane);
