@@ -393,9 +393,14 @@ def main():
 
     # The clocks of an idle MI355X take a few milliseconds of work to come up, and the driver's default run is 5 warm-up
     # + 20 timed steps of ~10 us: an untimed ramp of the same step keeps the timed region from measuring the ramp.
-    for _ in range(300):
-        steps_fn[args.workload]()
-    torch.cuda.synchronize()
+    # (by time, not by count: 300 steps of the current kernels are 1 ms; the ramp runs for 30 ms)
+    ramp_steps = 0
+    t_ramp = time.perf_counter()
+    while time.perf_counter() - t_ramp < 0.030:
+        for _ in range(100):
+            steps_fn[args.workload]()
+        ramp_steps += 100
+        torch.cuda.synchronize()
     step_no[0] = 0
 
     elapsed = time_steps(steps_fn[args.workload], args.steps, args.warmup, dist, torch, final_gather,
@@ -725,7 +730,7 @@ def main():
                                 linear_solve="default of mrs_tg_plan_solve: solve_rows_kernel, blocks formed in registers "
                                              "(nothing materialised); the assembly kernel is timed on its own (roofline) and "
                                              "inside extras.materialized_blocks_step",
-                                clock_ramp_steps=300,
+                                clock_ramp_steps=ramp_steps, clock_ramp_ms=30,
                                 step_issue=("mrs_tg_bound_solve_launch_many: the K steps are issued round-robin over the "
                                             "streams by the library's C loop" if block_for(args.workload) is not None
                                             else "one Python call per step"),

@@ -549,8 +549,13 @@ static size_t rows_lds_bytes(int Smax, int ppw, bool sampling) {
 
 bool rows_kernel_applies(const BatchView& b, bool with_sampling) {
   if (b.n_paths == 0) return false;
-  if (const char* e = std::getenv("MRS_TG_ROWS_KERNEL"))
-    if (std::atoi(e) == 0) return false;  // tuning / test knob: fall back to the tile and lane kernels
+  // tuning / test knob, read once per process (a getenv per launch is a measurable share of a 3 us launch):
+  // MRS_TG_ROWS_KERNEL=0 falls back to the tile and lane kernels
+  static const bool disabled = [] {
+    const char* e = std::getenv("MRS_TG_ROWS_KERNEL");
+    return e != nullptr && std::atoi(e) == 0;
+  }();
+  if (disabled) return false;
   return rows_lds_bytes(b.max_segments, 1, with_sampling) <= kRowsLdsBudget;
 }
 
@@ -565,7 +570,11 @@ hipError_t launch_solve_rows(const BatchView& b, int d, const uint8_t* mask, con
   // wavefronts per launch let two launches run side by side, 512 two-path wavefronts four (1024 x 10, four streams:
   // 4.9 -> 4.1 us per step; alone on the device the two-path launch is 0.9 us slower)
   int ppw = (b.n_paths <= 2048 && !(shared_device_hint() && !sampling)) ? 1 : 2;
-  if (const char* e = std::getenv("MRS_TG_ROWS_PPW")) ppw = std::atoi(e) == 1 ? 1 : 2;
+  static const int forced_ppw = [] {  // MRS_TG_ROWS_PPW=1|2, read once per process
+    const char* e = std::getenv("MRS_TG_ROWS_PPW");
+    return e ? (std::atoi(e) == 1 ? 1 : 2) : 0;
+  }();
+  if (forced_ppw) ppw = forced_ppw;
   if (rows_lds_bytes(b.max_segments, 2, sampling) > kRowsLdsBudget) ppw = 1;
   const size_t lds_bytes = rows_lds_bytes(b.max_segments, ppw, sampling);
   const bool with_tail = sampling || tail.maxima != nullptr;
