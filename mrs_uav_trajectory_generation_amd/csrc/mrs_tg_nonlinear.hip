@@ -1243,6 +1243,95 @@ __device__ __forceinline__ double evaluate_careful(const uint8_t* __restrict__ m
   return J0;
 }
 
+// ---- lean sweeps (large batches of plain paths) --------------------------------------------------------------------
+// The sweeping evaluation of evaluate_objective<1> for plain paths only (start | interior ... | end): the block constants
+// come from the LDS table, the brackets from dp on the fly, and nothing of the general step is compiled in -- which is what
+// keeps the kernel at <= 256 VGPRs, i.e. TWO wavefronts per SIMD where optimize_compact_kernel (436 VGPRs) has one.  The
+// kernels are bound by the dependent chain of a step, not by issue (DESIGN.md section 13): the second wavefront runs in
+// the first one's idle issue slots.  Lane k of a group of G sweeps time vector k (k, k + G, ... when S + 1 > G).
+__host__ __device__ constexpr int lean_eval_doubles(int Sb) { return 4 * Sb + 4 * (Sb + 1); }  // dp, staging area
+
+__device__ __forceinline__ double evaluate_lean(const double* tabs, const double* ev, int S, int d, const double* pt,
+                                                double* grad, int g, int G, bool active, int* tripped) {
+  const double* dp = ev;
+  const double* tab = tabs;  // left-to-right table
+  const double corr = kGradStep / ((double)S - 1.0);
+  double J0 = 0.0;
+  const int g_shift = __builtin_ctz((unsigned)G);  // G is a power of two
+  const int rounds = (S + G) >> g_shift;
+  for (int r = 0; r < rounds; ++r) {
+    const int k = g + (r << g_shift);
+    double Jk = 0.0, qfk = 0.0;
+    if (active && k <= S && (k == 0 || S > 1)) {
+      Elim<4> st;
+      st.init();
+      // (the brackets as a 36-double array per step: forming them where they are consumed instead brings the kernel from
+      // 256 VGPRs + 41 spilled to 204 without spills and makes it 5 % slower -- measured, 65536 x 10: 848 vs 896 us)
+      for (int i = 0; i < S; ++i) {
+        double p2[9];
+        segment_powers(perturbed_time(pt, i, k, corr), d, p2);
+        FastStep<4> fast;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const double dq = dp[i * 4 + q];
+#pragma unroll
+          for (int j = 0; j < 8; ++j) fast.w[q][j] = tab[36 + j] * dq;
+          fast.w[q][8] = tab[44] * dq * dq;
+        }
+        if (i == 0) fast.template start_t<false>(st, tab, p2);
+        else if (i < S - 1) fast.template interior_t<false>(st, tab, p2);
+        else fast.end(st, tab, p2);
+      }
+      Jk = 0.5 * (st.qf - st.red);
+      qfk = st.qf;
+    }
+    Jk = guarded_cost(Jk, qfk, k == 0);
+    if (tripped && active && k <= S && Jk == kUnreliableCost) *tripped = 1;
+    if (r == 0) J0 = __shfl(Jk, (int)(threadIdx.x & ~(unsigned)(G - 1)), 64);
+    if (active && k >= 1 && k <= S) grad[k - 1] = (S > 1) ? (Jk - J0) / kGradStep : 0.0;
+  }
+  return J0;
+}
+
+// per-group LDS of the plain-path kernels and their staging
+__host__ __device__ constexpr int ps_group_doubles(int Sb) {
+  return (5 + 2 * kLbfgsM) * Sb + (kLbfgsM + 1) + kTickState + ps_eval_doubles(Sb);
+}
+__host__ __device__ constexpr int lean_group_doubles(int Sb) {
+  return (5 + 2 * kLbfgsM) * Sb + (kLbfgsM + 1) + kTickState + lean_eval_doubles(Sb);
+}
+
+// positions -> dp of every segment; returns whether the path is one the evaluation takes (group-uniform)
+__device__ __forceinline__ bool stage_ps(const uint8_t* __restrict__ mask, const double* __restrict__ vals, int v0, int S,
+                                         int Sb, double* ev, int g, int G, bool active, int min_segments) {
+  double* dp = ev;
+  double* tmp = ev + 4 * (size_t)Sb;  // the record area, not in use yet
+  int ok = (S >= min_segments) ? 1 : 0;
+  if (active)
+    for (int v = g; v <= S; v += G) {
+      double f[kHalf][kD];
+      bool pf;
+      const unsigned fb = load_vertex<kD>(mask, vals, v0 + v, 0, f, pf);
+      double nz = 0.0;
+#pragma unroll
+      for (int k = 1; k < kHalf; ++k)
+#pragma unroll
+        for (int q = 0; q < kD; ++q) nz += fabs(f[k][q]);
+      const unsigned want = (v == 0 || v == S) ? 0u : 0xFu;
+      if (!(pf && nz == 0.0 && fb == want)) ok = 0;
+#pragma unroll
+      for (int q = 0; q < kD; ++q) tmp[v * 4 + q] = f[0][q];
+    }
+  const bool all_ok = group_and(ok, G) != 0;
+  ps_wave_sync();
+  if (active)
+    for (int i = g; i < S; i += G)
+#pragma unroll
+      for (int q = 0; q < kD; ++q) dp[i * 4 + q] = tmp[i * 4 + q] - tmp[(i + 1) * 4 + q];
+  ps_wave_sync();
+  return all_ok;
+}
+
 // ---------------------------------------------------------------------------------------------
 // the outer-loop kernel: optimiser ticks (one objective evaluation each).  On exit seg_times holds the
 // last evaluated point and opt_status the stopping reason (-2: start rejected, as NLopt would).
@@ -1256,11 +1345,13 @@ struct BinTable {
 
 // CAREFUL (optimize_careful_kernel): one listed path per workgroup of 64, the primal cost in every evaluation, `careful_ws`
 // the factor store of its lanes.
-template <int DS, bool MASKED4 = false, bool CAREFUL = false>
+// LEAN (optimize_lean_kernel): plain paths only, the lean sweeps of evaluate_lean; a path it does not take is flagged in
+// `fallback` and left to the general instantiation launched behind it.
+template <int DS, bool MASKED4 = false, bool CAREFUL = false, bool LEAN = false>
 __device__ __forceinline__ void optimize_body(const BatchView& b, const NonlinearParams& prm, const BinTable& bins,
                                               const uint8_t* __restrict__ mask, const double* __restrict__ vals,
                                               double* __restrict__ seg_times, int32_t* __restrict__ opt_status,
-                                              double* careful_ws = nullptr) {
+                                              double* careful_ws = nullptr, int32_t* __restrict__ fallback = nullptr) {
   extern __shared__ double lds[];
   MRS_TG_PHASE_MARK(0);
   int bin = 0;
@@ -1289,7 +1380,7 @@ __device__ __forceinline__ void optimize_body(const BatchView& b, const Nonlinea
   const int qi = block_in_bin * per_block + grp;
   bool active = qi < q_count;
   const int q = q_begin + (active ? qi : 0);
-  if (!CAREFUL && prm.only_flagged) {  // the plain-path kernel in front of this launch took the other paths
+  if (!CAREFUL && !LEAN && prm.only_flagged) {  // the plain-path kernel in front of this launch took the other paths
     active = active && prm.only_flagged[q] != 0;
     if (!__syncthreads_or(active ? 1 : 0)) return;  // (an all-plain batch: every workgroup ends here)
   }
@@ -1297,11 +1388,14 @@ __device__ __forceinline__ void optimize_body(const BatchView& b, const Nonlinea
   int S = pr.S;
   const int d = prm.derivative;
 
-  double* hc = lds;  // [kBlockConsts], shared by the groups of the block
-  if (wave == 0) stage_block_constants(d, hc, lane, 64);
+  double* hc = lds;  // [kBlockConsts] (LEAN: the two direction tables of stage_ps_tables), shared by the groups of the block
+  if (LEAN) stage_ps_tables(d, hc, lane, 64);
+  else if (wave == 0) stage_block_constants(d, hc, lane, 64);
   constexpr bool kExtras = DS == 4;
-  double* base = lds + kBlockConsts + (size_t)grp * group_lds_doubles(Sb, kExtras);
-  double* pair_state = lds + kBlockConsts + (size_t)per_block * group_lds_doubles(Sb, kExtras);  // [64 * kPairState] (two_wave only)
+  constexpr int kConsts = LEAN ? 2 * kPsTable : kBlockConsts;
+  const int group_doubles = LEAN ? lean_group_doubles(Sb) : group_lds_doubles(Sb, kExtras);
+  double* base = lds + kConsts + (size_t)grp * group_doubles;
+  double* pair_state = lds + kConsts + (size_t)per_block * group_doubles;  // [64 * kPairState] (two_wave only)
   int* pair_flags = reinterpret_cast<int*>(pair_state + 64 * kPairState);              // [0] all done, [1] two-sided evaluation, [2] moving start / masked segments
   double* x = base;
   double* gr = x + Sb;
@@ -1315,9 +1409,15 @@ __device__ __forceinline__ void optimize_body(const BatchView& b, const Nonlinea
   int* tick_i = reinterpret_cast<int*>(tick_f + 2);
   double* vtx = tick_f + kTickState;  // [(Sb + 1) * kVtxLds]
   double* seg = vtx + (size_t)(Sb + 1) * kVtxLds + (kExtras ? kStartExtra : 0);  // [Sb * kSegLds], the moving-start extras in front
-  if (active && wave == 0) stage_vertices(mask, vals, pr.v0, S, vtx, g, G);
-  __syncthreads();
-  if (active && wave == 0) stage_segments(vtx, S, d, seg, g, G, kExtras);
+  if (LEAN) {  // vtx = the evaluation area: dp of every segment; the path's eligibility decides who runs it
+    const bool takes = stage_ps(mask, vals, pr.v0, S, Sb, vtx, g, G, active, 2);
+    if (active && g == 0) fallback[q] = takes ? 0 : 1;
+    active = active && takes;
+  } else {
+    if (active && wave == 0) stage_vertices(mask, vals, pr.v0, S, vtx, g, G);
+    __syncthreads();
+    if (active && wave == 0) stage_segments(vtx, S, d, seg, g, G, kExtras);
+  }
 
   // ---- start point; NLopt rejects a start below the lower bound (-> INVALID_ARGS)
   int ok = 1;
@@ -1417,7 +1517,9 @@ __device__ __forceinline__ void optimize_body(const BatchView& b, const Nonlinea
       G = __builtin_amdgcn_readfirstlane(Gv);
     }
     double fn;
-    if (CAREFUL) {
+    if (LEAN) {
+      fn = evaluate_lean(hc, vtx, S, d, xn, gn, g, G, !done, tick_i + 4);
+    } else if (CAREFUL) {
       fn = evaluate_careful(mask, vals, pr.v0, S, d, xn, gn, g, !done, careful_ws, (size_t)gridDim.x * 64,
                             blockIdx.x * 64u + (unsigned)lane);
     } else if (pair_ok) {
@@ -1802,101 +1904,11 @@ __global__ void careful_close_kernel(int32_t* __restrict__ careful) {
   careful[0] = 0;
 }
 
-// ---- lean sweeps (large batches of plain paths) --------------------------------------------------------------------
-// The sweeping evaluation of evaluate_objective<1> for plain paths only (start | interior ... | end): the block constants
-// come from the LDS table, the brackets from dp on the fly, and nothing of the general step is compiled in -- which is what
-// keeps the kernel at <= 256 VGPRs, i.e. TWO wavefronts per SIMD where optimize_compact_kernel (436 VGPRs) has one.  The
-// kernels are bound by the dependent chain of a step, not by issue (DESIGN.md section 13): the second wavefront runs in
-// the first one's idle issue slots.  Lane k of a group of G sweeps time vector k (k, k + G, ... when S + 1 > G).
-__host__ __device__ constexpr int lean_eval_doubles(int Sb) { return 4 * Sb + 4 * (Sb + 1); }  // dp, staging area
-
-__device__ __forceinline__ double evaluate_lean(const double* tabs, const double* ev, int S, int d, const double* pt,
-                                                double* grad, int g, int G, bool active, int* tripped) {
-  const double* dp = ev;
-  const double* tab = tabs;  // left-to-right table
-  const double corr = kGradStep / ((double)S - 1.0);
-  double J0 = 0.0;
-  const int g_shift = __builtin_ctz((unsigned)G);  // G is a power of two
-  const int rounds = (S + G) >> g_shift;
-  for (int r = 0; r < rounds; ++r) {
-    const int k = g + (r << g_shift);
-    double Jk = 0.0, qfk = 0.0;
-    if (active && k <= S && (k == 0 || S > 1)) {
-      Elim<4> st;
-      st.init();
-      // (the brackets as a 36-double array per step: forming them where they are consumed instead brings the kernel from
-      // 256 VGPRs + 41 spilled to 204 without spills and makes it 5 % slower -- measured, 65536 x 10: 848 vs 896 us)
-      for (int i = 0; i < S; ++i) {
-        double p2[9];
-        segment_powers(perturbed_time(pt, i, k, corr), d, p2);
-        FastStep<4> fast;
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          const double dq = dp[i * 4 + q];
-#pragma unroll
-          for (int j = 0; j < 8; ++j) fast.w[q][j] = tab[36 + j] * dq;
-          fast.w[q][8] = tab[44] * dq * dq;
-        }
-        if (i == 0) fast.template start_t<false>(st, tab, p2);
-        else if (i < S - 1) fast.template interior_t<false>(st, tab, p2);
-        else fast.end(st, tab, p2);
-      }
-      Jk = 0.5 * (st.qf - st.red);
-      qfk = st.qf;
-    }
-    Jk = guarded_cost(Jk, qfk, k == 0);
-    if (tripped && active && k <= S && Jk == kUnreliableCost) *tripped = 1;
-    if (r == 0) J0 = __shfl(Jk, (int)(threadIdx.x & ~(unsigned)(G - 1)), 64);
-    if (active && k >= 1 && k <= S) grad[k - 1] = (S > 1) ? (Jk - J0) / kGradStep : 0.0;
-  }
-  return J0;
-}
-
 // ---- the outer loop on the prefix / suffix evaluation -----------------------------------------------------------
-// Groups of 8 lanes, 8 paths per wavefront.  The optimiser's vectors live in LDS and a lane owns the elements g, g + 8, ...
-// (the general bookkeeping of optimize_body, same arithmetic).  A path the evaluation does not take (not plain, S < 4) is
+// (the experiment of DESIGN.md section 13; not the default.)  Groups of 8 lanes, 8 paths per wavefront.  The optimiser's
+// vectors live in LDS and a lane owns the elements g, g + 8, ... (the general bookkeeping of optimize_body, same arithmetic).  A path the evaluation does not take (not plain, S < 4) is
 // flagged in `fallback` and left to the sweeping kernel, which is launched behind this one for the flagged paths only.
 // per-group LDS: x, g, xn, gn, dir [5 Sb], s / y pairs [2 M Sb], rho [M + 1], tick state, evaluation area
-__host__ __device__ constexpr int ps_group_doubles(int Sb) {
-  return (5 + 2 * kLbfgsM) * Sb + (kLbfgsM + 1) + kTickState + ps_eval_doubles(Sb);
-}
-__host__ __device__ constexpr int lean_group_doubles(int Sb) {
-  return (5 + 2 * kLbfgsM) * Sb + (kLbfgsM + 1) + kTickState + lean_eval_doubles(Sb);
-}
-
-// positions -> dp of every segment; returns whether the path is one the evaluation takes (group-uniform)
-__device__ __forceinline__ bool stage_ps(const uint8_t* __restrict__ mask, const double* __restrict__ vals, int v0, int S,
-                                         int Sb, double* ev, int g, int G, bool active, int min_segments) {
-  double* dp = ev;
-  double* tmp = ev + 4 * (size_t)Sb;  // the record area, not in use yet
-  int ok = (S >= min_segments) ? 1 : 0;
-  if (active)
-    for (int v = g; v <= S; v += G) {
-      double f[kHalf][kD];
-      bool pf;
-      const unsigned fb = load_vertex<kD>(mask, vals, v0 + v, 0, f, pf);
-      double nz = 0.0;
-#pragma unroll
-      for (int k = 1; k < kHalf; ++k)
-#pragma unroll
-        for (int q = 0; q < kD; ++q) nz += fabs(f[k][q]);
-      const unsigned want = (v == 0 || v == S) ? 0u : 0xFu;
-      if (!(pf && nz == 0.0 && fb == want)) ok = 0;
-#pragma unroll
-      for (int q = 0; q < kD; ++q) tmp[v * 4 + q] = f[0][q];
-    }
-  const bool all_ok = group_and(ok, G) != 0;
-  ps_wave_sync();
-  if (active)
-    for (int i = g; i < S; i += G)
-#pragma unroll
-      for (int q = 0; q < kD; ++q) dp[i * 4 + q] = tmp[i * 4 + q] - tmp[(i + 1) * 4 + q];
-  ps_wave_sync();
-  return all_ok;
-}
-
-// ROLES: the prefix / suffix evaluation (G = 8); otherwise the lean sweeps (G = the bin's group size)
-template <bool ROLES>
 __device__ __forceinline__ void plain_body(const BatchView& b, const NonlinearParams& prm, int G, int q_begin, int q_count, int Sb,
                                            int block_in_bin, const uint8_t* __restrict__ mask, const double* __restrict__ vals,
                                            double* __restrict__ seg_times, int32_t* __restrict__ opt_status,
@@ -1913,7 +1925,7 @@ __device__ __forceinline__ void plain_body(const BatchView& b, const NonlinearPa
   const int d = prm.derivative;
   double* tabs = lds;
   stage_ps_tables(d, tabs, lane, 64);
-  double* base = lds + 2 * kPsTable + (size_t)grp * (ROLES ? ps_group_doubles(Sb) : lean_group_doubles(Sb));
+  double* base = lds + 2 * kPsTable + (size_t)grp * ps_group_doubles(Sb);
   double* x = base;
   double* gr = x + Sb;
   double* xn = gr + Sb;
@@ -1930,7 +1942,7 @@ __device__ __forceinline__ void plain_body(const BatchView& b, const NonlinearPa
 #pragma unroll
   for (int off = 32; off >= 1; off >>= 1) Smax = max(Smax, __shfl_xor(Smax, off, 64));
   Smax = __builtin_amdgcn_readfirstlane(Smax);
-  const bool takes = stage_ps(mask, vals, pr.v0, S, Sb, ev, g, G, active, ROLES ? 4 : 2);
+  const bool takes = stage_ps(mask, vals, pr.v0, S, Sb, ev, g, G, active, 4);
   if (active && g == 0) fallback[q] = takes ? 0 : 1;
   active = active && takes;
 
@@ -1959,8 +1971,7 @@ __device__ __forceinline__ void plain_body(const BatchView& b, const NonlinearPa
 
   while (true) {
     if (__ballot(!done) == 0ull) break;
-    const double fn = ROLES ? evaluate_ps(tabs, ev, S, Sb, Smax, d, xn, gn, g, !done, tick_i + 4)
-                            : evaluate_lean(tabs, ev, S, d, xn, gn, g, G, !done, tick_i + 4);
+    const double fn = evaluate_ps(tabs, ev, S, Sb, Smax, d, xn, gn, g, !done, tick_i + 4);
     ps_wave_sync();
     timed_out = t_deadline != 0ll && (long long)wall_clock64() > t_deadline;
     bool new_dir = false;
@@ -2129,20 +2140,16 @@ __global__ __launch_bounds__(64, 2) void optimize_ps_kernel(BatchView b, Nonline
                                                             const uint8_t* __restrict__ mask, const double* __restrict__ vals,
                                                             double* __restrict__ seg_times, int32_t* __restrict__ opt_status,
                                                             int32_t* __restrict__ fallback) {
-  plain_body<true>(b, prm, kPsGroup, q_begin, q_count, Sb, (int)blockIdx.x, mask, vals, seg_times, opt_status, fallback);
+  plain_body(b, prm, kPsGroup, q_begin, q_count, Sb, (int)blockIdx.x, mask, vals, seg_times, opt_status, fallback);
 }
 
-// every bin in one launch, as the sweeping kernels
+// every bin in one launch, as the sweeping kernels; optimize_body's own bookkeeping (one vector element per lane in
+// registers where the group is as wide as the path is long)
 __global__ __launch_bounds__(64, 2) void optimize_lean_kernel(BatchView b, NonlinearParams prm, BinTable bins,
                                                               const uint8_t* __restrict__ mask, const double* __restrict__ vals,
                                                               double* __restrict__ seg_times, int32_t* __restrict__ opt_status,
                                                               int32_t* __restrict__ fallback) {
-  int bin = 0;
-#pragma unroll
-  for (int i = 1; i < 5; ++i)
-    if (i < bins.n && (int)blockIdx.x >= bins.block_begin[i]) bin = i;
-  plain_body<false>(b, prm, bins.group[bin], bins.q_begin[bin], bins.q_count[bin], bins.max_S[bin],
-                    (int)blockIdx.x - bins.block_begin[bin], mask, vals, seg_times, opt_status, fallback);
+  optimize_body<1, false, false, true>(b, prm, bins, mask, vals, seg_times, opt_status, nullptr, fallback);
 }
 
 // The outer loop again, from the untouched start times, for the paths the fast kernels listed (a trial point whose
