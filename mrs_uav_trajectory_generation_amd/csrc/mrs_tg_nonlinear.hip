@@ -2766,7 +2766,10 @@ static bool ps_applies(const NonlinearPlan&) {
   return false;
 }
 
-// Lean sweeps for plain paths (optimize_lean_kernel): two wavefronts per SIMD where the general sweeping kernel has one.  Tuning / test knob: MRS_TG_LEAN=0|1.
+// Lean sweeps for plain paths (optimize_lean_kernel): two wavefronts per SIMD where the general sweeping kernel has one.
+// (Objective orders below snap leave slots free at the end vertices of a rest-to-rest path: not plain, those launches stay
+// on optimize_compact_kernel<true>.  A lean variant with the masked step at the two ends was measured: 96 spilled
+// registers at two wavefronts per SIMD, 8192 x 10 random-walk paths at d = 2 429 vs 365 us -- not kept.)  Tuning / test knob: MRS_TG_LEAN=0|1.
 static bool lean_applies(const NonlinearPlan& nl) {
   if (const char* e = std::getenv("MRS_TG_LEAN")) return std::atoi(e) != 0;
   return nl.dim_split == 1;

@@ -1,5 +1,5 @@
 """Mellinger pipeline step time (inputs resident, one batch in flight) for a batch shape; MRS_TG_PS=0|1 selects the outer loop.
-usage: ps_step.py n_paths n_seg|ragged"""
+usage: ps_step.py n_paths n_seg|ragged [derivative_to_optimize] [box|walk]"""
 import os
 import sys
 import time
@@ -13,16 +13,18 @@ from mrs_uav_trajectory_generation_amd import api, problem as pr
 P = int(sys.argv[1])
 n_seg = sys.argv[2] if len(sys.argv) > 2 else "10"
 n_seg = n_seg if n_seg == "ragged" else int(n_seg)
+deriv = int(sys.argv[3]) if len(sys.argv) > 3 else 4
+gen = sys.argv[4] if len(sys.argv) > 4 else "box"
 ctx = api.Context(0)
 ctx.use_torch_stream()
-batch = pr.random_batch(P, n_seg, seed0=0)
+batch = pr.random_batch(P, n_seg, seed0=0, derivative_to_optimize=deriv, generator=gen)
 plan = api.Plan(ctx, batch.seg_offsets)
 db = api.DeviceBatch(batch, "cuda:0", sample_capacity=512)
-est = api.default_options(estimate_times=1)
+est = api.default_options(estimate_times=1, derivative_to_optimize=deriv)
 plan.solve(est, db.fixed_mask, db.fixed_values, db.seg_times, db.coeffs, db.status, db.cost, waypoints=db.waypoints, limits=db.limits)
 torch.cuda.synchronize()
 t0 = db.seg_times.clone()
-opt = api.default_options(time_alloc_method=api.TIME_ALLOC_MELLINGER, sampling_dt=0.2, sample_capacity=512)
+opt = api.default_options(time_alloc_method=api.TIME_ALLOC_MELLINGER, sampling_dt=0.2, sample_capacity=512, derivative_to_optimize=deriv)
 
 
 def step():
