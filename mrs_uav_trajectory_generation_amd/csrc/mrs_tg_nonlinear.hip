@@ -769,7 +769,17 @@ __device__ __forceinline__ double segment_maximum(const double* __restrict__ c, 
 // (__shfl_xor) cost ~700 shader cycles per 64-lane reduction; DPP moves inside a row of 16 lanes and v_readlane
 // across rows cost ~150.  Every lane of a group receives the bit-identical sum (each step adds the same two partial
 // sums on both sides), which the control flow relies on.
+// G = 0: the group is the wavefront but only lanes 0..15 hold non-zero terms (a vector of at most 16 elements in a
+// 64-lane group): the sum of row 0, read from lane 0 -- the same number as the four-row sum (the other rows add + 0.0), three
+// cross-row reads and adds cheaper.
 __device__ __forceinline__ double group_sum(double v, int G) {
+  if (G == 0) {
+    v += dpp_move<0xB1>(v);
+    v += dpp_move<0x4E>(v);
+    v += dpp_move<0x141>(v);
+    v += dpp_move<0x140>(v);
+    return row_value(v, 0);
+  }
   v += dpp_move<0xB1>(v);                 // quad_perm [1,0,3,2]: lane ^ 1
   if (G >= 4) v += dpp_move<0x4E>(v);     // quad_perm [2,3,0,1]: lane ^ 2
   if (G >= 8) v += dpp_move<0x141>(v);    // row_half_mirror: the other quad of each 8
@@ -787,6 +797,19 @@ __device__ __forceinline__ double group_sum(double v, int G) {
 // group_sum calls cannot overlap, each carries its own control flow.
 template <int N>
 __device__ __forceinline__ void group_sum_n(double (&v)[N], int G) {
+  if (G == 0) {  // row 0 only, see group_sum
+#pragma unroll
+    for (int n = 0; n < N; ++n) v[n] += dpp_move<0xB1>(v[n]);
+#pragma unroll
+    for (int n = 0; n < N; ++n) v[n] += dpp_move<0x4E>(v[n]);
+#pragma unroll
+    for (int n = 0; n < N; ++n) v[n] += dpp_move<0x141>(v[n]);
+#pragma unroll
+    for (int n = 0; n < N; ++n) v[n] += dpp_move<0x140>(v[n]);
+#pragma unroll
+    for (int n = 0; n < N; ++n) v[n] = row_value(v[n], 0);
+    return;
+  }
 #pragma unroll
   for (int n = 0; n < N; ++n) v[n] += dpp_move<0xB1>(v[n]);
   if (G >= 4) {
@@ -1546,6 +1569,7 @@ __device__ __forceinline__ void optimize_body(const BatchView& b, const Nonlinea
     // registers) and are read / written once per tick; `xi_`, `gi_` carry them from the accept step to the direction.
     double xi_ = 0.0, gi_ = 0.0;
     const bool me = g < S;
+    const int Gr = (G == 64 && Sb <= 16) ? 0 : G;  // reductions of the register-resident bookkeeping (group_sum)
     if (single && !done) {
       ++neval;
       xi_ = me ? x[g] : 0.0;
@@ -1566,7 +1590,7 @@ __device__ __forceinline__ void optimize_body(const BatchView& b, const Nonlinea
         // rejected step, which is cheaper than three more reductions on an accepted one)
         const double si = xni - xi_, yi = gni - gi_;
         double red4[4] = {gi_ * si, si * yi, si * si, yi * yi};
-        group_sum_n<4>(red4, G);
+        group_sum_n<4>(red4, Gr);
         const double slope = red4[0];
         if (fn <= f + 1e-4 * slope) {
           int stop = 0;
@@ -1738,20 +1762,20 @@ __device__ __forceinline__ void optimize_body(const BatchView& b, const Nonlinea
 #pragma unroll
           for (int k = kLbfgsM - 1; k >= 0; --k)
             if (k < npairs) {
-              al[k] = rk[k] * group_sum(sk[k] * di, G);
+              al[k] = rk[k] * group_sum(sk[k] * di, Gr);
               di -= al[k] * yk[k];
             }
           di *= rho[kLbfgsM];  // s^T y / y^T y of the newest pair, computed when it was stored
 #pragma unroll
           for (int k = 0; k < kLbfgsM; ++k)
             if (k < npairs) {
-              const double beta = rk[k] * group_sum(yk[k] * di, G);
+              const double beta = rk[k] * group_sum(yk[k] * di, Gr);
               di += (al[k] - beta) * sk[k];
             }
         }
         if (xi_ <= kTimeLowerBound && di < 0.0) di = 0.0;
         double red3[3] = {gi_ * di, xi_ * xi_, di * di};
-        group_sum_n<3>(red3, G);
+        group_sum_n<3>(red3, Gr);
         double gd = red3[0];
         const double nx = red3[1];
         double nd = red3[2];
@@ -1761,7 +1785,7 @@ __device__ __forceinline__ void optimize_body(const BatchView& b, const Nonlinea
           if (xi_ <= kTimeLowerBound && v < 0.0) v = 0.0;
           di = v;
           double red2[2] = {gi_ * v, v * v};
-          group_sum_n<2>(red2, G);
+          group_sum_n<2>(red2, Gr);
           gd = red2[0];
           nd = red2[1];
           npairs = 0;
