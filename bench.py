@@ -197,6 +197,26 @@ def measured_traffic(n_paths, n_seg):
     return best
 
 
+def fill_ceiling(n_paths, n_seg):
+    """Per-dispatch duration of the fastest PURE FILL of the assembly kernel's bytes (scripts/k1_variants.hip under
+    rocprofv3 --kernel-trace --stats, committed): what any kernel that writes 1024 x 10 segments' blocks can reach at most."""
+    if (n_paths, n_seg) != (1024, 10):
+        return None
+    import csv
+    best = None
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "round*_k1_fill_ceiling_kernel_stats.csv"))):
+        try:
+            with open(f) as fh:
+                rows = [r for r in csv.DictReader(fh) if "k_fill" in r["Name"]]
+        except (OSError, KeyError):
+            continue
+        if rows:
+            r = min(rows, key=lambda r: float(r["AverageNs"]))
+            best = dict(kernel=r["Name"].split("(")[0].replace("void ", ""), avg_launch_us=float(r["AverageNs"]) / 1e3,
+                        source=os.path.relpath(f, ROOT))
+    return best
+
+
 def main():
     argv = sys.argv[1:]
     args = parse_args(argv)
@@ -437,6 +457,12 @@ def main():
                                       "next one's ramp, so this is NOT a kernel duration (%.3f of peak if it were)"
                                       % (alg_bytes / (asm_b2b * 1e-3) / 1e9 / HBM_PEAK_GBS),
                     note="16 MB per launch: launch-ramp bound, see extras.roofline_large for the same kernel at 1 GB")
+    ceil = fill_ceiling(P, args.segments)
+    if ceil is not None:
+        ceil["frac"] = alg_bytes / (ceil["avg_launch_us"] * 1e-6) / 1e9 / HBM_PEAK_GBS
+        ceil["note"] = ("fastest pure fill of the same bytes, per dispatch, from profiles/ (not this run): the ceiling of this "
+                        "launch size")
+        roofline["fill_ceiling"] = ceil
 
     # ---- FP64 rooflines of the solve kernel and of the outer-loop kernel (per dispatch, flop model of SURVEY.md 8d) ----
     db.coeffs, db.seg_times, db.status = out_coeffs[0], out_times[0], status_i32[0]

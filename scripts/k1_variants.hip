@@ -13,6 +13,11 @@
 #include <vector>
 
 #include "mrs_tg_device.hpp"
+// the library's own assembly kernel, timed under the same conditions as the variants
+#include "../mrs_uav_trajectory_generation_amd/csrc/mrs_tg_kernels.hip"
+#include "../mrs_uav_trajectory_generation_amd/csrc/mrs_tg_tile.hip"
+#include "../mrs_uav_trajectory_generation_amd/csrc/mrs_tg_rows.hip"
+#include "../mrs_uav_trajectory_generation_amd/csrc/mrs_tg_pool.hip"
 
 using namespace mrs_tg;
 
@@ -433,5 +438,9 @@ int main(int argc, char** argv) {
   ZPAD(128, 256);
   ZPAD(64, 64);
   ZPAD(512, 64);
+  measure("library assemble_blocks_uniform_kernel", [&] {
+    hipLaunchKernelGGL(assemble_blocks_uniform_kernel, dim3(cdiv(P, kAssembleChunk) * kN * S), dim3(kAssembleChunk), 0, st, P, S, d,
+                       T, H, A);
+  }, st, bytes);
   return 0;
 }
