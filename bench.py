@@ -69,6 +69,9 @@ def parse_args(argv=None):
     ap.add_argument("--force-dist", action="store_true", help="initialise torch.distributed even for one rank (tests the RCCL path)")
     ap.add_argument("--dist-backend", choices=["nccl", "gloo"], default="nccl",
                     help="gloo: the collectives go through host memory (lets several ranks share one GPU in a test)")
+    ap.add_argument("--issue-threads", type=int, default=2,
+                    help="host threads of the library's issue loop (mrs_tg_bound_solve_launch_many_mt): one runtime launch "
+                         "costs the host more than four concurrent kernels take to retire one")
     ap.add_argument("--in-flight", type=int, default=4,
                     help="independent batches in flight per GPU: steps are issued round-robin on this many HIP streams "
                          "(one context + plan each); 1 = every step waits for the previous one")
@@ -383,7 +386,8 @@ def main():
                     slot_free[slot] = None
             key = (kind, lanes, slots)
             if key not in round_robin:
-                round_robin[key] = api.RoundRobin([slot_call(kind, sl, sl % lanes) for sl in range(slots)])
+                round_robin[key] = api.RoundRobin([slot_call(kind, sl, sl % lanes) for sl in range(slots)],
+                                                  threads=min(args.issue_threads, slots))
             round_robin[key](n)
             step_no[0] = n
             last_slot[0] = ((n - 1) % slots, ((n - 1) % slots) % lanes)
@@ -757,8 +761,9 @@ def main():
                                              "(nothing materialised); the assembly kernel is timed on its own (roofline) and "
                                              "inside extras.materialized_blocks_step",
                                 clock_ramp_steps=ramp_steps, clock_ramp_ms=30,
-                                step_issue=("mrs_tg_bound_solve_launch_many: the K steps are issued round-robin over the "
-                                            "streams by the library's C loop" if block_for(args.workload) is not None
+                                step_issue=("mrs_tg_bound_solve_launch_many_mt: the K steps are issued round-robin over the "
+                                            "streams by the library's C loop on %d host thread(s)"
+                                            % min(args.issue_threads, n_lanes) if block_for(args.workload) is not None
                                             else "one Python call per step"),
                                 launch_hint=("MRS_TG_FLAG_SHARED_DEVICE (several batches in flight: two paths per wavefront "
                                              "so that four launches fit the SIMDs side by side)" if n_lanes > 1 else "none"),

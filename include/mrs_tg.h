@@ -246,6 +246,13 @@ void mrs_tg_bound_solve_destroy(mrs_tg_bound_solve* bound);
  * (one bound solve per context + stream).  Stops at the first error and returns its code (mrs_tg_last_error of that
  * solve's context has the text). */
 int mrs_tg_bound_solve_launch_many(mrs_tg_bound_solve* const* bound, int32_t n_bound, int32_t n_launches);
+/* The same loop on n_threads host threads (the caller + helper threads of the library, created on first use): thread j issues
+ * the launches of bound[j], bound[j + n_threads], ... -- a runtime launch costs the host 3.5-4.5 us, more than four
+ * concurrent 10 us kernels take to retire one, so one issuing thread bounds a host with four batches in flight.  n_threads
+ * is lowered to a divisor of n_bound (a bound solve stays on one thread); the helpers spin for 2 ms after a run before they
+ * go to sleep.  Returns when every launch has been issued (not finished). */
+int mrs_tg_bound_solve_launch_many_mt(mrs_tg_bound_solve* const* bound, int32_t n_bound, int32_t n_launches,
+                                      int32_t n_threads);
 /* The same run of launches captured once as a HIP graph and re-issued with ONE submission per run (launch-bound loops:
  * short runs on an idle device, where every first launch of a stream pays the runtime's idle-to-busy path).  The streams of
  * the bound solves become parallel branches, forked from and joined back into the stream of bound[0]'s context, on which

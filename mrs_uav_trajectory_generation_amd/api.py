@@ -74,7 +74,7 @@ EXPORTED_SYMBOLS = [
     "mrs_tg_set_stream", "mrs_tg_reset_stream", "mrs_tg_synchronize", "mrs_tg_solve_batch", "mrs_tg_plan_create", "mrs_tg_plan_destroy",
     "mrs_tg_plan_n_paths", "mrs_tg_plan_n_segments", "mrs_tg_plan_max_segments", "mrs_tg_plan_get_order",
     "mrs_tg_plan_assemble", "mrs_tg_plan_block_bytes", "mrs_tg_plan_solve", "mrs_tg_plan_bind_solve",
-    "mrs_tg_bound_solve_launch", "mrs_tg_bound_solve_launch_many", "mrs_tg_bound_solve_graph_create",
+    "mrs_tg_bound_solve_launch", "mrs_tg_bound_solve_launch_many", "mrs_tg_bound_solve_launch_many_mt", "mrs_tg_bound_solve_graph_create",
     "mrs_tg_graph_launch", "mrs_tg_graph_destroy", "mrs_tg_bound_solve_destroy", "mrs_tg_plan_cost_gradient",
     "mrs_tg_plan_segment_maxima", "mrs_tg_plan_sample_states", "mrs_tg_plan_careful_count", "mrs_tg_set_profiling", "mrs_tg_last_kernel_ms", "mrs_tg_kernel_ms_history",
     "mrs_tg_find_trajectory",
@@ -142,6 +142,8 @@ def load_library():
     L.mrs_tg_bound_solve_launch.argtypes = [vp]
     L.mrs_tg_bound_solve_launch_many.restype = C.c_int
     L.mrs_tg_bound_solve_launch_many.argtypes = [C.POINTER(vp), C.c_int32, C.c_int32]
+    L.mrs_tg_bound_solve_launch_many_mt.restype = C.c_int
+    L.mrs_tg_bound_solve_launch_many_mt.argtypes = [C.POINTER(vp), C.c_int32, C.c_int32, C.c_int32]
     L.mrs_tg_bound_solve_graph_create.restype = C.c_int
     L.mrs_tg_bound_solve_graph_create.argtypes = [C.POINTER(vp), C.c_int32, C.c_int32, C.POINTER(vp)]
     L.mrs_tg_graph_launch.restype = C.c_int
@@ -550,13 +552,14 @@ class RoundRobin:
     """The issue loop of a host that keeps several batches in flight, in C (mrs_tg_bound_solve_launch_many): launch k goes to
     calls[k % len(calls)], each a callable returned by Plan.bind_solve (one per context + stream)."""
 
-    def __init__(self, calls):
+    def __init__(self, calls, threads=1):
         self._calls = list(calls)
         self._arr = (C.c_void_p * len(self._calls))(*[c.handle for c in self._calls])
-        self._fn = load_library().mrs_tg_bound_solve_launch_many
+        self._fn = load_library().mrs_tg_bound_solve_launch_many_mt
+        self._threads = int(threads)
 
     def __call__(self, n_launches):
-        rc = self._fn(self._arr, len(self._calls), int(n_launches))
+        rc = self._fn(self._arr, len(self._calls), int(n_launches), self._threads)
         if rc:
             for c in self._calls:
                 c.ctx._check(rc, "mrs_tg_bound_solve_launch_many")

@@ -6,6 +6,9 @@
 #include "mrs_tg_pool.h"
 
 #include <algorithm>
+#include <thread>
+#include <memory>
+#include <condition_variable>
 #include <atomic>
 #include <chrono>
 #include <cfloat>
@@ -566,6 +569,122 @@ int mrs_tg_bound_solve_launch(mrs_tg_bound_solve* b) {
 }
 
 void mrs_tg_bound_solve_destroy(mrs_tg_bound_solve* b) { delete b; }
+
+// ---- the issue loop on several host threads ------------------------------------------------------
+// One runtime launch costs the host 3.5-4.5 us; four 10 us kernels in flight retire one every 2.6 us, so a single issuing
+// thread is what bounds a host that keeps four batches in flight.  Helper threads (created on first use, one per extra
+// issuing thread) take the launches of the bound solves k = j, j + T, ... -- the order within a bound solve's stream is kept,
+// the streams are independent anyway.  A helper spins for work for kSpinUs after its last job (a server that issues runs
+// back to back never pays a wake-up), then sleeps on a condition variable.
+namespace {
+
+struct IssueJob {
+  mrs_tg_bound_solve* const* bound = nullptr;
+  int n_bound = 0, n_launches = 0, first = 0, stride = 1;
+  int rc = MRS_TG_OK;
+};
+
+class IssuePool {
+ public:
+  static IssuePool& instance() {
+    static IssuePool pool;
+    return pool;
+  }
+  // runs jobs[1..] on helpers and jobs[0] on the caller; returns when all are done
+  void run(std::vector<IssueJob>& jobs) {
+    const int helpers = (int)jobs.size() - 1;
+    ensure(helpers);
+    for (int j = 0; j < helpers; ++j) workers_[j]->post(&jobs[j + 1]);
+    issue(jobs[0]);
+    for (int j = 0; j < helpers; ++j) workers_[j]->wait();
+  }
+  static void issue(IssueJob& job) {
+    for (int k = job.first; k < job.n_launches; k += job.stride) {
+      const int rc = mrs_tg_bound_solve_launch(job.bound[k % job.n_bound]);
+      if (rc != MRS_TG_OK) {
+        job.rc = rc;
+        return;
+      }
+    }
+  }
+
+ private:
+  static constexpr int kSpinUs = 2000;
+  struct Worker {
+    std::atomic<IssueJob*> job{nullptr};
+    std::atomic<bool> done{true}, quit{false};
+    std::mutex m;
+    std::condition_variable cv;
+    std::thread th;
+    Worker() : th([this] { loop(); }) {}
+    ~Worker() {
+      quit.store(true);
+      {
+        std::lock_guard<std::mutex> lk(m);
+      }
+      cv.notify_one();
+      th.join();
+    }
+    void post(IssueJob* j) {
+      done.store(false, std::memory_order_relaxed);
+      job.store(j, std::memory_order_release);
+      {
+        std::lock_guard<std::mutex> lk(m);  // pairs with the sleeper's predicate check
+      }
+      cv.notify_one();
+    }
+    void wait() {
+      while (!done.load(std::memory_order_acquire)) __builtin_ia32_pause();
+    }
+    void loop() {
+      while (!quit.load()) {
+        IssueJob* j = nullptr;
+        const auto t_end = std::chrono::steady_clock::now() + std::chrono::microseconds(kSpinUs);
+        while (!(j = job.exchange(nullptr, std::memory_order_acquire))) {
+          if (quit.load()) return;
+          if (std::chrono::steady_clock::now() > t_end) {
+            std::unique_lock<std::mutex> lk(m);
+            cv.wait(lk, [this] { return job.load(std::memory_order_acquire) != nullptr || quit.load(); });
+          } else {
+            __builtin_ia32_pause();
+          }
+        }
+        IssuePool::issue(*j);
+        done.store(true, std::memory_order_release);
+      }
+    }
+  };
+  void ensure(int helpers) {
+    while ((int)workers_.size() < helpers) workers_.emplace_back(new Worker());
+  }
+  std::vector<std::unique_ptr<Worker>> workers_;
+};
+
+}  // namespace
+
+int mrs_tg_bound_solve_launch_many_mt(mrs_tg_bound_solve* const* bound, int32_t n_bound, int32_t n_launches,
+                                      int32_t n_threads) {
+  if (!bound || n_bound < 1 || n_launches < 0) return fail(nullptr, MRS_TG_ERR_INVALID_ARG, "bound solves are required");
+  int T = n_threads < 1 ? 1 : n_threads;
+  if (T > n_bound) T = n_bound;  // a bound solve's launches stay on one thread
+  if (T > 8) T = 8;
+  // thread j takes the launches whose bound solve index is congruent to j modulo T: n_bound must be a multiple of T for the
+  // round-robin order k -> k % n_bound to keep a solve on one thread
+  while (T > 1 && n_bound % T != 0) --T;
+  if (T == 1) return mrs_tg_bound_solve_launch_many(bound, n_bound, n_launches);
+  std::vector<IssueJob> jobs((size_t)T);
+  for (int j = 0; j < T; ++j) {
+    jobs[j].bound = bound;
+    jobs[j].n_bound = n_bound;
+    jobs[j].n_launches = n_launches;
+    jobs[j].first = j;
+    jobs[j].stride = T;
+  }
+  IssuePool::instance().run(jobs);
+  for (const IssueJob& j : jobs)
+    if (j.rc != MRS_TG_OK) return j.rc;
+  return MRS_TG_OK;
+}
 
 int mrs_tg_bound_solve_launch_many(mrs_tg_bound_solve* const* bound, int32_t n_bound, int32_t n_launches) {
   if (!bound || n_bound < 1 || n_launches < 0) return fail(nullptr, MRS_TG_ERR_INVALID_ARG, "bound solves are required");

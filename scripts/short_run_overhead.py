@@ -12,7 +12,7 @@ from mrs_uav_trajectory_generation_amd import api, problem as pr  # noqa: E402
 
 P, S, LANES = 1024, 10, 4
 batch = pr.random_batch(P, S, seed0=0)
-streams = [torch.cuda.Stream() for _ in range(LANES)]
+streams = [torch.cuda.current_stream()] + [torch.cuda.Stream() for _ in range(LANES - 1)]
 plans, dbs, calls, ctxs = [], [], [], []
 est = api.default_options(estimate_times=1)
 opt = api.default_options(flags=api.FLAG_SHARED_DEVICE)
@@ -25,7 +25,9 @@ for st in streams:
         pl.solve(est, db.fixed_mask, db.fixed_values, db.seg_times, db.coeffs, db.status, db.cost, waypoints=db.waypoints, limits=db.limits)
         ctxs.append(c), plans.append(pl), dbs.append(db)
         calls.append(pl.bind_solve(opt, db.fixed_mask, db.fixed_values, db.seg_times, db.coeffs, db.status, db.cost))
-rr = api.RoundRobin(calls)
+THREADS = int(os.environ.get("ISSUE_THREADS", "1"))
+rr = api.RoundRobin(calls, threads=THREADS)
+print("issuing threads:", THREADS)
 rr(600)
 torch.cuda.synchronize()
 
@@ -49,6 +51,9 @@ def timed(n, reps=30):
 for n in (0, 1, 4, 20, 100):
     b, m, issue = timed(n)
     print("%3d launches + synchronize: best %.1f us, mean %.1f us (issue loop of the last repetition %.1f us)" % (n, b, m, issue))
+
+
+sys.exit(0)
 
 
 def timed_graph(n, reps=30):

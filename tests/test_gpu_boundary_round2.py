@@ -246,3 +246,37 @@ def test_run_of_solves_as_one_hip_graph(gpu_ctx):
         pl.close()
     for c in ctxs:
         c.close()
+
+
+def test_issue_loop_on_several_host_threads(gpu_ctx):
+    """mrs_tg_bound_solve_launch_many_mt: the launches of a bound solve stay on one thread (stream order kept), the threads
+    issue concurrently; same results as the single-threaded loop, errors still come back."""
+    batch = pr.random_batch(200, 8, seed0=77)
+    streams = [torch.cuda.Stream() for _ in range(4)]
+    ctxs, plans, dbs, calls = [], [], [], []
+    est = api.default_options(estimate_times=1)
+    lin = api.default_options(flags=api.FLAG_SHARED_DEVICE)
+    for st in streams:
+        with torch.cuda.stream(st):
+            c = api.Context(0)
+            c.use_torch_stream()
+            pl = api.Plan(c, batch.seg_offsets)
+            db = api.DeviceBatch(batch, "cuda:0", sample_capacity=16)
+            pl.solve(est, db.fixed_mask, db.fixed_values, db.seg_times, db.coeffs, db.status, db.cost, waypoints=db.waypoints,
+                     limits=db.limits)
+            ctxs.append(c), plans.append(pl), dbs.append(db)
+            calls.append(pl.bind_solve(lin, db.fixed_mask, db.fixed_values, db.seg_times, db.coeffs, db.status, db.cost))
+    torch.cuda.synchronize()
+    ref = gpu_ctx.solve_batch(batch, None)
+    for threads in (2, 3, 4):   # (3 does not divide 4 bound solves: the library lowers it to 2)
+        for db in dbs:
+            db.coeffs.zero_()
+        torch.cuda.synchronize()
+        api.RoundRobin(calls, threads=threads)(41)
+        torch.cuda.synchronize()
+        for db in dbs:
+            assert np.array_equal(db.coeffs.cpu().numpy().reshape(ref["coeffs"].shape), ref["coeffs"])
+    for pl in plans:
+        pl.close()
+    for c in ctxs:
+        c.close()
