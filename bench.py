@@ -69,7 +69,7 @@ def parse_args(argv=None):
     ap.add_argument("--force-dist", action="store_true", help="initialise torch.distributed even for one rank (tests the RCCL path)")
     ap.add_argument("--dist-backend", choices=["nccl", "gloo"], default="nccl",
                     help="gloo: the collectives go through host memory (lets several ranks share one GPU in a test)")
-    ap.add_argument("--issue-threads", type=int, default=2,
+    ap.add_argument("--issue-threads", type=int, default=1,
                     help="host threads of the library's issue loop (mrs_tg_bound_solve_launch_many_mt): one runtime launch "
                          "costs the host more than four concurrent kernels take to retire one")
     ap.add_argument("--in-flight", type=int, default=4,
