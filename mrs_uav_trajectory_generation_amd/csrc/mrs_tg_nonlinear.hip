@@ -1274,9 +1274,12 @@ __device__ __forceinline__ double evaluate_careful(const uint8_t* __restrict__ m
 // the first one's idle issue slots.  Lane k of a group of G sweeps time vector k (k, k + G, ... when S + 1 > G).
 __host__ __device__ constexpr int lean_eval_doubles(int Sb) { return 4 * Sb + 4 * (Sb + 1); }  // dp, staging area
 
-__device__ __forceinline__ double evaluate_lean(const double* tabs, const double* ev, int S, int d, const double* pt,
+template <bool MASKED>
+__device__ __forceinline__ double evaluate_lean(const double* tabs, const double* ev, int S, int Sb, int d, const double* pt,
                                                 double* grad, int g, int G, bool active, int* tripped) {
   const double* dp = ev;
+  // MASKED: free masks of the two end vertices (stage_ps); 0 = fully constrained, the plain start / end step
+  const unsigned m_first = MASKED ? (unsigned)ev[4 * (size_t)Sb] : 0u, m_last = MASKED ? (unsigned)ev[4 * (size_t)Sb + 1] : 0u;
   const double* tab = tabs;  // left-to-right table
   const double corr = kGradStep / ((double)S - 1.0);
   double J0 = 0.0;
@@ -1301,9 +1304,18 @@ __device__ __forceinline__ double evaluate_lean(const double* tabs, const double
           for (int j = 0; j < 8; ++j) fast.w[q][j] = tab[36 + j] * dq;
           fast.w[q][8] = tab[44] * dq * dq;
         }
-        if (i == 0) fast.template start_t<false>(st, tab, p2);
-        else if (i < S - 1) fast.template interior_t<false>(st, tab, p2);
-        else fast.end(st, tab, p2);
+        if (i == 0) {
+          if (MASKED && m_first != 0u) fast.template masked_t<false>(st, tab, p2, m_first, 0xFu);
+          else fast.template start_t<false>(st, tab, p2);
+        } else if (i < S - 1) {
+          fast.template interior_t<false>(st, tab, p2);
+        } else if (MASKED && m_last != 0u) {
+          fast.template masked_t<false>(st, tab, p2, 0xFu, m_last);
+          double L[10], z[kNB][4];
+          st.factor_vertex(m_last, L, z);
+        } else {
+          fast.end(st, tab, p2);
+        }
       }
       Jk = 0.5 * (st.qf - st.red);
       qfk = st.qf;
@@ -1325,11 +1337,15 @@ __host__ __device__ constexpr int lean_group_doubles(int Sb) {
 }
 
 // positions -> dp of every segment; returns whether the path is one the evaluation takes (group-uniform)
+// end_masks: the two end vertices may leave slots free (rest-to-rest paths under an objective order below snap: jerk and /
+// or snap stay free there); their free masks are left at ev[4 Sb] and ev[4 Sb + 1] for evaluate_lean<true>
 __device__ __forceinline__ bool stage_ps(const uint8_t* __restrict__ mask, const double* __restrict__ vals, int v0, int S,
-                                         int Sb, double* ev, int g, int G, bool active, int min_segments) {
+                                         int Sb, double* ev, int g, int G, bool active, int min_segments,
+                                         bool end_masks = false) {
   double* dp = ev;
   double* tmp = ev + 4 * (size_t)Sb;  // the record area, not in use yet
   int ok = (S >= min_segments) ? 1 : 0;
+  unsigned fb_first = 0u, fb_last = 0u;
   if (active)
     for (int v = g; v <= S; v += G) {
       double f[kHalf][kD];
@@ -1340,8 +1356,11 @@ __device__ __forceinline__ bool stage_ps(const uint8_t* __restrict__ mask, const
       for (int k = 1; k < kHalf; ++k)
 #pragma unroll
         for (int q = 0; q < kD; ++q) nz += fabs(f[k][q]);
-      const unsigned want = (v == 0 || v == S) ? 0u : 0xFu;
-      if (!(pf && nz == 0.0 && fb == want)) ok = 0;
+      const bool end = v == 0 || v == S;
+      const bool pattern_ok = end ? (end_masks || fb == 0u) : fb == 0xFu;
+      if (!(pf && nz == 0.0 && pattern_ok)) ok = 0;
+      if (v == 0) fb_first = fb;
+      if (v == S) fb_last = fb;
 #pragma unroll
       for (int q = 0; q < kD; ++q) tmp[v * 4 + q] = f[0][q];
     }
@@ -1351,6 +1370,11 @@ __device__ __forceinline__ bool stage_ps(const uint8_t* __restrict__ mask, const
     for (int i = g; i < S; i += G)
 #pragma unroll
       for (int q = 0; q < kD; ++q) dp[i * 4 + q] = tmp[i * 4 + q] - tmp[(i + 1) * 4 + q];
+  ps_wave_sync();
+  if (end_masks && active) {
+    if (g == 0) tmp[0] = (double)fb_first;
+    if (g == (S & (G - 1))) tmp[1] = (double)fb_last;  // the lane that loaded vertex S
+  }
   ps_wave_sync();
   return all_ok;
 }
@@ -1433,7 +1457,7 @@ __device__ __forceinline__ void optimize_body(const BatchView& b, const Nonlinea
   double* vtx = tick_f + kTickState;  // [(Sb + 1) * kVtxLds]
   double* seg = vtx + (size_t)(Sb + 1) * kVtxLds + (kExtras ? kStartExtra : 0);  // [Sb * kSegLds], the moving-start extras in front
   if (LEAN) {  // vtx = the evaluation area: dp of every segment; the path's eligibility decides who runs it
-    const bool takes = stage_ps(mask, vals, pr.v0, S, Sb, vtx, g, G, active, 2);
+    const bool takes = stage_ps(mask, vals, pr.v0, S, Sb, vtx, g, G, active, 2, MASKED4);
     if (active && g == 0) fallback[q] = takes ? 0 : 1;
     active = active && takes;
   } else {
@@ -1541,7 +1565,7 @@ __device__ __forceinline__ void optimize_body(const BatchView& b, const Nonlinea
     }
     double fn;
     if (LEAN) {
-      fn = evaluate_lean(hc, vtx, S, d, xn, gn, g, G, !done, tick_i + 4);
+      fn = evaluate_lean<MASKED4>(hc, vtx, S, Sb, d, xn, gn, g, G, !done, tick_i + 4);
     } else if (CAREFUL) {
       fn = evaluate_careful(mask, vals, pr.v0, S, d, xn, gn, g, !done, careful_ws, (size_t)gridDim.x * 64,
                             blockIdx.x * 64u + (unsigned)lane);
@@ -2176,6 +2200,17 @@ __global__ __launch_bounds__(64, 2) void optimize_lean_kernel(BatchView b, Nonli
   optimize_body<1, false, false, true>(b, prm, bins, mask, vals, seg_times, opt_status, nullptr, fallback);
 }
 
+// the end vertices may leave slots free (launches whose objective order is below snap: the masked step at the two ends of
+// the sweep); one wavefront per SIMD -- at two it spills 96 registers and loses to the general kernel
+__global__ __launch_bounds__(64) void optimize_lean_masked_kernel(BatchView b, NonlinearParams prm, BinTable bins,
+                                                                  const uint8_t* __restrict__ mask,
+                                                                  const double* __restrict__ vals,
+                                                                  double* __restrict__ seg_times,
+                                                                  int32_t* __restrict__ opt_status,
+                                                                  int32_t* __restrict__ fallback) {
+  optimize_body<1, true, false, true>(b, prm, bins, mask, vals, seg_times, opt_status, nullptr, fallback);
+}
+
 // The outer loop again, from the untouched start times, for the paths the fast kernels listed (a trial point whose
 // by-product cost failed the guard): one path per workgroup, every evaluation through primal_cost_lane.
 __global__ __launch_bounds__(64) void optimize_careful_kernel(BatchView b, NonlinearParams prm, const uint8_t* __restrict__ mask,
@@ -2791,9 +2826,9 @@ static bool ps_applies(const NonlinearPlan&) {
 }
 
 // Lean sweeps for plain paths (optimize_lean_kernel): two wavefronts per SIMD where the general sweeping kernel has one.
-// (Objective orders below snap leave slots free at the end vertices of a rest-to-rest path: not plain, those launches stay
-// on optimize_compact_kernel<true>.  A lean variant with the masked step at the two ends was measured: 96 spilled
-// registers at two wavefronts per SIMD, 8192 x 10 random-walk paths at d = 2 429 vs 365 us -- not kept.)  Tuning / test knob: MRS_TG_LEAN=0|1.
+// Objective orders below snap leave slots free at the end vertices of a rest-to-rest path: optimize_lean_masked_kernel takes
+// those (masked step at the two ends of the sweep), at one wavefront per SIMD -- 256 + 74 registers; forced to two it spills
+// 96 and loses to the general kernel (8192 x 10 random-walk paths at d = 2: 429 vs 365 us; at one wavefront 332 us).
 static bool lean_applies(const NonlinearPlan& nl) {
   if (const char* e = std::getenv("MRS_TG_LEAN")) return std::atoi(e) != 0;
   return nl.dim_split == 1;
@@ -2876,11 +2911,17 @@ hipError_t launch_nonlinear(NonlinearPlan& nl, const BatchView& b, const Nonline
       blocks += (int)cdiv_u(bin.q_count, 64 / bin.group);
       plds = std::max(plds, plain_lds(bin));
     }
+    const bool lean_masked = prm.derivative < 4;  // rest-to-rest paths end on vertices with free slots
     if (plds > 64 * 1024 &&
-        (e = hipFuncSetAttribute((const void*)optimize_lean_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)plds)) != hipSuccess)
+        (e = hipFuncSetAttribute(lean_masked ? (const void*)optimize_lean_masked_kernel : (const void*)optimize_lean_kernel,
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)plds)) != hipSuccess)
       return e;
-    MRS_TG_LAUNCH_TIMED(optimize_lean_kernel, dim3(blocks), dim3(64), plds, stream, b, prm, bt, mask, vals, seg_times,
-                        nl.d_opt_status, nl.d_fallback);
+    if (lean_masked)
+      MRS_TG_LAUNCH_TIMED(optimize_lean_masked_kernel, dim3(blocks), dim3(64), plds, stream, b, prm, bt, mask, vals, seg_times,
+                          nl.d_opt_status, nl.d_fallback);
+    else
+      MRS_TG_LAUNCH_TIMED(optimize_lean_kernel, dim3(blocks), dim3(64), plds, stream, b, prm, bt, mask, vals, seg_times,
+                          nl.d_opt_status, nl.d_fallback);
     if ((e = hipGetLastError()) != hipSuccess) return e;
     prm.only_flagged = nl.d_fallback;
   }
