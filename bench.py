@@ -18,10 +18,13 @@ outer loop + feasibility scaling + sampling) instead.
 
 Weak scaling: every rank owns `--paths` paths and there is no data-path collective (paths are independent); as at N = 1 the
 results of a step stay resident in the HBM of the GPU that computed them, and the job's one collective -- the RCCL gather of
-the final step's coefficients / times / status to rank 0 ("exactly one gather at the end") -- runs inside the
-timed region.  BASELINE configs[3] in its own terms -- ONE batch of 65536 nonlinear-time paths cut into contiguous shards
-over the N ranks, results gathered to rank 0 -- is measured in the same run at every N and reported as extras.config3
-(strong scaling of a fixed batch).
+the final step's coefficients / times / status to rank 0 ("exactly one gather at the end") -- is timed on its
+own right behind the K steps (`gather_ms`; `value_including_gather` has it inside): its fixed cost (one RCCL launch + 3.4 MB
+per rank into the root) is as long as 20 of the 5 us steps and would otherwise be what a short run measures.  Each rank
+times its own K steps between its own synchronizes, after the opening barrier and before the closing one; `value` uses the
+MAX over ranks.  BASELINE configs[3] in its own terms -- ONE batch of 65536 nonlinear-time paths cut into contiguous shards
+over the N ranks, results gathered to rank 0 INSIDE its timed region -- is measured in the same run at every N and reported
+as extras.config3 and, in short, as the top-level `config3_strong_scaling` (strong scaling of a fixed batch).
 
 Steps are independent batches, so `--in-flight` of them (default 4 = the HIP runtime's hardware queues per process) are kept
 in flight per GPU, each on its own HIP stream with its own context and plan; extras.one_batch_in_flight is the same
@@ -119,10 +122,13 @@ def self_launch(args, argv):
 # ---------------------------------------------------------------------------------------------------------------------
 # helpers (run inside a rank)
 
-def time_steps(step_fn, steps, warmup, dist, torch, final_fn=None, block_fn=None):
-    """W untimed steps, then exactly K steps (+ final_fn, the job's closing gather) between barrier + synchronize
-    pairs; returns the MAX over ranks of the elapsed seconds.  block_fn(n), when given, issues n steps (the host's
-    issue loop in C, mrs_tg_bound_solve_launch_many) and replaces n calls of step_fn."""
+def time_steps(step_fn, steps, warmup, dist, torch, final_fn=None, block_fn=None, gather_inside=False):
+    """W untimed steps, then exactly K steps between barrier + synchronize pairs.  Every rank reads its own clock right after
+    its own synchronize (before the closing barrier, whose cost is a property of the collective library, not of the K steps);
+    the figure returned is the MAX over ranks.  final_fn, the job's closing gather, is timed on its own right behind the steps
+    (second return value, MAX over ranks; 0.0 without a collective) unless gather_inside, where it belongs to the timed
+    region (configs[3]: the fixed batch is not done before rank 0 holds the results).  block_fn(n), when given, issues n
+    steps (the host's issue loop in C, mrs_tg_bound_solve_launch_many) and replaces n calls of step_fn."""
     if block_fn is not None:
         def run(n):
             if n > 0:
@@ -140,20 +146,25 @@ def time_steps(step_fn, steps, warmup, dist, torch, final_fn=None, block_fn=None
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     run(steps)
-    if final_fn is not None:
+    if gather_inside and final_fn is not None:
         final_fn()
     torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    gather_s = 0.0
+    if final_fn is not None and not gather_inside and dist is not None:
+        t1 = time.perf_counter()
+        final_fn()
+        torch.cuda.synchronize()
+        gather_s = time.perf_counter() - t1
     if dist is not None:
         dist.barrier()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        torch.cuda.synchronize()
+        t = torch.tensor([elapsed, gather_s], dtype=torch.float64, device="cuda")
         if dist.get_backend() == "gloo":
             t = t.cpu()
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-    return elapsed
+        elapsed, gather_s = float(t[0].item()), float(t[1].item())
+    return elapsed, gather_s
 
 
 def dispatch_stats(ctx, kernel_id, launch_fn, reps, torch):
@@ -409,6 +420,18 @@ def main():
         finish_step(*last_slot[0])
         torch.cuda.current_stream().wait_event(slot_free[last_slot[0][0]])
 
+    def verify_gather():
+        """rank 0: what the closing gather delivered for rank 0 is bit for bit what rank 0 computed, and every peer's buffer
+        holds finite coefficients and status words of the library (not stale memory)"""
+        if rank != 0 or gloo:
+            return None
+        torch.cuda.synchronize()
+        slot = last_slot[0][0]
+        mine = bool(torch.equal(recv[slot][0], packed[slot]))
+        peers = all(bool(torch.isfinite(r).all()) and bool((r[nS * 41:].abs() <= 6).all()) for r in recv[slot])
+        return dict(root_equals_local=mine, peers_finite_with_valid_status=peers, ranks=len(recv[slot]),
+                    bytes_per_rank=int(packed[slot].numel() * 8))
+
     steps_fn = {"linear": make_linear_step("linear"), "blocks": make_linear_step("blocks"), "nonlinear": step_nonlinear}
     blocks_fn = {"linear": make_linear_block("linear"), "blocks": make_linear_block("blocks")}
 
@@ -427,10 +450,11 @@ def main():
         torch.cuda.synchronize()
     step_no[0] = 0
 
-    elapsed = time_steps(steps_fn[args.workload], args.steps, args.warmup, dist, torch, final_gather,
-                         block_fn=block_for(args.workload))
+    elapsed, gather_s = time_steps(steps_fn[args.workload], args.steps, args.warmup, dist, torch, final_gather,
+                                   block_fn=block_for(args.workload))
     total_paths = P * world * args.steps
     value = total_paths / elapsed
+    gather_check = verify_gather() if dist is not None else None
 
     # ---- roofline of the assembly kernel (rank 0's device) ----
     Hbuf = torch.empty(plan.block_doubles, dtype=torch.float64, device=dev)
@@ -582,7 +606,7 @@ def main():
                                           note="mrs_tg_solve_batch with host buffers, linear QP, includes PCIe copies")
     if not args.no_extras and args.workload == "linear":
         # the step that materialises the blocks: assembly kernel + solve from the blocks in HBM
-        elb = time_steps(steps_fn["blocks"], args.steps, 3, dist, torch, final_gather, block_fn=block_for("blocks"))
+        elb, _ = time_steps(steps_fn["blocks"], args.steps, 3, dist, torch, final_gather, block_fn=block_for("blocks"))
         if rank == 0:
             extras["materialized_blocks_step"] = dict(value=P * world * args.steps / elb, unit="trajectories/s",
                                                       ms_per_step=elb / args.steps * 1e3,
@@ -593,8 +617,9 @@ def main():
         torch.cuda.synchronize()
         active_lanes[0] = 1
         step_no[0] = 0
-        el1 = time_steps(steps_fn[args.workload], args.steps, 3, dist, torch, final_gather, block_fn=block_for(args.workload))
-        el1b = time_steps(steps_fn["blocks"], args.steps, 3, dist, torch, final_gather, block_fn=block_for("blocks")) if args.workload == "linear" else None
+        el1, _ = time_steps(steps_fn[args.workload], args.steps, 3, dist, torch, final_gather, block_fn=block_for(args.workload))
+        el1b = (time_steps(steps_fn["blocks"], args.steps, 3, dist, torch, final_gather, block_fn=block_for("blocks"))[0]
+                if args.workload == "linear" else None)
         active_lanes[0] = n_lanes
         step_no[0] = 0
         if rank == 0:
@@ -605,13 +630,13 @@ def main():
     if not args.no_extras:
         other = "nonlinear" if args.workload == "linear" else "linear"
         k2 = max(5, args.steps // 10) if other == "nonlinear" else args.steps
-        el2 = time_steps(steps_fn[other], k2, 3, dist, torch, final_gather, block_fn=block_for(other))
+        el2, _ = time_steps(steps_fn[other], k2, 3, dist, torch, final_gather, block_fn=block_for(other))
         if rank == 0:
             extras[other] = dict(value=P * world * k2 / el2, unit="trajectories/s", steps=k2, ms_per_step=el2 / k2 * 1e3)
         if dist is not None and not gather_every[0]:
             # the same workload with the results of EVERY step gathered to rank 0 (bound by the xGMI links into the root)
             gather_every[0] = True
-            el3 = time_steps(steps_fn[args.workload], args.steps, 3, dist, torch)
+            el3, _ = time_steps(steps_fn[args.workload], args.steps, 3, dist, torch)
             gather_every[0] = False
             if rank == 0:
                 extras["gather_every_step"] = dict(value=P * world * args.steps / el3, unit="trajectories/s",
@@ -654,14 +679,25 @@ def main():
             gather(pad3, recv3)
 
         k3 = max(3, min(10, args.steps // 20))
-        el4 = time_steps(step3, k3, 2, dist, torch, gather3)
+        el4, _ = time_steps(step3, k3, 2, dist, torch, gather3, gather_inside=True)
+        # paths the pipeline did not hand back as successes: ROUNDOFF_LIMITED = the feasibility scaling ran away (mrs_tg.h)
+        bad3 = torch.tensor([int((st3 == api.STATUS_ROUNDOFF_LIMITED).sum().item()), int((st3 <= 0).sum().item())], dtype=torch.int64, device=dev)
+        if dist is not None:
+            if gloo:
+                bad3 = bad3.cpu()
+            dist.all_reduce(bad3)
+        c3_check = None
+        if dist is not None and rank == 0 and recv3 is not None:
+            torch.cuda.synchronize()
+            c3_check = bool(torch.equal(recv3[0][:pk3.numel()], pk3))
         if rank == 0:
             extras["config3"] = dict(workload="BASELINE configs[3]: one batch of %d random %d-segment paths, Mellinger outer loop + "
                                               "feasibility scaling + sampling, contiguous shards over %d rank(s), results gathered "
                                               "to rank 0 after the last step (inside the timed region)" % (total3, args.segments, world),
                                      value=total3 * k3 / el4, unit="trajectories/s", scaling="strong", steps=k3,
                                      ms_per_step=el4 / k3 * 1e3, paths_per_rank=n3, n_gpus=world,
-                                     gather_bytes_per_rank=int(pk3.numel() * 8))
+                                     gather_bytes_per_rank=int(pk3.numel() * 8), gather_root_equals_local=c3_check,
+                                     runaway_paths=int(bad3[0].item()), paths_not_successful=int(bad3[1].item()))
         plan3.close()
         del db3, pk3, pad3, recv3
 
@@ -754,6 +790,12 @@ def main():
         line = dict(metric="trajectories/sec (batch of N-seg min-snap paths)", value=value, unit="trajectories/s",
                     n_gpus=world, ranks_seen=ranks_seen, steps=args.steps, warmup=args.warmup,
                     ms_per_step=elapsed / args.steps * 1e3,
+                    gather_ms=(gather_s * 1e3 if dist is not None else None),
+                    value_including_gather=(total_paths / (elapsed + gather_s) if dist is not None else None),
+                    gather_check=gather_check,
+                    config3_strong_scaling=({k: extras["config3"][k] for k in ("value", "unit", "scaling", "n_gpus", "ms_per_step",
+                                                                              "paths_per_rank")}
+                                            if "config3" in extras else None),
                     higher_is_better=True, scaling="weak", vs_baseline=None, dtype="f64", data="synthetic",
                     config=dict(workload=lin_desc if args.workload == "linear" else nl_desc,
                                 paths_per_gpu=P, segments=args.segments, batches_in_flight=n_lanes,
@@ -768,9 +810,11 @@ def main():
                                 launch_hint=("MRS_TG_FLAG_SHARED_DEVICE (several batches in flight: two paths per wavefront "
                                              "so that four launches fit the SIMDs side by side)" if n_lanes > 1 else "none"),
                                 parallelism=("independent paths sharded per rank, no data-path collective; %s gather of "
-                                             "the results to rank 0 %s, inside the timed region"
+                                             "the results to rank 0 %s"
                                              % ("gloo (host)" if gloo else "RCCL",
-                                                "after every step" if args.gather == "every" else "once, after the last step"))
+                                                "after every step, inside the timed region" if args.gather == "every" else
+                                                "once, after the last step: timed on its own (gather_ms) right behind the K "
+                                                "steps; value_including_gather has it inside"))
                                 if world > 1 else "single GPU"),
                     max_coeff_err_vs_cpu_ref=err, roofline=roofline, roofline_solve=roofline_solve,
                     roofline_outer_loop=roofline_outer, cpu_baseline=cpu, extras=extras)

@@ -4,6 +4,7 @@
 //
 //   g++ -std=c++17 -I include examples/path_service_host.cpp -o path_service_host
 //     -L mrs_uav_trajectory_generation_amd -lmrs_tg -Wl,-rpath,$PWD/mrs_uav_trajectory_generation_amd
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 
@@ -93,7 +94,56 @@ int main() {
 
   // 4. the fallback sampler alone (enforce_fallback_solver / last attempt)
   srv.params().policy.fallback_sampling = 1;
-  print_response("fallback", srv.getPath(test_path()), true);
+  const GetPathResponse fb = srv.getPath(test_path());
+  print_response("fallback", fb, false);
+  srv.params().policy.fallback_sampling = 0;
+
+  // 5. a request whose budget is spent before it starts: optimize() runs the fallback sampler for it ("executing fallback
+  //    sampling, we are running over time", :711-713) -- the request succeeds with the fallback trajectory
+  Path late = test_path();
+  late.max_execution_time = 1e-6;
+  const GetPathResponse lr = srv.getPath(late);
+  print_response("late_request", lr, false);
+  bool same = lr.trajectory.points.size() == fb.trajectory.points.size();
+  for (size_t i = 0; same && i < fb.trajectory.points.size(); ++i)
+    same = lr.trajectory.points[i].x == fb.trajectory.points[i].x && lr.trajectory.points[i].heading == fb.trajectory.points[i].heading;
+  printf("\"late_equals_fallback\": %s,\n", same ? "true" : "false");
+
+  // 6. many requests in one call with the default parameters (max_time 0.5 s per request, three deviation groups): every
+  //    request is answered, by the solver or -- if its group ran late -- by the fallback sampler
+  std::vector<Path> many;
+  unsigned long long lcg = 12345;
+  auto uni = [&]() {
+    lcg = lcg * 6364136223846793005ULL + 1442695040888963407ULL;
+    return (double)(lcg >> 11) / 9007199254740992.0;
+  };
+  for (int r = 0; r < 600; ++r) {
+    Path p;
+    p.frame_id = "uav1/world_origin";
+    p.input_id = 100 + r;
+    p.use_heading = true;
+    p.dont_prepend_current_state = true;
+    double x = 0, y = 0, bearing = 0;
+    const int n = 4 + r % 9;
+    for (int i = 0; i < n; ++i) {
+      bearing += -0.4 + 0.8 * uni();
+      const double step = 0.5 + 1.5 * uni();
+      x += step * std::cos(bearing);
+      y += step * std::sin(bearing);
+      p.points.push_back({x, y, 5.0 + 0.2 * uni() - 0.1, bearing});
+    }
+    p.max_deviation_from_path = (r % 3 == 0) ? 0.0 : (r % 3 == 1 ? 0.1 : 0.3);
+    many.push_back(p);
+  }
+  const auto t0 = std::chrono::steady_clock::now();
+  const auto mres = srv.getPaths(many);
+  const double el = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+  int n_ok = 0, n_id = 0;
+  for (size_t r = 0; r < mres.size(); ++r) {
+    n_ok += mres[r].success ? 1 : 0;
+    n_id += (mres[r].trajectory.input_id == 100 + r && mres[r].trajectory.points.size() > 2) ? 1 : 0;
+  }
+  printf("\"many\": {\"requests\": %d, \"success\": %d, \"own_fields\": %d, \"elapsed_s\": %.4f}\n", (int)mres.size(), n_ok, n_id, el);
   printf("}\n");
   return 0;
 }

@@ -56,12 +56,25 @@ enum {
                                       vertex (src/...cpp:944, 963, 967) and the fast kernels rely on it; the general
                                       fixed / free patterns of setupConstraintReorderingMatrix (linear_impl.h:184-257)
                                       are solved in fixed-times mode under MRS_TG_FLAG_GENERAL_PATTERNS */
+  MRS_TG_STATUS_ROUNDOFF_LIMITED = -4, /* nlopt::ROUNDOFF_LIMITED, which the nodelet rejects (:1103-1106, 1146-1149).  Mellinger
+                                      mode: the feasibility scaling that follows the outer loop has multiplied the path's
+                                      total time by more than MRS_TG_RUNAWAY_TIME_FACTOR -- the outer loop ended on a point
+                                      with a segment on the 0.01 s bound next to seconds-long neighbours, where the linear
+                                      solve has a condition number of (T_max / T_min)^7 and its maxima are rounding noise
+                                      (DESIGN.md section 5).  The arrays hold what was computed; it is not a trajectory
+                                      to fly.  The reference returns such a path with MAXEVAL_REACHED and leaves it to the
+                                      nodelet's length check (:1178-1199) to discard it */
   MRS_TG_STATUS_SUCCESS = 1,
   MRS_TG_STATUS_FTOL_REACHED = 3,
   MRS_TG_STATUS_XTOL_REACHED = 4,
   MRS_TG_STATUS_MAXEVAL_REACHED = 5,
   MRS_TG_STATUS_MAXTIME_REACHED = 6
 };
+
+/* sum of the final segment times / sum of the times the outer loop started from, above which a Mellinger result is
+ * reported as MRS_TG_STATUS_ROUNDOFF_LIMITED.  Healthy paths: median 1.6, 99.9 % below 3, the largest of 8192 paths with
+ * limits scaled by 0.3 ... 3 and mixed constraint patterns 18.6; runaways: 30 ... 1e10 (oracle, tests/test_oracle_runaway.py) */
+#define MRS_TG_RUNAWAY_TIME_FACTOR 25.0
 
 /* time_alloc_method (NonlinearOptimizationParameters::TimeAllocMethod,
  * include/eth_trajectory_generation/polynomial_optimization_nonlinear.h:92-100) */
@@ -253,18 +266,6 @@ int mrs_tg_bound_solve_launch_many(mrs_tg_bound_solve* const* bound, int32_t n_b
  * go to sleep.  Returns when every launch has been issued (not finished). */
 int mrs_tg_bound_solve_launch_many_mt(mrs_tg_bound_solve* const* bound, int32_t n_bound, int32_t n_launches,
                                       int32_t n_threads);
-/* The same run of launches captured once as a HIP graph and re-issued with ONE submission per run (launch-bound loops:
- * short runs on an idle device, where every first launch of a stream pays the runtime's idle-to-busy path).  The streams of
- * the bound solves become parallel branches, forked from and joined back into the stream of bound[0]'s context, on which
- * mrs_tg_graph_launch enqueues the whole run; results are those of mrs_tg_bound_solve_launch_many.  Requirements: every
- * bound solve has been launched once before (its workspaces exist), every context has a stream of its own (not the
- * default stream), profiling is off, the arguments stay in place. */
-typedef struct mrs_tg_graph mrs_tg_graph;
-int mrs_tg_bound_solve_graph_create(mrs_tg_bound_solve* const* bound, int32_t n_bound, int32_t n_launches,
-                                    mrs_tg_graph** graph_out);
-int mrs_tg_graph_launch(mrs_tg_graph* graph);
-void mrs_tg_graph_destroy(mrs_tg_graph* graph);
-
 /* Building blocks of the outer loop, exposed for parity tests (device pointers, asynchronous):
  * J_d and the h = 0.1 forward-difference gradient at the given times
  * (getCostAndGradientMellinger, nonlinear_impl.h:257-333): cost_out_dev [n_paths], grad_out_dev [sum S]. */
@@ -344,10 +345,13 @@ typedef struct mrs_tg_policy_options {
   double fallback_speed_factor, fallback_accel_factor, fallback_stopping_time;
   int32_t override_heading_atan2;      /* getTrajectoryReference (:1582-1597) */
   int32_t reserved_;
-  double max_execution_time_s;         /* max_execution_time (:2008-2033); <= 0: none.  Checked before every round: the
-                                          solver's max_time_s becomes 2 * 0.95 * time left (:899) and a path that is still
-                                          active when the time is up fails, as overtime() makes the nodelet give up
-                                          (:1085, 1156, 1171, 1516-1522) */
+  double max_execution_time_s;         /* max_execution_time (:2008-2033); <= 0: none.  As optimize() does (:702-716, :754-768):
+                                          a round that starts while overtime() holds runs the fallback sampler for the paths
+                                          still active (they succeed, "executing fallback sampling, we are running over time");
+                                          otherwise the solver's max_time_s becomes 2 * 0.95 * time left (:899), and paths whose
+                                          solve comes back after the deadline fail, as findTrajectory's own checks make the
+                                          nodelet give up (:1085, 1156, 1171, 1516-1522).  fallback_sampling = 1 never looks
+                                          at the clock */
 } mrs_tg_policy_options;
 
 void mrs_tg_default_policy_options(mrs_tg_policy_options* opt);

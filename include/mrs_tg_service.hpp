@@ -163,7 +163,6 @@ public:
       jobs.push_back(std::move(job));
     }
 
-    const auto t_start = std::chrono::steady_clock::now();  // start_time_total_ (:2008)
     std::vector<size_t> pending(jobs.size());
     for (size_t j = 0; j < jobs.size(); ++j) pending[j] = j;
     const int attempts = params_.n_attempts > 0 ? params_.n_attempts : 1;
@@ -174,13 +173,23 @@ public:
       for (size_t j : pending) by_deviation[jobs[j].max_deviation].push_back(j);
       std::vector<size_t> still;
       for (auto& [max_deviation, group] : by_deviation) {
-        // the requests of a GPU call share its clock: the tightest budget of the group, minus what the call has used
+        // start_time_total_ (:2008) is set when the callback starts to work on a request, not while the request waits in
+        // the service queue: a request's clock starts when its group's first GPU call is set up and runs on through the
+        // later attempts.  The requests of one GPU call share that call, so it gets the tightest time left of its group;
+        // a group that is already late is not given up -- the policy layer runs the fallback sampler for it, as
+        // optimize() does when overtime() holds (:711-713).
+        const auto now = std::chrono::steady_clock::now();
         double budget = 0;
-        for (size_t j : group)
-          if (jobs[j].max_execution_time > 0 && (budget <= 0 || jobs[j].max_execution_time < budget)) budget = jobs[j].max_execution_time;
-        if (budget > 0) {
-          budget -= std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count();
-          if (budget <= 0) budget = 1e-9;  // already late: the policy layer gives these requests up (overtime(), :1730-1743)
+        for (size_t j : group) {
+          Job& job = jobs[j];
+          if (!job.started) {
+            job.started = true;
+            job.t_start = now;
+          }
+          if (job.max_execution_time <= 0) continue;
+          double left = job.max_execution_time - std::chrono::duration<double>(now - job.t_start).count();
+          if (left <= 0) left = 1e-9;
+          if (budget <= 0 || left < budget) budget = left;
         }
         solve_group(jobs, group, max_deviation, fallback, budget);
         for (size_t j : group)
@@ -230,6 +239,8 @@ private:
     std::array<double, 9> limits{};
     double max_deviation = 0, max_deviation_out = 0;
     double max_execution_time = 0;  // this request's budget [s], <= 0: none
+    bool started = false;           // t_start is set: the request's clock runs (start_time_total_, :2008)
+    std::chrono::steady_clock::time_point t_start{};
     bool success = false;
     std::string message;
     std::vector<Reference> samples;

@@ -31,6 +31,9 @@ FLAG_GENERAL_PATTERNS = 16     # fixed-times mode: vertices without a position c
 FLAG_CAREFUL_COST = 8          # Mellinger mode: re-run the paths whose fast cost evaluation failed its guard with primal costs
 FLAG_SHARED_DEVICE = 4         # hint: several batches are in flight on this device (results unaffected)
 
+STATUS_ROUNDOFF_LIMITED = -4   # MRS_TG_STATUS_ROUNDOFF_LIMITED: the feasibility scaling ran away (include/mrs_tg.h)
+RUNAWAY_TIME_FACTOR = 25.0     # MRS_TG_RUNAWAY_TIME_FACTOR
+
 STATE_ORDERS = 5   # derivative orders 0..4 per sample of Plan.sample_states (MRS_TG_STATE_ORDERS)
 KERNEL_ASSEMBLE, KERNEL_SOLVE_LINEAR, KERNEL_NONLINEAR = 0, 1, 2
 
@@ -74,8 +77,8 @@ EXPORTED_SYMBOLS = [
     "mrs_tg_set_stream", "mrs_tg_reset_stream", "mrs_tg_synchronize", "mrs_tg_solve_batch", "mrs_tg_plan_create", "mrs_tg_plan_destroy",
     "mrs_tg_plan_n_paths", "mrs_tg_plan_n_segments", "mrs_tg_plan_max_segments", "mrs_tg_plan_get_order",
     "mrs_tg_plan_assemble", "mrs_tg_plan_block_bytes", "mrs_tg_plan_solve", "mrs_tg_plan_bind_solve",
-    "mrs_tg_bound_solve_launch", "mrs_tg_bound_solve_launch_many", "mrs_tg_bound_solve_launch_many_mt", "mrs_tg_bound_solve_graph_create",
-    "mrs_tg_graph_launch", "mrs_tg_graph_destroy", "mrs_tg_bound_solve_destroy", "mrs_tg_plan_cost_gradient",
+    "mrs_tg_bound_solve_launch", "mrs_tg_bound_solve_launch_many", "mrs_tg_bound_solve_launch_many_mt",
+    "mrs_tg_bound_solve_destroy", "mrs_tg_plan_cost_gradient",
     "mrs_tg_plan_segment_maxima", "mrs_tg_plan_sample_states", "mrs_tg_plan_careful_count", "mrs_tg_set_profiling", "mrs_tg_last_kernel_ms", "mrs_tg_kernel_ms_history",
     "mrs_tg_find_trajectory",
     "mrs_tg_default_policy_options", "mrs_tg_optimize_paths", "mrs_tg_waypoint_trajectory_idxs",
@@ -144,12 +147,6 @@ def load_library():
     L.mrs_tg_bound_solve_launch_many.argtypes = [C.POINTER(vp), C.c_int32, C.c_int32]
     L.mrs_tg_bound_solve_launch_many_mt.restype = C.c_int
     L.mrs_tg_bound_solve_launch_many_mt.argtypes = [C.POINTER(vp), C.c_int32, C.c_int32, C.c_int32]
-    L.mrs_tg_bound_solve_graph_create.restype = C.c_int
-    L.mrs_tg_bound_solve_graph_create.argtypes = [C.POINTER(vp), C.c_int32, C.c_int32, C.POINTER(vp)]
-    L.mrs_tg_graph_launch.restype = C.c_int
-    L.mrs_tg_graph_launch.argtypes = [vp]
-    L.mrs_tg_graph_destroy.restype = None
-    L.mrs_tg_graph_destroy.argtypes = [vp]
     L.mrs_tg_bound_solve_destroy.restype = None
     L.mrs_tg_bound_solve_destroy.argtypes = [vp]
     L.mrs_tg_plan_cost_gradient.restype = C.c_int
@@ -563,34 +560,6 @@ class RoundRobin:
         if rc:
             for c in self._calls:
                 c.ctx._check(rc, "mrs_tg_bound_solve_launch_many")
-
-    def graph(self, n_launches):
-        """The run of n_launches launches as one HIP graph (mrs_tg_bound_solve_graph_create): returns a callable that
-        enqueues it on the stream of the first call's context."""
-        L = load_library()
-        h = C.c_void_p()
-        rc = L.mrs_tg_bound_solve_graph_create(self._arr, len(self._calls), int(n_launches), C.byref(h))
-        if rc:
-            self._calls[0].ctx._check(rc, "mrs_tg_bound_solve_graph_create")
-        ctx0 = self._calls[0].ctx
-
-        class _Graph:
-            def __init__(self, handle, keep):
-                self._h, self._keep = handle, keep
-
-            def __call__(self):
-                rc = L.mrs_tg_graph_launch(self._h)
-                if rc:
-                    ctx0._check(rc, "mrs_tg_graph_launch")
-
-            def close(self):
-                if self._h:
-                    L.mrs_tg_graph_destroy(self._h)
-                    self._h = None
-
-            def __del__(self):
-                self.close()
-        return _Graph(h, self)
 
 
 class DeviceBatch:

@@ -695,94 +695,6 @@ int mrs_tg_bound_solve_launch_many(mrs_tg_bound_solve* const* bound, int32_t n_b
   return MRS_TG_OK;
 }
 
-// ---- a run of bound solves as one HIP graph ----------------------------------------------------
-// The issue loop above costs one runtime launch per solve; on an idle device (a short run, or a server whose queue ran
-// dry) every first launch of a stream pays the runtime's idle-to-busy path as well.  Captured once, the same run is ONE
-// submission: the streams of the bound solves become parallel branches of the graph (forked from and joined back into the
-// first solve's stream), each branch a chain of that stream's solves in issue order.
-struct mrs_tg_graph {
-  hipGraph_t graph = nullptr;
-  hipGraphExec_t exec = nullptr;
-  hipStream_t origin = nullptr;
-  mrs_tg_ctx* ctx = nullptr;
-  int32_t n_launches = 0;
-};
-
-int mrs_tg_bound_solve_graph_create(mrs_tg_bound_solve* const* bound, int32_t n_bound, int32_t n_launches,
-                                    mrs_tg_graph** graph_out) {
-  if (!graph_out) return MRS_TG_ERR_INVALID_ARG;
-  *graph_out = nullptr;
-  if (!bound || n_bound < 1 || n_launches < 1) return fail(nullptr, MRS_TG_ERR_INVALID_ARG, "bound solves are required");
-  for (int32_t i = 0; i < n_bound; ++i)
-    if (!bound[i]) return fail(nullptr, MRS_TG_ERR_INVALID_ARG, "bound solve %d is NULL", i);
-  mrs_tg_ctx* ctx = bound[0]->plan->ctx;
-  for (int32_t i = 0; i < n_bound; ++i) {
-    mrs_tg_ctx* c = bound[i]->plan->ctx;
-    if (c->device != ctx->device) return fail(ctx, MRS_TG_ERR_INVALID_ARG, "the bound solves of a graph share one device");
-    if (c->profiling) return fail(ctx, MRS_TG_ERR_INVALID_ARG, "per-dispatch timing cannot be captured: switch profiling off");
-    if (c->stream == nullptr) return fail(ctx, MRS_TG_ERR_INVALID_ARG, "the default stream cannot be captured: give every context a stream");
-  }
-  HIP_TRY(ctx, use_device(ctx->device));
-  std::vector<hipStream_t> others;  // the distinct streams besides the origin
-  for (int32_t i = 0; i < n_bound; ++i) {
-    hipStream_t st = bound[i]->plan->ctx->stream;
-    if (st != ctx->stream && std::find(others.begin(), others.end(), st) == others.end()) others.push_back(st);
-  }
-  mrs_tg_graph* g = new (std::nothrow) mrs_tg_graph();
-  if (!g) return fail(ctx, MRS_TG_ERR_NOMEM, "out of host memory");
-  g->origin = ctx->stream;
-  g->ctx = ctx;
-  g->n_launches = n_launches;
-  std::vector<hipEvent_t> events(others.size() + 1, nullptr);
-  hipError_t e = hipSuccess;
-  for (hipEvent_t& ev : events)
-    if (e == hipSuccess) e = hipEventCreateWithFlags(&ev, hipEventDisableTiming);
-  bool capturing = false;
-  int rc = MRS_TG_OK;
-  if (e == hipSuccess) e = hipStreamBeginCapture(g->origin, hipStreamCaptureModeRelaxed);
-  if (e == hipSuccess) {
-    capturing = true;
-    e = hipEventRecord(events[0], g->origin);  // fork
-    for (size_t i = 0; i < others.size() && e == hipSuccess; ++i) e = hipStreamWaitEvent(others[i], events[0], 0);
-    for (int32_t k = 0; k < n_launches && e == hipSuccess && rc == MRS_TG_OK; ++k) rc = mrs_tg_bound_solve_launch(bound[k % n_bound]);
-    for (size_t i = 0; i < others.size() && e == hipSuccess; ++i) {  // join
-      e = hipEventRecord(events[i + 1], others[i]);
-      if (e == hipSuccess) e = hipStreamWaitEvent(g->origin, events[i + 1], 0);
-    }
-  }
-  if (capturing) {
-    const hipError_t e2 = hipStreamEndCapture(g->origin, &g->graph);
-    if (e == hipSuccess) e = e2;
-  }
-  if (e == hipSuccess && rc == MRS_TG_OK) e = hipGraphInstantiate(&g->exec, g->graph, nullptr, nullptr, 0);
-  for (hipEvent_t ev : events)
-    if (ev) (void)hipEventDestroy(ev);
-  if (e != hipSuccess || rc != MRS_TG_OK) {
-    if (g->exec) (void)hipGraphExecDestroy(g->exec);
-    if (g->graph) (void)hipGraphDestroy(g->graph);
-    delete g;
-    if (rc != MRS_TG_OK) return rc;
-    (void)hipGetLastError();
-    return fail(ctx, MRS_TG_ERR_HIP, "graph capture: %s", hipGetErrorString(e));
-  }
-  *graph_out = g;
-  return MRS_TG_OK;
-}
-
-int mrs_tg_graph_launch(mrs_tg_graph* g) {
-  if (!g) return fail(nullptr, MRS_TG_ERR_INVALID_ARG, "graph is NULL");
-  HIP_TRY(g->ctx, use_device(g->ctx->device));
-  HIP_TRY(g->ctx, hipGraphLaunch(g->exec, g->origin));
-  return MRS_TG_OK;
-}
-
-void mrs_tg_graph_destroy(mrs_tg_graph* g) {
-  if (!g) return;
-  if (g->exec) (void)hipGraphExecDestroy(g->exec);
-  if (g->graph) (void)hipGraphDestroy(g->graph);
-  delete g;
-}
-
 int mrs_tg_plan_cost_gradient(mrs_tg_plan* plan, int32_t d, const uint8_t* mask, const double* vals,
                               const double* seg_times, double* cost, double* grad) {
   if (!plan || !mask || !vals || !seg_times || !cost || !grad)

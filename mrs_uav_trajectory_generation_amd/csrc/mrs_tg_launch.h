@@ -6,6 +6,8 @@
 #include <cstddef>
 #include <cstdint>
 
+#include "../../include/mrs_tg.h"
+
 struct mrs_tg_ctx;
 
 namespace mrs_tg {
@@ -76,6 +78,7 @@ struct RowsTail {
   const double* maxima = nullptr;        // [n_segments][9]; with limits and opt_status: scale the times first
   const double* limits = nullptr;        // [n_paths][9]
   const int32_t* opt_status = nullptr;   // paths whose search was refused (-2) keep their times
+  const double* sum_t0 = nullptr;        // [n_paths] total time the outer loop started from: the runaway test (mrs_tg.h)
   double* seg_times_out = nullptr;       // the (scaled) times are written here (the caller's seg_times)
   double sampling_dt = 0.0;              // > 0: sample
   int sample_capacity = 0;

@@ -22,6 +22,7 @@ struct NonlinearParams {
   int32_t* careful_count = nullptr;
   int32_t* careful_list = nullptr;
   int careful_cap = 0;
+  double* sum_t0 = nullptr;  // [n_paths] by path: sum of the times the search starts from (the runaway test of the final solve)
 };
 
 // Paths are sorted by segment count (longest first), so every lane-group class is a contiguous range
@@ -52,6 +53,7 @@ struct NonlinearPlan {
   size_t ws_doubles = 0;
   int32_t* d_opt_status = nullptr; // stopping reason of the outer loop per path
   double* d_maxima = nullptr;      // [n_segments][9] per-segment maxima
+  double* d_sum_t0 = nullptr;      // [n_paths] sum of the times the outer loop started from (runaway test)
   int32_t* d_fallback = nullptr;   // [n_paths] by position: 1 = the prefix / suffix kernel left the path to the sweeping kernel
   int32_t* d_careful = nullptr;    // [0] count, [2] count of the last completed call, [4..] list of guarded paths
   double* d_careful_ws = nullptr;  // factor store of optimize_careful_kernel's lanes

@@ -916,13 +916,15 @@ __device__ __forceinline__ double evaluate_pair(const double* seg, const double*
   __syncthreads();  // the partner's half sweeps are in LDS
   double Jk = 0.0, qfk = 0.0;
   if (work) {
-    const double* ps = pair_state + (size_t)g * kPairState;
+    // element-major (element e of lane g at [e * 64 + g]): lane-major records of 16 doubles put every lane of a
+    // half-wavefront on the same two banks -- a 16-way conflict on each of the 16 stores and 16 loads of a hand-over
+    const double* ps = pair_state + g;
 #pragma unroll
-    for (int e = 0; e < 10; ++e) st.Sm[e] += ps[e];
+    for (int e = 0; e < 10; ++e) st.Sm[e] += ps[e * 64];
 #pragma unroll
-    for (int r = 0; r < kNB; ++r) st.y[r][0] += ps[10 + r];
-    st.qf += ps[14];
-    st.red += ps[15];
+    for (int r = 0; r < kNB; ++r) st.y[r][0] += ps[(10 + r) * 64];
+    st.qf += ps[14 * 64];
+    st.red += ps[15 * 64];
     FastStep<1> fs;
     double L[10], Linv[kNB], z[kNB][1];
     // free mask of the middle vertex = end mask of the segment in front of it
@@ -942,24 +944,11 @@ __device__ __forceinline__ double evaluate_pair(const double* seg, const double*
   return J0;
 }
 
-// ---- prefix / suffix evaluation (large batches) ------------------------------------------------------------------
-// Every perturbed time vector of the forward-difference gradient is the SAME vector B' = max(T - h/(S-1), 0.01) with one
-// component replaced (T_k + h), so J(perturbation k) = join(forward state of B' on vertex k-1, segment k-1 at its perturbed
-// time, backward state of B' on vertex k).  One forward and one backward sweep over B' hand out all those states; a
-// perturbation then costs one segment step and one vertex factorisation instead of a sweep: ~5 S elimination steps per
-// evaluation instead of S (S + 1).  Lane roles of a path's group of 8 (direction = role & 1, fixed for the kernel, so that
-// every lane runs the same forward-form step on its own direction's constant table):
-//   0 prefix sweep of B'        1 suffix sweep of B'          (S - 1 steps each, publishing their state after every step)
-//   2 / 3 the two halves of the sweep at T itself (J(T), joined on the middle vertex as in evaluate_pair)
-//   4 forward joins k = m .. 1  5 backward joins k = m' .. S  (one per time slot, from the middle outwards: join k needs the
-//                                prefix state of vertex k-1 and the suffix state of vertex k, of which the older one was
-//                                parked in LDS and the newer one is this very slot's)
-//   6 the middle join of an odd S (both of its states are parked ones)      7 idle
-// S - 1 time slots per evaluation, each one segment step for every busy lane; 8 paths per wavefront instead of 4 (or 2).
-// Plain paths only (start | interior ... | end segment kinds, S >= 4); anything else goes to the sweeping kernel.
-constexpr int kPsRec = 28;    // Sm[10], y[4][4], qf, red
+// ---- direction tables of the lean sweeps ------------------------------------------------------------------------------
+// (These tables and stage_ps below were built for the prefix / suffix evaluation of the Mellinger gradient -- an experiment
+// that was verified, measured slower than the sweeping kernels and removed from the source in round 3; DESIGN.md section 13
+// keeps its description and numbers.  The lean sweeps use the tables and the staging pass.)
 constexpr int kPsTable = 45;  // near block [10] | coupling [16] | far block [10] | near bracket consts [4] | far [4] | qf const
-constexpr int kPsGroup = 8;
 
 // [0]: the table of a left-to-right lane, [1]: of a right-to-left lane (near / far swapped, coupling transposed), so that
 // FastStep's REV = false forms compute either direction
@@ -989,188 +978,10 @@ __device__ __forceinline__ void stage_ps_tables(int d, double* tab, int tid, int
   }
 }
 
-__device__ __forceinline__ void ps_store(double* rec, const Elim<4>& st) {
-#pragma unroll
-  for (int e = 0; e < 10; ++e) rec[e] = st.Sm[e];
-#pragma unroll
-  for (int r = 0; r < kNB; ++r)
-#pragma unroll
-    for (int q = 0; q < 4; ++q) rec[10 + r * 4 + q] = st.y[r][q];
-  rec[26] = st.qf;
-  rec[27] = st.red;
-}
-
-__device__ __forceinline__ void ps_load(const double* rec, Elim<4>& st) {
-#pragma unroll
-  for (int e = 0; e < 10; ++e) st.Sm[e] = rec[e];
-#pragma unroll
-  for (int r = 0; r < kNB; ++r)
-#pragma unroll
-    for (int q = 0; q < 4; ++q) st.y[r][q] = rec[10 + r * 4 + q];
-  st.qf = rec[26];
-  st.red = rec[27];
-}
-
-__device__ __forceinline__ void ps_add(const double* rec, Elim<4>& st) {
-#pragma unroll
-  for (int e = 0; e < 10; ++e) st.Sm[e] += rec[e];
-#pragma unroll
-  for (int r = 0; r < kNB; ++r)
-#pragma unroll
-    for (int q = 0; q < 4; ++q) st.y[r][q] += rec[10 + r * 4 + q];
-  st.qf += rec[26];
-  st.red += rec[27];
-}
-
 __device__ __forceinline__ void ps_wave_sync() {
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
   __builtin_amdgcn_wave_barrier();
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-}
-
-// per-group LDS of the evaluation: dp [Sb][4], records [(Sb + 2)][kPsRec], J / qf of the S + 1 time vectors [2][Sb + 1]
-__host__ __device__ constexpr int ps_eval_doubles(int Sb) { return 4 * Sb + (Sb + 2) * kPsRec + 2 * (Sb + 1); }
-
-// One objective evaluation of every path of the wavefront (one wavefront, wave-uniform control flow; Smax = the largest
-// segment count among its active groups: the number of time slots).  pt: the group's trial times (LDS), grad: its gradient (LDS).  Returns J(T) to every lane
-// of the group.
-__device__ __forceinline__ double evaluate_ps(const double* tabs, double* ev, int S, int Sb, int Smax, int d, const double* pt,
-                                              double* grad, int g, bool active, int* tripped) {
-  double* dp = ev;  // (Sb: the segment count the group's LDS block is laid out for)
-  double* rec = ev + 4 * (size_t)Sb;
-  double* jout = rec + (size_t)(Sb + 2) * kPsRec;
-  double* qout = jout + (Sb + 1);
-  const int rev = g & 1, role = g;
-  const double* tab = tabs + rev * kPsTable;
-  const int m = S / 2;
-  const bool odd = (S & 1) != 0;
-  // parked prefix states P_1 .. P_m at records 0 .. m-1, suffix states Q_(m+1) .. Q_(S-1) at m .. S-2; then the three hand-overs
-  double* p_fresh = rec + (size_t)(S - 1) * kPsRec;
-  double* q_fresh = p_fresh + kPsRec;
-  double* j_hand = q_fresh + kPsRec;
-  const double corr = kGradStep / ((double)S - 1.0);
-  Elim<4> st;
-  st.init();
-  for (int s = 0; s + 2 <= Smax; ++s) {
-    const bool in_range = active && s + 2 <= S;
-    int seg = -1, k = -1;
-    bool start_kind = false, from_rec = false;
-    const double* src = rec;
-    double T = 1.0;
-    if (in_range) {
-      if (role == 0) {
-        seg = s;
-        start_kind = s == 0;
-      } else if (role == 1) {
-        seg = S - 1 - s;
-        start_kind = s == 0;
-      } else if (role == 2) {
-        if (s < m) seg = s;
-        start_kind = s == 0;
-      } else if (role == 3) {
-        if (s < S - m) seg = S - 1 - s;
-        start_kind = s == 0;
-      } else if (role == 4) {
-        k = S - 1 - s;  // forward join k at slot S - 1 - k: its suffix state is this slot's
-        if (k >= 1 && k <= m) {
-          seg = k - 1;
-          start_kind = k == 1;
-          from_rec = k >= 2;
-          src = rec + (size_t)(k - 2) * kPsRec;  // P_(k-1)
-        } else {
-          k = -1;
-        }
-      } else if (role == 5) {
-        k = s + 2;  // backward join k at slot k - 2: its prefix state is this slot's
-        const int k_first = odd ? m + 2 : m + 1;
-        if (k >= k_first && k <= S) {
-          seg = k - 1;
-          start_kind = k == S;
-          from_rec = k <= S - 1;
-          src = rec + (size_t)(k - 1) * kPsRec;  // Q_k
-        } else {
-          k = -1;
-        }
-      } else if (role == 6) {
-        if (odd && s == m) {  // the middle join of an odd S: P_m and Q_(m+1) are both parked
-          k = m + 1;
-          seg = m;
-          from_rec = true;
-          src = rec + (size_t)(m - 1) * kPsRec;  // P_m
-        }
-      }
-    }
-    if (seg >= 0) {
-      T = pt[seg];
-      if (role <= 1) T = fmax(T - corr, kTimeLowerBound);
-      else if (role >= 4) T = fmax(T + kGradStep, kTimeLowerBound);
-      if (from_rec) ps_load(src, st);
-      double p2[9];
-      segment_powers(T, d, p2);
-      FastStep<4> fast;
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const double dq = dp[seg * 4 + q];
-#pragma unroll
-        for (int j = 0; j < 8; ++j) fast.w[q][j] = tab[36 + j] * dq;
-        fast.w[q][8] = tab[44] * dq * dq;
-      }
-      if (start_kind) {
-        st.qf = 0.0;
-        st.red = 0.0;
-        fast.template start_t<false>(st, tab, p2);
-      } else {
-        fast.template interior_t<false>(st, tab, p2);
-      }
-      // publish: a state that a later join reads goes to its parking place, the others to the hand-over record of the
-      // role; the consumer of this slot's state works out the same address (one block of stores for every publisher)
-      double* dst = nullptr;
-      if (role == 0) dst = (s + 1 <= m) ? rec + (size_t)s * kPsRec : p_fresh;                           // P_(s+1)
-      else if (role == 1) dst = (S - 1 - s >= m + 1) ? rec + (size_t)(S - 2 - s) * kPsRec : q_fresh;    // Q_(S-1-s)
-      else if (role == 3 && s == S - m - 1) dst = j_hand;
-      if (dst) ps_store(dst, st);
-    }
-    ps_wave_sync();
-    // joins that end in this slot
-    const double* other = nullptr;
-    int kk = -1;
-    if (in_range) {
-      if (role == 4 && k >= 1) {  // Q_k, this slot's suffix state (parked iff k >= m + 1: never for a forward join)
-        other = q_fresh;
-        kk = k;
-      } else if (role == 5 && k >= 1) {  // P_(k-1), this slot's prefix state (parked iff k - 1 <= m)
-        other = (k - 1 <= m) ? rec + (size_t)(k - 2) * kPsRec : p_fresh;
-        kk = k;
-      } else if (role == 6 && k >= 1) {
-        other = rec + (size_t)m * kPsRec;  // Q_(m+1)
-        kk = k;
-      } else if (role == 2 && s == S - m - 1) {
-        other = j_hand;
-        kk = 0;
-      }
-    }
-    if (kk >= 0) {
-      if (other) ps_add(other, st);
-      FastStep<4> fs;
-      double L[10], Linv[kNB], z[kNB][4];
-      fs.factor(st, L, Linv, z);
-      jout[kk] = 0.5 * (st.qf - st.red);
-      qout[kk] = st.qf;
-    }
-    ps_wave_sync();
-  }
-  // gradient
-  double J0 = 0.0;
-  if (active) {
-    J0 = guarded_cost(jout[0], qout[0], true);
-    if (tripped && J0 == kUnreliableCost) *tripped = 1;
-    for (int kq = 1 + g; kq <= S; kq += kPsGroup) {
-      const double Jk = guarded_cost(jout[kq], qout[kq], false);
-      if (tripped && Jk == kUnreliableCost) *tripped = 1;
-      grad[kq - 1] = (S > 1) ? (Jk - J0) / kGradStep : 0.0;
-    }
-  }
-  return J0;
 }
 
 // ---- careful evaluation: the cost as the reference computes it -----------------------------------------------------
@@ -1329,9 +1140,6 @@ __device__ __forceinline__ double evaluate_lean(const double* tabs, const double
 }
 
 // per-group LDS of the plain-path kernels and their staging
-__host__ __device__ constexpr int ps_group_doubles(int Sb) {
-  return (5 + 2 * kLbfgsM) * Sb + (kLbfgsM + 1) + kTickState + ps_eval_doubles(Sb);
-}
 __host__ __device__ constexpr int lean_group_doubles(int Sb) {
   return (5 + 2 * kLbfgsM) * Sb + (kLbfgsM + 1) + kTickState + lean_eval_doubles(Sb);
 }
@@ -1468,13 +1276,19 @@ __device__ __forceinline__ void optimize_body(const BatchView& b, const Nonlinea
 
   // ---- start point; NLopt rejects a start below the lower bound (-> INVALID_ARGS)
   int ok = 1;
-  if (active && wave == 0)
+  if (active && wave == 0) {
+    double t_sum = 0.0;
     for (int i = g; i < S; i += G) {
       const double t = seg_times[pr.s0 + i];
       x[i] = t;
       xn[i] = t;
+      t_sum += t;
       if (t < kTimeLowerBound) ok = 0;
     }
+    // the total time the search starts from: what the final solve measures a runaway of the feasibility scaling against
+    t_sum = group_sum(t_sum, G);
+    if (g == 0 && prm.sum_t0) prm.sum_t0[pr.p] = t_sum;
+  }
   const bool bad = active && wave == 0 && !group_and(ok, G);
   __syncthreads();
   MRS_TG_PHASE_MARK(1);
@@ -1521,13 +1335,13 @@ __device__ __forceinline__ void optimize_body(const BatchView& b, const Nonlinea
           Elim<1> st;
           if (pair_special & 0x7FFFFFFFu) half_sweep<true, 2>(seg, hc, S, S / 2, d, xn, k, dim0, pair_special, st);
           else half_sweep<true, 0>(seg, hc, S, S / 2, d, xn, k, dim0, 0u, st);  // a moving start is the forward half's business
-          double* ps = pair_state + (size_t)lane * kPairState;
+          double* ps = pair_state + lane;  // element-major, see evaluate_pair
 #pragma unroll
-          for (int e = 0; e < 10; ++e) ps[e] = st.Sm[e];
+          for (int e = 0; e < 10; ++e) ps[e * 64] = st.Sm[e];
 #pragma unroll
-          for (int r = 0; r < kNB; ++r) ps[10 + r] = st.y[r][0];
-          ps[14] = st.qf;
-          ps[15] = st.red;
+          for (int r = 0; r < kNB; ++r) ps[(10 + r) * 64] = st.y[r][0];
+          ps[14 * 64] = st.qf;
+          ps[15 * 64] = st.red;
         }
         __syncthreads();  // hand-over
         __syncthreads();  // after the evaluation
@@ -1952,245 +1766,6 @@ __global__ void careful_close_kernel(int32_t* __restrict__ careful) {
   careful[0] = 0;
 }
 
-// ---- the outer loop on the prefix / suffix evaluation -----------------------------------------------------------
-// (the experiment of DESIGN.md section 13; not the default.)  Groups of 8 lanes, 8 paths per wavefront.  The optimiser's
-// vectors live in LDS and a lane owns the elements g, g + 8, ... (the general bookkeeping of optimize_body, same arithmetic).  A path the evaluation does not take (not plain, S < 4) is
-// flagged in `fallback` and left to the sweeping kernel, which is launched behind this one for the flagged paths only.
-// per-group LDS: x, g, xn, gn, dir [5 Sb], s / y pairs [2 M Sb], rho [M + 1], tick state, evaluation area
-__device__ __forceinline__ void plain_body(const BatchView& b, const NonlinearParams& prm, int G, int q_begin, int q_count, int Sb,
-                                           int block_in_bin, const uint8_t* __restrict__ mask, const double* __restrict__ vals,
-                                           double* __restrict__ seg_times, int32_t* __restrict__ opt_status,
-                                           int32_t* __restrict__ fallback) {
-  extern __shared__ double lds[];
-  const int lane = threadIdx.x;
-  const int g_shift = __builtin_ctz((unsigned)G);  // G is a power of two
-  const int g = lane & (G - 1), grp = lane >> g_shift;
-  const int qi = block_in_bin * (64 >> g_shift) + grp;
-  bool active = qi < q_count;
-  const int q = q_begin + (active ? qi : 0);
-  const PathRef pr = path_at(b, q);
-  const int S = pr.S;
-  const int d = prm.derivative;
-  double* tabs = lds;
-  stage_ps_tables(d, tabs, lane, 64);
-  double* base = lds + 2 * kPsTable + (size_t)grp * ps_group_doubles(Sb);
-  double* x = base;
-  double* gr = x + Sb;
-  double* xn = gr + Sb;
-  double* gn = xn + Sb;
-  double* dir = gn + Sb;
-  double* sm = dir + Sb;
-  double* ym = sm + kLbfgsM * Sb;
-  double* rho = ym + kLbfgsM * Sb;
-  double* tick_f = rho + kLbfgsM + 1;
-  int* tick_i = reinterpret_cast<int*>(tick_f + 2);
-  double* ev = tick_f + kTickState;
-  // the largest segment count among the groups of this wavefront bounds the evaluation's slot loop
-  int Smax = active ? S : 0;
-#pragma unroll
-  for (int off = 32; off >= 1; off >>= 1) Smax = max(Smax, __shfl_xor(Smax, off, 64));
-  Smax = __builtin_amdgcn_readfirstlane(Smax);
-  const bool takes = stage_ps(mask, vals, pr.v0, S, Sb, ev, g, G, active, 4);
-  if (active && g == 0) fallback[q] = takes ? 0 : 1;
-  active = active && takes;
-
-  int ok = 1;
-  if (active)
-    for (int i = g; i < S; i += G) {
-      const double t = seg_times[pr.s0 + i];
-      x[i] = t;
-      xn[i] = t;
-      if (t < kTimeLowerBound) ok = 0;
-    }
-  const bool bad = active && !group_and(ok, G);
-  if (g == 0) tick_i[4] = 0;
-  ps_wave_sync();
-
-  const int maxeval = prm.max_iterations;
-  const long long t_deadline = prm.time_budget_ticks > 0 ? (long long)wall_clock64() + prm.time_budget_ticks : 0ll;
-  bool timed_out = false;
-  auto budget_spent = [&](int n) { return (maxeval > 0 && n >= maxeval) || timed_out; };
-  auto budget_code = [&](int n) { return (maxeval > 0 && n >= maxeval) ? 5 : 6; };
-  int ret = -1;
-  bool done = !active || bad;
-  int neval = 0, npairs = 0, head = 0;
-  double f = 0.0, alpha = 1.0;
-  bool first = true;
-
-  while (true) {
-    if (__ballot(!done) == 0ull) break;
-    const double fn = evaluate_ps(tabs, ev, S, Sb, Smax, d, xn, gn, g, !done, tick_i + 4);
-    ps_wave_sync();
-    timed_out = t_deadline != 0ll && (long long)wall_clock64() > t_deadline;
-    bool new_dir = false;
-    if (!done) {
-      ++neval;
-      if (first) {
-        f = fn;
-        for (int i = g; i < S; i += G) {
-          x[i] = xn[i];
-          gr[i] = gn[i];
-        }
-        if (budget_spent(neval)) {
-          ret = budget_code(neval);
-          done = true;
-        } else {
-          new_dir = true;
-        }
-      } else {
-        double slope = 0.0;
-        for (int i = g; i < S; i += G) slope += gr[i] * (xn[i] - x[i]);
-        slope = group_sum(slope, G);
-        if (fn <= f + 1e-4 * slope) {
-          int stop = 0;
-          if (relstop(f, fn, prm.f_rel, prm.f_abs)) {
-            stop = 3;
-          } else {
-            int allx = 1;
-            for (int i = g; i < S; i += G)
-              if (!relstop(x[i], xn[i], prm.x_rel, prm.x_abs)) allx = 0;
-            if (group_and(allx, G)) stop = 4;
-          }
-          double sums[3] = {0.0, 0.0, 0.0};
-          for (int i = g; i < S; i += G) {
-            const double si = xn[i] - x[i], yi = gn[i] - gr[i];
-            sums[0] += si * yi;
-            sums[1] += si * si;
-            sums[2] += yi * yi;
-          }
-          group_sum_n<3>(sums, G);
-          const double sy = sums[0], ss = sums[1], yy = sums[2];
-          const bool budget_out = budget_spent(neval);
-          int slot = -1;
-          if (!stop && !budget_out && sy > 1e-10 * sqrt(ss) * sqrt(yy)) {
-            if (npairs == kLbfgsM) {
-              slot = head;
-              head = (head + 1) % kLbfgsM;
-            } else {
-              slot = (head + npairs) % kLbfgsM;
-              ++npairs;
-            }
-          }
-          for (int i = g; i < S; i += G) {
-            if (slot >= 0) {
-              sm[slot * Sb + i] = xn[i] - x[i];
-              ym[slot * Sb + i] = gn[i] - gr[i];
-            }
-            x[i] = xn[i];
-            gr[i] = gn[i];
-          }
-          if (slot >= 0 && g == 0) rho[slot] = 1.0 / sy;
-          f = fn;
-          if (stop) {
-            ret = stop;
-            done = true;
-          } else if (budget_out) {
-            ret = budget_code(neval);
-            done = true;
-          } else {
-            new_dir = true;
-          }
-        } else if (budget_spent(neval)) {
-          for (int i = g; i < S; i += G) x[i] = xn[i];
-          ret = budget_code(neval);
-          done = true;
-        } else {
-          alpha *= 0.5;
-          if (alpha < 1e-12) {
-            for (int i = g; i < S; i += G) x[i] = xn[i];
-            ret = 4;
-            done = true;
-          }
-        }
-      }
-    }
-    first = false;
-    ps_wave_sync();
-    if (new_dir) {
-      double al[kLbfgsM];
-      for (int i = g; i < S; i += G) dir[i] = -gr[i];
-      if (npairs > 0) {
-        for (int k = npairs - 1; k >= 0; --k) {
-          const int id = (head + k) % kLbfgsM;
-          const double sd = group_dot(sm + id * Sb, dir, S, g, G);
-          al[k] = rho[id] * sd;
-          for (int i = g; i < S; i += G) dir[i] -= al[k] * ym[id * Sb + i];
-        }
-        const int nw = (head + npairs - 1) % kLbfgsM;
-        const double sy = group_dot(sm + nw * Sb, ym + nw * Sb, S, g, G);
-        const double yy = group_dot(ym + nw * Sb, ym + nw * Sb, S, g, G);
-        const double gamma = sy / yy;
-        for (int i = g; i < S; i += G) dir[i] *= gamma;
-        for (int k = 0; k < npairs; ++k) {
-          const int id = (head + k) % kLbfgsM;
-          const double yd = group_dot(ym + id * Sb, dir, S, g, G);
-          const double beta = rho[id] * yd;
-          for (int i = g; i < S; i += G) dir[i] += (al[k] - beta) * sm[id * Sb + i];
-        }
-      }
-      double gd = 0.0;
-      for (int i = g; i < S; i += G) {
-        if (x[i] <= kTimeLowerBound && dir[i] < 0.0) dir[i] = 0.0;
-        gd += gr[i] * dir[i];
-      }
-      gd = group_sum(gd, G);
-      if (!(gd < 0.0)) {
-        gd = 0.0;
-        for (int i = g; i < S; i += G) {
-          double v = -gr[i];
-          if (x[i] <= kTimeLowerBound && v < 0.0) v = 0.0;
-          dir[i] = v;
-          gd += gr[i] * v;
-        }
-        gd = group_sum(gd, G);
-        npairs = 0;
-        head = 0;
-        if (!(gd < 0.0)) {
-          ret = 1;
-          done = true;
-        }
-      }
-      alpha = 1.0;
-      if (!done && npairs == 0) {
-        double nn[2] = {0.0, 0.0};
-        for (int i = g; i < S; i += G) {
-          nn[0] += x[i] * x[i];
-          nn[1] += dir[i] * dir[i];
-        }
-        group_sum_n<2>(nn, G);
-        const double cap = 0.1 * sqrt(nn[0]) / sqrt(nn[1]);
-        if (cap < alpha) alpha = cap;
-      }
-    }
-    if (!done)
-      for (int i = g; i < S; i += G) xn[i] = fmax(x[i] + alpha * dir[i], kTimeLowerBound);
-    ps_wave_sync();
-  }
-
-  if (active) {
-    bool listed = false;
-    if (prm.careful_count && !bad && tick_i[4] != 0) {
-      int okl = 0;
-      if (g == 0) {
-        const int idx = atomicAdd(prm.careful_count, 1);
-        okl = idx < prm.careful_cap;
-        if (okl) prm.careful_list[idx] = q;
-      }
-      listed = __shfl(okl, (int)(threadIdx.x & ~(unsigned)(G - 1)), 64) != 0;
-    }
-    if (!listed)
-      for (int i = g; i < S; i += G) seg_times[pr.s0 + i] = x[i];
-    if (g == 0) opt_status[pr.p] = bad ? -2 : ret;
-  }
-}
-
-__global__ __launch_bounds__(64, 2) void optimize_ps_kernel(BatchView b, NonlinearParams prm, int q_begin, int q_count, int Sb,
-                                                            const uint8_t* __restrict__ mask, const double* __restrict__ vals,
-                                                            double* __restrict__ seg_times, int32_t* __restrict__ opt_status,
-                                                            int32_t* __restrict__ fallback) {
-  plain_body(b, prm, kPsGroup, q_begin, q_count, Sb, (int)blockIdx.x, mask, vals, seg_times, opt_status, fallback);
-}
-
 // every bin in one launch, as the sweeping kernels; optimize_body's own bookkeeping (one vector element per lane in
 // registers where the group is as wide as the path is long)
 __global__ __launch_bounds__(64, 2) void optimize_lean_kernel(BatchView b, NonlinearParams prm, BinTable bins,
@@ -2257,6 +1832,20 @@ __global__ __launch_bounds__(256) void apply_scaling_kernel(BatchView b, const d
 }
 
 // J_d and the forward-difference gradient at the given times (parity-test building block)
+// The runaway test of the final solve for the pipelines whose scaling is its own launch (the rows kernel does it in its
+// tail): a path whose scaled total time exceeds MRS_TG_RUNAWAY_TIME_FACTOR times the total it started from leaves the
+// pipeline with ROUNDOFF_LIMITED (-4) instead of the outer loop's stopping reason (include/mrs_tg.h).
+__global__ __launch_bounds__(256) void runaway_kernel(BatchView b, const double* __restrict__ seg_times,
+                                                      const double* __restrict__ sum_t0, int32_t* __restrict__ opt_status) {
+  const int q = blockIdx.x * blockDim.x + threadIdx.x;
+  if (q >= b.n_paths) return;
+  const PathRef pr = path_at(b, q);
+  if (opt_status[pr.p] <= 0) return;
+  double t = 0.0;
+  for (int i = 0; i < pr.S; ++i) t += seg_times[pr.s0 + i];
+  if (t > MRS_TG_RUNAWAY_TIME_FACTOR * sum_t0[pr.p]) opt_status[pr.p] = MRS_TG_STATUS_ROUNDOFF_LIMITED;
+}
+
 template <int DS>
 __global__ __launch_bounds__(64) void cost_gradient_kernel(BatchView b, int d, int G, int q_begin, int q_count, int Sb,
                                                            const uint8_t* __restrict__ mask,
@@ -2289,44 +1878,6 @@ __global__ __launch_bounds__(64) void cost_gradient_kernel(BatchView b, int d, i
   __syncthreads();
   const double J = evaluate_objective<DS>(vtx, seg, hc, pr.S, d, x, gr, g, G, active);
   __syncthreads();
-  if (active) {
-    for (int i = g; i < pr.S; i += G) grad[pr.s0 + i] = gr[i];
-    if (g == 0) cost[pr.p] = J;
-  }
-}
-
-// the same through the prefix / suffix evaluation (paths it does not take are flagged for cost_gradient_kernel)
-__global__ __launch_bounds__(64) void cost_gradient_ps_kernel(BatchView b, int d, int q_begin, int q_count, int Sb,
-                                                              const uint8_t* __restrict__ mask,
-                                                              const double* __restrict__ vals,
-                                                              const double* __restrict__ seg_times,
-                                                              double* __restrict__ cost, double* __restrict__ grad,
-                                                              int32_t* __restrict__ fallback) {
-  extern __shared__ double lds[];
-  constexpr int G = kPsGroup;
-  const int lane = threadIdx.x;
-  const int g = lane & (G - 1), grp = lane >> 3;
-  const int qi = (int)blockIdx.x * (64 / G) + grp;
-  bool active = qi < q_count;
-  const int q = q_begin + (active ? qi : 0);
-  const PathRef pr = path_at(b, q);
-  double* tabs = lds;
-  stage_ps_tables(d, tabs, lane, 64);
-  double* x = lds + 2 * kPsTable + (size_t)grp * (2 * Sb + ps_eval_doubles(Sb));
-  double* gr = x + Sb;
-  double* ev = gr + Sb;
-  int Smax = active ? pr.S : 0;
-#pragma unroll
-  for (int off = 32; off >= 1; off >>= 1) Smax = max(Smax, __shfl_xor(Smax, off, 64));
-  Smax = __builtin_amdgcn_readfirstlane(Smax);
-  const bool takes = stage_ps(mask, vals, pr.v0, pr.S, Sb, ev, g, kPsGroup, active, 4);
-  if (active && g == 0) fallback[q] = takes ? 0 : 1;
-  active = active && takes;
-  if (active)
-    for (int i = g; i < pr.S; i += G) x[i] = seg_times[pr.s0 + i];
-  ps_wave_sync();
-  const double J = evaluate_ps(tabs, ev, pr.S, Sb, Smax, d, x, gr, g, active, nullptr);
-  ps_wave_sync();
   if (active) {
     for (int i = g; i < pr.S; i += G) grad[pr.s0 + i] = gr[i];
     if (g == 0) cost[pr.p] = J;
@@ -2765,6 +2316,8 @@ void nonlinear_plan_free(NonlinearPlan& nl) {
   if (nl.d_ws) (void)mrs_tg::pool_free(nl.d_ws);
   if (nl.d_opt_status) (void)mrs_tg::pool_free(nl.d_opt_status);
   if (nl.d_maxima) (void)mrs_tg::pool_free(nl.d_maxima);
+  if (nl.d_sum_t0) (void)mrs_tg::pool_free(nl.d_sum_t0);
+  nl.d_sum_t0 = nullptr;
   if (nl.d_careful) (void)mrs_tg::pool_free(nl.d_careful);
   nl.d_careful = nullptr;
   if (nl.d_fallback) (void)mrs_tg::pool_free(nl.d_fallback);
@@ -2810,19 +2363,13 @@ static hipError_t ensure_buffers(NonlinearPlan& nl, const BatchView& b) {
     return e;
   if (!nl.d_maxima && (e = mrs_tg::pool_alloc(&nl.d_maxima, sizeof(double) * 9 * (size_t)(b.n_segments > 0 ? b.n_segments : 1))) != hipSuccess)
     return e;
+  if (!nl.d_sum_t0 && (e = mrs_tg::pool_alloc(&nl.d_sum_t0, sizeof(double) * (size_t)(b.n_paths > 0 ? b.n_paths : 1))) != hipSuccess)
+    return e;
   if (!nl.d_careful) {
     if ((e = mrs_tg::pool_alloc(&nl.d_careful, sizeof(int32_t) * (4 + kCarefulCap))) != hipSuccess) return e;
     if ((e = hipMemset(nl.d_careful, 0, sizeof(int32_t) * 4)) != hipSuccess) return e;  // once per plan: every call leaves the counter at zero
   }
   return hipSuccess;
-}
-
-// The prefix / suffix kernels are built, verified (tests/test_gpu_prefix_suffix.py) and NOT the default: measured on
-// 8192 x 10 they tie the sweeping kernel (311 vs 317 us), on 4096 x 10 and on ragged batches they lose (269 vs 201 us,
-// 1.3 vs 0.6 ms) -- DESIGN.md section 13.  MRS_TG_PS=1 switches them on.
-static bool ps_applies(const NonlinearPlan&) {
-  if (const char* e = std::getenv("MRS_TG_PS")) return std::atoi(e) != 0;
-  return false;
 }
 
 // Lean sweeps for plain paths (optimize_lean_kernel): two wavefronts per SIMD where the general sweeping kernel has one.
@@ -2849,6 +2396,7 @@ hipError_t launch_nonlinear(NonlinearPlan& nl, const BatchView& b, const Nonline
   if (e != hipSuccess) return e;
   // 1. outer loop: every bin in one launch
   NonlinearParams prm = prm_in;
+  prm.sum_t0 = nl.d_sum_t0;
   const bool careful = prm_in.careful_cap != 0;  // the caller asked for the careful re-run (MRS_TG_FLAG_CAREFUL_COST)
   int careful_cap = 0;
   if (careful) {
@@ -2872,30 +2420,15 @@ hipError_t launch_nonlinear(NonlinearPlan& nl, const BatchView& b, const Nonline
     prm.careful_list = nullptr;
     prm.careful_cap = 0;
   }
-  // 1a. a plain-path kernel (lean sweeps, or the prefix / suffix evaluation) takes every path it can and flags the others
-  // for the sweeping kernel below
-  int plain_mode = ps_applies(nl) ? 1 : (lean_applies(nl) ? 2 : 0);
-  if ((int)nl.bins.size() > 5) plain_mode = 0;
+  // 1a. the lean kernel takes every plain path and flags the others for the sweeping kernel below
+  bool lean = lean_applies(nl) && (int)nl.bins.size() <= 5;
   auto plain_lds = [&](const NonlinearBin& bin) {
-    return plain_mode == 1 ? ((size_t)(64 / kPsGroup) * ps_group_doubles(bin.max_S) + 2 * kPsTable) * sizeof(double)
-                           : ((size_t)(64 / bin.group) * lean_group_doubles(bin.max_S) + 2 * kPsTable) * sizeof(double);
+    return ((size_t)(64 / bin.group) * lean_group_doubles(bin.max_S) + 2 * kPsTable) * sizeof(double);
   };
-  if (plain_mode)
+  if (lean)
     for (const NonlinearBin& bin : nl.bins)
-      if (plain_lds(bin) > 160 * 1024) plain_mode = 0;
-  if (plain_mode == 1) {
-    if ((e = ensure_fallback(nl, b)) != hipSuccess) return e;
-    for (const NonlinearBin& bin : nl.bins) {
-      const size_t plds = plain_lds(bin);
-      if (plds > 64 * 1024 &&
-          (e = hipFuncSetAttribute((const void*)optimize_ps_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)plds)) != hipSuccess)
-        return e;
-      MRS_TG_LAUNCH_TIMED(optimize_ps_kernel, dim3(cdiv_u(bin.q_count, 64 / kPsGroup)), dim3(64), plds, stream, b, prm,
-                          bin.q_begin, bin.q_count, bin.max_S, mask, vals, seg_times, nl.d_opt_status, nl.d_fallback);
-      if ((e = hipGetLastError()) != hipSuccess) return e;
-    }
-    prm.only_flagged = nl.d_fallback;
-  } else if (plain_mode == 2) {
+      if (plain_lds(bin) > 160 * 1024) lean = false;
+  if (lean) {
     if ((e = ensure_fallback(nl, b)) != hipSuccess) return e;
     BinTable bt{};
     bt.n = (int)nl.bins.size();
@@ -2997,6 +2530,7 @@ hipError_t launch_nonlinear(NonlinearPlan& nl, const BatchView& b, const Nonline
     tail.maxima = nl.d_maxima;
     tail.limits = limits;
     tail.opt_status = nl.d_opt_status;
+    tail.sum_t0 = nl.d_sum_t0;
     tail.seg_times_out = seg_times;
     if (want_samples) {
       tail.sampling_dt = sampling_dt;
@@ -3009,6 +2543,8 @@ hipError_t launch_nonlinear(NonlinearPlan& nl, const BatchView& b, const Nonline
   }
   hipLaunchKernelGGL(apply_scaling_kernel, dim3(cdiv_u(b.n_segments, 256)), dim3(256), 0, stream, b, nl.d_maxima, limits,
                      nl.d_opt_status, seg_times);
+  if ((e = hipGetLastError()) != hipSuccess) return e;
+  hipLaunchKernelGGL(runaway_kernel, dim3(cdiv_u(b.n_paths, 256)), dim3(256), 0, stream, b, seg_times, nl.d_sum_t0, nl.d_opt_status);
   if ((e = hipGetLastError()) != hipSuccess) return e;
   // 4. updateSegmentTimes + solveLinear with the scaled times (nonlinear_impl.h:405-408), final status
   return launch_solve_linear(b, prm.derivative, true, mask, vals, seg_times, nullptr, nullptr, nl.d_ws, coeffs, status,
@@ -3079,22 +2615,8 @@ hipError_t launch_dfo(NonlinearPlan& nl, const BatchView& b, const DfoParams& pr
 
 hipError_t launch_cost_gradient(NonlinearPlan& nl, const BatchView& b, int d, const uint8_t* mask, const double* vals,
                                 const double* seg_times, double* cost, double* grad, hipStream_t stream) {
-  const bool ps = ps_applies(nl);
   hipError_t e;
-  if (ps) {
-    if ((e = ensure_fallback(nl, b)) != hipSuccess) return e;
-    for (const NonlinearBin& bin : nl.bins) {
-      const size_t lds_bytes = ((size_t)(64 / kPsGroup) * (2 * bin.max_S + ps_eval_doubles(bin.max_S)) + 2 * kPsTable) * sizeof(double);
-      if (lds_bytes > 160 * 1024) return hipErrorInvalidValue;
-      if (lds_bytes > 64 * 1024 &&
-          (e = hipFuncSetAttribute((const void*)cost_gradient_ps_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes)) != hipSuccess)
-        return e;
-      hipLaunchKernelGGL(cost_gradient_ps_kernel, dim3(cdiv_u(bin.q_count, 64 / kPsGroup)), dim3(64), lds_bytes, stream, b, d,
-                         bin.q_begin, bin.q_count, bin.max_S, mask, vals, seg_times, cost, grad, nl.d_fallback);
-      if ((e = hipGetLastError()) != hipSuccess) return e;
-    }
-  }
-  const int32_t* only = ps ? nl.d_fallback : nullptr;
+  const int32_t* only = nullptr;
   for (const NonlinearBin& bin : nl.bins) {
     const int per_block = 64 / bin.group;
     const size_t lds_bytes = ((size_t)per_block * gradient_lds_doubles(bin.max_S, nl.dim_split == 4) + kBlockConsts) * sizeof(double);

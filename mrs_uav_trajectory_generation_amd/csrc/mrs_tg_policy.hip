@@ -338,9 +338,23 @@ int mrs_tg_optimize_paths(mrs_tg_ctx* ctx, int32_t n_paths, const int32_t* wp_of
     for (int p = 0; p < n_paths; ++p)
       if (!st[p].done) active.push_back(p);
     if (active.empty()) break;
+    // optimize() picks the solver of a round in this order (:702-716, :754-768): fallback sampling when it was asked for,
+    // fallback sampling when overtime() says the request is running late ("executing fallback sampling, we are running
+    // over time" -- the request still succeeds), else findTrajectory.  Only the checks BEHIND the solve (:1085, :1156,
+    // :1171, :1516-1522) give a request up.
+    double budget_left = 0.0;  // timeLeft() :1749-1761
+    auto overtime = [&]() {    // overtime() :1730-1743 (OVERTIME_SAFETY_FACTOR 0.95, OVERTIME_SAFETY_OFFSET 0.01 s)
+      return o.max_execution_time_s > 0 && elapsed() > 0.95 * o.max_execution_time_s - 0.01;
+    };
+    bool use_fallback = o.fallback_sampling != 0;
+    if (!use_fallback && o.max_execution_time_s > 0) {
+      const double spent = elapsed();
+      budget_left = spent >= o.max_execution_time_s ? 0.0 : o.max_execution_time_s - spent;
+      use_fallback = overtime();
+    }
     // the requests are independent: one that cannot be solved (its deviation loop has subdivided it beyond the longest
     // path a plan takes; the reference has no such limit) fails on its own and leaves the others alone
-    if (!o.fallback_sampling) {
+    if (!use_fallback) {
       size_t kept = 0;
       for (int p : active) {
         if (st[p].n_wp - 1 > MRS_TG_MAX_SEGMENTS) {
@@ -354,22 +368,8 @@ int mrs_tg_optimize_paths(mrs_tg_ctx* ctx, int32_t n_paths, const int32_t* wp_of
       active.resize(kept);
       if (active.empty()) break;
     }
-    // overtime() (:1085, 1156, 1171, 1516-1522): out of time, every request that is still being worked on is given up
-    double budget_left = 0.0;  // timeLeft() :1749-1761
-    if (o.max_execution_time_s > 0) {
-      const double spent = elapsed();
-      budget_left = spent >= o.max_execution_time_s ? 0.0 : o.max_execution_time_s - spent;
-      if (spent > 0.95 * o.max_execution_time_s - 0.01) {  // overtime() :1730-1743 (OVERTIME_SAFETY_FACTOR, _OFFSET)
-        for (int p : active) {
-          st[p].done = true;
-          st[p].ok = false;
-          st[p].n_samples = 0;
-        }
-        break;
-      }
-    }
     // ---- solve every active path (one batched GPU call, or the fallback sampler on the host)
-    if (o.fallback_sampling) {
+    if (use_fallback) {
       for (int p : active) {
         double* out = samples_out + (size_t)p * sample_capacity * 4;
         const int ns = fallback_sampling(st[p], limits + (size_t)p * 9, relax_heading && relax_heading[p], o, dt, out, sample_capacity);
@@ -430,9 +430,10 @@ int mrs_tg_optimize_paths(mrs_tg_ctx* ctx, int32_t n_paths, const int32_t* wp_of
       const int rc = mrs_tg_solve_batch(ctx, (int32_t)active.size(), so.data(), wp.data(), mask.data(), vals.data(), lim.data(),
                                         &so_opt, times.data(), coeffs.data(), status.data(), cost.data(), ns.data(), smp.data());
       if (rc != MRS_TG_OK) return rc;
+      const bool late = overtime();  // findTrajectory's own checks behind optimize() and the sampler: "return {}" (:1085, :1156, :1171)
       for (size_t a = 0; a < active.size(); ++a) {
         const int p = active[a];
-        bool ok = (status[a] >= 1 && status[a] != 6) || status[a] == -1;  // :1138-1149
+        bool ok = !late && ((status[a] >= 1 && status[a] != 6) || status[a] == -1);  // :1138-1149
         const double len = (double)ns[a] * dt;                            // :1178-1199
         if (ok && len > 1.0 && (len > o.max_trajectory_len_factor * st[p].baca_total || len < o.min_trajectory_len_factor * st[p].baca_total))
           ok = false;

@@ -504,13 +504,26 @@ __global__ __launch_bounds__(64) void solve_rows_kernel(BatchView b, int d, int 
     const int l16 = lane & 15;
     double s = 0.0;
     for (int e = l16; e < pr.S * kD; e += 16) s += pc0[e];
+    // the path's total (scaled) time, for the runaway test of a pipeline's last solve
+    double ts = 0.0;
+    const bool runaway_test = TAIL && tail.sum_t0 != nullptr;
+    if (runaway_test)
+      for (int i = l16; i < pr.S; i += 16) ts += seg0[(size_t)i * kRSegRec + kRSegT];
     s += __shfl_xor(s, 8, 64);
+    if (runaway_test) ts += __shfl_xor(ts, 8, 64);
     s += __shfl_xor(s, 4, 64);
+    if (runaway_test) ts += __shfl_xor(ts, 4, 64);
     s += __shfl_xor(s, 2, 64);
+    if (runaway_test) ts += __shfl_xor(ts, 2, 64);
     s += __shfl_xor(s, 1, 64);
+    if (runaway_test) ts += __shfl_xor(ts, 1, 64);
     if (l16 == 0) {
       if (cost) cost[pr.p] = s;
-      if (status) status[pr.p] = merge_status((pl ? pos_bad[1] : pos_bad[0]) == 0ull, status_in, pr.p);
+      if (status) {
+        int st = merge_status((pl ? pos_bad[1] : pos_bad[0]) == 0ull, status_in, pr.p);
+        if (runaway_test && st > 0 && ts > MRS_TG_RUNAWAY_TIME_FACTOR * tail.sum_t0[pr.p]) st = MRS_TG_STATUS_ROUNDOFF_LIMITED;
+        status[pr.p] = st;
+      }
     }
   }
   MRS_TG_PHASE_MARK(5);

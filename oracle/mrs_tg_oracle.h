@@ -30,10 +30,11 @@ extern "C" {
 #define MTO_D 4     /* dimensions x,y,z,heading      (src/mrs_trajectory_generation.cpp:902)  */
 #define MTO_HALF 5  /* derivative slots per segment end (N/2) */
 #define MTO_MAX_SEG 128
+#define MTO_RUNAWAY_TIME_FACTOR 25.0 /* see solve_one in mto_nonlinear.c */
 
 /* nlopt-style result codes (nlopt.h; gate at src/mrs_trajectory_generation.cpp:1138-1149) */
 enum {
-  MTO_FAILURE = -1, MTO_INVALID_ARGS = -2,
+  MTO_FAILURE = -1, MTO_INVALID_ARGS = -2, MTO_ROUNDOFF_LIMITED = -4,
   MTO_SUCCESS = 1, MTO_STOPVAL_REACHED = 2, MTO_FTOL_REACHED = 3, MTO_XTOL_REACHED = 4,
   MTO_MAXEVAL_REACHED = 5, MTO_MAXTIME_REACHED = 6
 };

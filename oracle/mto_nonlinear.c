@@ -531,6 +531,8 @@ static int solve_one(int S, const double* wp, const uint8_t* mask, const double*
   int status = MTO_SUCCESS;
   if (opt->estimate_times) mto_estimate_segment_times_euclidean(S, wp, lim, times); /* :1046 */
   if (opt->time_alloc_method == 2) {
+    double sum_t0 = 0.0, sum_t1 = 0.0;
+    for (int i = 0; i < S; ++i) sum_t0 += times[i];
     int rc = mto_optimize_times_mellinger(&path, &opt->nlopt, times, NULL, NULL); /* :1083 -> nonlinear_impl.h:160 */
     status = rc;
     if (rc == MTO_INVALID_ARGS) {
@@ -544,6 +546,12 @@ static int solve_one(int S, const double* wp, const uint8_t* mask, const double*
       mto_solve_linear(&path, times, coeffs);
       mto_scale_segment_times_to_meet_constraints(S, coeffs, times, lim, NULL);
       mto_solve_linear(&path, times, coeffs);
+      /* Not in the reference (it hands such a path back with the outer loop's code and leaves it to the nodelet's length
+       * check, src/mrs_trajectory_generation.cpp:1178-1199): a scaling that multiplied the total time by more than
+       * MTO_RUNAWAY_TIME_FACTOR is reported as nlopt's ROUNDOFF_LIMITED, which the nodelet's gate rejects (:1103, :1146);
+       * the same rule as the product's include/mrs_tg.h states. */
+      for (int i = 0; i < S; ++i) sum_t1 += times[i];
+      if (status > 0 && sum_t1 > MTO_RUNAWAY_TIME_FACTOR * sum_t0) status = MTO_ROUNDOFF_LIMITED;
     }
   } else if (opt->time_alloc_method == 0 || opt->time_alloc_method == 1) {
     /* optimizeTime (nonlinear_impl.h:121-157): no feasibility scaling afterwards; the trajectory is the one

@@ -51,35 +51,3 @@ def timed(n, reps=30):
 for n in (0, 1, 4, 20, 100):
     b, m, issue = timed(n)
     print("%3d launches + synchronize: best %.1f us, mean %.1f us (issue loop of the last repetition %.1f us)" % (n, b, m, issue))
-
-
-sys.exit(0)
-
-
-def timed_graph(n, reps=30):
-    g = rr.graph(n)
-    g()
-    torch.cuda.synchronize()
-    best, tot = 1e9, 0.0
-    for _ in range(reps):
-        rr(300)
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        g()
-        torch.cuda.synchronize()
-        t2 = time.perf_counter()
-        best = min(best, t2 - t0)
-        tot += t2 - t0
-    g.close()
-    return best * 1e6, tot / reps * 1e6
-
-
-for n in (1, 4, 20, 100, 200):
-    b, m = timed_graph(n)
-    print("%3d launches as one graph + synchronize: best %.1f us, mean %.1f us" % (n, b, m))
-for db in dbs:
-    db.coeffs.zero_()
-g = rr.graph(8)
-g()
-torch.cuda.synchronize()
-print("graph results written:", all(bool((db.coeffs != 0).any()) for db in dbs))

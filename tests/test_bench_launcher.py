@@ -80,3 +80,30 @@ def test_two_ranks_started_by_bench_itself_on_one_gpu():
     c3 = line["extras"]["config3"]
     assert c3["n_gpus"] == 2 and c3["paths_per_rank"] == 1024 and c3["scaling"] == "strong" and c3["value"] > 0
     assert line["roofline"]["frac"] > 0 and line["roofline_solve"]["achieved"] > 0 and line["roofline_outer_loop"]["avg_launch_us"] > 0
+    # the closing gather is timed on its own; the per-rank throughput of the two ranks sharing one GPU is reported as is
+    assert line["gather_ms"] is not None and line["value_including_gather"] <= line["value"]
+
+
+@pytest.mark.gpu
+def test_single_rank_rccl_path_runs_and_the_gather_delivers_the_local_results():
+    """The only way to execute RCCL's initialisation and `dist.gather` on a one-GPU lease: `--force-dist --dist-backend nccl`
+    with one rank.  The line must say one rank was seen, carry configs[3]'s object, time the closing gather on its own and
+    confirm that what the gather put into rank 0's receive buffers is bit for bit what rank 0 computed."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--force-dist", "--dist-backend", "nccl",
+                          "--steps", "5", "--warmup", "2", "--config3-paths", "4096", "--no-cpu-baseline"],
+                         capture_output=True, text=True, env=env, timeout=900)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith('{"metric"')]
+    assert len(lines) == 1
+    line = json.loads(lines[0])
+    assert line["ranks_seen"] == 1 and line["n_gpus"] == 1
+    assert line["gather_ms"] is not None and line["gather_ms"] > 0 and line["value_including_gather"] < line["value"]
+    assert line["gather_check"] == dict(root_equals_local=True, peers_finite_with_valid_status=True, ranks=1,
+                                        bytes_per_rank=(1024 * 10 * 41 + 1024) * 8)
+    c3 = line["extras"]["config3"]
+    assert c3 is not None and c3["value"] > 0 and c3["scaling"] == "strong" and c3["paths_per_rank"] == 4096
+    assert c3["gather_root_equals_local"] is True
+    assert line["config3_strong_scaling"]["value"] == c3["value"]
+    assert "gather_every_step" in line["extras"] and line["extras"]["gather_every_step"]["value"] > 0

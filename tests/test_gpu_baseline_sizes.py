@@ -32,10 +32,17 @@ def _per_path(arr, offsets, p):
 def _check_nonlinear(gpu_ctx, batch, n_oracle, min_good=0.95):
     out = gpu_ctx.solve_batch(batch, None, time_alloc_method=api.TIME_ALLOC_MELLINGER, sampling_dt=0.2, sample_capacity=CAP)
     P, so = batch.n_paths, batch.seg_offsets
-    assert np.all(np.isin(out["status"], (1, 3, 4, 5)))
+    assert np.all(np.isin(out["status"], (1, 3, 4, 5, api.STATUS_ROUNDOFF_LIMITED)))
     assert np.all(np.isfinite(out["coeffs"])) and np.all(np.isfinite(out["times"])) and np.all(out["times"] >= 0.01)
-    # sample counts from the times
+    # no runaway leaves the pipeline as a success: a path whose feasibility scaling multiplied its total time by more than
+    # MRS_TG_RUNAWAY_TIME_FACTOR carries ROUNDOFF_LIMITED (which the nodelet's gate rejects), and only such paths do
     total = np.add.reduceat(out["times"], so[:-1])
+    total0 = np.add.reduceat(gpu_ctx.solve_batch(batch, None)["times"], so[:-1])      # the Euclidean start
+    runaway = total > api.RUNAWAY_TIME_FACTOR * total0
+    assert np.array_equal(runaway, out["status"] == api.STATUS_ROUNDOFF_LIMITED), (runaway.sum(), (out["status"] == -4).sum())
+    assert runaway.mean() < 2e-3, runaway.sum()
+    print("runaway paths flagged: %d of %d (largest healthy ratio %.2f)" % (runaway.sum(), P, (total / total0)[~runaway].max()))
+    # sample counts from the times
     expect = np.minimum(np.ceil(total / 0.2 - 1e-9), CAP + 1)
     assert np.all(np.abs(out["n_samples"] - expect) <= 1), np.max(np.abs(out["n_samples"] - expect))
     # first sample = first waypoint (positions exactly; heading wrapped)
@@ -80,7 +87,11 @@ def test_config2_1024_paths_nonlinear(gpu_ctx):
 
 
 def test_config3_whole_65536_paths_nonlinear(gpu_ctx):
-    _check_nonlinear(gpu_ctx, pr.random_batch(65536, 10, seed0=0), 96, min_good=0.98)
+    batch = pr.random_batch(65536, 10, seed0=0)
+    _check_nonlinear(gpu_ctx, batch, 96, min_good=0.98)
+    # path 8615 (a 2.7 s segment next to one scaled to 9e11 s) and its siblings, which round 2 returned as successes
+    out = gpu_ctx.solve_batch(batch.select([8615]), None, time_alloc_method=api.TIME_ALLOC_MELLINGER)
+    assert out["status"][0] == api.STATUS_ROUNDOFF_LIMITED and out["times"].sum() > 1e6
 
 
 def test_config4_8192_ragged_paths_nonlinear(gpu_ctx):

@@ -65,6 +65,23 @@ def test_batch_members_keep_their_own_request_fields(host_output):
     assert 2.2 < v.max() < 4.0 * 1.05
 
 
+def test_a_late_request_gets_the_fallback_trajectory(host_output):
+    """optimize() with overtime() true at its start (src/mrs_trajectory_generation.cpp:711-713) runs the fallback sampler:
+    the request succeeds, and the trajectory is the one `fallback_sampling` alone produces"""
+    r = host_output["late_request"]
+    assert r["success"] and r["message"] == "trajectory generated"
+    assert host_output["late_equals_fallback"] is True
+    assert check_trajectory(np.array(r["points"]), TEST_PATH)
+
+
+def test_many_requests_with_the_default_deadline_are_all_answered(host_output):
+    """ServiceParams' default max_time (0.5 s, config/public/trajectory_generation.yaml:4) on a call of 600 requests in three
+    deviation groups: a request's clock starts with its own group's GPU call, and running late means fallback sampling,
+    not failure -- nobody is dropped"""
+    m = host_output["many"]
+    assert m["requests"] == 600 and m["success"] == 600 and m["own_fields"] == 600
+
+
 def test_plain_c99_host(tmp_path):
     """examples/solve_batch_host.c: the header is C (not C++), the library needs nothing but itself at link time"""
     exe = str(tmp_path / "solve_batch_host")

@@ -157,7 +157,11 @@ def _check_invariants(batch, out, limits_tol=1.05):
     assert np.all(np.isfinite(out["coeffs"])) and np.all(t >= 0.01)
     assert util.continuity_defect(batch, out["coeffs"], t) < 1e-9
     assert util.constraint_defect(batch, out["coeffs"], t) < 1e-9
-    assert np.all(np.isin(out["status"], (1, 3, 4, 5)))
+    assert np.all(np.isin(out["status"], (1, 3, 4, 5, api.STATUS_ROUNDOFF_LIMITED)))
+    # a result counts as a success only while its total time stays within MRS_TG_RUNAWAY_TIME_FACTOR of the Euclidean start
+    so = batch.seg_offsets
+    ratio = np.add.reduceat(t, so[:-1]) / np.add.reduceat(util.oracle_times(batch), so[:-1])
+    assert np.array_equal(ratio > api.RUNAWAY_TIME_FACTOR, out["status"] == api.STATUS_ROUNDOFF_LIMITED)
 
 
 # (20, 24) and (15, 32): one path per wavefront with / without enough lanes for the two-sided evaluation in one round

@@ -1,0 +1,37 @@
+"""The runaway rule shared by the product (include/mrs_tg.h, MRS_TG_RUNAWAY_TIME_FACTOR) and the oracle (solve_one in
+oracle/mto_nonlinear.c): a Mellinger result whose feasibility scaling multiplied the path's total time by more than 25
+is reported with nlopt's ROUNDOFF_LIMITED (-4), a code the nodelet's gate rejects
+(src/mrs_trajectory_generation.cpp:1103-1106, 1146-1149), instead of the outer loop's stopping reason.  The reference has
+no such rule inside findTrajectory's optimiser -- it discards such a trajectory one step later by its length check
+(:1178-1199)."""
+import numpy as np
+
+from mrs_uav_trajectory_generation_amd import api, problem as pr
+from oracle import pyoracle as po
+from tests import util
+
+
+def _solve(batch):
+    return po.solve_batch(batch.seg_offsets, batch.waypoints, batch.fixed_mask, batch.fixed_values, batch.limits,
+                          np.zeros(batch.n_segments), deriv=4, time_alloc_method=2, estimate_times=True, n_threads=8)
+
+
+def test_path_8615_of_the_benchmark_batch_is_flagged():
+    # random_batch seeds path p of a batch with seed0 + p: this is path 8615 of bench.py's configs[3] batch
+    batch = pr.random_batch(1, 10, seed0=8615)
+    out = _solve(batch)
+    assert out["status"][0] == -4 == api.STATUS_ROUNDOFF_LIMITED
+    assert out["times"].sum() > 1e6 * util.oracle_times(batch).sum()
+    assert np.all(np.isfinite(out["coeffs"]))
+
+
+def test_healthy_paths_are_far_from_the_threshold_and_runaways_far_beyond():
+    batch = pr.random_batch(2048, 10, seed0=8000)
+    out = _solve(batch)
+    so = batch.seg_offsets
+    ratio = np.add.reduceat(out["times"], so[:-1]) / np.add.reduceat(util.oracle_times(batch), so[:-1])
+    flagged = out["status"] == -4
+    assert np.array_equal(flagged, ratio > api.RUNAWAY_TIME_FACTOR)
+    assert ratio[~flagged].max() < 6.0 and np.median(ratio) < 2.0
+    assert flagged.sum() >= 1 and ratio[flagged].min() > 100.0      # (path 8615 is one of them)
+    assert np.all(np.isin(out["status"][~flagged], (1, 3, 4, 5)))
