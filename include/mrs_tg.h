@@ -213,6 +213,19 @@ int mrs_tg_solve_batch(mrs_tg_ctx* ctx, int32_t n_paths, const int32_t* seg_offs
                        const mrs_tg_options* opt, double* seg_times_inout, double* coeffs_out, int32_t* status_out,
                        double* cost_out, int32_t* n_samples_out, double* samples_out);
 
+/* Pinned host memory for the arrays of mrs_tg_solve_batch, mrs_tg_multi_solve_batch and mrs_tg_find_trajectory.  The call
+ * keeps one device block and one pinned staging block per context and moves each array the cheapest way its location
+ * allows: an array in pinned memory (from mrs_tg_host_alloc, registered with mrs_tg_host_register, or any block of
+ * hipHostMalloc) is read / written by the DMA engines in place; small pageable arrays are packed into the staging block
+ * and travel as ONE copy per direction; large pageable arrays go through hipMemcpyAsync on the caller's pages.  A host that
+ * calls in a loop (the nodelet's worker: std::vector outputs it re-uses) gets the PCIe rate by allocating its in / out
+ * arrays here once.  mrs_tg_host_register pins an existing allocation until mrs_tg_host_unregister: the caller must
+ * unregister before it frees or reallocates the block. */
+int mrs_tg_host_alloc(size_t bytes, void** ptr_out);
+void mrs_tg_host_free(void* ptr);
+int mrs_tg_host_register(void* ptr, size_t bytes);
+int mrs_tg_host_unregister(void* ptr);
+
 /* ---- plan interface: analysis once, device-resident data, asynchronous ----------------------- */
 
 /* Analyse the batch structure (host seg_offsets): sorts paths by segment count, sizes the
@@ -259,11 +272,12 @@ void mrs_tg_bound_solve_destroy(mrs_tg_bound_solve* bound);
  * (one bound solve per context + stream).  Stops at the first error and returns its code (mrs_tg_last_error of that
  * solve's context has the text). */
 int mrs_tg_bound_solve_launch_many(mrs_tg_bound_solve* const* bound, int32_t n_bound, int32_t n_launches);
-/* The same loop on n_threads host threads (the caller + helper threads of the library, created on first use): thread j issues
- * the launches of bound[j], bound[j + n_threads], ... -- a runtime launch costs the host 3.5-4.5 us, more than four
- * concurrent 10 us kernels take to retire one, so one issuing thread bounds a host with four batches in flight.  n_threads
- * is lowered to a divisor of n_bound (a bound solve stays on one thread); the helpers spin for 2 ms after a run before they
- * go to sleep.  Returns when every launch has been issued (not finished). */
+/* The same loop on n_threads host threads (the caller + helper threads of the library, created on first use) -- a runtime
+ * launch costs the host 3.5-4.5 us, more than four concurrent 10 us kernels take to retire one, so one issuing thread
+ * bounds a host with four batches in flight.  The bound solves are partitioned by CONTEXT: all solves of one context are
+ * issued by the same thread (a context is driven by one thread at a time), in their order within the run; n_threads is
+ * lowered to the number of distinct contexts.  Concurrent callers are served one run after the other.  The helpers spin
+ * for 2 ms after a run before they go to sleep.  Returns when every launch has been issued (not finished). */
 int mrs_tg_bound_solve_launch_many_mt(mrs_tg_bound_solve* const* bound, int32_t n_bound, int32_t n_launches,
                                       int32_t n_threads);
 /* Building blocks of the outer loop, exposed for parity tests (device pointers, asynchronous):

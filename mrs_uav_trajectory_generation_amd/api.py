@@ -17,7 +17,7 @@ import numpy as np
 from .problem import Batch, N_COEFF, N_DIM
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libmrs_tg.so")
+LIB_PATH = os.environ.get("MRS_TG_LIB_PATH") or os.path.join(_HERE, "libmrs_tg.so")   # (the override: experiment builds)
 
 TIME_ALLOC_NONE = -1
 TIME_ALLOC_SQUARED_TIME = 0
@@ -78,7 +78,8 @@ EXPORTED_SYMBOLS = [
     "mrs_tg_plan_n_paths", "mrs_tg_plan_n_segments", "mrs_tg_plan_max_segments", "mrs_tg_plan_get_order",
     "mrs_tg_plan_assemble", "mrs_tg_plan_block_bytes", "mrs_tg_plan_solve", "mrs_tg_plan_bind_solve",
     "mrs_tg_bound_solve_launch", "mrs_tg_bound_solve_launch_many", "mrs_tg_bound_solve_launch_many_mt",
-    "mrs_tg_bound_solve_destroy", "mrs_tg_plan_cost_gradient",
+    "mrs_tg_bound_solve_destroy", "mrs_tg_host_alloc", "mrs_tg_host_free", "mrs_tg_host_register",
+    "mrs_tg_host_unregister", "mrs_tg_plan_cost_gradient",
     "mrs_tg_plan_segment_maxima", "mrs_tg_plan_sample_states", "mrs_tg_plan_careful_count", "mrs_tg_set_profiling", "mrs_tg_last_kernel_ms", "mrs_tg_kernel_ms_history",
     "mrs_tg_find_trajectory",
     "mrs_tg_default_policy_options", "mrs_tg_optimize_paths", "mrs_tg_waypoint_trajectory_idxs",
@@ -116,6 +117,14 @@ def load_library():
     L.mrs_tg_abi_version.restype = C.c_int
     L.mrs_tg_default_options.restype = None
     L.mrs_tg_default_options.argtypes = [C.POINTER(Options)]
+    L.mrs_tg_host_alloc.restype = C.c_int
+    L.mrs_tg_host_alloc.argtypes = [C.c_size_t, C.POINTER(vp)]
+    L.mrs_tg_host_free.restype = None
+    L.mrs_tg_host_free.argtypes = [vp]
+    L.mrs_tg_host_register.restype = C.c_int
+    L.mrs_tg_host_register.argtypes = [vp, C.c_size_t]
+    L.mrs_tg_host_unregister.restype = C.c_int
+    L.mrs_tg_host_unregister.argtypes = [vp]
     L.mrs_tg_set_stream.restype = C.c_int
     L.mrs_tg_set_stream.argtypes = [vp, vp]
     L.mrs_tg_reset_stream.restype = C.c_int
@@ -219,6 +228,45 @@ def _np_ptr(a):
     return C.c_void_p(a.ctypes.data) if a is not None else None
 
 
+class _PinnedBlock:
+    """keeps a block of mrs_tg_host_alloc alive for the numpy array that views it"""
+
+    def __init__(self, nbytes):
+        self._L = load_library()
+        self.ptr = C.c_void_p()
+        rc = self._L.mrs_tg_host_alloc(C.c_size_t(nbytes), C.byref(self.ptr))
+        if rc:
+            raise MrsTgError("mrs_tg_host_alloc failed (%d): %s" % (rc, self._L.mrs_tg_last_error(None).decode()))
+        self.buf = (C.c_char * max(int(nbytes), 1)).from_address(self.ptr.value)
+
+    def __del__(self):
+        if getattr(self, "ptr", None) is not None and self.ptr.value:
+            self._L.mrs_tg_host_free(self.ptr)
+            self.ptr = C.c_void_p()
+
+
+def pinned_empty(shape, dtype=np.float64):
+    """A numpy array in pinned host memory (mrs_tg_host_alloc): the GPU's DMA engines read / write it directly, so
+    mrs_tg_solve_batch neither stages nor pins it per call."""
+    dtype = np.dtype(dtype)
+    n = int(np.prod(shape)) if np.ndim(shape) else int(shape)
+    block = _PinnedBlock(n * dtype.itemsize)
+    a = np.frombuffer(block.buf, dtype=dtype, count=n).reshape(shape)
+    _PINNED_KEEPALIVE[id(block)] = block
+    import weakref
+    weakref.finalize(a, _PINNED_KEEPALIVE.pop, id(block), None)
+    return a
+
+
+_PINNED_KEEPALIVE = {}
+
+
+def pinned_copy(a):
+    out = pinned_empty(a.shape, a.dtype)
+    out[...] = a
+    return out
+
+
 def _t_ptr(t):
     return C.c_void_p(t.data_ptr()) if t is not None else None
 
@@ -274,22 +322,34 @@ class Context:
             self._check(n, "kernel_ms_history")
         return [buf[i] for i in range(n)]
 
-    def solve_batch(self, batch: Batch, seg_times=None, **opts):
-        """Host arrays in, host arrays out (mrs_tg_solve_batch).  seg_times None => estimate_times."""
+    def solve_batch(self, batch: Batch, seg_times=None, out=None, **opts):
+        """Host arrays in, host arrays out (mrs_tg_solve_batch).  seg_times None => estimate_times.
+        out: the dict of a previous call with the same shapes (or arrays from pinned_empty): its arrays are written in place
+        instead of allocating new ones -- what a server that calls in a loop does; `times` is then used as given AND
+        overwritten unless seg_times is passed."""
         opt = default_options(derivative_to_optimize=batch.derivative_to_optimize, **opts)
         nS, P = batch.n_segments, batch.n_paths
-        if seg_times is None:
-            opt.estimate_times = 1
-            t = np.zeros(nS)
-        else:
-            t = np.ascontiguousarray(seg_times, dtype=np.float64).copy()
-            assert t.size == nS
-        coeffs = np.zeros((nS, N_DIM, N_COEFF))
-        status = np.zeros(P, dtype=np.int32)
-        cost = np.zeros(P)
         sampling = opt.sampling_dt > 0
-        n_samples = np.zeros(P, dtype=np.int32) if sampling else None
-        samples = np.zeros((P, max(opt.sample_capacity, 1), N_DIM)) if sampling else None
+        if out is not None:
+            t, coeffs, status, cost = out["times"], out["coeffs"], out["status"], out["cost"]
+            n_samples, samples = (out["n_samples"], out["samples"]) if sampling else (None, None)
+            if seg_times is None:
+                opt.estimate_times = 1
+            else:
+                t[:] = seg_times
+            assert t.size == nS and coeffs.shape == (nS, N_DIM, N_COEFF) and status.size == P
+        else:
+            if seg_times is None:
+                opt.estimate_times = 1
+                t = np.zeros(nS)
+            else:
+                t = np.ascontiguousarray(seg_times, dtype=np.float64).copy()
+                assert t.size == nS
+            coeffs = np.zeros((nS, N_DIM, N_COEFF))
+            status = np.zeros(P, dtype=np.int32)
+            cost = np.zeros(P)
+            n_samples = np.zeros(P, dtype=np.int32) if sampling else None
+            samples = np.zeros((P, max(opt.sample_capacity, 1), N_DIM)) if sampling else None
         rc = self._L.mrs_tg_solve_batch(self._h, P, _np_ptr(batch.seg_offsets), _np_ptr(batch.waypoints),
                                         _np_ptr(batch.fixed_mask), _np_ptr(batch.fixed_values), _np_ptr(batch.limits),
                                         C.byref(opt), _np_ptr(t), _np_ptr(coeffs), _np_ptr(status), _np_ptr(cost),

@@ -35,16 +35,18 @@ def _stale():
     return any(os.path.getmtime(d) > t for d in deps if os.path.exists(d))
 
 
-def build(force=False, verbose=False):
-    if not force and not _stale():
+def build(force=False, verbose=False, extra_flags=(), lib=None, objdir_name="build"):
+    """extra_flags / lib / objdir_name: experiment builds (scripts/variants.sh): another -D set into another .so"""
+    lib = lib or LIB
+    if lib == LIB and not force and not _stale():
         return LIB
     hipcc = _hipcc()
-    objdir = os.path.join(HERE, "build")
+    objdir = os.path.join(HERE, objdir_name)
     os.makedirs(objdir, exist_ok=True)
 
     def compile_one(src):
         obj = os.path.join(objdir, src.replace(".hip", ".o"))
-        cmd = [hipcc] + FLAGS + ["-c", os.path.join(CSRC, src), "-o", obj]
+        cmd = [hipcc] + FLAGS + list(extra_flags) + ["-c", os.path.join(CSRC, src), "-o", obj]
         if verbose:
             print(" ".join(cmd), flush=True)
         subprocess.check_call(cmd)
@@ -52,12 +54,18 @@ def build(force=False, verbose=False):
 
     with ThreadPoolExecutor(max_workers=len(SOURCES)) as ex:
         objs = list(ex.map(compile_one, SOURCES))
-    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
+    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib] + objs
     if verbose:
         print(" ".join(cmd), flush=True)
     subprocess.check_call(cmd)
-    return LIB
+    return lib
 
 
 if __name__ == "__main__":
-    print(build(force="--force" in sys.argv, verbose=True))
+    if "--variant" in sys.argv:   # python -m ...build --variant NAME -DX=1 ... -> libmrs_tg_NAME.so (api: MRS_TG_LIB_PATH)
+        i = sys.argv.index("--variant")
+        name = sys.argv[i + 1]
+        print(build(force=True, verbose=False, extra_flags=sys.argv[i + 2:], lib=os.path.join(HERE, "libmrs_tg_%s.so" % name),
+                    objdir_name="build_" + name))
+    else:
+        print(build(force="--force" in sys.argv, verbose=True))

@@ -56,6 +56,12 @@ struct mrs_tg_ctx {
   // plan of the most recent mrs_tg_solve_batch: a caller that sends the same batch shape again (the nodelet's
   // deviation loop, a server's fixed batch size) skips the analysis, the uploads and the device allocations
   mrs_tg_plan* cached_plan = nullptr;
+  // mrs_tg_solve_batch's transfer arenas, kept across calls: one device block holding every input and output array of a
+  // call, and a pinned host block (hipHostMalloc) through which the small host arrays travel packed, one copy each way
+  void* d_arena = nullptr;
+  size_t d_arena_bytes = 0;
+  void* h_arena = nullptr;
+  size_t h_arena_bytes = 0;
 };
 
 struct mrs_tg_plan {
@@ -288,6 +294,8 @@ void mrs_tg_destroy(mrs_tg_ctx* ctx) {
     for (hipEvent_t e : ctx->ev_stop[i])
       if (e) (void)hipEventDestroy(e);
   }
+  if (ctx->d_arena) (void)mrs_tg::pool_free(ctx->d_arena);
+  if (ctx->h_arena) (void)hipHostFree(ctx->h_arena);
   if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
   delete ctx;
   if (--g_live_contexts == 0) mrs_tg::pool_release_cached();  // the cached device blocks go with the last context
@@ -485,6 +493,7 @@ int mrs_tg_plan_solve(mrs_tg_plan* plan, const double* wp, const uint8_t* mask, 
     prm.use_soft = opt->use_soft_constraints;
     prm.initial_stepsize_rel = opt->initial_stepsize_rel;
     prm.time_budget_ticks = opt->max_time_s > 0 ? budget_ticks(ctx, opt->max_time_s) : 0;
+    ProfileScope ps(ctx, 2);
     HIP_TRY(ctx, mrs_tg::launch_dfo(plan->nl, b, prm, mask, vals, limits, seg_times, coeffs, status, cost, ctx->stream));
   } else if (opt->time_alloc_method == MRS_TG_TIME_ALLOC_MELLINGER) {
     mrs_tg::NonlinearParams prm;
@@ -580,7 +589,8 @@ namespace {
 
 struct IssueJob {
   mrs_tg_bound_solve* const* bound = nullptr;
-  int n_bound = 0, n_launches = 0, first = 0, stride = 1;
+  int n_bound = 0, n_launches = 0, me = 0;
+  const int* owner = nullptr;  // [n_bound] the thread that issues bound solve i: solves that share a context share a thread
   int rc = MRS_TG_OK;
 };
 
@@ -592,6 +602,7 @@ class IssuePool {
   }
   // runs jobs[1..] on helpers and jobs[0] on the caller; returns when all are done
   void run(std::vector<IssueJob>& jobs) {
+    std::lock_guard<std::mutex> one_caller(run_mutex_);  // the workers and their job slots serve one run at a time
     const int helpers = (int)jobs.size() - 1;
     ensure(helpers);
     for (int j = 0; j < helpers; ++j) workers_[j]->post(&jobs[j + 1]);
@@ -599,8 +610,9 @@ class IssuePool {
     for (int j = 0; j < helpers; ++j) workers_[j]->wait();
   }
   static void issue(IssueJob& job) {
-    for (int k = job.first; k < job.n_launches; k += job.stride) {
-      const int rc = mrs_tg_bound_solve_launch(job.bound[k % job.n_bound]);
+    for (int k = 0, i = 0; k < job.n_launches; ++k, i = (i + 1 == job.n_bound) ? 0 : i + 1) {
+      if (job.owner[i] != job.me) continue;
+      const int rc = mrs_tg_bound_solve_launch(job.bound[i]);
       if (rc != MRS_TG_OK) {
         job.rc = rc;
         return;
@@ -658,6 +670,7 @@ class IssuePool {
     while ((int)workers_.size() < helpers) workers_.emplace_back(new Worker());
   }
   std::vector<std::unique_ptr<Worker>> workers_;
+  std::mutex run_mutex_;
 };
 
 }  // namespace
@@ -665,31 +678,51 @@ class IssuePool {
 int mrs_tg_bound_solve_launch_many_mt(mrs_tg_bound_solve* const* bound, int32_t n_bound, int32_t n_launches,
                                       int32_t n_threads) {
   if (!bound || n_bound < 1 || n_launches < 0) return fail(nullptr, MRS_TG_ERR_INVALID_ARG, "bound solves are required");
-  int T = n_threads < 1 ? 1 : n_threads;
-  if (T > n_bound) T = n_bound;  // a bound solve's launches stay on one thread
-  if (T > 8) T = 8;
-  // thread j takes the launches whose bound solve index is congruent to j modulo T: n_bound must be a multiple of T for the
-  // round-robin order k -> k % n_bound to keep a solve on one thread
-  while (T > 1 && n_bound % T != 0) --T;
-  if (T == 1) return mrs_tg_bound_solve_launch_many(bound, n_bound, n_launches);
-  std::vector<IssueJob> jobs((size_t)T);
-  for (int j = 0; j < T; ++j) {
-    jobs[j].bound = bound;
-    jobs[j].n_bound = n_bound;
-    jobs[j].n_launches = n_launches;
-    jobs[j].first = j;
-    jobs[j].stride = T;
+  for (int32_t i = 0; i < n_bound; ++i)
+    if (!bound[i]) return fail(nullptr, MRS_TG_ERR_INVALID_ARG, "bound solve %d is NULL", i);
+  try {
+    // A context (its plans' workspaces, its timers, its error string) is driven by one thread at a time: the bound solves
+    // are partitioned by CONTEXT, not by index -- every solve of a context goes to the same issuing thread, and the
+    // number of threads is at most the number of distinct contexts.
+    std::vector<mrs_tg_ctx*> ctxs;
+    std::vector<int> owner((size_t)n_bound);
+    for (int32_t i = 0; i < n_bound; ++i) {
+      mrs_tg_ctx* c = bound[i]->plan->ctx;
+      size_t j = 0;
+      while (j < ctxs.size() && ctxs[j] != c) ++j;
+      if (j == ctxs.size()) ctxs.push_back(c);
+      owner[(size_t)i] = (int)j;
+    }
+    int T = n_threads < 1 ? 1 : n_threads;
+    if (T > (int)ctxs.size()) T = (int)ctxs.size();
+    if (T > 8) T = 8;
+    if (T == 1) return mrs_tg_bound_solve_launch_many(bound, n_bound, n_launches);
+    for (int& o : owner) o %= T;
+    std::vector<IssueJob> jobs((size_t)T);
+    for (int j = 0; j < T; ++j) {
+      jobs[j].bound = bound;
+      jobs[j].n_bound = n_bound;
+      jobs[j].n_launches = n_launches;
+      jobs[j].me = j;
+      jobs[j].owner = owner.data();
+    }
+    IssuePool::instance().run(jobs);
+    for (const IssueJob& j : jobs)
+      if (j.rc != MRS_TG_OK) return j.rc;
+    return MRS_TG_OK;
+  } catch (const std::bad_alloc&) {
+    return fail(nullptr, MRS_TG_ERR_NOMEM, "out of host memory");
+  } catch (const std::exception& ex) {  // std::system_error of a thread that could not be started: nothing crosses the C boundary
+    return fail(nullptr, MRS_TG_ERR_UNSUPPORTED, "issue threads: %s", ex.what());
   }
-  IssuePool::instance().run(jobs);
-  for (const IssueJob& j : jobs)
-    if (j.rc != MRS_TG_OK) return j.rc;
-  return MRS_TG_OK;
 }
 
 int mrs_tg_bound_solve_launch_many(mrs_tg_bound_solve* const* bound, int32_t n_bound, int32_t n_launches) {
   if (!bound || n_bound < 1 || n_launches < 0) return fail(nullptr, MRS_TG_ERR_INVALID_ARG, "bound solves are required");
-  for (int32_t k = 0; k < n_launches; ++k) {
-    const int rc = mrs_tg_bound_solve_launch(bound[k % n_bound]);
+  for (int32_t i = 0; i < n_bound; ++i)
+    if (!bound[i]) return fail(nullptr, MRS_TG_ERR_INVALID_ARG, "bound solve %d is NULL", i);
+  for (int32_t k = 0, i = 0; k < n_launches; ++k, i = (i + 1 == n_bound) ? 0 : i + 1) {
+    const int rc = mrs_tg_bound_solve_launch(bound[i]);
     if (rc != MRS_TG_OK) return rc;
   }
   return MRS_TG_OK;
@@ -769,27 +802,112 @@ int mrs_tg_solve_batch(mrs_tg_ctx* ctx, int32_t n_paths, const int32_t* so, cons
   const bool sampling = opt->sampling_dt > 0;
   if (sampling && !n_samples) return fail(ctx, MRS_TG_ERR_INVALID_ARG, "n_samples_out is required when sampling");
   const size_t samp_doubles = sampling && samples ? (size_t)n_paths * (size_t)opt->sample_capacity * 4 : 0;
-  DevBuf d_wp, d_mask, d_vals, d_lim, d_t, d_c, d_st, d_cost, d_ns, d_smp;
-  struct SyncOnExit {  // declared after the buffers, so it runs before they return to the pool (also on error paths)
-    hipStream_t s;
-    ~SyncOnExit() { (void)hipStreamSynchronize(s); }
-  } sync_on_exit{ctx->stream};
-  HIP_TRY(ctx, d_wp.alloc(nV * 4 * sizeof(double)));
-  HIP_TRY(ctx, d_mask.alloc(nV * 5));
-  HIP_TRY(ctx, d_vals.alloc(nV * 20 * sizeof(double)));
-  HIP_TRY(ctx, d_lim.alloc((size_t)n_paths * 9 * sizeof(double)));
-  HIP_TRY(ctx, d_t.alloc(nS * sizeof(double)));
-  HIP_TRY(ctx, d_c.alloc(nS * 40 * sizeof(double)));
-  HIP_TRY(ctx, d_st.alloc((size_t)n_paths * sizeof(int32_t)));
-  HIP_TRY(ctx, d_cost.alloc((size_t)n_paths * sizeof(double)));
-  HIP_TRY(ctx, d_ns.alloc((size_t)n_paths * sizeof(int32_t)));
-  HIP_TRY(ctx, d_smp.alloc(samp_doubles * sizeof(double)));
+  HIP_TRY(ctx, use_device(ctx->device));
   hipStream_t s = ctx->stream;
-  if (wp) HIP_TRY(ctx, hipMemcpyAsync(d_wp.p, wp, nV * 4 * sizeof(double), hipMemcpyHostToDevice, s));
-  HIP_TRY(ctx, hipMemcpyAsync(d_mask.p, mask, nV * 5, hipMemcpyHostToDevice, s));
-  HIP_TRY(ctx, hipMemcpyAsync(d_vals.p, vals, nV * 20 * sizeof(double), hipMemcpyHostToDevice, s));
-  if (limits) HIP_TRY(ctx, hipMemcpyAsync(d_lim.p, limits, (size_t)n_paths * 9 * sizeof(double), hipMemcpyHostToDevice, s));
-  HIP_TRY(ctx, hipMemcpyAsync(d_t.p, seg_times, nS * sizeof(double), hipMemcpyHostToDevice, s));
+
+  // ---- the arrays of the call.  Every one gets its place in ONE device block kept by the context (no allocation per call
+  // once a batch shape has been seen).  How an array travels depends on where the caller keeps it:
+  //   * pinned host memory (mrs_tg_host_alloc / mrs_tg_host_register, or any hipHostMalloc'ed block), which the GPU
+  //     addresses directly: all pinned inputs are gathered by ONE copy kernel, all pinned outputs scattered by one (a
+  //     kernel launch costs the host ~3 us, a hipMemcpyAsync 10-25 us, and seven of those were half of a 1024-path call).
+  //     Fixed-times mode with every array pinned needs no copy at all: the solve kernel reads the caller's inputs once and
+  //     writes the caller's outputs once, over PCIe, while it computes;
+  //   * pageable memory, small (<= stage_max bytes): packed into the context's pinned staging block, which travels with the
+  //     pinned arrays in the same copy kernel -- one transfer each way, no synchronisation in between;
+  //   * pageable memory, large: hipMemcpyAsync on the caller's buffer (the runtime pins the pages in place; staging 3 MB
+  //     of coefficients through another host copy costs more than that).
+  // Waypoints are only read by the time estimator: not uploaded when estimate_times is off.
+  static const size_t stage_max = [] {
+    const char* e = std::getenv("MRS_TG_STAGE_MAX_BYTES");
+    return e ? (size_t)std::atoll(e) : (size_t)256 * 1024;
+  }();
+  static const bool zero_copy_allowed = [] {
+    const char* e = std::getenv("MRS_TG_ZERO_COPY");
+    return e == nullptr || std::atoi(e) != 0;
+  }();
+  struct Arr {
+    const void* src;  // host source (inputs)
+    void* dst;        // host destination (outputs)
+    size_t bytes;
+    bool staged;
+    void* pinned;     // device-side address of the caller's array when it lives in pinned memory
+    size_t off;       // offset in the device arena
+  };
+  auto pinned_address = [](const void* ptr) -> void* {
+    hipPointerAttribute_t at;
+    if (hipPointerGetAttributes(&at, ptr) != hipSuccess) {
+      (void)hipGetLastError();  // an ordinary (pageable) pointer is reported as an error by some runtimes
+      return nullptr;
+    }
+    if (at.type != hipMemoryTypeHost) return nullptr;
+    return at.devicePointer ? at.devicePointer : const_cast<void*>(ptr);
+  };
+  auto make = [&](const void* src, void* dst, size_t bytes) {
+    const void* host = src ? src : dst;
+    Arr a{src, dst, bytes, false, nullptr, 0};
+    if (host != nullptr && bytes > 0) {
+      a.pinned = pinned_address(host);
+      a.staged = a.pinned == nullptr && bytes <= stage_max;
+    }
+    return a;
+  };
+  const bool want_wp = wp != nullptr && opt->estimate_times != 0;
+  enum { A_WP, A_MASK, A_VALS, A_LIM, A_T, A_C, A_ST, A_COST, A_NS, A_SMP, A_COUNT };
+  Arr arr[A_COUNT] = {
+      make(want_wp ? wp : nullptr, nullptr, want_wp ? nV * 4 * sizeof(double) : 0),
+      make(mask, nullptr, nV * 5),
+      make(vals, nullptr, nV * 20 * sizeof(double)),
+      make(limits, nullptr, limits ? (size_t)n_paths * 9 * sizeof(double) : 0),
+      make(seg_times, seg_times, nS * sizeof(double)),
+      make(nullptr, coeffs, nS * 40 * sizeof(double)),
+      make(nullptr, status, (size_t)n_paths * sizeof(int32_t)),
+      make(nullptr, cost, (size_t)n_paths * sizeof(double)),   // the kernels want a cost buffer even when the caller does not
+      make(nullptr, sampling ? n_samples : nullptr, (size_t)n_paths * sizeof(int32_t)),
+      make(nullptr, samp_doubles ? samples : nullptr, samp_doubles * sizeof(double)),
+  };
+  // device layout: unstaged inputs | staged inputs | seg_times (in and out) | staged outputs | unstaged outputs: the staged
+  // arrays of each direction are one contiguous span, and the host arena mirrors [staged inputs | seg_times | staged outputs]
+  const int in_ids[4] = {A_WP, A_MASK, A_VALS, A_LIM};
+  const int out_ids[5] = {A_C, A_ST, A_COST, A_NS, A_SMP};
+  auto align = [](size_t x) { return (x + 255) & ~(size_t)255; };
+  size_t off = 0;
+  for (int id : in_ids)
+    if (!arr[id].staged) { arr[id].off = off; off += align(arr[id].bytes); }
+  const size_t span_begin = off;
+  for (int id : in_ids)
+    if (arr[id].staged) { arr[id].off = off; off += align(arr[id].bytes); }
+  const size_t t_off = off;
+  arr[A_T].off = off;
+  off += align(arr[A_T].bytes);
+  const size_t in_span_end = arr[A_T].staged ? off : t_off;
+  const size_t out_span_begin = arr[A_T].staged ? t_off : off;
+  for (int id : out_ids)
+    if (arr[id].staged) { arr[id].off = off; off += align(arr[id].bytes); }
+  const size_t span_end = off;
+  for (int id : out_ids)
+    if (!arr[id].staged) { arr[id].off = off; off += align(arr[id].bytes ? arr[id].bytes : 8); }
+  const size_t d_need = off ? off : 256, h_need = span_end - span_begin;
+  if (ctx->d_arena_bytes < d_need) {
+    if (ctx->d_arena) (void)mrs_tg::pool_free(ctx->d_arena);
+    ctx->d_arena = nullptr;
+    ctx->d_arena_bytes = 0;
+    HIP_TRY(ctx, mrs_tg::pool_alloc(&ctx->d_arena, d_need));
+    ctx->d_arena_bytes = d_need;
+  }
+  if (ctx->h_arena_bytes < h_need) {
+    if (ctx->h_arena) (void)hipHostFree(ctx->h_arena);
+    ctx->h_arena = nullptr;
+    ctx->h_arena_bytes = 0;
+    HIP_TRY(ctx, hipHostMalloc(&ctx->h_arena, h_need, hipHostMallocDefault));
+    ctx->h_arena_bytes = h_need;
+  }
+  char* dbase = static_cast<char*>(ctx->d_arena);
+  char* hbase = static_cast<char*>(ctx->h_arena) - span_begin;  // hbase + device offset = the array's place in the host arena
+  struct SyncOnExit {  // nothing of this call is in flight when it returns, on error paths as well (the arenas are reused)
+    hipStream_t st;
+    ~SyncOnExit() { (void)hipStreamSynchronize(st); }
+  } sync_on_exit{s};
+
   mrs_tg_options local = *opt;
   if (local.time_alloc_method == MRS_TG_TIME_ALLOC_NONE && !(local.flags & MRS_TG_FLAG_GENERAL_PATTERNS)) {
     // the masks are in host memory here: a vertex without a position constraint switches the general solver on
@@ -799,22 +917,102 @@ int mrs_tg_solve_batch(mrs_tg_ctx* ctx, int32_t n_paths, const int32_t* so, cons
         break;
       }
   }
+  // zero copy: one pass over every array (fixed times, default solve) and every array the caller passed is pinned
+  bool zero_copy = zero_copy_allowed && local.time_alloc_method == MRS_TG_TIME_ALLOC_NONE && !local.estimate_times &&
+                   (local.flags & (MRS_TG_FLAG_GENERAL_PATTERNS | MRS_TG_FLAG_MATERIALIZED_BLOCKS)) == 0 &&
+                   mrs_tg::rows_kernel_applies(plan->view, sampling) && (!sampling || mrs_tg::rows_tail_sampling_pays(plan->view));
+  for (int id = 0; id < A_COUNT && zero_copy; ++id) {
+    const Arr& a = arr[id];
+    if ((a.src || a.dst) && a.bytes && !a.pinned) zero_copy = false;
+  }
+  // where the kernels find array `id`: the caller's own (pinned) memory under zero copy, its slot of the arena otherwise
+  auto dev = [&](int id) -> void* {
+    const Arr& a = arr[id];
+    return (zero_copy && a.pinned && a.bytes) ? a.pinned : static_cast<void*>(dbase + a.off);
+  };
+
+  // ---- host to device
+  if (!zero_copy) {
+    mrs_tg::CopyList up;
+    for (int id : {A_WP, A_MASK, A_VALS, A_LIM, A_T}) {
+      const Arr& a = arr[id];
+      if (!a.src || !a.bytes) continue;
+      if (a.staged) std::memcpy(hbase + a.off, a.src, a.bytes);
+      else if (a.pinned) up.add(a.pinned, dbase + a.off, a.bytes);
+      else HIP_TRY(ctx, hipMemcpyAsync(dbase + a.off, a.src, a.bytes, hipMemcpyHostToDevice, s));
+    }
+    if (in_span_end > span_begin) up.add(hbase + span_begin, dbase + span_begin, in_span_end - span_begin);
+    HIP_TRY(ctx, mrs_tg::launch_copy_many(up, s));
+  }
   if (local.max_time_s > 0) {  // what is left of the caller's budget when the kernels start
     const double spent = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_call).count();
     local.max_time_s = local.max_time_s - spent > 1.0e-9 ? local.max_time_s - spent : 1.0e-9;
   }
-  rc = mrs_tg_plan_solve(plan, wp ? d_wp.as<double>() : nullptr, d_mask.as<uint8_t>(), d_vals.as<double>(),
-                         limits ? d_lim.as<double>() : nullptr, &local, d_t.as<double>(), d_c.as<double>(),
-                         d_st.as<int32_t>(), d_cost.as<double>(), sampling ? d_ns.as<int32_t>() : nullptr,
-                         samp_doubles ? d_smp.as<double>() : nullptr);
+  // (estimate_times without waypoints is refused by mrs_tg_plan_solve, as before)
+  rc = mrs_tg_plan_solve(plan, want_wp ? static_cast<double*>(dev(A_WP)) : nullptr, static_cast<uint8_t*>(dev(A_MASK)),
+                         static_cast<double*>(dev(A_VALS)), limits ? static_cast<double*>(dev(A_LIM)) : nullptr, &local,
+                         static_cast<double*>(dev(A_T)), static_cast<double*>(dev(A_C)), static_cast<int32_t*>(dev(A_ST)),
+                         static_cast<double*>(dev(A_COST)), sampling ? static_cast<int32_t*>(dev(A_NS)) : nullptr,
+                         samp_doubles ? static_cast<double*>(dev(A_SMP)) : nullptr);
   if (rc != MRS_TG_OK) return rc;
-  HIP_TRY(ctx, hipMemcpyAsync(seg_times, d_t.p, nS * sizeof(double), hipMemcpyDeviceToHost, s));
-  HIP_TRY(ctx, hipMemcpyAsync(coeffs, d_c.p, nS * 40 * sizeof(double), hipMemcpyDeviceToHost, s));
-  HIP_TRY(ctx, hipMemcpyAsync(status, d_st.p, (size_t)n_paths * sizeof(int32_t), hipMemcpyDeviceToHost, s));
-  if (cost) HIP_TRY(ctx, hipMemcpyAsync(cost, d_cost.p, (size_t)n_paths * sizeof(double), hipMemcpyDeviceToHost, s));
-  if (sampling) HIP_TRY(ctx, hipMemcpyAsync(n_samples, d_ns.p, (size_t)n_paths * sizeof(int32_t), hipMemcpyDeviceToHost, s));
-  if (samp_doubles) HIP_TRY(ctx, hipMemcpyAsync(samples, d_smp.p, samp_doubles * sizeof(double), hipMemcpyDeviceToHost, s));
+
+  // ---- device to host: pinned arrays and the staged span in one copy kernel, large pageable arrays by the runtime; one
+  // synchronisation
+  if (!zero_copy) {
+    mrs_tg::CopyList down;
+    if (span_end > out_span_begin) down.add(dbase + out_span_begin, hbase + out_span_begin, span_end - out_span_begin);
+    for (int id : {A_T, A_C, A_ST, A_COST, A_NS, A_SMP}) {
+      const Arr& a = arr[id];
+      if (!a.dst || !a.bytes || a.staged) continue;
+      if (a.pinned) down.add(dbase + a.off, a.pinned, a.bytes);
+      else HIP_TRY(ctx, hipMemcpyAsync(a.dst, dbase + a.off, a.bytes, hipMemcpyDeviceToHost, s));
+    }
+    HIP_TRY(ctx, mrs_tg::launch_copy_many(down, s));
+  }
   HIP_TRY(ctx, hipStreamSynchronize(s));
+  if (!zero_copy)
+    for (int id : {A_T, A_C, A_ST, A_COST, A_NS, A_SMP}) {
+      const Arr& a = arr[id];
+      if (a.dst && a.bytes && a.staged) std::memcpy(a.dst, hbase + a.off, a.bytes);
+    }
+  return MRS_TG_OK;
+}
+
+// Pinned host memory for the arrays of mrs_tg_solve_batch / mrs_tg_optimize_paths: buffers allocated (or registered) here
+// are read and written by the GPU's DMA engines directly, with no staging copy on either side.
+int mrs_tg_host_alloc(size_t bytes, void** ptr_out) {
+  if (!ptr_out) return fail(nullptr, MRS_TG_ERR_INVALID_ARG, "ptr_out is NULL");
+  *ptr_out = nullptr;
+  const hipError_t e = hipHostMalloc(ptr_out, bytes ? bytes : 8, hipHostMallocDefault);
+  if (e != hipSuccess) {
+    (void)hipGetLastError();
+    return fail(nullptr, e == hipErrorOutOfMemory ? MRS_TG_ERR_NOMEM : MRS_TG_ERR_HIP, "hipHostMalloc(%zu) failed: %s", bytes,
+                hipGetErrorString(e));
+  }
+  return MRS_TG_OK;
+}
+
+void mrs_tg_host_free(void* ptr) {
+  if (ptr) (void)hipHostFree(ptr);
+}
+
+int mrs_tg_host_register(void* ptr, size_t bytes) {
+  if (!ptr || !bytes) return fail(nullptr, MRS_TG_ERR_INVALID_ARG, "nothing to register");
+  const hipError_t e = hipHostRegister(ptr, bytes, hipHostRegisterDefault);
+  if (e != hipSuccess) {
+    (void)hipGetLastError();
+    return fail(nullptr, MRS_TG_ERR_HIP, "hipHostRegister failed: %s", hipGetErrorString(e));
+  }
+  return MRS_TG_OK;
+}
+
+int mrs_tg_host_unregister(void* ptr) {
+  if (!ptr) return MRS_TG_OK;
+  const hipError_t e = hipHostUnregister(ptr);
+  if (e != hipSuccess) {
+    (void)hipGetLastError();
+    return fail(nullptr, MRS_TG_ERR_HIP, "hipHostUnregister failed: %s", hipGetErrorString(e));
+  }
   return MRS_TG_OK;
 }
 

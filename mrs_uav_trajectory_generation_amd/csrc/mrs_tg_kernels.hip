@@ -293,6 +293,50 @@ hipError_t launch_solve_linear(const BatchView& b, int d, bool fused, const uint
   return hipGetLastError();
 }
 
+// blockIdx.y = entry of the list; 16-byte words where both ends are 16-byte aligned (every array of the ABI in practice),
+// narrower words otherwise; grid-stride, so that a few hundred workgroups keep enough PCIe reads / writes in flight
+__global__ __launch_bounds__(256) void copy_many_kernel(CopyList cl) {
+  const int e = blockIdx.y;
+  const char* src = static_cast<const char*>(cl.src[e]);
+  char* dst = static_cast<char*>(cl.dst[e]);
+  const unsigned long long bytes = cl.bytes[e];
+  const unsigned long long tid = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const unsigned long long stride = (unsigned long long)gridDim.x * blockDim.x;
+  const unsigned long long align = (unsigned long long)(uintptr_t)src | (unsigned long long)(uintptr_t)dst;
+  unsigned long long done = 0;
+  if ((align & 15ull) == 0) {
+    const unsigned long long n = bytes >> 4;
+    const uint4* s4 = reinterpret_cast<const uint4*>(src);
+    uint4* d4 = reinterpret_cast<uint4*>(dst);
+    for (unsigned long long i = tid; i < n; i += stride) d4[i] = s4[i];
+    done = n << 4;
+  } else if ((align & 7ull) == 0) {
+    const unsigned long long n = bytes >> 3;
+    const unsigned long long* s8 = reinterpret_cast<const unsigned long long*>(src);
+    unsigned long long* d8 = reinterpret_cast<unsigned long long*>(dst);
+    for (unsigned long long i = tid; i < n; i += stride) d8[i] = s8[i];
+    done = n << 3;
+  } else if ((align & 3ull) == 0) {
+    const unsigned long long n = bytes >> 2;
+    const unsigned* s32 = reinterpret_cast<const unsigned*>(src);
+    unsigned* d32 = reinterpret_cast<unsigned*>(dst);
+    for (unsigned long long i = tid; i < n; i += stride) d32[i] = s32[i];
+    done = n << 2;
+  }
+  for (unsigned long long i = done + tid; i < bytes; i += stride) dst[i] = src[i];
+}
+
+hipError_t launch_copy_many(const CopyList& cl, hipStream_t stream) {
+  if (cl.n == 0) return hipSuccess;
+  unsigned long long most = 0;
+  for (int i = 0; i < cl.n; ++i) most = cl.bytes[i] > most ? cl.bytes[i] : most;
+  // one 16-byte word per thread up to 512 workgroups, grid-stride beyond
+  unsigned blocks = (unsigned)((most / 16 + 255) / 256);
+  blocks = blocks < 1 ? 1 : (blocks > 512 ? 512 : blocks);
+  hipLaunchKernelGGL(copy_many_kernel, dim3(blocks, (unsigned)cl.n), dim3(256), 0, stream, cl);
+  return hipGetLastError();
+}
+
 hipError_t launch_estimate_times(const BatchView& b, const double* wp, const double* limits, double* seg_times,
                                  hipStream_t stream) {
   if (b.n_segments == 0) return hipSuccess;

@@ -50,6 +50,24 @@ hipError_t launch_solve_linear(const BatchView& b, int d, bool fused, const uint
                                const double* seg_times, const double* H, const double* Ainv, double* ws,
                                double* coeffs, int32_t* status, double* cost, const int32_t* status_in,
                                hipStream_t stream);
+// Up to kCopyMax flat copies in ONE launch: how mrs_tg_solve_batch moves arrays between pinned host memory (which the
+// GPU addresses directly) and the device -- a kernel launch costs the host ~3 us, a hipMemcpyAsync 10-25 us.
+constexpr int kCopyMax = 8;
+struct CopyList {
+  const void* src[kCopyMax];
+  void* dst[kCopyMax];
+  unsigned long long bytes[kCopyMax];
+  int n = 0;
+  void add(const void* s, void* d, size_t b) {
+    if (b == 0 || s == nullptr || d == nullptr) return;
+    src[n] = s;
+    dst[n] = d;
+    bytes[n] = b;
+    ++n;
+  }
+};
+hipError_t launch_copy_many(const CopyList& cl, hipStream_t stream);
+
 hipError_t launch_estimate_times(const BatchView& b, const double* wp, const double* limits, double* seg_times,
                                  hipStream_t stream);
 hipError_t launch_sample(const BatchView& b, const double* coeffs, const double* seg_times, double dt, int capacity,

@@ -14,6 +14,7 @@ struct NonlinearParams {
   int max_iterations;
   double f_rel, f_abs, x_rel, x_abs;
   long long time_budget_ticks = 0;  // nlopt maxtime in ticks of the device's constant wall clock (s_memrealtime); 0 = none
+  const long long* deadline = nullptr;  // filled in by launch_nonlinear: the call's absolute deadline (device word), or none
   // Paths on which the by-product cost lost its digits (guarded_cost) are listed for the careful re-run
   // (optimize_careful_kernel): position q of the path appended to careful_list (capacity careful_cap) through
   // careful_count; a listed path keeps its start times.  nullptr: no list (the fast kernel's result stands).  A caller of

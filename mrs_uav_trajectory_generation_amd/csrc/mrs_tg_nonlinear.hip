@@ -42,6 +42,13 @@
 
 namespace mrs_tg {
 
+#ifndef MRS_TG_LEAN_RELOAD
+#define MRS_TG_LEAN_RELOAD 0
+#endif
+#ifndef MRS_TG_LEAN_WAVES
+#define MRS_TG_LEAN_WAVES 2
+#endif
+
 constexpr int kLbfgsM = 5;
 constexpr double kGradStep = 0.1;  // increment_time, nonlinear_impl.h:281
 
@@ -1099,11 +1106,117 @@ __device__ __forceinline__ double evaluate_lean(const double* tabs, const double
   for (int r = 0; r < rounds; ++r) {
     const int k = g + (r << g_shift);
     double Jk = 0.0, qfk = 0.0;
-    if (active && k <= S && (k == 0 || S > 1)) {
+    if (!MASKED && active && k <= S && (k == 0 || S > 1)) {
+      // The plain sweep (start | interior ... | end), written out for four dimensions per lane with the smallest live set
+      // the step allows.  The right-hand-side brackets are not materialised per (dimension, row) (FastStep::w: 36 doubles
+      // that lived across the whole step and pushed the kernel to 256 VGPRs + 116 bytes of scratch): row r of every
+      // dimension shares cN[r] = HBAR[1+r][0] T^(r+2-2d), so y[r][q] -= cN[r] dp[q] is one multiply per row and one FMA
+      // per (row, dimension) -- 8 multiplies + 32 FMAs per step where the bracket form had 32 + 32 -- and the f^T H f term
+      // of a segment is one FMA with the staged HBAR[0][0] |dp|^2.
+      const double* qs = ev + 4 * (size_t)Sb + 2;  // HBAR[0][0] |dp_i|^2 per segment (stage_ps)
+      double Sm[10], y[kNB][4], qf, red = 0.0;
+      {  // segment 0: the start vertex is fully constrained, the state moves to vertex 1
+        double p2[9];
+        segment_powers(perturbed_time(pt, 0, k, corr), d, p2);
+        qf = p2[0] * qs[0];
+#pragma unroll
+        for (int r = 0; r < kNB; ++r) {
+#pragma unroll
+          for (int c = 0; c <= r; ++c) Sm[tri(r, c)] = tab[26 + tri(r, c)] * p2[r + c + 2];
+          const double cF = tab[40 + r] * p2[r + 1];
+#pragma unroll
+          for (int q = 0; q < 4; ++q) y[r][q] = -(cF * dp[q]);
+        }
+      }
+      for (int i = 1; i < S; ++i) {
+#if MRS_TG_LEAN_RELOAD
+        // the far-block and coupling constants are read from LDS in every step (the pointer goes through an empty asm, so
+        // the loads cannot be hoisted out of the loop): hoisted, all 45 table constants live in 90 VGPRs across the sweep
+        const double* tabr = tab;
+        asm volatile("" : "+v"(tabr));
+#else
+        const double* tabr = tab;
+#endif
+        const double* tabn = MRS_TG_LEAN_RELOAD >= 2 ? tabr : tab;  // 2: the near-block constants as well
+        double p2[9];
+        segment_powers(perturbed_time(pt, i, k, corr), d, p2);
+        double dq[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) dq[q] = dp[i * 4 + q];
+        qf = fma(p2[0], qs[i], qf);
+        // vertex i: its block and right-hand side are complete with this segment's near part
+#pragma unroll
+        for (int r = 0; r < kNB; ++r) {
+#pragma unroll
+          for (int c = 0; c <= r; ++c) Sm[tri(r, c)] = fma(tabn[tri(r, c)], p2[r + c + 2], Sm[tri(r, c)]);
+          const double cN = tabn[36 + r] * p2[r + 1];
+#pragma unroll
+          for (int q = 0; q < 4; ++q) y[r][q] = fma(-cN, dq[q], y[r][q]);
+        }
+        // Cholesky of the block (only the off-diagonal entries and the reciprocal diagonal are ever used), z = L^-1 y
+        double L[10], Linv[kNB], z[kNB][4];
+#pragma unroll
+        for (int c = 0; c < kNB; ++c) {
+          double dsum = Sm[tri(c, c)];
+#pragma unroll
+          for (int m = 0; m < c; ++m) dsum = fma(-L[tri(c, m)], L[tri(c, m)], dsum);
+          const double inv = rsqrt_refined(dsum);
+          Linv[c] = inv;
+#pragma unroll
+          for (int rr = c + 1; rr < kNB; ++rr) {
+            double t = Sm[tri(rr, c)];
+#pragma unroll
+            for (int m = 0; m < c; ++m) t = fma(-L[tri(rr, m)], L[tri(c, m)], t);
+            L[tri(rr, c)] = t * inv;
+          }
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+          for (int rr = 0; rr < kNB; ++rr) {
+            double t = y[rr][q];
+#pragma unroll
+            for (int m = 0; m < rr; ++m) t = fma(-L[tri(rr, m)], z[m][q], t);
+            z[rr][q] = t * Linv[rr];
+            red = fma(z[rr][q], z[rr][q], red);
+          }
+        if (i < S - 1) {  // interior vertex: W = L^-1 E, then the Schur complement and right-hand side of vertex i + 1
+          double W[kNB][kNB];
+#pragma unroll
+          for (int c = 0; c < kNB; ++c)
+#pragma unroll
+            for (int rr = 0; rr < kNB; ++rr) {
+              double t = tabr[10 + rr * kNB + c] * p2[rr + c + 2];
+#pragma unroll
+              for (int m = 0; m < rr; ++m) t = fma(-L[tri(rr, m)], W[m][c], t);
+              W[rr][c] = t * Linv[rr];
+            }
+#pragma unroll
+          for (int rr = 0; rr < kNB; ++rr) {
+#pragma unroll
+            for (int c = 0; c <= rr; ++c) {
+              double t = tabr[26 + tri(rr, c)] * p2[rr + c + 2];
+#pragma unroll
+              for (int m = 0; m < kNB; ++m) t = fma(-W[m][rr], W[m][c], t);
+              Sm[tri(rr, c)] = t;
+            }
+            const double cF = tabr[40 + rr] * p2[rr + 1];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+              double t = -(cF * dq[q]);
+#pragma unroll
+              for (int m = 0; m < kNB; ++m) t = fma(-W[m][rr], z[m][q], t);
+              y[rr][q] = t;
+            }
+          }
+        }
+      }
+      Jk = 0.5 * (qf - red);
+      qfk = qf;
+    }
+    if (MASKED && active && k <= S && (k == 0 || S > 1)) {
       Elim<4> st;
       st.init();
-      // (the brackets as a 36-double array per step: forming them where they are consumed instead brings the kernel from
-      // 256 VGPRs + 41 spilled to 204 without spills and makes it 5 % slower -- measured, 65536 x 10: 848 vs 896 us)
       for (int i = 0; i < S; ++i) {
         double p2[9];
         segment_powers(perturbed_time(pt, i, k, corr), d, p2);
@@ -1116,11 +1229,11 @@ __device__ __forceinline__ double evaluate_lean(const double* tabs, const double
           fast.w[q][8] = tab[44] * dq * dq;
         }
         if (i == 0) {
-          if (MASKED && m_first != 0u) fast.template masked_t<false>(st, tab, p2, m_first, 0xFu);
+          if (m_first != 0u) fast.template masked_t<false>(st, tab, p2, m_first, 0xFu);
           else fast.template start_t<false>(st, tab, p2);
         } else if (i < S - 1) {
           fast.template interior_t<false>(st, tab, p2);
-        } else if (MASKED && m_last != 0u) {
+        } else if (m_last != 0u) {
           fast.template masked_t<false>(st, tab, p2, 0xFu, m_last);
           double L[10], z[kNB][4];
           st.factor_vertex(m_last, L, z);
@@ -1148,7 +1261,7 @@ __host__ __device__ constexpr int lean_group_doubles(int Sb) {
 // end_masks: the two end vertices may leave slots free (rest-to-rest paths under an objective order below snap: jerk and /
 // or snap stay free there); their free masks are left at ev[4 Sb] and ev[4 Sb + 1] for evaluate_lean<true>
 __device__ __forceinline__ bool stage_ps(const uint8_t* __restrict__ mask, const double* __restrict__ vals, int v0, int S,
-                                         int Sb, double* ev, int g, int G, bool active, int min_segments,
+                                         int Sb, double* ev, int g, int G, bool active, int min_segments, int d,
                                          bool end_masks = false) {
   double* dp = ev;
   double* tmp = ev + 4 * (size_t)Sb;  // the record area, not in use yet
@@ -1182,6 +1295,15 @@ __device__ __forceinline__ bool stage_ps(const uint8_t* __restrict__ mask, const
   if (end_masks && active) {
     if (g == 0) tmp[0] = (double)fb_first;
     if (g == (S & (G - 1))) tmp[1] = (double)fb_last;  // the lane that loaded vertex S
+  }
+  if (active) {  // f^T HBAR f of every segment (position terms only: all a plain path has), behind the two mask slots
+    const double h00 = c_hbar[d][0][0];
+    for (int i = g; i < S; i += G) {
+      double n2 = 0.0;
+#pragma unroll
+      for (int q = 0; q < kD; ++q) n2 = fma(dp[i * 4 + q], dp[i * 4 + q], n2);
+      tmp[2 + i] = h00 * n2;
+    }
   }
   ps_wave_sync();
   return all_ok;
@@ -1265,7 +1387,7 @@ __device__ __forceinline__ void optimize_body(const BatchView& b, const Nonlinea
   double* vtx = tick_f + kTickState;  // [(Sb + 1) * kVtxLds]
   double* seg = vtx + (size_t)(Sb + 1) * kVtxLds + (kExtras ? kStartExtra : 0);  // [Sb * kSegLds], the moving-start extras in front
   if (LEAN) {  // vtx = the evaluation area: dp of every segment; the path's eligibility decides who runs it
-    const bool takes = stage_ps(mask, vals, pr.v0, S, Sb, vtx, g, G, active, 2, MASKED4);
+    const bool takes = stage_ps(mask, vals, pr.v0, S, Sb, vtx, g, G, active, 2, d, MASKED4);
     if (active && g == 0) fallback[q] = takes ? 0 : 1;
     active = active && takes;
   } else {
@@ -1296,7 +1418,10 @@ __device__ __forceinline__ void optimize_body(const BatchView& b, const Nonlinea
   const int maxeval = prm.max_iterations;
   // nlopt maxtime (src/mrs_trajectory_generation.cpp:899): the constant-rate wall clock of the device, read once per
   // evaluation; a path that is still running when it passes stops with MAXTIME_REACHED (6) at its last evaluated point
-  const long long t_deadline = prm.time_budget_ticks > 0 ? (long long)wall_clock64() + prm.time_budget_ticks : 0ll;
+  // ONE deadline per call, written to a device word by a one-thread kernel in front of the outer-loop launches: a workgroup
+  // that starts late (batches of several residency rounds, the general kernel behind the lean one, the careful re-run) is
+  // measured against the call's clock, not its own
+  const long long t_deadline = prm.deadline ? *prm.deadline : 0ll;
   bool timed_out = false;
   // nlopt checks the evaluation count first, then the clock (nlopt_stop_evals, nlopt_stop_time)
   auto budget_spent = [&](int n) { return (maxeval > 0 && n >= maxeval) || timed_out; };
@@ -1736,9 +1861,13 @@ __device__ __forceinline__ void optimize_body(const BatchView& b, const Nonlinea
       }
       listed = __shfl(ok, (int)(threadIdx.x & ~(unsigned)(G - 1)), 64) != 0;
     }
+    // the path's offsets are looked up again rather than carried (as addresses, in registers or scratch) through the ticks
+    int q_again = q;
+    asm volatile("" : "+v"(q_again));
+    const PathRef pe = path_at(b, q_again);
     if (!listed)
-      for (int i = g; i < S; i += G) seg_times[pr.s0 + i] = x[i];
-    if (g == 0) opt_status[pr.p] = bad ? -2 : ret;
+      for (int i = g; i < S; i += G) seg_times[pe.s0 + i] = x[i];
+    if (g == 0) opt_status[pe.p] = bad ? -2 : ret;
   }
 }
 
@@ -1760,6 +1889,10 @@ __global__ __launch_bounds__(64) void optimize_compact_kernel(BatchView b, Nonli
   optimize_body<1, MASKED4>(b, prm, bins, mask, vals, seg_times, opt_status);
 }
 
+__global__ void set_deadline_kernel(long long* __restrict__ deadline, long long budget_ticks) {
+  *deadline = (long long)wall_clock64() + budget_ticks;
+}
+
 // closes a call's list of guarded paths: [2] = their number (for mrs_tg_plan_careful_count), [0] = 0 for the next call
 __global__ void careful_close_kernel(int32_t* __restrict__ careful) {
   careful[2] = careful[0];
@@ -1768,7 +1901,7 @@ __global__ void careful_close_kernel(int32_t* __restrict__ careful) {
 
 // every bin in one launch, as the sweeping kernels; optimize_body's own bookkeeping (one vector element per lane in
 // registers where the group is as wide as the path is long)
-__global__ __launch_bounds__(64, 2) void optimize_lean_kernel(BatchView b, NonlinearParams prm, BinTable bins,
+__global__ __launch_bounds__(64, MRS_TG_LEAN_WAVES) void optimize_lean_kernel(BatchView b, NonlinearParams prm, BinTable bins,
                                                               const uint8_t* __restrict__ mask, const double* __restrict__ vals,
                                                               double* __restrict__ seg_times, int32_t* __restrict__ opt_status,
                                                               int32_t* __restrict__ fallback) {
@@ -2397,6 +2530,13 @@ hipError_t launch_nonlinear(NonlinearPlan& nl, const BatchView& b, const Nonline
   // 1. outer loop: every bin in one launch
   NonlinearParams prm = prm_in;
   prm.sum_t0 = nl.d_sum_t0;
+  prm.deadline = nullptr;
+  if (prm_in.time_budget_ticks > 0) {
+    if (!nl.d_dfo_deadline && (e = mrs_tg::pool_alloc(&nl.d_dfo_deadline, sizeof(long long))) != hipSuccess) return e;
+    hipLaunchKernelGGL(set_deadline_kernel, dim3(1), dim3(1), 0, stream, nl.d_dfo_deadline, prm_in.time_budget_ticks);
+    if ((e = hipGetLastError()) != hipSuccess) return e;
+    prm.deadline = nl.d_dfo_deadline;
+  }
   const bool careful = prm_in.careful_cap != 0;  // the caller asked for the careful re-run (MRS_TG_FLAG_CAREFUL_COST)
   int careful_cap = 0;
   if (careful) {
@@ -2420,6 +2560,10 @@ hipError_t launch_nonlinear(NonlinearPlan& nl, const BatchView& b, const Nonline
     prm.careful_list = nullptr;
     prm.careful_cap = 0;
   }
+  // per-dispatch timing (kernel family 2): one pair of events spans ALL outer-loop launches of the call -- the start event
+  // rides on the first, the stop event on the last (the lean kernel, the general kernel for the paths it flagged, the
+  // careful re-run)
+  const KernelTimer kt = take_kernel_timer();
   // 1a. the lean kernel takes every plain path and flags the others for the sweeping kernel below
   bool lean = lean_applies(nl) && (int)nl.bins.size() <= 5;
   auto plain_lds = [&](const NonlinearBin& bin) {
@@ -2450,11 +2594,11 @@ hipError_t launch_nonlinear(NonlinearPlan& nl, const BatchView& b, const Nonline
                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)plds)) != hipSuccess)
       return e;
     if (lean_masked)
-      MRS_TG_LAUNCH_TIMED(optimize_lean_masked_kernel, dim3(blocks), dim3(64), plds, stream, b, prm, bt, mask, vals, seg_times,
-                          nl.d_opt_status, nl.d_fallback);
+      hipExtLaunchKernelGGL(optimize_lean_masked_kernel, dim3(blocks), dim3(64), plds, stream, kt.start, nullptr, 0, b, prm, bt, mask,
+                            vals, seg_times, nl.d_opt_status, nl.d_fallback);
     else
-      MRS_TG_LAUNCH_TIMED(optimize_lean_kernel, dim3(blocks), dim3(64), plds, stream, b, prm, bt, mask, vals, seg_times,
-                          nl.d_opt_status, nl.d_fallback);
+      hipExtLaunchKernelGGL(optimize_lean_kernel, dim3(blocks), dim3(64), plds, stream, kt.start, nullptr, 0, b, prm, bt, mask, vals,
+                            seg_times, nl.d_opt_status, nl.d_fallback);
     if ((e = hipGetLastError()) != hipSuccess) return e;
     prm.only_flagged = nl.d_fallback;
   }
@@ -2492,15 +2636,16 @@ hipError_t launch_nonlinear(NonlinearPlan& nl, const BatchView& b, const Nonline
       e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
       if (e != hipSuccess) return e;
     }
+    const hipEvent_t ev_start = lean ? nullptr : kt.start, ev_stop = careful ? nullptr : kt.stop;
     if (nl.dim_split == 4)
-      MRS_TG_LAUNCH_TIMED(optimize_split_kernel, dim3(blocks), dim3(threads), lds_bytes, stream, b, prm, bt, mask, vals,
-                          seg_times, nl.d_opt_status);
+      hipExtLaunchKernelGGL(optimize_split_kernel, dim3(blocks), dim3(threads), lds_bytes, stream, ev_start, ev_stop, 0, b, prm, bt,
+                            mask, vals, seg_times, nl.d_opt_status);
     else if (masked4)
-      MRS_TG_LAUNCH_TIMED(optimize_compact_kernel<true>, dim3(blocks), dim3(64), lds_bytes, stream, b, prm, bt, mask, vals,
-                          seg_times, nl.d_opt_status);
+      hipExtLaunchKernelGGL(optimize_compact_kernel<true>, dim3(blocks), dim3(64), lds_bytes, stream, ev_start, ev_stop, 0, b, prm,
+                            bt, mask, vals, seg_times, nl.d_opt_status);
     else
-      MRS_TG_LAUNCH_TIMED(optimize_compact_kernel<false>, dim3(blocks), dim3(64), lds_bytes, stream, b, prm, bt, mask, vals,
-                          seg_times, nl.d_opt_status);
+      hipExtLaunchKernelGGL(optimize_compact_kernel<false>, dim3(blocks), dim3(64), lds_bytes, stream, ev_start, ev_stop, 0, b, prm,
+                            bt, mask, vals, seg_times, nl.d_opt_status);
     if ((e = hipGetLastError()) != hipSuccess) return e;
     if (careful) {
       const size_t clds = ((size_t)group_lds_doubles(b.max_segments, true) + kBlockConsts) * sizeof(double);
@@ -2508,8 +2653,8 @@ hipError_t launch_nonlinear(NonlinearPlan& nl, const BatchView& b, const Nonline
       if (clds > 64 * 1024 &&
           (e = hipFuncSetAttribute((const void*)optimize_careful_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)clds)) != hipSuccess)
         return e;
-      hipLaunchKernelGGL(optimize_careful_kernel, dim3(careful_cap), dim3(64), clds, stream, b, prm, mask, vals, seg_times,
-                         nl.d_opt_status, nl.d_careful_ws);
+      hipExtLaunchKernelGGL(optimize_careful_kernel, dim3(careful_cap), dim3(64), clds, stream, nullptr, kt.stop, 0, b, prm, mask,
+                            vals, seg_times, nl.d_opt_status, nl.d_careful_ws);
       if ((e = hipGetLastError()) != hipSuccess) return e;
       hipLaunchKernelGGL(careful_close_kernel, dim3(1), dim3(1), 0, stream, nl.d_careful);
       if ((e = hipGetLastError()) != hipSuccess) return e;
@@ -2554,6 +2699,7 @@ hipError_t launch_nonlinear(NonlinearPlan& nl, const BatchView& b, const Nonline
 hipError_t launch_dfo(NonlinearPlan& nl, const BatchView& b, const DfoParams& prm, const uint8_t* mask, const double* vals,
                       const double* limits, double* seg_times, double* coeffs, int32_t* status, double* cost,
                       hipStream_t stream) {
+  const KernelTimer kt = take_kernel_timer();  // family 2: the whole search, dfo_init_kernel to dfo_finalize_kernel
   if (b.n_paths == 0) return hipSuccess;
   hipError_t e = ensure_buffers(nl, b);
   if (e != hipSuccess) return e;
@@ -2580,8 +2726,8 @@ hipError_t launch_dfo(NonlinearPlan& nl, const BatchView& b, const DfoParams& pr
   if ((e = launch_solve_linear(b, prm.derivative, true, mask, vals, seg_times, nullptr, nullptr, nl.d_ws, coeffs, status,
                                cost, nullptr, stream)) != hipSuccess)
     return e;
-  hipLaunchKernelGGL(dfo_init_kernel, dim3(pblocks), dim3(64), 0, stream, b, prm, mask, limits, seg_times, coeffs,
-                     nl.d_dfo_vec, nl.d_dfo_f, nl.d_dfo_state, nl.d_dfo_fidx, nl.d_dfo_deadline);
+  hipExtLaunchKernelGGL(dfo_init_kernel, dim3(pblocks), dim3(64), 0, stream, kt.start, nullptr, 0, b, prm, mask, limits, seg_times,
+                        coeffs, nl.d_dfo_vec, nl.d_dfo_f, nl.d_dfo_state, nl.d_dfo_fidx, nl.d_dfo_deadline);
   if ((e = hipGetLastError()) != hipSuccess) return e;
   // NLopt's maxeval <= 0 means "no limit"; the host loop needs one
   const int rounds = prm.max_iterations > 0 ? prm.max_iterations : 1000;
@@ -2609,7 +2755,8 @@ hipError_t launch_dfo(NonlinearPlan& nl, const BatchView& b, const DfoParams& pr
     hipLaunchKernelGGL(dfo_sum_cost_kernel, dim3(pblocks), dim3(64), 0, stream, b, nl.d_dfo_segcost, cost);
     if ((e = hipGetLastError()) != hipSuccess) return e;
   }
-  hipLaunchKernelGGL(dfo_finalize_kernel, dim3(pblocks), dim3(64), 0, stream, b.n_paths, nl.d_dfo_state, status);
+  hipExtLaunchKernelGGL(dfo_finalize_kernel, dim3(pblocks), dim3(64), 0, stream, nullptr, kt.stop, 0, b.n_paths, nl.d_dfo_state,
+                        status);
   return hipGetLastError();
 }
 

@@ -20,6 +20,7 @@
 #ifndef MRS_TG_ORACLE_H_
 #define MRS_TG_ORACLE_H_
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -222,4 +223,13 @@ int mto_optimize_path(const double* wps_in, const uint8_t* stop_in, int n_in, co
 #ifdef __cplusplus
 }
 #endif
+/* per-thread scratch memory for temporaries (mto_scratch.c): mark, allocate (64-byte aligned; zero != 0 clears), release */
+typedef struct {
+  int block;
+  size_t top;
+} mto_scratch_state;
+mto_scratch_state mto_scratch_mark(void);
+void mto_scratch_release(mto_scratch_state s);
+void* mto_scratch_alloc(size_t bytes, int zero);
+
 #endif

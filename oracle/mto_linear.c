@@ -144,14 +144,15 @@ void mto_segment_hessian(int derivative, double T, double* Hout, double* Ainv_ou
 
 /* dense Householder QR solve of M x = B (M n x n, B n x nrhs, both overwritten; X returned in B) */
 static int qr_solve(double* M, int n, double* B, int nrhs) {
-  double* v = (double*)malloc(sizeof(double) * (size_t)n);
+  const mto_scratch_state mark = mto_scratch_mark();
+  double* v = (double*)mto_scratch_alloc(sizeof(double) * (size_t)n, 0);
   if (!v) return -1;
   for (int c = 0; c < n; ++c) {
     double norm = 0.0;
     for (int r = c; r < n; ++r) norm += M[r * n + c] * M[r * n + c];
     norm = sqrt(norm);
     if (norm == 0.0) {
-      free(v);
+      mto_scratch_release(mark);
       return -2;
     }
     const double alpha = (M[c * n + c] > 0) ? -norm : norm;
@@ -180,7 +181,7 @@ static int qr_solve(double* M, int n, double* B, int nrhs) {
       for (int k = r + 1; k < n; ++k) s -= M[r * n + k] * B[k * nrhs + j];
       B[r * nrhs + j] = s / M[r * n + r];
     }
-  free(v);
+  mto_scratch_release(mark);
   return 0;
 }
 
@@ -201,7 +202,9 @@ int mto_coeffs_from_free_constraints(const mto_path* path, const double* seg_tim
   const int S = path->n_seg, V = S + 1;
   if (S < 1 || S > MTO_MAX_SEG) return -1;
   const int n_all = HALF * V, n_free = mto_count_free_constraints(path);
-  int* fidx = (int*)malloc(sizeof(int) * (size_t)n_all);
+  const mto_scratch_state mark = mto_scratch_mark();
+  int* fidx = (int*)mto_scratch_alloc(sizeof(int) * (size_t)n_all, 0);
+  if (!fidx) return -1;
   for (int i = 0, cp = 0; i < n_all; ++i) fidx[i] = path->fixed_mask[i] ? -1 : cp++;
   for (int i = 0; i < S; ++i) {
     double A[N * N], Ai[N * N];
@@ -221,7 +224,7 @@ int mto_coeffs_from_free_constraints(const mto_path* path, const double* seg_tim
       }
     }
   }
-  free(fidx);
+  mto_scratch_release(mark);
   return 0;
 }
 
@@ -232,7 +235,8 @@ int mto_solve_linear_free(const mto_path* path, const double* seg_times, double*
   const int n_all = HALF * V;
   /* column index of each (vertex, slot): fixed ones first, then free, each sorted by
    * (vertex, derivative) like the std::set<Constraint> walk at linear_impl.h:191-254 */
-  int* col = (int*)malloc(sizeof(int) * (size_t)n_all);
+  const mto_scratch_state mark = mto_scratch_mark();
+  int* col = (int*)mto_scratch_alloc(sizeof(int) * (size_t)n_all, 0);
   int n_fixed = 0, n_free = 0;
   for (int i = 0; i < n_all; ++i) n_fixed += path->fixed_mask[i] ? 1 : 0;
   n_free = n_all - n_fixed;
@@ -241,8 +245,13 @@ int mto_solve_linear_free(const mto_path* path, const double* seg_times, double*
     for (int i = 0; i < n_all; ++i) col[i] = path->fixed_mask[i] ? cf++ : cp++;
   }
   /* R = C^T blkdiag(H_i) C: row (10 i + r) of C selects unknown (vertex i + r/5, slot r%5) */
-  double* R = (double*)calloc((size_t)n_all * (size_t)n_all, sizeof(double));
-  double* Ainv = (double*)malloc(sizeof(double) * (size_t)S * N * N);
+  double* R = (double*)mto_scratch_alloc(sizeof(double) * (size_t)n_all * (size_t)n_all, 1);
+  double* Ainv = (double*)mto_scratch_alloc(sizeof(double) * (size_t)S * N * N, 0);
+  double* dall = (double*)mto_scratch_alloc(sizeof(double) * (size_t)n_all * DIM, 1);
+  if (!col || !R || !Ainv || !dall) {
+    mto_scratch_release(mark);
+    return -1;
+  }
   double Hm[N * N];
   for (int i = 0; i < S; ++i) {
     mto_segment_hessian(d, seg_times[i], Hm, Ainv + (size_t)i * N * N);
@@ -255,14 +264,17 @@ int mto_solve_linear_free(const mto_path* path, const double* seg_times, double*
     }
   }
   /* d_f per dimension, then d_p = -Rpp^-1 Rpf d_f  (linear_impl.h:360-369) */
-  double* dall = (double*)calloc((size_t)n_all * DIM, sizeof(double));
   for (int i = 0; i < n_all; ++i)
     if (path->fixed_mask[i])
       for (int k = 0; k < DIM; ++k) dall[(size_t)col[i] * DIM + k] = path->fixed_values[(size_t)i * DIM + k];
   int rc = 0;
   if (n_free > 0) {
-    double* Rpp = (double*)malloc(sizeof(double) * (size_t)n_free * (size_t)n_free);
-    double* rhs = (double*)malloc(sizeof(double) * (size_t)n_free * DIM);
+    double* Rpp = (double*)mto_scratch_alloc(sizeof(double) * (size_t)n_free * (size_t)n_free, 0);
+    double* rhs = (double*)mto_scratch_alloc(sizeof(double) * (size_t)n_free * DIM, 0);
+    if (!Rpp || !rhs) {
+      mto_scratch_release(mark);
+      return -1;
+    }
     for (int r = 0; r < n_free; ++r) {
       for (int c = 0; c < n_free; ++c) Rpp[(size_t)r * n_free + c] = R[(size_t)(n_fixed + r) * n_all + n_fixed + c];
       for (int k = 0; k < DIM; ++k) {
@@ -277,8 +289,6 @@ int mto_solve_linear_free(const mto_path* path, const double* seg_times, double*
         dall[(size_t)(n_fixed + r) * DIM + k] = rhs[(size_t)r * DIM + k];
         if (free_out) free_out[(size_t)k * n_free + r] = rhs[(size_t)r * DIM + k];
       }
-    free(Rpp);
-    free(rhs);
   }
   /* coefficients: c = A_i^-1 (C_i d)   linear_impl.h:264-282 */
   for (int i = 0; i < S; ++i)
@@ -292,10 +302,7 @@ int mto_solve_linear_free(const mto_path* path, const double* seg_times, double*
         c[r] = s;
       }
     }
-  free(col);
-  free(R);
-  free(Ainv);
-  free(dall);
+  mto_scratch_release(mark);
   return rc;
 }
 

@@ -39,14 +39,15 @@ static const double kTimeLowerBound = 0.01; /* kOptimizationTimeLowerBound, nonl
 
 double mto_cost_and_gradient_mellinger(const mto_path* path, const double* seg_times, double* grad) {
   const int S = path->n_seg, d = path->derivative_to_optimize;
-  double* coeffs = (double*)malloc(sizeof(double) * (size_t)S * DIM * N);
+  const mto_scratch_state mark = mto_scratch_mark();
+  double* coeffs = (double*)mto_scratch_alloc(sizeof(double) * (size_t)S * DIM * N, 0);
   double bigger[MTO_MAX_SEG];
   /* objectiveFunctionTimeMellingerOuterLoop: updateSegmentTimes + solveLinear (nonlinear_impl.h:626-627) */
   mto_solve_linear(path, seg_times, coeffs);
   const double J_d = mto_compute_cost(S, d, seg_times, coeffs);
   if (S == 1) { /* nonlinear_impl.h:264-271 */
     if (grad) grad[0] = 0.0;
-    free(coeffs);
+    mto_scratch_release(mark);
     return J_d;
   }
   if (grad) {
@@ -66,7 +67,7 @@ double mto_cost_and_gradient_mellinger(const mto_path* path, const double* seg_t
     /* the reference restores and re-solves here (nonlinear_impl.h:327-328); the result equals the
      * first solve, nothing observable depends on it, so the oracle does not repeat it */
   }
-  free(coeffs);
+  mto_scratch_release(mark);
   return J_d;
 }
 

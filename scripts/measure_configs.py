@@ -58,7 +58,8 @@ def main():
     if len(sys.argv) > 2:   # one config only, few repetitions: the command to put under rocprofv3
         which = sys.argv[2]
         batch = {"config3": lambda: pr.random_batch(1024, 10, seed0=0), "config4": lambda: pr.random_batch(8192, 10, seed0=0),
-                 "config5": lambda: pr.random_batch(8192, "ragged", seed0=0)}[which]()
+                 "config5": lambda: pr.random_batch(8192, "ragged", seed0=0),
+                 "config6": lambda: pr.random_batch(65536, 10, seed0=0)}[which]()
         print(which, measure(ctx, batch, True, 10))
         return
     out = {}

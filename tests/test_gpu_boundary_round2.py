@@ -1,6 +1,7 @@
 """Boundary features added for ABI 2, through the C ABI on the GPU: several devices, the nlopt-style time budget
 (MAXTIME_REACHED), the cached plan of the one-call interface, per-dispatch kernel timing, and the policy layer's handling
 of one unsolvable request next to healthy ones."""
+import ctypes as C
 import time
 
 import numpy as np
@@ -93,11 +94,14 @@ def test_policy_falls_back_to_the_sampler_when_out_of_time(gpu_ctx):
 def test_policy_gives_up_when_the_solve_comes_back_late(gpu_ctx):
     """findTrajectory's checks behind the solve (:1085, :1156, :1171): a budget that is still open when the round starts but
     spent when the solve returns ends the request as "failed to find trajectory" (the next attempt then falls back)."""
-    paths = [pr.random_walk_waypoints(30, 170 + i) for i in range(512)]
-    # overtime() holds from 0.95 * max - 0.01 s on: 0.0158 s leaves the round 5 ms to start in (the preprocessing of 512 short
-    # lists takes a fraction of that) and a 512 x 30-segment solve with 33 MB of samples coming back does not fit into it
-    late = api.optimize_paths(gpu_ctx, paths, policy=api.default_policy_options(max_execution_time_s=0.0158), sample_capacity=2048)
+    paths = [pr.random_walk_waypoints(30, 170 + i) for i in range(32)]
+    # overtime() holds from 0.95 * max - 0.01 s on: 0.01474 s leaves the round 4 ms to start in (the preprocessing of 32 short
+    # lists takes a fraction of a millisecond), and a round that has to set up and bring back 67 MB of sample buffers
+    # (capacity 65536 per path) takes several times that
+    late = api.optimize_paths(gpu_ctx, paths, policy=api.default_policy_options(max_execution_time_s=0.01474), sample_capacity=65536)
     assert late["success"].sum() == 0 and late["n_samples"].sum() == 0
+    roomy = api.optimize_paths(gpu_ctx, paths, policy=api.default_policy_options(max_execution_time_s=30.0), sample_capacity=65536)
+    assert roomy["success"].sum() >= 30
 
 
 def test_one_oversized_request_does_not_fail_the_batch(gpu_ctx):
@@ -256,3 +260,84 @@ def test_issue_loop_on_several_host_threads(gpu_ctx):
         pl.close()
     for c in ctxs:
         c.close()
+
+
+def test_pinned_pageable_and_mixed_host_buffers_give_identical_results(gpu_ctx):
+    """mrs_tg_solve_batch moves every array the way its location allows (pinned: DMA in place; small pageable: packed
+    through the context's staging block; large pageable: hipMemcpyAsync on the caller's pages).  Whatever the mix, the
+    results are the same bits -- small batch (everything staged), large batch (coefficients not staged), pinned arrays,
+    a registered pageable array, and outputs re-used across calls."""
+    L = api.load_library()
+    for P, n_seg in ((24, 6), (2048, 10)):
+        batch = pr.random_batch(P, n_seg, seed0=300)
+        kw = dict(time_alloc_method=api.TIME_ALLOC_MELLINGER, sampling_dt=0.2, sample_capacity=256)
+        ref = gpu_ctx.solve_batch(batch, None, **kw)
+        # all inputs and outputs pinned
+        pb = pr.Batch(batch.seg_offsets, api.pinned_copy(batch.waypoints), api.pinned_copy(batch.fixed_mask),
+                      api.pinned_copy(batch.fixed_values), api.pinned_copy(batch.limits), batch.derivative_to_optimize)
+        out = dict(times=api.pinned_empty(batch.n_segments), coeffs=api.pinned_empty(ref["coeffs"].shape),
+                   status=api.pinned_empty(P, np.int32), cost=api.pinned_empty(P), n_samples=api.pinned_empty(P, np.int32),
+                   samples=api.pinned_empty(ref["samples"].shape))
+        for k in out:
+            out[k][...] = 0
+        for rep in range(2):     # the second call re-uses the arenas and the cached plan
+            got = gpu_ctx.solve_batch(pb, None, out=out, **kw)
+            for k in ("times", "coeffs", "status", "cost", "n_samples"):
+                assert np.array_equal(got[k], ref[k]), (P, k, rep)
+            n = np.minimum(ref["n_samples"], 256)
+            assert all(np.array_equal(got["samples"][p, :n[p]], ref["samples"][p, :n[p]]) for p in range(0, P, max(1, P // 64)))
+        # mixed: pinned values, pageable everything else; and a pageable coefficient array pinned in place by registration
+        mixed = pr.Batch(batch.seg_offsets, batch.waypoints, batch.fixed_mask, pb.fixed_values, batch.limits, batch.derivative_to_optimize)
+        keep = gpu_ctx.solve_batch(mixed, None, **kw)
+        assert np.array_equal(keep["coeffs"], ref["coeffs"]) and np.array_equal(keep["times"], ref["times"])
+        assert L.mrs_tg_host_register(keep["coeffs"].ctypes.data, keep["coeffs"].nbytes) == 0
+        keep["coeffs"][...] = 0
+        again = gpu_ctx.solve_batch(mixed, None, out=keep, **kw)
+        assert L.mrs_tg_host_unregister(keep["coeffs"].ctypes.data) == 0
+        assert np.array_equal(again["coeffs"], ref["coeffs"]) and np.array_equal(again["status"], ref["status"])
+    assert L.mrs_tg_host_register(None, 0) != 0 and b"nothing to register" in L.mrs_tg_last_error(None)
+
+
+def test_two_bound_solves_of_one_context_are_issued_by_one_thread(gpu_ctx):
+    """The multi-threaded issue loop partitions by CONTEXT: two bound solves that share a plan (and its workspaces) must not
+    be driven by two threads at once -- with one context there is nothing to spread, and the results are those of the
+    single-threaded loop; a NULL entry is refused with a message."""
+    batch = pr.random_batch(300, 9, seed0=5)
+    plan = api.Plan(gpu_ctx, batch.seg_offsets)
+    dbs = [api.DeviceBatch(batch, "cuda:0", sample_capacity=64) for _ in range(2)]
+    nl = api.default_options(time_alloc_method=api.TIME_ALLOC_MELLINGER, estimate_times=1)
+    calls = [plan.bind_solve(nl, db.fixed_mask, db.fixed_values, db.seg_times, db.coeffs, db.status, db.cost, waypoints=db.waypoints,
+                             limits=db.limits) for db in dbs]
+    ref = gpu_ctx.solve_batch(batch, None, time_alloc_method=api.TIME_ALLOC_MELLINGER)
+    for threads in (1, 2, 4):
+        for db in dbs:
+            db.coeffs.zero_()
+        api.RoundRobin(calls, threads=threads)(6)
+        torch.cuda.synchronize()
+        for db in dbs:
+            assert np.array_equal(db.coeffs.cpu().numpy().reshape(ref["coeffs"].shape), ref["coeffs"]), threads
+            assert np.array_equal(db.status.cpu().numpy(), ref["status"])
+    L = api.load_library()
+    arr = (C.c_void_p * 2)(calls[0].handle, None)
+    assert L.mrs_tg_bound_solve_launch_many_mt(arr, 2, 4, 2) == -1 and b"bound solve 1 is NULL" in L.mrs_tg_last_error(None)
+    assert L.mrs_tg_bound_solve_launch_many(arr, 2, 4) == -1
+    plan.close()
+
+
+def test_outer_loop_timing_spans_every_outer_loop_launch_and_the_gradient_free_modes(gpu_ctx):
+    """Kernel family 2 under profiling: one pair of events from the first outer-loop launch of a call to the last (lean kernel
+    + the general kernel for the paths it flags), and the gradient-free searches report a time again."""
+    mixed = pr.random_mixed_batch(4096, seed0=9)          # > 2560 paths: lean kernel first, general kernel for stop_at / moving starts
+    plain = pr.random_batch(4096, 10, seed0=9)
+    gpu_ctx.set_profiling(True)
+    try:
+        gpu_ctx.solve_batch(plain, None, time_alloc_method=api.TIME_ALLOC_MELLINGER)
+        ms_plain = gpu_ctx.last_kernel_ms(api.KERNEL_NONLINEAR)
+        gpu_ctx.solve_batch(mixed, None, time_alloc_method=api.TIME_ALLOC_MELLINGER)
+        ms_mixed = gpu_ctx.last_kernel_ms(api.KERNEL_NONLINEAR)
+        small = pr.random_batch(64, 6, seed0=2)
+        gpu_ctx.solve_batch(small, None, time_alloc_method=api.TIME_ALLOC_RICHTER_TIME)
+        ms_dfo = gpu_ctx.last_kernel_ms(api.KERNEL_NONLINEAR)
+    finally:
+        gpu_ctx.set_profiling(False)
+    assert 0.02 < ms_plain < 5.0 and 0.02 < ms_mixed < 20.0 and 0.01 < ms_dfo < 20.0, (ms_plain, ms_mixed, ms_dfo)

@@ -16,7 +16,11 @@ Stated factors (measured in the build container, asserted with ~10 % slack):
     median own / scipy 0.99 (box paths) and 1.12 (random-walk paths);
   * with the reference's tolerances (ftol_rel 0.05, xtol_rel 0.1, src/mrs_trajectory_generation.cpp:884-885) it stops after
     3.6 / 5.5 evaluations on average and ends at a median 1.26 / 1.75 of scipy's 10-evaluation result, while still taking
-    the scale-invariant cost down to 0.39 / 0.17 of the Euclidean start.
+    the scale-invariant cost down to 0.39 / 0.17 of the Euclidean start;
+  * LIKE FOR LIKE (round 3): scipy's L-BFGS-B under the SAME stopping rule (NLopt's relstop with ftol_rel 0.05 / xtol_rel 0.1
+    on successive accepted iterates, 10 evaluations at most) stops after 3.7 / 5.6 evaluations -- the early stop belongs to the
+    reference's tolerances, not to the search -- and the own search ends at a median 0.87 (box) / 1.05 (random walk) of what
+    scipy reaches under that rule (p90 1.01 / 2.03): the gap of the previous item is the stopping rule's.
 """
 import json
 import os
@@ -77,6 +81,33 @@ def test_own_lbfgs_against_scipy_lbfgsb_on_the_oracle(quality, gen, tol):
     assert np.mean(own < st) >= helped, np.mean(own < st)
 
 
+# generator -> bounds on median and 90th percentile of own / scipy-under-the-same-stopping-rule (measured 0.865, 1.013 and
+# 1.054, 2.029), and on the mean number of evaluations either search spends (measured 3.63 vs 3.69 and 5.49 vs 5.55)
+SAME_RULE = {"box": (0.95, 1.10, 4.0), "walk": (1.15, 2.30, 6.0)}
+
+
+def _same_rule_reference(quality, gen):
+    s = [x for x in quality["sets"] if x["generator"] == gen][0]
+    return (np.array([r["J_scipy_same_rule"] * r["sum_T_scipy_same_rule"] ** 7 for r in s["paths"]]),
+            np.mean([r["evaluations_same_rule"] for r in s["paths"]]))
+
+
+@pytest.mark.parametrize("gen", ["box", "walk"])
+def test_own_lbfgs_against_scipy_under_the_same_stopping_rule(quality, gen):
+    batch, _, _ = _reference(quality, gen)
+    sr, scipy_evals = _same_rule_reference(quality, gen)
+    own, evals = np.zeros(batch.n_paths), []
+    for p in range(batch.n_paths):
+        wp, m, v = batch.path(p)
+        _, t, ne, _ = po.optimize_times(4, m, v, po.estimate_times(wp, batch.limits[p]), po.default_nlopt())
+        own[p] = _normalised(po.cost_and_gradient(4, m, v, t)[0], t)
+        evals.append(ne)
+    med, p90, ev = SAME_RULE[gen]
+    r = own / sr
+    assert np.median(r) <= med and np.percentile(r, 90) <= p90, (np.median(r), np.percentile(r, 90))
+    assert np.mean(evals) <= ev and scipy_evals <= ev       # both stop early: the rule, not the search
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("gen", ["box", "walk"])
 def test_gpu_outer_loop_against_scipy_lbfgsb(gpu_ctx, quality, gen):
@@ -94,3 +125,6 @@ def test_gpu_outer_loop_against_scipy_lbfgsb(gpu_ctx, quality, gen):
     r = own / sc
     assert np.median(r) <= med and np.percentile(r, 90) <= p90, (np.median(r), np.percentile(r, 90))
     assert np.median(own / st) <= start and np.mean(own < st) >= helped
+    sr, _ = _same_rule_reference(quality, gen)
+    med, p90, _ = SAME_RULE[gen]
+    assert np.median(own / sr) <= med and np.percentile(own / sr, 90) <= p90, (np.median(own / sr), np.percentile(own / sr, 90))
