@@ -75,9 +75,19 @@ def parse_args(argv=None):
     ap.add_argument("--issue-threads", type=int, default=1,
                     help="host threads of the library's issue loop (mrs_tg_bound_solve_launch_many_mt): one runtime launch "
                          "costs the host more than four concurrent kernels take to retire one")
-    ap.add_argument("--in-flight", type=int, default=4,
-                    help="independent batches in flight per GPU: steps are issued round-robin on this many HIP streams "
-                         "(one context + plan each); 1 = every step waits for the previous one")
+    ap.add_argument("--in-flight", type=int, default=10,
+                    help="independent batches (sets of input / output arrays) in flight per GPU; 1 = every step waits for the "
+                         "previous one.  --issue grouped: --group-size of them per dispatch; --issue streams and the "
+                         "nonlinear workload: one per HIP stream, at most --streams of them")
+    ap.add_argument("--streams", type=int, default=4,
+                    help="HIP streams (one context + plan each) per GPU: the hardware queues the runtime gives a process")
+    ap.add_argument("--issue", choices=["grouped", "streams"], default="grouped",
+                    help="how the K linear steps are issued: 'grouped' packs the steps of a round (one per batch in flight) into "
+                         "ONE dispatch on one stream (mrs_tg_bound_solve_launch_group); 'streams' issues one dispatch per step, "
+                         "round-robin over --in-flight HIP streams (the round-2 method, reported as extras.streams_in_flight)")
+    ap.add_argument("--group-size", type=int, default=5,
+                    help="--issue grouped: batches per dispatch; the --in-flight batches are spread over in-flight / group-size "
+                         "streams, each stream's dispatches carry group-size steps")
     ap.add_argument("--config3-paths", type=int, default=CONFIG3_PATHS, help="size of the fixed batch of extras.config3")
     return ap.parse_args(argv)
 
@@ -302,7 +312,9 @@ def main():
     # Output double buffer: results of step k are gathered to rank 0 on a side stream while step k+1 computes
     # (the gather is the job's only collective; RCCL over xGMI).  Coefficients, times and status share one
     # f64 buffer per slot so that the gather is a single collective.
-    n_lanes = max(1, args.in_flight)   # batches in flight: lane 0 = torch's current stream (ctx, plan), lanes 1.. = side streams
+    # lanes = HIP streams (lane 0 = torch's current stream with ctx / plan, lanes 1.. = side streams with their own); slots =
+    # sets of output arrays.  Stream-issued steps keep one batch in flight per lane; grouped steps --in-flight of them
+    n_lanes = max(1, min(args.in_flight, args.streams))
     lane_stream = [torch.cuda.current_stream()] + [torch.cuda.Stream(device=dev) for _ in range(n_lanes - 1)]
     lane_ctx, lane_plan = [ctx], [plan]
     for st in lane_stream[1:]:
@@ -311,7 +323,8 @@ def main():
             c.use_torch_stream()
             lane_ctx.append(c)
             lane_plan.append(api.Plan(c, batch.seg_offsets))
-    n_slots = max(n_lanes, 2 if dist is not None else 1)   # slot s runs on lane s % n_lanes
+    n_group_slots = max(1, args.in_flight)                                  # grouped issue: slot s on lane s // group size
+    n_slots = max(n_lanes, 2 if dist is not None else 1, n_group_slots)     # stream issue: slot s runs on lane s % n_lanes
     active_lanes = [n_lanes]                               # extras.one_batch_in_flight sets this to 1
     packed = [torch.zeros(nS * 41 + P, dtype=torch.float64, device=dev) for _ in range(n_slots)]
     out_coeffs = [p[:nS * 40].view(nS, 4, 10) for p in packed]
@@ -385,23 +398,33 @@ def main():
 
     round_robin = {}
 
+    grouped_mode = [args.issue == "grouped"]
+
     def make_linear_block(kind):
-        """n steps of a fixed-times workload through the library's own issue loop (mrs_tg_bound_solve_launch_many): step k
-        runs slot k % slots on lane slot % lanes.  Not for --gather every (a collective follows every step there)."""
+        """n steps of a fixed-times workload through the library's own issue loop: step k runs slot k % slots.  streams:
+        on lane slot % lanes, one dispatch per step (mrs_tg_bound_solve_launch_many).  grouped (the default solve only): all
+        slots are bound to lane 0's plan and the steps of a round -- one per batch in flight -- go out as ONE dispatch
+        (mrs_tg_bound_solve_launch_group).  Not for --gather every (a collective follows every step there)."""
         def block(n):
             lanes = active_lanes[0]
-            slots = max(lanes, 2 if dist is not None else 1)
+            grouped = grouped_mode[0] and kind == "linear" and lanes > 1 and n_group_slots > 1
+            slots = n_group_slots if grouped else max(lanes, 2 if dist is not None else 1)
             for slot in range(slots):       # a slot whose last result is still being gathered: its lane waits for that
                 if slot_free[slot] is not None:
-                    lane_stream[slot % lanes].wait_event(slot_free[slot])
+                    lane_stream[min(slot // max(1, min(args.group_size, slots)), lanes - 1) if grouped else slot % lanes].wait_event(slot_free[slot])
                     slot_free[slot] = None
-            key = (kind, lanes, slots)
+            key = (kind, lanes, slots, grouped)
             if key not in round_robin:
-                round_robin[key] = api.RoundRobin([slot_call(kind, sl, sl % lanes) for sl in range(slots)],
-                                                  threads=min(args.issue_threads, slots))
+                if grouped:   # slot sl on lane sl // group size: consecutive slots of a lane go out as one dispatch
+                    gs = max(1, min(args.group_size, slots))
+                    round_robin[key] = api.RoundRobin([slot_call(kind, sl, min(sl // gs, lanes - 1)) for sl in range(slots)], grouped=True)
+                else:
+                    round_robin[key] = api.RoundRobin([slot_call(kind, sl, sl % lanes) for sl in range(slots)],
+                                                      threads=min(args.issue_threads, slots))
             round_robin[key](n)
             step_no[0] = n
-            last_slot[0] = ((n - 1) % slots, ((n - 1) % slots) % lanes)
+            last_slot[0] = ((n - 1) % slots, min(((n - 1) % slots) // max(1, min(args.group_size, slots)), lanes - 1) if grouped
+                            else ((n - 1) % slots) % lanes)
         return block
 
     def step_nonlinear():
@@ -650,6 +673,15 @@ def main():
                                                       ms_per_step=elb / args.steps * 1e3,
                                                       note="MRS_TG_FLAG_MATERIALIZED_BLOCKS: assemble_blocks kernel (16.5 MB to "
                                                            "HBM) + solve_tile_kernel reading the blocks back; %d in flight" % n_lanes)
+    if n_lanes > 1 and not args.no_extras and args.workload == "linear" and grouped_mode[0]:
+        # the same K steps issued one dispatch per step, round-robin over the streams (the headline's method up to round 2)
+        grouped_mode[0] = False
+        els, _ = time_steps(steps_fn["linear"], args.steps, 3, dist, torch, final_gather, block_fn=block_for("linear"))
+        grouped_mode[0] = True
+        if rank == 0:
+            extras["streams_in_flight"] = dict(value=P * world * args.steps / els, unit="trajectories/s", ms_per_step=els / args.steps * 1e3,
+                                               note="one dispatch per step on %d HIP streams (mrs_tg_bound_solve_launch_many), "
+                                                    "MRS_TG_FLAG_SHARED_DEVICE" % n_lanes)
     if n_lanes > 1 and not args.no_extras:
         # the same steps with one batch in flight: every step waits for the previous one (single stream)
         torch.cuda.synchronize()
@@ -836,17 +868,24 @@ def main():
                                             if "config3" in extras else None),
                     higher_is_better=True, scaling="weak", vs_baseline=None, dtype="f64", data="synthetic",
                     config=dict(workload=lin_desc if args.workload == "linear" else nl_desc,
-                                paths_per_gpu=P, segments=args.segments, batches_in_flight=n_lanes,
+                                paths_per_gpu=P, segments=args.segments,
+                                batches_in_flight=(n_group_slots if (grouped_mode[0] and args.workload == "linear" and n_lanes > 1) else n_lanes),
+                                hip_streams=n_lanes,
                                 linear_solve="default of mrs_tg_plan_solve: solve_rows_kernel, blocks formed in registers "
                                              "(nothing materialised); the assembly kernel is timed on its own (roofline) and "
                                              "inside extras.materialized_blocks_step",
                                 clock_ramp_steps=ramp_steps, clock_ramp_ms=30,
-                                step_issue=("mrs_tg_bound_solve_launch_many_mt: the K steps are issued round-robin over the "
-                                            "streams by the library's C loop on %d host thread(s)"
-                                            % min(args.issue_threads, n_lanes) if block_for(args.workload) is not None
-                                            else "one Python call per step"),
+                                step_issue=(("mrs_tg_bound_solve_launch_group: %d consecutive steps (each a full pass over its own batch, "
+                                             "with its own input / output arrays) go out as ONE dispatch; the dispatches alternate "
+                                             "over %d HIP stream(s)" % (max(1, min(args.group_size, n_group_slots)),
+                                                                       min(n_lanes, (n_group_slots + max(1, min(args.group_size, n_group_slots)) - 1)
+                                                                           // max(1, min(args.group_size, n_group_slots)))) if (grouped_mode[0] and args.workload == "linear" and n_lanes > 1)
+                                             else "mrs_tg_bound_solve_launch_many_mt: the K steps are issued round-robin over the "
+                                                  "streams by the library's C loop on %d host thread(s)" % min(args.issue_threads, n_lanes))
+                                            if block_for(args.workload) is not None else "one Python call per step"),
                                 launch_hint=("MRS_TG_FLAG_SHARED_DEVICE (several batches in flight: two paths per wavefront "
-                                             "so that four launches fit the SIMDs side by side)" if n_lanes > 1 else "none"),
+                                             "so that four launches fit the SIMDs side by side)"
+                                             if (n_lanes > 1 and not (grouped_mode[0] and args.workload == "linear")) else "none"),
                                 parallelism=("independent paths sharded per rank, no data-path collective; %s gather of "
                                              "the results to rank 0 %s"
                                              % ("gloo (host)" if gloo else "RCCL",

@@ -77,7 +77,7 @@ EXPORTED_SYMBOLS = [
     "mrs_tg_set_stream", "mrs_tg_reset_stream", "mrs_tg_synchronize", "mrs_tg_solve_batch", "mrs_tg_plan_create", "mrs_tg_plan_destroy",
     "mrs_tg_plan_n_paths", "mrs_tg_plan_n_segments", "mrs_tg_plan_max_segments", "mrs_tg_plan_get_order",
     "mrs_tg_plan_assemble", "mrs_tg_plan_block_bytes", "mrs_tg_plan_solve", "mrs_tg_plan_bind_solve",
-    "mrs_tg_bound_solve_launch", "mrs_tg_bound_solve_launch_many", "mrs_tg_bound_solve_launch_many_mt",
+    "mrs_tg_bound_solve_launch", "mrs_tg_bound_solve_launch_many", "mrs_tg_bound_solve_launch_many_mt", "mrs_tg_bound_solve_launch_group",
     "mrs_tg_bound_solve_destroy", "mrs_tg_host_alloc", "mrs_tg_host_free", "mrs_tg_host_register",
     "mrs_tg_host_unregister", "mrs_tg_plan_cost_gradient",
     "mrs_tg_plan_segment_maxima", "mrs_tg_plan_sample_states", "mrs_tg_plan_careful_count", "mrs_tg_set_profiling", "mrs_tg_last_kernel_ms", "mrs_tg_kernel_ms_history",
@@ -156,6 +156,8 @@ def load_library():
     L.mrs_tg_bound_solve_launch_many.argtypes = [C.POINTER(vp), C.c_int32, C.c_int32]
     L.mrs_tg_bound_solve_launch_many_mt.restype = C.c_int
     L.mrs_tg_bound_solve_launch_many_mt.argtypes = [C.POINTER(vp), C.c_int32, C.c_int32, C.c_int32]
+    L.mrs_tg_bound_solve_launch_group.restype = C.c_int
+    L.mrs_tg_bound_solve_launch_group.argtypes = [C.POINTER(vp), C.c_int32, C.c_int32]
     L.mrs_tg_bound_solve_destroy.restype = None
     L.mrs_tg_bound_solve_destroy.argtypes = [vp]
     L.mrs_tg_plan_cost_gradient.restype = C.c_int
@@ -609,17 +611,23 @@ class RoundRobin:
     """The issue loop of a host that keeps several batches in flight, in C (mrs_tg_bound_solve_launch_many): launch k goes to
     calls[k % len(calls)], each a callable returned by Plan.bind_solve (one per context + stream)."""
 
-    def __init__(self, calls, threads=1):
+    def __init__(self, calls, threads=1, grouped=False):
+        """grouped: mrs_tg_bound_solve_launch_group -- the launches of a round go out as ONE dispatch (bound solves of one
+        plan, fixed times, default solve)."""
         self._calls = list(calls)
         self._arr = (C.c_void_p * len(self._calls))(*[c.handle for c in self._calls])
         self._fn = load_library().mrs_tg_bound_solve_launch_many_mt
+        self._group = load_library().mrs_tg_bound_solve_launch_group if grouped else None
         self._threads = int(threads)
 
     def __call__(self, n_launches):
-        rc = self._fn(self._arr, len(self._calls), int(n_launches), self._threads)
+        if self._group is not None:
+            rc = self._group(self._arr, len(self._calls), int(n_launches))
+        else:
+            rc = self._fn(self._arr, len(self._calls), int(n_launches), self._threads)
         if rc:
             for c in self._calls:
-                c.ctx._check(rc, "mrs_tg_bound_solve_launch_many")
+                c.ctx._check(rc, "mrs_tg_bound_solve_launch_group" if self._group is not None else "mrs_tg_bound_solve_launch_many")
 
 
 class DeviceBatch:

@@ -728,6 +728,51 @@ int mrs_tg_bound_solve_launch_many(mrs_tg_bound_solve* const* bound, int32_t n_b
   return MRS_TG_OK;
 }
 
+// The issue loop with consecutive launches packed into one dispatch: launch k still solves bound[k % n_bound], but a run of
+// consecutive launches whose bound solves share a PLAN (one batch structure, one context and stream; the solves differ in
+// their input / output arrays) goes out as a single kernel whose workgroups are divided among the batches, on that plan's
+// stream.  bound = [A0, A1, B0, B1] with A*, B* on two plans therefore issues (A0 A1), (B0 B1), (A0 A1), ... alternately on
+// the two streams.  Fixed times, the default solve, no sampling.  Every path runs the single-batch kernel's instructions.
+int mrs_tg_bound_solve_launch_group(mrs_tg_bound_solve* const* bound, int32_t n_bound, int32_t n_launches) {
+  if (!bound || n_bound < 1 || n_launches < 0) return fail(nullptr, MRS_TG_ERR_INVALID_ARG, "bound solves are required");
+  for (int32_t i = 0; i < n_bound; ++i)
+    if (!bound[i]) return fail(nullptr, MRS_TG_ERR_INVALID_ARG, "bound solve %d is NULL", i);
+  for (int32_t i = 0; i < n_bound; ++i) {
+    const mrs_tg_bound_solve* b = bound[i];
+    mrs_tg_ctx* ctx = b->plan->ctx;
+    const mrs_tg_options& o = b->opt;
+    if (o.time_alloc_method != MRS_TG_TIME_ALLOC_NONE || o.estimate_times || o.sampling_dt > 0 ||
+        (o.flags & (MRS_TG_FLAG_MATERIALIZED_BLOCKS | MRS_TG_FLAG_GENERAL_PATTERNS)))
+      return fail(ctx, MRS_TG_ERR_UNSUPPORTED, "grouped launches are for the fixed-times default solve without sampling (solve %d differs)", i);
+    if (!b->mask || !b->vals || !b->seg_times || !b->coeffs || !b->status)
+      return fail(ctx, MRS_TG_ERR_INVALID_ARG, "fixed_mask, fixed_values, seg_times, coeffs_out and status_out are required (solve %d)", i);
+    if (!mrs_tg::rows_kernel_applies(b->plan->view, false))
+      return fail(ctx, MRS_TG_ERR_UNSUPPORTED, "grouped launches need a batch the one-lane-per-unknown solve takes (solve %d: paths too long)", i);
+  }
+  for (int32_t k = 0; k < n_launches;) {
+    const mrs_tg_bound_solve* first = bound[k % n_bound];
+    mrs_tg_plan* plan = first->plan;
+    mrs_tg_ctx* ctx = plan->ctx;
+    mrs_tg::RowsGroup g;
+    for (; g.n < mrs_tg::kRowsGroupMax && k < n_launches; ++k, ++g.n) {
+      const mrs_tg_bound_solve* b = bound[k % n_bound];
+      if (b->plan != plan || b->opt.derivative_to_optimize != first->opt.derivative_to_optimize) break;
+      if (g.n > 0 && b == first) break;  // the round is complete: the same arrays twice in one launch would be written twice
+      g.mask[g.n] = b->mask;
+      g.vals[g.n] = b->vals;
+      g.seg_times[g.n] = b->seg_times;
+      g.coeffs[g.n] = b->coeffs;
+      g.status[g.n] = b->status;
+      g.cost[g.n] = b->cost;
+    }
+    if (plan->view.n_paths == 0) continue;
+    HIP_TRY(ctx, use_device(ctx->device));
+    ProfileScope ps(ctx, 1);
+    HIP_TRY(ctx, mrs_tg::launch_solve_rows_group(plan->view, first->opt.derivative_to_optimize, g, ctx->stream));
+  }
+  return MRS_TG_OK;
+}
+
 int mrs_tg_plan_cost_gradient(mrs_tg_plan* plan, int32_t d, const uint8_t* mask, const double* vals,
                               const double* seg_times, double* cost, double* grad) {
   if (!plan || !mask || !vals || !seg_times || !cost || !grad)
@@ -752,9 +797,9 @@ int mrs_tg_plan_careful_count(mrs_tg_plan* plan, int32_t* count_out) {
   if (!plan || !count_out) return fail(plan ? plan->ctx : nullptr, MRS_TG_ERR_INVALID_ARG, "NULL argument");
   mrs_tg_ctx* ctx = plan->ctx;
   *count_out = 0;
-  if (!plan->nl.d_careful) return MRS_TG_OK;  // no outer loop has run on this plan
   HIP_TRY(ctx, use_device(ctx->device));
   HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  if (!plan->nl.d_careful) return MRS_TG_OK;  // no outer loop has run on this plan
   HIP_TRY(ctx, hipMemcpy(count_out, plan->nl.d_careful + 2, sizeof(int32_t), hipMemcpyDeviceToHost));
   return MRS_TG_OK;
 }
@@ -964,7 +1009,10 @@ int mrs_tg_solve_batch(mrs_tg_ctx* ctx, int32_t n_paths, const int32_t* so, cons
     for (int id : {A_T, A_C, A_ST, A_COST, A_NS, A_SMP}) {
       const Arr& a = arr[id];
       if (!a.dst || !a.bytes || a.staged) continue;
-      if (a.pinned) down.add(dbase + a.off, a.pinned, a.bytes);
+      if (a.pinned && id == A_SMP)  // only the rows every path has produced (its capacity is sized for the longest acceptable one)
+        HIP_TRY(ctx, mrs_tg::launch_copy_samples(static_cast<const double*>(dev(A_SMP)), static_cast<double*>(a.pinned),
+                                                 static_cast<const int32_t*>(dev(A_NS)), n_paths, opt->sample_capacity, s));
+      else if (a.pinned) down.add(dbase + a.off, a.pinned, a.bytes);
       else HIP_TRY(ctx, hipMemcpyAsync(a.dst, dbase + a.off, a.bytes, hipMemcpyDeviceToHost, s));
     }
     HIP_TRY(ctx, mrs_tg::launch_copy_many(down, s));

@@ -326,6 +326,25 @@ __global__ __launch_bounds__(256) void copy_many_kernel(CopyList cl) {
   for (unsigned long long i = done + tid; i < bytes; i += stride) dst[i] = src[i];
 }
 
+__global__ __launch_bounds__(256) void copy_samples_kernel(const double* __restrict__ src, double* __restrict__ dst,
+                                                           const int32_t* __restrict__ n_samples, int n_paths, int capacity) {
+  for (int p = blockIdx.x; p < n_paths; p += gridDim.x) {
+    const int n = min(n_samples[p], capacity);
+    const size_t base = (size_t)p * (size_t)capacity * kD;
+    const double2* s2 = reinterpret_cast<const double2*>(src + base);  // a row of four doubles = two 16-byte words
+    double2* d2 = reinterpret_cast<double2*>(dst + base);
+    for (int e = threadIdx.x; e < 2 * n; e += blockDim.x) d2[e] = s2[e];
+  }
+}
+
+hipError_t launch_copy_samples(const double* src, double* dst, const int32_t* n_samples, int n_paths, int capacity,
+                               hipStream_t stream) {
+  if (n_paths <= 0 || capacity <= 0) return hipSuccess;
+  hipLaunchKernelGGL(copy_samples_kernel, dim3((unsigned)(n_paths < 2048 ? n_paths : 2048)), dim3(256), 0, stream, src, dst,
+                     n_samples, n_paths, capacity);
+  return hipGetLastError();
+}
+
 hipError_t launch_copy_many(const CopyList& cl, hipStream_t stream) {
   if (cl.n == 0) return hipSuccess;
   unsigned long long most = 0;

@@ -67,6 +67,10 @@ struct CopyList {
   }
 };
 hipError_t launch_copy_many(const CopyList& cl, hipStream_t stream);
+// samples [n_paths][capacity][4]: only the min(n_samples[p], capacity) rows a path has produced are copied (a sample buffer
+// is sized for the longest trajectory the caller would accept; a typical one uses a fraction of it)
+hipError_t launch_copy_samples(const double* src, double* dst, const int32_t* n_samples, int n_paths, int capacity,
+                               hipStream_t stream);
 
 hipError_t launch_estimate_times(const BatchView& b, const double* wp, const double* limits, double* seg_times,
                                  hipStream_t stream);
@@ -113,5 +117,18 @@ bool rows_tail_sampling_pays(const BatchView& b);
 hipError_t launch_solve_rows(const BatchView& b, int d, const uint8_t* mask, const double* vals, const double* seg_times,
                              double* coeffs, int32_t* status, double* cost, const int32_t* status_in, hipStream_t stream,
                              const RowsTail& tail = RowsTail());
+
+// up to kRowsGroupMax batches of one plan solved by one launch (fixed-times default solve): per batch its arrays
+constexpr int kRowsGroupMax = 8;
+struct RowsGroup {
+  const uint8_t* mask[kRowsGroupMax];
+  const double* vals[kRowsGroupMax];
+  const double* seg_times[kRowsGroupMax];
+  double* coeffs[kRowsGroupMax];
+  int32_t* status[kRowsGroupMax];
+  double* cost[kRowsGroupMax];
+  int n = 0;
+};
+hipError_t launch_solve_rows_group(const BatchView& b, int d, const RowsGroup& g, hipStream_t stream);
 
 }  // namespace mrs_tg

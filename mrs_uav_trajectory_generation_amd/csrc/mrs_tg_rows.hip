@@ -28,6 +28,10 @@
 #include "mrs_tg_rowelim.hpp"
 #include "mrs_tg_sampling.hpp"
 
+#ifndef MRS_TG_ROWS_WAVES
+#define MRS_TG_ROWS_WAVES 1
+#endif
+
 namespace mrs_tg {
 
 // LDS records (doubles)
@@ -308,14 +312,15 @@ struct RowSolve : RowCore {
 // TAIL: the launch scales the segment times first and / or samples afterwards (RowsTail); the plain solve is its own
 // instantiation, which the tail's code would otherwise cost 0.4 us at 1024 x 10
 template <bool TAIL>
-__global__ __launch_bounds__(64) void solve_rows_kernel(BatchView b, int d, int ppw, int Smax,
-                                                        const uint8_t* __restrict__ mask, const double* __restrict__ vals,
-                                                        const double* seg_times /* may be tail.seg_times_out */, double* __restrict__ coeffs,
-                                                        int32_t* __restrict__ status, double* __restrict__ cost,
-                                                        const int32_t* __restrict__ status_in, RowsTail tail) {
+__device__ __forceinline__ void solve_rows_body(const BatchView& b, int d, int ppw, int Smax, const uint8_t* __restrict__ mask,
+                                                const double* __restrict__ vals,
+                                                const double* seg_times /* may be tail.seg_times_out */,
+                                                double* __restrict__ coeffs, int32_t* __restrict__ status,
+                                                double* __restrict__ cost, const int32_t* __restrict__ status_in,
+                                                const RowsTail& tail, int block) {
   extern __shared__ double lds[];
   const int lane = threadIdx.x;
-  const int q0 = blockIdx.x * ppw;
+  const int q0 = block * ppw;
   const int n_here = min(ppw, b.n_paths - q0);
   const int PS = rows_path_doubles(Smax);
   MRS_TG_PHASE_MARK(0);
@@ -547,6 +552,25 @@ __global__ __launch_bounds__(64) void solve_rows_kernel(BatchView b, int d, int 
   }
 }
 
+template <bool TAIL>
+__global__ __launch_bounds__(64, MRS_TG_ROWS_WAVES) void solve_rows_kernel(BatchView b, int d, int ppw, int Smax,
+                                                        const uint8_t* __restrict__ mask, const double* __restrict__ vals,
+                                                        const double* seg_times, double* __restrict__ coeffs,
+                                                        int32_t* __restrict__ status, double* __restrict__ cost,
+                                                        const int32_t* __restrict__ status_in, RowsTail tail) {
+  solve_rows_body<TAIL>(b, d, ppw, Smax, mask, vals, seg_times, coeffs, status, cost, status_in, tail, (int)blockIdx.x);
+}
+
+// Several batches of ONE plan (same structure, their own input / output arrays) in one launch: workgroups
+// [j * blocks_per_batch, (j + 1) * blocks_per_batch) solve batch j.  Every path runs the instructions of the single-batch
+// kernel; what changes is the number of dispatches a host that keeps several batches in flight has to issue.
+__global__ __launch_bounds__(64, MRS_TG_ROWS_WAVES) void solve_rows_group_kernel(BatchView b, int d, int ppw, int Smax,
+                                                                                  RowsGroup g, int blocks_per_batch) {
+  const int j = __builtin_amdgcn_readfirstlane((int)blockIdx.x / blocks_per_batch);
+  solve_rows_body<false>(b, d, ppw, Smax, g.mask[j], g.vals[j], g.seg_times[j], g.coeffs[j], g.status[j], g.cost[j], nullptr,
+                         RowsTail(), (int)blockIdx.x - j * blocks_per_batch);
+}
+
 // ---------------------------------------------------------------------------------------------
 // launcher
 
@@ -603,6 +627,28 @@ hipError_t launch_solve_rows(const BatchView& b, int d, const uint8_t* mask, con
   else
     MRS_TG_LAUNCH_TIMED(solve_rows_kernel<false>, dim3(grid), dim3(64), lds_bytes, stream, b, d, ppw, b.max_segments, mask, vals,
                         seg_times, coeffs, status, cost, status_in, tail);
+  return hipGetLastError();
+}
+
+hipError_t launch_solve_rows_group(const BatchView& b, int d, const RowsGroup& g, hipStream_t stream) {
+  if (g.n < 1 || g.n > kRowsGroupMax) return hipErrorInvalidValue;
+  // two paths per wavefront as soon as the launch carries more than one small batch: a host that groups launches keeps
+  // several of them in flight (on alternating streams), and at 255 VGPRs a SIMD holds two wavefronts (launch_solve_rows)
+  int ppw = ((long long)b.n_paths * g.n <= 1024) ? 1 : 2;
+  static const int forced_ppw = [] {  // MRS_TG_ROWS_PPW=1|2, read once per process
+    const char* e = std::getenv("MRS_TG_ROWS_PPW");
+    return e ? (std::atoi(e) == 1 ? 1 : 2) : 0;
+  }();
+  if (forced_ppw) ppw = forced_ppw;
+  if (rows_lds_bytes(b.max_segments, 2, false) > kRowsLdsBudget) ppw = 1;
+  const size_t lds_bytes = rows_lds_bytes(b.max_segments, ppw, false);
+  if (lds_bytes > 64 * 1024) {
+    hipError_t e = hipFuncSetAttribute((const void*)solve_rows_group_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kRowsLdsBudget);
+    if (e != hipSuccess) return e;
+  }
+  const int per_batch = (b.n_paths + ppw - 1) / ppw;
+  MRS_TG_LAUNCH_TIMED(solve_rows_group_kernel, dim3((unsigned)(per_batch * g.n)), dim3(64), lds_bytes, stream, b, d, ppw,
+                      b.max_segments, g, per_batch);
   return hipGetLastError();
 }
 

@@ -223,6 +223,11 @@ int mto_optimize_path(const double* wps_in, const uint8_t* stop_in, int n_in, co
 #ifdef __cplusplus
 }
 #endif
+/* decision trace of mto_optimize_times_mellinger on the calling thread (see mto_nonlinear.c); buf NULL switches it off */
+#define MTO_TRACE_REC 8
+void mto_set_optimizer_trace(double* buf, int cap_records);
+int mto_optimizer_trace_count(void);
+
 /* per-thread scratch memory for temporaries (mto_scratch.c): mark, allocate (64-byte aligned; zero != 0 clears), release */
 typedef struct {
   int block;

@@ -84,6 +84,21 @@ static int relstop(double vold, double vnew, double reltol, double abstol) {
 
 #define LBFGS_M 5
 
+/* Optional per-thread trace of the search's decisions (scripts/divergence_histogram.py): one record of MTO_TRACE_REC doubles
+ * per objective evaluation after the first --
+ *   [0] evaluation number  [1] f of the current iterate  [2] fn of the trial  [3] slope g^T (xn - x)  [4] alpha
+ *   [5] Armijo margin (f + 1e-4 slope - fn) / |f|: >= 0 accepted
+ *   [6] ftol margin (f_rel (|fn| + |f|) / 2 - |fn - f|) / |f|: > 0 stops (accepted trials only, else 0)
+ *   [7] xtol margin min_i (x_rel (|xn_i| + |x_i|) / 2 - |xn_i - x_i|) / |x_i|: > 0 stops (accepted trials only, else 0) */
+static __thread double* t_trace = NULL;
+static __thread int t_trace_cap = 0, t_trace_n = 0;
+void mto_set_optimizer_trace(double* buf, int cap_records) {
+  t_trace = buf;
+  t_trace_cap = cap_records;
+  t_trace_n = 0;
+}
+int mto_optimizer_trace_count(void) { return t_trace_n; }
+
 int mto_optimize_times_mellinger(const mto_path* path, const mto_nlopt_params* prm, double* x, int* n_eval_out,
                                  double* final_cost_out) {
   const int S = path->n_seg;
@@ -166,6 +181,28 @@ int mto_optimize_times_mellinger(const mto_path* path, const mto_nlopt_params* p
       fn = mto_cost_and_gradient_mellinger(path, xn, gn);
       ++neval;
       f_last = fn;
+      if (t_trace && t_trace_n < t_trace_cap) {
+        double* r = t_trace + (size_t)t_trace_n * MTO_TRACE_REC;
+        const double fa = fabs(f) > 1e-300 ? fabs(f) : 1e-300;
+        r[0] = neval;
+        r[1] = f;
+        r[2] = fn;
+        r[3] = slope;
+        r[4] = alpha;
+        r[5] = (f + 1e-4 * slope - fn) / fa;
+        r[6] = 0.0;
+        r[7] = 0.0;
+        if (fn <= f + 1e-4 * slope) {
+          r[6] = (prm->f_rel * (fabs(fn) + fabs(f)) * 0.5 - fabs(fn - f)) / fa;
+          double mn = DBL_MAX;
+          for (int i = 0; i < S; ++i) {
+            const double m = (prm->x_rel * (fabs(xn[i]) + fabs(x[i])) * 0.5 - fabs(xn[i] - x[i])) / fabs(x[i]);
+            if (m < mn) mn = m;
+          }
+          r[7] = mn;
+        }
+        ++t_trace_n;
+      }
       if (fn <= f + 1e-4 * slope) break;
       if (prm->max_iterations > 0 && neval >= prm->max_iterations) { /* budget ends on a rejected trial */
         memcpy(x, xn, sizeof(double) * (size_t)S);

@@ -81,6 +81,9 @@ def lib():
         L.mto_compute_cost.argtypes = [C.c_int, C.c_int, dp, dp]
         L.mto_cost_and_gradient_mellinger.restype = C.c_double
         L.mto_cost_and_gradient_mellinger.argtypes = [C.POINTER(_Path), dp, dp]
+        L.mto_set_optimizer_trace.restype = None
+        L.mto_set_optimizer_trace.argtypes = [dp, C.c_int]
+        L.mto_optimizer_trace_count.restype = C.c_int
         L.mto_optimize_times_mellinger.restype = C.c_int
         L.mto_optimize_times_mellinger.argtypes = [C.POINTER(_Path), C.POINTER(NloptParams), dp, C.POINTER(C.c_int), dp]
         L.mto_segment_max_magnitude.restype = C.c_double
@@ -229,6 +232,19 @@ def optimize_times(deriv, fixed_mask, fixed_values, seg_times, params=None):
     fc = C.c_double(0)
     rc = lib().mto_optimize_times_mellinger(C.byref(p), C.byref(prm), _dp(t), C.byref(ne), C.byref(fc))
     return rc, t, ne.value, fc.value
+
+
+def optimize_times_traced(deriv, fixed_mask, fixed_values, seg_times, params=None, cap=64):
+    """optimize_times plus the search's decision trace: rows of [evaluation, f, fn, slope, alpha, Armijo margin, ftol margin,
+    xtol margin] (mto_set_optimizer_trace)"""
+    buf = np.zeros((cap, 8))
+    lib().mto_set_optimizer_trace(_dp(buf), cap)
+    try:
+        rc, t, ne, fc = optimize_times(deriv, fixed_mask, fixed_values, seg_times, params)
+        n = lib().mto_optimizer_trace_count()
+    finally:
+        lib().mto_set_optimizer_trace(None, 0)
+    return rc, t, ne, buf[:n].copy()
 
 
 def objective_time(deriv, fixed_mask, fixed_values, seg_times, limits, mode=0, time_penalty=100.0, soft=1, weight=1.5):

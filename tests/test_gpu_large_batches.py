@@ -114,6 +114,7 @@ def test_nonlinear_compact_mapping_matches_split_mapping(gpu_ctx):
         if out["status"][p] == small["status"][k] and \
                 np.max(np.abs(out["times"][a:b] - small["times"][10 * k:10 * k + 10]) / small["times"][10 * k:10 * k + 10]) < 1e-7:
             agree += 1
+    print("RATE compact_vs_split: %d / %d" % (agree, len(idx)))
     assert agree >= 0.97 * len(idx), agree
     # and against the oracle on a handful
     few = idx[:12]

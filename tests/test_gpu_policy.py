@@ -31,6 +31,7 @@ def test_policy_loop_matches_oracle(gpu_ctx, deriv):
             if n == 0 or np.max(np.abs(out["samples"][p, :n, :3] - ref["samples"][:, :3])) < 1e-6:
                 same += 1
                 assert abs(out["max_deviation"][p] - ref["max_deviation"]) < 1e-6
+    print("RATE policy deriv %d: %d / %d" % (deriv, same, len(paths)))
     assert same >= 0.9 * len(paths), same
 
 

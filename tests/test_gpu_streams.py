@@ -61,3 +61,55 @@ def test_concurrent_streams_match_serial_execution(gpu_ctx, nonlinear):
     for ctx, plan, db, t0 in lanes:
         plan.close()
         ctx.close()
+
+
+def test_grouped_launch_packs_the_steps_of_a_round_into_one_dispatch(gpu_ctx):
+    """mrs_tg_bound_solve_launch_group: bound solves of ONE plan with their own input / output arrays; the launches of a round go
+    out as one kernel whose workgroups are divided among the batches.  Same results as one launch per step, bit for bit
+    (1 and 2 paths per wavefront, a ragged batch, more launches than a multiple of the group, two plans in one run); what
+    does not fit is refused with a message."""
+    import ctypes as C
+    for batch, n_slots, n_launches in ((pr.random_batch(300, 10, seed0=3), 4, 11), (pr.random_batch(1024, 10, seed0=0), 4, 8),
+                                       (pr.random_batch(200, "ragged", seed0=8), 3, 7), (pr.random_batch(64, 5, seed0=1), 8, 8)):
+        plan = api.Plan(gpu_ctx, batch.seg_offsets)
+        est = api.default_options(estimate_times=1, derivative_to_optimize=4)
+        lin = api.default_options(derivative_to_optimize=4)
+        dbs, calls, refs = [], [], []
+        for s in range(n_slots):
+            # every slot solves its own problem: the same structure, other waypoints
+            other = pr.random_batch(batch.n_paths, 10, seed0=1000 * (s + 1)) if batch.seg_offsets[-1] == 10 * batch.n_paths else batch
+            b = pr.Batch(batch.seg_offsets, other.waypoints, other.fixed_mask, other.fixed_values, other.limits, 4) if other is not batch else batch
+            db = api.DeviceBatch(b, "cuda:0", sample_capacity=16)
+            plan.solve(est, db.fixed_mask, db.fixed_values, db.seg_times, db.coeffs, db.status, db.cost, waypoints=db.waypoints,
+                       limits=db.limits)
+            torch.cuda.synchronize()
+            refs.append((db.coeffs.cpu().numpy().copy(), db.cost.cpu().numpy().copy()))
+            db.coeffs.zero_()
+            db.cost.zero_()
+            db.status.zero_()
+            dbs.append(db)
+            calls.append(plan.bind_solve(lin, db.fixed_mask, db.fixed_values, db.seg_times, db.coeffs, db.status, db.cost))
+        api.RoundRobin(calls, grouped=True)(n_launches)
+        torch.cuda.synchronize()
+        for s, db in enumerate(dbs):
+            touched = s < n_launches
+            assert np.array_equal(db.coeffs.cpu().numpy(), refs[s][0] if touched else np.zeros_like(refs[s][0])), s
+            assert np.array_equal(db.cost.cpu().numpy(), refs[s][1]) and np.all(db.status.cpu().numpy() == 1)
+        # a solve that samples, or belongs to another plan, cannot be grouped
+        smp = api.default_options(derivative_to_optimize=4, sampling_dt=0.2, sample_capacity=16)
+        bad = plan.bind_solve(smp, dbs[0].fixed_mask, dbs[0].fixed_values, dbs[0].seg_times, dbs[0].coeffs, dbs[0].status, dbs[0].cost,
+                              n_samples=dbs[0].n_samples, samples=dbs[0].samples)
+        with pytest.raises(api.MrsTgError, match="fixed-times default solve without sampling"):
+            api.RoundRobin([calls[0], bad], grouped=True)(2)
+        # bound solves of another plan form their own dispatch: [A0, A1, B0] issues (A0 A1), (B0), (A0 A1), ...
+        plan2 = api.Plan(gpu_ctx, batch.seg_offsets)
+        last = dbs[-1]
+        foreign = plan2.bind_solve(lin, last.fixed_mask, last.fixed_values, last.seg_times, last.coeffs, last.status, last.cost)
+        for db in dbs:
+            db.coeffs.zero_()
+        api.RoundRobin([calls[0], calls[1], foreign], grouped=True)(6)
+        torch.cuda.synchronize()
+        for s in (0, 1, n_slots - 1):
+            assert np.array_equal(dbs[s].coeffs.cpu().numpy(), refs[s][0]), s
+        plan2.close()
+        plan.close()
