@@ -531,14 +531,19 @@ def main():
     torch.cuda.synchronize()
     sol_mean, sol_med, sol_min = dispatch_stats(ctx, api.KERNEL_SOLVE_LINEAR, launch_solve, 200, torch)
     solve_flop = SOLVE_FLOP_PER_SEGMENT * nS
-    sq = None   # SQ counters of this kernel at this batch shape from the committed PMC passes (scripts/pmc_sq.sh)
-    try:
-        with open(os.path.join(ROOT, "profiles", "round2_pmc_sq_solve_rows.json")) as fh:
-            sq = json.load(fh)
-        if sq.get("paths") != P or sq.get("segments") != args.segments:
-            sq = None
-    except (OSError, ValueError):
-        sq = None
+    def newest_sq(pattern):
+        """SQ counters of a kernel at this batch shape from the newest committed PMC passes (scripts/pmc_sq.sh, pmc_sq_json.py)"""
+        for f in sorted(glob.glob(os.path.join(ROOT, "profiles", pattern)), reverse=True):
+            try:
+                with open(f) as fh:
+                    d = json.load(fh)
+            except (OSError, ValueError):
+                continue
+            if d.get("paths") == P and d.get("segments") == args.segments:
+                return d
+        return None
+
+    sq = newest_sq("round*_pmc_sq_solve_rows.json")
     issue_peak = 256 * 4 * 2.4e9 / 4.0   # wavefront VALU instructions per second: one per 4 cycles per SIMD
     counted = None
     if sq is not None:
@@ -565,14 +570,7 @@ def main():
     torch.cuda.synchronize()
     nl_mean, nl_med, nl_min = dispatch_stats(ctx, api.KERNEL_NONLINEAR, launch_nl, 50, torch)
     nl_flop = NONLINEAR_FLOP_PER_PATH_S10 * (args.segments / 10.0) ** 2 * P
-    sq_nl = None   # SQ counters of the outer-loop kernel at this batch shape (scripts/pmc_sq.sh, committed)
-    try:
-        with open(os.path.join(ROOT, "profiles", "round2_pmc_sq_outer_loop.json")) as fh:
-            sq_nl = json.load(fh)
-        if sq_nl.get("paths") != P or sq_nl.get("segments") != args.segments:
-            sq_nl = None
-    except (OSError, ValueError):
-        sq_nl = None
+    sq_nl = newest_sq("round*_pmc_sq_outer_loop.json")
     if sq_nl is not None:
         # executed work: every VALU instruction counted as a 64-lane FP64 FMA -- an upper bound of the flops the kernel ran
         c = sq_nl["counters"]
@@ -586,7 +584,9 @@ def main():
                                            lds_instructions_per_launch=c["SQ_INSTS_LDS"],
                                            valu_issue_frac=c["SQ_INSTS_VALU"] / (nl_mean * 1e-3) / issue_peak,
                                            wait_share_of_wave_cycles=c["SQ_WAIT_ANY"] / c["SQ_WAVE_CYCLES"],
-                                           valu_active_share_of_wave_cycles=c["SQ_ACTIVE_INST_VALU"] / c["SQ_WAVE_CYCLES"]),
+                                           valu_active_share_of_wave_cycles=c["SQ_ACTIVE_INST_VALU"] / c["SQ_WAVE_CYCLES"],
+                                           lds_bank_conflict_share=(c["SQ_LDS_BANK_CONFLICT"] / c["SQ_LDS_IDX_ACTIVE"]
+                                                                    if c.get("SQ_LDS_IDX_ACTIVE") else None)),
                               reference_work_flop=nl_flop,
                               note="flop_per_launch = 2 x 64 x counted VALU instructions (upper bound of the executed FP64 work); "
                                    "reference_work_flop is SURVEY.md 8d's model of what the reference would execute for the same "

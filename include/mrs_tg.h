@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define MRS_TG_ABI_VERSION 2
+#define MRS_TG_ABI_VERSION 3
 #define MRS_TG_N_COEFF 10
 #define MRS_TG_N_DIM 4
 #define MRS_TG_N_SLOT 5 /* derivative slots per vertex: position .. snap */

@@ -273,7 +273,9 @@ hipError_t launch_solve_linear(const BatchView& b, int d, bool fused, const uint
     return launch_solve_rows(b, d, mask, vals, seg_times, coeffs, status, cost, status_in, stream);
   if (tile_kernel_applies(b, fused))
     return launch_solve_tile(b, d, fused, mask, vals, seg_times, H, Ainv, coeffs, status, cost, status_in, stream);
-  if (use_split_dims(b.n_paths)) {
+  // (the one-lane-per-path solve from materialised blocks -- 512 registers and 264 bytes of scratch per lane -- is gone: a
+  // blocks solve of a batch the tile kernel does not take runs four lanes per path whatever its size)
+  if (use_split_dims(b.n_paths) || !fused) {
     dim3 grid(cdiv((long long)b.n_paths * 4, 64));
     if (fused)
       MRS_TG_LAUNCH_TIMED((solve_linear_kernel<1, true>), grid, dim3(64), 0, stream, b, d, mask, vals, seg_times, H, Ainv,
@@ -283,12 +285,8 @@ hipError_t launch_solve_linear(const BatchView& b, int d, bool fused, const uint
                          Ainv, ws, coeffs, status, cost, status_in);
   } else {
     dim3 grid(cdiv(b.n_paths, 64));
-    if (fused)
-      MRS_TG_LAUNCH_TIMED((solve_linear_kernel<4, true>), grid, dim3(64), 0, stream, b, d, mask, vals, seg_times, H, Ainv,
-                         ws, coeffs, status, cost, status_in);
-    else
-      MRS_TG_LAUNCH_TIMED((solve_linear_kernel<4, false>), grid, dim3(64), 0, stream, b, d, mask, vals, seg_times, H,
-                         Ainv, ws, coeffs, status, cost, status_in);
+    MRS_TG_LAUNCH_TIMED((solve_linear_kernel<4, true>), grid, dim3(64), 0, stream, b, d, mask, vals, seg_times, H, Ainv,
+                        ws, coeffs, status, cost, status_in);
   }
   return hipGetLastError();
 }

@@ -45,6 +45,9 @@ namespace mrs_tg {
 #ifndef MRS_TG_LEAN_RELOAD
 #define MRS_TG_LEAN_RELOAD 0
 #endif
+#ifndef MRS_TG_MAXIMA_WAVES
+#define MRS_TG_MAXIMA_WAVES 4
+#endif
 #ifndef MRS_TG_LEAN_WAVES
 #define MRS_TG_LEAN_WAVES 2
 #endif
@@ -622,23 +625,22 @@ __host__ __device__ constexpr double falling(int j, int k) {
   return v;
 }
 
-// Coefficients of q^(K), q^(K+1), q^(K+2) (derivatives in normalised time) of NDIM dimensions, kept in
-// registers; every loop below has compile-time bounds so nothing is indexed dynamically.
+// Coefficients of q^(K) (derivative K in normalised time) of NDIM dimensions, kept in registers; every loop below has
+// compile-time bounds so nothing is indexed dynamically.  q^(K+1) and q^(K+2) come out of the same Horner pass (the nested
+// recurrence p'' <- p'' t + p', p' <- p' t + p, p <- p t + c): one coefficient array per dimension instead of three -- 18
+// instead of 48 doubles for the horizontal velocity -- which is what lets five wavefronts share a SIMD where three did
+// (142 -> VGPRs); the kernel waits on dependent FMA chains and on its lanes' uneven Newton loops, and more resident
+// wavefronts are what hides both.
 template <int K, int NDIM>
 struct MagPoly {
-  static constexpr int N0 = kN - K, N1 = kN - K - 1, N2 = kN - K - 2;
-  double d0[NDIM][N0], d1[NDIM][N1], d2[NDIM][N2];
+  static constexpr int N0 = kN - K;
+  double d0[NDIM][N0];
 
   __device__ __forceinline__ void init(const double (&cb)[NDIM][kN]) {
 #pragma unroll
-    for (int q = 0; q < NDIM; ++q) {
+    for (int q = 0; q < NDIM; ++q)
 #pragma unroll
       for (int j = 0; j < N0; ++j) d0[q][j] = cb[q][j + K] * falling(j + K, K);
-#pragma unroll
-      for (int j = 0; j < N1; ++j) d1[q][j] = cb[q][j + K + 1] * falling(j + K + 1, K + 1);
-#pragma unroll
-      for (int j = 0; j < N2; ++j) d2[q][j] = cb[q][j + K + 2] * falling(j + K + 2, K + 2);
-    }
   }
   // m2 = sum q^(K)^2 ;  g = (1/2) d m2 / dtau
   __device__ __forceinline__ void eval(double tau, double& m2, double& g) const {
@@ -646,13 +648,14 @@ struct MagPoly {
     g = 0.0;
 #pragma unroll
     for (int q = 0; q < NDIM; ++q) {
-      double v0 = d0[q][N0 - 1], v1 = d1[q][N1 - 1];
+      double v0 = d0[q][N0 - 1], v1 = 0.0;
 #pragma unroll
-      for (int j = N0 - 2; j >= 0; --j) v0 = v0 * tau + d0[q][j];
-#pragma unroll
-      for (int j = N1 - 2; j >= 0; --j) v1 = v1 * tau + d1[q][j];
-      m2 += v0 * v0;
-      g += v0 * v1;
+      for (int j = N0 - 2; j >= 0; --j) {
+        v1 = fma(v1, tau, v0);
+        v0 = fma(v0, tau, d0[q][j]);
+      }
+      m2 = fma(v0, v0, m2);
+      g = fma(v0, v1, g);
     }
   }
   // the same plus dg = derivative of g (Newton)
@@ -662,16 +665,16 @@ struct MagPoly {
     dg = 0.0;
 #pragma unroll
     for (int q = 0; q < NDIM; ++q) {
-      double v0 = d0[q][N0 - 1], v1 = d1[q][N1 - 1], v2 = d2[q][N2 - 1];
+      double v0 = d0[q][N0 - 1], v1 = 0.0, h2 = 0.0;  // h2 = q^(K+2) / 2
 #pragma unroll
-      for (int j = N0 - 2; j >= 0; --j) v0 = v0 * tau + d0[q][j];
-#pragma unroll
-      for (int j = N1 - 2; j >= 0; --j) v1 = v1 * tau + d1[q][j];
-#pragma unroll
-      for (int j = N2 - 2; j >= 0; --j) v2 = v2 * tau + d2[q][j];
-      m2 += v0 * v0;
-      g += v0 * v1;
-      dg += v1 * v1 + v0 * v2;
+      for (int j = N0 - 2; j >= 0; --j) {
+        h2 = fma(h2, tau, v1);
+        v1 = fma(v1, tau, v0);
+        v0 = fma(v0, tau, d0[q][j]);
+      }
+      m2 = fma(v0, v0, m2);
+      g = fma(v0, v1, g);
+      dg += fma(v1, v1, 2.0 * (v0 * h2));
     }
   }
 };
@@ -1137,7 +1140,10 @@ __device__ __forceinline__ double evaluate_lean(const double* tabs, const double
 #else
         const double* tabr = tab;
 #endif
-        const double* tabn = MRS_TG_LEAN_RELOAD >= 2 ? tabr : tab;  // 2: the near-block constants as well
+        const double* tabn = MRS_TG_LEAN_RELOAD == 2 ? tabr : tab;  // 2: the near-block constants as well
+        const double* tabc = (MRS_TG_LEAN_RELOAD == 1 || MRS_TG_LEAN_RELOAD == 2 || MRS_TG_LEAN_RELOAD == 4) ? tabr : tab;  // coupling block
+        const double* tabf = (MRS_TG_LEAN_RELOAD == 1 || MRS_TG_LEAN_RELOAD == 2 || MRS_TG_LEAN_RELOAD == 5) ? tabr : tab;  // far block
+        const double* tabw = (MRS_TG_LEAN_RELOAD >= 1) ? tabr : tab;                                                        // far brackets (3: only these)
         double p2[9];
         segment_powers(perturbed_time(pt, i, k, corr), d, p2);
         double dq[4];
@@ -1186,7 +1192,7 @@ __device__ __forceinline__ double evaluate_lean(const double* tabs, const double
           for (int c = 0; c < kNB; ++c)
 #pragma unroll
             for (int rr = 0; rr < kNB; ++rr) {
-              double t = tabr[10 + rr * kNB + c] * p2[rr + c + 2];
+              double t = tabc[10 + rr * kNB + c] * p2[rr + c + 2];
 #pragma unroll
               for (int m = 0; m < rr; ++m) t = fma(-L[tri(rr, m)], W[m][c], t);
               W[rr][c] = t * Linv[rr];
@@ -1195,12 +1201,12 @@ __device__ __forceinline__ double evaluate_lean(const double* tabs, const double
           for (int rr = 0; rr < kNB; ++rr) {
 #pragma unroll
             for (int c = 0; c <= rr; ++c) {
-              double t = tabr[26 + tri(rr, c)] * p2[rr + c + 2];
+              double t = tabf[26 + tri(rr, c)] * p2[rr + c + 2];
 #pragma unroll
               for (int m = 0; m < kNB; ++m) t = fma(-W[m][rr], W[m][c], t);
               Sm[tri(rr, c)] = t;
             }
-            const double cF = tabr[40 + rr] * p2[rr + 1];
+            const double cF = tabw[40 + rr] * p2[rr + 1];
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
               double t = -(cF * dq[q]);
@@ -1929,7 +1935,7 @@ __global__ __launch_bounds__(64) void optimize_careful_kernel(BatchView b, Nonli
 }
 
 // per-segment maxima, one (k, group) per blockIdx.y: maxima[seg * 9 + 3 (k-1) + group]
-__global__ __launch_bounds__(64) void segment_maxima9_kernel(int n_segments, const double* __restrict__ coeffs,
+__global__ __launch_bounds__(64, MRS_TG_MAXIMA_WAVES) void segment_maxima9_kernel(int n_segments, const double* __restrict__ coeffs,
                                                              const double* __restrict__ seg_times,
                                                              double* __restrict__ maxima) {
   // One lane per (segment, which).  A quad of lanes per polynomial, each a quarter of the grid (max_mag2's PARTS = 4), was

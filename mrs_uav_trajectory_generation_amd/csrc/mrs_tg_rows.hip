@@ -386,13 +386,12 @@ __device__ __forceinline__ void solve_rows_body(const BatchView& b, int d, int p
       pos_ok_lane = pos_ok_lane && pos_fixed;
     }
     const int p_t = __builtin_amdgcn_readlane(pr.p, tt * 16);
-    for (int i = lane; i < S_t; i += 64) {
-      double T = (i == lane) ? T_first : seg_times[s0_t + i];
+    // segment `i` of the path: its record from its time and the constrained positions of its two vertices
+    auto stage_segment = [&](int i, double T, const double (&pp)[2 * kD]) {
       if (TAIL && tail.maxima) {  // feasibility scaling of this segment (trajectory.cpp:625-657), then the solve at the scaled times
         if (tail.opt_status[p_t] != -2) T *= violation_scaling(tail.maxima + (size_t)(s0_t + i) * 9, tail.limits + (size_t)p_t * 9);
         tail.seg_times_out[s0_t + i] = T;
       }
-      const double* ps = vals + (size_t)(v0_t + i) * kHalf * kD;  // constrained position of vertex i, then of i + 1
       double* r = sb + (size_t)i * kRSegRec;
       // T^(2 - 2d) as the assembly kernel forms it: T / (T^d)^2 ... times T
       const double t2 = T * T;
@@ -409,8 +408,21 @@ __device__ __forceinline__ void solve_rows_body(const BatchView& b, int d, int p
       }
       r[kRSegT] = T;
 #pragma unroll
-      for (int dd = 0; dd < kD; ++dd)
-        r[kRSegDp + dd] = (i == lane) ? ps_first[dd] - ps_first[kD + dd] : ps[dd] - ps[kHalf * kD + dd];
+      for (int dd = 0; dd < kD; ++dd) r[kRSegDp + dd] = pp[dd] - pp[kD + dd];
+    };
+    // the first round works on what was requested in front of the vertex loop; written as a select inside one loop the
+    // compiler loaded time and positions again (a second trip to memory behind the first, ~800 cycles on the only wavefront
+    // of its SIMD)
+    if (lane < S_t) stage_segment(lane, T_first, ps_first);
+    for (int i = lane + 64; i < S_t; i += 64) {  // paths of more than 64 segments
+      const double* ps = vals + (size_t)(v0_t + i) * kHalf * kD;  // constrained position of vertex i, then of i + 1
+      double pp[2 * kD];
+#pragma unroll
+      for (int dd = 0; dd < kD; ++dd) {
+        pp[dd] = ps[dd];
+        pp[kD + dd] = ps[kHalf * kD + dd];
+      }
+      stage_segment(i, seg_times[s0_t + i], pp);
     }
     pos_bad[tt] = __ballot(!pos_ok_lane);
     gen_any[tt] = __ballot(nonzero_lane);

@@ -12,6 +12,12 @@ how far was it from flipping?
   * 'smooth': the two trial points differ by less than 1e-3 relative at the first divergent evaluation: no comparison
     flipped, the difference is rounding noise in the forward-difference gradient amplified by the L-BFGS update.
 
+A second pass runs the WHOLE pipeline (the batch's own limits: outer loop, solve, per-segment feasibility scaling, re-solve)
+and sorts the paths whose final times differ at 1e-6 by where the difference entered: in the search (above), or behind it --
+the two searches ended on the same point to 1e-6 and the scaling / re-solve at that point told them apart.  For the latter
+the shortest segment of the shared point and (T_max / T_min)^7, the growth of the linear system's condition number, are
+printed: those are the points with a segment on the 0.01 s bound.
+
 usage: divergence_histogram.py <generator: box|mixed|ragged> <n_paths> <deriv> [out.json]"""
 import json
 import os
@@ -27,18 +33,21 @@ from tests import util
 
 gen, P, deriv = sys.argv[1], int(sys.argv[2]), int(sys.argv[3])
 out_path = sys.argv[4] if len(sys.argv) > 4 else None
-if gen == "mixed":
-    full = pr.random_mixed_batch(P, deriv)
-elif gen == "ragged":
-    full = pr.random_batch(P, "ragged", seed0=0)
-else:
-    full = pr.random_batch(P, 10, seed0=0)
+def make_batch():
+    if gen == "mixed":
+        return pr.random_mixed_batch(P, deriv)
+    if gen == "ragged":
+        return pr.random_batch(P, "ragged", seed0=0)
+    return pr.random_batch(P, 10, seed0=0)
+
+
+full = make_batch()
+with_limits = make_batch()
 full.limits[:] = 1e12   # no feasibility scaling: what comes back is the outer loop's last evaluated point
 so = full.seg_offsets
 torch.zeros(1, device="cuda")
 ctx = api.Context(0)
-t0_all = util.oracle_times(pr.random_mixed_batch(P, deriv) if gen == "mixed" else
-                           (pr.random_batch(P, "ragged", seed0=0) if gen == "ragged" else pr.random_batch(P, 10, seed0=0)))
+t0_all = util.oracle_times(with_limits)
 
 
 def run(batch, t0, budget):
@@ -134,6 +143,28 @@ if smooth:
     print("smooth divergences: first gap median %.2e, final gap median %.2e; gradient difference at the shared point median %.2e" % (
         np.median([r["gap_there"] for r in smooth]), np.median([r["final_gap"] for r in smooth]),
         np.nanmedian([r.get("rel_dgrad_at_shared_point", np.nan) for r in smooth])))
+# ---- the whole pipeline, with the batch's own limits
+ref_p, out_p = run(with_limits, t0_all, 10)
+d_pipe = rel_diff(out_p["times"], ref_p["times"], so)
+differ = np.nonzero((d_pipe > 1e-6) | (out_p["status"] != ref_p["status"]))[0]
+in_search = [p for p in differ if d_final[p] > 1e-6 or out["status"][p] != ref["status"][p]]
+behind = [p for p in differ if p not in set(in_search)]
+print("whole pipeline: %d paths differ at 1e-6 (%.3f %%): %d already in the search, %d behind it (scaling + re-solve at a shared point)"
+      % (differ.size, 100.0 * differ.size / P, len(in_search), len(behind)))
+pipeline = dict(differing_at_1e6=int(differ.size), in_search=len(in_search), behind_search=len(behind))
+if behind:
+    tmin = np.array([ref["times"][so[p]:so[p + 1]].min() for p in behind])
+    spread = np.array([(ref["times"][so[p]:so[p + 1]].max() / ref["times"][so[p]:so[p + 1]].min()) ** 7 for p in behind])
+    gap_search = np.array([d_final[p] for p in behind])
+    on_bound = int((tmin <= 0.0100001).sum())
+    print("  behind the search: shortest segment of the shared point: %d of %d on the 0.01 s bound, median %.3f s; (T_max / T_min)^7 median %.1e, "
+          "smallest %.1e; gap of the searches there median %.1e; final gap median %.1e"
+          % (on_bound, len(behind), np.median(tmin), np.median(spread), spread.min(), np.median(gap_search), np.median(d_pipe[behind])))
+    runaway = int(sum(1 for p in behind if out_p["status"][p] == -4 or ref_p["status"][p] == -4))
+    print("  of these, flagged ROUNDOFF_LIMITED (runaway) by either side: %d" % runaway)
+    pipeline.update(on_bound=on_bound, median_min_segment=float(np.median(tmin)), median_spread7=float(np.median(spread)),
+                    min_spread7=float(spread.min()), flagged_runaway=runaway)
 if out_path:
     with open(out_path, "w") as f:
-        json.dump(dict(generator=gen, paths=P, derivative=deriv, differing_at_1e6=int(bad.size), kinds=kinds, records=records), f, indent=0)
+        json.dump(dict(generator=gen, paths=P, derivative=deriv, differing_at_1e6=int(bad.size), kinds=kinds, pipeline=pipeline,
+                       records=records), f, indent=0)

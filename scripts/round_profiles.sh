@@ -1,0 +1,22 @@
+#!/bin/bash
+# Everything under profiles/<tag>_* that comes from the GPU box, in one call (about ten minutes).  The results land in
+# gpurun_out/; the ones to be judged are then copied into profiles/.   usage: scripts/round_profiles.sh <tag>
+tag=${1:-round}
+cd "$(dirname "$0")/.." && export TMPDIR=/tmp
+mkdir -p gpurun_out
+O=gpurun_out
+python3 bench.py --steps 20 --warmup 5 2>/dev/null | grep '^{"metric' > $O/${tag}_bench_line_20_steps.json
+python3 bench.py --steps 200 --warmup 20 2>/dev/null | grep '^{"metric' > $O/${tag}_bench_line.json
+scripts/profile_round.sh $tag > $O/${tag}_profile_round.log 2>&1
+scripts/pmc_sq.sh $tag > $O/${tag}_pmc_sq.log 2>&1
+python3 scripts/pmc_sq_json.py $O/${tag}_pmc_sq_linear.csv solve_rows_kernel 65536 1024 10 $O/${tag}_pmc_sq_solve_rows.json
+python3 scripts/pmc_sq_json.py $O/${tag}_pmc_sq_nonlinear.csv optimize_split_kernel 131072 1024 10 $O/${tag}_pmc_sq_outer_loop.json
+scripts/pmc_sq_nl.sh $tag 8192 > $O/${tag}_pmc_sq_nl_8192.log 2>&1
+python3 scripts/measure_configs.py $tag > $O/${tag}_configs.txt 2>&1
+scripts/pipeline_stats.sh $tag > $O/${tag}_pipeline_stats.txt 2>&1
+python3 scripts/host_call_rate.py > $O/${tag}_host_call_rate.txt 2>&1
+python3 scripts/host_call_rate.py 64 >> $O/${tag}_host_call_rate.txt 2>&1
+python3 scripts/host_call_rate.py 8192 >> $O/${tag}_host_call_rate.txt 2>&1
+scripts/tile_phases.bin 1024 10 > $O/${tag}_phase_clocks_1024x10.txt 2>&1
+scripts/parity_sweep_all.sh $O/${tag}_parity_sweep.txt
+ls -la $O/${tag}_*

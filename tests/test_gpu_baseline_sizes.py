@@ -29,7 +29,7 @@ def _per_path(arr, offsets, p):
     return arr[offsets[p]:offsets[p + 1]]
 
 
-def _check_nonlinear(gpu_ctx, batch, n_oracle, min_good=0.95):
+def _check_nonlinear(gpu_ctx, batch, n_oracle, min_good=0.99):
     out = gpu_ctx.solve_batch(batch, None, time_alloc_method=api.TIME_ALLOC_MELLINGER, sampling_dt=0.2, sample_capacity=CAP)
     P, so = batch.n_paths, batch.seg_offsets
     assert np.all(np.isin(out["status"], (1, 3, 4, 5, api.STATUS_ROUNDOFF_LIMITED)))
@@ -81,15 +81,15 @@ def _check_nonlinear(gpu_ctx, batch, n_oracle, min_good=0.95):
 
 
 def test_config2_1024_paths_nonlinear(gpu_ctx):
-    """BASELINE configs[2] at its own size: every one of the 1024 paths through the invariants, a strided 128 of them
-    against the oracle (all 128 must agree: measured 128 / 128)."""
+    """BASELINE configs[2] at its own size: every one of the 1024 paths through the invariants, a strided 256 of them
+    against the oracle (measured 256 / 256)."""
     rate = _check_nonlinear(gpu_ctx, pr.random_batch(1024, 10, seed0=0), 256, min_good=0.99)
     print("configs[2] agreement with the oracle on the strided subset: %.4f" % rate)
 
 
 def test_config3_whole_65536_paths_nonlinear(gpu_ctx):
     batch = pr.random_batch(65536, 10, seed0=0)
-    _check_nonlinear(gpu_ctx, batch, 512, min_good=0.98)
+    _check_nonlinear(gpu_ctx, batch, 512, min_good=0.99)   # measured 512 / 512
     # path 8615 (a 2.7 s segment next to one scaled to 9e11 s) and its siblings, which round 2 returned as successes
     out = gpu_ctx.solve_batch(batch.select([8615]), None, time_alloc_method=api.TIME_ALLOC_MELLINGER)
     assert out["status"][0] == api.STATUS_ROUNDOFF_LIMITED and out["times"].sum() > 1e6
@@ -99,7 +99,7 @@ def test_config4_8192_ragged_paths_nonlinear(gpu_ctx):
     batch = pr.random_batch(8192, "ragged", seed0=0)
     counts = np.diff(batch.seg_offsets)
     assert counts.min() == 3 and counts.max() == 30
-    _check_nonlinear(gpu_ctx, batch, 512)
+    _check_nonlinear(gpu_ctx, batch, 512, min_good=0.99)   # measured 512 / 512 (round 2 ran 96 paths against a gate of 0.95)
 
 
 def test_config1_at_65536_paths_linear_is_linear_in_the_waypoints(gpu_ctx):

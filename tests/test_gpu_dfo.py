@@ -53,7 +53,7 @@ def test_long_budget_matches_oracle(gpu_ctx, mode, soft):
                 np.max(np.abs(out["times"][a:b] - ref["times"][a:b]) / ref["times"][a:b]) < 1e-9:
             same += 1
     print("RATE dfo_long mode %d soft %d: %d / %d" % (mode, soft, same, batch.n_paths))
-    assert same >= 0.9 * batch.n_paths, same
+    assert same >= batch.n_paths - 1, same   # measured 48 / 48 in every mode: one comparison may flip on a 1e-9 difference of the solves
     assert np.all(out["times"] >= 0.01)
     assert util.continuity_defect(batch, out["coeffs"], out["times"]) < 1e-9
 
@@ -126,5 +126,5 @@ def test_time_and_constraints_long_budget(gpu_ctx):
                 util.coeff_error(out["coeffs"][a:b], ref["coeffs"][a:b]) < 1e-5:
             same += 1
     print("RATE dfo_tc_long: %d / %d" % (same, batch.n_paths))
-    assert same >= 0.8 * batch.n_paths, same
+    assert same >= batch.n_paths - 1, same   # measured 24 / 24
     assert util.continuity_defect(batch, out["coeffs"], out["times"]) < 1e-9

@@ -115,7 +115,7 @@ def test_nonlinear_compact_mapping_matches_split_mapping(gpu_ctx):
                 np.max(np.abs(out["times"][a:b] - small["times"][10 * k:10 * k + 10]) / small["times"][10 * k:10 * k + 10]) < 1e-7:
             agree += 1
     print("RATE compact_vs_split: %d / %d" % (agree, len(idx)))
-    assert agree >= 0.97 * len(idx), agree
+    assert agree >= len(idx) - 1, agree   # measured 120 / 120
     # and against the oracle on a handful
     few = idx[:12]
     ref = po.solve_batch(batch.select(few).seg_offsets, batch.select(few).waypoints, batch.select(few).fixed_mask,

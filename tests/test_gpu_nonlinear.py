@@ -129,7 +129,7 @@ def test_nonlinear_moving_start_end_to_end_vs_oracle(gpu_ctx):
     same = (out["status"] == ref["status"]) & (out["n_samples"] == np.minimum(ref["n_samples"], cap + 1))
     print("RATE walk: 1e-6 %.4f" % (dt < 1e-6).mean())
     assert same.all(), same.mean()
-    assert (dt < 1e-6).mean() >= 0.99, (dt < 1e-6).mean()
+    assert (dt < 1e-6).mean() >= 0.995, (dt < 1e-6).mean()   # measured 100 %
 
 
 def test_segment_maxima_vs_oracle_and_exact(gpu_ctx, golden):
@@ -342,8 +342,10 @@ def test_mixed_constraint_patterns_vs_oracle(gpu_ctx, deriv):
     # 
     print("RATE mixed deriv %d: 1e-6 %.4f 1e-3 %.4f" % (deriv, (dt < 1e-6).mean(), (dt < 1e-3).mean()))
     assert same.all(), same.mean()
-    assert (dt < 1e-6).mean() >= 0.985, (dt < 1e-6).mean()
-    assert (dt < 1e-3).mean() >= 0.995, (dt < 1e-3).mean()
+    # round 3: 99.48 % / 99.09 % / 99.35 % to 1e-6, 100 % / 100 % / 99.87 % to 1e-3; where the rest comes from:
+    # profiles/round3_divergence_*.txt (scripts/divergence_histogram.py)
+    assert (dt < 1e-6).mean() >= 0.988, (dt < 1e-6).mean()
+    assert (dt < 1e-3).mean() >= 0.998, (dt < 1e-3).mean()
 
 
 @pytest.mark.parametrize("dt,cap", [(0.01, 16384), (0.05, 4096), (0.5, 256), (1.0, 128), (0.3, 512)])

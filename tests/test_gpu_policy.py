@@ -32,7 +32,7 @@ def test_policy_loop_matches_oracle(gpu_ctx, deriv):
                 same += 1
                 assert abs(out["max_deviation"][p] - ref["max_deviation"]) < 1e-6
     print("RATE policy deriv %d: %d / %d" % (deriv, same, len(paths)))
-    assert same >= 0.9 * len(paths), same
+    assert same >= len(paths) - 1, same   # measured 24 / 24 for both objectives
 
 
 def test_policy_with_initial_state_stop_at_and_relaxed_heading(gpu_ctx):
