@@ -1392,6 +1392,9 @@ __device__ __forceinline__ void optimize_body(const BatchView& b, const Nonlinea
   int* tick_i = reinterpret_cast<int*>(tick_f + 2);
   double* vtx = tick_f + kTickState;  // [(Sb + 1) * kVtxLds]
   double* seg = vtx + (size_t)(Sb + 1) * kVtxLds + (kExtras ? kStartExtra : 0);  // [Sb * kSegLds], the moving-start extras in front
+  // the start times are requested in front of the vertex staging (one trip to memory instead of two in a row)
+  double t_first = 0.0;
+  if (active && wave == 0 && g < S) t_first = seg_times[pr.s0 + g];
   if (LEAN) {  // vtx = the evaluation area: dp of every segment; the path's eligibility decides who runs it
     const bool takes = stage_ps(mask, vals, pr.v0, S, Sb, vtx, g, G, active, 2, d, MASKED4);
     if (active && g == 0) fallback[q] = takes ? 0 : 1;
@@ -1406,13 +1409,14 @@ __device__ __forceinline__ void optimize_body(const BatchView& b, const Nonlinea
   int ok = 1;
   if (active && wave == 0) {
     double t_sum = 0.0;
-    for (int i = g; i < S; i += G) {
-      const double t = seg_times[pr.s0 + i];
+    auto take = [&](int i, double t) {
       x[i] = t;
       xn[i] = t;
       t_sum += t;
       if (t < kTimeLowerBound) ok = 0;
-    }
+    };
+    if (g < S) take(g, t_first);
+    for (int i = g + G; i < S; i += G) take(i, seg_times[pr.s0 + i]);
     // the total time the search starts from: what the final solve measures a runaway of the feasibility scaling against
     t_sum = group_sum(t_sum, G);
     if (g == 0 && prm.sum_t0) prm.sum_t0[pr.p] = t_sum;

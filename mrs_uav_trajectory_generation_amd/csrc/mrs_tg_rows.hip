@@ -319,6 +319,11 @@ __device__ __forceinline__ void solve_rows_body(const BatchView& b, int d, int p
                                                 double* __restrict__ cost, const int32_t* __restrict__ status_in,
                                                 const RowsTail& tail, int block) {
   extern __shared__ double lds[];
+  // every kernel argument the staging pass reads is wanted in SGPRs HERE: left alone the compiler fetches them from the
+  // kernarg segment where they are first used -- four s_load / s_waitcnt round trips strung through the staging code, each
+  // an exposed scalar-cache miss on the only wavefront of its SIMD -- instead of in one batch at the top
+  asm volatile("" ::"s"(mask), "s"(vals), "s"(seg_times), "s"(coeffs), "s"(status), "s"(cost), "s"(status_in), "s"(d), "s"(ppw),
+               "s"(Smax), "s"(b.n_paths), "s"(b.uniform_S), "s"(b.order), "s"(b.seg_offsets));
   const int lane = threadIdx.x;
   const int q0 = block * ppw;
   const int n_here = min(ppw, b.n_paths - q0);
@@ -367,6 +372,7 @@ __device__ __forceinline__ void solve_rows_body(const BatchView& b, int d, int p
         ps_first[kD + dd] = ps[kHalf * kD + dd];
       }
     }
+    MRS_TG_PHASE_MARK(20);  // constants and the first segment round requested
     for (int v = lane; v <= S_t; v += 64) {
       double f[kHalf][kD];
       bool pos_fixed;
@@ -385,6 +391,7 @@ __device__ __forceinline__ void solve_rows_body(const BatchView& b, int d, int p
       for (int e = 0; e < kNB * kD; ++e) r[kRVtxX + e] = 0.0;  // stays for a fully constrained end vertex, which nobody solves
       pos_ok_lane = pos_ok_lane && pos_fixed;
     }
+    MRS_TG_PHASE_MARK(21);  // vertices staged
     const int p_t = __builtin_amdgcn_readlane(pr.p, tt * 16);
     // segment `i` of the path: its record from its time and the constrained positions of its two vertices
     auto stage_segment = [&](int i, double T, const double (&pp)[2 * kD]) {
@@ -424,6 +431,7 @@ __device__ __forceinline__ void solve_rows_body(const BatchView& b, int d, int p
       }
       stage_segment(i, seg_times[s0_t + i], pp);
     }
+    MRS_TG_PHASE_MARK(22);  // segments staged
     pos_bad[tt] = __ballot(!pos_ok_lane);
     gen_any[tt] = __ballot(nonzero_lane);
   }

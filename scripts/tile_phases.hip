@@ -122,6 +122,8 @@ int main(int argc, char** argv) {
            "build %lld  forward %lld  middle vertex %lld  backward %lld  recover %lld  total %lld\n",
            P, S, ppw, ms * 1e3 / n, clk[1] - clk[0], clk[10] - clk[1], clk[11] - clk[10], clk[12] - clk[11], clk[4] - clk[12],
            clk[5] - clk[4], clk[5] - clk[0]);
+    printf("   inside stage (last path of the wavefront): requests issued %lld  vertices in LDS %lld  segments in LDS %lld  fence %lld\n",
+           clk[20] - clk[0], clk[21] - clk[20], clk[22] - clk[21], clk[1] - clk[22]);
   }
   // sampler: serial walk (lane 0) and parallel evaluation, dt 0.2, capacity 512
   {
