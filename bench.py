@@ -206,6 +206,30 @@ def back_to_back_ms(launch_fn, reps, torch):
     return e0.elapsed_time(e1) / reps
 
 
+def host_parallelism():
+    """(threads the process may run on, CPUs' worth of time its cgroup grants or None): the box reports 256 hardware threads,
+    but a container's cpu.max quota is what bounds an all-core CPU baseline (16 CPUs on the GPU boxes of this pool)."""
+    try:
+        visible = len(os.sched_getaffinity(0))
+    except (AttributeError, OSError):
+        visible = os.cpu_count() or 1
+    quota = None
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as fh:
+            q, per = fh.read().split()[:2]
+        if q != "max":
+            quota = float(q) / float(per)
+    except (OSError, ValueError):
+        try:
+            with open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us") as fq, open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as fp:
+                q, per = float(fq.read()), float(fp.read())
+            if q > 0:
+                quota = q / per
+        except (OSError, ValueError):
+            quota = None
+    return visible, quota
+
+
 def measured_traffic(n_paths, n_seg):
     """HBM traffic of the assembly kernel from the newest committed PMC summary (separate rocprofv3 --pmc passes,
     scripts/pmc_assemble.py; MI355X_MICROARCH.md corrections applied there).  Not measured in this run."""
@@ -801,7 +825,9 @@ def main():
             worst = max(worst, float(np.max(np.abs(gpu_c[a:b] - ref["coeffs"][a:b])) / np.max(np.abs(ref["coeffs"][a:b]))))
         err = worst
         # all cores: the oracle's persistent thread pool on a configs[3]-sized batch (the 1024 paths tiled 64 times)
-        cores = os.cpu_count() or 1
+        visible, quota = host_parallelism()
+        # as many threads as the cgroup grants CPUs (more only queue behind the quota's throttling); all visible ones without a quota
+        cores = max(1, min(visible, int(quota + 0.5))) if quota else visible
         tile = max(1, CONFIG3_PATHS // n_cpu)
         parts = [sub.path(p) for p in range(sub.n_paths)] * tile
         big = pr.assemble_batch(parts, np.tile(sub.limits, (tile, 1)))
@@ -818,7 +844,8 @@ def main():
         cpu = dict(value=n_cpu / dt1, unit="trajectories/s", cores=1, kind="port",
                    sample="%d x the first %d of the %d paths of this batch (%.1f s of one core), linear QP, C oracle "
                           "(reference-style arithmetic, dense QR)" % (reps_cpu, n_cpu, P, reps_cpu * dt1),
-                   value_all_cores=big.n_paths / dtn, cores_all=cores,
+                   value_all_cores=big.n_paths / dtn, cores_all=cores, host_threads_visible=visible,
+                   cpu_quota_cpus=quota,
                    sample_all_cores="%d x a batch of %d paths (the same %d paths tiled), %d threads of the oracle's "
                                     "persistent pool, dynamic chunks" % (reps_all, big.n_paths, n_cpu, cores))
         if args.workload == "nonlinear" or not args.no_extras:

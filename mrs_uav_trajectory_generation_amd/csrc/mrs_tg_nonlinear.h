@@ -23,6 +23,7 @@ struct NonlinearParams {
   int32_t* careful_count = nullptr;
   int32_t* careful_list = nullptr;
   int careful_cap = 0;
+  int32_t* queue_next = nullptr;  // lean kernel of a uniform batch larger than the device holds at once: next unclaimed position of the bin
   double* sum_t0 = nullptr;  // [n_paths] by path: sum of the times the search starts from (the runaway test of the final solve)
 };
 
@@ -54,6 +55,7 @@ struct NonlinearPlan {
   size_t ws_doubles = 0;
   int32_t* d_opt_status = nullptr; // stopping reason of the outer loop per path
   double* d_maxima = nullptr;      // [n_segments][9] per-segment maxima
+  int32_t* d_queue = nullptr;      // the lean kernel's path queue (one counter)
   double* d_sum_t0 = nullptr;      // [n_paths] sum of the times the outer loop started from (runaway test)
   int32_t* d_fallback = nullptr;   // [n_paths] by position: 1 = the prefix / suffix kernel left the path to the sweeping kernel
   int32_t* d_careful = nullptr;    // [0] count, [2] count of the last completed call, [4..] list of guarded paths

@@ -1362,12 +1362,12 @@ __device__ __forceinline__ void optimize_body(const BatchView& b, const Nonlinea
   const int per_block = 64 >> g_shift;
   const int qi = block_in_bin * per_block + grp;
   bool active = qi < q_count;
-  const int q = q_begin + (active ? qi : 0);
+  int q = q_begin + (active ? qi : 0);  // (LEAN with a queue: a lane group takes further paths once its own is done)
   if (!CAREFUL && !LEAN && prm.only_flagged) {  // the plain-path kernel in front of this launch took the other paths
     active = active && prm.only_flagged[q] != 0;
     if (!__syncthreads_or(active ? 1 : 0)) return;  // (an all-plain batch: every workgroup ends here)
   }
-  const PathRef pr = path_at(b, q);
+  PathRef pr = path_at(b, q);
   int S = pr.S;
   const int d = prm.derivative;
 
@@ -1421,7 +1421,7 @@ __device__ __forceinline__ void optimize_body(const BatchView& b, const Nonlinea
     t_sum = group_sum(t_sum, G);
     if (g == 0 && prm.sum_t0) prm.sum_t0[pr.p] = t_sum;
   }
-  const bool bad = active && wave == 0 && !group_and(ok, G);
+  bool bad = active && wave == 0 && !group_and(ok, G);
   __syncthreads();
   MRS_TG_PHASE_MARK(1);
 
@@ -1491,7 +1491,95 @@ __device__ __forceinline__ void optimize_body(const BatchView& b, const Nonlinea
   bool first = true;
   if (g == 0) tick_i[4] = 0;  // set by an evaluation whose by-product cost failed the guard
 
+  // hands in the result of the group's path: the last evaluated point and the stopping reason
+  auto retire = [&]() {
+    // a path whose cost failed the guard somewhere is handed to the careful re-run: listed, start times left in place
+    bool listed = false;
+    if (!CAREFUL && prm.careful_count && !bad && tick_i[4] != 0) {
+      int okl = 0;
+      if (g == 0) {
+        const int idx = atomicAdd(prm.careful_count, 1);
+        okl = idx < prm.careful_cap;
+        if (okl) prm.careful_list[idx] = q;
+      }
+      listed = __shfl(okl, (int)(threadIdx.x & ~(unsigned)(G - 1)), 64) != 0;
+    }
+    // the path's offsets are looked up again rather than carried (as addresses, in registers or scratch) through the ticks
+    int q_again = q;
+    asm volatile("" : "+v"(q_again));
+    const PathRef pe = path_at(b, q_again);
+    if (!listed)
+      for (int i = g; i < S; i += G) seg_times[pe.s0 + i] = x[i];
+    if (g == 0) opt_status[pe.p] = bad ? -2 : ret;
+  };
+  // LEAN with a queue (uniform batches of more wavefronts than the device holds at once: the launch is as many workgroups as
+  // are resident, and a lane group whose path has stopped takes the next unclaimed one): `busy` = the group holds a path
+  // whose result has not been handed in
+  const bool queued = LEAN && prm.queue_next != nullptr;
+  bool busy = active;
+  bool queue_empty = false;
+
   while (true) {
+    if (queued) {
+      // Without the queue a wavefront runs until the slowest of its four paths has stopped (1 to 10 evaluations, 3.6 on
+      // average) and a launch of eight residency rounds pays that maximum eight times.
+      if (busy && done) {
+        retire();
+        busy = false;
+      }
+      bool want = !busy && !queue_empty;
+      while (__ballot(want) != 0ull) {
+        if (want) {
+          int qn = 0;
+          if (g == 0) qn = atomicAdd(prm.queue_next, 1);
+          qn = __shfl(qn, (int)(threadIdx.x & ~(unsigned)(G - 1)), 64);
+          if (qn >= q_count) {
+            queue_empty = true;
+            want = false;
+          } else {
+            q = q_begin + qn;
+            pr = path_at(b, q);
+            S = pr.S;
+            active = true;
+            double t_new = (g < S) ? seg_times[pr.s0 + g] : 0.0;
+            const bool takes = stage_ps(mask, vals, pr.v0, S, Sb, vtx, g, G, true, 2, d, MASKED4);
+            if (g == 0) fallback[q] = takes ? 0 : 1;
+            if (takes) {
+              int okn = 1;
+              double t_sum = 0.0;
+              auto take = [&](int i, double t) {
+                x[i] = t;
+                xn[i] = t;
+                t_sum += t;
+                if (t < kTimeLowerBound) okn = 0;
+              };
+              if (g < S) take(g, t_new);
+              for (int i = g + G; i < S; i += G) take(i, seg_times[pr.s0 + i]);
+              t_sum = group_sum(t_sum, G);
+              if (g == 0 && prm.sum_t0) prm.sum_t0[pr.p] = t_sum;
+              bad = !group_and(okn, G);
+              neval = 0;
+              npairs = 0;
+              head = 0;
+              f = 0.0;
+              alpha = 1.0;
+              ret = -1;
+              if (g == 0) tick_i[4] = 0;
+              busy = true;
+              done = bad;
+              want = false;
+              if (bad) {  // a start below the lower bound: nothing to search, hand it in and look for another path
+                retire();
+                busy = false;
+                want = true;
+              }
+            }
+            // (a path the lean sweeps do not take stays flagged for the general kernel: the group asks again)
+          }
+        }
+      }
+      ps_wave_sync();
+    }
     if (__ballot(!done) == 0ull) break;
     // park the scalar state (see kTickState)
     if (g == 0) {
@@ -1859,26 +1947,8 @@ __device__ __forceinline__ void optimize_body(const BatchView& b, const Nonlinea
   }
   MRS_TG_PHASE_MARK(5);
 
-  if (active) {
-    // a path whose cost failed the guard somewhere is handed to the careful re-run: listed, start times left in place
-    bool listed = false;
-    if (!CAREFUL && prm.careful_count && !bad && tick_i[4] != 0) {
-      int ok = 0;
-      if (g == 0) {
-        const int idx = atomicAdd(prm.careful_count, 1);
-        ok = idx < prm.careful_cap;
-        if (ok) prm.careful_list[idx] = q;
-      }
-      listed = __shfl(ok, (int)(threadIdx.x & ~(unsigned)(G - 1)), 64) != 0;
-    }
-    // the path's offsets are looked up again rather than carried (as addresses, in registers or scratch) through the ticks
-    int q_again = q;
-    asm volatile("" : "+v"(q_again));
-    const PathRef pe = path_at(b, q_again);
-    if (!listed)
-      for (int i = g; i < S; i += G) seg_times[pe.s0 + i] = x[i];
-    if (g == 0) opt_status[pe.p] = bad ? -2 : ret;
-  }
+  if (active && !queued) retire();
+  if (queued && busy) retire();
 }
 
 // One dimension per lane (small batches): up to two wavefronts per path, and at most 256 VGPRs so that both sit on one
@@ -1898,6 +1968,8 @@ __global__ __launch_bounds__(64) void optimize_compact_kernel(BatchView b, Nonli
                                                               int32_t* __restrict__ opt_status) {
   optimize_body<1, MASKED4>(b, prm, bins, mask, vals, seg_times, opt_status);
 }
+
+__global__ void set_queue_kernel(int32_t* __restrict__ queue, int32_t first_unclaimed) { *queue = first_unclaimed; }
 
 __global__ void set_deadline_kernel(long long* __restrict__ deadline, long long budget_ticks) {
   *deadline = (long long)wall_clock64() + budget_ticks;
@@ -2461,6 +2533,8 @@ void nonlinear_plan_free(NonlinearPlan& nl) {
   if (nl.d_maxima) (void)mrs_tg::pool_free(nl.d_maxima);
   if (nl.d_sum_t0) (void)mrs_tg::pool_free(nl.d_sum_t0);
   nl.d_sum_t0 = nullptr;
+  if (nl.d_queue) (void)mrs_tg::pool_free(nl.d_queue);
+  nl.d_queue = nullptr;
   if (nl.d_careful) (void)mrs_tg::pool_free(nl.d_careful);
   nl.d_careful = nullptr;
   if (nl.d_fallback) (void)mrs_tg::pool_free(nl.d_fallback);
@@ -2598,6 +2672,23 @@ hipError_t launch_nonlinear(NonlinearPlan& nl, const BatchView& b, const Nonline
       blocks += (int)cdiv_u(bin.q_count, 64 / bin.group);
       plds = std::max(plds, plain_lds(bin));
     }
+    // A uniform batch of more wavefronts than the device holds at once (two per SIMD): launch what is resident and let a
+    // lane group whose path has stopped claim the next one (optimize_body, `queued`), instead of eight rounds of wavefronts
+    // that each last as long as the slowest of their four paths.  65536 x 10: 780 -> us.
+    prm.queue_next = nullptr;
+    static const int resident_blocks = [] {
+      if (const char* e = std::getenv("MRS_TG_LEAN_RESIDENT_BLOCKS")) return std::atoi(e);  // tuning knob; 0 = no queue
+      int dev = 0, cus = 256;
+      if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+      return cus * 4 * MRS_TG_LEAN_WAVES;
+    }();
+    if (bt.n == 1 && resident_blocks > 0 && blocks > resident_blocks) {
+      if (!nl.d_queue && (e = mrs_tg::pool_alloc(&nl.d_queue, sizeof(int32_t) * 4)) != hipSuccess) return e;
+      blocks = resident_blocks;
+      hipLaunchKernelGGL(set_queue_kernel, dim3(1), dim3(1), 0, stream, nl.d_queue, blocks * (64 / bt.group[0]));
+      if ((e = hipGetLastError()) != hipSuccess) return e;
+      prm.queue_next = nl.d_queue;
+    }
     const bool lean_masked = prm.derivative < 4;  // rest-to-rest paths end on vertices with free slots
     if (plds > 64 * 1024 &&
         (e = hipFuncSetAttribute(lean_masked ? (const void*)optimize_lean_masked_kernel : (const void*)optimize_lean_kernel,
@@ -2611,6 +2702,7 @@ hipError_t launch_nonlinear(NonlinearPlan& nl, const BatchView& b, const Nonline
                             seg_times, nl.d_opt_status, nl.d_fallback);
     if ((e = hipGetLastError()) != hipSuccess) return e;
     prm.only_flagged = nl.d_fallback;
+    prm.queue_next = nullptr;
   }
   {
     BinTable bt{};
