@@ -363,6 +363,19 @@ __device__ __forceinline__ void solve_rows_body(const BatchView& b, int d, int p
     // compiler otherwise issues them after the vertex loop's stores, and the time after the positions -- three trips to
     // memory in a row
     double T_first = 1.0, ps_first[2 * kD] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+    const int p_t = __builtin_amdgcn_readlane(pr.p, tt * 16);
+    // TAIL with feasibility scaling: the segment's nine maxima, the path's nine limits and the search's stopping reason are
+    // requested here as well (behind the segment's time they were two more trips to memory in a row)
+    double mx_first[9] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0}, lim_first[9] = {1.0, 1.0, 1.0, 1.0, 1.0, 1.0, 1.0, 1.0, 1.0};
+    int st_first = -2;
+    if (TAIL && tail.maxima && lane < S_t) {
+      st_first = tail.opt_status[p_t];
+#pragma unroll
+      for (int e = 0; e < 9; ++e) {
+        mx_first[e] = tail.maxima[(size_t)(s0_t + lane) * 9 + e];
+        lim_first[e] = tail.limits[(size_t)p_t * 9 + e];
+      }
+    }
     if (lane < S_t) {
       T_first = seg_times[s0_t + lane];
       const double* ps = vals + (size_t)(v0_t + lane) * kHalf * kD;
@@ -392,11 +405,10 @@ __device__ __forceinline__ void solve_rows_body(const BatchView& b, int d, int p
       pos_ok_lane = pos_ok_lane && pos_fixed;
     }
     MRS_TG_PHASE_MARK(21);  // vertices staged
-    const int p_t = __builtin_amdgcn_readlane(pr.p, tt * 16);
     // segment `i` of the path: its record from its time and the constrained positions of its two vertices
-    auto stage_segment = [&](int i, double T, const double (&pp)[2 * kD]) {
+    auto stage_segment = [&](int i, double T, const double (&pp)[2 * kD], int opt_st, const double* mx, const double* lim) {
       if (TAIL && tail.maxima) {  // feasibility scaling of this segment (trajectory.cpp:625-657), then the solve at the scaled times
-        if (tail.opt_status[p_t] != -2) T *= violation_scaling(tail.maxima + (size_t)(s0_t + i) * 9, tail.limits + (size_t)p_t * 9);
+        if (opt_st != -2) T *= violation_scaling(mx, lim);
         tail.seg_times_out[s0_t + i] = T;
       }
       double* r = sb + (size_t)i * kRSegRec;
@@ -420,7 +432,7 @@ __device__ __forceinline__ void solve_rows_body(const BatchView& b, int d, int p
     // the first round works on what was requested in front of the vertex loop; written as a select inside one loop the
     // compiler loaded time and positions again (a second trip to memory behind the first, ~800 cycles on the only wavefront
     // of its SIMD)
-    if (lane < S_t) stage_segment(lane, T_first, ps_first);
+    if (lane < S_t) stage_segment(lane, T_first, ps_first, st_first, mx_first, lim_first);
     for (int i = lane + 64; i < S_t; i += 64) {  // paths of more than 64 segments
       const double* ps = vals + (size_t)(v0_t + i) * kHalf * kD;  // constrained position of vertex i, then of i + 1
       double pp[2 * kD];
@@ -429,7 +441,8 @@ __device__ __forceinline__ void solve_rows_body(const BatchView& b, int d, int p
         pp[dd] = ps[dd];
         pp[kD + dd] = ps[kHalf * kD + dd];
       }
-      stage_segment(i, seg_times[s0_t + i], pp);
+      stage_segment(i, seg_times[s0_t + i], pp, (TAIL && tail.maxima) ? tail.opt_status[p_t] : -2,
+                    tail.maxima + (size_t)(s0_t + i) * 9, tail.limits + (size_t)p_t * 9);
     }
     MRS_TG_PHASE_MARK(22);  // segments staged
     pos_bad[tt] = __ballot(!pos_ok_lane);
