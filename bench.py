@@ -26,15 +26,21 @@ MAX over ranks.  BASELINE configs[3] in its own terms -- ONE batch of 65536 nonl
 over the N ranks, results gathered to rank 0 INSIDE its timed region -- is measured in the same run at every N and reported
 as extras.config3 and, in short, as the top-level `config3_strong_scaling` (strong scaling of a fixed batch).
 
-Steps are independent batches, so `--in-flight` of them (default 4 = the HIP runtime's hardware queues per process) are kept
-in flight per GPU, each on its own HIP stream with its own context and plan; extras.one_batch_in_flight is the same
-measurement with one stream (each step waits for the previous).
+Steps are independent batches -- every step is a full pass over its own batch into its own output arrays -- so `--in-flight`
+of them (default 10) are kept in flight per GPU.  `--issue grouped` (default): `--group-size` (5) consecutive steps go out as
+ONE dispatch (mrs_tg_bound_solve_launch_group: the single-batch solve kernel's body, its workgroups divided among the
+batches), the dispatches alternating over two HIP streams; a runtime launch costs the host 3 us, so twenty one-step launches
+were half of the driver's 20-step timed region.  `--issue streams` is round 2's method -- one dispatch per step, round-robin over
+`--streams` (4 = the hardware queues the runtime gives a process) HIP streams with their own contexts and plans -- and is
+reported as extras.streams_in_flight; extras.one_batch_in_flight is one stream, every step waiting for the previous.  The
+nonlinear workload keeps one batch in flight per stream.
 
 Prints ONE JSON line (rank 0): `roofline` (assembly kernel, HBM-write bound; `achieved` uses the PER-DISPATCH duration --
 events attached to the kernel launch itself, what rocprofv3 --kernel-trace reports for the dispatch; the back-to-back
 launch interval is given beside it and labelled), `roofline_solve` / `roofline_outer_loop` (FP64, flop model of SURVEY.md 8d
 over the per-dispatch duration), and `cpu_baseline` (the C oracle on this box's host cores: one core, and all cores through
-its persistent thread pool on the configs[3]-sized batch).
+its persistent thread pool on the configs[3]-sized batch -- with as many threads as the container's cgroup grants CPUs,
+`cpu_quota_cpus`, when that is less than the hardware threads it sees).
 """
 import argparse
 import glob
