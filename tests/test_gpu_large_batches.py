@@ -124,3 +124,27 @@ def test_nonlinear_compact_mapping_matches_split_mapping(gpu_ctx):
     good = sum(1 for k, p in enumerate(few)
                if np.max(np.abs(out["times"][10 * p:10 * p + 10] - ref["times"][10 * k:10 * k + 10]) / ref["times"][10 * k:10 * k + 10]) < 1e-6)
     assert good >= len(few) - 1
+
+
+def test_separate_sampler_equals_the_sampler_in_the_solve_kernels_tail(gpu_ctx):
+    """Above 2048 paths the samples come from sample_kernel (its own launch), below from the tail of solve_rows_kernel: the
+    same walk -- the reference's additions in the reference's order -- so sample counts and every sample agree bit for bit, on
+    uniform and ragged paths, with a capacity some paths overflow, and with a path that ends exactly on a sample time.
+    (Round 3 also built a one-lane-per-path walk for large batches -- 64 paths per wavefront, the pair (time in segment,
+    segment) parked in the sample's own output slot, a second kernel evaluating it; bit-identical by this test and three times
+    SLOWER at 8192 paths, 147 + 41 us against 52: the lane-private 16-byte stores of the walk cost a memory round trip per
+    sample.  Not kept)"""
+    for batch, cap in ((pr.random_batch(4608, 10, seed0=40), 192), (pr.random_batch(4100, "ragged", seed0=41), 160)):
+        times = gpu_ctx.solve_batch(batch, None)["times"]
+        times[:10] = 1.0    # 10 s at dt 0.2: the last sample falls on the end time (the carry test decides)
+        big = gpu_ctx.solve_batch(batch, times, sampling_dt=0.2, sample_capacity=cap)
+        assert (big["n_samples"] == cap + 1).any() and (big["n_samples"] <= cap).any()
+        so = batch.seg_offsets
+        for a in range(0, batch.n_paths, 1024):
+            idx = list(range(a, min(a + 1024, batch.n_paths)))
+            sub = batch.select(idx)
+            small = gpu_ctx.solve_batch(sub, times[so[idx[0]]:so[idx[-1] + 1]], sampling_dt=0.2, sample_capacity=cap)
+            assert np.array_equal(small["n_samples"], big["n_samples"][idx])
+            for k, p in enumerate(idx):
+                n = min(int(small["n_samples"][k]), cap)
+                assert np.array_equal(small["samples"][k, :n], big["samples"][p, :n]), p
