@@ -55,7 +55,7 @@ enum {
                                       was not asked for.  Every caller of the reference constrains the position of every
                                       vertex (src/...cpp:944, 963, 967) and the fast kernels rely on it; the general
                                       fixed / free patterns of setupConstraintReorderingMatrix (linear_impl.h:184-257)
-                                      are solved in fixed-times mode under MRS_TG_FLAG_GENERAL_PATTERNS */
+                                      are solved under MRS_TG_FLAG_GENERAL_PATTERNS (every mode) */
   MRS_TG_STATUS_ROUNDOFF_LIMITED = -4, /* nlopt::ROUNDOFF_LIMITED, which the nodelet rejects (:1103-1106, 1146-1149).  Mellinger
                                       mode: the feasibility scaling that follows the outer loop has multiplied the path's
                                       total time by more than MRS_TG_RUNAWAY_TIME_FACTOR -- the outer loop ended on a point
@@ -100,13 +100,15 @@ enum {
                                          device (one context + stream each), so small batches are launched in shapes that
                                          leave wavefront slots to the other streams instead of minimising the latency of
                                          this one launch */
-  MRS_TG_FLAG_GENERAL_PATTERNS = 16,  /* fixed-times mode: some vertices may leave their POSITION free (setupFromVertices takes
-                                         any fixed / free pattern, linear_impl.h:184-257; the nodelet never builds such a
-                                         vertex).  The fast kernels return those paths with status -2; with this flag a
-                                         general kernel (5 x 5 vertex blocks, mrs_tg_general.hip) solves them afterwards.
-                                         mrs_tg_solve_batch sets it by itself when its host copy of fixed_mask shows such a
-                                         vertex; callers of the device-pointer interface say so.  The time-allocation modes
-                                         do not take such paths (status -2 stays) */
+  MRS_TG_FLAG_GENERAL_PATTERNS = 16,  /* some vertices may leave their POSITION free (setupFromVertices takes any fixed / free
+                                         pattern, linear_impl.h:184-257; the nodelet never builds such a vertex).  The fast
+                                         kernels return those paths with status -2; with this flag they take a general route
+                                         behind the fast kernels, in every time_alloc_method: 5 x 5 vertex blocks
+                                         (mrs_tg_general.hip) for every linear solve of the pipeline, and in Mellinger mode
+                                         the outer loop with that solve as its evaluation (optimize_general_kernel).  The
+                                         other paths of the batch are the fast kernels' results, bit for bit.
+                                         mrs_tg_solve_batch sets the flag by itself when its host copy of fixed_mask shows
+                                         such a vertex; callers of the device-pointer interface say so */
   MRS_TG_FLAG_CAREFUL_COST = 8        /* Mellinger mode: paths on which a trial point's cost lost its digits in the fast
                                          evaluation (a segment on the 0.01 s bound next to long neighbours; about 0.3 % of
                                          random 10-segment paths) are run again with the cost the reference computes,

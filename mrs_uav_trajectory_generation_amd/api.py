@@ -27,7 +27,7 @@ TIME_ALLOC_SQUARED_TIME_AND_CONSTRAINTS = 3
 TIME_ALLOC_RICHTER_TIME_AND_CONSTRAINTS = 4
 FLAG_FUSED_ASSEMBLY = 1        # the default since ABI 2
 FLAG_MATERIALIZED_BLOCKS = 2   # assembly kernel + solve from the materialised H / A^-1 blocks
-FLAG_GENERAL_PATTERNS = 16     # fixed-times mode: vertices without a position constraint may occur (general 5 x 5 solver)
+FLAG_GENERAL_PATTERNS = 16     # vertices without a position constraint may occur (general 5 x 5 route, every mode)
 FLAG_CAREFUL_COST = 8          # Mellinger mode: re-run the paths whose fast cost evaluation failed its guard with primal costs
 FLAG_SHARED_DEVICE = 4         # hint: several batches are in flight on this device (results unaffected)
 

@@ -494,7 +494,8 @@ int mrs_tg_plan_solve(mrs_tg_plan* plan, const double* wp, const uint8_t* mask, 
     prm.initial_stepsize_rel = opt->initial_stepsize_rel;
     prm.time_budget_ticks = opt->max_time_s > 0 ? budget_ticks(ctx, opt->max_time_s) : 0;
     ProfileScope ps(ctx, 2);
-    HIP_TRY(ctx, mrs_tg::launch_dfo(plan->nl, b, prm, mask, vals, limits, seg_times, coeffs, status, cost, ctx->stream));
+    HIP_TRY(ctx, mrs_tg::launch_dfo(plan->nl, b, prm, mask, vals, limits, seg_times, coeffs, status, cost, ctx->stream,
+                                    (opt->flags & MRS_TG_FLAG_GENERAL_PATTERNS) != 0));
   } else if (opt->time_alloc_method == MRS_TG_TIME_ALLOC_MELLINGER) {
     mrs_tg::NonlinearParams prm;
     prm.derivative = d;
@@ -507,7 +508,8 @@ int mrs_tg_plan_solve(mrs_tg_plan* plan, const double* wp, const uint8_t* mask, 
     prm.careful_cap = (opt->flags & MRS_TG_FLAG_CAREFUL_COST) ? 1 : 0;
     ProfileScope ps(ctx, 2);
     HIP_TRY(ctx, mrs_tg::launch_nonlinear(plan->nl, b, prm, mask, vals, limits, seg_times, coeffs, status, cost, ctx->stream,
-                                          opt->sampling_dt, opt->sample_capacity, n_samples, samples, &sampled));
+                                          opt->sampling_dt, opt->sample_capacity, n_samples, samples, &sampled,
+                                          (opt->flags & MRS_TG_FLAG_GENERAL_PATTERNS) != 0));
   } else {
     const bool fused = (opt->flags & MRS_TG_FLAG_MATERIALIZED_BLOCKS) == 0;  // the default since ABI 2
     const bool general = (opt->flags & MRS_TG_FLAG_GENERAL_PATTERNS) != 0;   // position-free vertices may occur
@@ -954,7 +956,7 @@ int mrs_tg_solve_batch(mrs_tg_ctx* ctx, int32_t n_paths, const int32_t* so, cons
   } sync_on_exit{s};
 
   mrs_tg_options local = *opt;
-  if (local.time_alloc_method == MRS_TG_TIME_ALLOC_NONE && !(local.flags & MRS_TG_FLAG_GENERAL_PATTERNS)) {
+  if (!(local.flags & MRS_TG_FLAG_GENERAL_PATTERNS)) {
     // the masks are in host memory here: a vertex without a position constraint switches the general solver on
     for (size_t v = 0; v < nV; ++v)
       if (mask[v * 5] == 0) {

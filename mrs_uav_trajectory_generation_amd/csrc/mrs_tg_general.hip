@@ -7,247 +7,55 @@
 // derivative slots 1..4, a path with a position-free vertex comes back from them with status -2.  This kernel solves those
 // paths: the same block-tridiagonal elimination with 5 x 5 vertex blocks (slots 0..4) and masks over all five, none of the
 // specialisations, one lane per (path, dimension) with the factors parked in global memory, coefficients and the cost
-// 0.5 c^T Q c on the way back.  Launched only when the caller says such vertices may occur
-// (MRS_TG_FLAG_GENERAL_PATTERNS; mrs_tg_solve_batch sees it in its host copy of the masks), fixed-times mode only.
+// 0.5 c^T Q c on the way back (mrs_tg_general.hpp).  Launched only when the caller says such vertices may occur
+// (MRS_TG_FLAG_GENERAL_PATTERNS; mrs_tg_solve_batch sees it in its host copy of the masks): behind the fast solve of the
+// fixed-times mode, and behind every fast solve of the time-allocation pipelines (mrs_tg_nonlinear.hip).
 #include <hip/hip_runtime.h>
 
 #include <cstdint>
 
-#include "mrs_tg_device.hpp"
+#include "mrs_tg_general.hpp"
 #include "mrs_tg_launch.h"
 
 namespace mrs_tg {
-
-constexpr int kGB = kHalf;                     // unknowns per vertex: derivative orders 0..4
-constexpr int kGTri = kGB * (kGB + 1) / 2;     // packed lower triangle of a vertex block
-constexpr int kGenWs = kGTri + kGB * kGB + kGB;  // L, W, z of one vertex
 
 size_t general_workspace_doubles(const BatchView& b) {
   return (size_t)(b.max_segments + 1) * kGenWs * 4 * (size_t)b.n_paths;
 }
 
-struct GenVertex {
-  double f[kGB];   // constrained values (0 where free)
-  unsigned free_bits;
-};
-
-__device__ __forceinline__ void gen_load_vertex(const uint8_t* __restrict__ mask, const double* __restrict__ vals, int v, int dim,
-                                                GenVertex& out) {
-  const uint8_t* __restrict__ mrow = mask + (size_t)v * kHalf;
-  const double* __restrict__ vrow = vals + (size_t)v * kHalf * kD + dim;
-  out.free_bits = 0u;
-#pragma unroll
-  for (int k = 0; k < kGB; ++k) {
-    const bool fixed = mrow[k] != 0;
-    out.f[k] = fixed ? vrow[k * kD] : 0.0;
-    if (!fixed) out.free_bits |= 1u << k;
-  }
-}
-
-// masked Cholesky of the vertex block, z = L^-1 y (constrained slots: unit row, zero right-hand side)
-__device__ __forceinline__ void gen_factor(double (&Sm)[kGTri], double (&y)[kGB], unsigned free_bits, double (&L)[kGTri],
-                                           double (&Linv)[kGB], double (&z)[kGB]) {
-#pragma unroll
-  for (int r = 0; r < kGB; ++r) {
-    const bool fr = (free_bits >> r) & 1u;
-#pragma unroll
-    for (int c = 0; c <= r; ++c) {
-      const bool fc = (free_bits >> c) & 1u;
-      const double v = Sm[tri(r, c)];
-      Sm[tri(r, c)] = (r == c) ? (fr ? v : 1.0) : ((fr && fc) ? v : 0.0);
-    }
-    y[r] = fr ? y[r] : 0.0;
-  }
-#pragma unroll
-  for (int c = 0; c < kGB; ++c) {
-    double dsum = Sm[tri(c, c)];
-#pragma unroll
-    for (int m = 0; m < c; ++m) dsum = fma(-L[tri(c, m)], L[tri(c, m)], dsum);
-    const double inv = rsqrt_refined(dsum);  // (a vanishing pivot leaves its variable at zero, see rsqrt_refined)
-    L[tri(c, c)] = fmax(dsum * inv, 1.0e-300);
-    Linv[c] = inv;
-#pragma unroll
-    for (int r = c + 1; r < kGB; ++r) {
-      double s = Sm[tri(r, c)];
-#pragma unroll
-      for (int m = 0; m < c; ++m) s = fma(-L[tri(r, m)], L[tri(c, m)], s);
-      L[tri(r, c)] = s * inv;
-    }
-  }
-#pragma unroll
-  for (int r = 0; r < kGB; ++r) {
-    double s = y[r];
-#pragma unroll
-    for (int m = 0; m < r; ++m) s = fma(-L[tri(r, m)], z[m], s);
-    z[r] = s * Linv[r];
-  }
-}
-
-__device__ __forceinline__ double* gen_ws_at(double* ws, size_t stride, unsigned lane, int vertex, int e) {
-  return ws + ((size_t)vertex * kGenWs + e) * stride + lane;
-}
-
-// One lane per (path, dimension); only paths the fast kernels returned with status -2.
+// One lane per (path, dimension).  Which paths: those listed in `only` (per path, non-zero = take it) when given, else those
+// the fast kernels returned with status -2.  Status out: 1, or the outer loop's stopping reason when `opt_status` is given
+// (merge_status); `status` and `cost` may be NULL.
 __global__ __launch_bounds__(64) void solve_general_kernel(BatchView b, int d, const uint8_t* __restrict__ mask,
                                                            const double* __restrict__ vals,
                                                            const double* __restrict__ seg_times, double* __restrict__ ws,
                                                            double* __restrict__ coeffs, int32_t* __restrict__ status,
-                                                           double* __restrict__ cost) {
+                                                           double* __restrict__ cost, const int32_t* __restrict__ only,
+                                                           const int32_t* __restrict__ opt_status) {
   const unsigned t = blockIdx.x * 64u + threadIdx.x;
   const int q = (int)(t >> 2), dim = (int)(t & 3u);
   if (q >= b.n_paths) return;
   const PathRef pr = path_at(b, q);
-  if (status[pr.p] != -2) return;  // (the four lanes of a path agree)
-  const int S = pr.S;
-  const size_t stride = (size_t)b.n_paths * 4;
-  double Sm[kGTri], y[kGB];
-#pragma unroll
-  for (int e = 0; e < kGTri; ++e) Sm[e] = 0.0;
-#pragma unroll
-  for (int r = 0; r < kGB; ++r) y[r] = 0.0;
-  GenVertex vs, ve;
-  gen_load_vertex(mask, vals, pr.v0, dim, vs);
-  for (int i = 0; i < S; ++i) {
-    gen_load_vertex(mask, vals, pr.v0 + i + 1, dim, ve);
-    double Hs[kSym10];
-    hessian_from_time(seg_times[pr.s0 + i], d, Hs);
-    double u[kN];
-#pragma unroll
-    for (int a = 0; a < kN; ++a) {
-      double s = 0.0;
-#pragma unroll
-      for (int c = 0; c < kGB; ++c) s = fma(Hs[sym10(a, c)], vs.f[c], s);
-#pragma unroll
-      for (int c = 0; c < kGB; ++c) s = fma(Hs[sym10(a, kHalf + c)], ve.f[c], s);
-      u[a] = s;
-    }
-#pragma unroll
-    for (int r = 0; r < kGB; ++r) {
-#pragma unroll
-      for (int c = 0; c <= r; ++c) Sm[tri(r, c)] += Hs[sym10(r, c)];
-      y[r] -= u[r];
-    }
-    double L[kGTri], Linv[kGB], z[kGB], W[kGB][kGB];
-    gen_factor(Sm, y, vs.free_bits, L, Linv, z);
-    // W = L^-1 E, E = coupling block restricted to (free here) x (free at the next vertex)
-#pragma unroll
-    for (int c = 0; c < kGB; ++c)
-#pragma unroll
-      for (int r = 0; r < kGB; ++r) {
-        const bool on = ((vs.free_bits >> r) & 1u) && ((ve.free_bits >> c) & 1u);
-        double s = on ? Hs[sym10(r, kHalf + c)] : 0.0;
-#pragma unroll
-        for (int m = 0; m < r; ++m) s = fma(-L[tri(r, m)], W[m][c], s);
-        W[r][c] = s * Linv[r];
-      }
-#pragma unroll
-    for (int e = 0; e < kGTri; ++e) *gen_ws_at(ws, stride, t, i, e) = L[e];
-#pragma unroll
-    for (int r = 0; r < kGB; ++r)
-#pragma unroll
-      for (int c = 0; c < kGB; ++c) *gen_ws_at(ws, stride, t, i, kGTri + r * kGB + c) = W[r][c];
-#pragma unroll
-    for (int r = 0; r < kGB; ++r) *gen_ws_at(ws, stride, t, i, kGTri + kGB * kGB + r) = z[r];
-    // state on the next vertex
-#pragma unroll
-    for (int r = 0; r < kGB; ++r) {
-#pragma unroll
-      for (int c = 0; c <= r; ++c) {
-        double s = Hs[sym10(kHalf + r, kHalf + c)];
-#pragma unroll
-        for (int m = 0; m < kGB; ++m) s = fma(-W[m][r], W[m][c], s);
-        Sm[tri(r, c)] = s;
-      }
-      double s = -u[kHalf + r];
-#pragma unroll
-      for (int m = 0; m < kGB; ++m) s = fma(-W[m][r], z[m], s);
-      y[r] = s;
-    }
-    vs = ve;
-  }
-  // last vertex
-  double xn[kGB], dn[kGB];
-  {
-    double L[kGTri], Linv[kGB], z[kGB];
-    gen_factor(Sm, y, vs.free_bits, L, Linv, z);
-#pragma unroll
-    for (int r = kGB - 1; r >= 0; --r) {
-      double s = z[r];
-#pragma unroll
-      for (int m = r + 1; m < kGB; ++m) s = fma(-L[tri(m, r)], xn[m], s);
-      xn[r] = s / L[tri(r, r)];
-    }
-#pragma unroll
-    for (int k = 0; k < kGB; ++k) dn[k] = vs.f[k] + (((vs.free_bits >> k) & 1u) ? xn[k] : 0.0);
-  }
-  double total = 0.0;
-  for (int i = S - 1; i >= 0; --i) {
-    double L[kGTri], W[kGB][kGB], z[kGB];
-#pragma unroll
-    for (int e = 0; e < kGTri; ++e) L[e] = *gen_ws_at(ws, stride, t, i, e);
-#pragma unroll
-    for (int r = 0; r < kGB; ++r)
-#pragma unroll
-      for (int c = 0; c < kGB; ++c) W[r][c] = *gen_ws_at(ws, stride, t, i, kGTri + r * kGB + c);
-#pragma unroll
-    for (int r = 0; r < kGB; ++r) z[r] = *gen_ws_at(ws, stride, t, i, kGTri + kGB * kGB + r);
-    GenVertex vc;
-    gen_load_vertex(mask, vals, pr.v0 + i, dim, vc);
-    double x[kGB], tt[kGB];
-#pragma unroll
-    for (int r = 0; r < kGB; ++r) {
-      double s = z[r];
-#pragma unroll
-      for (int c = 0; c < kGB; ++c) s = fma(-W[r][c], xn[c], s);
-      tt[r] = s;
-    }
-#pragma unroll
-    for (int r = kGB - 1; r >= 0; --r) {
-      double s = tt[r];
-#pragma unroll
-      for (int m = r + 1; m < kGB; ++m) s = fma(-L[tri(m, r)], x[m], s);
-      x[r] = s / L[tri(r, r)];
-    }
-    double dv[kN], c[kN];
-#pragma unroll
-    for (int k = 0; k < kGB; ++k) {
-      dv[k] = vc.f[k] + (((vc.free_bits >> k) & 1u) ? x[k] : 0.0);
-      dv[kHalf + k] = dn[k];
-    }
-    const double T = seg_times[pr.s0 + i];
-    coefficients_from_time(T, dv, c);
-    double* out = coeffs + ((size_t)(pr.s0 + i) * kD + dim) * kN;
-    double cb[kN];
-    double tk = 1.0;
-#pragma unroll
-    for (int k = 0; k < kN; ++k) {
-      out[k] = c[k];
-      cb[k] = c[k] * tk;  // unit-time coefficients for the cost form
-      tk *= T;
-    }
-    double p2[9];
-    hessian_powers(T, d, p2);  // p2[0] = T^(1 - 2d)
-    total = fma(cost_quadratic_form_d(d, cb), p2[0], total);
-#pragma unroll
-    for (int k = 0; k < kGB; ++k) {
-      dn[k] = dv[k];
-      xn[k] = ((vc.free_bits >> k) & 1u) ? x[k] : 0.0;
-    }
-  }
+  if (only ? only[pr.p] == 0 : status[pr.p] != -2) return;  // (the four lanes of a path agree)
+  const double* __restrict__ times = seg_times + pr.s0;
+  double total = general_solve_lane<true>(mask, vals, pr.v0, pr.S, d, dim, [&](int i) { return times[i]; }, ws,
+                                          (size_t)b.n_paths * 4, t, coeffs + (size_t)pr.s0 * kD * kN);
   total += __shfl_xor(total, 1, 64);
   total += __shfl_xor(total, 2, 64);
   if (dim == 0) {
     if (cost) cost[pr.p] = total;
-    status[pr.p] = 1;  // (after the reads above: the other three lanes of the quad are in this wavefront)
+    if (status) status[pr.p] = merge_status(true, opt_status, pr.p);  // (after the reads above: the other three lanes of the quad are in this wavefront)
   }
 }
 
 hipError_t launch_solve_general(const BatchView& b, int d, const uint8_t* mask, const double* vals, const double* seg_times,
-                                double* ws, double* coeffs, int32_t* status, double* cost, hipStream_t stream) {
+                                double* ws, double* coeffs, int32_t* status, double* cost, hipStream_t stream,
+                                const int32_t* only, const int32_t* opt_status) {
   if (b.n_paths == 0) return hipSuccess;
+  if (!only && !status) return hipErrorInvalidValue;
   const unsigned grid = (unsigned)(((size_t)b.n_paths * 4 + 63) / 64);
   hipLaunchKernelGGL(solve_general_kernel, dim3(grid), dim3(64), 0, stream, b, d, mask, vals, seg_times, ws, coeffs, status,
-                     cost);
+                     cost, only, opt_status);
   return hipGetLastError();
 }
 

@@ -81,10 +81,12 @@ constexpr int kSampleStateOrders = 5;
 hipError_t launch_sample_states(const BatchView& b, const double* coeffs, const double* seg_times, double dt, int capacity,
                                 int32_t* n_samples, double* states, hipStream_t stream);
 size_t linear_workspace_doubles(const BatchView& b);
-// any fixed / free pattern, position-free vertices included (mrs_tg_general.hip): solves the paths whose status is -2
+// any fixed / free pattern, position-free vertices included (mrs_tg_general.hip): solves the paths flagged in `only` (by
+// path, non-zero) or, without it, the paths whose status is -2; status out = 1 or opt_status' stopping reason
 size_t general_workspace_doubles(const BatchView& b);
 hipError_t launch_solve_general(const BatchView& b, int d, const uint8_t* mask, const double* vals, const double* seg_times,
-                                double* ws, double* coeffs, int32_t* status, double* cost, hipStream_t stream);
+                                double* ws, double* coeffs, int32_t* status, double* cost, hipStream_t stream,
+                                const int32_t* only = nullptr, const int32_t* opt_status = nullptr);
 // phase-split tile kernel (mrs_tg_tile.hip): small and medium batches whose per-path state fits in LDS
 bool tile_kernel_applies(const BatchView& b, bool fused);
 hipError_t launch_solve_tile(const BatchView& b, int d, bool fused, const uint8_t* mask, const double* vals,

@@ -61,6 +61,11 @@ struct NonlinearPlan {
   int32_t* d_careful = nullptr;    // [0] count, [2] count of the last completed call, [4..] list of guarded paths
   double* d_careful_ws = nullptr;  // factor store of optimize_careful_kernel's lanes
   size_t careful_ws_doubles = 0;
+  // paths with a position-free vertex (MRS_TG_FLAG_GENERAL_PATTERNS), allocated on first use
+  int32_t* d_general = nullptr;          // [0] count | [4 + p] flag by path | [4 + n_paths + k] list of positions
+  double* d_general_ws = nullptr;        // factor store of optimize_general_kernel's lanes
+  double* d_general_solve_ws = nullptr;  // factor store of solve_general_kernel (general_workspace_doubles)
+  double* d_general_t0 = nullptr;        // [n_segments] the times the call started from
   // gradient-free modes (0, 1, 3, 4), allocated on first use
   double* d_dfo_vec = nullptr;       // x | x0 | best | h | lb | ub, each 21 n_segments + 20 n_paths doubles
   double* d_dfo_f = nullptr;         // fbest | f_sweep | J_d scratch, 3 * n_paths doubles
@@ -74,16 +79,18 @@ struct NonlinearPlan {
 int nonlinear_plan_build(NonlinearPlan& nl, const std::vector<int32_t>& seg_offsets, const std::vector<int32_t>& order);
 void nonlinear_plan_free(NonlinearPlan& nl);
 
+// general: paths with a position-free vertex may occur (MRS_TG_FLAG_GENERAL_PATTERNS); they take the 5 x 5-block route
+// (optimize_general_kernel / solve_general_kernel) behind the fast kernels, the others are untouched by it.
 // sampling_dt > 0: the caller wants the result sampled; when the final solve runs on the rows kernel the sampling rides
 // on that launch (*sampled_out = true) and the caller must not launch the sampler again
 hipError_t launch_nonlinear(NonlinearPlan& nl, const BatchView& b, const NonlinearParams& prm, const uint8_t* mask,
                             const double* vals, const double* limits, double* seg_times, double* coeffs,
                             int32_t* status, double* cost, hipStream_t stream, double sampling_dt = 0.0,
                             int sample_capacity = 0, int32_t* n_samples = nullptr, double* samples = nullptr,
-                            bool* sampled_out = nullptr);
+                            bool* sampled_out = nullptr, bool general = false);
 hipError_t launch_dfo(NonlinearPlan& nl, const BatchView& b, const DfoParams& prm, const uint8_t* mask, const double* vals,
                       const double* limits, double* seg_times, double* coeffs, int32_t* status, double* cost,
-                      hipStream_t stream);
+                      hipStream_t stream, bool general = false);
 hipError_t launch_cost_gradient(NonlinearPlan& nl, const BatchView& b, int d, const uint8_t* mask, const double* vals,
                                 const double* seg_times, double* cost, double* grad, hipStream_t stream);
 hipError_t launch_segment_maxima(const BatchView& b, const double* coeffs, const double* seg_times, double* maxima,

@@ -39,6 +39,7 @@
 #include "mrs_tg_pool.h"
 #include "mrs_tg_solve.hpp"
 #include "mrs_tg_nonlinear.h"
+#include "mrs_tg_general.hpp"
 
 namespace mrs_tg {
 
@@ -1087,6 +1088,29 @@ __device__ __forceinline__ double evaluate_careful(const uint8_t* __restrict__ m
   return J0;
 }
 
+// evaluate_careful for ANY fixed / free pattern (paths with a vertex whose position is free, optimize_general_kernel): the
+// 5 x 5-block solve of mrs_tg_general.hpp at every perturbed time vector, the cost from the coefficients
+__device__ __forceinline__ double evaluate_general(const uint8_t* __restrict__ mask, const double* __restrict__ vals, int v0,
+                                                   int S, int d, const double* pt, double* grad, int g, bool active,
+                                                   double* ws, size_t wstride, unsigned wlane) {
+  const int kk = g >> 2, dim0 = g & 3;
+  const double corr = kGradStep / ((double)S - 1.0);
+  double J0 = 0.0;
+  const int rounds = (S + 16) >> 4;
+  for (int r = 0; r < rounds; ++r) {
+    const int k = kk + r * 16;
+    double Jk = 0.0;
+    if (active && k <= S && (k == 0 || S > 1))
+      Jk = general_solve_lane<false>(mask, vals, v0, S, d, dim0, [&](int i) { return perturbed_time(pt, i, k, corr); }, ws,
+                                     wstride, wlane, nullptr);
+    Jk += dpp_move<0xB1>(Jk);
+    Jk += dpp_move<0x4E>(Jk);
+    if (r == 0) J0 = row_value(Jk, 0);
+    if (active && dim0 == 0 && k >= 1 && k <= S) grad[k - 1] = (S > 1) ? (Jk - J0) / kGradStep : 0.0;
+  }
+  return J0;
+}
+
 // ---- lean sweeps (large batches of plain paths) --------------------------------------------------------------------
 // The sweeping evaluation of evaluate_objective<1> for plain paths only (start | interior ... | end): the block constants
 // come from the LDS table, the brackets from dp on the fly, and nothing of the general step is compiled in -- which is what
@@ -1330,11 +1354,15 @@ struct BinTable {
 // the factor store of its lanes.
 // LEAN (optimize_lean_kernel): plain paths only, the lean sweeps of evaluate_lean; a path it does not take is flagged in
 // `fallback` and left to the general instantiation launched behind it.
-template <int DS, bool MASKED4 = false, bool CAREFUL = false, bool LEAN = false>
+// GENERAL (optimize_general_kernel, with CAREFUL): the listed paths are those with a position-free vertex, every evaluation
+// is evaluate_general, and the start point is read from `start_times` (a copy taken before the fast kernels ran over the
+// batch: they do not know such paths and leave garbage in seg_times for them).
+template <int DS, bool MASKED4 = false, bool CAREFUL = false, bool LEAN = false, bool GENERAL = false>
 __device__ __forceinline__ void optimize_body(const BatchView& b, const NonlinearParams& prm, const BinTable& bins,
                                               const uint8_t* __restrict__ mask, const double* __restrict__ vals,
                                               double* __restrict__ seg_times, int32_t* __restrict__ opt_status,
-                                              double* careful_ws = nullptr, int32_t* __restrict__ fallback = nullptr) {
+                                              double* careful_ws = nullptr, int32_t* __restrict__ fallback = nullptr,
+                                              const double* __restrict__ start_times = nullptr) {
   extern __shared__ double lds[];
   MRS_TG_PHASE_MARK(0);
   int bin = 0;
@@ -1393,8 +1421,9 @@ __device__ __forceinline__ void optimize_body(const BatchView& b, const Nonlinea
   double* vtx = tick_f + kTickState;  // [(Sb + 1) * kVtxLds]
   double* seg = vtx + (size_t)(Sb + 1) * kVtxLds + (kExtras ? kStartExtra : 0);  // [Sb * kSegLds], the moving-start extras in front
   // the start times are requested in front of the vertex staging (one trip to memory instead of two in a row)
+  const double* t_src = GENERAL ? start_times : seg_times;
   double t_first = 0.0;
-  if (active && wave == 0 && g < S) t_first = seg_times[pr.s0 + g];
+  if (active && wave == 0 && g < S) t_first = t_src[pr.s0 + g];
   if (LEAN) {  // vtx = the evaluation area: dp of every segment; the path's eligibility decides who runs it
     const bool takes = stage_ps(mask, vals, pr.v0, S, Sb, vtx, g, G, active, 2, d, MASKED4);
     if (active && g == 0) fallback[q] = takes ? 0 : 1;
@@ -1416,7 +1445,7 @@ __device__ __forceinline__ void optimize_body(const BatchView& b, const Nonlinea
       if (t < kTimeLowerBound) ok = 0;
     };
     if (g < S) take(g, t_first);
-    for (int i = g + G; i < S; i += G) take(i, seg_times[pr.s0 + i]);
+    for (int i = g + G; i < S; i += G) take(i, t_src[pr.s0 + i]);
     // the total time the search starts from: what the final solve measures a runaway of the feasibility scaling against
     t_sum = group_sum(t_sum, G);
     if (g == 0 && prm.sum_t0) prm.sum_t0[pr.p] = t_sum;
@@ -1603,6 +1632,9 @@ __device__ __forceinline__ void optimize_body(const BatchView& b, const Nonlinea
     double fn;
     if (LEAN) {
       fn = evaluate_lean<MASKED4>(hc, vtx, S, Sb, d, xn, gn, g, G, !done, tick_i + 4);
+    } else if (GENERAL) {
+      fn = evaluate_general(mask, vals, pr.v0, S, d, xn, gn, g, !done, careful_ws, (size_t)gridDim.x * 64,
+                            blockIdx.x * 64u + (unsigned)lane);
     } else if (CAREFUL) {
       fn = evaluate_careful(mask, vals, pr.v0, S, d, xn, gn, g, !done, careful_ws, (size_t)gridDim.x * 64,
                             blockIdx.x * 64u + (unsigned)lane);
@@ -2010,6 +2042,34 @@ __global__ __launch_bounds__(64) void optimize_careful_kernel(BatchView b, Nonli
   optimize_body<4, false, true>(b, prm, none, mask, vals, seg_times, opt_status, ws);
 }
 
+// ---- paths with a position-free vertex (MRS_TG_FLAG_GENERAL_PATTERNS) ------------------------------------------------
+// general[0] = number of such paths, general[4 + p] = 1 where path p is one, general[4 + n_paths + k] = position q of the
+// k-th (in no particular order).  One thread per position.
+__global__ __launch_bounds__(256) void general_list_kernel(BatchView b, const uint8_t* __restrict__ mask,
+                                                           int32_t* __restrict__ general) {
+  const int q = blockIdx.x * blockDim.x + threadIdx.x;
+  if (q >= b.n_paths) return;
+  const PathRef pr = path_at(b, q);
+  bool any = false;
+  for (int v = 0; v <= pr.S; ++v) any = any || mask[(size_t)(pr.v0 + v) * kHalf] == 0;
+  general[4 + pr.p] = any ? 1 : 0;
+  if (any) general[4 + b.n_paths + atomicAdd(general, 1)] = q;
+}
+
+// the next launch of optimize_general_kernel takes the next `taken` entries of the list
+__global__ void general_advance_kernel(int32_t* __restrict__ general, int taken) {
+  general[0] = general[0] > taken ? general[0] - taken : 0;
+}
+
+// The outer loop for the listed paths: one path per workgroup, every evaluation through the 5 x 5-block solve.
+__global__ __launch_bounds__(64) void optimize_general_kernel(BatchView b, NonlinearParams prm, const uint8_t* __restrict__ mask,
+                                                              const double* __restrict__ vals, double* __restrict__ seg_times,
+                                                              int32_t* __restrict__ opt_status, double* __restrict__ ws,
+                                                              const double* __restrict__ start_times) {
+  BinTable none{};
+  optimize_body<4, false, true, false, true>(b, prm, none, mask, vals, seg_times, opt_status, ws, nullptr, start_times);
+}
+
 // per-segment maxima, one (k, group) per blockIdx.y: maxima[seg * 9 + 3 (k-1) + group]
 __global__ __launch_bounds__(64, MRS_TG_MAXIMA_WAVES) void segment_maxima9_kernel(int n_segments, const double* __restrict__ coeffs,
                                                              const double* __restrict__ seg_times,
@@ -2046,7 +2106,6 @@ __global__ __launch_bounds__(256) void apply_scaling_kernel(BatchView b, const d
   seg_times[idx] = seg_times[idx] * violation_scaling(maxima + (size_t)idx * 9, limits + (size_t)p * 9);
 }
 
-// J_d and the forward-difference gradient at the given times (parity-test building block)
 // The runaway test of the final solve for the pipelines whose scaling is its own launch (the rows kernel does it in its
 // tail): a path whose scaled total time exceeds MRS_TG_RUNAWAY_TIME_FACTOR times the total it started from leaves the
 // pipeline with ROUNDOFF_LIMITED (-4) instead of the outer loop's stopping reason (include/mrs_tg.h).
@@ -2061,6 +2120,7 @@ __global__ __launch_bounds__(256) void runaway_kernel(BatchView b, const double*
   if (t > MRS_TG_RUNAWAY_TIME_FACTOR * sum_t0[pr.p]) opt_status[pr.p] = MRS_TG_STATUS_ROUNDOFF_LIMITED;
 }
 
+// J_d and the forward-difference gradient at the given times (parity-test building block)
 template <int DS>
 __global__ __launch_bounds__(64) void cost_gradient_kernel(BatchView b, int d, int G, int q_begin, int q_count, int Sb,
                                                            const uint8_t* __restrict__ mask,
@@ -2535,6 +2595,14 @@ void nonlinear_plan_free(NonlinearPlan& nl) {
   nl.d_sum_t0 = nullptr;
   if (nl.d_queue) (void)mrs_tg::pool_free(nl.d_queue);
   nl.d_queue = nullptr;
+  if (nl.d_general) (void)mrs_tg::pool_free(nl.d_general);
+  nl.d_general = nullptr;
+  if (nl.d_general_ws) (void)mrs_tg::pool_free(nl.d_general_ws);
+  nl.d_general_ws = nullptr;
+  if (nl.d_general_solve_ws) (void)mrs_tg::pool_free(nl.d_general_solve_ws);
+  nl.d_general_solve_ws = nullptr;
+  if (nl.d_general_t0) (void)mrs_tg::pool_free(nl.d_general_t0);
+  nl.d_general_t0 = nullptr;
   if (nl.d_careful) (void)mrs_tg::pool_free(nl.d_careful);
   nl.d_careful = nullptr;
   if (nl.d_fallback) (void)mrs_tg::pool_free(nl.d_fallback);
@@ -2603,14 +2671,47 @@ static hipError_t ensure_fallback(NonlinearPlan& nl, const BatchView& b) {
   return mrs_tg::pool_alloc(&nl.d_fallback, sizeof(int32_t) * (size_t)(b.n_paths > 0 ? b.n_paths : 1));
 }
 
+// Buffers of the pipelines' route for paths with a position-free vertex, and the list / flags of this call's batch
+// (general_list_kernel).  `outer_loop`: also the factor store of optimize_general_kernel's lanes and the copy of the start
+// times; returns the number of paths one launch of that kernel takes in *cap.
+static hipError_t prepare_general(NonlinearPlan& nl, const BatchView& b, const uint8_t* mask, const double* seg_times,
+                                  bool outer_loop, int* cap, hipStream_t stream) {
+  hipError_t e;
+  const size_t P = (size_t)b.n_paths;
+  if (!nl.d_general && (e = mrs_tg::pool_alloc(&nl.d_general, sizeof(int32_t) * (4 + 2 * P))) != hipSuccess) return e;
+  if (!nl.d_general_solve_ws &&
+      (e = mrs_tg::pool_alloc(&nl.d_general_solve_ws, sizeof(double) * general_workspace_doubles(b))) != hipSuccess)
+    return e;
+  if (outer_loop) {
+    // as many paths per launch as a 2 GB factor store holds (64 lanes x S vertices x kGenWs doubles each)
+    const size_t per_path = (size_t)64 * (size_t)b.max_segments * kGenWs;
+    const size_t n = std::min<size_t>(P, std::max<size_t>((size_t)16, ((size_t)1 << 28) / per_path));
+    if (!nl.d_general_ws && (e = mrs_tg::pool_alloc(&nl.d_general_ws, sizeof(double) * per_path * n)) != hipSuccess) return e;
+    if (!nl.d_general_t0 &&
+        (e = mrs_tg::pool_alloc(&nl.d_general_t0, sizeof(double) * (size_t)std::max(b.n_segments, 1))) != hipSuccess)
+      return e;
+    if ((e = hipMemcpyAsync(nl.d_general_t0, seg_times, sizeof(double) * (size_t)b.n_segments, hipMemcpyDeviceToDevice, stream)) !=
+        hipSuccess)
+      return e;
+    if (cap) *cap = (int)n;
+  }
+  if ((e = hipMemsetAsync(nl.d_general, 0, sizeof(int32_t) * 4, stream)) != hipSuccess) return e;
+  hipLaunchKernelGGL(general_list_kernel, dim3(cdiv_u(b.n_paths, 256)), dim3(256), 0, stream, b, mask, nl.d_general);
+  return hipGetLastError();
+}
+
 hipError_t launch_nonlinear(NonlinearPlan& nl, const BatchView& b, const NonlinearParams& prm_in, const uint8_t* mask,
                             const double* vals, const double* limits, double* seg_times, double* coeffs,
                             int32_t* status, double* cost, hipStream_t stream, double sampling_dt, int sample_capacity,
-                            int32_t* n_samples, double* samples, bool* sampled_out) {
+                            int32_t* n_samples, double* samples, bool* sampled_out, bool general) {
   if (sampled_out) *sampled_out = false;
   if (b.n_paths == 0) return hipSuccess;
   hipError_t e = ensure_buffers(nl, b);
   if (e != hipSuccess) return e;
+  // paths with a position-free vertex (the caller says there may be some): flagged and listed, their start times kept aside
+  int general_cap = 0;
+  if (general && (e = prepare_general(nl, b, mask, seg_times, true, &general_cap, stream)) != hipSuccess) return e;
+  const int32_t* general_flag = general ? nl.d_general + 4 : nullptr;
   // 1. outer loop: every bin in one launch
   NonlinearParams prm = prm_in;
   prm.sum_t0 = nl.d_sum_t0;
@@ -2738,7 +2839,7 @@ hipError_t launch_nonlinear(NonlinearPlan& nl, const BatchView& b, const Nonline
       e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
       if (e != hipSuccess) return e;
     }
-    const hipEvent_t ev_start = lean ? nullptr : kt.start, ev_stop = careful ? nullptr : kt.stop;
+    const hipEvent_t ev_start = lean ? nullptr : kt.start, ev_stop = (careful || general) ? nullptr : kt.stop;
     if (nl.dim_split == 4)
       hipExtLaunchKernelGGL(optimize_split_kernel, dim3(blocks), dim3(threads), lds_bytes, stream, ev_start, ev_stop, 0, b, prm, bt,
                             mask, vals, seg_times, nl.d_opt_status);
@@ -2755,16 +2856,44 @@ hipError_t launch_nonlinear(NonlinearPlan& nl, const BatchView& b, const Nonline
       if (clds > 64 * 1024 &&
           (e = hipFuncSetAttribute((const void*)optimize_careful_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)clds)) != hipSuccess)
         return e;
-      hipExtLaunchKernelGGL(optimize_careful_kernel, dim3(careful_cap), dim3(64), clds, stream, nullptr, kt.stop, 0, b, prm, mask,
-                            vals, seg_times, nl.d_opt_status, nl.d_careful_ws);
+      hipExtLaunchKernelGGL(optimize_careful_kernel, dim3(careful_cap), dim3(64), clds, stream, nullptr,
+                            general ? nullptr : kt.stop, 0, b, prm, mask, vals, seg_times, nl.d_opt_status, nl.d_careful_ws);
       if ((e = hipGetLastError()) != hipSuccess) return e;
       hipLaunchKernelGGL(careful_close_kernel, dim3(1), dim3(1), 0, stream, nl.d_careful);
       if ((e = hipGetLastError()) != hipSuccess) return e;
+    }
+    // the paths none of the kernels above knows (what they wrote for them is overwritten here): the same search with the
+    // 5 x 5-block evaluation, from the start times kept aside, `general_cap` listed paths per launch
+    if (general) {
+      const size_t glds = ((size_t)group_lds_doubles(b.max_segments, true) + kBlockConsts) * sizeof(double);
+      if (glds > 160 * 1024) return hipErrorInvalidValue;
+      if (glds > 64 * 1024 &&
+          (e = hipFuncSetAttribute((const void*)optimize_general_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)glds)) != hipSuccess)
+        return e;
+      NonlinearParams gp = prm;
+      gp.only_flagged = nullptr;
+      gp.queue_next = nullptr;
+      gp.careful_count = nl.d_general;
+      gp.careful_cap = general_cap;
+      for (int off = 0; off < b.n_paths; off += general_cap) {
+        const bool last = off + general_cap >= b.n_paths;
+        gp.careful_list = nl.d_general + 4 + b.n_paths + off;
+        hipExtLaunchKernelGGL(optimize_general_kernel, dim3(general_cap), dim3(64), glds, stream, nullptr, last ? kt.stop : nullptr,
+                              0, b, gp, mask, vals, seg_times, nl.d_opt_status, nl.d_general_ws, nl.d_general_t0);
+        if ((e = hipGetLastError()) != hipSuccess) return e;
+        if (!last) {
+          hipLaunchKernelGGL(general_advance_kernel, dim3(1), dim3(1), 0, stream, nl.d_general, general_cap);
+          if ((e = hipGetLastError()) != hipSuccess) return e;
+        }
+      }
     }
   }
   // 2. trajectory of the last evaluated point (scaleSegmentTimesWithViolation works on poly_opt_'s state)
   if ((e = launch_solve_linear(b, prm.derivative, true, mask, vals, seg_times, nullptr, nullptr, nl.d_ws, coeffs, nullptr,
                                nullptr, nullptr, stream)) != hipSuccess)
+    return e;
+  if (general && (e = launch_solve_general(b, prm.derivative, mask, vals, seg_times, nl.d_general_solve_ws, coeffs, nullptr, nullptr,
+                                           stream, general_flag, nullptr)) != hipSuccess)
     return e;
   // 3. per-segment maxima and time scaling
   hipLaunchKernelGGL(segment_maxima9_kernel, dim3(cdiv_u(b.n_segments, 64), 9), dim3(64), 0, stream, b.n_segments,
@@ -2772,7 +2901,7 @@ hipError_t launch_nonlinear(NonlinearPlan& nl, const BatchView& b, const Nonline
   if ((e = hipGetLastError()) != hipSuccess) return e;
   // 3b + 4 in one launch where the rows kernel applies: its staging pass scales the times of its own path, its tail samples
   const bool want_samples = sampling_dt > 0.0 && n_samples != nullptr && rows_tail_sampling_pays(b);
-  if (rows_kernel_applies(b, want_samples)) {
+  if (!general && rows_kernel_applies(b, want_samples)) {
     RowsTail tail;
     tail.maxima = nl.d_maxima;
     tail.limits = limits;
@@ -2794,13 +2923,18 @@ hipError_t launch_nonlinear(NonlinearPlan& nl, const BatchView& b, const Nonline
   hipLaunchKernelGGL(runaway_kernel, dim3(cdiv_u(b.n_paths, 256)), dim3(256), 0, stream, b, seg_times, nl.d_sum_t0, nl.d_opt_status);
   if ((e = hipGetLastError()) != hipSuccess) return e;
   // 4. updateSegmentTimes + solveLinear with the scaled times (nonlinear_impl.h:405-408), final status
-  return launch_solve_linear(b, prm.derivative, true, mask, vals, seg_times, nullptr, nullptr, nl.d_ws, coeffs, status,
-                             cost, nl.d_opt_status, stream);
+  if ((e = launch_solve_linear(b, prm.derivative, true, mask, vals, seg_times, nullptr, nullptr, nl.d_ws, coeffs, status, cost,
+                               nl.d_opt_status, stream)) != hipSuccess)
+    return e;
+  if (general)
+    return launch_solve_general(b, prm.derivative, mask, vals, seg_times, nl.d_general_solve_ws, coeffs, status, cost, stream,
+                                general_flag, nl.d_opt_status);
+  return hipSuccess;
 }
 
 hipError_t launch_dfo(NonlinearPlan& nl, const BatchView& b, const DfoParams& prm, const uint8_t* mask, const double* vals,
                       const double* limits, double* seg_times, double* coeffs, int32_t* status, double* cost,
-                      hipStream_t stream) {
+                      hipStream_t stream, bool general) {
   const KernelTimer kt = take_kernel_timer();  // family 2: the whole search, dfo_init_kernel to dfo_finalize_kernel
   if (b.n_paths == 0) return hipSuccess;
   hipError_t e = ensure_buffers(nl, b);
@@ -2824,9 +2958,15 @@ hipError_t launch_dfo(NonlinearPlan& nl, const BatchView& b, const DfoParams& pr
   }
   const unsigned pblocks = cdiv_u(b.n_paths, 64), sblocks = cdiv_u(b.n_segments, 64);
   // modes 3 / 4 start from the linear solution at the given times (optimizeTimeAndFreeConstraints :436-438);
-  // for every mode this solve also marks position-free vertices (status -2)
+  // for every mode this solve also marks position-free vertices (status -2, which stays unless the caller has switched
+  // the general solve on: then every linear solve of the search is followed by the 5 x 5-block solve of those paths)
+  if (general && (e = prepare_general(nl, b, mask, seg_times, false, nullptr, stream)) != hipSuccess) return e;
+  const int32_t* general_flag = general ? nl.d_general + 4 : nullptr;
   if ((e = launch_solve_linear(b, prm.derivative, true, mask, vals, seg_times, nullptr, nullptr, nl.d_ws, coeffs, status,
                                cost, nullptr, stream)) != hipSuccess)
+    return e;
+  if (general && (e = launch_solve_general(b, prm.derivative, mask, vals, seg_times, nl.d_general_solve_ws, coeffs, status, cost,
+                                           stream, general_flag, nullptr)) != hipSuccess)
     return e;
   hipExtLaunchKernelGGL(dfo_init_kernel, dim3(pblocks), dim3(64), 0, stream, kt.start, nullptr, 0, b, prm, mask, limits, seg_times,
                         coeffs, nl.d_dfo_vec, nl.d_dfo_f, nl.d_dfo_state, nl.d_dfo_fidx, nl.d_dfo_deadline);
@@ -2842,6 +2982,9 @@ hipError_t launch_dfo(NonlinearPlan& nl, const BatchView& b, const DfoParams& pr
     } else if (r > 0) {  // round 0 evaluates the start point, solved above
       if ((e = launch_solve_linear(b, prm.derivative, true, mask, vals, seg_times, nullptr, nullptr, nl.d_ws, coeffs,
                                    nullptr, cost, nullptr, stream)) != hipSuccess)
+        return e;
+      if (general && (e = launch_solve_general(b, prm.derivative, mask, vals, seg_times, nl.d_general_solve_ws, coeffs, nullptr,
+                                               cost, stream, general_flag, nullptr)) != hipSuccess)
         return e;
     }
     hipLaunchKernelGGL(segment_maxima4_kernel, dim3(sblocks, 3), dim3(64), 0, stream, b.n_segments, coeffs, seg_times,

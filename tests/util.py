@@ -65,10 +65,10 @@ def _endpoint_scale(c, T):
     return np.maximum(sc, 1e-300)
 
 
-def continuity_defect(batch, coeffs, times):
+def continuity_defect(batch, coeffs, times, paths=None):
     """max over interior vertices / derivatives 0..4 of T^k |p_i^(k)(T_i) - p_{i+1}^(k)(0)| / end-point scale"""
     worst = 0.0
-    for p in range(batch.n_paths):
+    for p in (range(batch.n_paths) if paths is None else paths):
         a, b = int(batch.seg_offsets[p]), int(batch.seg_offsets[p + 1])
         for s in range(a, b - 1):
             T = times[s]
@@ -80,10 +80,10 @@ def continuity_defect(batch, coeffs, times):
     return worst
 
 
-def constraint_defect(batch, coeffs, times):
+def constraint_defect(batch, coeffs, times, paths=None):
     """max violation of the fixed vertex constraints by the polynomials (same normalisation)."""
     worst = 0.0
-    for p in range(batch.n_paths):
+    for p in (range(batch.n_paths) if paths is None else paths):
         a, b = int(batch.seg_offsets[p]), int(batch.seg_offsets[p + 1])
         wp, m, v = batch.path(p)
         S = b - a
