@@ -75,6 +75,16 @@ void mto_mapping_matrix(double T, double* A);                          /* linear
 void mto_invert_mapping_matrix(const double* A, double* Ainv);         /* linear_impl.h:148-177 */
 void mto_cost_matrix(int derivative, double T, double* Q);             /* linear_impl.h:606-618 */
 void mto_segment_hessian(int derivative, double T, double* Hout, double* Ainv_out); /* linear_impl.h:320 */
+/* Arithmetic route of the per-segment matrices H(T), A^-1(T) (process-wide; set it before a batch, not during one):
+ * 0 (default) = the reference's route (A inverted numerically, Q from pow(), dense products);
+ * 1 = the same matrices from exactly rounded unit-time tables (mto_linear.c) -- the reference's algorithm without the
+ *     rounding noise of its route, for tests that must tell the two apart;
+ * 2 = the whole linear solve (tables, R, QR, coefficients, cost) in 113-bit arithmetic, rounded to double once: the value
+ *     both other routes and the HIP path approximate.  ~50x slower; the optimisers around it stay in double. */
+void mto_set_arithmetic(int mode);
+int mto_get_arithmetic(void);
+/* the unit-time tables of route 1: ABAR^-1 [10][10], HBAR_d [5][10][10] (113-bit arithmetic, rounded once) */
+void mto_unit_tables(double* abar_inv_out, double* hbar_out);
 
 /* ---- linear QP ------------------------------------------------------------------------ */
 /* setupFromVertices + solveLinear (linear_impl.h:62-106,184-257,311-373).

@@ -75,6 +75,11 @@ def lib():
         L.mto_find_roots_jenkins_traub.restype = C.c_int
         L.mto_find_roots_jenkins_traub.argtypes = [dp, C.c_int, dp, dp]
         L.mto_segment_hessian.argtypes = [C.c_int, C.c_double, dp, dp]
+        L.mto_set_arithmetic.restype = None
+        L.mto_set_arithmetic.argtypes = [C.c_int]
+        L.mto_get_arithmetic.restype = C.c_int
+        L.mto_unit_tables.restype = None
+        L.mto_unit_tables.argtypes = [dp, dp]
         L.mto_solve_linear.restype = C.c_int
         L.mto_solve_linear.argtypes = [C.POINTER(_Path), dp, dp]
         L.mto_compute_cost.restype = C.c_double
@@ -191,6 +196,34 @@ def _make_path(n_seg, deriv, fixed_mask, fixed_values):
     p = _Path(n_seg, deriv, m.ctypes.data_as(C.POINTER(C.c_uint8)), _dp(v))
     p._keep = (m, v)
     return p
+
+
+REFERENCE_ARITHMETIC, EXACT_CONSTANTS, QUAD_PRECISION = 0, 1, 2
+
+
+class arithmetic:
+    """with po.arithmetic(po.EXACT_CONSTANTS): ...  -- the oracle's per-segment matrices from exactly rounded unit-time
+    tables instead of the reference's numerically inverted mapping matrix (mrs_tg_oracle.h); process-wide."""
+
+    def __init__(self, mode):
+        self.mode = int(mode)
+
+    def __enter__(self):
+        self.prev = lib().mto_get_arithmetic()
+        lib().mto_set_arithmetic(self.mode)
+        return self
+
+    def __exit__(self, *exc):
+        lib().mto_set_arithmetic(self.prev)
+        return False
+
+
+def unit_tables():
+    """(ABAR^-1 [10, 10], HBAR [5, 10, 10]) of the exact-constants route"""
+    a = np.zeros((10, 10))
+    h = np.zeros((5, 10, 10))
+    lib().mto_unit_tables(_dp(a), _dp(h))
+    return a, h
 
 
 def segment_hessian(deriv, T):

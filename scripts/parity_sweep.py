@@ -1,6 +1,9 @@
 """Whole-batch parity sweep against the oracle (all host cores): for every path of a large batch compare stopping
 reason, segment times, coefficients and sample count of the nonlinear pipeline; print the agreement statistics and the
-worst paths.  usage: parity_sweep.py [n_paths] [n_seg|ragged] [deriv] [generator]"""
+worst paths.  usage: parity_sweep.py [n_paths] [n_seg|ragged] [deriv] [generator] [mode]
+ORACLE_ARITH=1: the oracle's per-segment matrices from exactly rounded unit-time tables (oracle/mto_linear.c) instead of
+the reference's numerically inverted mapping matrix; ORACLE_ARITH=2: its whole linear solve in 113-bit arithmetic -- the
+same algorithm without the rounding noise of the reference's route (about 50 times slower)."""
 import os
 import sys
 import time
@@ -18,6 +21,8 @@ deriv = int(sys.argv[3]) if len(sys.argv) > 3 else 4
 gen = sys.argv[4] if len(sys.argv) > 4 else "box"
 mode = int(sys.argv[5]) if len(sys.argv) > 5 else 2
 ctx = api.Context(0)
+arith = int(os.environ.get("ORACLE_ARITH", "0"))
+po.lib().mto_set_arithmetic(arith)
 
 seed0 = int(os.environ.get("SEED0", "0"))  # other seeds: other paths
 batch = pr.random_mixed_batch(P, deriv, seed0=seed0) if gen == "mixed" else pr.random_batch(P, n_seg, seed0=seed0, derivative_to_optimize=deriv, generator=gen)
@@ -41,7 +46,8 @@ dt = np.array([np.max(np.abs(out["times"][a:b] - ref["times"][a:b]) / ref["times
 dc = np.array([np.max(np.abs(out["coeffs"][a:b] - ref["coeffs"][a:b])) / np.max(np.abs(ref["coeffs"][a:b]))
                for a, b in zip(so[:-1], so[1:])])
 ns_same = out["n_samples"] == np.minimum(ref["n_samples"], cap + 1)
-print("paths %d  segments %s  d=%d  generator %s  mode %d%s" % (P, n_seg, deriv, gen, mode, "  careful re-run" if flags else ""))
+print("paths %d  segments %s  d=%d  generator %s  mode %d%s%s" % (P, n_seg, deriv, gen, mode, "  careful re-run" if flags else "",
+                                                                 ("", "  ORACLE: exact unit-time constants", "  ORACLE: linear solve in 113-bit arithmetic")[arith]))
 print("status equal: %.4f %%   statuses gpu %s" % (100 * same_status.mean(), dict(zip(*np.unique(out["status"], return_counts=True)))))
 for tol in (1e-9, 1e-6, 1e-3):
     print("  times within %.0e: %.4f %%   coeffs within %.0e: %.4f %%" % (tol, 100 * (dt < tol).mean(), tol, 100 * (dc < tol).mean()))

@@ -360,3 +360,30 @@ def test_sampling_other_sampling_periods(gpu_ctx, dt, cap):
         assert min(n, cap + 1) == out["n_samples"][p], (p, n, out["n_samples"][p])
         n = min(n, cap)
         assert np.max(np.abs(out["samples"][p, :n, :3] - s[:n, :3])) < 1e-10
+
+
+# ---- against the oracle with its linear solve in 113-bit arithmetic (po.QUAD_PRECISION, oracle/mto_linear.c) ----------------
+# The reference's algorithm, bar rounding: what the reference-style oracle and the HIP path both approximate.  Against it the
+# HIP path's agreement is set by its own error only -- measured on 8192-path batches (profiles/round3_parity_sweep.txt): 99.96 %
+# of the random-box paths and 99.96 % of the mixed-pattern paths within 1e-6 on the times, 100 % within 1e-3 (against the
+# reference-style double oracle: 99.96 % / 98.9 %, and 99.98 % / 99.76 % within 1e-3); the worst path 2.4e-5.
+
+@pytest.mark.parametrize("gen,n_paths,deriv", [("box", 768, 4), ("mixed", 384, 4), ("walk", 512, 2)])
+def test_nonlinear_end_to_end_vs_the_113_bit_oracle(gpu_ctx, gen, n_paths, deriv):
+    batch = pr.random_mixed_batch(n_paths, deriv, seed0=31000) if gen == "mixed" else \
+        pr.random_batch(n_paths, 10, seed0=31000, derivative_to_optimize=deriv, generator=gen)
+    cap = 512
+    out = gpu_ctx.solve_batch(batch, None, time_alloc_method=api.TIME_ALLOC_MELLINGER, sampling_dt=0.2, sample_capacity=cap)
+    with po.arithmetic(po.QUAD_PRECISION):
+        ref = po.solve_batch(batch.seg_offsets, batch.waypoints, batch.fixed_mask, batch.fixed_values, batch.limits,
+                             np.zeros(batch.n_segments), deriv=deriv, time_alloc_method=2, estimate_times=True, sampling_dt=0.2,
+                             sample_capacity=cap, n_threads=16)
+    so = batch.seg_offsets
+    dt = np.array([np.max(np.abs(out["times"][a:b] - ref["times"][a:b]) / ref["times"][a:b]) for a, b in zip(so[:-1], so[1:])])
+    dc = np.array([util.coeff_error(out["coeffs"][a:b], ref["coeffs"][a:b]) for a, b in zip(so[:-1], so[1:])])
+    print("RATE 113-bit oracle %s d=%d: times 1e-6 %.4f, coeffs 1e-6 %.4f, worst dt %.1e" %
+          (gen, deriv, (dt < 1e-6).mean(), (dc < 1e-6).mean(), dt.max()))
+    assert np.array_equal(out["status"], ref["status"])
+    assert np.array_equal(out["n_samples"], np.minimum(ref["n_samples"], cap + 1))
+    assert (dt < 1e-6).mean() >= 0.995 and (dc < 1e-6).mean() >= 0.995
+    assert dt.max() < 1e-3

@@ -78,3 +78,65 @@ def test_oracle_maxima(golden):
                     val = po.segment_max_magnitude(exact_c[s], t[s], k, grp)
                     assert abs(val - mx[s, k - 1, gi]) <= 1e-10 * max(mx[s, k - 1, gi], 1e-6), (case["name"], s, k, gi)
     assert n >= 2
+
+
+# ---- the oracle's other arithmetic routes (mrs_tg_oracle.h: mto_set_arithmetic) -------------------------------------
+# 1: per-segment matrices from exactly rounded unit-time tables; 2: the whole linear solve in 113-bit arithmetic.  Same
+# algorithm as route 0 (the reference's), less and less rounding noise; the fixtures are the 60-digit ground truth.
+
+def test_unit_time_tables_equal_the_products_constants():
+    """two independent derivations of the same exact rational tables -- mpmath (tools/gen_constants.py -> mrs_tg_constants.h,
+    what the kernels use) and __float128 Gauss-Jordan (oracle/mto_linear.c) -- agree to the last bit"""
+    import os
+    import re
+    src = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "mrs_uav_trajectory_generation_amd", "csrc",
+                            "mrs_tg_constants.h")).read()
+
+    def table(name):
+        body = re.search(r"#define %s \{(.*?)\n\}\n" % name, src, re.S).group(1)
+        return np.array([float.fromhex(t) if "x" in t else float(t)
+                         for t in re.findall(r"-?0x[0-9a-f.]+p[+-]?\d+|-?\d+\.\d+", body)])
+
+    a, h = po.unit_tables()
+    assert np.array_equal(table("MRS_TG_ABAR_INV_INIT").reshape(10, 10), a)
+    assert np.array_equal(table("MRS_TG_HBAR_INIT").reshape(5, 10, 10), h)
+
+
+def test_oracle_routes_against_the_ground_truth(golden):
+    worst = {0: 0.0, 1: 0.0, 2: 0.0}
+    for case in golden["cases"]:
+        d, m, v, t, _ = util.case_arrays(case)
+        exact = np.array(case["coeffs"])
+        for mode in (po.REFERENCE_ARITHMETIC, po.EXACT_CONSTANTS, po.QUAD_PRECISION):
+            with po.arithmetic(mode):
+                c = po.solve_linear(d, m, v, t)
+                J = po.compute_cost(d, t, c)
+            e = util.coeff_error(c, exact)
+            worst[mode] = max(worst[mode], e)
+            if mode == po.QUAD_PRECISION:  # the correctly rounded result
+                assert e < 1e-15, (case["name"], e)
+                assert abs(J - case["cost"]) <= 4e-16 * abs(case["cost"]), case["name"]
+            elif mode == po.EXACT_CONSTANTS and "short" not in case["name"] and "walk" not in case["name"]:
+                assert e < 1e-12, (case["name"], e)   # what is left is the dense QR on R_pp in unscaled unknowns
+    assert po.lib().mto_get_arithmetic() == 0
+    assert worst[2] < worst[1] <= 1e-7 and worst[0] <= 1e-7
+
+
+def test_quad_route_gradient_and_outer_loop(golden):
+    """the outer loop runs on the 113-bit solve as on the others (same stopping reasons on the fixture paths; times within the
+    noise the reference-style gradient carries)"""
+    n = 0
+    for case in golden["cases"]:
+        if "gradient" not in case:
+            continue
+        d, m, v, t, _ = util.case_arrays(case)
+        with po.arithmetic(po.QUAD_PRECISION):
+            J, g = po.cost_and_gradient(d, m, v, t)
+            st2, t2, _, _ = po.optimize_times(d, m, v, t)
+        ge = np.array(case["gradient"])
+        assert abs(J - case["cost"]) <= 4e-16 * abs(case["cost"])
+        assert np.max(np.abs(g - ge)) <= 1e-12 * np.max(np.abs(ge)), case["name"]   # (J' - J) / h of two exact costs
+        st0, t0, _, _ = po.optimize_times(d, m, v, t)
+        assert st0 == st2 and np.max(np.abs(t0 - t2) / t2) < 1e-4, case["name"]
+        n += 1
+    assert n >= 4
