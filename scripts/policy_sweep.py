@@ -1,6 +1,7 @@
 """Whole-batch agreement of the policy layer (mrs_tg_optimize_paths: preprocessing, deviation loop, length check,
 sampling) with the oracle's optimize() restatement over many random requests with initial states, stop flags, relaxed
-heading and both waypoint generators."""
+heading and both waypoint generators.  ORACLE_ARITH=2: the oracle's linear solve in 113-bit arithmetic (oracle/mto_linear.c) -- 14 s per request on one core, so
+only for a few dozen requests."""
 import os
 import sys
 import time
@@ -14,6 +15,8 @@ from oracle import pyoracle as po
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 400
 deriv = int(sys.argv[2]) if len(sys.argv) > 2 else 2
 ctx = api.Context(0)
+arith = int(os.environ.get("ORACLE_ARITH", "0"))
+po.lib().mto_set_arithmetic(arith)
 rng = np.random.default_rng(7)
 paths, stops, inits, relax = [], [], [], []
 for i in range(N):
@@ -52,7 +55,9 @@ for p in range(N):
                 close += 1
         else:
             close += 1
-print("requests %d (d=%d): gpu %.2f s, oracle %.1f s" % (N, deriv, t_gpu, time.time() - t0))
+print("requests %d (d=%d)%s: gpu %.2f s, oracle %.1f s" % (N, deriv, ("", "  ORACLE: exact unit-time constants",
+                                                                   "  ORACLE: linear solve in 113-bit arithmetic")[arith],
+                                                          t_gpu, time.time() - t0))
 print("success flag equal: %.2f %%; same waypoint count / iterations / sample count: %.2f %%; of all, samples within 1e-6 m: %.2f %%"
       % (100 * same_succ / N, 100 * same_struct / N, 100 * close / N))
 print("successes gpu: %d; worst sample difference among structurally equal: %.3g m" % (int(out["success"].sum()), worst))
