@@ -285,7 +285,7 @@ int mrs_tg_bound_solve_launch_many_mt(mrs_tg_bound_solve* const* bound, int32_t 
 /* The same loop with consecutive launches packed into one dispatch: launch k still solves bound[k % n_bound], but a run of
  * consecutive launches whose bound solves share a PLAN (one batch structure, one context and stream; the solves differ in
  * their input / output arrays) goes out as a single kernel, on that plan's stream, whose workgroups are divided among the
- * batches (at most 8, and never the same bound solve twice).  bound = [A0, A1, B0, B1] with A*, B* bound to two plans issues
+ * batches (at most 16, and never the same bound solve twice).  bound = [A0, A1, B0, B1] with A*, B* bound to two plans issues
  * (A0 A1), (B0 B1), (A0 A1), ... alternately on the two plans' streams.  A launch costs the host 3 us and a 1024-path solve
  * occupies a quarter of an MI355X for 9 us: a host that issues them one by one is the bottleneck of a short run.
  * Requirements (else MRS_TG_ERR_UNSUPPORTED with a message): fixed segment times, the default solve (no

@@ -121,7 +121,7 @@ hipError_t launch_solve_rows(const BatchView& b, int d, const uint8_t* mask, con
                              const RowsTail& tail = RowsTail());
 
 // up to kRowsGroupMax batches of one plan solved by one launch (fixed-times default solve): per batch its arrays
-constexpr int kRowsGroupMax = 8;
+constexpr int kRowsGroupMax = 16;
 struct RowsGroup {
   const uint8_t* mask[kRowsGroupMax];
   const double* vals[kRowsGroupMax];

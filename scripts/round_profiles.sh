@@ -1,5 +1,5 @@
 #!/bin/bash
-# Everything under profiles/<tag>_* that comes from the GPU box, in one call (about ten minutes).  The results land in
+# Everything under profiles/<tag>_* that comes from the GPU box, in one call (about ten minutes, plus the parity sweeps).  The results land in
 # gpurun_out/; the ones to be judged are then copied into profiles/.   usage: scripts/round_profiles.sh <tag>
 tag=${1:-round}
 cd "$(dirname "$0")/.." && export TMPDIR=/tmp
@@ -18,5 +18,5 @@ python3 scripts/host_call_rate.py > $O/${tag}_host_call_rate.txt 2>&1
 python3 scripts/host_call_rate.py 64 >> $O/${tag}_host_call_rate.txt 2>&1
 python3 scripts/host_call_rate.py 8192 >> $O/${tag}_host_call_rate.txt 2>&1
 scripts/tile_phases.bin 1024 10 > $O/${tag}_phase_clocks_1024x10.txt 2>&1
-scripts/parity_sweep_all.sh $O/${tag}_parity_sweep.txt
+[ -n "$SKIP_PARITY" ] || scripts/parity_sweep_all.sh $O/${tag}_parity_sweep.txt   # ~17 minutes (the 113-bit oracle); SKIP_PARITY=1 leaves it out
 ls -la $O/${tag}_*
