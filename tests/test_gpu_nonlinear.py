@@ -63,6 +63,26 @@ def test_cost_gradient_vs_oracle(gpu_ctx, n_seg, n_paths):
         assert np.max(np.abs(g[a:b] - go)) <= 1e-6 * max(np.max(np.abs(go)), 1e-300)
 
 
+@pytest.mark.parametrize("n_seg,n_paths", [(10, 200), ("ragged", 60)])
+def test_cost_gradient_vs_the_113_bit_oracle(gpu_ctx, n_seg, n_paths):
+    """the same building block against the oracle's 113-bit route -- the HIP path's own error: J to 1.6e-9 worst (the by-product
+    cost 0.5 (qf - red) cancels on paths with a short segment; median 1e-13), the h = 0.1 difference quotient to 2.6e-8 worst"""
+    batch = pr.random_batch(n_paths, n_seg, seed0=77)
+    t = util.oracle_times(batch)
+    J, g = gpu_cost_gradient(gpu_ctx, batch, t)
+    eJ, eg, all_J = 0.0, 0.0, []
+    with po.arithmetic(po.QUAD_PRECISION):
+        for p in range(batch.n_paths):
+            a, b = batch.seg_offsets[p], batch.seg_offsets[p + 1]
+            _, m, v = batch.path(p)
+            Jo, go = po.cost_and_gradient(batch.derivative_to_optimize, m, v, t[a:b])
+            eJ = max(eJ, abs(J[p] - Jo) / abs(Jo))
+            all_J.append(abs(J[p] - Jo) / abs(Jo))
+            eg = max(eg, np.max(np.abs(g[a:b] - go)) / max(np.max(np.abs(go)), 1e-300))
+    print("ERR cost/gradient vs 113-bit %s: J %.1e (median %.1e), gradient %.1e" % (n_seg, eJ, np.median(all_J), eg))
+    assert eJ <= 1e-8 and np.median(all_J) <= 1e-11 and eg <= 2e-7
+
+
 def _moving_start_batch(n_paths, n_seg, deriv=4):
     parts = []
     for p in range(n_paths):
