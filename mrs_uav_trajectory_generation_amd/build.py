@@ -13,7 +13,7 @@ from concurrent.futures import ThreadPoolExecutor
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libmrs_tg.so")
-SOURCES = ["mrs_tg_kernels.hip", "mrs_tg_tile.hip", "mrs_tg_rows.hip", "mrs_tg_general.hip", "mrs_tg_nonlinear.hip", "mrs_tg_abi.hip", "mrs_tg_multi.hip", "mrs_tg_policy.hip",
+SOURCES = ["mrs_tg_kernels.hip", "mrs_tg_tile.hip", "mrs_tg_rows.hip", "mrs_tg_general.hip", "mrs_tg_nonlinear.hip", "mrs_tg_dfo.hip", "mrs_tg_abi.hip", "mrs_tg_multi.hip", "mrs_tg_policy.hip",
            "mrs_tg_pool.hip"]
 HEADERS = ["mrs_tg_device.hpp", "mrs_tg_solve.hpp", "mrs_tg_launch.h", "mrs_tg_nonlinear.h", "mrs_tg_constants.h", "mrs_tg_pool.h", "mrs_tg_rowelim.hpp",
            os.path.join("..", "..", "include", "mrs_tg.h")]

@@ -76,6 +76,12 @@ struct NonlinearPlan {
   long long* d_dfo_deadline = nullptr; // wall-clock deadline of the running search (0 = none), written by its first kernel
 };
 
+// shared by the launchers of mrs_tg_nonlinear.hip and mrs_tg_dfo.hip: the plan's lazily allocated buffers, and the flags / list
+// of a call's paths with a position-free vertex (`outer_loop`: also what optimize_general_kernel needs; *cap = paths per launch)
+hipError_t nonlinear_ensure_buffers(NonlinearPlan& nl, const BatchView& b);
+hipError_t nonlinear_prepare_general(NonlinearPlan& nl, const BatchView& b, const uint8_t* mask, const double* seg_times,
+                                     bool outer_loop, int* cap, hipStream_t stream);
+
 int nonlinear_plan_build(NonlinearPlan& nl, const std::vector<int32_t>& seg_offsets, const std::vector<int32_t>& order);
 void nonlinear_plan_free(NonlinearPlan& nl);
 

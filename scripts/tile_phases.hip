@@ -9,6 +9,7 @@
 #include "../mrs_uav_trajectory_generation_amd/csrc/mrs_tg_rows.hip"
 #include "../mrs_uav_trajectory_generation_amd/csrc/mrs_tg_general.hip"
 #include "../mrs_uav_trajectory_generation_amd/csrc/mrs_tg_nonlinear.hip"
+#include "../mrs_uav_trajectory_generation_amd/csrc/mrs_tg_dfo.hip"
 #include "../mrs_uav_trajectory_generation_amd/csrc/mrs_tg_pool.hip"
 
 #include <cmath>
