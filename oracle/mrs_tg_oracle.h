@@ -7,6 +7,9 @@
  * reference file:line it follows.  It deliberately uses the reference's own arithmetic route
  * (per-segment A(T), Schur-complement inverse, H = A^-T Q A^-1, dense R = C^T H C, QR solve,
  * Jenkins-Traub roots) and shares NO code or constants with the HIP product path.
+ * Two further arithmetic routes of the SAME algorithm can be switched on for the linear solve (mto_set_arithmetic below: exactly
+ * rounded unit-time tables; the whole solve in 113-bit arithmetic) -- tests use them to tell the rounding noise of the
+ * reference's route from a difference in the algorithm.
  *
  * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load this library.
  *
