@@ -44,6 +44,24 @@ def test_multi_device_solve_equals_single_device(gpu_ctx, n_seg, n_paths, n_dev)
     multi.close()
 
 
+def test_multi_device_solve_with_position_free_vertices(gpu_ctx):
+    """every shard sees its own masks: the shards that hold a position-free vertex switch the general route on for themselves,
+    in the fixed-times mode and in the time-allocation modes; path for path what one device returns"""
+    base = pr.random_batch(23, 6, seed0=4300)
+    m = base.fixed_mask.copy()
+    for p in (2, 11, 12, 20):
+        m[base.seg_offsets[p] + p + 1 + p % 5, 0] = 0
+    batch = pr.Batch(base.seg_offsets, base.waypoints, m, base.fixed_values, base.limits)
+    multi = api.MultiContext([0, 0, 0])
+    for kwargs in (dict(), dict(time_alloc_method=api.TIME_ALLOC_MELLINGER), dict(time_alloc_method=api.TIME_ALLOC_RICHTER_TIME)):
+        one = gpu_ctx.solve_batch(batch, None, **kwargs)
+        many = multi.solve_batch(batch, None, **kwargs)
+        assert np.all(one["status"] >= 1)
+        for key in ("times", "coeffs", "status", "cost"):
+            assert np.array_equal(one[key], many[key]), (key, kwargs)
+    multi.close()
+
+
 def test_multi_device_reports_the_failing_shard(gpu_ctx):
     batch = pr.random_batch(6, 4, seed0=1)
     multi = api.MultiContext([0, 0])
