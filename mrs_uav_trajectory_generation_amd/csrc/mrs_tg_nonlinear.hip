@@ -1490,7 +1490,13 @@ __device__ __forceinline__ void optimize_body(const BatchView& b, const Nonlinea
         // rejected step, which is cheaper than three more reductions on an accepted one)
         const double si = xni - xi_, yi = gni - gi_;
         double red4[4] = {gi_ * si, si * yi, si * si, yi * yi};
+#ifdef MRS_TG_PHASE_CLOCKS
+        if (neval == 2) MRS_TG_PHASE_MARK(23);  // tick 1: vectors read, terms formed
+#endif
         group_sum_n<4>(red4, Gr);
+#ifdef MRS_TG_PHASE_CLOCKS
+        if (neval == 2) MRS_TG_PHASE_MARK(24);  // tick 1: the four sums
+#endif
         const double slope = red4[0];
         if (fn <= f + 1e-4 * slope) {
           int stop = 0;
@@ -1503,6 +1509,9 @@ __device__ __forceinline__ void optimize_body(const BatchView& b, const Nonlinea
           const double sy = red4[1], ss = red4[2], yy = red4[3];
           const bool budget_out = budget_spent(neval);
           int slot = -1;
+#ifdef MRS_TG_PHASE_CLOCKS
+          if (neval == 2) MRS_TG_PHASE_MARK(25);  // tick 1: stopping rules
+#endif
           if (!stop && !budget_out && sy > 1e-10 * sqrt(ss) * sqrt(yy)) {
             if (npairs == kLbfgsM) {
               slot = head;  // overwrite the oldest pair
@@ -1520,6 +1529,9 @@ __device__ __forceinline__ void optimize_body(const BatchView& b, const Nonlinea
             rho[slot] = 1.0 / sy;
             rho[kLbfgsM] = sy / yy;  // the scaling of the initial Hessian, taken from the newest pair
           }
+#ifdef MRS_TG_PHASE_CLOCKS
+          if (neval == 2) MRS_TG_PHASE_MARK(26);  // tick 1: curvature pair stored
+#endif
           xi_ = xni;
           gi_ = gni;
           f = fn;
@@ -1659,6 +1671,9 @@ __device__ __forceinline__ void optimize_body(const BatchView& b, const Nonlinea
             rk[k] = have ? rho[id] : 0.0;
             al[k] = 0.0;
           }
+#ifdef MRS_TG_PHASE_CLOCKS
+          if (neval == 2) MRS_TG_PHASE_MARK(27);  // tick 1: pairs read
+#endif
 #pragma unroll
           for (int k = kLbfgsM - 1; k >= 0; --k)
             if (k < npairs) {
@@ -1673,6 +1688,9 @@ __device__ __forceinline__ void optimize_body(const BatchView& b, const Nonlinea
               di += (al[k] - beta) * sk[k];
             }
         }
+#ifdef MRS_TG_PHASE_CLOCKS
+        if (neval == 2) MRS_TG_PHASE_MARK(31);  // tick 1: two-loop recursion done
+#endif
         if (xi_ <= kTimeLowerBound && di < 0.0) di = 0.0;
         double red3[3] = {gi_ * di, xi_ * xi_, di * di};
         group_sum_n<3>(red3, Gr);

@@ -179,6 +179,9 @@ int main(int argc, char** argv) {
            total * 1e3 / n, clk[1] - clk[0], clk[5] - clk[0]);
     printf("  tick 1 in detail: accept step %lld, barrier %lld, direction + trial point %lld, flag + barrier %lld\n",
            clk[28] - clk[8], clk[29] - clk[28], clk[30] - clk[29], clk[9] - clk[30]);
+    printf("    accept step: vectors read %lld, four sums %lld, stopping rules %lld, pair stored %lld, rest %lld | direction: pairs read %lld, recursion %lld, rest %lld\n",
+           clk[23] - clk[8], clk[24] - clk[23], clk[25] - clk[24], clk[26] - clk[25], clk[28] - clk[26], clk[27] - clk[29],
+           clk[31] - clk[27], clk[30] - clk[31]);
     for (int t = 0; t < 6; ++t)
       printf("  tick %d: evaluation %lld cycles, bookkeeping + direction %lld\n", t,
              clk[6 + 2 * t] - (t == 0 ? clk[1] : clk[5 + 2 * t]), clk[7 + 2 * t] - clk[6 + 2 * t]);
