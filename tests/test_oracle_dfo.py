@@ -206,3 +206,30 @@ def test_batch_driver_modes_3_4():
         assert np.all(out["status"] == 5)
         assert util.continuity_defect(batch, out["coeffs"], out["times"]) < 1e-7
         assert util.constraint_defect(batch, out["coeffs"], out["times"]) < 1e-7
+
+
+def test_gradient_free_modes_run_on_every_arithmetic_route():
+    """the oracle's other arithmetic routes (exact unit-time tables, 113-bit linear solve) under the gradient-free searches:
+    same stopping reasons, times within the noise the reference-style route carries"""
+    import numpy as np
+    from mrs_uav_trajectory_generation_amd import problem as pr
+    from tests import util
+    batch = pr.random_batch(6, 4, seed0=321)
+    t = util.oracle_times(batch)
+    so = batch.seg_offsets
+    for p in range(batch.n_paths):
+        _, m, v = batch.path(p)
+        tp = t[so[p]:so[p + 1]]
+        base = {}
+        for mode in (0, 1, 3):
+            with po.arithmetic(po.REFERENCE_ARITHMETIC):
+                base[mode] = (po.optimize_times_dfo(4, m, v, tp, batch.limits[p], mode=mode, max_iterations=12) if mode < 3 else
+                              po.optimize_time_and_constraints_dfo(4, m, v, tp, batch.limits[p], mode=mode, max_iterations=12))
+        for route in (po.EXACT_CONSTANTS, po.QUAD_PRECISION):
+            with po.arithmetic(route):
+                for mode in (0, 1, 3):
+                    r = (po.optimize_times_dfo(4, m, v, tp, batch.limits[p], mode=mode, max_iterations=12) if mode < 3 else
+                         po.optimize_time_and_constraints_dfo(4, m, v, tp, batch.limits[p], mode=mode, max_iterations=12))
+                    assert r[0] == base[mode][0]   # stopping reason
+                    assert np.max(np.abs(r[1] - base[mode][1]) / base[mode][1]) < 1e-6, (p, mode, route)   # times
+    assert po.lib().mto_get_arithmetic() == 0
