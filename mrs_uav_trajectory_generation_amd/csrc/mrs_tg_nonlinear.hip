@@ -1,5 +1,5 @@
 // mrs_tg_nonlinear.hip -- segment-time outer loop (mode 2, Mellinger), feasibility scaling and the
-// final re-solve, fused in one kernel; plus the two building-block kernels exposed for parity tests.
+// final re-solve; plus the two building-block kernels exposed for parity tests.
 //
 // Reference behaviour being reproduced (paths relative to /root/reference/):
 //   include/eth_trajectory_generation/impl/polynomial_optimization_nonlinear_impl.h
@@ -8,13 +8,17 @@
 //   src/eth_trajectory_generation/trajectory.cpp:598-692  scaleSegmentTimesToMeetConstraints
 //   src/eth_trajectory_generation/segment.cpp:113-212     magnitude extremum candidates
 //
-// Pipeline per bin of paths (host-orchestrated, one stream):
-//   optimize_split_kernel / optimize_compact_kernel   the outer loop (one dimension / four dimensions per lane);
-//                        every tick = one objective evaluation = S+1 cost sweeps
-//   solve (fused)        coefficients at the last evaluated times             (mrs_tg_kernels / mrs_tg_tile)
-//   segment_maxima9      max |p^(k)| per segment, one (k, group) per blockIdx.y so wavefronts stay uniform
-//   apply_scaling        T <- T * max(1, v, sqrt a, cbrt j)
-//   solve (fused)        final coefficients, cost, merged status
+// Pipeline of a call (host-orchestrated, one stream; launch_nonlinear at the end of this file):
+//   optimize_lean_kernel (plain paths of large batches) and / or optimize_split_kernel / optimize_compact_kernel (one
+//                        dimension / four dimensions per lane): the outer loop, every bin of the plan in one launch;
+//                        every tick = one objective evaluation = S+1 cost sweeps.  On request behind them:
+//                        optimize_careful_kernel (MRS_TG_FLAG_CAREFUL_COST), optimize_general_kernel (paths with a
+//                        position-free vertex, MRS_TG_FLAG_GENERAL_PATTERNS)
+//   solve                coefficients at the last evaluated times              (mrs_tg_rows / mrs_tg_kernels)
+//   segment_maxima9      max |p^(k)| per segment (mrs_tg_maxima.hpp), one (k, group) per blockIdx.y
+//   solve with its tail  T <- T * max(1, v, sqrt a, cbrt j) in the staging pass, final coefficients, cost, merged status,
+//                        samples (mrs_tg_rows.hip); batches that kernel does not take: apply_scaling + runaway + solve
+// The gradient-free modes 0 / 1 / 3 / 4 live in mrs_tg_dfo.hip.
 //
 // Mapping of the outer loop onto the wavefront: one GROUP of G lanes per path, one wavefront per workgroup.
 // An objective evaluation needs the cost at S+1 time vectors (unperturbed + one per segment,
