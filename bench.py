@@ -38,7 +38,7 @@ nonlinear workload keeps one batch in flight per stream.
 Prints ONE JSON line (rank 0): `roofline` (assembly kernel, HBM-write bound; `achieved` uses the PER-DISPATCH duration --
 events attached to the kernel launch itself, what rocprofv3 --kernel-trace reports for the dispatch; the back-to-back
 launch interval is given beside it and labelled), `roofline_solve` / `roofline_outer_loop` (FP64, flop model of SURVEY.md 8d
-over the per-dispatch duration), and `cpu_baseline` (the C oracle on this box's host cores: one core, and all cores through
+over the per-dispatch duration), and `cpu_baseline` (rank 0 of an N = 1 run only; the C oracle on this box's host cores: one core, and all cores through
 its persistent thread pool on the configs[3]-sized batch -- with as many threads as the container's cgroup grants CPUs,
 `cpu_quota_cpus`, when that is less than the hardware threads it sees).
 """
@@ -810,7 +810,7 @@ def main():
     cpu = None
     err = None
     err_exact = None
-    if rank == 0 and not args.no_cpu_baseline:
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:   # (the contract: rank 0, at N = 1 only)
         from oracle import pyoracle as po
         active_lanes[0] = n_lanes
         step_no[0] = 0
