@@ -5,6 +5,9 @@ tag=${1:-round}
 cd "$(dirname "$0")/.." && export TMPDIR=/tmp
 mkdir -p gpurun_out
 O=gpurun_out
+# the micro-benchmark binaries are not tracked: build what is missing (hipcc is on the GPU box as well)
+[ -x scripts/tile_phases.bin ] || /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -I mrs_uav_trajectory_generation_amd/csrc -I include scripts/tile_phases.hip -o scripts/tile_phases.bin
+[ -x scripts/k1_variants.bin ] || /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -I mrs_uav_trajectory_generation_amd/csrc -I include scripts/k1_variants.hip -o scripts/k1_variants.bin
 python3 bench.py --steps 20 --warmup 5 2>/dev/null | grep '^{"metric' > $O/${tag}_bench_line_20_steps.json
 python3 bench.py --steps 200 --warmup 20 2>/dev/null | grep '^{"metric' > $O/${tag}_bench_line.json
 scripts/profile_round.sh $tag > $O/${tag}_profile_round.log 2>&1
