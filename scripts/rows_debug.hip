@@ -2,6 +2,7 @@
 // small path (development aid, not part of the library)
 #define MRS_TG_ROWS_DEBUG 1
 #include "../mrs_uav_trajectory_generation_amd/csrc/mrs_tg_rows.hip"
+#include "../mrs_uav_trajectory_generation_amd/csrc/mrs_tg_pool.hip"
 #include <cstdio>
 #include <vector>
 using namespace mrs_tg;
