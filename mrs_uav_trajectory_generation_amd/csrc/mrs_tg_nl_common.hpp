@@ -9,10 +9,12 @@
 namespace mrs_tg {
 
 // cross-lane moves (DPP within a row of 16, v_readlane across rows)
+// (bound_ctrl set: with all rows and banks enabled and a permutation that stays inside the row every lane is written, so
+// the "old" operand is dead -- without the flag the compiler materialises it, two more v_mov_b32 per moved double)
 template <int CTRL>
 __device__ __forceinline__ double dpp_move(double v) {
-  const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xF, 0xF, false);
-  const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xF, 0xF, false);
+  const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xF, 0xF, true);
+  const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xF, 0xF, true);
   return __hiloint2double(hi, lo);
 }
 
@@ -26,6 +28,14 @@ __device__ __forceinline__ bool relstop(double vold, double vnew, double reltol,
   if (isinf(vold)) return false;
   const double dv = fabs(vnew - vold);
   return dv < abstol || dv < reltol * (fabs(vnew) + fabs(vold)) * 0.5 || (reltol > 0 && vnew == vold);
+}
+
+// the same rule without branches (every term is evaluated; for the outer loop's bookkeeping, where the short-circuit form
+// turns into a ladder of exec-mask branches)
+__device__ __forceinline__ bool relstop_flat(double vold, double vnew, double reltol, double abstol) {
+  const double dv = fabs(vnew - vold);
+  const bool hit = (dv < abstol) | (dv < reltol * (fabs(vnew) + fabs(vold)) * 0.5) | ((reltol > 0) & (vnew == vold));
+  return (!isinf(vold)) & hit;
 }
 
 // reciprocal: hardware estimate + two Newton steps (~1 ulp)

@@ -248,7 +248,7 @@ int mto_optimize_times_mellinger(const mto_path* path, const mto_nlopt_params* p
       ret = MTO_MAXEVAL_REACHED;
       goto done;
     }
-    if (sy > 1e-10 * sqrt(ss) * sqrt(yy)) { /* curvature condition holds: remember the pair */
+    if (sy > 0.0 && sy * sy > 1e-20 * (ss * yy)) { /* curvature condition s^T y > 1e-10 |s| |y| (in squares): remember the pair */
       if (npairs == LBFGS_M) {
         for (int k = 1; k < LBFGS_M; ++k) {
           memcpy(sm[k - 1], sm[k], sizeof(double) * (size_t)S);
