@@ -76,7 +76,8 @@ __device__ __forceinline__ void row0_sum(double (&v)[N]) {
   for (int n = 0; n < N; ++n) v[n] = row_value(v[n], 0);
 }
 
-__device__ __forceinline__ bool uniform(bool c) { return __builtin_amdgcn_readfirstlane((int)c) != 0; }
+// a condition that is the same in every lane, as a scalar (v_cmp into an SGPR pair + s_cmp: no round trip through a VGPR)
+__device__ __forceinline__ bool uniform(bool c) { return __ballot(c) != 0ull; }
 
 // segment_powers with the objective order as three select masks (bits of d) instead of a branch tree per segment step:
 // T^d = (d & 1 ? T : 1) (d & 2 ? T^2 : 1) (d & 4 ? T^4 : 1), the same products as segment_powers forms (times exact ones)
@@ -335,7 +336,13 @@ __global__ __launch_bounds__(64, MRS_TG_WAVE_WAVES) void optimize_wave_kernel(Ba
   auto budget_spent = [&](int n) { return (maxeval > 0 && n >= maxeval) || timed_out; };
   auto budget_code = [&](int n) { return (maxeval > 0 && n >= maxeval) ? 5 : 6; };
 
-  int neval = 0, npairs = 0, head = 0, ret = -1;
+  // curvature pairs: slot k of sm / ym / rho holds the k-th oldest pair (slots >= npairs are read along and not used)
+  if (lane < kWvVec) {
+#pragma unroll
+    for (int k = 0; k < kLbfgsM; ++k) sm[k * kWvVec + lane] = ym[k * kWvVec + lane] = 0.0;
+    if (lane <= kLbfgsM) rho[lane] = 0.0;
+  }
+  int neval = 0, npairs = 0, ret = -1;
   double f = 0.0, alpha = 1.0;
   bool done = bad;
   while (!done) {
@@ -351,9 +358,21 @@ __global__ __launch_bounds__(64, MRS_TG_WAVE_WAVES) void optimize_wave_kernel(Ba
 #ifdef MRS_TG_PHASE_CLOCKS
     if (neval <= 6) MRS_TG_PHASE_MARK(4 + 2 * neval);  // after evaluation #neval - 1
 #endif
-    // (2) accept / reject; element i of every vector in lane i
-    double xi = me ? x[lane] : 0.0, gi = me ? gr[lane] : 0.0;
-    const double xni = me ? xn[lane] : 0.0, gni = me ? gn[lane] : 0.0;
+    // (2) accept / reject; element i of every vector in lane i.  Everything the tick may need is
+    // requested from LDS here, in one batch.  Lanes S .. 15 hold zeros (nobody writes those words); lanes >= 16 read row 0's
+    // words and compute along, but no sum (row 0 only), ballot (`me`) or store (`me`) looks at them.
+    const int vl = lane & (kWvVec - 1);
+    double xi = x[vl], gi = gr[vl];
+    double xni = xn[vl], gni = gn[vl];
+    double di = dir[vl];
+    double sk[kLbfgsM], yk[kLbfgsM], rk[kLbfgsM];
+#pragma unroll
+    for (int k = 0; k < kLbfgsM; ++k) {
+      sk[k] = sm[k * kWvVec + vl];
+      yk[k] = ym[k * kWvVec + vl];
+      rk[k] = rho[k];
+    }
+    double gamma = rho[kLbfgsM];  // s^T y / y^T y of the newest pair
     bool new_dir = false;
     if (neval == 1) {
       f = fn;
@@ -388,23 +407,40 @@ __global__ __launch_bounds__(64, MRS_TG_WAVE_WAVES) void optimize_wave_kernel(Ba
         const bool budget_out = budget_spent(neval);
         // curvature condition s^T y > 1e-10 |s| |y|, compared in squares (no square roots on the chain)
         if (!stop && !budget_out && uniform((sy > 0.0) & (sy * sy > 1e-20 * (ss * yy)))) {
-          int slot;
-          if (npairs == kLbfgsM) {
-            slot = head;  // overwrite the oldest pair
-            head = head + 1 == kLbfgsM ? 0 : head + 1;
-          } else {
-            slot = head + npairs;
-            slot = slot >= kLbfgsM ? slot - kLbfgsM : slot;
-            ++npairs;
+          if (npairs == kLbfgsM) {  // forget the oldest pair: the others move down one slot, in LDS and in this tick's copy
+#pragma unroll
+            for (int k = 0; k + 1 < kLbfgsM; ++k) {
+              sk[k] = sk[k + 1];
+              yk[k] = yk[k + 1];
+              rk[k] = rk[k + 1];
+              if (me) {
+                sm[k * kWvVec + lane] = sk[k];
+                ym[k * kWvVec + lane] = yk[k];
+              }
+              if (lane == 0) rho[k] = rk[k];
+            }
+            npairs = kLbfgsM - 1;
           }
+          // 1 / s^T y and the scaling of the initial Hessian s^T y / y^T y by refined reciprocals (~1 ulp; an IEEE division
+          // is a chain of a dozen dependent operations)
+          const double rho_new = rcp_refined(sy);
+          gamma = sy * rcp_refined(yy);
+#pragma unroll
+          for (int k = 0; k < kLbfgsM; ++k)  // (a ladder of scalar branches: a run-time index would send the arrays to scratch)
+            if (k == npairs) {
+              sk[k] = si;
+              yk[k] = yi;
+              rk[k] = rho_new;
+            }
           if (me) {
-            sm[slot * kWvVec + lane] = si;
-            ym[slot * kWvVec + lane] = yi;
+            sm[npairs * kWvVec + lane] = si;
+            ym[npairs * kWvVec + lane] = yi;
           }
           if (lane == 0) {
-            rho[slot] = 1.0 / sy;
-            rho[kLbfgsM] = sy / yy;  // the scaling of the initial Hessian, taken from the newest pair
+            rho[npairs] = rho_new;
+            rho[kLbfgsM] = gamma;
           }
+          ++npairs;
         }
 #ifdef MRS_TG_PHASE_CLOCKS
     if (neval == 2) MRS_TG_PHASE_MARK(26);
@@ -442,28 +478,15 @@ __global__ __launch_bounds__(64, MRS_TG_WAVE_WAVES) void optimize_wave_kernel(Ba
     if (neval == 2) MRS_TG_PHASE_MARK(28);  // tick 1: accept step done
 #endif
     // (3) search direction: L-BFGS two-loop recursion, projected on the lower bound
-    double di = 0.0;
 #ifdef MRS_TG_PHASE_CLOCKS
     if (neval == 2) MRS_TG_PHASE_MARK(29);
 #endif
     if (new_dir) {
-      __syncthreads();  // the pair stored above
       di = -gi;
       if (npairs > 0) {
-        // the pairs and their rho are read up front (independent of the recursion), the recursion runs in registers
-        double sk[kLbfgsM], yk[kLbfgsM], rk[kLbfgsM], al[kLbfgsM];
+        double al[kLbfgsM];
 #pragma unroll
-        for (int k = 0; k < kLbfgsM; ++k) {
-          sk[k] = yk[k] = rk[k] = al[k] = 0.0;
-          if (k < npairs) {
-            int id = head + k;
-            id = id >= kLbfgsM ? id - kLbfgsM : id;
-            sk[k] = me ? sm[id * kWvVec + lane] : 0.0;
-            yk[k] = me ? ym[id * kWvVec + lane] : 0.0;
-            rk[k] = rho[id];
-          }
-        }
-        const double gamma = rho[kLbfgsM];  // s^T y / y^T y of the newest pair, computed when it was stored
+        for (int k = 0; k < kLbfgsM; ++k) al[k] = 0.0;
 #ifdef MRS_TG_PHASE_CLOCKS
     if (neval == 2) MRS_TG_PHASE_MARK(27);
 #endif
@@ -504,7 +527,6 @@ __global__ __launch_bounds__(64, MRS_TG_WAVE_WAVES) void optimize_wave_kernel(Ba
         gd = red2[0];
         nd = red2[1];
         npairs = 0;
-        head = 0;
         if (!uniform(gd < 0.0)) {  // projected gradient vanishes
           ret = 1;
           done = true;
@@ -517,8 +539,6 @@ __global__ __launch_bounds__(64, MRS_TG_WAVE_WAVES) void optimize_wave_kernel(Ba
         if (cap < alpha) alpha = cap;
       }
       if (me) dir[lane] = di;
-    } else if (me) {
-      di = dir[lane];
     }
     // (4) next trial point
     if (!done && me) xn[lane] = fmax(xi + alpha * di, kTimeLowerBound);
