@@ -94,6 +94,8 @@ def parse_args(argv=None):
     ap.add_argument("--group-size", type=int, default=8,
                     help="--issue grouped: batches per dispatch; the --in-flight batches are spread over in-flight / group-size "
                          "streams, each stream's dispatches carry group-size steps")
+    ap.add_argument("--shared-inputs", dest="distinct_slots", action="store_false",
+                    help="every batch in flight reads slot 0's input arrays (the round-3 set-up; default: each slot has its own batch)")
     ap.add_argument("--config3-paths", type=int, default=CONFIG3_PATHS, help="size of the fixed batch of extras.config3")
     return ap.parse_args(argv)
 
@@ -138,6 +140,9 @@ def self_launch(args, argv):
 # ---------------------------------------------------------------------------------------------------------------------
 # helpers (run inside a rank)
 
+LAST_OWN_ELAPSED = [0.0]
+
+
 def time_steps(step_fn, steps, warmup, dist, torch, final_fn=None, block_fn=None, gather_inside=False):
     """W untimed steps, then exactly K steps between barrier + synchronize pairs.  Every rank reads its own clock right after
     its own synchronize (before the closing barrier, whose cost is a property of the collective library, not of the K steps);
@@ -166,6 +171,7 @@ def time_steps(step_fn, steps, warmup, dist, torch, final_fn=None, block_fn=None
         final_fn()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
+    LAST_OWN_ELAPSED[0] = elapsed   # this rank's own figure, before the MAX over ranks
     gather_s = 0.0
     if final_fn is not None and not gather_inside and dist is not None:
         t1 = time.perf_counter()
@@ -377,6 +383,24 @@ def main():
     slot_cost = [torch.zeros(P, dtype=torch.float64, device=dev) for _ in range(n_slots)]
     slot_nsamp = [torch.zeros(P, dtype=torch.int32, device=dev) for _ in range(n_slots)]
     slot_samples = [db.samples] + [torch.zeros_like(db.samples) for _ in range(n_slots - 1)]
+    # Fixed-times steps: every batch in flight has its OWN inputs as well -- slot s of rank r holds the paths seeded
+    # (r * slots + s) * paths + p (slot 0 of rank 0 = the paths 0 .. P-1 every other figure of the line is quoted on), its own
+    # masks, constrained values and Euclidean times, so sixteen batches in flight read sixteen different batches.
+    slot_batch, slot_db, slot_t = [batch], [db], [t_fixed]
+    for sl in range(1, n_slots if args.distinct_slots else 1):
+        bs = pr.random_batch(args.paths, args.segments, seed0=(rank * n_slots + sl) * args.paths)
+        dbs = api.DeviceBatch(bs, dev, sample_capacity=0)
+        plan.solve(est, dbs.fixed_mask, dbs.fixed_values, dbs.seg_times, dbs.coeffs, dbs.status, dbs.cost,
+                   waypoints=dbs.waypoints, limits=dbs.limits)
+        torch.cuda.synchronize()
+        slot_batch.append(bs)
+        slot_db.append(dbs)
+        slot_t.append(dbs.seg_times.clone())
+
+    def slot_inputs(slot):
+        i = slot if slot < len(slot_db) else 0
+        return slot_db[i].fixed_mask, slot_db[i].fixed_values, slot_t[i]
+
     bound = {}
 
     def slot_call(kind, slot, lane):
@@ -384,9 +408,9 @@ def main():
         key = (kind, slot, lane, sh)
         if key not in bound:
             if kind in ("linear", "blocks"):
-                bound[key] = lane_plan[lane].bind_solve(opt_lin[sh] if kind == "linear" else opt_blocks[sh], db.fixed_mask,
-                                                        db.fixed_values, t_fixed, out_coeffs[slot], status_i32[slot],
-                                                        slot_cost[slot])
+                s_mask, s_vals, s_times = slot_inputs(slot)
+                bound[key] = lane_plan[lane].bind_solve(opt_lin[sh] if kind == "linear" else opt_blocks[sh], s_mask, s_vals,
+                                                        s_times, out_coeffs[slot], status_i32[slot], slot_cost[slot])
             else:
                 bound[key] = lane_plan[lane].bind_solve(opt_nl[sh], db.fixed_mask, db.fixed_values, out_times[slot], out_coeffs[slot],
                                                         status_i32[slot], slot_cost[slot], limits=db.limits,
@@ -512,6 +536,16 @@ def main():
                                    block_fn=block_for(args.workload))
     total_paths = P * world * args.steps
     value = total_paths / elapsed
+    # what every rank saw, so that a first multi-GPU curve can be read from the line alone: its own K-step time, the device it
+    # ran on, and whether the dmabuf IPC mode the pool's driver needs was set in its environment
+    props = torch.cuda.get_device_properties(dev)
+    rank_info = dict(rank=rank, local_rank=local_rank, device_index=dev_index, device=props.name,
+                     arch=getattr(props, "gcnArchName", None), ms_per_step=LAST_OWN_ELAPSED[0] / args.steps * 1e3,
+                     hsa_enable_ipc_mode_legacy=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY"))
+    per_rank = [rank_info]
+    if dist is not None:
+        per_rank = [None] * dist.get_world_size()
+        dist.all_gather_object(per_rank, rank_info)
     gather_check = verify_gather() if dist is not None else None
 
     # ---- roofline of the assembly kernel (rank 0's device) ----
@@ -610,10 +644,11 @@ def main():
         # executed work: every VALU instruction counted as a 64-lane FP64 FMA -- an upper bound of the flops the kernel ran
         c = sq_nl["counters"]
         nl_exec = 2.0 * 64 * c["SQ_INSTS_VALU"]
-        roofline_outer = dict(kernel=sq_nl["kernel"], bound="fp64 vector", unit="TFLOP/s", peak=FP64_VECTOR_PEAK_TFLOPS,
-                              flop_per_launch=nl_exec, avg_launch_us=nl_mean * 1e3, median_launch_us=nl_med * 1e3,
-                              achieved=nl_exec / (nl_mean * 1e-3) / 1e12,
-                              frac=nl_exec / (nl_mean * 1e-3) / 1e12 / FP64_VECTOR_PEAK_TFLOPS,
+        roofline_outer = dict(kernel=sq_nl["kernel"], bound="fp64 vector issue", unit="wavefront VALU instructions/s",
+                              peak=issue_peak, avg_launch_us=nl_mean * 1e3, median_launch_us=nl_med * 1e3,
+                              achieved=c["SQ_INSTS_VALU"] / (nl_mean * 1e-3),
+                              valu_issue_frac=c["SQ_INSTS_VALU"] / (nl_mean * 1e-3) / issue_peak,
+                              valu_lane_flop_upper_bound_per_launch=nl_exec,
                               counted=dict(source=sq_nl["source"] + " (separate rocprofv3 --pmc passes; from profiles/, not this run)",
                                            valu_instructions_per_launch=c["SQ_INSTS_VALU"],
                                            lds_instructions_per_launch=c["SQ_INSTS_LDS"],
@@ -623,14 +658,15 @@ def main():
                                            lds_bank_conflict_share=(c["SQ_LDS_BANK_CONFLICT"] / c["SQ_LDS_IDX_ACTIVE"]
                                                                     if c.get("SQ_LDS_IDX_ACTIVE") else None)),
                               reference_work_flop=nl_flop,
-                              note="flop_per_launch = 2 x 64 x counted VALU instructions (upper bound of the executed FP64 work); "
+                              note="an ISSUE rate, not a flop rate: counted VALU instructions per second against one per 4 cycles per SIMD "
+                                   "(valu_lane_flop_upper_bound_per_launch = 2 x 64 x that count, if every instruction were a full FP64 FMA); "
                                    "reference_work_flop is SURVEY.md 8d's model of what the reference would execute for the same "
                                    "batch (7e6 flop per 10-segment path = 121 linear solves), which the kernel undercuts by running "
                                    "forward-only cost sweeps on exact constants and stopping on ftol / xtol -- not a rate")
     else:
-        roofline_outer = dict(kernel="optimize_split_kernel / optimize_compact_kernel", bound="fp64 vector", unit="TFLOP/s",
-                              peak=FP64_VECTOR_PEAK_TFLOPS, flop_per_launch=None, avg_launch_us=nl_mean * 1e3,
-                              median_launch_us=nl_med * 1e3, achieved=None, frac=None, reference_work_flop=nl_flop,
+        roofline_outer = dict(kernel="optimize_wave_kernel / optimize_split_kernel / optimize_lean_kernel", bound="fp64 vector issue",
+                              unit="wavefront VALU instructions/s", peak=issue_peak, avg_launch_us=nl_mean * 1e3,
+                              median_launch_us=nl_med * 1e3, achieved=None, valu_issue_frac=None, reference_work_flop=nl_flop,
                               note="no committed SQ counters for this batch shape (scripts/pmc_sq.sh); reference_work_flop is "
                                    "SURVEY.md 8d's model of the reference's work, not what the kernel executes")
 
@@ -836,6 +872,36 @@ def main():
             a, b = sub.seg_offsets[p], sub.seg_offsets[p + 1]
             worst = max(worst, float(np.max(np.abs(gpu_c[a:b] - ref["coeffs"][a:b])) / np.max(np.abs(ref["coeffs"][a:b]))))
         err = worst
+        # every batch in flight against the oracle: each slot solved ITS OWN batch (seeds (rank * slots + slot) * paths + p)
+        slots_checked = None
+        if len(slot_db) > 1:
+            slots_run = n_group_slots if (grouped_mode[0] and n_lanes > 1 and n_group_slots > 1) else n_lanes
+            # one more round through the headline's own issue path (the extras above have used the slots for other workloads
+            # since the timed region), from zeroed outputs: what is compared is what that round wrote
+            for sl in range(min(slots_run, len(slot_db))):
+                out_coeffs[sl].zero_()
+                status_i32[sl].zero_()
+            torch.cuda.synchronize()
+            step_no[0] = 0
+            if block_for("linear") is not None:
+                block_for("linear")(slots_run)
+            else:
+                for _ in range(slots_run):
+                    steps_fn["linear"]()
+            torch.cuda.synchronize()
+            worst_slot = []
+            for sl in range(min(slots_run, len(slot_db))):
+                bs = slot_batch[sl]
+                rs = po.solve_batch(bs.seg_offsets, bs.waypoints, bs.fixed_mask, bs.fixed_values, bs.limits, slot_t[sl].cpu().numpy(),
+                                    deriv=4, n_threads=cores_for_checks())
+                gc = out_coeffs[sl].cpu().numpy()
+                st_ok = bool((status_i32[sl].cpu().numpy() == 1).all())
+                w = max(float(np.max(np.abs(gc[a:b] - rs["coeffs"][a:b])) / np.max(np.abs(rs["coeffs"][a:b])))
+                        for a, b in zip(bs.seg_offsets[:-1], bs.seg_offsets[1:]))
+                worst_slot.append((w, st_ok))
+            slots_checked = dict(slots=len(worst_slot), max_coeff_err_vs_cpu_ref=max(w for w, _ in worst_slot),
+                                 every_status_success=all(ok for _, ok in worst_slot),
+                                 distinct_inputs=True, seeds="(rank * slots + slot) * paths + p")
         # the same comparison against the oracle's 113-bit route (the reference's algorithm without its rounding: what is left is
         # the HIP path's own error, where the figure above is dominated by the double-precision oracle's)
         po.lib().mto_set_arithmetic(po.QUAD_PRECISION)
@@ -912,6 +978,11 @@ def main():
         line = dict(metric="trajectories/sec (batch of N-seg min-snap paths)", value=value, unit="trajectories/s",
                     n_gpus=world, ranks_seen=ranks_seen, steps=args.steps, warmup=args.warmup,
                     ms_per_step=elapsed / args.steps * 1e3,
+                    ms_per_step_by_rank=dict(min=min(r["ms_per_step"] for r in per_rank), max=max(r["ms_per_step"] for r in per_rank)),
+                    ranks=per_rank,
+                    value_definition="paths of all ranks x K / MAX over ranks of a rank's own time between its two synchronizes "
+                                     "around its K steps; the closing gather is timed on its own (gather_ms) and is inside "
+                                     "value_including_gather -- compare THAT figure across N when the collective matters",
                     gather_ms=(gather_s * 1e3 if dist is not None else None),
                     value_including_gather=(total_paths / (elapsed + gather_s) if dist is not None else None),
                     gather_check=gather_check,
@@ -927,8 +998,11 @@ def main():
                                              "(nothing materialised); the assembly kernel is timed on its own (roofline) and "
                                              "inside extras.materialized_blocks_step",
                                 clock_ramp_steps=ramp_steps, clock_ramp_ms=30,
-                                step_issue=(("mrs_tg_bound_solve_launch_group: %d consecutive steps (each a full pass over its own batch, "
-                                             "with its own input / output arrays) go out as ONE dispatch; the dispatches alternate "
+                                slot_inputs=("every batch in flight has its own masks, constrained values and segment times (path seeds "
+                                             "(rank * slots + slot) * paths + p) and its own outputs" if len(slot_db) > 1 else
+                                             "the batches in flight share ONE set of input arrays (--shared-inputs); outputs per slot"),
+                                step_issue=(("mrs_tg_bound_solve_launch_group: %d consecutive steps (each a full pass over the batch of "
+                                             "its slot, see slot_inputs) go out as ONE dispatch; the dispatches alternate "
                                              "over %d HIP stream(s)" % (max(1, min(args.group_size, n_group_slots)),
                                                                        min(n_lanes, (n_group_slots + max(1, min(args.group_size, n_group_slots)) - 1)
                                                                            // max(1, min(args.group_size, n_group_slots)))) if (grouped_mode[0] and args.workload == "linear" and n_lanes > 1)
@@ -945,7 +1019,8 @@ def main():
                                                 "once, after the last step: timed on its own (gather_ms) right behind the K "
                                                 "steps; value_including_gather has it inside"))
                                 if world > 1 else "single GPU"),
-                    max_coeff_err_vs_cpu_ref=err, max_coeff_err_vs_113bit_ref=err_exact, roofline=roofline, roofline_solve=roofline_solve,
+                    max_coeff_err_vs_cpu_ref=err, max_coeff_err_vs_113bit_ref=err_exact,
+                    in_flight_slots_vs_cpu_ref=(slots_checked if (rank == 0 and world == 1 and not args.no_cpu_baseline) else None), roofline=roofline, roofline_solve=roofline_solve,
                     roofline_outer_loop=roofline_outer, cpu_baseline=cpu, extras=extras)
         import ctypes
         ctypes.CDLL(None).fflush(None)   # RCCL's banner sits in C stdio: keep the JSON line the last thing printed

@@ -230,8 +230,8 @@ def _np_ptr(a):
     return C.c_void_p(a.ctypes.data) if a is not None else None
 
 
-class _PinnedBlock:
-    """keeps a block of mrs_tg_host_alloc alive for the numpy array that views it"""
+class _PinnedOwner:
+    """frees a block of mrs_tg_host_alloc when the last reference to it is gone"""
 
     def __init__(self, nbytes):
         self._L = load_library()
@@ -239,7 +239,6 @@ class _PinnedBlock:
         rc = self._L.mrs_tg_host_alloc(C.c_size_t(nbytes), C.byref(self.ptr))
         if rc:
             raise MrsTgError("mrs_tg_host_alloc failed (%d): %s" % (rc, self._L.mrs_tg_last_error(None).decode()))
-        self.buf = (C.c_char * max(int(nbytes), 1)).from_address(self.ptr.value)
 
     def __del__(self):
         if getattr(self, "ptr", None) is not None and self.ptr.value:
@@ -249,18 +248,15 @@ class _PinnedBlock:
 
 def pinned_empty(shape, dtype=np.float64):
     """A numpy array in pinned host memory (mrs_tg_host_alloc): the GPU's DMA engines read / write it directly, so
-    mrs_tg_solve_batch neither stages nor pins it per call."""
+    mrs_tg_solve_batch neither stages nor pins it per call.  The block lives as long as ANY array that views it: numpy
+    collapses chains of views onto the buffer object they all come from (here the ctypes array), so the owner of the block
+    hangs on that object -- not on the first array handed out, which a slice or a ravel() of it does not keep alive."""
     dtype = np.dtype(dtype)
     n = int(np.prod(shape)) if np.ndim(shape) else int(shape)
-    block = _PinnedBlock(n * dtype.itemsize)
-    a = np.frombuffer(block.buf, dtype=dtype, count=n).reshape(shape)
-    _PINNED_KEEPALIVE[id(block)] = block
-    import weakref
-    weakref.finalize(a, _PINNED_KEEPALIVE.pop, id(block), None)
-    return a
-
-
-_PINNED_KEEPALIVE = {}
+    owner = _PinnedOwner(n * dtype.itemsize)
+    buf = (C.c_char * max(n * dtype.itemsize, 1)).from_address(owner.ptr.value)
+    buf._owner = owner   # buffer object -> owner; every view -> buffer object
+    return np.frombuffer(buf, dtype=dtype, count=n).reshape(shape)
 
 
 def pinned_copy(a):

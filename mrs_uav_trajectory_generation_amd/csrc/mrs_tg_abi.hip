@@ -880,20 +880,33 @@ int mrs_tg_solve_batch(mrs_tg_ctx* ctx, int32_t n_paths, const int32_t* so, cons
     void* pinned;     // device-side address of the caller's array when it lives in pinned memory
     size_t off;       // offset in the device arena
   };
-  auto pinned_address = [](const void* ptr) -> void* {
-    hipPointerAttribute_t at;
-    if (hipPointerGetAttributes(&at, ptr) != hipSuccess) {
-      (void)hipGetLastError();  // an ordinary (pageable) pointer is reported as an error by some runtimes
-      return nullptr;
+  // device-side address of a host range the GPU can address as a whole: first AND last byte must be pinned and lie in the
+  // same mapping (a range that mrs_tg_host_register covers only in part, or an allocation shorter than the batch implies,
+  // takes the copying route -- where a short array is a host-side fault of the caller's, not a GPU page fault)
+  auto pinned_address = [](const void* ptr, size_t bytes) -> void* {
+    auto query = [](const void* q, hipPointerAttribute_t* at) {
+      if (hipPointerGetAttributes(at, q) != hipSuccess) {
+        (void)hipGetLastError();  // an ordinary (pageable) pointer is reported as an error by some runtimes
+        return false;
+      }
+      return at->type == hipMemoryTypeHost;
+    };
+    hipPointerAttribute_t first, last;
+    if (!query(ptr, &first)) return nullptr;
+    void* dev_first = first.devicePointer ? first.devicePointer : const_cast<void*>(ptr);
+    if (bytes > 1) {
+      const char* end = static_cast<const char*>(ptr) + (bytes - 1);
+      if (!query(end, &last)) return nullptr;
+      const char* dev_last = static_cast<const char*>(last.devicePointer ? last.devicePointer : (void*)end);
+      if (dev_last - static_cast<const char*>(dev_first) != (ptrdiff_t)(bytes - 1)) return nullptr;  // two mappings
     }
-    if (at.type != hipMemoryTypeHost) return nullptr;
-    return at.devicePointer ? at.devicePointer : const_cast<void*>(ptr);
+    return dev_first;
   };
   auto make = [&](const void* src, void* dst, size_t bytes) {
     const void* host = src ? src : dst;
     Arr a{src, dst, bytes, false, nullptr, 0};
     if (host != nullptr && bytes > 0) {
-      a.pinned = pinned_address(host);
+      a.pinned = pinned_address(host, bytes);
       a.staged = a.pinned == nullptr && bytes <= stage_max;
     }
     return a;
@@ -970,6 +983,7 @@ int mrs_tg_solve_batch(mrs_tg_ctx* ctx, int32_t n_paths, const int32_t* so, cons
                    mrs_tg::rows_kernel_applies(plan->view, sampling) && (!sampling || mrs_tg::rows_tail_sampling_pays(plan->view));
   for (int id = 0; id < A_COUNT && zero_copy; ++id) {
     const Arr& a = arr[id];
+    if (id == A_LIM) continue;  // the fixed-times solve never reads the limits: a pageable limits array does not decide this
     if ((a.src || a.dst) && a.bytes && !a.pinned) zero_copy = false;
   }
   // where the kernels find array `id`: the caller's own (pinned) memory under zero copy, its slot of the arena otherwise

@@ -63,9 +63,12 @@ __global__ __launch_bounds__(64) void segment_maxima4_kernel(int n_segments, con
   maxima4[(size_t)s * 3 + (k - 1)] = sqrt(m2) * scale;
 }
 
-enum { kDfoFirst = -1, kDfoInitPlus = 0, kDfoInitMinus = 1, kDfoCompass = 2 };
+enum { kDfoFirst = -1, kDfoSearch = 0, kDfoRevisit = 1, kDfoInitPlus = 2, kDfoInitMinus = 3, kDfoCompass = 4 };
+constexpr double kDfoMinDecrease = 1.0e-6;  // a trial must lower the best value by more than this share of it (oracle/mto_dfo.c)
 // per-path int state: [0] phase [1] i [2] sg [3] neval [4] improved [5] ret [6] done [7] number of variables
-constexpr int kDfoInts = 8;
+//                     [8] a trial of the current coordinate was accepted [9] code to stop with after the revisit
+//                     [10] the last evaluated trial is the best point
+constexpr int kDfoInts = 11;
 
 __host__ __device__ __forceinline__ size_t dfo_var_offset(int s0, int p) { return (size_t)21 * s0 + (size_t)20 * p; }
 __host__ __device__ __forceinline__ size_t dfo_var_total(int n_segments, int n_paths) {
@@ -177,6 +180,9 @@ __global__ __launch_bounds__(64) void dfo_init_kernel(BatchView b, DfoParams prm
   st[5] = bad ? -2 : -1;
   st[6] = bad ? 1 : 0;
   st[7] = n_var;
+  st[8] = 0;
+  st[9] = 0;
+  st[10] = 0;
   fvals[p] = 0.0;
   fvals[b.n_paths + p] = 0.0;
 }
@@ -274,79 +280,136 @@ __global__ __launch_bounds__(64) void dfo_step_kernel(BatchView b, DfoParams prm
     }
     f += soft;
   }
-  // ---- state machine (same transitions as oracle/mto_dfo.c::dfo_step)
-  int phase = st[0], ci = st[1], sg = st[2], neval = st[3], improved = st[4];
+  // ---- state machine (same transitions as oracle/mto_dfo.c::dfo_step: greedy coordinate search with step doubling /
+  // halving whose last evaluation is its best point)
+  const bool greedy = prm.mode < 3;  // modes 0 / 1: greedy coordinate search; 3 / 4: interpolation sweep + compass
+  int phase = st[0], ci = st[1], sg = st[2], neval = st[3], improved = st[4], acc_any = st[8], pending = st[9],
+      last_is_best = st[10];
   double fbest = fvals[p], f_sweep = fvals[b.n_paths + p];
   bool accepted = false;
   ++neval;
-  if (phase == kDfoFirst) {
-    fbest = f;
-  } else if (f < fbest) {
-    fbest = f;
-    for (int k = 0; k < n; ++k) w.best[k] = x[k];
-    improved = 1;
-    accepted = true;
-  }
   int ret = -1;
   bool done = false;
-  if (prm.max_iterations > 0 && neval >= prm.max_iterations) {
-    ret = 5;
+  if (phase == kDfoRevisit) {  // back on the best point: that was the search's last evaluation
+    ret = pending;
     done = true;
-  } else if (deadline && *deadline != 0ll && (long long)wall_clock64() > *deadline) {
-    ret = 6;  // nlopt maxtime
-    done = true;
+  } else {
+    if (phase == kDfoFirst) {
+      fbest = f;
+      last_is_best = 1;
+    } else if (greedy ? f < fbest - kDfoMinDecrease * fabs(fbest) : f < fbest) {
+      fbest = f;
+      for (int k = 0; k < n; ++k) w.best[k] = x[k];
+      improved = 1;
+      accepted = true;
+      last_is_best = 1;
+      if (greedy) w.h[ci] *= 2.0;
+    } else {
+      last_is_best = 0;
+    }
+    if (prm.max_iterations > 0 && neval >= prm.max_iterations) {
+      ret = 5;
+      done = true;
+    } else if (deadline && *deadline != 0ll && (long long)wall_clock64() > *deadline) {
+      ret = 6;  // nlopt maxtime
+      done = true;
+    }
   }
   while (!done) {
-    if (phase == kDfoFirst) {
-      phase = kDfoInitPlus;
-      ci = 0;
-    } else if (phase == kDfoInitPlus) {
-      if (++ci >= n) {
-        phase = kDfoInitMinus;
+    int stop = 0;
+    if (!greedy) {
+      // modes 3 / 4: Powell's decision-free interpolation sweep x0 +- h_i e_i, then the compass search (oracle/mto_dfo.c,
+      // dfo_step_sweep, and why these modes keep it)
+      if (phase == kDfoFirst) {
+        phase = kDfoInitPlus;
         ci = 0;
-      }
-    } else if (phase == kDfoInitMinus) {
-      if (++ci >= n) {
-        phase = kDfoCompass;
-        for (int k = 0; k < n; ++k) w.h[k] *= 0.5;
-        ci = 0;
-        sg = 0;
-        f_sweep = fbest;
-        improved = 0;
-        accepted = false;
-      }
-    } else {
-      if (sg == 0 && !accepted) {
-        sg = 1;
+      } else if (phase == kDfoInitPlus) {
+        if (++ci >= n) {
+          phase = kDfoInitMinus;
+          ci = 0;
+        }
+      } else if (phase == kDfoInitMinus) {
+        if (++ci >= n) {
+          phase = kDfoCompass;
+          for (int k = 0; k < n; ++k) w.h[k] *= 0.5;
+          ci = 0;
+          sg = 0;
+          f_sweep = fbest;
+          improved = 0;
+          accepted = false;
+        }
       } else {
-        sg = 0;
-        ++ci;
-      }
-      accepted = false;
-      if (ci >= n) {
-        if (improved) {
-          if (relstop(f_sweep, fbest, prm.f_rel, prm.f_abs)) {
-            ret = 3;
-            done = true;
-            break;
+        if (sg == 0 && !accepted) {
+          sg = 1;
+        } else {
+          sg = 0;
+          ++ci;
+        }
+        accepted = false;
+        if (ci >= n) {
+          if (improved) {
+            if (relstop(f_sweep, fbest, prm.f_rel, prm.f_abs)) stop = 3;
+          } else {
+            bool all_small = true;
+            for (int k = 0; k < n; ++k) {
+              w.h[k] *= 0.5;
+              if (!(w.h[k] < prm.x_abs || w.h[k] < prm.x_rel * fabs(w.best[k]))) all_small = false;
+            }
+            if (all_small) stop = 4;
           }
+          f_sweep = fbest;
+          improved = 0;
+          ci = 0;
+          sg = 0;
+        }
+      }
+    } else if (phase == kDfoFirst) {
+      phase = kDfoSearch;
+      ci = 0;
+      sg = 0;
+      acc_any = 0;
+      improved = 0;
+      f_sweep = fbest;
+    } else if (accepted) {
+      acc_any = 1;  // same coordinate, same direction, doubled step
+    } else if (!acc_any && sg == 0) {
+      sg = 1;  // the first + trial failed: the other direction
+    } else {
+      sg = 0;
+      acc_any = 0;
+      if (++ci >= n) {  // end of a sweep
+        if (improved) {
+          if (relstop(f_sweep, fbest, prm.f_rel, prm.f_abs)) stop = 3;
         } else {
           bool all_small = true;
           for (int k = 0; k < n; ++k) {
             w.h[k] *= 0.5;
             if (!(w.h[k] < prm.x_abs || w.h[k] < prm.x_rel * fabs(w.best[k]))) all_small = false;
           }
-          if (all_small) {
-            ret = 4;
-            done = true;
-            break;
-          }
+          if (all_small) stop = 4;
         }
         f_sweep = fbest;
         improved = 0;
         ci = 0;
-        sg = 0;
       }
+    }
+    accepted = false;
+    if (stop) {
+      if (last_is_best) {
+        ret = stop;
+        done = true;
+        break;
+      }
+      phase = kDfoRevisit;
+      pending = stop;
+      for (int k = 0; k < n; ++k) x[k] = w.best[k];
+      break;
+    }
+    if (prm.max_iterations > 0 && neval >= prm.max_iterations - 1) {  // the budget's last evaluation belongs to the best point
+      phase = kDfoRevisit;
+      pending = 5;
+      for (int k = 0; k < n; ++k) x[k] = w.best[k];
+      break;
     }
     const double lo = w.lb[ci], hi = w.ub[ci], hc = w.h[ci];
     if (phase == kDfoInitPlus) {
@@ -362,7 +425,7 @@ __global__ __launch_bounds__(64) void dfo_step_kernel(BatchView b, DfoParams prm
       break;
     }
     const double t = fmin(fmax(w.best[ci] + (sg == 0 ? hc : -hc), lo), hi);
-    if (t == w.best[ci]) continue;
+    if (t == w.best[ci]) continue;  // nothing to try in this direction: as a failed trial
     for (int k = 0; k < n; ++k) x[k] = w.best[k];
     x[ci] = t;
     break;
@@ -374,6 +437,9 @@ __global__ __launch_bounds__(64) void dfo_step_kernel(BatchView b, DfoParams prm
   st[2] = sg;
   st[3] = neval;
   st[4] = improved;
+  st[8] = acc_any;
+  st[9] = pending;
+  st[10] = last_is_best;
   if (done) {
     st[5] = ret;
     st[6] = 1;

@@ -85,6 +85,11 @@ void mto_segment_hessian(int derivative, double T, double* Hout, double* Ainv_ou
  * 2 = the whole linear solve (tables, R, QR, coefficients, cost) in 113-bit arithmetic, rounded to double once: the value
  *     both other routes and the HIP path approximate.  ~50x slower; the optimisers around it stay in double. */
 void mto_set_arithmetic(int mode);
+/* 1: mto_solve_batch reports a Mellinger result whose feasibility scaling multiplied the path's total time by more than
+ * MTO_RUNAWAY_TIME_FACTOR as MTO_ROUNDOFF_LIMITED, as the PRODUCT does (a documented deviation of include/mrs_tg.h from the
+ * reference, which returns the outer loop's code and discards the trajectory by the nodelet's length check); 0 (default): the
+ * reference's behaviour. */
+void mto_set_runaway_rule(int on);
 int mto_get_arithmetic(void);
 /* the unit-time tables of route 1: ABAR^-1 [10][10], HBAR_d [5][10][10] (113-bit arithmetic, rounded once) */
 void mto_unit_tables(double* abar_inv_out, double* hbar_out);

@@ -15,10 +15,11 @@
  *
  * The reference minimises this objective with NLopt's LN_BOBYQA (un-vendored).  BOBYQA is not restated; the
  * driver below is this project's own deterministic derivative-free search ("MRS-DFO"),
- * which the HIP path implements identically: Powell's initial interpolation sweep x0 +- h_i e_i (the only part
- * BOBYQA reaches with the shipping max_iterations = 10), then a compass search with step halving.  As with
- * mode 2 the point that is kept is the LAST EVALUATED one (the optimiser object's state), and there is no
- * feasibility scaling in these modes.
+ * which the HIP path implements identically: for the time-only modes 0 / 1 a greedy coordinate search with step doubling /
+ * halving (dfo_step), for modes 3 / 4 Powell's decision-free initial interpolation sweep + compass search (dfo_step_sweep,
+ * and why); either spends its last evaluation on the best point it has found.  As with mode 2 the point that is kept is the LAST EVALUATED one
+ * (the optimiser object's state) -- which is why the search ends there -- and there is no feasibility scaling in these
+ * modes.
  */
 #include <float.h>
 #include <math.h>
@@ -90,30 +91,55 @@ static int relstop(double vold, double vnew, double reltol, double abstol) {
 }
 
 /* ---- MRS-DFO as an explicit state machine: one objective evaluation per step -------------------------- */
+/* The search: a greedy coordinate search whose last evaluation is its best point.
+ *   - evaluate x0; then for every coordinate i in turn try best + h_i e_i; a trial that improves on the best value is
+ *     (by more than 1e-6 of it) is accepted at once (the search moves), h_i doubles (and stays doubled) and the same direction is tried again; when
+ *     the first trial in the + direction fails, - h_i is tried the same way; then the next coordinate;
+ *   - a sweep over all coordinates that improved: NLopt's relstop rule on f (-> FTOL_REACHED); one that did not: every h
+ *     halves, and the search stops with XTOL_REACHED when every h_i < x_abs or < x_rel |best_i|;
+ *   - the reference keeps the LAST EVALUATED point (its optimiser object's state), so the search spends its last
+ *     evaluation -- the budget's, or one more after a tolerance stop -- on the best point it has found.
+ * (Round 4: replaces Powell's initial sweep x0 +- h_i e_i + compass search, whose kept point -- x0 + h e_9 with the
+ * shipping budget of 10 evaluations -- was on average no better than the start; measured against scipy's Powell and COBYLA
+ * in tests/test_dfo_quality.py.) */
 
-enum { DFO_FIRST = -1, DFO_INIT_PLUS = 0, DFO_INIT_MINUS = 1, DFO_COMPASS = 2 };
+enum { DFO_FIRST = -1, DFO_SEARCH = 0, DFO_REVISIT = 1, DFO_INIT_PLUS = 2, DFO_INIT_MINUS = 3, DFO_COMPASS = 4 };
+/* a trial is accepted when it lowers the best value by more than this share of it: decisions then do not hang on the last
+ * digits of f (two correct evaluations of f differ by ~1e-9 relative through their linear solves; a trial that moves a free
+ * derivative of value 0 by 1e-13 changes f by less than that) */
+static const double kDfoMinDecrease = 1.0e-6;
 
 typedef struct {
-  int phase, i, sg, neval, improved, ret, done;
+  int phase, i, sg, neval, improved, ret, done, acc_any, pending, last_is_best;
   double fbest, f_sweep;
 } dfo_state;
 
 static double clampd(double t, double lo, double hi) { return t < lo ? lo : (t > hi ? hi : t); }
 
 /* consume the objective value f of the trial held in x (the last evaluated point); write the next trial into x.
- * x0, best, h, lb, ub are the per-path vectors of the search (n variables). */
-static void dfo_step(dfo_state* st, int n, double f, double* x, double* x0, double* best, double* h, const double* lb,
+ * best, h, lb, ub are the per-path vectors of the search (n variables). */
+static void dfo_step(dfo_state* st, int n, double f, double* x, double* best, double* h, const double* lb,
                      const double* ub, const mto_dfo_params* prm) {
   const int maxeval = prm->nlopt.max_iterations;
   int accepted = 0;
   st->neval++;
+  if (st->phase == DFO_REVISIT) { /* back on the best point: that was the search's last evaluation */
+    st->ret = st->pending;
+    st->done = 1;
+    return;
+  }
   if (st->phase == DFO_FIRST) {
     st->fbest = f;
-  } else if (f < st->fbest) {
+    st->last_is_best = 1;
+  } else if (f < st->fbest - kDfoMinDecrease * fabs(st->fbest)) {
     st->fbest = f;
     memcpy(best, x, sizeof(double) * (size_t)n);
     st->improved = 1;
     accepted = 1;
+    st->last_is_best = 1;
+    h[st->i] *= 2.0;
+  } else {
+    st->last_is_best = 0;
   }
   if (maxeval > 0 && st->neval >= maxeval) {
     st->ret = MTO_MAXEVAL_REACHED;
@@ -121,6 +147,100 @@ static void dfo_step(dfo_state* st, int n, double f, double* x, double* x0, doub
     return;
   }
   for (;;) {
+    int stop = 0;
+    if (st->phase == DFO_FIRST) {
+      st->phase = DFO_SEARCH;
+      st->i = 0;
+      st->sg = 0;
+      st->acc_any = 0;
+      st->improved = 0;
+      st->f_sweep = st->fbest;
+    } else if (accepted) {
+      st->acc_any = 1; /* same coordinate, same direction, doubled step */
+    } else if (!st->acc_any && st->sg == 0) {
+      st->sg = 1; /* the first + trial failed: the other direction */
+    } else {
+      st->sg = 0;
+      st->acc_any = 0;
+      if (++st->i >= n) { /* end of a sweep */
+        if (st->improved) {
+          if (relstop(st->f_sweep, st->fbest, prm->nlopt.f_rel, prm->nlopt.f_abs)) stop = MTO_FTOL_REACHED;
+        } else {
+          int all_small = 1;
+          for (int k = 0; k < n; ++k) {
+            h[k] *= 0.5;
+            if (!(h[k] < prm->nlopt.x_abs || h[k] < prm->nlopt.x_rel * fabs(best[k]))) all_small = 0;
+          }
+          if (all_small) stop = MTO_XTOL_REACHED;
+        }
+        st->f_sweep = st->fbest;
+        st->improved = 0;
+        st->i = 0;
+      }
+    }
+    accepted = 0;
+    if (stop) {
+      if (st->last_is_best) {
+        st->ret = stop;
+        st->done = 1;
+        return;
+      }
+      st->phase = DFO_REVISIT;
+      st->pending = stop;
+      memcpy(x, best, sizeof(double) * (size_t)n);
+      return;
+    }
+    if (maxeval > 0 && st->neval >= maxeval - 1) { /* the budget's last evaluation belongs to the best point */
+      st->phase = DFO_REVISIT;
+      st->pending = MTO_MAXEVAL_REACHED;
+      memcpy(x, best, sizeof(double) * (size_t)n);
+      return;
+    }
+    const int i = st->i;
+    const double t = clampd(best[i] + (st->sg == 0 ? h[i] : -h[i]), lb[i], ub[i]);
+    if (t == best[i]) continue; /* nothing to try in this direction: as a failed trial */
+    memcpy(x, best, sizeof(double) * (size_t)n);
+    x[i] = t;
+    return;
+  }
+}
+
+/* Modes 3 / 4 (variables = segment times AND free end-point derivatives).  Their objective moves by ~1e-3 when the
+ * held derivatives move by 1e-9 (a snap cost at times the derivatives were not solved for), so two correct implementations
+ * disagree on f in the third digit and any search whose trial points depend on comparisons of f takes different roads in
+ * them.  These modes therefore keep the DECISION-FREE start: Powell's initial interpolation sweep x0 + h_i e_i, then
+ * x0 - h_i e_i (the points BOBYQA itself starts with; 2 n + 1 = 309 evaluations for a 10-segment min-snap path, i.e. every
+ * practical budget), then a compass search with step halving -- and, like the greedy search, the last evaluation goes back
+ * to the best point found (one comparison per evaluated point, not a road). */
+static void dfo_step_sweep(dfo_state* st, int n, double f, double* x, double* x0, double* best, double* h, const double* lb,
+                           const double* ub, const mto_dfo_params* prm) {
+  const int maxeval = prm->nlopt.max_iterations;
+  int accepted = 0;
+  st->neval++;
+  if (st->phase == DFO_REVISIT) {
+    st->ret = st->pending;
+    st->done = 1;
+    return;
+  }
+  if (st->phase == DFO_FIRST) {
+    st->fbest = f;
+    st->last_is_best = 1;
+  } else if (f < st->fbest) {
+    st->fbest = f;
+    memcpy(best, x, sizeof(double) * (size_t)n);
+    st->improved = 1;
+    accepted = 1;
+    st->last_is_best = 1;
+  } else {
+    st->last_is_best = 0;
+  }
+  if (maxeval > 0 && st->neval >= maxeval) {
+    st->ret = MTO_MAXEVAL_REACHED;
+    st->done = 1;
+    return;
+  }
+  for (;;) {
+    int stop = 0;
     if (st->phase == DFO_FIRST) {
       st->phase = DFO_INIT_PLUS;
       st->i = 0;
@@ -149,28 +269,37 @@ static void dfo_step(dfo_state* st, int n, double f, double* x, double* x0, doub
       accepted = 0;
       if (st->i >= n) { /* end of a sweep */
         if (st->improved) {
-          if (relstop(st->f_sweep, st->fbest, prm->nlopt.f_rel, prm->nlopt.f_abs)) {
-            st->ret = MTO_FTOL_REACHED;
-            st->done = 1;
-            return;
-          }
+          if (relstop(st->f_sweep, st->fbest, prm->nlopt.f_rel, prm->nlopt.f_abs)) stop = MTO_FTOL_REACHED;
         } else {
           int all_small = 1;
           for (int k = 0; k < n; ++k) {
             h[k] *= 0.5;
             if (!(h[k] < prm->nlopt.x_abs || h[k] < prm->nlopt.x_rel * fabs(best[k]))) all_small = 0;
           }
-          if (all_small) {
-            st->ret = MTO_XTOL_REACHED;
-            st->done = 1;
-            return;
-          }
+          if (all_small) stop = MTO_XTOL_REACHED;
         }
         st->f_sweep = st->fbest;
         st->improved = 0;
         st->i = 0;
         st->sg = 0;
       }
+    }
+    if (stop) {
+      if (st->last_is_best) {
+        st->ret = stop;
+        st->done = 1;
+        return;
+      }
+      st->phase = DFO_REVISIT;
+      st->pending = stop;
+      memcpy(x, best, sizeof(double) * (size_t)n);
+      return;
+    }
+    if (maxeval > 0 && st->neval >= maxeval - 1) { /* the budget's last evaluation belongs to the best point */
+      st->phase = DFO_REVISIT;
+      st->pending = MTO_MAXEVAL_REACHED;
+      memcpy(x, best, sizeof(double) * (size_t)n);
+      return;
     }
     /* build the trial of the current (phase, i, sg) */
     const int i = st->i;
@@ -195,22 +324,22 @@ static void dfo_step(dfo_state* st, int n, double f, double* x, double* x0, doub
 int mto_optimize_time_dfo(const mto_path* path, const double* limits9, const mto_dfo_params* prm, double* x,
                           int* n_eval_out, double* f_last_out) {
   const int n = path->n_seg;
-  double x0[MTO_MAX_SEG], h[MTO_MAX_SEG], best[MTO_MAX_SEG], lb[MTO_MAX_SEG], ub[MTO_MAX_SEG];
+  double h[MTO_MAX_SEG], best[MTO_MAX_SEG], lb[MTO_MAX_SEG], ub[MTO_MAX_SEG];
   for (int i = 0; i < n; ++i) {
     if (x[i] < 0.01) { /* NLopt rejects a start outside the bounds */
       if (n_eval_out) *n_eval_out = 0;
       return MTO_INVALID_ARGS;
     }
-    x0[i] = best[i] = x[i];
+    best[i] = x[i];
     h[i] = prm->initial_stepsize_rel * x[i]; /* nonlinear_impl.h:127-130 */
     lb[i] = 0.01;                            /* kOptimizationTimeLowerBound, :134-135 */
     ub[i] = DBL_MAX;
   }
-  dfo_state st = {DFO_FIRST, 0, 0, 0, 0, MTO_FAILURE, 0, 0.0, 0.0};
+  dfo_state st = {DFO_FIRST, 0, 0, 0, 0, MTO_FAILURE, 0, 0, 0, 0, 0.0, 0.0};
   double f = 0.0;
   while (!st.done) {
     f = mto_objective_time(path, x, limits9, prm, NULL);
-    dfo_step(&st, n, f, x, x0, best, h, lb, ub, prm);
+    dfo_step(&st, n, f, x, best, h, lb, ub, prm);
   }
   if (n_eval_out) *n_eval_out = st.neval;
   if (f_last_out) *f_last_out = f;
@@ -293,12 +422,12 @@ int mto_optimize_time_and_constraints_dfo(const mto_path* path, const double* li
     else if (x[i] > ub[i]) ub[i] = x[i];
     x0[i] = best[i] = x[i];
   }
-  dfo_state st = {DFO_FIRST, 0, 0, 0, 0, MTO_FAILURE, 0, 0.0, 0.0};
+  dfo_state st = {DFO_FIRST, 0, 0, 0, 0, MTO_FAILURE, 0, 0, 0, 0, 0.0, 0.0};
   double f = 0.0;
   while (!st.done) {
     f = mto_objective_time_and_constraints(path, x, limits9, prm, coeffs_out, NULL);
     memcpy(seg_times, x, sizeof(double) * (size_t)S); /* the optimiser object holds the last evaluated point */
-    dfo_step(&st, n, f, x, x0, best, h, lb, ub, prm);
+    dfo_step_sweep(&st, n, f, x, x0, best, h, lb, ub, prm);
   }
   if (n_eval_out) *n_eval_out = st.neval;
   if (f_last_out) *f_last_out = f;

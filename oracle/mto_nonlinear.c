@@ -562,6 +562,11 @@ void mto_estimate_segment_times_baca(int n_seg, const double* wp, const double* 
 /* ------------------------------------------------------------------------------------------- */
 /* one path, and the batch driver                                                               */
 
+/* 0 (default): the reference's behaviour -- the outer loop's own code whatever the feasibility scaling did to the times;
+ * 1: the product's runaway rule (see solve_one). */
+static int g_runaway_rule = 0;
+void mto_set_runaway_rule(int on) { g_runaway_rule = on ? 1 : 0; }
+
 static int solve_one(int S, const double* wp, const uint8_t* mask, const double* vals, const double* lim,
                      const mto_options* opt, double* times, double* coeffs, double* cost_out, int32_t* n_samples,
                      double* samples, int capacity) {
@@ -585,11 +590,12 @@ static int solve_one(int S, const double* wp, const uint8_t* mask, const double*
       mto_scale_segment_times_to_meet_constraints(S, coeffs, times, lim, NULL);
       mto_solve_linear(&path, times, coeffs);
       /* Not in the reference (it hands such a path back with the outer loop's code and leaves it to the nodelet's length
-       * check, src/mrs_trajectory_generation.cpp:1178-1199): a scaling that multiplied the total time by more than
-       * MTO_RUNAWAY_TIME_FACTOR is reported as nlopt's ROUNDOFF_LIMITED, which the nodelet's gate rejects (:1103, :1146);
-       * the same rule as the product's include/mrs_tg.h states. */
+       * check, src/mrs_trajectory_generation.cpp:1178-1199) and therefore OFF by default here: with
+       * mto_set_runaway_rule(1) a scaling that multiplied the total time by more than MTO_RUNAWAY_TIME_FACTOR is reported
+       * as nlopt's ROUNDOFF_LIMITED, which the nodelet's gate rejects (:1103, :1146) -- the product's documented deviation
+       * (include/mrs_tg.h), switched on by the tests that compare status words with the product's. */
       for (int i = 0; i < S; ++i) sum_t1 += times[i];
-      if (status > 0 && sum_t1 > MTO_RUNAWAY_TIME_FACTOR * sum_t0) status = MTO_ROUNDOFF_LIMITED;
+      if (g_runaway_rule && status > 0 && sum_t1 > MTO_RUNAWAY_TIME_FACTOR * sum_t0) status = MTO_ROUNDOFF_LIMITED;
     }
   } else if (opt->time_alloc_method == 0 || opt->time_alloc_method == 1) {
     /* optimizeTime (nonlinear_impl.h:121-157): no feasibility scaling afterwards; the trajectory is the one

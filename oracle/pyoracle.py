@@ -77,6 +77,8 @@ def lib():
         L.mto_segment_hessian.argtypes = [C.c_int, C.c_double, dp, dp]
         L.mto_set_arithmetic.restype = None
         L.mto_set_arithmetic.argtypes = [C.c_int]
+        L.mto_set_runaway_rule.restype = None
+        L.mto_set_runaway_rule.argtypes = [C.c_int]
         L.mto_get_arithmetic.restype = C.c_int
         L.mto_unit_tables.restype = None
         L.mto_unit_tables.argtypes = [dp, dp]
@@ -419,8 +421,11 @@ def unwrap_heading(what, frm):
 
 def solve_batch(seg_offsets, waypoints, fixed_mask, fixed_values, limits, seg_times, *, deriv=4,
                 time_alloc_method=-1, estimate_times=False, max_iterations=10, sampling_dt=0.0,
-                sample_capacity=0, n_threads=1, time_penalty=100.0, use_soft_constraints=1, soft_constraint_weight=1.5):
-    """Batch driver in the C-ABI's CSR layout. Returns dict(times, coeffs, status, cost, n_samples, samples)."""
+                sample_capacity=0, n_threads=1, time_penalty=100.0, use_soft_constraints=1, soft_constraint_weight=1.5,
+                runaway_rule=True):
+    """Batch driver in the C-ABI's CSR layout. Returns dict(times, coeffs, status, cost, n_samples, samples).
+    runaway_rule: report a runaway of the feasibility scaling as ROUNDOFF_LIMITED (-4) like the product does (its documented
+    deviation); False = the reference's behaviour, the outer loop's own code (mto_set_runaway_rule)."""
     so = np.ascontiguousarray(seg_offsets, dtype=np.int32)
     P = so.size - 1
     total_S = int(so[-1])
@@ -436,10 +441,12 @@ def solve_batch(seg_offsets, waypoints, fixed_mask, fixed_values, limits, seg_ti
     samples = np.zeros((P, max(sample_capacity, 1), D))
     opt = make_options(deriv, time_alloc_method, estimate_times, max_iterations, sampling_dt, time_penalty,
                        use_soft_constraints, soft_constraint_weight)
+    lib().mto_set_runaway_rule(1 if runaway_rule else 0)
     lib().mto_solve_batch(P, so.ctypes.data_as(C.POINTER(C.c_int32)), _dp(w), m.ctypes.data_as(C.POINTER(C.c_uint8)),
                           _dp(v), _dp(lim), C.byref(opt), _dp(t), _dp(coeffs),
                           status.ctypes.data_as(C.POINTER(C.c_int32)), _dp(cost),
                           ns.ctypes.data_as(C.POINTER(C.c_int32)), _dp(samples) if sample_capacity > 0 else None,
                           sample_capacity, n_threads)
+    lib().mto_set_runaway_rule(0)
     return dict(times=t, coeffs=coeffs, status=status, cost=cost, n_samples=ns,
                 samples=samples if sample_capacity > 0 else None)

@@ -280,6 +280,29 @@ def test_issue_loop_on_several_host_threads(gpu_ctx):
         c.close()
 
 
+def test_pinned_block_lives_as_long_as_any_view_of_it(gpu_ctx):
+    """the pinned block used to be freed when the FIRST array handed out died, although slices / ravel() /
+    reshape of it (which numpy attaches to the underlying buffer object, not to that array) were still alive"""
+    import gc
+    import weakref
+    a = api.pinned_copy(np.arange(4096.0))
+    buf = a
+    while isinstance(buf, np.ndarray):   # every view ends at the buffer object the block was wrapped in
+        buf = buf.base
+    owner = weakref.ref(buf._owner)
+    del buf
+    view = a.reshape(64, 64)[3:5].ravel()[8:16]
+    expect = view.copy()
+    del a
+    gc.collect()
+    assert owner() is not None, "the block was released while a view of it is alive"
+    others = [api.pinned_copy(np.full(4096, -1.0)) for _ in range(8)]   # would land in a released block
+    assert np.array_equal(view, expect)
+    del view, others
+    gc.collect()
+    assert owner() is None, "the block is not released with its last view"
+
+
 def test_pinned_pageable_and_mixed_host_buffers_give_identical_results(gpu_ctx):
     """mrs_tg_solve_batch moves every array the way its location allows (pinned: DMA in place; small pageable: packed
     through the context's staging block; large pageable: hipMemcpyAsync on the caller's pages).  Whatever the mix, the

@@ -1,0 +1,51 @@
+"""Multi-GPU pre-flight on the one GPU of the box: BASELINE configs[3]'s per-GPU shard size (8192 random 10-segment paths,
+Mellinger outer loop + feasibility scaling + sampling) through the C ABI's device list (mrs_tg_create_multi /
+mrs_tg_multi_solve_batch, two contexts on device 0, one host thread each), and the sharded result against the ORACLE -- the
+other multi-device tests compare with the single-device solve only, at <= 41 paths."""
+import numpy as np
+import pytest
+
+from mrs_uav_trajectory_generation_amd import api, problem as pr
+from oracle import pyoracle as po
+from tests import util
+
+pytestmark = pytest.mark.gpu
+CAP = 192
+
+
+def test_config3_shard_over_a_device_list_against_the_oracle(gpu_ctx):
+    batch = pr.random_batch(8192, 10, seed0=0)
+    multi = api.MultiContext([0, 0])
+    shard = multi.shard(batch.seg_offsets)
+    sizes = np.bincount(shard, minlength=2)
+    assert sizes.tolist() == [4096, 4096] and np.all(np.diff(shard) >= 0)   # contiguous halves
+    opts = dict(time_alloc_method=api.TIME_ALLOC_MELLINGER, sampling_dt=0.2, sample_capacity=CAP)
+    many = multi.solve_batch(batch, None, **opts)
+    multi.close()
+    so = batch.seg_offsets
+    assert np.all(np.isin(many["status"], (1, 3, 4, 5, api.STATUS_ROUNDOFF_LIMITED)))
+    assert np.all(np.isfinite(many["coeffs"])) and np.all(many["times"] >= 0.01)
+    # a strided subset that straddles the shard boundary, against the oracle
+    idx = sorted(set(range(0, 8192, 32)) | set(range(4090, 4102)))
+    sub = batch.select(idx)
+    ref = po.solve_batch(sub.seg_offsets, sub.waypoints, sub.fixed_mask, sub.fixed_values, sub.limits,
+                         np.zeros(sub.n_segments), deriv=4, time_alloc_method=2, estimate_times=True, sampling_dt=0.2,
+                         sample_capacity=CAP, n_threads=8)
+    good = 0
+    for k, p in enumerate(idx):
+        a, b = sub.seg_offsets[k], sub.seg_offsets[k + 1]
+        t = many["times"][so[p]:so[p + 1]]
+        c = many["coeffs"][so[p]:so[p + 1]]
+        same = (many["status"][p] == ref["status"][k] and many["n_samples"][p] == ref["n_samples"][k]
+                and np.max(np.abs(t - ref["times"][a:b]) / ref["times"][a:b]) < 1e-6
+                and util.coeff_error(c, ref["coeffs"][a:b]) < 1e-6)
+        if same:
+            n = min(int(ref["n_samples"][k]), CAP)
+            same = np.max(np.abs(many["samples"][p, :n, :3] - ref["samples"][k, :n, :3])) < 1e-5
+        good += bool(same)
+    print("RATE device list [0, 0], 8192 x 10 Mellinger: %d / %d paths agree with the oracle" % (good, len(idx)))
+    assert good >= 0.99 * len(idx), (good, len(idx))
+    # and with the single-device solve, bit for bit (same kernels per path)
+    one = gpu_ctx.solve_batch(batch, None, **opts)
+    for key in ("times", "coeffs", "status", "n_samples"):
+        assert np.array_equal(one[key], many[key]), key

@@ -59,20 +59,82 @@ def test_soft_constraint_cost_is_capped():
     assert parts[2] == 12e12
 
 
+def _python_search(fun, x0, lb, ub, budget, f_rel=0.05, x_rel=0.1):
+    """DESIGN.md 5b restated in Python (an independent transcription of the specification, not of the C code): greedy
+    coordinate search, h_i doubles on success and all h halve after a sweep without one, the last evaluation is the best
+    point.  Returns (kept point, its value, evaluations, code)."""
+    n = len(x0)
+    h = 0.1 * np.abs(x0)
+    h[np.abs(x0) <= np.finfo(float).eps] = 1e-13
+    evals = [0]
+
+    def relstop(a, b, tol):
+        return abs(b - a) < tol * (abs(a) + abs(b)) * 0.5 or (tol > 0 and a == b)
+
+    def f(x):
+        evals[0] += 1
+        return fun(x)
+    best, fbest = np.array(x0, dtype=float), f(x0)
+    last_is_best = True
+    if budget == 1:
+        return best, fbest, 1, 5
+
+    def finish(code):   # the search ends on its best point
+        if last_is_best and code != 5:
+            return best, fbest, evals[0], code
+        return best, f(best), evals[0], code
+    while True:
+        f_sweep, improved = fbest, False
+        for i in range(n):
+            acc_any = False
+            for sg in (+1.0, -1.0):
+                while True:
+                    if evals[0] >= budget - 1:
+                        return finish(5)
+                    t = min(max(best[i] + sg * h[i], lb[i]), ub[i])
+                    if t == best[i]:
+                        break
+                    x = best.copy()
+                    x[i] = t
+                    v = f(x)
+                    if v < fbest - 1e-6 * abs(fbest):
+                        best, fbest, improved, acc_any, last_is_best = x, v, True, True, True
+                        h[i] *= 2.0
+                        continue
+                    last_is_best = False
+                    break
+                if acc_any:
+                    break
+        if improved:
+            if relstop(f_sweep, fbest, f_rel):
+                return finish(3)
+        else:
+            h *= 0.5
+            if np.all(h < x_rel * np.abs(best)):
+                return finish(4)
+
+
 @pytest.mark.parametrize("n_seg,mode", [(1, 0), (3, 0), (3, 1), (10, 0), (10, 1)])
-def test_dfo_first_evaluations_follow_the_initial_interpolation_sweep(n_seg, mode):
-    """the shipping budget (max_iterations = 10) never leaves x0 +- h e_i with h = 0.1 x0 for S >= 5"""
+def test_dfo_follows_its_specification_evaluation_by_evaluation(n_seg, mode):
+    """every budget from 1 to 40: the kept point, its value, the evaluation count and the code of the C search equal those of
+    the Python transcription of DESIGN.md 5b; the kept point is the BEST evaluated point (the search's last evaluation
+    revisits it), so its value never goes up with the budget"""
     _, m, v, t = _path(n_seg, 21 + n_seg)
     lim = pr.DEFAULT_LIMITS
-    for budget in range(1, 2 * n_seg + 2):
+    fun = lambda x: po.objective_time(4, m, v, x, lim, mode=mode)[0]  # noqa: E731
+    f_prev = np.inf
+    for budget in range(1, 41):
         rc, x, ne, fl = po.optimize_times_dfo(4, m, v, t, lim, mode=mode, max_iterations=budget)
-        assert rc == 5 and ne == budget
-        exp = t.copy()
-        if budget >= 2:
-            i = (budget - 2) % n_seg
-            exp[i] = t[i] * (1.1 if budget - 2 < n_seg else 0.9)
-        assert np.allclose(x, exp, rtol=1e-15, atol=0)
-        assert fl == pytest.approx(po.objective_time(4, m, v, x, lim, mode=mode)[0], rel=1e-15)
+        ex, ef, en, ec = _python_search(fun, t, np.full(n_seg, 0.01), np.full(n_seg, np.inf), budget)
+        assert (rc, ne) == (ec, en), (budget, rc, ne, ec, en)
+        assert np.array_equal(x, ex) and fl == ef
+        assert fl == pytest.approx(fun(x), rel=1e-15)
+        assert fl <= f_prev
+        f_prev = fl
+        if rc != 5:
+            break
+    # the first trial is x0 + 0.1 x0 e_0 (initial_stepsize_rel, nonlinear_impl.h:127-130)
+    assert f_prev <= fun(t)
 
 
 def test_dfo_converges_and_never_leaves_the_bounds():
@@ -82,11 +144,10 @@ def test_dfo_converges_and_never_leaves_the_bounds():
     rc, x, ne, fl = po.optimize_times_dfo(4, m, v, t, lim, mode=1, max_iterations=400)
     assert rc in (3, 4) and ne < 400
     assert np.all(x >= 0.01)
-    # the last evaluated point is at most one compass step from the best point, whose value is <= f(x0)
+    # a budget that is exactly what the search used ends on the same point (by the budget's rule then: code 5)
     rc2, x2, ne2, fl2 = po.optimize_times_dfo(4, m, v, t, lim, mode=1, max_iterations=ne)
     assert np.array_equal(x, x2) and fl == fl2
-    best = min(po.optimize_times_dfo(4, m, v, t, lim, mode=1, max_iterations=k)[3] for k in range(1, ne + 1))
-    assert best < f_start
+    assert fl < f_start
 
 
 def test_dfo_rejects_start_below_lower_bound():
@@ -161,27 +222,45 @@ def test_free_derivative_bounds_snap_and_the_acceleration_quirk():
 
 
 @pytest.mark.parametrize("mode", [3, 4])
-def test_dfo_time_and_constraints_first_evaluations(mode):
+def test_dfo_time_and_constraints_follows_its_specification(mode):
     _, m, v, t = _path(4, 6)
     lim = pr.DEFAULT_LIMITS
     c0, free = po.solve_linear_free(4, m, v, t)
     rc, x, c, ne, fl = po.optimize_time_and_constraints_dfo(4, m, v, t, lim, mode=mode, max_iterations=1)
     assert rc == 5 and ne == 1 and np.array_equal(x, t) and util.coeff_error(c, c0) < 1e-13
-    # second evaluation: T_0 + 10 % with the free constraints held (not re-solved)
-    rc, x, c, ne, fl = po.optimize_time_and_constraints_dfo(4, m, v, t, lim, mode=mode, max_iterations=2)
+    # variables [T, free derivatives of dimension 0, 1, 2, 3], bounds widened to the start (:496-501)
+    x0 = np.concatenate([t, free.ravel()])
+    lo, hi = po.free_derivative_bounds(4, m, v, lim)
+    lb = np.concatenate([np.full(len(t), 0.01), np.minimum(lo.ravel(), free.ravel())])
+    ub = np.concatenate([np.full(len(t), np.inf), np.maximum(hi.ravel(), free.ravel())])
+    fun = lambda z: po.objective_time_and_constraints(4, m, v, z, lim, mode=mode)[0]  # noqa: E731
+    # the first trial is T_0 + 10 % with the free constraints HELD (setFreeConstraints, not a re-solve)
     t1 = t.copy()
     t1[0] *= 1.1
-    assert np.allclose(x, t1, rtol=1e-15)
-    assert util.coeff_error(c, po.coeffs_from_free(4, m, v, t1, free)) < 1e-13
-    assert util.coeff_error(c, po.solve_linear(4, m, v, t1)) > 1e-6
-    # evaluation S + 2 perturbs the first free constraint of dimension 0
-    rc, x, c, ne, fl = po.optimize_time_and_constraints_dfo(4, m, v, t, lim, mode=mode, max_iterations=len(t) + 2)
-    f2 = free.copy()
-    f2[0, 0] = min(f2[0, 0] + 0.1 * abs(f2[0, 0]), max(lim[0], f2[0, 0])) if f2[0, 0] + 0.1 * abs(f2[0, 0]) <= max(lim[0], f2[0, 0]) \
-        else f2[0, 0] - 0.1 * abs(f2[0, 0])
-    assert np.array_equal(x, t) and util.coeff_error(c, po.coeffs_from_free(4, m, v, t, f2)) < 1e-12
-    assert fl == pytest.approx(po.objective_time_and_constraints(4, m, v, np.concatenate([t, f2.ravel()]), lim, mode=mode)[0],
-                               rel=1e-12)
+    x1 = np.concatenate([t1, free.ravel()])
+    rc, x, c, ne, fl = po.optimize_time_and_constraints_dfo(4, m, v, t, lim, mode=mode, max_iterations=3)
+    assert rc == 5 and ne == 3
+    if fun(x1) < fun(x0):
+        assert np.allclose(x, t1, rtol=1e-15)
+        assert util.coeff_error(c, po.coeffs_from_free(4, m, v, t1, free)) < 1e-13
+        assert util.coeff_error(c, po.solve_linear(4, m, v, t1)) > 1e-6
+    else:
+        assert np.array_equal(x, t) and util.coeff_error(c, c0) < 1e-13
+    # every budget up to 30 (inside the interpolation sweep: n = 52 variables): evaluation k >= 2 is x0 + h e_(k-2), the last
+    # one goes back to the best of them
+    h = 0.1 * np.abs(x0)
+    h[np.abs(x0) <= np.finfo(float).eps] = 1e-13
+    trials = [x0]
+    for i in range(30):
+        z = x0.copy()
+        z[i] = min(max(x0[i] + h[i] if x0[i] + h[i] <= ub[i] else x0[i] - h[i], lb[i]), ub[i])
+        trials.append(z)
+    values = [fun(z) for z in trials]
+    for budget in range(2, 31):
+        rc, x, c, ne, fl = po.optimize_time_and_constraints_dfo(4, m, v, t, lim, mode=mode, max_iterations=budget)
+        k = int(np.argmin(values[:budget - 1]))     # budget - 1 evaluations of the sweep (x0 included), then the revisit
+        assert rc == 5 and ne == budget and np.array_equal(x, trials[k][:len(t)]) and fl == pytest.approx(values[k], rel=1e-13), budget
+        assert util.coeff_error(c, po.coeffs_from_free(4, m, v, trials[k][:len(t)], trials[k][len(t):].reshape(4, -1))) < 1e-12
 
 
 def test_dfo_time_and_constraints_long_run_improves_and_keeps_continuity():

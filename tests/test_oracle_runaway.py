@@ -11,9 +11,19 @@ from oracle import pyoracle as po
 from tests import util
 
 
-def _solve(batch):
+def _solve(batch, runaway_rule=True):
     return po.solve_batch(batch.seg_offsets, batch.waypoints, batch.fixed_mask, batch.fixed_values, batch.limits,
-                          np.zeros(batch.n_segments), deriv=4, time_alloc_method=2, estimate_times=True, n_threads=8)
+                          np.zeros(batch.n_segments), deriv=4, time_alloc_method=2, estimate_times=True, n_threads=8,
+                          runaway_rule=runaway_rule)
+
+
+def test_the_rule_is_the_products_deviation_not_the_references_behaviour():
+    """without the switch the oracle does what the reference does: the outer loop's own stopping reason, whatever the
+    feasibility scaling made of the times (the nodelet throws the trajectory away by its length check); same numbers"""
+    batch = pr.random_batch(1, 10, seed0=8615)
+    ref_like, product_like = _solve(batch, runaway_rule=False), _solve(batch, runaway_rule=True)
+    assert ref_like["status"][0] in (1, 3, 4, 5) and product_like["status"][0] == -4
+    assert np.array_equal(ref_like["times"], product_like["times"]) and np.array_equal(ref_like["coeffs"], product_like["coeffs"])
 
 
 def test_path_8615_of_the_benchmark_batch_is_flagged():
