@@ -24,6 +24,7 @@ struct NonlinearParams {
   int32_t* careful_list = nullptr;
   int careful_cap = 0;
   int32_t* queue_next = nullptr;  // lean kernel of a uniform batch larger than the device holds at once: next unclaimed position of the bin
+  int lean_shared = 0;  // lean kernels: shared half sweeps (evaluate_lean_shared) 1: in batches where every path has its S + 4 lanes (own kernel), 2: also wave by wave inside the mixed kernel
   double* sum_t0 = nullptr;  // [n_paths] by path: sum of the times the search starts from (the runaway test of the final solve)
 };
 
@@ -46,6 +47,7 @@ struct NonlinearBin {
   int q_begin;    // first position of the bin
   int q_count;    // number of paths in the bin
   int max_S;      // largest segment count in the bin
+  int min_S;      // smallest
 };
 
 struct NonlinearPlan {

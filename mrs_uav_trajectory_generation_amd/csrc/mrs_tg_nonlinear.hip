@@ -365,7 +365,8 @@ __device__ __forceinline__ double evaluate_general(const uint8_t* __restrict__ m
 // keeps the kernel at <= 256 VGPRs, i.e. TWO wavefronts per SIMD where optimize_compact_kernel (436 VGPRs) has one.  The
 // kernels are bound by the dependent chain of a step, not by issue: the second wavefront runs in
 // the first one's idle issue slots.  Lane k of a group of G sweeps time vector k (k, k + G, ... when S + 1 > G).
-__host__ __device__ constexpr int lean_eval_doubles(int Sb) { return 4 * Sb + 4 * (Sb + 1); }  // dp, staging area
+constexpr int kLeanPub = 3 * 28;  // evaluate_lean_shared's hand-over area: three half-sweep states of 28 doubles
+__host__ __device__ constexpr int lean_eval_doubles(int Sb) { return 4 * Sb + 4 * (Sb + 1) + kLeanPub; }  // dp, staging area, hand-over
 
 template <bool MASKED>
 __device__ __forceinline__ double evaluate_lean(const double* tabs, const double* ev, int S, int Sb, int d, const double* pt,
@@ -530,6 +531,192 @@ __device__ __forceinline__ double evaluate_lean(const double* tabs, const double
   return J0;
 }
 
+// ---- lean sweeps with shared halves ------------------------------------------------------------------------------------
+// The S + 1 time vectors of an evaluation share their half sweeps across the middle vertex m = S / 2 (mrs_tg_wave.hip has the
+// argument): m + 2 distinct left halves (x, B', one per left segment) and S - m + 2 right ones.  Here every lane runs ONE half
+// sweep for all four dimensions -- S + 4 lanes of the group instead of S + 1, each for S - m steps and a join instead of S
+// steps: 0.6 of the lane-steps at S = 10.  A lane's direction is data: it reads the table of its direction (stage_ps_tables)
+// into its registers; dp and the f^T H f terms do not depend on the direction.  The three half sweeps that more than one vector
+// needs (right half of x, right half of B', left half of B') go through LDS (28 doubles each), the other S + 1 lanes add
+// their partner's state to their own and factor the middle vertex.  For plain paths with 4 <= S and S + 4 <= G.
+//   lanes of the group: 0: x left | 1 .. m: vector k = lane, left | m + 1: B' left |
+//                       m + 2: x right | m + 2 + r: vector m + r, right (r = 1 .. S - m) | S + 3: B' right
+__device__ __forceinline__ double evaluate_lean_shared(const double* tabs, const double* ev, double* pub, int S, int Sb, int d,
+                                                       const double* pt, double* grad, int g, int G, bool active, int* tripped) {
+  const double* dp = ev;
+  const double* qs = ev + 4 * (size_t)Sb + 2;  // HBAR[0][0] |dp_i|^2 per segment (stage_ps)
+  const int m = S >> 1, nL = m + 2;
+  const bool left = g < nL;
+  const int r = left ? g : g - nL;
+  const int nhalf = left ? m : S - m;
+  const bool valid = active && g < S + 4;
+  const bool pure = r == nhalf + 1, base = r == 0;
+  const int k = base ? 0 : pure ? (left ? S : 1) : (left ? r : m + r);
+  const double corr = kGradStep / ((double)S - 1.0);
+  double tab[kPsTable];
+  {
+    const double* tsrc = tabs + (left ? 0 : kPsTable);
+#pragma unroll
+    for (int e = 0; e < kPsTable; ++e) tab[e] = tsrc[e];
+  }
+  double Sm[10], y[kNB][4], qf = 0.0, red = 0.0;
+#pragma unroll
+  for (int e = 0; e < 10; ++e) Sm[e] = 0.0;
+#pragma unroll
+  for (int rr = 0; rr < kNB; ++rr)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) y[rr][q] = 0.0;
+  int i = left ? 0 : S - 1;
+  const int di = left ? 1 : -1;
+  for (int s = 0; __ballot(valid && s < nhalf) != 0ull; ++s) {
+    if (valid && s < nhalf) {
+      double T = pt[i];
+      if (k > 0) T = (i == k - 1) ? T + kGradStep : fmax(T - corr, kTimeLowerBound);
+      double p2[9];
+      segment_powers(T, d, p2);
+      double dq[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) dq[q] = dp[i * 4 + q];
+      qf = fma(p2[0], qs[i], qf);
+      if (s == 0) {  // the end vertex is fully constrained: the state moves to the next vertex
+#pragma unroll
+        for (int rr = 0; rr < kNB; ++rr) {
+#pragma unroll
+          for (int c = 0; c <= rr; ++c) Sm[tri(rr, c)] = tab[26 + tri(rr, c)] * p2[rr + c + 2];
+          const double cF = tab[40 + rr] * p2[rr + 1];
+#pragma unroll
+          for (int q = 0; q < 4; ++q) y[rr][q] = -(cF * dq[q]);
+        }
+      } else {
+        // the vertex the sweep stands on: its block and right-hand side are complete with this segment's near part
+#pragma unroll
+        for (int rr = 0; rr < kNB; ++rr) {
+#pragma unroll
+          for (int c = 0; c <= rr; ++c) Sm[tri(rr, c)] = fma(tab[tri(rr, c)], p2[rr + c + 2], Sm[tri(rr, c)]);
+          const double cN = tab[36 + rr] * p2[rr + 1];
+#pragma unroll
+          for (int q = 0; q < 4; ++q) y[rr][q] = fma(-cN, dq[q], y[rr][q]);
+        }
+        double L[10], Linv[kNB], z[kNB][4], W[kNB][kNB];
+#pragma unroll
+        for (int c = 0; c < kNB; ++c) {
+          double dsum = Sm[tri(c, c)];
+#pragma unroll
+          for (int mm = 0; mm < c; ++mm) dsum = fma(-L[tri(c, mm)], L[tri(c, mm)], dsum);
+          const double inv = rsqrt_refined(dsum);
+          Linv[c] = inv;
+#pragma unroll
+          for (int rr = c + 1; rr < kNB; ++rr) {
+            double t = Sm[tri(rr, c)];
+#pragma unroll
+            for (int mm = 0; mm < c; ++mm) t = fma(-L[tri(rr, mm)], L[tri(c, mm)], t);
+            L[tri(rr, c)] = t * inv;
+          }
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+          for (int rr = 0; rr < kNB; ++rr) {
+            double t = y[rr][q];
+#pragma unroll
+            for (int mm = 0; mm < rr; ++mm) t = fma(-L[tri(rr, mm)], z[mm][q], t);
+            z[rr][q] = t * Linv[rr];
+            red = fma(z[rr][q], z[rr][q], red);
+          }
+#pragma unroll
+        for (int c = 0; c < kNB; ++c)
+#pragma unroll
+          for (int rr = 0; rr < kNB; ++rr) {
+            double t = tab[10 + rr * kNB + c] * p2[rr + c + 2];
+#pragma unroll
+            for (int mm = 0; mm < rr; ++mm) t = fma(-L[tri(rr, mm)], W[mm][c], t);
+            W[rr][c] = t * Linv[rr];
+          }
+#pragma unroll
+        for (int rr = 0; rr < kNB; ++rr) {
+#pragma unroll
+          for (int c = 0; c <= rr; ++c) {
+            double t = tab[26 + tri(rr, c)] * p2[rr + c + 2];
+#pragma unroll
+            for (int mm = 0; mm < kNB; ++mm) t = fma(-W[mm][rr], W[mm][c], t);
+            Sm[tri(rr, c)] = t;
+          }
+          const double cF = tab[40 + rr] * p2[rr + 1];
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            double t = -(cF * dq[q]);
+#pragma unroll
+            for (int mm = 0; mm < kNB; ++mm) t = fma(-W[mm][rr], z[mm][q], t);
+            y[rr][q] = t;
+          }
+        }
+      }
+    }
+    i += di;
+  }
+  // hand-over: slot 0 right half of x | 1 right half of B' | 2 left half of B'
+  const bool base_right = !left && base;
+  if (valid && (pure || base_right)) {
+    double* ps = pub + (base_right ? 0 : (left ? 2 : 1)) * 28;
+#pragma unroll
+    for (int e = 0; e < 10; ++e) ps[e] = Sm[e];
+#pragma unroll
+    for (int rr = 0; rr < kNB; ++rr)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) ps[10 + rr * 4 + q] = y[rr][q];
+    ps[26] = qf;
+    ps[27] = red;
+  }
+  ps_wave_sync();
+  const bool join = valid && !pure && !base_right;
+  double Jk = 0.0, qfk = 0.0;
+  if (join) {
+    const double* ps = pub + (left ? (base ? 0 : 1) : 2) * 28;
+#pragma unroll
+    for (int e = 0; e < 10; ++e) Sm[e] += ps[e];
+#pragma unroll
+    for (int rr = 0; rr < kNB; ++rr)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) y[rr][q] += ps[10 + rr * 4 + q];
+    qf += ps[26];
+    red += ps[27];
+    double L[10], Linv[kNB], z[kNB][4];
+#pragma unroll
+    for (int c = 0; c < kNB; ++c) {
+      double dsum = Sm[tri(c, c)];
+#pragma unroll
+      for (int mm = 0; mm < c; ++mm) dsum = fma(-L[tri(c, mm)], L[tri(c, mm)], dsum);
+      const double inv = rsqrt_refined(dsum);
+      Linv[c] = inv;
+#pragma unroll
+      for (int rr = c + 1; rr < kNB; ++rr) {
+        double t = Sm[tri(rr, c)];
+#pragma unroll
+        for (int mm = 0; mm < c; ++mm) t = fma(-L[tri(rr, mm)], L[tri(c, mm)], t);
+        L[tri(rr, c)] = t * inv;
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+      for (int rr = 0; rr < kNB; ++rr) {
+        double t = y[rr][q];
+#pragma unroll
+        for (int mm = 0; mm < rr; ++mm) t = fma(-L[tri(rr, mm)], z[mm][q], t);
+        z[rr][q] = t * Linv[rr];
+        red = fma(z[rr][q], z[rr][q], red);
+      }
+    Jk = 0.5 * (qf - red);
+    qfk = qf;
+  }
+  ps_wave_sync();  // (the area is written again by the next evaluation)
+  Jk = guarded_cost(Jk, qfk, k == 0);
+  if (tripped && join && Jk == kUnreliableCost) *tripped = 1;
+  const double J0 = __shfl(Jk, (int)(threadIdx.x & ~(unsigned)(G - 1)), 64);  // lane 0 of the group: x, joined
+  if (join && k >= 1) grad[k - 1] = (Jk - J0) / kGradStep;
+  return J0;
+}
+
 // per-group LDS of the plain-path kernels and their staging
 __host__ __device__ constexpr int lean_group_doubles(int Sb) {
   return (5 + 2 * kLbfgsM) * Sb + (kLbfgsM + 1) + kTickState + lean_eval_doubles(Sb);
@@ -605,7 +792,10 @@ struct BinTable {
 // GENERAL (optimize_general_kernel, with CAREFUL): the listed paths are those with a position-free vertex, every evaluation
 // is evaluate_general, and the start point is read from `start_times` (a copy taken before the fast kernels ran over the
 // batch: they do not know such paths and leave garbage in seg_times for them).
-template <int DS, bool MASKED4 = false, bool CAREFUL = false, bool LEAN = false, bool GENERAL = false>
+// LEANSHARED (optimize_lean_shared_kernel, with LEAN): every bin of the launch holds paths of 4 <= S <= G - 4 segments only (the
+// host checks), so evaluate_lean_shared is the ONLY evaluation compiled in -- next to the one-sided sweeps it costs both their
+// registers (124 instead of 28 bytes of scratch).
+template <int DS, bool MASKED4 = false, bool CAREFUL = false, bool LEAN = false, bool GENERAL = false, bool LEANSHARED = false>
 __device__ __forceinline__ void optimize_body(const BatchView& b, const NonlinearParams& prm, const BinTable& bins,
                                               const uint8_t* __restrict__ mask, const double* __restrict__ vals,
                                               double* __restrict__ seg_times, int32_t* __restrict__ opt_status,
@@ -879,7 +1069,14 @@ __device__ __forceinline__ void optimize_body(const BatchView& b, const Nonlinea
     }
     double fn;
     if (LEAN) {
-      fn = evaluate_lean<MASKED4>(hc, vtx, S, Sb, d, xn, gn, g, G, !done, tick_i + 4);
+      // shared half sweeps when every path of the wavefront takes them (plain paths of 4 <= S <= G - 4 segments: S + 4 lanes)
+      const bool shared_path = S >= 4 && S + 4 <= G;
+      if (LEANSHARED)
+        fn = evaluate_lean_shared(hc, vtx, vtx + 4 * (size_t)Sb + 4 * ((size_t)Sb + 1), S, Sb, d, xn, gn, g, G, !done, tick_i + 4);
+      else if (!MASKED4 && prm.lean_shared == 2 && __ballot(!done && !shared_path) == 0ull)
+        fn = evaluate_lean_shared(hc, vtx, vtx + 4 * (size_t)Sb + 4 * ((size_t)Sb + 1), S, Sb, d, xn, gn, g, G, !done, tick_i + 4);
+      else
+        fn = evaluate_lean<MASKED4>(hc, vtx, S, Sb, d, xn, gn, g, G, !done, tick_i + 4);
     } else if (GENERAL) {
       fn = evaluate_general(mask, vals, pr.v0, S, d, xn, gn, g, !done, careful_ws, (size_t)gridDim.x * 64,
                             blockIdx.x * 64u + (unsigned)lane);
@@ -1288,6 +1485,14 @@ __global__ __launch_bounds__(64, MRS_TG_LEAN_WAVES) void optimize_lean_kernel(Ba
   optimize_body<1, false, false, true>(b, prm, bins, mask, vals, seg_times, opt_status, nullptr, fallback);
 }
 
+// every path of every bin has 4 <= S <= G - 4 segments: shared half sweeps only (see optimize_body)
+__global__ __launch_bounds__(64, MRS_TG_LEAN_WAVES) void optimize_lean_shared_kernel(BatchView b, NonlinearParams prm, BinTable bins,
+                                                              const uint8_t* __restrict__ mask, const double* __restrict__ vals,
+                                                              double* __restrict__ seg_times, int32_t* __restrict__ opt_status,
+                                                              int32_t* __restrict__ fallback) {
+  optimize_body<1, false, false, true, false, true>(b, prm, bins, mask, vals, seg_times, opt_status, nullptr, fallback);
+}
+
 // the end vertices may leave slots free (launches whose objective order is below snap: the masked step at the two ends of
 // the sweep); one wavefront per SIMD -- at two it spills 96 registers and loses to the general kernel
 __global__ __launch_bounds__(64) void optimize_lean_masked_kernel(BatchView b, NonlinearParams prm, BinTable bins,
@@ -1457,6 +1662,7 @@ int nonlinear_plan_build(NonlinearPlan& nl, const std::vector<int32_t>& so, cons
     int e = q;
     while (e < P && group_for(so[order[e] + 1] - so[order[e]], nl.dim_split) == bin.group) ++e;
     bin.q_count = e - q;
+    bin.min_S = so[order[e - 1] + 1] - so[order[e - 1]];  // ... and the last one its shortest
     nl.bins.push_back(bin);
     q = e;
   }
@@ -1589,6 +1795,13 @@ hipError_t launch_nonlinear(NonlinearPlan& nl, const BatchView& b, const Nonline
   const int32_t* general_flag = general ? nl.d_general + 4 : nullptr;
   // 1. outer loop: every bin in one launch
   NonlinearParams prm = prm_in;
+  static const int lean_shared = [] {
+    // tuning / test knob, read once per process; 0: one-sided lean sweeps only, 1: shared half sweeps where a whole batch
+    // takes them (optimize_lean_shared_kernel), 2 (default): also wave by wave inside the mixed kernel (ragged batches)
+    const char* e = std::getenv("MRS_TG_LEAN_SHARED");
+    return e == nullptr ? 2 : std::atoi(e);
+  }();
+  prm.lean_shared = lean_shared;
   prm.sum_t0 = nl.d_sum_t0;
   prm.deadline = nullptr;
   if (prm_in.time_budget_ticks > 0) {
@@ -1666,12 +1879,20 @@ hipError_t launch_nonlinear(NonlinearPlan& nl, const BatchView& b, const Nonline
       prm.queue_next = nl.d_queue;
     }
     const bool lean_masked = prm.derivative < 4;  // rest-to-rest paths end on vertices with free slots
+    // shared half sweeps (evaluate_lean_shared) where every path of every bin has its S + 4 lanes
+    bool lean_shared_only = prm.lean_shared != 0 && !lean_masked;
+    for (const NonlinearBin& bin : nl.bins)
+      if (bin.min_S < 4 || bin.max_S + 4 > bin.group) lean_shared_only = false;
     if (plds > 64 * 1024 &&
-        (e = hipFuncSetAttribute(lean_masked ? (const void*)optimize_lean_masked_kernel : (const void*)optimize_lean_kernel,
+        (e = hipFuncSetAttribute(lean_masked ? (const void*)optimize_lean_masked_kernel
+                                 : lean_shared_only ? (const void*)optimize_lean_shared_kernel : (const void*)optimize_lean_kernel,
                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)plds)) != hipSuccess)
       return e;
     if (lean_masked)
       hipExtLaunchKernelGGL(optimize_lean_masked_kernel, dim3(blocks), dim3(64), plds, stream, kt.start, nullptr, 0, b, prm, bt, mask,
+                            vals, seg_times, nl.d_opt_status, nl.d_fallback);
+    else if (lean_shared_only)
+      hipExtLaunchKernelGGL(optimize_lean_shared_kernel, dim3(blocks), dim3(64), plds, stream, kt.start, nullptr, 0, b, prm, bt, mask,
                             vals, seg_times, nl.d_opt_status, nl.d_fallback);
     else
       hipExtLaunchKernelGGL(optimize_lean_kernel, dim3(blocks), dim3(64), plds, stream, kt.start, nullptr, 0, b, prm, bt, mask, vals,
