@@ -770,7 +770,14 @@ int mrs_tg_bound_solve_launch_group(mrs_tg_bound_solve* const* bound, int32_t n_
     if (plan->view.n_paths == 0) continue;
     HIP_TRY(ctx, use_device(ctx->device));
     ProfileScope ps(ctx, 1);
-    HIP_TRY(ctx, mrs_tg::launch_solve_rows_group(plan->view, first->opt.derivative_to_optimize, g, ctx->stream));
+    if (mrs_tg::quad_kernel_applies(plan->view, (long long)plan->view.n_paths * g.n, false)) {
+      // the dispatch carries more paths than the rows kernel has wavefront slots for: four lanes per path, factors in LDS
+      int rc = ensure_ws(plan, (size_t)mrs_tg::kRowsGroupMax * mrs_tg::linear_workspace_doubles(plan->view));
+      if (rc != MRS_TG_OK) return rc;
+      HIP_TRY(ctx, mrs_tg::launch_solve_quad_group(plan->view, first->opt.derivative_to_optimize, g, plan->d_ws, ctx->stream));
+    } else {
+      HIP_TRY(ctx, mrs_tg::launch_solve_rows_group(plan->view, first->opt.derivative_to_optimize, g, ctx->stream));
+    }
   }
   return MRS_TG_OK;
 }

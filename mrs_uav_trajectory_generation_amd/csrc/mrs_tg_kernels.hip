@@ -269,6 +269,8 @@ hipError_t launch_solve_linear(const BatchView& b, int d, bool fused, const uint
                                double* coeffs, int32_t* status, double* cost, const int32_t* status_in,
                                hipStream_t stream) {
   if (b.n_paths == 0) return hipSuccess;
+  if (fused && ws != nullptr && quad_kernel_applies(b, b.n_paths, false))  // saturated device: four lanes per path, factors in LDS
+    return launch_solve_quad(b, d, mask, vals, seg_times, coeffs, status, cost, status_in, ws, stream);
   if (fused && rows_kernel_applies(b))
     return launch_solve_rows(b, d, mask, vals, seg_times, coeffs, status, cost, status_in, stream);
   if (tile_kernel_applies(b, fused))

@@ -133,4 +133,14 @@ struct RowsGroup {
 };
 hipError_t launch_solve_rows_group(const BatchView& b, int d, const RowsGroup& g, hipStream_t stream);
 
+// four lanes per path, factors in LDS (mrs_tg_quad.hip): the fixed-times solve of launches that carry more paths than the rows
+// kernel has wavefront slots for (paths_in_launch: of all batches a grouped launch carries).  ws: the plan's global factor
+// store (linear_workspace_doubles per batch), used by wavefronts whose paths need the general masked step.  tail: the
+// feasibility scaling of a Mellinger pipeline's last solve (no sampling on this launch).
+bool quad_kernel_applies(const BatchView& b, long long paths_in_launch, bool with_sampling);
+hipError_t launch_solve_quad(const BatchView& b, int d, const uint8_t* mask, const double* vals, const double* seg_times,
+                             double* coeffs, int32_t* status, double* cost, const int32_t* status_in, double* ws,
+                             hipStream_t stream, const RowsTail& tail = RowsTail());
+hipError_t launch_solve_quad_group(const BatchView& b, int d, const RowsGroup& g, double* ws, hipStream_t stream);
+
 }  // namespace mrs_tg

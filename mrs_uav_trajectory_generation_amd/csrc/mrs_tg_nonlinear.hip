@@ -2002,6 +2002,15 @@ hipError_t launch_nonlinear(NonlinearPlan& nl, const BatchView& b, const Nonline
   if ((e = hipGetLastError()) != hipSuccess) return e;
   // 3b + 4 in one launch where the rows kernel applies: its staging pass scales the times of its own path, its tail samples
   const bool want_samples = sampling_dt > 0.0 && n_samples != nullptr && rows_tail_sampling_pays(b);
+  if (!general && quad_kernel_applies(b, b.n_paths, false)) {  // saturated device; the caller's sampler follows
+    RowsTail tail;
+    tail.maxima = nl.d_maxima;
+    tail.limits = limits;
+    tail.opt_status = nl.d_opt_status;
+    tail.sum_t0 = nl.d_sum_t0;
+    tail.seg_times_out = seg_times;
+    return launch_solve_quad(b, prm.derivative, mask, vals, seg_times, coeffs, status, cost, nl.d_opt_status, nl.d_ws, stream, tail);
+  }
   if (!general && rows_kernel_applies(b, want_samples)) {
     RowsTail tail;
     tail.maxima = nl.d_maxima;

@@ -1,0 +1,424 @@
+// mrs_tg_quad.hip -- the linear QP solve for SATURATED devices: four lanes per path, the factors of the block elimination in LDS.
+//
+// What it replaces: PolynomialOptimization::updateSegmentTimes + constructR + solveLinear +
+// updateSegmentsFromCompactConstraints + computeCost for every path of a batch
+// (/root/reference/include/eth_trajectory_generation/impl/polynomial_optimization_linear_impl.h:289-304, 311-373,
+// 264-282, 128-141) -- the same contract as mrs_tg_rows.hip, chosen by the launcher once a launch carries more paths than
+// the device has wavefront slots for the rows kernel.
+//
+// Why a second solve kernel.  solve_rows_kernel spends a whole wavefront on one or two paths (one lane per unknown, rank-one
+// updates by DPP row broadcasts): the shortest dependent chain there is, ~1900 wavefront instructions per path -- 3 % of the
+// lanes carry useful work.  With 65536 paths every SIMD sees 64 of them one after the other, and the solve is bound by that
+// instruction count (202 us).  Here a quad of lanes owns a path (lane = dimension) and runs the block-tridiagonal Cholesky of
+// the vertex chain sequentially: 16 paths per wavefront, ~5000 wavefront instructions for all of them -- ~300 per path.  What
+// made the four-lanes-per-path kernel of round 1 slow was its factor store (L, W, z of every vertex, written for the back
+// substitution) in global memory: 30 doubles per vertex and LANE, 250 MB out and back in at 65536 x 10.  Here the store is in
+// LDS, once per PATH (the four lanes of a quad hold the same L: lane 0 writes it, every lane its own z; W is formed again in
+// the back substitution instead of being kept): 26 doubles per vertex, 31 KB per wavefront at 10 segments, five wavefronts
+// per CU.  Barely more than one wavefront per SIMD -- a step's latencies are exposed, so positions are requested three
+// segments ahead -- and still a multiple of the rows kernel's throughput.
+//
+//   prologue  segment times -> LDS (the feasibility scaling of a Mellinger pipeline's last solve applied on the way);
+//             is every path of the wavefront "plain" (start | interior ... | end: position-only interior vertices, fully
+//             constrained ends at rest)?
+//   plain     forward: per segment near block + factor + W + Schur complement, all from the exact unit-time constants times
+//             powers of T (as FastStep::interior_t); backward: x_v = L^-T (z - W x_{v+1}), c = A^-1 d segment by segment,
+//             cost 0.5 c^T Q c as the reference computes it
+//   other     the general masked step of mrs_tg_solve.hpp::solve_path (factors in the plan's global workspace)
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <cstdlib>
+
+#include "mrs_tg_device.hpp"
+#include "mrs_tg_launch.h"
+#include "mrs_tg_nl_common.hpp"
+#include "mrs_tg_solve.hpp"
+
+namespace mrs_tg {
+
+constexpr int kQdPaths = 16;  // paths per wavefront
+// LDS record of (vertex, path): L off-diagonal [6] | 1 / diag L [4] | z [4 rows][4 dimensions].  W = L^-1 E is NOT kept: the
+// back substitution forms W x_{v+1} as L^-1 (E x_{v+1}) from the segment's time again (~25 instructions more per vertex,
+// 16 doubles less per record: five wavefronts per CU instead of three at 10 segments)
+constexpr int kQdL = 0, kQdLinv = 6, kQdZ = 10, kQdRec = 26;
+
+__host__ __device__ constexpr size_t quad_lds_doubles(int Smax) {
+  return (size_t)(Smax > 1 ? Smax - 1 : 1) * kQdRec * kQdPaths + (size_t)Smax * kQdPaths;  // records | times
+}
+
+// T^(m + 1 - 2d), m = 0..8, the objective order as select masks (no branch tree per segment)
+__device__ __forceinline__ void quad_powers(double T, bool d1, bool d2, bool d4, double (&p2)[9]) {
+  const double t2 = T * T;
+  const double t4 = t2 * t2;
+  const double td = ((d1 ? T : 1.0) * (d2 ? t2 : 1.0)) * (d4 ? t4 : 1.0);
+  p2[0] = T * rcp_refined(td * td);
+  p2[1] = p2[0] * T;
+  p2[2] = p2[0] * t2;
+  p2[3] = p2[1] * t2;
+  p2[4] = p2[0] * t4;
+  p2[5] = p2[1] * t4;
+  p2[6] = p2[2] * t4;
+  p2[7] = p2[3] * t4;
+  p2[8] = p2[4] * t4;
+}
+
+__device__ __forceinline__ void quad_wave_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
+
+__device__ __forceinline__ double quad_sum(double v) {  // over the four lanes of a quad, to all of them
+  v += dpp_move<0xB1>(v);
+  v += dpp_move<0x4E>(v);
+  return v;
+}
+
+__device__ __forceinline__ void solve_quad_body(const BatchView& b, int d, const uint8_t* __restrict__ mask,
+                                                const double* __restrict__ vals, const double* seg_times,
+                                                double* __restrict__ coeffs, int32_t* __restrict__ status,
+                                                double* __restrict__ cost, const int32_t* __restrict__ status_in, double* ws,
+                                                const RowsTail& tail, int block) {
+  extern __shared__ double lds[];
+  const int lane = threadIdx.x, pl = lane >> 2, dim = lane & 3;
+  const int q = block * kQdPaths + pl;
+  const bool active = q < b.n_paths;
+  const PathRef pr = path_at(b, active ? q : b.n_paths - 1);
+  const int S = pr.S;
+  const int Smax = b.max_segments;
+  double* rec0 = lds;
+  double* tbuf = lds + (size_t)(Smax > 1 ? Smax - 1 : 1) * kQdRec * kQdPaths;  // [segment][path]
+
+  // ---- prologue: times (scaled, for the last solve of a Mellinger pipeline), plainness of the path
+  const bool scaling = tail.maxima != nullptr;
+  double t_sum = 0.0;
+  bool ok = S >= 2, pos_ok = true;
+  if (active) {
+    const int opt_st = scaling ? tail.opt_status[pr.p] : 0;
+    for (int i = dim; i < S; i += 4) {
+      double T = seg_times[pr.s0 + i];
+      if (scaling) {  // scaleSegmentTimesToMeetConstraints (trajectory.cpp:625-657), then the solve at the scaled times
+        if (opt_st != -2) T *= violation_scaling(tail.maxima + (size_t)(pr.s0 + i) * 9, tail.limits + (size_t)pr.p * 9);
+        tail.seg_times_out[pr.s0 + i] = T;
+      }
+      tbuf[i * kQdPaths + pl] = T;
+      t_sum += T;
+    }
+    for (int v = dim; v <= S; v += 4) {
+      const uint8_t* mrow = mask + (size_t)(pr.v0 + v) * kHalf;
+      const bool end = v == 0 || v == S;
+      unsigned fixed = 0;
+#pragma unroll
+      for (int k = 0; k < kHalf; ++k) fixed |= (mrow[k] != 0 ? 1u : 0u) << k;
+      pos_ok = pos_ok && (fixed & 1u);
+      if (end) {
+        const double* vrow = vals + (size_t)(pr.v0 + v) * kHalf * kD;
+        double nz = 0.0;
+#pragma unroll
+        for (int e = kD; e < kHalf * kD; ++e) nz += fabs(vrow[e]);
+        ok = ok && fixed == 0x1Fu && nz == 0.0;
+      } else {
+        ok = ok && fixed == 0x1u;
+      }
+    }
+  }
+  t_sum = quad_sum(t_sum);
+  const bool plain_wave = __ballot(active && !ok) == 0ull;
+  const unsigned long long pos_bad = __ballot(active && !pos_ok);
+  const bool path_pos_ok = ((pos_bad >> (lane & ~3)) & 0xFull) == 0ull;
+  quad_wave_sync();
+
+  double my_cost = 0.0;
+  if (plain_wave) {
+    // ---- the exact unit-time constants of this objective order (uniform: scalar loads)
+    const double (*hb)[kN] = c_hbar[d];
+    double cNear[10], cCpl[kNB][kNB], cFar[10], cN[kNB], cF[kNB];
+#pragma unroll
+    for (int r = 0; r < kNB; ++r) {
+#pragma unroll
+      for (int c = 0; c <= r; ++c) {
+        cNear[tri(r, c)] = hb[kSlot0 + r][kSlot0 + c];
+        cFar[tri(r, c)] = hb[kHalf + kSlot0 + r][kHalf + kSlot0 + c];
+      }
+#pragma unroll
+      for (int c = 0; c < kNB; ++c) cCpl[r][c] = hb[kSlot0 + r][kHalf + kSlot0 + c];
+      cN[r] = hb[kSlot0 + r][0];
+      cF[r] = hb[kHalf + kSlot0 + r][0];
+    }
+    const bool d1 = (d & 1) != 0, d2 = (d & 2) != 0, d4 = (d & 4) != 0;
+    const int Sw = __builtin_amdgcn_readfirstlane(S);  // (a wavefront's paths may differ in length: ragged batches)
+    int Smx = Sw;
+    {  // longest path of the wavefront
+      int s = active ? S : 0;
+      for (int off = 32; off >= 4; off >>= 1) s = max(s, __shfl_xor(s, off, 64));
+      Smx = __builtin_amdgcn_readfirstlane(s);
+    }
+    const double* pv = vals + (size_t)pr.v0 * kHalf * kD + dim;  // position of vertex v, this dimension: pv[v * 20]
+    // ---- forward: block Cholesky over the vertex chain
+    double Sm[10], y[kNB];
+    // positions are requested three segments ahead: with less than one wavefront per SIMD nothing else hides a trip to memory,
+    // and a segment step is shorter than one
+    auto pos = [&](int v) { return (active && v <= S) ? pv[(size_t)v * kHalf * kD] : 0.0; };
+    double p_cur = pos(0), p_nxt = pos(1), p_a2 = pos(2), p_a3 = pos(3);
+    for (int i = 0; i < Smx; ++i) {
+      const bool on = active && i < S;
+      const double T = on ? tbuf[i * kQdPaths + pl] : 1.0;
+      const double p_a4 = pos(i + 4);
+      double p2[9];
+      quad_powers(T, d1, d2, d4, p2);
+      const double dp = p_cur - p_nxt;
+      if (on) {
+        if (i == 0) {  // the start vertex is fully constrained: the state moves to vertex 1
+#pragma unroll
+          for (int r = 0; r < kNB; ++r) {
+#pragma unroll
+            for (int c = 0; c <= r; ++c) Sm[tri(r, c)] = cFar[tri(r, c)] * p2[r + c + 2];
+            y[r] = -((cF[r] * p2[r + 1]) * dp);
+          }
+        } else {
+          // vertex i: its block and right-hand side are complete with this segment's near part
+#pragma unroll
+          for (int r = 0; r < kNB; ++r) {
+#pragma unroll
+            for (int c = 0; c <= r; ++c) Sm[tri(r, c)] = fma(cNear[tri(r, c)], p2[r + c + 2], Sm[tri(r, c)]);
+            y[r] = fma(-(cN[r] * p2[r + 1]), dp, y[r]);
+          }
+          double L[10], Linv[kNB], z[kNB];
+#pragma unroll
+          for (int c = 0; c < kNB; ++c) {
+            double dsum = Sm[tri(c, c)];
+#pragma unroll
+            for (int m = 0; m < c; ++m) dsum = fma(-L[tri(c, m)], L[tri(c, m)], dsum);
+            const double inv = rsqrt_refined(dsum);
+            Linv[c] = inv;
+#pragma unroll
+            for (int r = c + 1; r < kNB; ++r) {
+              double t = Sm[tri(r, c)];
+#pragma unroll
+              for (int m = 0; m < c; ++m) t = fma(-L[tri(r, m)], L[tri(c, m)], t);
+              L[tri(r, c)] = t * inv;
+            }
+          }
+#pragma unroll
+          for (int r = 0; r < kNB; ++r) {
+            double t = y[r];
+#pragma unroll
+            for (int m = 0; m < r; ++m) t = fma(-L[tri(r, m)], z[m], t);
+            z[r] = t * Linv[r];
+          }
+          double* rec = rec0 + (size_t)(i - 1) * kQdRec * kQdPaths + pl;
+          if (dim == 0) {
+            rec[(kQdL + 0) * kQdPaths] = L[tri(1, 0)];
+            rec[(kQdL + 1) * kQdPaths] = L[tri(2, 0)];
+            rec[(kQdL + 2) * kQdPaths] = L[tri(2, 1)];
+            rec[(kQdL + 3) * kQdPaths] = L[tri(3, 0)];
+            rec[(kQdL + 4) * kQdPaths] = L[tri(3, 1)];
+            rec[(kQdL + 5) * kQdPaths] = L[tri(3, 2)];
+#pragma unroll
+            for (int r = 0; r < kNB; ++r) rec[(kQdLinv + r) * kQdPaths] = Linv[r];
+          }
+#pragma unroll
+          for (int r = 0; r < kNB; ++r) rec[(kQdZ + r * kD + dim) * kQdPaths] = z[r];
+          if (i < S - 1) {  // W = L^-1 E, then the Schur complement and right-hand side of vertex i + 1
+            double W[kNB][kNB];
+#pragma unroll
+            for (int c = 0; c < kNB; ++c)
+#pragma unroll
+              for (int r = 0; r < kNB; ++r) {
+                double t = cCpl[r][c] * p2[r + c + 2];
+#pragma unroll
+                for (int m = 0; m < r; ++m) t = fma(-L[tri(r, m)], W[m][c], t);
+                W[r][c] = t * Linv[r];
+              }
+#pragma unroll
+            for (int r = 0; r < kNB; ++r) {
+#pragma unroll
+              for (int c = 0; c <= r; ++c) {
+                double t = cFar[tri(r, c)] * p2[r + c + 2];
+#pragma unroll
+                for (int m = 0; m < kNB; ++m) t = fma(-W[m][r], W[m][c], t);
+                Sm[tri(r, c)] = t;
+              }
+              double t = -((cF[r] * p2[r + 1]) * dp);
+#pragma unroll
+              for (int m = 0; m < kNB; ++m) t = fma(-W[m][r], z[m], t);
+              y[r] = t;
+            }
+          }
+        }
+      }
+      p_cur = p_nxt;
+      p_nxt = p_a2;
+      p_a2 = p_a3;
+      p_a3 = p_a4;
+    }
+    quad_wave_sync();  // (lane 0 of a quad wrote L and W for the other three)
+    // ---- backward: x_v = L^-T (z - W x_{v+1}); coefficients and cost of segment v from x_v, x_{v+1}
+    double xn[kNB] = {0.0, 0.0, 0.0, 0.0};  // the last vertex is fully constrained
+    // (positions again, requested three vertices ahead of their use; a path shorter than the wavefront's longest joins late)
+    auto posb = [&](int v) { return (active && v >= 0 && v <= S) ? pv[(size_t)v * kHalf * kD] : 0.0; };
+    double p_end = posb(S), p_b0 = posb(Smx - 1), p_b1 = posb(Smx - 2), p_b2 = posb(Smx - 3);
+    for (int v = Smx - 1; v >= 0; --v) {
+      const bool on = active && v < S;
+      double x[kNB] = {0.0, 0.0, 0.0, 0.0};
+      const double p_start = p_b0;
+      p_b0 = p_b1;
+      p_b1 = p_b2;
+      p_b2 = posb(v - 3);
+      if (on && v >= 1) {
+        const double* rec = rec0 + (size_t)(v - 1) * kQdRec * kQdPaths + pl;
+        double t[kNB];
+#pragma unroll
+        for (int r = 0; r < kNB; ++r) t[r] = rec[(kQdZ + r * kD + dim) * kQdPaths];
+        const double l10 = rec[(kQdL + 0) * kQdPaths], l20 = rec[(kQdL + 1) * kQdPaths], l21 = rec[(kQdL + 2) * kQdPaths],
+                     l30 = rec[(kQdL + 3) * kQdPaths], l31 = rec[(kQdL + 4) * kQdPaths], l32 = rec[(kQdL + 5) * kQdPaths];
+        const double i0 = rec[(kQdLinv + 0) * kQdPaths], i1 = rec[(kQdLinv + 1) * kQdPaths], i2 = rec[(kQdLinv + 2) * kQdPaths],
+                     i3 = rec[(kQdLinv + 3) * kQdPaths];
+        if (v < S - 1) {  // t = z - W x_{v+1},  W x = L^-1 (E x),  E[r][c] = HBAR[1+r][6+c] T_v^(r+c+2-2d)
+          double pw[9];
+          quad_powers(tbuf[v * kQdPaths + pl], d1, d2, d4, pw);
+          double u[kNB];
+#pragma unroll
+          for (int r = 0; r < kNB; ++r) {
+            u[r] = 0.0;
+#pragma unroll
+            for (int c = 0; c < kNB; ++c) u[r] = fma(cCpl[r][c] * pw[r + c + 2], xn[c], u[r]);
+          }
+          const double w0 = u[0] * i0;
+          const double w1 = fma(-l10, w0, u[1]) * i1;
+          const double w2 = fma(-l21, w1, fma(-l20, w0, u[2])) * i2;
+          const double w3 = fma(-l32, w2, fma(-l31, w1, fma(-l30, w0, u[3]))) * i3;
+          t[0] -= w0;
+          t[1] -= w1;
+          t[2] -= w2;
+          t[3] -= w3;
+        }
+        x[3] = t[3] * i3;
+        x[2] = fma(-l32, x[3], t[2]) * i2;
+        x[1] = fma(-l31, x[3], fma(-l21, x[2], t[1])) * i1;
+        x[0] = fma(-l30, x[3], fma(-l20, x[2], fma(-l10, x[1], t[0]))) * i0;
+      }
+      if (on) {
+        const double T = tbuf[v * kQdPaths + pl];
+        // c_k = T^-k sum_j ABAR_INV[k][j] T^(j%5) d_j ; cb_k = c_k T^k is what the cost needs
+        const double dv[kN] = {p_start, x[0], x[1], x[2], x[3], p_end, xn[0], xn[1], xn[2], xn[3]};
+        double w[kHalf];
+        w[0] = 1.0;
+#pragma unroll
+        for (int k = 1; k < kHalf; ++k) w[k] = w[k - 1] * T;
+        double db[kN], cb[kN], c[kN];
+#pragma unroll
+        for (int j = 0; j < kN; ++j) db[j] = dv[j] * w[j % kHalf];
+        const double ti = 1.0 / T;
+        double tik = 1.0;
+#pragma unroll
+        for (int k = 0; k < kN; ++k) {
+          double s = 0.0;
+          if (k < kHalf) {
+            s = c_abar_inv[k][k] * db[k];  // the upper half of ABAR_INV is diag(1/k!)
+          } else {
+#pragma unroll
+            for (int j = 0; j < kN; ++j) s += c_abar_inv[k][j] * db[j];
+          }
+          cb[k] = s;
+          c[k] = s * tik;
+          tik *= ti;
+        }
+        double2* out = reinterpret_cast<double2*>(coeffs + ((size_t)(pr.s0 + v) * kD + dim) * kN);
+#pragma unroll
+        for (int k = 0; k < kN; k += 2) out[k / 2] = make_double2(c[k], c[k + 1]);
+        double p2[9];
+        quad_powers(T, d1, d2, d4, p2);  // p2[0] = T^(1 - 2d)
+        my_cost = fma(cost_quadratic_form_d(d, cb), p2[0], my_cost);
+      }
+#pragma unroll
+      for (int r = 0; r < kNB; ++r) xn[r] = x[r];
+      if (on) p_end = p_start;
+    }
+  } else if (active) {
+    // ---- any other constraint pattern: the general masked step, factors in the plan's global workspace
+    bool pok = true;
+    BlockSource none{nullptr, nullptr, 0, 0};
+    // (the times of this path, contiguous: the scaled ones were written to seg_times_out above, by this quad)
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+    const double* times = (scaling ? tail.seg_times_out : seg_times) + pr.s0;
+    my_cost = solve_path<1, true>(mask, vals, pr.v0, S, d, times, dim, none, ws, (size_t)b.n_paths * 4,
+                                  (unsigned)q * 4u + (unsigned)dim, coeffs + (size_t)pr.s0 * kD * kN, pok);
+  }
+  my_cost = quad_sum(my_cost);
+  if (active && dim == 0) {
+    if (cost) cost[pr.p] = my_cost;
+    if (status) {
+      int st = merge_status(path_pos_ok, status_in, pr.p);
+      if (tail.sum_t0 != nullptr && st > 0 && t_sum > MRS_TG_RUNAWAY_TIME_FACTOR * tail.sum_t0[pr.p]) st = MRS_TG_STATUS_ROUNDOFF_LIMITED;
+      status[pr.p] = st;
+    }
+  }
+}
+
+__global__ __launch_bounds__(64) void solve_quad_kernel(BatchView b, int d, const uint8_t* __restrict__ mask,
+                                                        const double* __restrict__ vals, const double* seg_times,
+                                                        double* __restrict__ coeffs, int32_t* __restrict__ status,
+                                                        double* __restrict__ cost, const int32_t* __restrict__ status_in,
+                                                        double* ws, RowsTail tail) {
+  solve_quad_body(b, d, mask, vals, seg_times, coeffs, status, cost, status_in, ws, tail, (int)blockIdx.x);
+}
+
+// several batches of ONE plan in one launch (as solve_rows_group_kernel): workgroups [j * blocks_per_batch, ...) solve batch j
+// (ws: one factor store of ws_batch_doubles per batch, for wavefronts that take the general step)
+__global__ __launch_bounds__(64) void solve_quad_group_kernel(BatchView b, int d, RowsGroup g, double* ws, size_t ws_batch_doubles,
+                                                              int blocks_per_batch) {
+  const int j = __builtin_amdgcn_readfirstlane((int)blockIdx.x / blocks_per_batch);
+  solve_quad_body(b, d, g.mask[j], g.vals[j], g.seg_times[j], g.coeffs[j], g.status[j], g.cost[j], nullptr,
+                  ws + (size_t)j * ws_batch_doubles, RowsTail(), (int)blockIdx.x - j * blocks_per_batch);
+}
+
+// ---------------------------------------------------------------------------------------------
+// launcher
+
+static constexpr size_t kQuadLdsBudget = 80 * 1024;  // at least two wavefronts per CU
+
+// MRS_TG_QUAD_MIN_PATHS: paths per launch from which the quad kernel takes over (tuning / test knob, read once per process)
+static long long quad_min_paths() {
+  static const long long v = [] {
+    const char* e = std::getenv("MRS_TG_QUAD_MIN_PATHS");
+    return e ? std::atoll(e) : 6144ll;
+  }();
+  return v;
+}
+
+bool quad_kernel_applies(const BatchView& b, long long paths_in_launch, bool with_sampling) {
+  if (b.n_paths == 0 || with_sampling) return false;
+  if (paths_in_launch < quad_min_paths()) return false;
+  return quad_lds_doubles(b.max_segments) * sizeof(double) <= kQuadLdsBudget;
+}
+
+hipError_t launch_solve_quad(const BatchView& b, int d, const uint8_t* mask, const double* vals, const double* seg_times,
+                             double* coeffs, int32_t* status, double* cost, const int32_t* status_in, double* ws,
+                             hipStream_t stream, const RowsTail& tail) {
+  const size_t lds_bytes = quad_lds_doubles(b.max_segments) * sizeof(double);
+  if (lds_bytes > 64 * 1024) {
+    hipError_t e = hipFuncSetAttribute((const void*)solve_quad_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kQuadLdsBudget);
+    if (e != hipSuccess) return e;
+  }
+  const unsigned grid = (unsigned)((b.n_paths + kQdPaths - 1) / kQdPaths);
+  MRS_TG_LAUNCH_TIMED(solve_quad_kernel, dim3(grid), dim3(64), lds_bytes, stream, b, d, mask, vals, seg_times, coeffs, status, cost,
+                      status_in, ws, tail);
+  return hipGetLastError();
+}
+
+hipError_t launch_solve_quad_group(const BatchView& b, int d, const RowsGroup& g, double* ws, hipStream_t stream) {
+  if (g.n < 1 || g.n > kRowsGroupMax) return hipErrorInvalidValue;
+  const size_t lds_bytes = quad_lds_doubles(b.max_segments) * sizeof(double);
+  if (lds_bytes > 64 * 1024) {
+    hipError_t e = hipFuncSetAttribute((const void*)solve_quad_group_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kQuadLdsBudget);
+    if (e != hipSuccess) return e;
+  }
+  const int per_batch = (b.n_paths + kQdPaths - 1) / kQdPaths;
+  MRS_TG_LAUNCH_TIMED(solve_quad_group_kernel, dim3((unsigned)(per_batch * g.n)), dim3(64), lds_bytes, stream, b, d, g, ws,
+                      linear_workspace_doubles(b), per_batch);
+  return hipGetLastError();
+}
+
+}  // namespace mrs_tg

@@ -21,6 +21,7 @@ def child(which):
     ctx = api.Context(0)
     ctx.use_torch_stream()
     r = measure(ctx, batch, True, 10)
+    rl = measure(ctx, batch, False, 20)
     # the outer-loop kernel(s) alone
     plan = api.Plan(ctx, batch.seg_offsets)
     db = api.DeviceBatch(batch, "cuda:0", sample_capacity=512)
@@ -36,8 +37,8 @@ def child(which):
                    n_samples=db.n_samples, samples=db.samples)
     vals = ctx.kernel_ms_history(api.KERNEL_NONLINEAR, 8)
     ctx.set_profiling(False)
-    print("%s: pipeline %.1f us per step, outer-loop kernel %.1f us (median of %d), checksum times %.9f status %s"
-          % (which, r["ms_per_step"] * 1e3, float(np.median(vals)) * 1e3, len(vals), float(db.seg_times.sum().item()),
+    print("%s: linear %.1f us per step; Mellinger pipeline %.1f us per step, outer-loop kernel %.1f us (median of %d), checksum times %.9f status %s"
+          % (which, rl["ms_per_step"] * 1e3, r["ms_per_step"] * 1e3, float(np.median(vals)) * 1e3, len(vals), float(db.seg_times.sum().item()),
              r["status_histogram"]), flush=True)
 
 

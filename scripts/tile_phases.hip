@@ -7,6 +7,7 @@
 #include "../mrs_uav_trajectory_generation_amd/csrc/mrs_tg_kernels.hip"
 #include "../mrs_uav_trajectory_generation_amd/csrc/mrs_tg_tile.hip"
 #include "../mrs_uav_trajectory_generation_amd/csrc/mrs_tg_rows.hip"
+#include "../mrs_uav_trajectory_generation_amd/csrc/mrs_tg_quad.hip"
 #include "../mrs_uav_trajectory_generation_amd/csrc/mrs_tg_general.hip"
 #include "../mrs_uav_trajectory_generation_amd/csrc/mrs_tg_nonlinear.hip"
 #include "../mrs_uav_trajectory_generation_amd/csrc/mrs_tg_wave.hip"
