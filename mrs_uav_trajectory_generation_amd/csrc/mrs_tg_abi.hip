@@ -505,6 +505,9 @@ int mrs_tg_plan_solve(mrs_tg_plan* plan, const double* wp, const uint8_t* mask, 
     prm.x_rel = opt->x_rel;
     prm.x_abs = opt->x_abs;
     prm.time_budget_ticks = opt->max_time_s > 0 ? budget_ticks(ctx, opt->max_time_s) : 0;
+    if ((opt->flags & MRS_TG_FLAG_CAREFUL_COST) && !mrs_tg::careful_rerun_built())
+      return fail(ctx, MRS_TG_ERR_UNSUPPORTED,
+                  "MRS_TG_FLAG_CAREFUL_COST: this library was built without the careful re-run (rebuild with -DMRS_TG_WITH_CAREFUL=1)");
     prm.careful_cap = (opt->flags & MRS_TG_FLAG_CAREFUL_COST) ? 1 : 0;
     ProfileScope ps(ctx, 2);
     HIP_TRY(ctx, mrs_tg::launch_nonlinear(plan->nl, b, prm, mask, vals, limits, seg_times, coeffs, status, cost, ctx->stream,
@@ -569,6 +572,18 @@ int mrs_tg_plan_bind_solve(mrs_tg_plan* plan, const double* wp, const uint8_t* m
   mrs_tg_bound_solve* b = new (std::nothrow) mrs_tg_bound_solve{plan, wp, mask, vals, limits, *opt, seg_times, coeffs, status, cost,
                                                                 n_samples, samples};
   if (!b) return fail(plan->ctx, MRS_TG_ERR_NOMEM, "out of host memory");
+  // A fixed-times default solve can go out in grouped launches (mrs_tg_bound_solve_launch_group), whose saturated-device kernel
+  // wants one factor store per batch of the group for paths that need the general step: allocated HERE, once per plan, so that
+  // the first large group does not pay an allocation and a stream synchronisation inside somebody's timed region
+  if (opt->time_alloc_method == MRS_TG_TIME_ALLOC_NONE && !opt->estimate_times && opt->sampling_dt <= 0 &&
+      !(opt->flags & (MRS_TG_FLAG_MATERIALIZED_BLOCKS | MRS_TG_FLAG_GENERAL_PATTERNS)) &&
+      mrs_tg::quad_kernel_applies(plan->view, (long long)plan->view.n_paths * mrs_tg::kRowsGroupMax, false)) {
+    const int rcw = ensure_ws(plan, (size_t)mrs_tg::kRowsGroupMax * mrs_tg::linear_workspace_doubles(plan->view));
+    if (rcw != MRS_TG_OK) {
+      delete b;
+      return rcw;
+    }
+  }
   *bound_out = b;
   return MRS_TG_OK;
 }

@@ -84,6 +84,9 @@ hipError_t nonlinear_ensure_buffers(NonlinearPlan& nl, const BatchView& b);
 hipError_t nonlinear_prepare_general(NonlinearPlan& nl, const BatchView& b, const uint8_t* mask, const double* seg_times,
                                      bool outer_loop, int* cap, hipStream_t stream);
 
+// whether optimize_careful_kernel (MRS_TG_FLAG_CAREFUL_COST) is in this build (-DMRS_TG_WITH_CAREFUL=1)
+bool careful_rerun_built();
+
 int nonlinear_plan_build(NonlinearPlan& nl, const std::vector<int32_t>& seg_offsets, const std::vector<int32_t>& order);
 void nonlinear_plan_free(NonlinearPlan& nl);
 

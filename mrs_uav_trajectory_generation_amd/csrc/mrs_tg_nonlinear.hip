@@ -60,6 +60,13 @@ namespace mrs_tg {
 #ifndef MRS_TG_LEAN_WAVES
 #define MRS_TG_LEAN_WAVES 2
 #endif
+// The careful re-run (MRS_TG_FLAG_CAREFUL_COST: a second outer-loop kernel with the primal cost for the paths whose by-product
+// cost failed the guard) moved 65536 x 10 from 99.9435 % to 99.9481 % agreement with the oracle at 2-3x the outer loop's time
+// (DESIGN.md section 5): it is not in the shipped library.  -DMRS_TG_WITH_CAREFUL=1 builds it in
+// (python -m mrs_uav_trajectory_generation_amd.build --variant careful -DMRS_TG_WITH_CAREFUL=1).
+#ifndef MRS_TG_WITH_CAREFUL
+#define MRS_TG_WITH_CAREFUL 0
+#endif
 
 // ---- two-sided evaluation for small batches ------------------------------------------------------------------
 // With one path per wavefront (DS = 4, 4 (S+1) <= 64 lanes) the machine holds one wavefront per SIMD and a tick is
@@ -1504,6 +1511,7 @@ __global__ __launch_bounds__(64) void optimize_lean_masked_kernel(BatchView b, N
   optimize_body<1, true, false, true>(b, prm, bins, mask, vals, seg_times, opt_status, nullptr, fallback);
 }
 
+#if MRS_TG_WITH_CAREFUL
 // The outer loop again, from the untouched start times, for the paths the fast kernels listed (a trial point whose
 // by-product cost failed the guard): one path per workgroup, every evaluation through primal_cost_lane.
 __global__ __launch_bounds__(64) void optimize_careful_kernel(BatchView b, NonlinearParams prm, const uint8_t* __restrict__ mask,
@@ -1512,6 +1520,8 @@ __global__ __launch_bounds__(64) void optimize_careful_kernel(BatchView b, Nonli
   BinTable none{};
   optimize_body<4, false, true>(b, prm, none, mask, vals, seg_times, opt_status, ws);
 }
+
+#endif
 
 // ---- paths with a position-free vertex (MRS_TG_FLAG_GENERAL_PATTERNS) ------------------------------------------------
 // general[0] = number of such paths, general[4 + p] = 1 where path p is one, general[4 + n_paths + k] = position q of the
@@ -1714,6 +1724,8 @@ void nonlinear_plan_free(NonlinearPlan& nl) {
 
 
 constexpr int kCarefulCap = 1024;  // paths per call that can be re-run with primal costs; further ones keep the fast result
+
+bool careful_rerun_built() { return MRS_TG_WITH_CAREFUL != 0; }
 
 hipError_t nonlinear_ensure_buffers(NonlinearPlan& nl, const BatchView& b) {
   hipError_t e;
@@ -1951,6 +1963,7 @@ hipError_t launch_nonlinear(NonlinearPlan& nl, const BatchView& b, const Nonline
                             bt, mask, vals, seg_times, nl.d_opt_status);
     }
     if ((e = hipGetLastError()) != hipSuccess) return e;
+#if MRS_TG_WITH_CAREFUL
     if (careful) {
       const size_t clds = ((size_t)group_lds_doubles(b.max_segments, true) + kBlockConsts) * sizeof(double);
       if (clds > 160 * 1024) return hipErrorInvalidValue;
@@ -1963,6 +1976,9 @@ hipError_t launch_nonlinear(NonlinearPlan& nl, const BatchView& b, const Nonline
       hipLaunchKernelGGL(careful_close_kernel, dim3(1), dim3(1), 0, stream, nl.d_careful);
       if ((e = hipGetLastError()) != hipSuccess) return e;
     }
+#else
+    if (careful) return hipErrorNotSupported;  // (mrs_tg_plan_solve refuses the flag before it gets here)
+#endif
     // the paths none of the kernels above knows (what they wrote for them is overwritten here): the same search with the
     // 5 x 5-block evaluation, from the start times kept aside, `general_cap` listed paths per launch
     if (general) {
