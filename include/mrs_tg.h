@@ -115,7 +115,10 @@ enum {
                                          0.5 c^T Q c from the coefficients (computeCost, linear_impl.h:128-141), in every
                                          evaluation.  One more kernel per call, about the duration of the outer loop
                                          itself; without the flag such a trial point is rejected where the reference may
-                                         accept it */
+                                         accept it.  A COMPILE-TIME OPTION since round 4
+                                         (-DMRS_TG_WITH_CAREFUL=1; it moved 65536 x 10 from 99.9435 % to 99.9481 % agreement
+                                         with the oracle): a library built without it refuses the flag with
+                                         MRS_TG_ERR_UNSUPPORTED */
 };
 
 typedef struct mrs_tg_options {
