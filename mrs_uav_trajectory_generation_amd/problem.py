@@ -189,14 +189,14 @@ def random_batch(n_paths, n_seg=10, *, seed0=0, derivative_to_optimize=SNAP, gen
     return assemble_batch(parts, lim, derivative_to_optimize)
 
 
-def random_mixed_batch(n_paths, derivative_to_optimize=SNAP, seed0=0):
-    """Every constraint pattern the adapter produces, mixed in one batch: 1..30 segments, both waypoint generators,
+def random_mixed_batch(n_paths, derivative_to_optimize=SNAP, seed0=0, max_segments=30):
+    """Every constraint pattern the adapter produces, mixed in one batch: 1..max_segments segments, both waypoint generators,
     stop_at interior vertices (src/mrs_trajectory_generation.cpp:959-966), non-zero initial states (:946-957), limits
     scaled by 0.3..3 per path."""
     parts, lims = [], []
     for p in range(seed0, seed0 + n_paths):
         rng = SplitMix64(0xABCDEF + p)
-        S = 1 + rng.next_u64() % 30
+        S = 1 + rng.next_u64() % max_segments
         wp = (random_box_waypoints if rng.next_u64() % 2 else random_walk_waypoints)(S, p)
         stop = [rng.next_u64() % 4 == 0 for _ in range(S + 1)]
         init = None

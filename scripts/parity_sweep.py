@@ -25,7 +25,8 @@ arith = int(os.environ.get("ORACLE_ARITH", "0"))
 po.lib().mto_set_arithmetic(arith)
 
 seed0 = int(os.environ.get("SEED0", "0"))  # other seeds: other paths
-batch = pr.random_mixed_batch(P, deriv, seed0=seed0) if gen == "mixed" else pr.random_batch(P, n_seg, seed0=seed0, derivative_to_optimize=deriv, generator=gen)
+max_seg = int(os.environ.get("MAX_SEGMENTS", "30"))  # mixed batches: 12 = what optimize_wave_kernel takes (with P <= 2560)
+batch = pr.random_mixed_batch(P, deriv, seed0=seed0, max_segments=max_seg) if gen == "mixed" else pr.random_batch(P, n_seg, seed0=seed0, derivative_to_optimize=deriv, generator=gen)
 cap = 256
 flags = api.FLAG_CAREFUL_COST if os.environ.get("CAREFUL") == "1" else 0  # CAREFUL=1: with the careful re-run of guarded paths
 out = ctx.solve_batch(batch, None, time_alloc_method=mode, sampling_dt=0.2, sample_capacity=cap, flags=flags)
@@ -46,7 +47,7 @@ dt = np.array([np.max(np.abs(out["times"][a:b] - ref["times"][a:b]) / ref["times
 dc = np.array([np.max(np.abs(out["coeffs"][a:b] - ref["coeffs"][a:b])) / np.max(np.abs(ref["coeffs"][a:b]))
                for a, b in zip(so[:-1], so[1:])])
 ns_same = out["n_samples"] == np.minimum(ref["n_samples"], cap + 1)
-print("paths %d  segments %s  d=%d  generator %s  mode %d%s%s" % (P, n_seg, deriv, gen, mode, "  careful re-run" if flags else "",
+print("paths %d  segments %s  d=%d  generator %s  mode %d%s%s" % (P, ("1..%d" % max_seg) if gen == "mixed" else n_seg, deriv, gen, mode, "  careful re-run" if flags else "",
                                                                  ("", "  ORACLE: exact unit-time constants", "  ORACLE: linear solve in 113-bit arithmetic")[arith]))
 print("status equal: %.4f %%   statuses gpu %s" % (100 * same_status.mean(), dict(zip(*np.unique(out["status"], return_counts=True)))))
 for tol in (1e-9, 1e-6, 1e-3):

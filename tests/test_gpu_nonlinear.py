@@ -368,6 +368,28 @@ def test_mixed_constraint_patterns_vs_oracle(gpu_ctx, deriv):
     assert (dt < 1e-3).mean() >= 0.998, (dt < 1e-3).mean()
 
 
+@pytest.mark.parametrize("deriv", [2, 3, 4])
+def test_mixed_constraint_patterns_through_the_one_wavefront_kernel(gpu_ctx, deriv):
+    """The same mix of patterns with at most 12 segments per path: a batch optimize_wave_kernel takes (round 4) -- its plain,
+    moving-start and masked evaluations with both directions in one wavefront, and the one-sided sweeps behind the call for
+    everything else (paths of 1-3 segments, a moving start into a stop, ...), all in one launch."""
+    batch = pr.random_mixed_batch(768, deriv, seed0=52000, max_segments=12)
+    assert np.diff(batch.seg_offsets).max() <= 12
+    cap = 512
+    out = gpu_ctx.solve_batch(batch, None, time_alloc_method=api.TIME_ALLOC_MELLINGER, sampling_dt=0.2, sample_capacity=cap)
+    ref = po.solve_batch(batch.seg_offsets, batch.waypoints, batch.fixed_mask, batch.fixed_values, batch.limits,
+                         np.zeros(batch.n_segments), deriv=deriv, time_alloc_method=2, estimate_times=True,
+                         sampling_dt=0.2, sample_capacity=cap, n_threads=8)
+    assert np.all(np.isfinite(out["coeffs"])) and np.all(np.isfinite(out["times"]))
+    so = batch.seg_offsets
+    dt = np.array([np.max(np.abs(out["times"][a:b] - ref["times"][a:b]) / ref["times"][a:b]) for a, b in zip(so[:-1], so[1:])])
+    same = (out["status"] == ref["status"]) & (out["n_samples"] == np.minimum(ref["n_samples"], cap + 1))
+    print("RATE mixed <= 12 segments deriv %d: 1e-6 %.4f 1e-3 %.4f" % (deriv, (dt < 1e-6).mean(), (dt < 1e-3).mean()))
+    assert same.all(), same.mean()
+    assert (dt < 1e-6).mean() >= 0.988, (dt < 1e-6).mean()
+    assert (dt < 1e-3).mean() >= 0.998, (dt < 1e-3).mean()
+
+
 @pytest.mark.parametrize("dt,cap", [(0.01, 16384), (0.05, 4096), (0.5, 256), (1.0, 128), (0.3, 512)])
 def test_sampling_other_sampling_periods(gpu_ctx, dt, cap):
     """the walk is defined by repeated addition of dt: every period has its own rounding pattern at the segment
