@@ -843,6 +843,25 @@ def main():
                                      ms_per_step=el4 / k3 * 1e3, paths_per_rank=n3, n_gpus=world,
                                      gather_bytes_per_rank=int(pk3.numel() * 8), gather_root_equals_local=c3_check,
                                      runaway_paths=int(bad3[0].item()), paths_not_successful=int(bad3[1].item()))
+        # the fixed-times solve of the same shard, per dispatch: the solve kernel of a SATURATED device beside roofline_solve's
+        # single small batch (four lanes per path with the factors in LDS once a launch carries >= 6144 paths, mrs_tg_quad.hip)
+        if rank == 0:
+            for _ in range(2):
+                plan3.solve(opt_lin[0], db3.fixed_mask, db3.fixed_values, t3, c3, st3, db3.cost)
+            torch.cuda.synchronize()
+            m_sat, med_sat, _ = dispatch_stats(ctx, api.KERNEL_SOLVE_LINEAR,
+                                               lambda: plan3.solve(opt_lin[0], db3.fixed_mask, db3.fixed_values, t3, c3, st3, db3.cost), 10, torch)
+            flop_sat = SOLVE_FLOP_PER_SEGMENT * n3 * args.segments
+            extras["roofline_solve_saturated"] = dict(
+                kernel="solve_quad_kernel" if n3 >= 6144 else "solve_rows_kernel", paths=n3, bound="fp64 vector", unit="TFLOP/s",
+                peak=FP64_VECTOR_PEAK_TFLOPS, flop_per_launch=flop_sat, avg_launch_us=m_sat * 1e3, median_launch_us=med_sat * 1e3,
+                achieved=flop_sat / (m_sat * 1e-3) / 1e12, frac=flop_sat / (m_sat * 1e-3) / 1e12 / FP64_VECTOR_PEAK_TFLOPS,
+                trajectories_per_s=n3 / (m_sat * 1e-3),
+                compulsory_bytes_per_launch=int(n3 * (40 * args.segments + 288 + 328 * args.segments)),
+                hbm_frac_of_compulsory_bytes=n3 * (40 * args.segments + 288 + 328 * args.segments) / (m_sat * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                note="flop model of SURVEY.md 8d (6e3 flop per segment: it counts the reference's two dense 10^3 products per segment, "
+                     "which no kernel here executes), per dispatch with events on the launch; compulsory bytes = SURVEY 8d's "
+                     "(40 S + 288) in + 328 S out per path")
         plan3.close()
         del db3, pk3, pad3, recv3
 
