@@ -340,7 +340,9 @@ def main():
     opt_lin = [api.default_options(derivative_to_optimize=4, flags=f) for f in (0, api.FLAG_SHARED_DEVICE)]
     opt_blocks = [api.default_options(derivative_to_optimize=4, flags=api.FLAG_MATERIALIZED_BLOCKS | f)
                   for f in (0, api.FLAG_SHARED_DEVICE)]
-    opt_nl = [api.default_options(derivative_to_optimize=4, time_alloc_method=api.TIME_ALLOC_MELLINGER,
+    # the nonlinear step is findTrajectory's: segment-time estimate from the waypoints, outer loop from there, scaling,
+    # sampling (estimate_times=1: every step starts from the same point without a reset of the times in front of it)
+    opt_nl = [api.default_options(derivative_to_optimize=4, time_alloc_method=api.TIME_ALLOC_MELLINGER, estimate_times=1,
                                   sampling_dt=0.2, sample_capacity=512, flags=f) for f in (0, api.FLAG_SHARED_DEVICE)]
 
     def gather(tensor, bufs):
@@ -413,8 +415,8 @@ def main():
                                                         s_times, out_coeffs[slot], status_i32[slot], slot_cost[slot])
             else:
                 bound[key] = lane_plan[lane].bind_solve(opt_nl[sh], db.fixed_mask, db.fixed_values, out_times[slot], out_coeffs[slot],
-                                                        status_i32[slot], slot_cost[slot], limits=db.limits,
-                                                        n_samples=slot_nsamp[slot], samples=slot_samples[slot])
+                                                        status_i32[slot], slot_cost[slot], waypoints=db.waypoints,
+                                                        limits=db.limits, n_samples=slot_nsamp[slot], samples=slot_samples[slot])
         return bound[key]
 
     def finish_step(slot, lane):
@@ -488,8 +490,6 @@ def main():
 
     def step_nonlinear():
         slot, lane = begin_step()
-        with torch.cuda.stream(lane_stream[lane]):
-            out_times[slot].copy_(t_init)   # the outer loop overwrites the times: restart from the same point
         slot_call("nonlinear", slot, lane)()
         last_slot[0] = (slot, lane)
         if gather_every[0]:
@@ -595,9 +595,8 @@ def main():
         plan.solve(opt_lin[0], db.fixed_mask, db.fixed_values, t_fixed, out_coeffs[0], status_i32[0], slot_cost[0])
 
     def launch_nl():
-        out_times[0].copy_(t_init)
         plan.solve(opt_nl[0], db.fixed_mask, db.fixed_values, out_times[0], out_coeffs[0], status_i32[0], slot_cost[0],
-                   limits=db.limits, n_samples=slot_nsamp[0], samples=slot_samples[0])
+                   waypoints=db.waypoints, limits=db.limits, n_samples=slot_nsamp[0], samples=slot_samples[0])
 
     for _ in range(10):
         launch_solve()
@@ -809,11 +808,10 @@ def main():
         cap3 = (total3 + world - 1) // world
         pad3 = torch.zeros(cap3 * args.segments * 41 + cap3, dtype=torch.float64, device=dev) if dist is not None else None
         recv3 = ([torch.empty_like(pad3) for _ in range(world)] if (dist is not None and rank == 0 and not gloo) else None)
-        call3 = plan3.bind_solve(opt_nl[0], db3.fixed_mask, db3.fixed_values, tt3, c3, st3, db3.cost, limits=db3.limits,
-                                 n_samples=db3.n_samples, samples=db3.samples)
+        call3 = plan3.bind_solve(opt_nl[0], db3.fixed_mask, db3.fixed_values, tt3, c3, st3, db3.cost, waypoints=db3.waypoints,
+                                 limits=db3.limits, n_samples=db3.n_samples, samples=db3.samples)
 
         def step3():
-            tt3.copy_(t3)
             call3()
 
         def gather3():

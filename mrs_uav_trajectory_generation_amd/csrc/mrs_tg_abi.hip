@@ -477,7 +477,9 @@ int mrs_tg_plan_solve(mrs_tg_plan* plan, const double* wp, const uint8_t* mask, 
     ~SharedDeviceScope() { mrs_tg::set_shared_device_hint(false); }
   } shared_scope((opt->flags & MRS_TG_FLAG_SHARED_DEVICE) != 0);
   bool sampled = false;  // the sampling rode on the final solve's launch
-  if (opt->estimate_times) HIP_TRY(ctx, mrs_tg::launch_estimate_times(b, wp, limits, seg_times, ctx->stream));
+  // (the Mellinger pipeline takes the estimate as its start point itself: mrs_tg::NonlinearParams::estimate_wp)
+  if (opt->estimate_times && opt->time_alloc_method != MRS_TG_TIME_ALLOC_MELLINGER)
+    HIP_TRY(ctx, mrs_tg::launch_estimate_times(b, wp, limits, seg_times, ctx->stream));
 
   if (opt->time_alloc_method != MRS_TG_TIME_ALLOC_NONE && opt->time_alloc_method != MRS_TG_TIME_ALLOC_MELLINGER) {
     mrs_tg::DfoParams prm;
@@ -509,6 +511,10 @@ int mrs_tg_plan_solve(mrs_tg_plan* plan, const double* wp, const uint8_t* mask, 
       return fail(ctx, MRS_TG_ERR_UNSUPPORTED,
                   "MRS_TG_FLAG_CAREFUL_COST: this library was built without the careful re-run (rebuild with -DMRS_TG_WITH_CAREFUL=1)");
     prm.careful_cap = (opt->flags & MRS_TG_FLAG_CAREFUL_COST) ? 1 : 0;
+    if (opt->estimate_times) {
+      prm.estimate_wp = wp;
+      prm.estimate_limits = limits;
+    }
     ProfileScope ps(ctx, 2);
     HIP_TRY(ctx, mrs_tg::launch_nonlinear(plan->nl, b, prm, mask, vals, limits, seg_times, coeffs, status, cost, ctx->stream,
                                           opt->sampling_dt, opt->sample_capacity, n_samples, samples, &sampled,

@@ -14,6 +14,7 @@
 #include <cstdint>
 
 #include "mrs_tg_device.hpp"
+#include "mrs_tg_estimate.hpp"
 #include "mrs_tg_sampling.hpp"
 #include "mrs_tg_solve.hpp"
 #include "mrs_tg_launch.h"
@@ -136,21 +137,6 @@ __global__ __launch_bounds__(64) void solve_linear_kernel(BatchView b, int d, co
 // segment-time initialisation: estimateSegmentTimesEuclidean
 // (/root/reference/src/eth_trajectory_generation/vertex.cpp:491-565), one thread per segment
 
-__device__ __forceinline__ double wrap_pi(double a) {
-  const double two_pi = 2.0 * M_PI;
-  double r = fmod(a + M_PI, two_pi);
-  if (r < 0) r += two_pi;
-  return r - M_PI;
-}
-
-__device__ __forceinline__ double angle_dist(double a, double bb) {
-  const double two_pi = 2.0 * M_PI;
-  double dlt = wrap_pi(a) - wrap_pi(bb);
-  if (dlt < -M_PI) dlt += two_pi;
-  else if (dlt >= M_PI) dlt -= two_pi;
-  return fabs(dlt);
-}
-
 __global__ __launch_bounds__(256) void estimate_times_kernel(BatchView b, const double* __restrict__ wp,
                                                              const double* __restrict__ limits,
                                                              double* __restrict__ seg_times) {
@@ -170,26 +156,7 @@ __global__ __launch_bounds__(256) void estimate_times_kernel(BatchView b, const 
     p = lo;
   }
   const int v = idx + p;  // vertex index of the segment's start
-  const double* s = wp + (size_t)v * 4;
-  const double* e = s + 4;
-  const double* lim = limits + (size_t)p * 9;
-  const double v_h = lim[0], v_v = lim[1], w_max = lim[2], a_max = lim[5];
-  const double dx = e[0] - s[0], dy = e[1] - s[1], dz = e[2] - s[2];
-  const double inclinator = atan2(dz, sqrt(dx * dx + dy * dy));
-  const double thr = atan2(v_v, v_h);
-  const double vmax = (inclinator > thr || inclinator < -thr) ? fabs(v_v / sin(inclinator)) : fabs(v_h / cos(inclinator));
-  double t = sqrt(dx * dx + dy * dy + dz * dz) / vmax;
-  if (t < 0.01) t = 0.01;
-  const double ang = angle_dist(s[3], e[3]);
-  double t_vel = 0.0, t_acc = 0.0;
-  if (w_max < (double)FLT_MAX && a_max < (double)FLT_MAX) {
-    const double reduced = (ang - (w_max * w_max) / a_max) / w_max;
-    t_vel = (reduced < 0) ? ang / w_max : reduced;
-    if (ang > M_PI / 4) t_acc = 2 * (w_max / a_max);
-  }
-  const double hf = 1.5 * (t_vel + t_acc);
-  if (hf > t) t = hf;
-  seg_times[idx] = t;
+  seg_times[idx] = estimate_segment_time(wp + (size_t)v * 4, limits + (size_t)p * 9);
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -100,6 +100,8 @@ hipError_t launch_solve_tile(const BatchView& b, int d, bool fused, const uint8_
 // All-null / zero = the plain solve.
 struct RowsTail {
   const double* maxima = nullptr;        // [n_segments][9]; with limits and opt_status: scale the times first
+  bool maxima_in_launch = false;         // instead: solve at the incoming times, take the maxima of THAT trajectory, scale, solve
+                                         // again (the closing stages of a pipeline in one launch; rows_pipeline_applies)
   const double* limits = nullptr;        // [n_paths][9]
   const int32_t* opt_status = nullptr;   // paths whose search was refused (-2) keep their times
   const double* sum_t0 = nullptr;        // [n_paths] total time the outer loop started from: the runaway test (mrs_tg.h)
@@ -116,6 +118,8 @@ bool rows_kernel_applies(const BatchView& b, bool with_sampling = false);
 // less, 1024 x 10 nonlinear 138 -> 132 us); with two paths per wavefront the walks of the two run one after the other and
 // the separate sampler (one wavefront per path) is faster (8192 x 10: 483 vs 548 us)
 bool rows_tail_sampling_pays(const BatchView& b);
+// solve -> maxima -> scaling -> solve -> sampling of a pipeline in one launch of the rows kernel (small batches)
+bool rows_pipeline_applies(const BatchView& b);
 hipError_t launch_solve_rows(const BatchView& b, int d, const uint8_t* mask, const double* vals, const double* seg_times,
                              double* coeffs, int32_t* status, double* cost, const int32_t* status_in, hipStream_t stream,
                              const RowsTail& tail = RowsTail());

@@ -36,17 +36,10 @@ __host__ __device__ constexpr double falling(int j, int k) {
 // instead of 48 doubles for the horizontal velocity -- which is what lets five wavefronts share a SIMD where three did
 // (142 -> VGPRs); the kernel waits on dependent FMA chains and on its lanes' uneven Newton loops, and more resident
 // wavefronts are what hides both.
-template <int K, int NDIM>
-struct MagPoly {
-  static constexpr int N0 = kN - K;
+template <int NDIM, int N0>
+struct MagPolyBase {
   double d0[NDIM][N0];
 
-  __device__ __forceinline__ void init(const double (&cb)[NDIM][kN]) {
-#pragma unroll
-    for (int q = 0; q < NDIM; ++q)
-#pragma unroll
-      for (int j = 0; j < N0; ++j) d0[q][j] = cb[q][j + K] * falling(j + K, K);
-  }
   // m2 = sum q^(K)^2 ;  g = (1/2) d m2 / dtau
   __device__ __forceinline__ void eval(double tau, double& m2, double& g) const {
     m2 = 0.0;
@@ -84,6 +77,39 @@ struct MagPoly {
   }
 };
 
+template <int K, int NDIM>
+struct MagPoly : MagPolyBase<NDIM, kN - K> {
+  static constexpr int N0 = kN - K;
+
+  __device__ __forceinline__ void init(const double (&cb)[NDIM][kN]) {
+#pragma unroll
+    for (int q = 0; q < NDIM; ++q)
+#pragma unroll
+      for (int j = 0; j < N0; ++j) this->d0[q][j] = cb[q][j + K] * falling(j + K, K);
+  }
+};
+
+// The derivative order as DATA (lanes of one wavefront working on different k: the in-launch maxima of the pipeline kernel,
+// mrs_tg_rows.hip): every lane carries the nine coefficients of k = 1, the ones a higher k does not have are 0.0.  A leading
+// zero coefficient leaves Horner's recurrences at exactly 0.0 until the first real one arrives, so every value -- and with it
+// every decision of the search below -- is bit for bit that of MagPoly<K, NDIM>.
+template <int NDIM>
+struct MagPolyAny : MagPolyBase<NDIM, kN - 1> {
+  static constexpr int N0 = kN - 1;
+
+  __device__ __forceinline__ void init(const double (&cb)[NDIM][kN], int K) {
+#pragma unroll
+    for (int q = 0; q < NDIM; ++q)
+#pragma unroll
+      for (int j = 0; j < N0; ++j) {
+        const double a1 = cb[q][j + 1] * falling(j + 1, 1);
+        const double a2 = (j + 2 < kN) ? cb[q][j + 2 < kN ? j + 2 : 0] * falling(j + 2, 2) : 0.0;
+        const double a3 = (j + 3 < kN) ? cb[q][j + 3 < kN ? j + 3 : 0] * falling(j + 3, 3) : 0.0;
+        this->d0[q][j] = (K == 1) ? a1 : (K == 2) ? a2 : a3;
+      }
+  }
+};
+
 // max over tau in [0,1] of sum_dim q^(K)(tau)^2.
 // Pass 1 walks the grid and records, as a bit mask, the cells where g changes sign + -> - (a local
 // maximum inside).  Pass 2 polishes the recorded cells.  Keeping the two apart matters on a 64-wide
@@ -93,12 +119,10 @@ struct MagPoly {
 // grid points and the same polished cells as one lane walking all 32, so the maximum over the PARTS lanes (taken by the
 // caller) is the same number; the dependent work of a lane, and with it the time a wavefront waits for its slowest lane's
 // Newton loops, is PARTS times shorter.
-template <int K, int NDIM, int PARTS = 1>
-__device__ __forceinline__ double max_mag2(const double (&cb)[NDIM][kN], int part = 0) {
+template <int PARTS, class Poly>
+__device__ __forceinline__ double max_mag2_search(const Poly& mp, int part) {
   static_assert(kGridCells <= 32 && kGridCells % PARTS == 0, "cell mask is 32 bits");
   constexpr int kCells = kGridCells / PARTS;
-  MagPoly<K, NDIM> mp;
-  mp.init(cb);
   const double h = 1.0 / kGridCells;
   const int i0 = part * kCells;
   double m2, g;
@@ -141,6 +165,13 @@ __device__ __forceinline__ double max_mag2(const double (&cb)[NDIM][kN], int par
   return best;
 }
 
+template <int K, int NDIM, int PARTS = 1>
+__device__ __forceinline__ double max_mag2(const double (&cb)[NDIM][kN], int part = 0) {
+  MagPoly<K, NDIM> mp;
+  mp.init(cb);
+  return max_mag2_search<PARTS>(mp, part);
+}
+
 // which = 3*(k-1) + group: maximum of |p^(k)| over [0, T] for one (k, group) of one segment
 template <int PARTS = 1>
 __device__ __forceinline__ double segment_maximum(const double* __restrict__ c, double T, int which, int part = 0) {
@@ -174,6 +205,33 @@ __device__ __forceinline__ double segment_maximum(const double* __restrict__ c, 
     m2 = fmax(m2, dpp_move<0xB1>(m2));
     m2 = fmax(m2, dpp_move<0x4E>(m2));
   }
+  return sqrt(m2) * scale;
+}
+
+// The same number for a derivative order k = 1..3 that is data: NDIM = 2 is the horizontal group (dimensions 0 and 1), NDIM = 1
+// the dimension `dim` (2: vertical, 3: heading).  PARTS = 2: lanes 2 j and 2 j + 1 share the polynomial, half the grid each.
+template <int NDIM, int PARTS>
+__device__ __forceinline__ double segment_maximum_any(const double* c, double T, int k, int dim, int part) {
+  double tp = 1.0;
+  const double ti = 1.0 / T;
+  double scale = ti;
+  if (k == 2) scale = ti * ti;
+  else if (k == 3) scale = ti * ti * ti;
+  double cb[NDIM][kN];
+#pragma unroll
+  for (int j = 0; j < kN; ++j) {
+    if (NDIM == 2) {
+      cb[0][j] = c[0 * kN + j] * tp;
+      cb[NDIM - 1][j] = c[1 * kN + j] * tp;
+    } else {
+      cb[0][j] = c[dim * kN + j] * tp;
+    }
+    tp *= T;
+  }
+  MagPolyAny<NDIM> mp;
+  mp.init(cb, k);
+  double m2 = max_mag2_search<PARTS>(mp, part);
+  if (PARTS == 2) m2 = fmax(m2, dpp_move<0xB1>(m2));
   return sqrt(m2) * scale;
 }
 

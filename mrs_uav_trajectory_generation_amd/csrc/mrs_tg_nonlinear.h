@@ -26,6 +26,11 @@ struct NonlinearParams {
   int32_t* queue_next = nullptr;  // lean kernel of a uniform batch larger than the device holds at once: next unclaimed position of the bin
   int lean_shared = 0;  // lean kernels: shared half sweeps (evaluate_lean_shared) 1: in batches where every path has its S + 4 lanes (own kernel), 2: also wave by wave inside the mixed kernel
   double* sum_t0 = nullptr;  // [n_paths] by path: sum of the times the search starts from (the runaway test of the final solve)
+  // The search starts from estimateSegmentTimesEuclidean of these waypoints ([n_vertices][4]) under estimate_limits
+  // ([n_paths][9]) instead of from the incoming seg_times: optimize_wave_kernel computes the estimate itself, in front of
+  // every other outer-loop kernel launch_nonlinear launches estimate_times_kernel.  nullptr: start from seg_times.
+  const double* estimate_wp = nullptr;
+  const double* estimate_limits = nullptr;
 };
 
 // Paths are sorted by segment count (longest first), so every lane-group class is a contiguous range

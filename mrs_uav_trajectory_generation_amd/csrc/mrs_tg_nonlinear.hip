@@ -1801,6 +1801,14 @@ hipError_t launch_nonlinear(NonlinearPlan& nl, const BatchView& b, const Nonline
   if (b.n_paths == 0) return hipSuccess;
   hipError_t e = nonlinear_ensure_buffers(nl, b);
   if (e != hipSuccess) return e;
+  // the start point is the estimate (prm_in.estimate_wp): computed by the one-wavefront kernel itself, by a launch of its own in
+  // front of the others (which read their start from seg_times, some of them more than once)
+  const bool lean_route = lean_applies(nl) && (int)nl.bins.size() <= 5;
+  const bool estimate_in_kernel = prm_in.estimate_wp != nullptr && !general && prm_in.careful_cap == 0 && !lean_route &&
+                                  wave_kernel_applies(b, nl.dim_split);
+  if (prm_in.estimate_wp && !estimate_in_kernel &&
+      (e = launch_estimate_times(b, prm_in.estimate_wp, prm_in.estimate_limits, seg_times, stream)) != hipSuccess)
+    return e;
   // paths with a position-free vertex (the caller says there may be some): flagged and listed, their start times kept aside
   int general_cap = 0;
   if (general && (e = nonlinear_prepare_general(nl, b, mask, seg_times, true, &general_cap, stream)) != hipSuccess) return e;
@@ -1814,6 +1822,7 @@ hipError_t launch_nonlinear(NonlinearPlan& nl, const BatchView& b, const Nonline
     return e == nullptr ? 2 : std::atoi(e);
   }();
   prm.lean_shared = lean_shared;
+  if (!estimate_in_kernel) prm.estimate_wp = prm.estimate_limits = nullptr;
   prm.sum_t0 = nl.d_sum_t0;
   prm.deadline = nullptr;
   if (prm_in.time_budget_ticks > 0) {
@@ -2004,6 +2013,23 @@ hipError_t launch_nonlinear(NonlinearPlan& nl, const BatchView& b, const Nonline
         }
       }
     }
+  }
+  // 2-4 in one launch for the small batches whose wavefronts hold one path (solve_rows_pipeline_kernel, mrs_tg_rows.hip)
+  if (!general && !quad_kernel_applies(b, b.n_paths, false) && rows_pipeline_applies(b)) {
+    RowsTail tail;
+    tail.maxima_in_launch = true;
+    tail.limits = limits;
+    tail.opt_status = nl.d_opt_status;
+    tail.sum_t0 = nl.d_sum_t0;
+    tail.seg_times_out = seg_times;
+    if (sampling_dt > 0.0 && n_samples != nullptr) {
+      tail.sampling_dt = sampling_dt;
+      tail.sample_capacity = sample_capacity;
+      tail.n_samples = n_samples;
+      tail.samples = samples;
+      if (sampled_out) *sampled_out = true;
+    }
+    return launch_solve_rows(b, prm.derivative, mask, vals, seg_times, coeffs, status, cost, nl.d_opt_status, stream, tail);
   }
   // 2. trajectory of the last evaluated point (scaleSegmentTimesWithViolation works on poly_opt_'s state)
   if ((e = launch_solve_linear(b, prm.derivative, true, mask, vals, seg_times, nullptr, nullptr, nl.d_ws, coeffs, nullptr,

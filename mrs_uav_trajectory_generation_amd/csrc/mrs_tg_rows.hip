@@ -25,6 +25,7 @@
 
 #include "mrs_tg_device.hpp"
 #include "mrs_tg_launch.h"
+#include "mrs_tg_maxima.hpp"
 #include "mrs_tg_rowelim.hpp"
 #include "mrs_tg_sampling.hpp"
 
@@ -309,9 +310,34 @@ struct RowSolve : RowCore {
   }
 };
 
-// TAIL: the launch scales the segment times first and / or samples afterwards (RowsTail); the plain solve is its own
-// instantiation, which the tail's code would otherwise cost 0.4 us at 1024 x 10
-template <bool TAIL>
+// T^(2 + k - 2 d), k = 0..3, and T of a segment record
+__device__ __forceinline__ void rows_segment_time(double* r, int d, double T) {
+  // T^(2 - 2d) as the assembly kernel forms it: T / (T^d)^2 ... times T
+  const double t2 = T * T;
+  double td = 1.0;
+  if (d == 1) td = T;
+  else if (d == 2) td = t2;
+  else if (d == 3) td = t2 * T;
+  else if (d == 4) td = t2 * t2;
+  double qk = t2 / (td * td);
+#pragma unroll
+  for (int kk = 0; kk < 4; ++kk) {
+    r[kRSegPow + kk] = qk;
+    qk *= T;
+  }
+  r[kRSegT] = T;
+}
+
+// TAIL = 1: the launch scales the segment times first and / or samples afterwards (RowsTail); the plain solve (TAIL = 0) is
+// its own instantiation, which the tail's code would otherwise cost 0.4 us at 1024 x 10.
+// TAIL = 2 (RowsTail::maxima_in_launch): the closing stages of a time-allocation pipeline in ONE launch, for the small
+// batches whose wavefronts hold one path -- solve at the incoming times, the per-segment maxima of that trajectory, the
+// feasibility scaling, the solve at the scaled times (only if some time moved: the same solve on the same numbers
+// otherwise), cost, status, sampling.  A workgroup is two wavefronts: the second one only helps with the maxima (3 S
+// horizontal searches, two lanes each, in wavefront 0; 6 S vertical and heading searches in wavefront 1 -- the numbers of
+// segment_maxima9_kernel, mrs_tg_maxima.hpp) and leaves.  Every other stage is the code of the separate launches on the
+// same numbers; what goes away is two launches, the gaps between three, and two staging passes.
+template <int TAIL>
 __device__ __forceinline__ void solve_rows_body(const BatchView& b, int d, int ppw, int Smax, const uint8_t* __restrict__ mask,
                                                 const double* __restrict__ vals,
                                                 const double* seg_times /* may be tail.seg_times_out */,
@@ -324,7 +350,8 @@ __device__ __forceinline__ void solve_rows_body(const BatchView& b, int d, int p
   // an exposed scalar-cache miss on the only wavefront of its SIMD -- instead of in one batch at the top
   asm volatile("" ::"s"(mask), "s"(vals), "s"(seg_times), "s"(coeffs), "s"(status), "s"(cost), "s"(status_in), "s"(d), "s"(ppw),
                "s"(Smax), "s"(b.n_paths), "s"(b.uniform_S), "s"(b.order), "s"(b.seg_offsets));
-  const int lane = threadIdx.x;
+  const int lane = threadIdx.x & 63;
+  const int helper = (TAIL == 2) ? __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6) : 0;
   const int q0 = block * ppw;
   const int n_here = min(ppw, b.n_paths - q0);
   const int PS = rows_path_doubles(Smax);
@@ -347,12 +374,21 @@ __device__ __forceinline__ void solve_rows_body(const BatchView& b, int d, int p
   rs.d = d;
   rs.load_constants();
 
+  // TAIL = 2: the path's limits and the search's stopping reason, for the scaling between the two solves
+  // (parked in LDS behind the maxima: nine doubles held in registers across the solve made it spill)
+  double* mx_lds = lds + (size_t)ppw * PS + (size_t)ppw * ((size_t)Smax * (kD * kN + 1)) + kSampleBuffer + kSampleBuffer / 4 + 2;
+  int st_keep = -2;
+  if (TAIL == 2 && !helper) {
+    st_keep = __builtin_amdgcn_readfirstlane(tail.opt_status[__builtin_amdgcn_readfirstlane(pr.p)]);
+    if (lane < 9) mx_lds[(size_t)Smax * 9 + lane] = tail.limits[(size_t)pr.p * 9 + lane];
+  }
+
   // ---- stage: constraints and segment data of the wavefront's paths -> LDS
   bool pos_ok_lane = true, nonzero_lane = false;
   unsigned long long pos_bad[2] = {0ull, 0ull}, gen_any[2] = {0ull, 0ull};
 #pragma unroll
   for (int tt = 0; tt < 2; ++tt) {
-    if (tt >= n_here) break;
+    if (tt >= n_here || helper) break;
     const int S_t = __builtin_amdgcn_readlane(pr.S, tt * 16), s0_t = __builtin_amdgcn_readlane(pr.s0, tt * 16),
               v0_t = __builtin_amdgcn_readlane(pr.v0, tt * 16);
     double* vb = lds + (size_t)tt * PS;
@@ -368,7 +404,7 @@ __device__ __forceinline__ void solve_rows_body(const BatchView& b, int d, int p
     // requested here as well (behind the segment's time they were two more trips to memory in a row)
     double mx_first[9] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0}, lim_first[9] = {1.0, 1.0, 1.0, 1.0, 1.0, 1.0, 1.0, 1.0, 1.0};
     int st_first = -2;
-    if (TAIL && tail.maxima && lane < S_t) {
+    if (TAIL == 1 && tail.maxima && lane < S_t) {
       st_first = tail.opt_status[p_t];
 #pragma unroll
       for (int e = 0; e < 9; ++e) {
@@ -407,25 +443,12 @@ __device__ __forceinline__ void solve_rows_body(const BatchView& b, int d, int p
     MRS_TG_PHASE_MARK(21);  // vertices staged
     // segment `i` of the path: its record from its time and the constrained positions of its two vertices
     auto stage_segment = [&](int i, double T, const double (&pp)[2 * kD], int opt_st, const double* mx, const double* lim) {
-      if (TAIL && tail.maxima) {  // feasibility scaling of this segment (trajectory.cpp:625-657), then the solve at the scaled times
+      if (TAIL == 1 && tail.maxima) {  // feasibility scaling of this segment (trajectory.cpp:625-657), then the solve at the scaled times
         if (opt_st != -2) T *= violation_scaling(mx, lim);
         tail.seg_times_out[s0_t + i] = T;
       }
       double* r = sb + (size_t)i * kRSegRec;
-      // T^(2 - 2d) as the assembly kernel forms it: T / (T^d)^2 ... times T
-      const double t2 = T * T;
-      double td = 1.0;
-      if (d == 1) td = T;
-      else if (d == 2) td = t2;
-      else if (d == 3) td = t2 * T;
-      else if (d == 4) td = t2 * t2;
-      double qk = t2 / (td * td);
-#pragma unroll
-      for (int kk = 0; kk < 4; ++kk) {
-        r[kRSegPow + kk] = qk;
-        qk *= T;
-      }
-      r[kRSegT] = T;
+      rows_segment_time(r, d, T);
 #pragma unroll
       for (int dd = 0; dd < kD; ++dd) r[kRSegDp + dd] = pp[dd] - pp[kD + dd];
     };
@@ -441,7 +464,7 @@ __device__ __forceinline__ void solve_rows_body(const BatchView& b, int d, int p
         pp[dd] = ps[dd];
         pp[kD + dd] = ps[kHalf * kD + dd];
       }
-      stage_segment(i, seg_times[s0_t + i], pp, (TAIL && tail.maxima) ? tail.opt_status[p_t] : -2,
+      stage_segment(i, seg_times[s0_t + i], pp, (TAIL == 1 && tail.maxima) ? tail.opt_status[p_t] : -2,
                     tail.maxima + (size_t)(s0_t + i) * 9, tail.limits + (size_t)p_t * 9);
     }
     MRS_TG_PHASE_MARK(22);  // segments staged
@@ -451,91 +474,136 @@ __device__ __forceinline__ void solve_rows_body(const BatchView& b, int d, int p
   wave_lds_sync();
   MRS_TG_PHASE_MARK(1);
 
-  // ---- build + solve
-  {
-    rs.store_ok = pl < n_here;
-    rs.general = (t ? gen_any[1] : gen_any[0]) != 0ull;
-    rs.S = pr.S;
-    rs.mid = pr.S / 2;
-    rs.vtx0 = vtx0;
-    rs.seg0 = seg0;
-    // vertices a side eliminates: [0, m) or (m, S]; a fully constrained end vertex (every rest-to-rest path has two)
-    // has nothing to eliminate -- its rows are identity rows, its couplings are masked -- and is left out
-    {
-      const int len = rs.dir ? pr.S - rs.mid : rs.mid;
-      const double* ef = vtx0 + (size_t)(rs.dir ? pr.S : 0) * kRVtxRec + kRVtxFree;
-      const bool end_fixed = (ef[0] + ef[1] + ef[2] + ef[3]) == 0.0;
-      rs.nact = (len > 0 && end_fixed) ? len - 1 : len;
-    }
-    int wmax = max(max(__builtin_amdgcn_readlane(rs.nact, 0), __builtin_amdgcn_readlane(rs.nact, 16)),
-                   max(__builtin_amdgcn_readlane(rs.nact, 32), __builtin_amdgcn_readlane(rs.nact, 48)));
-    rs.run(wmax);
-  }
-  wave_lds_sync();
-  MRS_TG_PHASE_MARK(4);
+  // TAIL = 2: mx_lds = [Smax][9] maxima of the first solve's trajectory, behind the sampler's areas
+#pragma clang loop unroll(disable)
+  for (int pass = 0; pass < (TAIL == 2 ? 2 : 1); ++pass) {
+    if (!helper) {
+      // ---- build + solve
+      {
+        rs.store_ok = pl < n_here;
+        rs.general = (t ? gen_any[1] : gen_any[0]) != 0ull;
+        rs.S = pr.S;
+        rs.mid = pr.S / 2;
+        rs.vtx0 = vtx0;
+        rs.seg0 = seg0;
+        // vertices a side eliminates: [0, m) or (m, S]; a fully constrained end vertex (every rest-to-rest path has two)
+        // has nothing to eliminate -- its rows are identity rows, its couplings are masked -- and is left out
+        {
+          const int len = rs.dir ? pr.S - rs.mid : rs.mid;
+          const double* ef = vtx0 + (size_t)(rs.dir ? pr.S : 0) * kRVtxRec + kRVtxFree;
+          const bool end_fixed = (ef[0] + ef[1] + ef[2] + ef[3]) == 0.0;
+          rs.nact = (len > 0 && end_fixed) ? len - 1 : len;
+        }
+        int wmax = max(max(__builtin_amdgcn_readlane(rs.nact, 0), __builtin_amdgcn_readlane(rs.nact, 16)),
+                       max(__builtin_amdgcn_readlane(rs.nact, 32), __builtin_amdgcn_readlane(rs.nact, 48)));
+        rs.run(wmax);
+      }
+      wave_lds_sync();
+      MRS_TG_PHASE_MARK(4);
 
-  // ---- recover: coefficients c = A^-1 [d_i; d_{i+1}] and the cost share 0.5 c^T Q c per (segment, dimension)
-  const int per_path = Smax * kD;
-  for (int item = lane; item < n_here * per_path; item += 64) {
-    const int tt = item >= per_path ? 1 : 0;
-    const int r = item - tt * per_path;
-    const int i = r >> 2, dim = r & 3;
-    const int S_t = __builtin_amdgcn_readlane(pr.S, 0);
-    const int S_u = __builtin_amdgcn_readlane(pr.S, 16);
-    if (i >= (tt ? S_u : S_t)) continue;
-    const int s0_t = tt ? __builtin_amdgcn_readlane(pr.s0, 16) : __builtin_amdgcn_readlane(pr.s0, 0);
-    const double* vb = lds + (size_t)tt * PS;
-    const double* sb = vb + (size_t)(Smax + 1) * kRVtxRec;
-    double* pcb = const_cast<double*>(sb) + (size_t)Smax * kRSegRec;
-    const double* vs = vb + (size_t)i * kRVtxRec;
-    const double* ve = vs + kRVtxRec;
-    const double T = sb[(size_t)i * kRSegRec + kRSegT];
-    double dv[kN];
-#pragma unroll
-    for (int kk = 0; kk < kHalf; ++kk) {
-      dv[kk] = vs[kRVtxDer + kk * kD + dim];
-      dv[kHalf + kk] = ve[kRVtxDer + kk * kD + dim];
-      if (kk >= kSlot0) {
-        dv[kk] += vs[kRVtxX + (kk - kSlot0) * kD + dim];
-        dv[kHalf + kk] += ve[kRVtxX + (kk - kSlot0) * kD + dim];
+      // ---- recover: coefficients c = A^-1 [d_i; d_{i+1}] and the cost share 0.5 c^T Q c per (segment, dimension)
+      const int per_path = Smax * kD;
+      for (int item = lane; item < n_here * per_path; item += 64) {
+        const int tt = item >= per_path ? 1 : 0;
+        const int r = item - tt * per_path;
+        const int i = r >> 2, dim = r & 3;
+        const int S_t = __builtin_amdgcn_readlane(pr.S, 0);
+        const int S_u = __builtin_amdgcn_readlane(pr.S, 16);
+        if (i >= (tt ? S_u : S_t)) continue;
+        const int s0_t = tt ? __builtin_amdgcn_readlane(pr.s0, 16) : __builtin_amdgcn_readlane(pr.s0, 0);
+        const double* vb = lds + (size_t)tt * PS;
+        const double* sb = vb + (size_t)(Smax + 1) * kRVtxRec;
+        double* pcb = const_cast<double*>(sb) + (size_t)Smax * kRSegRec;
+        const double* vs = vb + (size_t)i * kRVtxRec;
+        const double* ve = vs + kRVtxRec;
+        const double T = sb[(size_t)i * kRSegRec + kRSegT];
+        double dv[kN];
+    #pragma unroll
+        for (int kk = 0; kk < kHalf; ++kk) {
+          dv[kk] = vs[kRVtxDer + kk * kD + dim];
+          dv[kHalf + kk] = ve[kRVtxDer + kk * kD + dim];
+          if (kk >= kSlot0) {
+            dv[kk] += vs[kRVtxX + (kk - kSlot0) * kD + dim];
+            dv[kHalf + kk] += ve[kRVtxX + (kk - kSlot0) * kD + dim];
+          }
+        }
+        // c_k = T^-k sum_j ABAR_INV[k][j] T^(j%5) d_j ; cb_k = c_k T^k is what the cost needs
+        double w[kHalf];
+        w[0] = 1.0;
+    #pragma unroll
+        for (int kk = 1; kk < kHalf; ++kk) w[kk] = w[kk - 1] * T;
+        double db[kN], cb[kN], c[kN];
+    #pragma unroll
+        for (int j = 0; j < kN; ++j) db[j] = dv[j] * w[j % kHalf];
+        const double ti = 1.0 / T;
+        double tik = 1.0;
+    #pragma unroll
+        for (int kk = 0; kk < kN; ++kk) {
+          double s = 0.0;
+          if (kk < kHalf) {
+            s = c_abar_inv[kk][kk] * db[kk];  // the upper half of ABAR_INV is diag(1/k!)
+          } else {
+    #pragma unroll
+            for (int j = 0; j < kN; ++j) s += c_abar_inv[kk][j] * db[j];
+          }
+          cb[kk] = s;
+          c[kk] = s * tik;
+          tik *= ti;
+        }
+        double* out = coeffs + ((size_t)(s0_t + i) * kD + dim) * kN;
+    #pragma unroll
+        for (int kk = 0; kk < kN; ++kk) out[kk] = c[kk];
+        if ((TAIL && tail.sampling_dt > 0.0 && tail.samples) || TAIL == 2) {  // the sampler (the maxima searches) of this launch read them from LDS
+          double* sc = lds + (size_t)ppw * PS + (size_t)tt * ((size_t)Smax * (kD * kN + 1)) + Smax + (size_t)r * kN;
+    #pragma unroll
+          for (int kk = 0; kk < kN; ++kk) sc[kk] = c[kk];
+        }
+        const double quad_form = cost_quadratic_form_d(d, cb);
+        // T^(1 - 2d) = q[0] / T
+        pcb[r] = quad_form * (sb[(size_t)i * kRSegRec + kRSegPow] * ti);
       }
+      wave_lds_sync();
     }
-    // c_k = T^-k sum_j ABAR_INV[k][j] T^(j%5) d_j ; cb_k = c_k T^k is what the cost needs
-    double w[kHalf];
-    w[0] = 1.0;
-#pragma unroll
-    for (int kk = 1; kk < kHalf; ++kk) w[kk] = w[kk - 1] * T;
-    double db[kN], cb[kN], c[kN];
-#pragma unroll
-    for (int j = 0; j < kN; ++j) db[j] = dv[j] * w[j % kHalf];
-    const double ti = 1.0 / T;
-    double tik = 1.0;
-#pragma unroll
-    for (int kk = 0; kk < kN; ++kk) {
-      double s = 0.0;
-      if (kk < kHalf) {
-        s = c_abar_inv[kk][kk] * db[kk];  // the upper half of ABAR_INV is diag(1/k!)
-      } else {
-#pragma unroll
-        for (int j = 0; j < kN; ++j) s += c_abar_inv[kk][j] * db[j];
+    if (TAIL == 2 && pass == 0) {
+      // ---- maxima of the trajectory just solved: which = 3 (k - 1) + group
+      const int S_p = __builtin_amdgcn_readfirstlane(pr.S);
+      const double* sb = lds + (size_t)(Smax + 1) * kRVtxRec;
+      const double* sc = lds + (size_t)ppw * PS + Smax;
+      __syncthreads();
+      MRS_TG_PHASE_MARK(6);
+      if (!helper) {  // horizontal: (k, segment) x two halves of the grid
+        for (int t = lane; t < 6 * S_p; t += 64) {
+          const int task = t >> 1, k = task / S_p, i = task - k * S_p;
+          mx_lds[i * 9 + 3 * k] = segment_maximum_any<2, 2>(sc + (size_t)i * kD * kN, sb[(size_t)i * kRSegRec + kRSegT], k + 1, 0, t & 1);
+        }
+      } else {        // vertical and heading: (k, group, segment)
+        for (int t = lane; t < 6 * S_p; t += 64) {
+          const int kg = t / S_p, i = t - kg * S_p, k = kg >> 1, grp = 1 + (kg & 1);
+          mx_lds[i * 9 + 3 * k + grp] = segment_maximum_any<1, 1>(sc + (size_t)i * kD * kN, sb[(size_t)i * kRSegRec + kRSegT], k + 1, 1 + grp, 0);
+        }
       }
-      cb[kk] = s;
-      c[kk] = s * tik;
-      tik *= ti;
+      __syncthreads();
+      MRS_TG_PHASE_MARK(7);
+      if (helper) return;
+      // ---- feasibility scaling (trajectory.cpp:625-657): T_i <- s_i T_i; nothing moved = the solve above is the last one
+      bool moved = false;
+      for (int i = lane; i < S_p; i += 64) {
+        double* r = const_cast<double*>(sb) + (size_t)i * kRSegRec;
+        const double T = r[kRSegT];
+        double Tn = T;
+        if (st_keep != -2) Tn = T * violation_scaling(mx_lds + (size_t)i * 9, mx_lds + (size_t)Smax * 9);
+        if (Tn != T) {
+          moved = true;
+          rows_segment_time(r, d, Tn);
+          tail.seg_times_out[pr.s0 + i] = Tn;
+        }
+      }
+      MRS_TG_PHASE_MARK(14);
+      if (__ballot(moved) == 0ull) break;
+      rs.load_constants();  // (again: held across the searches above they cost the registers the searches need)
+      wave_lds_sync();
     }
-    double* out = coeffs + ((size_t)(s0_t + i) * kD + dim) * kN;
-#pragma unroll
-    for (int kk = 0; kk < kN; ++kk) out[kk] = c[kk];
-    if (TAIL && tail.sampling_dt > 0.0 && tail.samples) {  // the sampler of this launch reads them from LDS
-      double* sc = lds + (size_t)ppw * PS + (size_t)tt * ((size_t)Smax * (kD * kN + 1)) + Smax + (size_t)r * kN;
-#pragma unroll
-      for (int kk = 0; kk < kN; ++kk) sc[kk] = c[kk];
-    }
-    const double quad_form = cost_quadratic_form_d(d, cb);
-    // T^(1 - 2d) = q[0] / T
-    pcb[r] = quad_form * (sb[(size_t)i * kRSegRec + kRSegPow] * ti);
   }
-  wave_lds_sync();
 
   // ---- cost and status: the 16 lanes of a path's first row add its partial costs in a fixed order
   if ((lane >> 5) == 0 && pl < n_here) {
@@ -583,9 +651,10 @@ __device__ __forceinline__ void solve_rows_body(const BatchView& b, int d, int p
       wave_lds_sync();
     }
   }
+  MRS_TG_PHASE_MARK(8);
 }
 
-template <bool TAIL>
+template <int TAIL>
 __global__ __launch_bounds__(64, MRS_TG_ROWS_WAVES) void solve_rows_kernel(BatchView b, int d, int ppw, int Smax,
                                                         const uint8_t* __restrict__ mask, const double* __restrict__ vals,
                                                         const double* seg_times, double* __restrict__ coeffs,
@@ -594,13 +663,22 @@ __global__ __launch_bounds__(64, MRS_TG_ROWS_WAVES) void solve_rows_kernel(Batch
   solve_rows_body<TAIL>(b, d, ppw, Smax, mask, vals, seg_times, coeffs, status, cost, status_in, tail, (int)blockIdx.x);
 }
 
+// the closing stages of a pipeline in one launch (TAIL = 2 above): two wavefronts per path
+__global__ __launch_bounds__(128, 2) void solve_rows_pipeline_kernel(BatchView b, int d, int Smax, const uint8_t* __restrict__ mask,
+                                                                     const double* __restrict__ vals, const double* seg_times,
+                                                                     double* __restrict__ coeffs, int32_t* __restrict__ status,
+                                                                     double* __restrict__ cost,
+                                                                     const int32_t* __restrict__ status_in, RowsTail tail) {
+  solve_rows_body<2>(b, d, 1, Smax, mask, vals, seg_times, coeffs, status, cost, status_in, tail, (int)blockIdx.x);
+}
+
 // Several batches of ONE plan (same structure, their own input / output arrays) in one launch: workgroups
 // [j * blocks_per_batch, (j + 1) * blocks_per_batch) solve batch j.  Every path runs the instructions of the single-batch
 // kernel; what changes is the number of dispatches a host that keeps several batches in flight has to issue.
 __global__ __launch_bounds__(64, MRS_TG_ROWS_WAVES) void solve_rows_group_kernel(BatchView b, int d, int ppw, int Smax,
                                                                                   RowsGroup g, int blocks_per_batch) {
   const int j = __builtin_amdgcn_readfirstlane((int)blockIdx.x / blocks_per_batch);
-  solve_rows_body<false>(b, d, ppw, Smax, g.mask[j], g.vals[j], g.seg_times[j], g.coeffs[j], g.status[j], g.cost[j], nullptr,
+  solve_rows_body<0>(b, d, ppw, Smax, g.mask[j], g.vals[j], g.seg_times[j], g.coeffs[j], g.status[j], g.cost[j], nullptr,
                          RowsTail(), (int)blockIdx.x - j * blocks_per_batch);
 }
 
@@ -611,9 +689,10 @@ static constexpr size_t kRowsLdsBudget = 144 * 1024;
 
 // LDS of one wavefront: the records of its paths, and for a launch that samples the times and coefficients of those paths
 // plus one sample buffer
-static size_t rows_lds_bytes(int Smax, int ppw, bool sampling) {
+static size_t rows_lds_bytes(int Smax, int ppw, bool sampling, bool maxima = false) {
   size_t doubles = (size_t)ppw * rows_path_doubles(Smax);
-  if (sampling) doubles += (size_t)ppw * (size_t)Smax * (kD * kN + 1) + kSampleBuffer + kSampleBuffer / 4 + 2;
+  if (sampling || maxima) doubles += (size_t)ppw * (size_t)Smax * (kD * kN + 1) + kSampleBuffer + kSampleBuffer / 4 + 2;
+  if (maxima) doubles += (size_t)Smax * 9 + 10;  // + the path's nine limits
   return doubles * sizeof(double);
 }
 
@@ -631,10 +710,30 @@ bool rows_kernel_applies(const BatchView& b, bool with_sampling) {
 
 bool rows_tail_sampling_pays(const BatchView& b) { return b.n_paths <= 2048 && rows_kernel_applies(b, true); }
 
+bool rows_pipeline_applies(const BatchView& b) {
+  static const bool on = [] {  // MRS_TG_ROWS_PIPELINE=0: the separate launches (tuning / test knob, read once per process)
+    const char* e = std::getenv("MRS_TG_ROWS_PIPELINE");
+    return e == nullptr || std::atoi(e) != 0;
+  }();
+  return on && b.n_paths > 0 && b.n_paths <= 2048 && rows_lds_bytes(b.max_segments, 1, true, true) <= kRowsLdsBudget;
+}
+
 hipError_t launch_solve_rows(const BatchView& b, int d, const uint8_t* mask, const double* vals, const double* seg_times,
                              double* coeffs, int32_t* status, double* cost, const int32_t* status_in, hipStream_t stream,
                              const RowsTail& tail) {
   const bool sampling = tail.sampling_dt > 0.0;
+  if (tail.maxima_in_launch) {
+    if (!tail.limits || !tail.opt_status || !tail.seg_times_out) return hipErrorInvalidValue;
+    const size_t lds_bytes = rows_lds_bytes(b.max_segments, 1, true, true);
+    if (lds_bytes > 64 * 1024) {
+      hipError_t e = hipFuncSetAttribute((const void*)solve_rows_pipeline_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                         (int)kRowsLdsBudget);
+      if (e != hipSuccess) return e;
+    }
+    MRS_TG_LAUNCH_TIMED(solve_rows_pipeline_kernel, dim3((unsigned)b.n_paths), dim3(128), lds_bytes, stream, b, d, b.max_segments,
+                        mask, vals, seg_times, coeffs, status, cost, status_in, tail);
+    return hipGetLastError();
+  }
   // one path per wavefront while that still leaves SIMDs idle (256 CUs x 4); two paths per wavefront otherwise -- and
   // when the caller says other batches share the device: at 255 VGPRs a SIMD holds two wavefronts, so 1024 one-path
   // wavefronts per launch let two launches run side by side, 512 two-path wavefronts four (1024 x 10, four streams:
@@ -649,16 +748,16 @@ hipError_t launch_solve_rows(const BatchView& b, int d, const uint8_t* mask, con
   const size_t lds_bytes = rows_lds_bytes(b.max_segments, ppw, sampling);
   const bool with_tail = sampling || tail.maxima != nullptr;
   if (lds_bytes > 64 * 1024) {  // beyond the default limit of a launch: raise it (a driver call, so only when needed)
-    hipError_t e = hipFuncSetAttribute(with_tail ? (const void*)solve_rows_kernel<true> : (const void*)solve_rows_kernel<false>,
+    hipError_t e = hipFuncSetAttribute(with_tail ? (const void*)solve_rows_kernel<1> : (const void*)solve_rows_kernel<0>,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)kRowsLdsBudget);
     if (e != hipSuccess) return e;
   }
   const unsigned grid = (unsigned)((b.n_paths + ppw - 1) / ppw);
   if (with_tail)
-    MRS_TG_LAUNCH_TIMED(solve_rows_kernel<true>, dim3(grid), dim3(64), lds_bytes, stream, b, d, ppw, b.max_segments, mask, vals,
+    MRS_TG_LAUNCH_TIMED(solve_rows_kernel<1>, dim3(grid), dim3(64), lds_bytes, stream, b, d, ppw, b.max_segments, mask, vals,
                         seg_times, coeffs, status, cost, status_in, tail);
   else
-    MRS_TG_LAUNCH_TIMED(solve_rows_kernel<false>, dim3(grid), dim3(64), lds_bytes, stream, b, d, ppw, b.max_segments, mask, vals,
+    MRS_TG_LAUNCH_TIMED(solve_rows_kernel<0>, dim3(grid), dim3(64), lds_bytes, stream, b, d, ppw, b.max_segments, mask, vals,
                         seg_times, coeffs, status, cost, status_in, tail);
   return hipGetLastError();
 }

@@ -36,6 +36,7 @@
 #include <cstdlib>
 
 #include "mrs_tg_device.hpp"
+#include "mrs_tg_estimate.hpp"
 #include "mrs_tg_nl_common.hpp"
 #include "mrs_tg_nonlinear.h"
 #include "mrs_tg_sweep.hpp"
@@ -279,7 +280,9 @@ __global__ __launch_bounds__(64, MRS_TG_WAVE_WAVES) void optimize_wave_kernel(Ba
 
   // the start times are requested in front of the vertex staging (one trip to memory instead of two in a row)
   double t_first = 0.0;
-  if (me) t_first = seg_times[pr.s0 + lane];
+  if (me)
+    t_first = prm.estimate_wp ? estimate_segment_time(prm.estimate_wp + (size_t)(pr.v0 + lane) * 4, prm.estimate_limits + (size_t)pr.p * 9)
+                              : seg_times[pr.s0 + lane];
   stage_ps_tables(d, lds + kWvTabs, lane, 64);
   stage_block_constants(d, lds + kWvHc, lane, 64);
   stage_vertices(mask, vals, pr.v0, S, vtx, lane, 64);
