@@ -730,15 +730,29 @@ def main():
         wp1 = pr.random_box_waypoints(args.segments, 12345)
         for _ in range(3):
             ctx.find_trajectory(wp1, sample_capacity=1024)
-        lat = []
+        lat_py = []
         for _ in range(30):
             t0 = time.perf_counter()
             ctx.find_trajectory(wp1, sample_capacity=1024)
+            lat_py.append(time.perf_counter() - t0)
+        lat_py.sort()
+        call1, _ = ctx.bind_find_trajectory(wp1, sample_capacity=1024)   # the ctypes arguments marshalled once
+        for _ in range(3):
+            call1()
+        lat = []
+        for _ in range(100):
+            t0 = time.perf_counter()
+            call1()
             lat.append(time.perf_counter() - t0)
         lat.sort()
         extras["single_request_latency"] = dict(median_us=lat[len(lat) // 2] * 1e6, min_us=lat[0] * 1e6, max_us=lat[-1] * 1e6,
+                                                python_wrapper_median_us=lat_py[len(lat_py) // 2] * 1e6,
                                                 call="mrs_tg_find_trajectory through ctypes, one %d-segment path, Mellinger + "
-                                                     "scaling + sampling dt 0.2, host buffers in and out" % args.segments)
+                                                     "scaling + sampling dt 0.2, host buffers in and out; median_us: the foreign "
+                                                     "call with its arguments marshalled once (what a C++ host pays, cf. "
+                                                     "examples/request_latency_host.cpp); python_wrapper_median_us: "
+                                                     "Context.find_trajectory, which builds the ctypes structures and output arrays "
+                                                     "per call (the figure of rounds 1-3)" % args.segments)
     if not args.no_extras and args.workload == "linear":
         # the step that materialises the blocks: assembly kernel + solve from the blocks in HBM
         elb, _ = time_steps(steps_fn["blocks"], args.steps, 3, dist, torch, final_gather, block_fn=block_for("blocks"))

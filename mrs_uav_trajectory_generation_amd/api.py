@@ -355,9 +355,10 @@ class Context:
         self._check(rc, "mrs_tg_solve_batch")
         return dict(times=t, coeffs=coeffs, status=status, cost=cost, n_samples=n_samples, samples=samples)
 
-    def find_trajectory(self, waypoints, stop_at=None, initial_state=None, limits=None, relax_heading=False,
-                        sample_capacity=4096, **opts):
-        """findTrajectory() for one path (mrs_tg_find_trajectory)."""
+    def bind_find_trajectory(self, waypoints, stop_at=None, initial_state=None, limits=None, relax_heading=False,
+                             sample_capacity=4096, **opts):
+        """The arguments of mrs_tg_find_trajectory marshalled ONCE: returns (call, result) -- call() is the foreign call alone
+        (what a C++ host pays per request; the ctypes structures and output arrays are reused), result() reads its outputs."""
         from .problem import DEFAULT_LIMITS
         wp = np.asarray(waypoints, dtype=np.float64).reshape(-1, 4)
         n = wp.shape[0]
@@ -384,13 +385,28 @@ class Context:
         status = C.c_int32(0)
         ns = C.c_int32(0)
         samples = np.zeros((sample_capacity, N_DIM))
-        rc = self._L.mrs_tg_find_trajectory(self._h, arr, n, C.byref(init) if init is not None else None, _np_ptr(lim),
-                                            C.byref(opt), int(bool(relax_heading)), _np_ptr(times), _np_ptr(coeffs),
-                                            C.cast(C.byref(status), C.c_void_p), C.cast(C.byref(ns), C.c_void_p),
-                                            _np_ptr(samples))
-        self._check(rc, "mrs_tg_find_trajectory")
-        return dict(times=times, coeffs=coeffs, status=status.value, n_samples=ns.value,
-                    samples=samples[:min(ns.value, sample_capacity)])
+        fn, h, check = self._L.mrs_tg_find_trajectory, self._h, self._check
+        a_init = C.byref(init) if init is not None else None
+        a_lim, a_opt, a_relax, a_t, a_c = _np_ptr(lim), C.byref(opt), int(bool(relax_heading)), _np_ptr(times), _np_ptr(coeffs)
+        a_st, a_ns, a_smp = C.cast(C.byref(status), C.c_void_p), C.cast(C.byref(ns), C.c_void_p), _np_ptr(samples)
+        keep = (arr, init, lim, opt, times, coeffs, status, ns, samples)
+
+        def call(_keep=keep):
+            rc = fn(h, arr, n, a_init, a_lim, a_opt, a_relax, a_t, a_c, a_st, a_ns, a_smp)
+            if rc:
+                check(rc, "mrs_tg_find_trajectory")
+
+        def result():
+            return dict(times=times.copy(), coeffs=coeffs.copy(), status=status.value, n_samples=ns.value,
+                        samples=samples[:min(ns.value, sample_capacity)].copy())
+        return call, result
+
+    def find_trajectory(self, waypoints, stop_at=None, initial_state=None, limits=None, relax_heading=False,
+                        sample_capacity=4096, **opts):
+        """findTrajectory() for one path (mrs_tg_find_trajectory)."""
+        call, result = self.bind_find_trajectory(waypoints, stop_at, initial_state, limits, relax_heading, sample_capacity, **opts)
+        call()
+        return result()
 
 
 class MultiContext:

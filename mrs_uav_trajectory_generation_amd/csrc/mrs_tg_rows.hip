@@ -715,7 +715,9 @@ bool rows_pipeline_applies(const BatchView& b) {
     const char* e = std::getenv("MRS_TG_ROWS_PIPELINE");
     return e == nullptr || std::atoi(e) != 0;
   }();
-  return on && b.n_paths > 0 && b.n_paths <= 2048 && rows_lds_bytes(b.max_segments, 1, true, true) <= kRowsLdsBudget;
+  // up to one solving wavefront per SIMD (its helper shares the SIMD of another path's solver): 1024 x 10 pipeline 106.6 ->
+  // 101.0 us; at 2048 paths two solvers share every SIMD and the separate launches win (153 vs 169 us)
+  return on && b.n_paths > 0 && b.n_paths <= 1024 && rows_lds_bytes(b.max_segments, 1, true, true) <= kRowsLdsBudget;
 }
 
 hipError_t launch_solve_rows(const BatchView& b, int d, const uint8_t* mask, const double* vals, const double* seg_times,
