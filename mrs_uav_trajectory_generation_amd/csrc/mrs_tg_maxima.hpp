@@ -235,4 +235,37 @@ __device__ __forceinline__ double segment_maximum_any(const double* c, double T,
   return sqrt(m2) * scale;
 }
 
+// ---------------------------------------------------------------------------------------------
+// An upper bound on max |q^(K)| over [0, 1] without a search: the largest Bernstein coefficient of q^(K) (a polynomial is a
+// convex combination of its Bernstein coefficients on [0, 1]).  Used where the maxima only feed the feasibility scaling
+// max(1, max / limit, ...) (trajectory.cpp:625-642): a (segment, k, group) whose bound is below its limit cannot move the
+// scaling, whatever its exact maximum is, and its search is skipped (segment_maxima_scaling_kernel).
+__host__ __device__ constexpr double binomial(int n, int k) {
+  double v = 1.0;
+  for (int i = 1; i <= k; ++i) v = v * (double)(n - k + i) / (double)i;
+  return v;
+}
+
+// cb[j] = c_j T^j of one dimension -> bound on |q^(K)(tau)|, tau in [0, 1], plus an allowance for the rounding of the bound
+// itself (1e-12 of the sum of the magnitudes that went into it)
+template <int K>
+__device__ __forceinline__ double bernstein_bound(const double (&cb)[kN]) {
+  constexpr int n = kN - 1 - K;
+  double a[n + 1], mag = 0.0;
+#pragma unroll
+  for (int j = 0; j <= n; ++j) {
+    a[j] = cb[j + K] * falling(j + K, K);
+    mag += fabs(a[j]);
+  }
+  double best = 0.0;
+#pragma unroll
+  for (int i = 0; i <= n; ++i) {
+    double bi = 0.0;
+#pragma unroll
+    for (int j = 0; j <= i; ++j) bi = fma(binomial(i, j) / binomial(n, j), a[j], bi);
+    best = fmax(best, fabs(bi));
+  }
+  return fma(1.0e-12, mag, best);
+}
+
 }  // namespace mrs_tg

@@ -1,7 +1,13 @@
-"""solve_rows_pipeline_kernel (mrs_tg_rows.hip): the closing stages of a time-allocation pipeline -- solve, per-segment maxima,
-feasibility scaling, second solve, cost, status, sampling -- in one launch for small batches.  Every stage is the code of the
-separate launches on the same numbers, so the results must be THE SAME BITS as with MRS_TG_ROWS_PIPELINE=0 (read once per
-process: the other setting runs in a child process); and, like them, agree with the oracle."""
+"""Two shortcuts of the time-allocation pipelines that must not change a bit of the results:
+
+* solve_rows_pipeline_kernel (mrs_tg_rows.hip): the closing stages -- solve, per-segment maxima, feasibility scaling, second
+  solve, cost, status, sampling -- in one launch for batches of up to 1024 paths;
+* segment_maxima_scaling_kernel (mrs_tg_nonlinear.hip), larger batches: a (segment, k, group) maximum whose Bernstein bound is
+  below its limit is not searched for (it cannot move the scaling).
+
+Every stage is the code of the separate launches / of the full search on the same numbers, so the results must be THE SAME
+BITS as with MRS_TG_ROWS_PIPELINE=0 MRS_TG_MAXIMA_BOUNDS=0 (read once per process: that setting runs in a child process); and,
+like them, agree with the oracle."""
 import os
 import subprocess
 import sys
@@ -17,12 +23,17 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CAP = 256
 CASES = [("uniform10", 300, 10, 4, 2), ("ragged", 200, "ragged12", 4, 2), ("snap3", 64, 3, 4, 2), ("jerk8", 96, 8, 3, 2),
-         ("acc6", 96, 6, 2, 2), ("dfo0", 64, 6, 4, 0), ("one", 1, 10, 4, 2)]
+         ("acc6", 96, 6, 2, 2), ("dfo0", 64, 6, 4, 0), ("one", 1, 10, 4, 2),
+         # more than 1024 paths: separate launches, the maxima through segment_maxima_scaling_kernel
+         ("big10", 3000, 10, 4, 2), ("bigragged", 1500, "ragged", 4, 2), ("bigmixed", 2048, "mixed30", 4, 2),
+         ("bigjerk", 1300, 7, 3, 2)]
 
 
 def _batch(n, n_seg, d):
     if n_seg == "ragged12":
         return pr.random_mixed_batch(n, d, seed0=77, max_segments=12)
+    if n_seg == "mixed30":   # limits scaled by 0.3 .. 3 per path: tight limits leave few entries to the bounds
+        return pr.random_mixed_batch(n, d, seed0=177, max_segments=30)
     return pr.random_batch(n, n_seg, seed0=500, derivative_to_optimize=d)
 
 
@@ -38,7 +49,7 @@ import sys
 sys.path.insert(0, %r)
 import numpy as np
 from mrs_uav_trajectory_generation_amd import api
-from tests.test_gpu_rows_pipeline import _solve, CASES
+from tests.test_gpu_pipeline_shortcuts import _solve, CASES
 ctx = api.Context(0)
 res = {}
 for c in CASES:
@@ -51,16 +62,16 @@ np.savez(sys.argv[1], **res)
 
 @pytest.fixture(scope="module")
 def separate_launches(tmp_path_factory):
-    path = str(tmp_path_factory.mktemp("rows_pipeline") / "separate.npz")
-    env = dict(os.environ, MRS_TG_ROWS_PIPELINE="0")
+    path = str(tmp_path_factory.mktemp("pipeline_shortcuts") / "separate.npz")
+    env = dict(os.environ, MRS_TG_ROWS_PIPELINE="0", MRS_TG_MAXIMA_BOUNDS="0")
     subprocess.run([sys.executable, "-c", CHILD % ROOT, path], check=True, env=env, cwd=ROOT, timeout=600)
     return np.load(path)
 
 
 @pytest.mark.parametrize("name", [c[0] for c in CASES])
-def test_one_launch_gives_the_bits_of_the_separate_launches(gpu_ctx, separate_launches, name):
-    if os.environ.get("MRS_TG_ROWS_PIPELINE", "1") == "0":
-        pytest.skip("the pipeline kernel is switched off in this process")
+def test_shortcuts_give_the_bits_of_the_separate_launches_with_every_maximum_searched(gpu_ctx, separate_launches, name):
+    if os.environ.get("MRS_TG_ROWS_PIPELINE", "1") == "0" or os.environ.get("MRS_TG_MAXIMA_BOUNDS", "1") == "0":
+        pytest.skip("a shortcut is switched off in this process")
     batch, out = _solve(gpu_ctx, name)
     ref = separate_launches
     assert np.array_equal(out["status"], ref[name + "/status"])
