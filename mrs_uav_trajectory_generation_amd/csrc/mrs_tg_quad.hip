@@ -64,9 +64,9 @@ __device__ __forceinline__ void quad_powers(double T, bool d1, bool d2, bool d4,
 }
 
 __device__ __forceinline__ void quad_wave_sync() {
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
   __builtin_amdgcn_wave_barrier();
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
 }
 
 __device__ __forceinline__ double quad_sum(double v) {  // over the four lanes of a quad, to all of them

@@ -49,10 +49,12 @@ __host__ __device__ constexpr int rows_path_doubles(int S) {
   return base + (base & 1) + 2;  // 16-byte aligned records, paths of a wavefront off each other's banks
 }
 
+// (LDS only: a fence over every address space also drains the global-memory counter -- s_waitcnt vmcnt(0) -- and the
+// wavefront then sits out the write latency of the coefficients it has just stored before it may add up its cost or sample)
 __device__ __forceinline__ void wave_lds_sync() {
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
   __builtin_amdgcn_wave_barrier();
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
 }
 
 #ifdef MRS_TG_ROWS_DEBUG

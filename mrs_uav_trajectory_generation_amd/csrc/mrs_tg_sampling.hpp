@@ -62,9 +62,10 @@ __device__ __forceinline__ int sample_path_walk(const double* s_T, const double*
   int n_flushed = 0;  // samples [n_flushed, n) are parked in the buffer
   auto flush = [&](int upto) {
     if (!out) return;
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    // (the fences order LDS only: over every address space they wait for the samples stored by the previous flush as well)
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
     __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
     for (int e = n_flushed + lane; e < upto; e += 64) {
       if (e >= capacity) break;
       const double tj = s_t[e - n_flushed];
@@ -84,9 +85,9 @@ __device__ __forceinline__ int sample_path_walk(const double* s_T, const double*
         for (int dd = 0; dd < kD; ++dd) out[((size_t)e * (NDER + 1) + k) * kD + dd] = v[dd];
       }
     }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
     __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
   };
   if (i < S) {
     acc -= s_T[i];

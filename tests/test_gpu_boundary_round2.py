@@ -178,7 +178,8 @@ def test_per_dispatch_kernel_timing(gpu_ctx):
         for _ in range(40):  # queued back to back: every launch carries its own pair of events
             plan.assemble(4, db.seg_times, H, A)
         hist = gpu_ctx.kernel_ms_history(api.KERNEL_ASSEMBLE)
-        assert len(hist) == 40 and all(1e-3 < v < 0.1 for v in hist), hist
+        # (6 us each on an idle device; one of forty was seen above 0.1 ms on a busy box)
+        assert len(hist) == 40 and all(1e-3 < v < 1.0 for v in hist) and float(np.median(hist)) < 0.1, hist
         ms_asm = gpu_ctx.last_kernel_ms(api.KERNEL_ASSEMBLE)
         assert ms_asm == hist[-1]
         plan.solve(api.default_options(), db.fixed_mask, db.fixed_values, db.seg_times, db.coeffs, db.status, db.cost)
