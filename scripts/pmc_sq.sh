@@ -17,5 +17,5 @@ for wl in linear nonlinear; do
     i=$((i+1))
   done
   python3 scripts/summarize_pmc.py gpurun_out/${tag}_pmc_sq_${wl}.csv $dirs > /dev/null
-  grep -E "solve_rows|optimize_|sample_kernel|segment_maxima9|assemble_blocks_uniform" gpurun_out/${tag}_pmc_sq_${wl}.csv | grep -E "102400|,1024,|65536|,64,|131072|92160|,655360" | head -80
+  grep -E "solve_rows|optimize_|sample_kernel|segment_maxima|assemble_blocks_uniform" gpurun_out/${tag}_pmc_sq_${wl}.csv | grep -E "102400|,1024,|65536|,64,|131072|92160|,655360" | head -80
 done

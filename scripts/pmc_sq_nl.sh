@@ -17,4 +17,4 @@ for g in "${groups[@]}"; do
   i=$((i+1))
 done
 python3 scripts/summarize_pmc.py gpurun_out/${tag}_pmc_sq_nonlinear_${paths}.csv $dirs > /dev/null
-grep -E "optimize_|solve_rows|segment_maxima9|sample_kernel" gpurun_out/${tag}_pmc_sq_nonlinear_${paths}.csv | head -120
+grep -E "optimize_|solve_rows|segment_maxima|sample_kernel" gpurun_out/${tag}_pmc_sq_nonlinear_${paths}.csv | head -120

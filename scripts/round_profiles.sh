@@ -21,5 +21,9 @@ python3 scripts/host_call_rate.py > $O/${tag}_host_call_rate.txt 2>&1
 python3 scripts/host_call_rate.py 64 >> $O/${tag}_host_call_rate.txt 2>&1
 python3 scripts/host_call_rate.py 8192 >> $O/${tag}_host_call_rate.txt 2>&1
 scripts/tile_phases.bin 1024 10 > $O/${tag}_phase_clocks_1024x10.txt 2>&1
+[ -x scripts/pipeline_phases.bin ] || /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -I mrs_uav_trajectory_generation_amd/csrc -I include scripts/pipeline_phases.hip -o scripts/pipeline_phases.bin
+(scripts/pipeline_phases.bin 1024 10; scripts/pipeline_phases.bin 1 10) 2>&1 | grep -v amdgpu.ids > $O/${tag}_phase_clocks_closing_stages.txt
+(scripts/request_latency.sh; scripts/request_timeline.sh) 2>&1 | grep -v amdgpu.ids > $O/${tag}_request_latency.txt
+python3 scripts/lean_ab.py MRS_TG_MAXIMA_BOUNDS 0,1 config4,config5,config6 2>&1 | grep -v amdgpu.ids > $O/${tag}_maxima_bounds_ab.txt
 [ -n "$SKIP_PARITY" ] || scripts/parity_sweep_all.sh $O/${tag}_parity_sweep.txt   # ~17 minutes (the 113-bit oracle); SKIP_PARITY=1 leaves it out
 ls -la $O/${tag}_*
