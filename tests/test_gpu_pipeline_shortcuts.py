@@ -24,6 +24,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CAP = 256
 CASES = [("uniform10", 300, 10, 4, 2), ("ragged", 200, "ragged12", 4, 2), ("snap3", 64, 3, 4, 2), ("jerk8", 96, 8, 3, 2),
          ("acc6", 96, 6, 2, 2), ("dfo0", 64, 6, 4, 0), ("one", 1, 10, 4, 2),
+         # paths of more than 12 segments (another outer-loop kernel in front) and of more than 64 (the closing stages' loops)
+         ("ragged30", 400, "ragged", 4, 2), ("long100", 12, 100, 4, 2),
          # more than 1024 paths: separate launches, the maxima through segment_maxima_scaling_kernel
          ("big10", 3000, 10, 4, 2), ("bigragged", 1500, "ragged", 4, 2), ("bigmixed", 2048, "mixed30", 4, 2),
          ("bigjerk", 1300, 7, 3, 2)]
