@@ -40,6 +40,7 @@
 #include <cstdlib>
 
 #include "mrs_tg_device.hpp"
+#include "mrs_tg_estimate.hpp"
 #include "mrs_tg_pool.h"
 #include "mrs_tg_solve.hpp"
 #include "mrs_tg_nonlinear.h"
@@ -782,6 +783,17 @@ __device__ __forceinline__ bool stage_ps(const uint8_t* __restrict__ mask, const
 }
 
 // ---------------------------------------------------------------------------------------------
+// the time a search starts segment i from: the incoming one, or -- the call asked for the estimate and no launch computed it
+// in front of this kernel (NonlinearParams::estimate_wp) -- estimateSegmentTimesEuclidean of the segment's waypoints
+// (a real call: inlined, the estimate's trigonometry raised the lean kernels' scratch from 72-96 to 168-180 bytes per lane)
+__device__ __attribute__((noinline)) double start_time_estimate(const double* wp, const double* lim) {
+  return estimate_segment_time(wp, lim);
+}
+__device__ __forceinline__ double start_time(const NonlinearParams& prm, const double* t_src, const PathRef& pr, int i) {
+  return prm.estimate_wp ? start_time_estimate(prm.estimate_wp + (size_t)(pr.v0 + i) * 4, prm.estimate_limits + (size_t)pr.p * 9)
+                         : t_src[pr.s0 + i];
+}
+
 // the outer-loop kernel: optimiser ticks (one objective evaluation each).  On exit seg_times holds the
 // last evaluated point and opt_status the stopping reason (-2: start rejected, as NLopt would).
 
@@ -868,7 +880,7 @@ __device__ __forceinline__ void optimize_body(const BatchView& b, const Nonlinea
   // the start times are requested in front of the vertex staging (one trip to memory instead of two in a row)
   const double* t_src = GENERAL ? start_times : seg_times;
   double t_first = 0.0;
-  if (active && wave == 0 && g < S) t_first = t_src[pr.s0 + g];
+  if (active && wave == 0 && g < S) t_first = start_time(prm, t_src, pr, g);
   if (LEAN) {  // vtx = the evaluation area: dp of every segment; the path's eligibility decides who runs it
     const bool takes = stage_ps(mask, vals, pr.v0, S, Sb, vtx, g, G, active, 2, d, MASKED4);
     if (active && g == 0) fallback[q] = takes ? 0 : 1;
@@ -890,7 +902,7 @@ __device__ __forceinline__ void optimize_body(const BatchView& b, const Nonlinea
       if (t < kTimeLowerBound) ok = 0;
     };
     if (g < S) take(g, t_first);
-    for (int i = g + G; i < S; i += G) take(i, t_src[pr.s0 + i]);
+    for (int i = g + G; i < S; i += G) take(i, start_time(prm, t_src, pr, i));
     // the total time the search starts from: what the final solve measures a runaway of the feasibility scaling against
     t_sum = group_sum(t_sum, G);
     if (g == 0 && prm.sum_t0) prm.sum_t0[pr.p] = t_sum;
@@ -1015,7 +1027,7 @@ __device__ __forceinline__ void optimize_body(const BatchView& b, const Nonlinea
             pr = path_at(b, q);
             S = pr.S;
             active = true;
-            double t_new = (g < S) ? seg_times[pr.s0 + g] : 0.0;
+            double t_new = (g < S) ? start_time(prm, seg_times, pr, g) : 0.0;
             const bool takes = stage_ps(mask, vals, pr.v0, S, Sb, vtx, g, G, true, 2, d, MASKED4);
             if (g == 0) fallback[q] = takes ? 0 : 1;
             if (takes) {
@@ -1028,7 +1040,7 @@ __device__ __forceinline__ void optimize_body(const BatchView& b, const Nonlinea
                 if (t < kTimeLowerBound) okn = 0;
               };
               if (g < S) take(g, t_new);
-              for (int i = g + G; i < S; i += G) take(i, seg_times[pr.s0 + i]);
+              for (int i = g + G; i < S; i += G) take(i, start_time(prm, seg_times, pr, i));
               t_sum = group_sum(t_sum, G);
               if (g == 0 && prm.sum_t0) prm.sum_t0[pr.p] = t_sum;
               bad = !group_and(okn, G);
@@ -1890,11 +1902,10 @@ hipError_t launch_nonlinear(NonlinearPlan& nl, const BatchView& b, const Nonline
   if (b.n_paths == 0) return hipSuccess;
   hipError_t e = nonlinear_ensure_buffers(nl, b);
   if (e != hipSuccess) return e;
-  // the start point is the estimate (prm_in.estimate_wp): computed by the one-wavefront kernel itself, by a launch of its own in
-  // front of the others (which read their start from seg_times, some of them more than once)
-  const bool lean_route = lean_applies(nl) && (int)nl.bins.size() <= 5;
-  const bool estimate_in_kernel = prm_in.estimate_wp != nullptr && !general && prm_in.careful_cap == 0 && !lean_route &&
-                                  wave_kernel_applies(b, nl.dim_split);
+  // the start point is the estimate (prm_in.estimate_wp): computed by the outer-loop kernels themselves (start_time), by a
+  // launch of its own in front of the kernels that read their start from a copy
+  // (every outer-loop kernel but the one for position-free paths and the careful re-run, which start from a copy of the times)
+  const bool estimate_in_kernel = prm_in.estimate_wp != nullptr && !general && prm_in.careful_cap == 0;
   if (prm_in.estimate_wp && !estimate_in_kernel &&
       (e = launch_estimate_times(b, prm_in.estimate_wp, prm_in.estimate_limits, seg_times, stream)) != hipSuccess)
     return e;
