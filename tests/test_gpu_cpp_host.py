@@ -119,3 +119,19 @@ def test_cpp_stream_server_keeps_batches_in_flight(tmp_path):
     assert r["paths"] == 1024 and r["in_flight"] == 4 and r["steps"] == 400
     assert r["max_abs_diff_vs_one_call_interface"] == 0.0
     assert r["trajectories_per_s"] > 2.0e7   # (hundreds of millions on an idle MI355X; a loose floor for a shared box)
+
+
+def test_cpp_request_latency_host(tmp_path):
+    """examples/request_latency_host.cpp: one request through mrs_tg_find_trajectory from a g++-built host, repeated; the
+    request succeeds, yields samples, and a call is a fraction of a millisecond (60-100 us on an idle MI355X)."""
+    exe = str(tmp_path / "request_latency_host")
+    libdir = os.path.join(ROOT, "mrs_uav_trajectory_generation_amd")
+    subprocess.check_call(["g++", "-std=c++17", "-O2", "-I", os.path.join(ROOT, "include"),
+                           os.path.join(ROOT, "examples", "request_latency_host.cpp"), "-o", exe, "-L", libdir, "-lmrs_tg",
+                           "-Wl,-rpath," + libdir])
+    out = subprocess.run([exe, "11", "100"], check=True, capture_output=True, text=True, timeout=300).stdout
+    import re
+    m = re.search(r"10 segments \(status (-?\d+), (\d+) samples, ([\d.]+) s of trajectory\): median ([\d.]+) us", out)
+    assert m, out
+    assert int(m.group(1)) >= 1 and int(m.group(2)) > 10 and float(m.group(3)) > 1.0
+    assert float(m.group(4)) < 1000.0, out
