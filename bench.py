@@ -1029,9 +1029,11 @@ def main():
                                 paths_per_gpu=P, segments=args.segments,
                                 batches_in_flight=(n_group_slots if (grouped_mode[0] and args.workload == "linear" and n_lanes > 1) else n_lanes),
                                 hip_streams=n_lanes,
-                                linear_solve="default of mrs_tg_plan_solve: solve_rows_kernel, blocks formed in registers "
-                                             "(nothing materialised); the assembly kernel is timed on its own (roofline) and "
-                                             "inside extras.materialized_blocks_step",
+                                linear_solve="default of mrs_tg_plan_solve, blocks formed in registers (nothing materialised): "
+                                             "solve_rows_kernel for a launch of one batch, solve_quad_group_kernel for a "
+                                             "dispatch that carries >= 6144 paths (the grouped steps of the headline: 8 x 1024), "
+                                             "solve_rows_group_kernel for a smaller group; the assembly kernel is timed on its "
+                                             "own (roofline) and inside extras.materialized_blocks_step",
                                 clock_ramp_steps=ramp_steps, clock_ramp_ms=30,
                                 slot_inputs=("every batch in flight has its own masks, constrained values and segment times (path seeds "
                                              "(rank * slots + slot) * paths + p) and its own outputs" if len(slot_db) > 1 else
