@@ -27,7 +27,7 @@ over the N ranks, results gathered to rank 0 INSIDE its timed region -- is measu
 as extras.config3 and, in short, as the top-level `config3_strong_scaling` (strong scaling of a fixed batch).
 
 Steps are independent batches -- every step is a full pass over its own batch into its own output arrays -- so `--in-flight`
-of them (default 16) are kept in flight per GPU.  `--issue grouped` (default): `--group-size` (8) consecutive steps go out as
+of them (default 20) are kept in flight per GPU.  `--issue grouped` (default): `--group-size` (10) consecutive steps go out as
 ONE dispatch (mrs_tg_bound_solve_launch_group: the single-batch solve kernel's body, its workgroups divided among the
 batches), the dispatches alternating over two HIP streams; a runtime launch costs the host 3 us, so twenty one-step launches
 were half of the driver's 20-step timed region.  `--issue streams` is round 2's method -- one dispatch per step, round-robin over
@@ -81,7 +81,7 @@ def parse_args(argv=None):
     ap.add_argument("--issue-threads", type=int, default=1,
                     help="host threads of the library's issue loop (mrs_tg_bound_solve_launch_many_mt): one runtime launch "
                          "costs the host more than four concurrent kernels take to retire one")
-    ap.add_argument("--in-flight", type=int, default=16,
+    ap.add_argument("--in-flight", type=int, default=20,
                     help="independent batches (sets of input / output arrays) in flight per GPU; 1 = every step waits for the "
                          "previous one.  --issue grouped: --group-size of them per dispatch; --issue streams and the "
                          "nonlinear workload: one per HIP stream, at most --streams of them")
@@ -91,7 +91,7 @@ def parse_args(argv=None):
                     help="how the K linear steps are issued: 'grouped' packs the steps of a round (one per batch in flight) into "
                          "ONE dispatch on one stream (mrs_tg_bound_solve_launch_group); 'streams' issues one dispatch per step, "
                          "round-robin over --in-flight HIP streams (the round-2 method, reported as extras.streams_in_flight)")
-    ap.add_argument("--group-size", type=int, default=8,
+    ap.add_argument("--group-size", type=int, default=10,
                     help="--issue grouped: batches per dispatch; the --in-flight batches are spread over in-flight / group-size "
                          "streams, each stream's dispatches carry group-size steps")
     ap.add_argument("--shared-inputs", dest="distinct_slots", action="store_false",
@@ -387,7 +387,7 @@ def main():
     slot_samples = [db.samples] + [torch.zeros_like(db.samples) for _ in range(n_slots - 1)]
     # Fixed-times steps: every batch in flight has its OWN inputs as well -- slot s of rank r holds the paths seeded
     # (r * slots + s) * paths + p (slot 0 of rank 0 = the paths 0 .. P-1 every other figure of the line is quoted on), its own
-    # masks, constrained values and Euclidean times, so sixteen batches in flight read sixteen different batches.
+    # masks, constrained values and Euclidean times, so twenty batches in flight read twenty different batches.
     slot_batch, slot_db, slot_t = [batch], [db], [t_fixed]
     for sl in range(1, n_slots if args.distinct_slots else 1):
         bs = pr.random_batch(args.paths, args.segments, seed0=(rank * n_slots + sl) * args.paths)

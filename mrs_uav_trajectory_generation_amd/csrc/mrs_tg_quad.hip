@@ -35,6 +35,18 @@
 #include "mrs_tg_nl_common.hpp"
 #include "mrs_tg_solve.hpp"
 
+// wavefronts per SIMD the kernels are compiled for.  The single launch keeps its 262 registers (one wavefront per SIMD; LDS
+// would allow 1.25): at 65536 x 10 the two-wavefront build is 8 % slower (137 vs 127 us, 20 B of scratch).  The grouped launch
+// is compiled for two (256 VGPRs + 12 B): a host that keeps several dispatches in flight then has 1280 instead of 1024
+// wavefront slots for them -- grouped headline over 200 steps 485 -> 539-556 M/s, over 20 steps 339 -> 345-357 with ten
+// steps per dispatch and twenty batches in flight.
+#ifndef MRS_TG_QUAD_WAVES
+#define MRS_TG_QUAD_WAVES 1
+#endif
+#ifndef MRS_TG_QUAD_GROUP_WAVES
+#define MRS_TG_QUAD_GROUP_WAVES 2
+#endif
+
 namespace mrs_tg {
 
 constexpr int kQdPaths = 16;  // paths per wavefront
@@ -357,7 +369,7 @@ __device__ __forceinline__ void solve_quad_body(const BatchView& b, int d, const
   }
 }
 
-__global__ __launch_bounds__(64) void solve_quad_kernel(BatchView b, int d, const uint8_t* __restrict__ mask,
+__global__ __launch_bounds__(64, MRS_TG_QUAD_WAVES) void solve_quad_kernel(BatchView b, int d, const uint8_t* __restrict__ mask,
                                                         const double* __restrict__ vals, const double* seg_times,
                                                         double* __restrict__ coeffs, int32_t* __restrict__ status,
                                                         double* __restrict__ cost, const int32_t* __restrict__ status_in,
@@ -367,7 +379,7 @@ __global__ __launch_bounds__(64) void solve_quad_kernel(BatchView b, int d, cons
 
 // several batches of ONE plan in one launch (as solve_rows_group_kernel): workgroups [j * blocks_per_batch, ...) solve batch j
 // (ws: one factor store of ws_batch_doubles per batch, for wavefronts that take the general step)
-__global__ __launch_bounds__(64) void solve_quad_group_kernel(BatchView b, int d, RowsGroup g, double* ws, size_t ws_batch_doubles,
+__global__ __launch_bounds__(64, MRS_TG_QUAD_GROUP_WAVES) void solve_quad_group_kernel(BatchView b, int d, RowsGroup g, double* ws, size_t ws_batch_doubles,
                                                               int blocks_per_batch) {
   const int j = __builtin_amdgcn_readfirstlane((int)blockIdx.x / blocks_per_batch);
   solve_quad_body(b, d, g.mask[j], g.vals[j], g.seg_times[j], g.coeffs[j], g.status[j], g.cost[j], nullptr,
