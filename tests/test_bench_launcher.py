@@ -26,7 +26,7 @@ def test_launcher_command_is_the_drivers_command():
     assert cmd == ["python3", "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "8", "--master-addr", "127.0.0.1",
                    "--master-port", "29411", "/x/bench.py", "--gpus", "8", "--steps", "20", "--warmup", "5"]
     args = bench.parse_args(argv)
-    assert (args.gpus, args.steps, args.warmup, args.workload, args.paths, args.in_flight, args.streams, args.group_size) == (8, 20, 5, "linear", 1024, 16, 4, 8)
+    assert (args.gpus, args.steps, args.warmup, args.workload, args.paths, args.in_flight, args.streams, args.group_size) == (8, 20, 5, "linear", 1024, 20, 4, 10)
     assert bench.parse_args([]).gpus == 1
 
 
