@@ -12,6 +12,12 @@
 #include <cfloat>
 #include <cmath>
 #include <cstdint>
+#include <cstring>
+#include <algorithm>
+#include <map>
+#include <mutex>
+#include <utility>
+#include <vector>
 
 #include "mrs_tg_device.hpp"
 #include "mrs_tg_estimate.hpp"
@@ -185,7 +191,8 @@ __global__ __launch_bounds__(256) void estimate_times_kernel(BatchView b, const 
 template <int NDER>
 __global__ __launch_bounds__(64) void sample_kernel(BatchView b, const double* __restrict__ coeffs,
                                                     const double* __restrict__ seg_times, double dt, int capacity,
-                                                    int32_t* __restrict__ n_samples, double* __restrict__ samples) {
+                                                    int32_t* __restrict__ n_samples, double* __restrict__ samples,
+                                                    const double* __restrict__ acc_table, int acc_n) {
   extern __shared__ double s_T[];  // [max_segments] segment times | [S][4][10] coefficients of this path | sample buffer
   const int q = blockIdx.x;
   const PathRef pr = path_at(b, q);
@@ -203,7 +210,7 @@ __global__ __launch_bounds__(64) void sample_kernel(BatchView b, const double* _
   __syncthreads();
   MRS_TG_PHASE_MARK(1);
   double* out = samples ? samples + (size_t)pr.p * capacity * (NDER + 1) * kD : nullptr;
-  const int n = sample_path_walk<NDER>(s_T, s_c, s_t, s_seg, S, dt, capacity, out);
+  const int n = sample_path_walk<NDER>(s_T, s_c, s_t, s_seg, S, dt, capacity, out, acc_table, acc_n);
   MRS_TG_PHASE_MARK(2);
   if (lane == 0 && n_samples) n_samples[pr.p] = n;
 }
@@ -331,6 +338,48 @@ hipError_t launch_estimate_times(const BatchView& b, const double* wp, const dou
   return hipGetLastError();
 }
 
+// The accumulated time of the reference's sampling walk, A[k] = k additions of dt to 0 (mrs_tg_sampling.hpp): computed on the
+// host with the additions the device would make (IEEE double, round to nearest), once per (device, dt), kept for the
+// process; grows when a caller asks for a larger capacity.  Returns the device array and its length (>= capacity + 80).
+hipError_t sample_acc_table(double dt, int capacity, const double** table_out, int* n_out) {
+  struct Entry {
+    double* d = nullptr;
+    int n = 0;
+  };
+  static std::mutex mu;
+  static std::map<std::pair<int, unsigned long long>, Entry> cache;
+  int dev = 0;
+  hipError_t e = hipGetDevice(&dev);
+  if (e != hipSuccess) return e;
+  unsigned long long bits;
+  static_assert(sizeof(bits) == sizeof(dt), "dt as a key");
+  std::memcpy(&bits, &dt, sizeof(bits));
+  const int need = (capacity > 0 ? capacity : 0) + 80;
+  std::lock_guard<std::mutex> lock(mu);
+  Entry& en = cache[std::make_pair(dev, bits)];
+  if (en.n < need) {
+    const int n = std::max(need, 1024 + 80);
+    std::vector<double> host((size_t)n);
+    double acc = 0.0;
+    for (int k = 0; k < n; ++k) {
+      host[(size_t)k] = acc;
+      acc += dt;
+    }
+    double* d = nullptr;
+    if ((e = hipMalloc(&d, sizeof(double) * (size_t)n)) != hipSuccess) return e;
+    if ((e = hipMemcpy(d, host.data(), sizeof(double) * (size_t)n, hipMemcpyHostToDevice)) != hipSuccess) {
+      (void)hipFree(d);
+      return e;
+    }
+    // (the old, shorter table may still be read by a launch in flight: it is left alone -- a few KB per (device, dt, growth))
+    en.d = d;
+    en.n = n;
+  }
+  *table_out = en.d;
+  *n_out = en.n;
+  return hipSuccess;
+}
+
 template <int NDER>
 static hipError_t launch_sample_n(const BatchView& b, const double* coeffs, const double* seg_times, double dt, int capacity,
                                   int32_t* n_samples, double* samples, hipStream_t stream) {
@@ -340,8 +389,12 @@ static hipError_t launch_sample_n(const BatchView& b, const double* coeffs, cons
     hipError_t e = hipFuncSetAttribute((const void*)sample_kernel<NDER>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
   }
+  const double* acc_table = nullptr;
+  int acc_n = 0;
+  hipError_t et = sample_acc_table(dt, capacity, &acc_table, &acc_n);
+  if (et != hipSuccess) return et;
   hipLaunchKernelGGL(sample_kernel<NDER>, dim3(b.n_paths), dim3(64), lds, stream, b, coeffs, seg_times, dt, capacity,
-                     n_samples, samples);
+                     n_samples, samples, acc_table, acc_n);
   return hipGetLastError();
 }
 

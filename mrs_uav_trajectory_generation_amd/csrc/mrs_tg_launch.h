@@ -110,7 +110,13 @@ struct RowsTail {
   int sample_capacity = 0;
   int32_t* n_samples = nullptr;
   double* samples = nullptr;
+  const double* sample_acc = nullptr;    // the walk's accumulated times (sample_acc_table): filled in by launch_solve_rows
+  int sample_acc_n = 0;
 };
+
+// A[k] = k additions of dt to 0, the accumulated time of the reference's sampling walk, on the current device (cached per
+// (device, dt) for the process; at least capacity + 80 entries)
+hipError_t sample_acc_table(double dt, int capacity, const double** table_out, int* n_out);
 
 // one lane per unknown, no materialised blocks (mrs_tg_rows.hip): the fused linear solve of every path that fits its LDS record
 bool rows_kernel_applies(const BatchView& b, bool with_sampling = false);

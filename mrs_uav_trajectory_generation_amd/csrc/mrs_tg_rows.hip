@@ -648,7 +648,8 @@ __device__ __forceinline__ void solve_rows_body(const BatchView& b, int d, int p
       for (int i = lane; i < S_t; i += 64) sT[i] = sb[(size_t)i * kRSegRec + kRSegT];
       wave_lds_sync();
       double* out = tail.samples ? tail.samples + (size_t)p_t * tail.sample_capacity * kD : nullptr;
-      const int n = sample_path_walk(sT, sT + Smax, s_t, s_seg, S_t, tail.sampling_dt, tail.sample_capacity, out);
+      const int n = sample_path_walk(sT, sT + Smax, s_t, s_seg, S_t, tail.sampling_dt, tail.sample_capacity, out, tail.sample_acc,
+                                     tail.sample_acc_n);
       if (lane == 0 && tail.n_samples) tail.n_samples[p_t] = n;
       wave_lds_sync();
     }
@@ -726,6 +727,11 @@ hipError_t launch_solve_rows(const BatchView& b, int d, const uint8_t* mask, con
                              double* coeffs, int32_t* status, double* cost, const int32_t* status_in, hipStream_t stream,
                              const RowsTail& tail) {
   const bool sampling = tail.sampling_dt > 0.0;
+  RowsTail tail_k = tail;  // (the copy the kernel gets: with the sampling walk's table filled in)
+  if (sampling) {
+    hipError_t et = sample_acc_table(tail.sampling_dt, tail.sample_capacity, &tail_k.sample_acc, &tail_k.sample_acc_n);
+    if (et != hipSuccess) return et;
+  }
   if (tail.maxima_in_launch) {
     if (!tail.limits || !tail.opt_status || !tail.seg_times_out) return hipErrorInvalidValue;
     const size_t lds_bytes = rows_lds_bytes(b.max_segments, 1, true, true);
@@ -735,7 +741,7 @@ hipError_t launch_solve_rows(const BatchView& b, int d, const uint8_t* mask, con
       if (e != hipSuccess) return e;
     }
     MRS_TG_LAUNCH_TIMED(solve_rows_pipeline_kernel, dim3((unsigned)b.n_paths), dim3(128), lds_bytes, stream, b, d, b.max_segments,
-                        mask, vals, seg_times, coeffs, status, cost, status_in, tail);
+                        mask, vals, seg_times, coeffs, status, cost, status_in, tail_k);
     return hipGetLastError();
   }
   // one path per wavefront while that still leaves SIMDs idle (256 CUs x 4); two paths per wavefront otherwise -- and
@@ -759,7 +765,7 @@ hipError_t launch_solve_rows(const BatchView& b, int d, const uint8_t* mask, con
   const unsigned grid = (unsigned)((b.n_paths + ppw - 1) / ppw);
   if (with_tail)
     MRS_TG_LAUNCH_TIMED(solve_rows_kernel<1>, dim3(grid), dim3(64), lds_bytes, stream, b, d, ppw, b.max_segments, mask, vals,
-                        seg_times, coeffs, status, cost, status_in, tail);
+                        seg_times, coeffs, status, cost, status_in, tail_k);
   else
     MRS_TG_LAUNCH_TIMED(solve_rows_kernel<0>, dim3(grid), dim3(64), lds_bytes, stream, b, d, ppw, b.max_segments, mask, vals,
                         seg_times, coeffs, status, cost, status_in, tail);

@@ -43,21 +43,54 @@ constexpr int kSampleBuffer = 192;  // samples parked per flush.  1024 made the 
 // derivative orders 0..4 of every dimension -- sampleTrajectoryInRange's position / velocity / acceleration / jerk / snap
 // and yaw / yaw rate / yaw acceleration (trajectory_sampling.cpp:49-104), each evaluated as Polynomial::evaluate(t, k)
 // does: Horner over j!/(j-k)! c_j (polynomial.h:150-163).
+//
+// The ACCUMULATED time of the reference's walk (`accumulated_time += dt` from 0, trajectory.cpp:131-149: the loop runs while
+// it is below the trajectory's end) does not depend on the path: sample k is taken at A[k] = (...((0 + dt) + dt)...) + dt, k
+// additions, whatever the segments are.  The launcher hands the kernel that sequence (acc_table[0 .. acc_n), computed once per
+// dt with the same IEEE additions, sample_acc_table), the walk finds N = #{k : A[k] < t_end} with one look at the table around
+// t_end / dt, and "accumulated < t_end" for sample k is "k < N": the second of the two dependent additions per sample that the
+// walk used to carry is gone, bit for bit the same samples.
 template <int NDER = 0>
 __device__ __forceinline__ int sample_path_walk(const double* s_T, const double* s_c, double* s_t, unsigned short* s_seg, int S,
-                                                double dt, int capacity, double* out) {
+                                                double dt, int capacity, double* out, const double* __restrict__ acc_table,
+                                                int acc_n) {
   const int lane = threadIdx.x & 63;
-  // every lane carries the same walk state (i, Ti, tin, acc, n): t_end and the start segment as the reference
+  // every lane carries the same walk state (i, Ti, tin, n): t_end and the start segment as the reference
   // computes them (trajectory.cpp:100-120, t_start = 0)
   double t_end = 0.0;
   for (int i = 0; i < S; ++i) t_end += s_T[i];
-  double acc = 0.0;
-  int i = 0;
-  for (i = 0; i < S; ++i) {
-    acc += s_T[i];
-    if (acc > 0.0) break;
-  }
   const double inv_dt = 1.0 / dt;
+  // N = the first k with A[k] >= t_end (A increases strictly): a window of 64 table entries around t_end / dt, moved if the
+  // estimate was off; no entry at or above t_end in the table = more samples than any buffer this table was built for holds
+  int n_total = 0;
+  if (t_end == t_end) {  // (a t_end that is not a number ends the reference's loop at once: no sample)
+    const double est = fmin(fmax(t_end * inv_dt, 0.0), (double)(acc_n - 1));
+    int base = max((int)est - 8, 0);
+    for (;;) {
+      const int k = min(base + lane, acc_n - 1);
+      const unsigned long long ge = __ballot(acc_table[k] >= t_end);
+      if (ge == 0ull) {
+        if (base + 64 >= acc_n) {
+          n_total = 0x3fffffff;
+          break;
+        }
+        base += 56;
+      } else if ((ge & 1ull) && base > 0) {
+        base = max(base - 56, 0);
+      } else {
+        n_total = base + __builtin_ctzll(ge);
+        break;
+      }
+    }
+  }
+  int i = 0;
+  {
+    double acc = 0.0;
+    for (i = 0; i < S; ++i) {
+      acc += s_T[i];
+      if (acc > 0.0) break;
+    }
+  }
   int n = 0;
   int n_flushed = 0;  // samples [n_flushed, n) are parked in the buffer
   auto flush = [&](int upto) {
@@ -90,11 +123,10 @@ __device__ __forceinline__ int sample_path_walk(const double* s_T, const double*
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
   };
   if (i < S) {
-    acc -= s_T[i];
-    double tin = 0.0 - acc;
+    double tin = 0.0;  // (t_start = 0: the walk enters the first segment of positive length at its start)
     double Ti = s_T[i];
     while (true) {  // trajectory.cpp:131-150, one chunk per iteration
-      if (!(acc < t_end)) break;
+      if (n >= n_total) break;
       bool past_end = false;
       while (tin > Ti) {  // carry the remainder into the next segment(s)
         tin = tin - Ti;
@@ -113,15 +145,15 @@ __device__ __forceinline__ int sample_path_walk(const double* s_T, const double*
       const double room = (Ti - tin) * inv_dt;
       const int last = __builtin_amdgcn_readfirstlane((room < 61.0) ? (int)room + 2 : 63);
       // lane j adds dt j times: in iteration r the lanes above r add.  EXEC starts as "lanes 1..63" and is shifted left by
-      // one lane per iteration, so an iteration is two additions (two independent dependent chains) and one scalar shift;
-      // as a lane compare and two selects per iteration the walk was three times as long
-      double tj = tin, aj = acc;
+      // one lane per iteration, so an iteration is one addition and one scalar shift; as a lane compare and a select per
+      // iteration the walk was three times as long
+      double tj = tin;
       {
         unsigned long long saved_exec;
         int counter;
         const double dtv = dt;
         // (iterations beyond `last` only touch lanes above `last`, which are not used: the count is rounded up to the unrolling)
-#define MRS_TG_WALK_STEP "v_add_f64 %[tj], %[tj], %[dt]\n\tv_add_f64 %[aj], %[aj], %[dt]\n\ts_lshl_b64 exec, exec, 1\n\t"
+#define MRS_TG_WALK_STEP "v_add_f64 %[tj], %[tj], %[dt]\n\ts_lshl_b64 exec, exec, 1\n\t"
         asm volatile(
             "s_mov_b64 %[save], exec\n\t"
             "s_add_u32 %[cnt], %[n], 7\n\t"
@@ -136,12 +168,12 @@ __device__ __forceinline__ int sample_path_walk(const double* s_T, const double*
             "s_cbranch_scc1 .Lwalk_loop_%=\n"
             ".Lwalk_done_%=:\n\t"
             "s_mov_b64 exec, %[save]"
-            : [tj] "+v"(tj), [aj] "+v"(aj), [save] "=&s"(saved_exec), [cnt] "=&s"(counter)
+            : [tj] "+v"(tj), [save] "=&s"(saved_exec), [cnt] "=&s"(counter)
             : [dt] "v"(dtv), [n] "s"(last)
             : "scc");
 #undef MRS_TG_WALK_STEP
       }
-      const bool ok = (lane <= last) && (aj < t_end) && !(tj > Ti) && (n + lane <= capacity);
+      const bool ok = (lane <= last) && (n + lane < n_total) && !(tj > Ti) && (n + lane <= capacity);
       const unsigned long long okmask = __ballot(ok);
       const int m = (~okmask == 0ull) ? 64 : __builtin_ctzll(~okmask);  // lanes [0, m) emit a sample
       if (out) {
@@ -157,13 +189,11 @@ __device__ __forceinline__ int sample_path_walk(const double* s_T, const double*
       n += m;
       if (m == last + 1) {  // every computed lane emitted: the chunk ran out before the walk stopped
         tin = lane_value(tj, last) + dt;
-        acc = lane_value(aj, last) + dt;
         if (n > capacity) break;
         continue;
       }
-      // lane m is the first that did not emit: its values are the walk's state at the stop
+      // lane m is the first that did not emit: its value is the walk's state at the stop
       tin = lane_value(tj, m);
-      acc = lane_value(aj, m);
       if (n > capacity) break;  // overflow: report capacity + 1
     }
   }
