@@ -218,6 +218,20 @@ def back_to_back_ms(launch_fn, reps, torch):
     return e0.elapsed_time(e1) / reps
 
 
+def measured_traffic_solve_quad(n_paths, n_seg):
+    """HBM traffic of solve_quad_kernel from the newest committed PMC summary (scripts/pmc_solve_quad.sh); not measured in this run"""
+    best = None
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "round*_pmc_solve_quad_hbm_traffic.json"))):
+        try:
+            with open(f) as fh:
+                d = json.load(fh)
+        except (OSError, ValueError):
+            continue
+        if d.get("paths") == n_paths and d.get("segments") == n_seg:
+            best = (d, os.path.relpath(f, ROOT))
+    return best
+
+
 def cores_for_checks():
     visible, quota = host_parallelism()
     return max(1, min(visible, int(quota + 0.5))) if quota else min(visible, 16)
@@ -874,6 +888,14 @@ def main():
                 note="flop model of SURVEY.md 8d (6e3 flop per segment: it counts the reference's two dense 10^3 products per segment, "
                      "which no kernel here executes), per dispatch with events on the launch; compulsory bytes = SURVEY 8d's "
                      "(40 S + 288) in + 328 S out per path")
+            tq = measured_traffic_solve_quad(n3, args.segments) if n3 >= 6144 else None
+            if tq is not None:
+                extras["roofline_solve_saturated"].update(
+                    traffic=tq[0]["hbm_bytes_per_launch"], traffic_source=tq[1] + " (separate rocprofv3 --pmc passes; from profiles/, not this run)",
+                    traffic_over_compulsory=tq[0]["hbm_bytes_per_launch"] / float(n3 * (40 * args.segments + 288 + 328 * args.segments)),
+                    traffic_note="writes 211 MB = the coefficients; reads 137 MB for 45 MB of inputs: the position row of an interior "
+                                 "vertex is 32 bytes of a 160-byte record of the caller's [vertex][5][4] value array, and whole cache "
+                                 "lines come along")
         plan3.close()
         del db3, pk3, pad3, recv3
 

@@ -15,6 +15,7 @@ scripts/pmc_sq.sh $tag > $O/${tag}_pmc_sq.log 2>&1
 python3 scripts/pmc_sq_json.py $O/${tag}_pmc_sq_linear.csv solve_rows_kernel 65536 1024 10 $O/${tag}_pmc_sq_solve_rows.json
 python3 scripts/pmc_sq_json.py $O/${tag}_pmc_sq_nonlinear.csv optimize_wave_kernel 65536 1024 10 $O/${tag}_pmc_sq_outer_loop.json
 scripts/pmc_sq_nl.sh $tag 8192 > $O/${tag}_pmc_sq_nl_8192.log 2>&1
+scripts/pmc_solve_quad.sh $tag > $O/${tag}_pmc_solve_quad.log 2>&1
 python3 scripts/measure_configs.py $tag > $O/${tag}_configs.txt 2>&1
 scripts/pipeline_stats.sh $tag > $O/${tag}_pipeline_stats.txt 2>&1
 python3 scripts/host_call_rate.py > $O/${tag}_host_call_rate.txt 2>&1
