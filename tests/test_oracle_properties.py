@@ -243,3 +243,33 @@ def test_linear_solution_equals_the_textbook_kkt_solution(n_seg, deriv, seed):
     J = po.compute_cost(deriv, t, c)
     Jref = po.compute_cost(deriv, t, ref)
     assert abs(J - Jref) <= 1e-8 * abs(Jref)
+
+
+def test_sample_count_is_a_property_of_dt_and_the_total_time_only():
+    """The premise of the HIP sampler's accumulated-time table (mrs_tg_sampling.hpp, sample_acc_table): the reference's
+    `accumulated_time += dt` runs from 0 whatever the segments are, so the number of samples of a trajectory is
+    #{k : A[k] < t_end} with A[k] = k sequential additions of dt and t_end the sequential sum of the segment times -- checked
+    against the oracle's walk (Trajectory::evaluateRange restated) on trajectories cut into segments in different ways,
+    including totals that are multiples of dt, where the count hangs on the rounding of the accumulation."""
+    rng = np.random.default_rng(5)
+    for dt in (0.2, 0.1, 0.05, 0.3):
+        acc = [0.0]
+        for _ in range(6000):
+            acc.append(acc[-1] + dt)
+        acc = np.array(acc)
+        for trial in range(40):
+            n_seg = int(rng.integers(1, 9))
+            if trial % 4 == 0:    # a total that is a multiple of dt (in exact arithmetic)
+                times = np.full(n_seg, dt * int(rng.integers(3, 40)))
+            else:
+                times = rng.uniform(0.05, 12.0, n_seg)
+            coeffs = rng.standard_normal((n_seg, 4, 10))
+            t_end = 0.0
+            for t in times:
+                t_end += float(t)
+            expect = int(np.searchsorted(acc, t_end, side="left"))   # the first k with A[k] >= t_end
+            _, n = po.sample_trajectory(coeffs, times, dt, capacity=8192)
+            # (the carry into the next segment can run off the last segment one sample early: the reference's own break)
+            assert n in (expect, expect - 1), (dt, times, n, expect)
+            if n == expect - 1:
+                assert abs(acc[expect - 1] - t_end) < 1e-9 * max(1.0, t_end)
