@@ -141,6 +141,7 @@ def self_launch(args, argv):
 # helpers (run inside a rank)
 
 LAST_OWN_ELAPSED = [0.0]
+LAST_OWN_GATHER = [0.0]
 
 
 def time_steps(step_fn, steps, warmup, dist, torch, final_fn=None, block_fn=None, gather_inside=False):
@@ -178,6 +179,7 @@ def time_steps(step_fn, steps, warmup, dist, torch, final_fn=None, block_fn=None
         final_fn()
         torch.cuda.synchronize()
         gather_s = time.perf_counter() - t1
+    LAST_OWN_GATHER[0] = gather_s   # this rank's own closing gather
     if dist is not None:
         dist.barrier()
         torch.cuda.synchronize()
@@ -310,14 +312,28 @@ def main():
     n_dev = torch.cuda.device_count()
     dev_index = local_rank if local_rank < n_dev else local_rank % max(n_dev, 1)   # gloo test: ranks share the GPU
     dist = None
+    rccl_version = None
     if world > 1 or args.force_dist:
         import torch.distributed as dist_mod
         if args.force_dist and "RANK" not in os.environ:   # stand-alone single-rank rendezvous
             os.environ.update(RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
             os.environ.setdefault("MASTER_PORT", str(_free_port()))
+        if args.dist_backend == "nccl" and world > n_dev:
+            # fail fast, with a message: RCCL cannot put two ranks on one GPU, and a rank that wrapped around onto a device
+            # another rank owns would hang in the communicator set-up instead of saying so
+            raise SystemExit("bench.py: --gpus %d under RCCL needs %d visible GPUs, torch.cuda.device_count() = %d "
+                             "(rank %d, local rank %d; --dist-backend gloo lets ranks share a GPU in a test)"
+                             % (args.gpus, world, n_dev, rank, local_rank))
         torch.cuda.set_device(dev_index)
         if args.dist_backend == "nccl":
+            try:
+                rccl_version = ".".join(str(v) for v in torch.cuda.nccl.version())
+            except Exception as ex:   # (diagnostics only)
+                rccl_version = "unknown (%s)" % type(ex).__name__
+            if rank == 0:
+                print("bench.py: RCCL %s, %d rank(s), HSA_ENABLE_IPC_MODE_LEGACY=%s" %
+                      (rccl_version, world, os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY")), file=sys.stderr, flush=True)
             dist_mod.init_process_group("nccl", device_id=torch.device("cuda", dev_index))
         else:
             dist_mod.init_process_group("gloo")
@@ -559,12 +575,87 @@ def main():
     props = torch.cuda.get_device_properties(dev)
     rank_info = dict(rank=rank, local_rank=local_rank, device_index=dev_index, device=props.name,
                      arch=getattr(props, "gcnArchName", None), ms_per_step=LAST_OWN_ELAPSED[0] / args.steps * 1e3,
+                     gather_ms=(LAST_OWN_GATHER[0] * 1e3 if dist is not None else None),
                      hsa_enable_ipc_mode_legacy=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY"))
     per_rank = [rank_info]
     if dist is not None:
         per_rank = [None] * dist.get_world_size()
         dist.all_gather_object(per_rank, rank_info)
     gather_check = verify_gather() if dist is not None else None
+
+    # ---- the same issue path over 200 steps (the driver's run is 20): kept as a top-level key so that rounds stay comparable
+    value_200 = None
+    if args.steps != 200 and args.workload == "linear" and not args.no_extras:
+        el200, _ = time_steps(steps_fn[args.workload], 200, 0, dist, torch, None, block_fn=block_for(args.workload))
+        value_200 = P * world * 200 / el200
+
+    # ---- roofline of the kernel the timed region RUNS (rank 0's device): the dispatches of the headline's own issue path,
+    # each with its own pair of events (the library times the launches of kernel family 1 on the lane's context) ----
+    roofline_headline = None
+    if args.workload == "linear" and block_for("linear") is not None:
+        group_n = max(1, min(args.group_size, n_group_slots)) if (grouped_mode[0] and n_lanes > 1 and n_group_slots > 1) else 1
+        api.kernel_trace_reset()
+        block_for("linear")(n_group_slots if group_n > 1 else n_lanes)          # one round: what kernels does a dispatch run?
+        traced = api.kernel_trace()
+        torch.cuda.synchronize()
+        head_kernel = traced[-1] if traced else "unknown"
+        for c in lane_ctx:
+            c.set_profiling(True)
+        try:
+            block_for("linear")(max(200, 10 * n_group_slots))
+            torch.cuda.synchronize()
+            hv = []
+            for c in lane_ctx:
+                hv += c.kernel_ms_history(api.KERNEL_SOLVE_LINEAR, 512)
+        finally:
+            for c in lane_ctx:
+                c.set_profiling(False)
+        hv.sort()
+        h_mean = sum(hv) / max(len(hv), 1)
+        paths_disp = P * group_n
+        comp_bytes = paths_disp * (40 * args.segments + 288 + 328 * args.segments)
+        ach = comp_bytes / (h_mean * 1e-3) / 1e9
+        # over the timed region itself: compulsory bytes of all K steps / the region's wall time (dispatches overlap on two streams)
+        ach_region = (P * args.steps * (40 * args.segments + 288 + 328 * args.segments)) / LAST_OWN_ELAPSED[0] / 1e9
+        roofline_headline = dict(
+            kernel=head_kernel, kernels_of_one_round=traced, in_timed_region=True, bound="hbm", unit="GB/s", peak=HBM_PEAK_GBS,
+            paths_per_dispatch=paths_disp, steps_per_dispatch=group_n,
+            compulsory_bytes_per_dispatch=comp_bytes,
+            bytes_model="SURVEY.md 8d: (40 S + 288) B in + 328 S B out per path = %d B at S = %d; nothing is materialised"
+                        % (40 * args.segments + 288 + 328 * args.segments, args.segments),
+            avg_dispatch_us=h_mean * 1e3, median_dispatch_us=(hv[len(hv) // 2] * 1e3 if hv else None), dispatches_timed=len(hv),
+            achieved=ach, frac=ach / HBM_PEAK_GBS,
+            achieved_over_timed_region=ach_region, frac_over_timed_region=ach_region / HBM_PEAK_GBS,
+            timing="per dispatch: a pair of events attached to each launch of the headline's own issue path (two streams, so two "
+                   "dispatches overlap as in the timed region); *_over_timed_region: all K steps' compulsory bytes / the timed "
+                   "region's wall time",
+            traffic=None, traffic_over_compulsory=None, valu_issue_frac=None)
+        for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "round*_pmc_solve_quad_group_hbm_traffic.json"))):
+            try:
+                with open(f) as fh:
+                    d = json.load(fh)
+            except (OSError, ValueError):
+                continue
+            if d.get("paths_per_dispatch") == paths_disp and d.get("segments") == args.segments and d.get("kernel") == head_kernel:
+                roofline_headline.update(traffic=d["hbm_bytes_per_dispatch"],
+                                         traffic_over_compulsory=d["hbm_bytes_per_dispatch"] / float(comp_bytes),
+                                         traffic_source=os.path.relpath(f, ROOT) + " (separate rocprofv3 --pmc passes; from "
+                                                                                   "profiles/, not this run)")
+        for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "round*_pmc_sq_solve_quad_group.json"))):
+            try:
+                with open(f) as fh:
+                    d = json.load(fh)
+            except (OSError, ValueError):
+                continue
+            if d.get("paths") == paths_disp and d.get("segments") == args.segments and head_kernel in d.get("kernel", ""):
+                c = d["counters"]
+                issue_peak_h = 256 * 4 * 2.4e9 / 4.0
+                roofline_headline.update(
+                    valu_issue_frac=c["SQ_INSTS_VALU"] / (h_mean * 1e-3) / issue_peak_h,
+                    valu_instructions_per_dispatch=c["SQ_INSTS_VALU"], lds_instructions_per_dispatch=c.get("SQ_INSTS_LDS"),
+                    wait_share_of_wave_cycles=(c["SQ_WAIT_ANY"] / c["SQ_WAVE_CYCLES"] if c.get("SQ_WAVE_CYCLES") else None),
+                    valu_active_share_of_wave_cycles=(c["SQ_ACTIVE_INST_VALU"] / c["SQ_WAVE_CYCLES"] if c.get("SQ_WAVE_CYCLES") else None),
+                    counters_source=d["source"] + " (separate rocprofv3 --pmc passes; from profiles/, not this run)")
 
     # ---- roofline of the assembly kernel (rank 0's device) ----
     Hbuf = torch.empty(plan.block_doubles, dtype=torch.float64, device=dev)
@@ -585,7 +676,11 @@ def main():
     if tm is not None:
         traffic = tm[0]["hbm_bytes_per_launch"]
         traffic_source = "%s (separate rocprofv3 --pmc passes; from profiles/, not this run)" % tm[1]
-    roofline = dict(kernel="assemble_blocks_uniform_kernel", bound="hbm", achieved=achieved, peak=HBM_PEAK_GBS, unit="GB/s",
+    roofline = dict(kernel="assemble_blocks_uniform_kernel", in_timed_region=False,
+                    scope="SURVEY.md 8d's contract kernel (the HBM-bound Hessian / mapping-block assembly behind mrs_tg_plan_assemble and "
+                          "MRS_TG_FLAG_MATERIALIZED_BLOCKS), measured on its own AFTER the timed region: the headline's default solve "
+                          "forms the blocks in registers and never launches it -- the kernel the timed steps run is roofline_headline",
+                    bound="hbm", achieved=achieved, peak=HBM_PEAK_GBS, unit="GB/s",
                     frac=achieved / HBM_PEAK_GBS, traffic=traffic, traffic_source=traffic_source, bytes_per_launch=alg_bytes,
                     avg_launch_us=asm_mean * 1e3, median_launch_us=asm_med * 1e3, min_launch_us=asm_min * 1e3,
                     timing="per dispatch: a pair of events attached to each of 300 queued launches (what rocprofv3 --kernel-trace "
@@ -829,12 +924,14 @@ def main():
         torch.cuda.synchronize()
         t3 = db3.seg_times.clone()
         nS3 = batch3.n_segments
-        pk3 = torch.zeros(nS3 * 41 + n3, dtype=torch.float64, device=dev)
-        c3, tt3 = pk3[:nS3 * 40].view(nS3, 4, 10), pk3[nS3 * 40:nS3 * 41]
+        pk3 = torch.zeros(shard.packed_doubles(n3, nS3), dtype=torch.float64, device=dev)
+        c3, tt3, st3_f64 = shard.packed_views(pk3, n3, nS3)
         st3 = torch.zeros(n3, dtype=torch.int32, device=dev)
-        # equal shards gather in one collective; the (rare) uneven cut pads to the largest shard
-        cap3 = (total3 + world - 1) // world
-        pad3 = torch.zeros(cap3 * args.segments * 41 + cap3, dtype=torch.float64, device=dev) if dist is not None else None
+        # equal shards gather in one collective; an uneven cut pads to the largest shard (shard.gather_packed_shards, the code
+        # tests/test_dist_gloo.py runs on four gloo ranks with 65535 paths)
+        cap3 = shard.shard_capacity(total3, world)
+        pad3 = (torch.zeros(shard.packed_doubles(cap3, cap3 * args.segments), dtype=torch.float64, device=dev)
+                if dist is not None else None)
         recv3 = ([torch.empty_like(pad3) for _ in range(world)] if (dist is not None and rank == 0 and not gloo) else None)
         call3 = plan3.bind_solve(opt_nl[0], db3.fixed_mask, db3.fixed_values, tt3, c3, st3, db3.cost, waypoints=db3.waypoints,
                                  limits=db3.limits, n_samples=db3.n_samples, samples=db3.samples)
@@ -845,9 +942,8 @@ def main():
         def gather3():
             if dist is None:
                 return
-            pk3[nS3 * 41:].copy_(st3)
-            pad3[:pk3.numel()].copy_(pk3)
-            gather(pad3, recv3)
+            st3_f64.copy_(st3)
+            shard.gather_packed_shards(pk3, pad3, dist, bufs=recv3, via_host=gloo)
 
         k3 = max(3, min(10, args.steps // 20))
         el4, _ = time_steps(step3, k3, 2, dist, torch, gather3, gather_inside=True)
@@ -1046,16 +1142,24 @@ def main():
                     config3_strong_scaling=({k: extras["config3"][k] for k in ("value", "unit", "scaling", "n_gpus", "ms_per_step",
                                                                               "paths_per_rank")}
                                             if "config3" in extras else None),
+                    one_batch_in_flight=(extras["one_batch_in_flight"]["value"] if "one_batch_in_flight" in extras else None),
+                    value_200_steps=(value if args.steps == 200 else value_200),
                     higher_is_better=True, scaling="weak", vs_baseline=None, dtype="f64", data="synthetic",
                     config=dict(workload=lin_desc if args.workload == "linear" else nl_desc,
                                 paths_per_gpu=P, segments=args.segments,
                                 batches_in_flight=(n_group_slots if (grouped_mode[0] and args.workload == "linear" and n_lanes > 1) else n_lanes),
                                 hip_streams=n_lanes,
+                                issue_policy=dict(batches_in_flight=args.in_flight, steps_per_dispatch=args.group_size, issue=args.issue,
+                                                  frozen="since round 4: 20 batches in flight, 10 steps per dispatch, two streams; "
+                                                         "rounds 1-3 used 4 / 4 / 16 in flight (HISTORY.md) -- compare rounds on "
+                                                         "one_batch_in_flight (one batch, one dispatch per step: the strict reading "
+                                                         "of configs[1]) and value_200_steps, both top-level keys"),
                                 linear_solve="default of mrs_tg_plan_solve, blocks formed in registers (nothing materialised): "
                                              "solve_rows_kernel for a launch of one batch, solve_quad_group_kernel for a "
-                                             "dispatch that carries >= 6144 paths (the grouped steps of the headline: 8 x 1024), "
+                                             "dispatch that carries >= 6144 paths (the grouped steps of the headline: %d x %d), "
                                              "solve_rows_group_kernel for a smaller group; the assembly kernel is timed on its "
-                                             "own (roofline) and inside extras.materialized_blocks_step",
+                                             "own (roofline) and inside extras.materialized_blocks_step"
+                                             % (max(1, min(args.group_size, n_group_slots)), P),
                                 clock_ramp_steps=ramp_steps, clock_ramp_ms=30,
                                 slot_inputs=("every batch in flight has its own masks, constrained values and segment times (path seeds "
                                              "(rank * slots + slot) * paths + p) and its own outputs" if len(slot_db) > 1 else
@@ -1079,7 +1183,9 @@ def main():
                                                 "steps; value_including_gather has it inside"))
                                 if world > 1 else "single GPU"),
                     max_coeff_err_vs_cpu_ref=err, max_coeff_err_vs_113bit_ref=err_exact,
-                    in_flight_slots_vs_cpu_ref=(slots_checked if (rank == 0 and world == 1 and not args.no_cpu_baseline) else None), roofline=roofline, roofline_solve=roofline_solve,
+                    in_flight_slots_vs_cpu_ref=(slots_checked if (rank == 0 and world == 1 and not args.no_cpu_baseline) else None),
+                    rccl_version=rccl_version,
+                    roofline=roofline, roofline_headline=roofline_headline, roofline_solve=roofline_solve,
                     roofline_outer_loop=roofline_outer, cpu_baseline=cpu, extras=extras)
         import ctypes
         ctypes.CDLL(None).fflush(None)   # RCCL's banner sits in C stdio: keep the JSON line the last thing printed

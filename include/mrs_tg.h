@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define MRS_TG_ABI_VERSION 3
+#define MRS_TG_ABI_VERSION 4
 #define MRS_TG_N_COEFF 10
 #define MRS_TG_N_DIM 4
 #define MRS_TG_N_SLOT 5 /* derivative slots per vertex: position .. snap */
@@ -115,10 +115,16 @@ enum {
                                          0.5 c^T Q c from the coefficients (computeCost, linear_impl.h:128-141), in every
                                          evaluation.  One more kernel per call, about the duration of the outer loop
                                          itself; without the flag such a trial point is rejected where the reference may
-                                         accept it.  A COMPILE-TIME OPTION since round 4
-                                         (-DMRS_TG_WITH_CAREFUL=1; it moved 65536 x 10 from 99.9435 % to 99.9481 % agreement
-                                         with the oracle): a library built without it refuses the flag with
-                                         MRS_TG_ERR_UNSUPPORTED */
+                                         accept it.  The re-run kernel is a compile-time option
+                                         (MRS_TG_WITH_CAREFUL, ON in the shipped library since ABI 4; it moves 65536 x 10
+                                         from 99.9435 % to 99.9481 % agreement with the oracle): a library built without it
+                                         (-DMRS_TG_WITH_CAREFUL=0) refuses the flag with MRS_TG_ERR_UNSUPPORTED, and
+                                         mrs_tg_capabilities() says which one is loaded */
+};
+
+/* mrs_tg_capabilities(): what this build of the library contains beyond the mandatory surface */
+enum {
+  MRS_TG_CAP_CAREFUL_COST = 1 /* MRS_TG_FLAG_CAREFUL_COST is honoured (optimize_careful_kernel is built in) */
 };
 
 typedef struct mrs_tg_options {
@@ -158,6 +164,7 @@ int mrs_tg_create(int device_ordinal, mrs_tg_ctx** ctx_out);
 void mrs_tg_destroy(mrs_tg_ctx* ctx);
 const char* mrs_tg_last_error(const mrs_tg_ctx* ctx); /* ctx may be NULL: last global error */
 int mrs_tg_abi_version(void);
+int mrs_tg_capabilities(void); /* MRS_TG_CAP_* bits (ABI 4) */
 void mrs_tg_default_options(mrs_tg_options* opt);
 
 /* Launch on a caller-owned hipStream_t (e.g. torch.cuda.current_stream().cuda_stream) instead of
@@ -332,6 +339,13 @@ int mrs_tg_last_kernel_ms(mrs_tg_ctx* ctx, int kernel_id, float* ms_out);
  * back to back, every one carries its own pair of events).  Returns the number written (<= capacity) or a negative
  * MRS_TG_ERR_*.  Blocks until those launches have finished. */
 int mrs_tg_kernel_ms_history(mrs_tg_ctx* ctx, int kernel_id, float* ms_out, int capacity);
+
+/* Diagnostics (ABI 4): the names of the kernels the CALLING THREAD has launched through this library since its last
+ * mrs_tg_kernel_trace_reset(), oldest first; at most the newest 32 are kept.  names_out receives pointers to static
+ * strings ("solve_quad_group_kernel", ...).  Returns the number written.  A test or a benchmark can state which kernels a
+ * call ran instead of inferring them from the batch size. */
+void mrs_tg_kernel_trace_reset(void);
+int mrs_tg_kernel_trace(const char** names_out, int capacity);
 
 /* ---- single-path convenience mirroring findTrajectory()'s signature ------------------------- */
 

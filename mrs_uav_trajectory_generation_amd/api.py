@@ -73,7 +73,8 @@ class InitialState(C.Structure):
 
 
 EXPORTED_SYMBOLS = [
-    "mrs_tg_create", "mrs_tg_destroy", "mrs_tg_last_error", "mrs_tg_abi_version", "mrs_tg_default_options",
+    "mrs_tg_create", "mrs_tg_destroy", "mrs_tg_last_error", "mrs_tg_abi_version", "mrs_tg_capabilities", "mrs_tg_default_options",
+    "mrs_tg_kernel_trace_reset", "mrs_tg_kernel_trace",
     "mrs_tg_set_stream", "mrs_tg_reset_stream", "mrs_tg_synchronize", "mrs_tg_solve_batch", "mrs_tg_plan_create", "mrs_tg_plan_destroy",
     "mrs_tg_plan_n_paths", "mrs_tg_plan_n_segments", "mrs_tg_plan_max_segments", "mrs_tg_plan_get_order",
     "mrs_tg_plan_assemble", "mrs_tg_plan_block_bytes", "mrs_tg_plan_solve", "mrs_tg_plan_bind_solve",
@@ -115,6 +116,10 @@ def load_library():
     L.mrs_tg_last_error.restype = C.c_char_p
     L.mrs_tg_last_error.argtypes = [vp]
     L.mrs_tg_abi_version.restype = C.c_int
+    L.mrs_tg_capabilities.restype = C.c_int
+    L.mrs_tg_kernel_trace_reset.restype = None
+    L.mrs_tg_kernel_trace.restype = C.c_int
+    L.mrs_tg_kernel_trace.argtypes = [C.POINTER(C.c_char_p), C.c_int]
     L.mrs_tg_default_options.restype = None
     L.mrs_tg_default_options.argtypes = [C.POINTER(Options)]
     L.mrs_tg_host_alloc.restype = C.c_int
@@ -200,6 +205,24 @@ def load_library():
     L.mrs_tg_multi_last_error.argtypes = [vp]
     _lib = L
     return L
+
+
+CAP_CAREFUL_COST = 1   # MRS_TG_CAP_CAREFUL_COST
+
+
+def capabilities():
+    return load_library().mrs_tg_capabilities()
+
+
+def kernel_trace_reset():
+    load_library().mrs_tg_kernel_trace_reset()
+
+
+def kernel_trace():
+    """Names of the kernels this thread has launched through the library since kernel_trace_reset() (newest 32, oldest first)."""
+    buf = (C.c_char_p * 32)()
+    n = load_library().mrs_tg_kernel_trace(buf, 32)
+    return [buf[i].decode() for i in range(n)]
 
 
 def default_policy_options(solver=None, **overrides):

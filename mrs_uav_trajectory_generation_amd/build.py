@@ -18,6 +18,9 @@ SOURCES = ["mrs_tg_kernels.hip", "mrs_tg_tile.hip", "mrs_tg_rows.hip", "mrs_tg_q
 # every header under csrc/ (a header that is split or added is picked up without editing this file) + the public ABI
 HEADERS = sorted(f for f in os.listdir(CSRC) if f.endswith((".h", ".hpp"))) + [os.path.join("..", "..", "include", "mrs_tg.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
+# the careful re-run of MRS_TG_FLAG_CAREFUL_COST (optimize_careful_kernel) is built in unless MRS_TG_WITH_CAREFUL=0 is set in the
+# environment of the build (mrs_tg_capabilities() reports which library is loaded)
+FLAGS.append("-DMRS_TG_WITH_CAREFUL=%d" % (0 if os.environ.get("MRS_TG_WITH_CAREFUL", "1") == "0" else 1))
 
 
 def _hipcc():

@@ -221,6 +221,15 @@ extern "C" {
 
 int mrs_tg_abi_version(void) { return MRS_TG_ABI_VERSION; }
 
+int mrs_tg_capabilities(void) { return mrs_tg::careful_rerun_built() ? MRS_TG_CAP_CAREFUL_COST : 0; }
+
+void mrs_tg_kernel_trace_reset(void) { mrs_tg::kernel_trace_reset(); }
+
+int mrs_tg_kernel_trace(const char** names_out, int capacity) {
+  if (!names_out || capacity <= 0) return 0;
+  return mrs_tg::kernel_trace(names_out, capacity);
+}
+
 void mrs_tg_default_options(mrs_tg_options* opt) {
   if (!opt) return;
   std::memset(opt, 0, sizeof(*opt));
@@ -298,7 +307,10 @@ void mrs_tg_destroy(mrs_tg_ctx* ctx) {
   if (ctx->h_arena) (void)hipHostFree(ctx->h_arena);
   if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
   delete ctx;
-  if (--g_live_contexts == 0) mrs_tg::pool_release_cached();  // the cached device blocks go with the last context
+  if (--g_live_contexts == 0) {  // the sampling tables and the cached device blocks go with the last context
+    mrs_tg::sample_tables_release();
+    mrs_tg::pool_release_cached();
+  }
 }
 
 int mrs_tg_set_stream(mrs_tg_ctx* ctx, void* hip_stream) {
@@ -553,6 +565,8 @@ int mrs_tg_plan_solve(mrs_tg_plan* plan, const double* wp, const uint8_t* mask, 
   return MRS_TG_OK;
 }
 
+static constexpr size_t kGroupWsPresizeBytes = (size_t)256 << 20;  // bind-time reservation of a grouped launch's factor stores
+
 struct mrs_tg_bound_solve {
   mrs_tg_plan* plan;
   const double* wp;
@@ -579,11 +593,15 @@ int mrs_tg_plan_bind_solve(mrs_tg_plan* plan, const double* wp, const uint8_t* m
                                                                 n_samples, samples};
   if (!b) return fail(plan->ctx, MRS_TG_ERR_NOMEM, "out of host memory");
   // A fixed-times default solve can go out in grouped launches (mrs_tg_bound_solve_launch_group), whose saturated-device kernel
-  // wants one factor store per batch of the group for paths that need the general step: allocated HERE, once per plan, so that
-  // the first large group does not pay an allocation and a stream synchronisation inside somebody's timed region
+  // wants one factor store per batch of the group for paths that need the general step.  SMALL plans reserve it HERE, once,
+  // so that the first large group does not pay an allocation and a stream synchronisation inside somebody's timed region;
+  // a plan whose full group would hold more than kGroupWsPresizeBytes (1024 x 10: 157 MB for 16 batches; 8192 x 10 would
+  // be 1.26 GB, 65536 x 10 ten) reserves nothing at bind time -- most bound solves are never launched in a group -- and
+  // mrs_tg_bound_solve_launch_group sizes the store for the group it actually launches.
   if (opt->time_alloc_method == MRS_TG_TIME_ALLOC_NONE && !opt->estimate_times && opt->sampling_dt <= 0 &&
       !(opt->flags & (MRS_TG_FLAG_MATERIALIZED_BLOCKS | MRS_TG_FLAG_GENERAL_PATTERNS)) &&
-      mrs_tg::quad_kernel_applies(plan->view, (long long)plan->view.n_paths * mrs_tg::kRowsGroupMax, false)) {
+      mrs_tg::quad_kernel_applies(plan->view, (long long)plan->view.n_paths * mrs_tg::kRowsGroupMax, false) &&
+      (size_t)mrs_tg::kRowsGroupMax * mrs_tg::linear_workspace_doubles(plan->view) * sizeof(double) <= kGroupWsPresizeBytes) {
     const int rcw = ensure_ws(plan, (size_t)mrs_tg::kRowsGroupMax * mrs_tg::linear_workspace_doubles(plan->view));
     if (rcw != MRS_TG_OK) {
       delete b;
@@ -793,7 +811,8 @@ int mrs_tg_bound_solve_launch_group(mrs_tg_bound_solve* const* bound, int32_t n_
     ProfileScope ps(ctx, 1);
     if (mrs_tg::quad_kernel_applies(plan->view, (long long)plan->view.n_paths * g.n, false)) {
       // the dispatch carries more paths than the rows kernel has wavefront slots for: four lanes per path, factors in LDS
-      int rc = ensure_ws(plan, (size_t)mrs_tg::kRowsGroupMax * mrs_tg::linear_workspace_doubles(plan->view));
+      // (one factor store per batch of THIS group; grows when a larger group comes, never shrinks)
+      int rc = ensure_ws(plan, (size_t)g.n * mrs_tg::linear_workspace_doubles(plan->view));
       if (rc != MRS_TG_OK) return rc;
       HIP_TRY(ctx, mrs_tg::launch_solve_quad_group(plan->view, first->opt.derivative_to_optimize, g, plan->d_ws, ctx->stream));
     } else {

@@ -497,7 +497,7 @@ hipError_t launch_dfo(NonlinearPlan& nl, const BatchView& b, const DfoParams& pr
     if (!nl.d_dfo_segcost && (e = mrs_tg::pool_alloc(&nl.d_dfo_segcost, sizeof(double) * nS * kD)) != hipSuccess) return e;
     if (!nl.d_dfo_seg_path) {
       if ((e = mrs_tg::pool_alloc(&nl.d_dfo_seg_path, sizeof(int32_t) * nS)) != hipSuccess) return e;
-      hipLaunchKernelGGL(dfo_segment_path_kernel, dim3(cdiv_u(b.n_paths, 64)), dim3(64), 0, stream, b, nl.d_dfo_seg_path);
+      MRS_TG_LAUNCH(dfo_segment_path_kernel, dim3(cdiv_u(b.n_paths, 64)), dim3(64), 0, stream, b, nl.d_dfo_seg_path);
       if ((e = hipGetLastError()) != hipSuccess) return e;
     }
   }
@@ -513,14 +513,14 @@ hipError_t launch_dfo(NonlinearPlan& nl, const BatchView& b, const DfoParams& pr
   if (general && (e = launch_solve_general(b, prm.derivative, mask, vals, seg_times, nl.d_general_solve_ws, coeffs, status, cost,
                                            stream, general_flag, nullptr)) != hipSuccess)
     return e;
-  hipExtLaunchKernelGGL(dfo_init_kernel, dim3(pblocks), dim3(64), 0, stream, kt.start, nullptr, 0, b, prm, mask, limits, seg_times,
+  MRS_TG_LAUNCH_EXT(dfo_init_kernel, dim3(pblocks), dim3(64), 0, stream, kt.start, nullptr, 0, b, prm, mask, limits, seg_times,
                         coeffs, nl.d_dfo_vec, nl.d_dfo_f, nl.d_dfo_state, nl.d_dfo_fidx, nl.d_dfo_deadline);
   if ((e = hipGetLastError()) != hipSuccess) return e;
   // NLopt's maxeval <= 0 means "no limit"; the host loop needs one
   const int rounds = prm.max_iterations > 0 ? prm.max_iterations : 1000;
   for (int r = 0; r < rounds; ++r) {
     if (with_free) {
-      hipLaunchKernelGGL(dfo_free_eval_kernel, dim3(sblocks, kD), dim3(64), 0, stream, b, prm.derivative, mask, vals,
+      MRS_TG_LAUNCH(dfo_free_eval_kernel, dim3(sblocks, kD), dim3(64), 0, stream, b, prm.derivative, mask, vals,
                          nl.d_dfo_fidx, nl.d_dfo_state, nl.d_dfo_vec, nl.d_dfo_seg_path, seg_times, coeffs,
                          nl.d_dfo_segcost);
       if ((e = hipGetLastError()) != hipSuccess) return e;
@@ -532,20 +532,20 @@ hipError_t launch_dfo(NonlinearPlan& nl, const BatchView& b, const DfoParams& pr
                                                cost, stream, general_flag, nullptr)) != hipSuccess)
         return e;
     }
-    hipLaunchKernelGGL(segment_maxima4_kernel, dim3(sblocks, 3), dim3(64), 0, stream, b.n_segments, coeffs, seg_times,
+    MRS_TG_LAUNCH(segment_maxima4_kernel, dim3(sblocks, 3), dim3(64), 0, stream, b.n_segments, coeffs, seg_times,
                        nl.d_maxima);
     if ((e = hipGetLastError()) != hipSuccess) return e;
-    hipLaunchKernelGGL(dfo_step_kernel, dim3(pblocks), dim3(64), 0, stream, b, prm, limits, cost, nl.d_dfo_segcost,
+    MRS_TG_LAUNCH(dfo_step_kernel, dim3(pblocks), dim3(64), 0, stream, b, prm, limits, cost, nl.d_dfo_segcost,
                        nl.d_maxima, seg_times, nl.d_dfo_vec, nl.d_dfo_f, nl.d_dfo_state, nl.d_dfo_deadline);
     if ((e = hipGetLastError()) != hipSuccess) return e;
   }
   // paths that stopped early were re-evaluated at their final point every round; paths that used the whole budget
   // hold the trajectory of their last trial: both are "the last evaluated point"
   if (with_free) {  // J_d of the last evaluated point for the caller
-    hipLaunchKernelGGL(dfo_sum_cost_kernel, dim3(pblocks), dim3(64), 0, stream, b, nl.d_dfo_segcost, cost);
+    MRS_TG_LAUNCH(dfo_sum_cost_kernel, dim3(pblocks), dim3(64), 0, stream, b, nl.d_dfo_segcost, cost);
     if ((e = hipGetLastError()) != hipSuccess) return e;
   }
-  hipExtLaunchKernelGGL(dfo_finalize_kernel, dim3(pblocks), dim3(64), 0, stream, nullptr, kt.stop, 0, b.n_paths, nl.d_dfo_state,
+  MRS_TG_LAUNCH_EXT(dfo_finalize_kernel, dim3(pblocks), dim3(64), 0, stream, nullptr, kt.stop, 0, b.n_paths, nl.d_dfo_state,
                         status);
   return hipGetLastError();
 }

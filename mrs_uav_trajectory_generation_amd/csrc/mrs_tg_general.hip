@@ -54,7 +54,7 @@ hipError_t launch_solve_general(const BatchView& b, int d, const uint8_t* mask, 
   if (b.n_paths == 0) return hipSuccess;
   if (!only && !status) return hipErrorInvalidValue;
   const unsigned grid = (unsigned)(((size_t)b.n_paths * 4 + 63) / 64);
-  hipLaunchKernelGGL(solve_general_kernel, dim3(grid), dim3(64), 0, stream, b, d, mask, vals, seg_times, ws, coeffs, status,
+  MRS_TG_LAUNCH(solve_general_kernel, dim3(grid), dim3(64), 0, stream, b, d, mask, vals, seg_times, ws, coeffs, status,
                      cost, only, opt_status);
   return hipGetLastError();
 }

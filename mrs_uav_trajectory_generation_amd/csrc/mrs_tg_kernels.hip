@@ -24,6 +24,7 @@
 #include "mrs_tg_sampling.hpp"
 #include "mrs_tg_solve.hpp"
 #include "mrs_tg_launch.h"
+#include "mrs_tg_pool.h"
 
 namespace mrs_tg {
 
@@ -314,7 +315,7 @@ __global__ __launch_bounds__(256) void copy_samples_kernel(const double* __restr
 hipError_t launch_copy_samples(const double* src, double* dst, const int32_t* n_samples, int n_paths, int capacity,
                                hipStream_t stream) {
   if (n_paths <= 0 || capacity <= 0) return hipSuccess;
-  hipLaunchKernelGGL(copy_samples_kernel, dim3((unsigned)(n_paths < 2048 ? n_paths : 2048)), dim3(256), 0, stream, src, dst,
+  MRS_TG_LAUNCH(copy_samples_kernel, dim3((unsigned)(n_paths < 2048 ? n_paths : 2048)), dim3(256), 0, stream, src, dst,
                      n_samples, n_paths, capacity);
   return hipGetLastError();
 }
@@ -326,28 +327,92 @@ hipError_t launch_copy_many(const CopyList& cl, hipStream_t stream) {
   // one 16-byte word per thread up to 512 workgroups, grid-stride beyond
   unsigned blocks = (unsigned)((most / 16 + 255) / 256);
   blocks = blocks < 1 ? 1 : (blocks > 512 ? 512 : blocks);
-  hipLaunchKernelGGL(copy_many_kernel, dim3(blocks, (unsigned)cl.n), dim3(256), 0, stream, cl);
+  MRS_TG_LAUNCH(copy_many_kernel, dim3(blocks, (unsigned)cl.n), dim3(256), 0, stream, cl);
   return hipGetLastError();
 }
 
 hipError_t launch_estimate_times(const BatchView& b, const double* wp, const double* limits, double* seg_times,
                                  hipStream_t stream) {
   if (b.n_segments == 0) return hipSuccess;
-  hipLaunchKernelGGL(estimate_times_kernel, dim3(cdiv(b.n_segments, 256)), dim3(256), 0, stream, b, wp, limits,
+  MRS_TG_LAUNCH(estimate_times_kernel, dim3(cdiv(b.n_segments, 256)), dim3(256), 0, stream, b, wp, limits,
                      seg_times);
   return hipGetLastError();
 }
 
-// The accumulated time of the reference's sampling walk, A[k] = k additions of dt to 0 (mrs_tg_sampling.hpp): computed on the
-// host with the additions the device would make (IEEE double, round to nearest), once per (device, dt), kept for the
-// process; grows when a caller asks for a larger capacity.  Returns the device array and its length (>= capacity + 80).
-hipError_t sample_acc_table(double dt, int capacity, const double** table_out, int* n_out) {
-  struct Entry {
-    double* d = nullptr;
-    int n = 0;
-  };
-  static std::mutex mu;
-  static std::map<std::pair<int, unsigned long long>, Entry> cache;
+// The accumulated time of the reference's sampling walk, A[k] = k additions of dt to 0 (mrs_tg_sampling.hpp).  One lane makes
+// the additions the reference makes, in its order (IEEE double, round to nearest: v_add_f64) -- a dependent chain of n
+// additions, ~20 us for 4096 entries, once per (device, dt).
+__global__ void sample_acc_table_kernel(double* __restrict__ table, int n, double dt) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  double acc = 0.0;
+  for (int k = 0; k < n; ++k) {
+    table[k] = acc;
+    acc += dt;
+  }
+}
+
+// Cache of those tables, per (device, bit pattern of dt).  Everything a call does here is ordered on ITS stream and legal
+// under stream capture once the table exists (the first version ran hipMalloc + a synchronous hipMemcpy inside
+// the launch path, never evicted, and leaked outgrown tables):
+//   * a table is built by a kernel on the calling stream, from a block of the library's pool; an event recorded behind the
+//     build is what a launch on ANOTHER stream waits for (hipStreamWaitEvent) until the build has been seen complete once;
+//   * at most kAccCacheMax tables are kept; the least recently used one is retired when a new dt arrives, and a table that
+//     is outgrown (a larger capacity) is retired too.  A retired table may still be read by a launch in flight on some
+//     stream, so it is parked; when kAccRetiredMax tables are parked the device is synchronised ONCE and all of them go back
+//     to the pool -- a host that derives a new dt per request pays one device synchronisation per 64 requests and holds at
+//     most 96 small tables;
+//   * sample_tables_release() (the last context of the process is destroyed) frees everything.
+namespace {
+struct AccEntry {
+  double* d = nullptr;
+  int n = 0;
+  hipEvent_t ready = nullptr;  // recorded behind the build
+  hipStream_t built_on = nullptr;
+  bool ready_seen = false;
+  unsigned long long stamp = 0;
+};
+struct AccRetired {
+  int device;
+  double* d;
+};
+constexpr size_t kAccCacheMax = 32, kAccRetiredMax = 64;
+std::mutex g_acc_mu;
+std::map<std::pair<int, unsigned long long>, AccEntry> g_acc_cache;
+std::vector<AccRetired> g_acc_retired;
+unsigned long long g_acc_clock = 0;
+
+void acc_retire(int device, AccEntry& en) {
+  if (en.ready) (void)hipEventDestroy(en.ready);
+  if (en.d) g_acc_retired.push_back(AccRetired{device, en.d});
+  en = AccEntry{};
+}
+
+void acc_drain_retired() {  // (g_acc_mu held) no launch that reads a parked table is in flight after the synchronisations
+  if (g_acc_retired.empty()) return;
+  int cur = 0;
+  (void)hipGetDevice(&cur);
+  int last = -1;
+  for (const AccRetired& r : g_acc_retired) {
+    if (r.device != last) {
+      (void)hipSetDevice(r.device);
+      (void)hipDeviceSynchronize();
+      last = r.device;
+    }
+    pool_free(r.d);
+  }
+  g_acc_retired.clear();
+  (void)hipSetDevice(cur);
+}
+}  // namespace
+
+void sample_tables_release() {
+  std::lock_guard<std::mutex> lock(g_acc_mu);
+  for (auto& kv : g_acc_cache) acc_retire(kv.first.first, kv.second);
+  g_acc_cache.clear();
+  acc_drain_retired();
+}
+
+hipError_t sample_acc_table(double dt, int capacity, hipStream_t stream, const double** table_out, int* n_out) {
   int dev = 0;
   hipError_t e = hipGetDevice(&dev);
   if (e != hipSuccess) return e;
@@ -355,25 +420,49 @@ hipError_t sample_acc_table(double dt, int capacity, const double** table_out, i
   static_assert(sizeof(bits) == sizeof(dt), "dt as a key");
   std::memcpy(&bits, &dt, sizeof(bits));
   const int need = (capacity > 0 ? capacity : 0) + 80;
-  std::lock_guard<std::mutex> lock(mu);
-  Entry& en = cache[std::make_pair(dev, bits)];
-  if (en.n < need) {
-    const int n = std::max(need, 1024 + 80);
-    std::vector<double> host((size_t)n);
-    double acc = 0.0;
-    for (int k = 0; k < n; ++k) {
-      host[(size_t)k] = acc;
-      acc += dt;
+  std::lock_guard<std::mutex> lock(g_acc_mu);
+  const auto key = std::make_pair(dev, bits);
+  auto it = g_acc_cache.find(key);
+  if (it == g_acc_cache.end() || it->second.n < need) {
+    if (it == g_acc_cache.end()) {
+      if (g_acc_cache.size() >= kAccCacheMax) {  // retire the least recently used table
+        auto lru = g_acc_cache.begin();
+        for (auto j = g_acc_cache.begin(); j != g_acc_cache.end(); ++j)
+          if (j->second.stamp < lru->second.stamp) lru = j;
+        acc_retire(lru->first.first, lru->second);
+        g_acc_cache.erase(lru);
+      }
+      it = g_acc_cache.emplace(key, AccEntry{}).first;
+    } else {
+      acc_retire(dev, it->second);  // outgrown
     }
-    double* d = nullptr;
-    if ((e = hipMalloc(&d, sizeof(double) * (size_t)n)) != hipSuccess) return e;
-    if ((e = hipMemcpy(d, host.data(), sizeof(double) * (size_t)n, hipMemcpyHostToDevice)) != hipSuccess) {
-      (void)hipFree(d);
+    if (g_acc_retired.size() >= kAccRetiredMax) acc_drain_retired();
+    AccEntry& en = it->second;
+    int n = 1024 + 80;
+    while (n < need) n *= 2;  // (growth by doubling: a caller that raises its capacity step by step rebuilds log2 times)
+    if ((e = pool_alloc(&en.d, sizeof(double) * (size_t)n)) != hipSuccess) {
+      g_acc_cache.erase(it);
       return e;
     }
-    // (the old, shorter table may still be read by a launch in flight: it is left alone -- a few KB per (device, dt, growth))
-    en.d = d;
     en.n = n;
+    MRS_TG_LAUNCH(sample_acc_table_kernel, dim3(1), dim3(64), 0, stream, en.d, n, dt);
+    if ((e = hipGetLastError()) == hipSuccess) e = hipEventCreateWithFlags(&en.ready, hipEventDisableTiming);
+    if (e == hipSuccess) e = hipEventRecord(en.ready, stream);
+    if (e != hipSuccess) {
+      acc_retire(dev, en);
+      g_acc_cache.erase(it);
+      return e;
+    }
+    en.built_on = stream;
+  }
+  AccEntry& en = it->second;
+  en.stamp = ++g_acc_clock;
+  if (!en.ready_seen) {
+    if (hipEventQuery(en.ready) == hipSuccess) {
+      en.ready_seen = true;
+    } else if (stream != en.built_on) {  // (the building stream itself is ordered behind the build)
+      if ((e = hipStreamWaitEvent(stream, en.ready, 0)) != hipSuccess) return e;
+    }
   }
   *table_out = en.d;
   *n_out = en.n;
@@ -391,9 +480,9 @@ static hipError_t launch_sample_n(const BatchView& b, const double* coeffs, cons
   }
   const double* acc_table = nullptr;
   int acc_n = 0;
-  hipError_t et = sample_acc_table(dt, capacity, &acc_table, &acc_n);
+  hipError_t et = sample_acc_table(dt, capacity, stream, &acc_table, &acc_n);
   if (et != hipSuccess) return et;
-  hipLaunchKernelGGL(sample_kernel<NDER>, dim3(b.n_paths), dim3(64), lds, stream, b, coeffs, seg_times, dt, capacity,
+  MRS_TG_LAUNCH(sample_kernel<NDER>, dim3(b.n_paths), dim3(64), lds, stream, b, coeffs, seg_times, dt, capacity,
                      n_samples, samples, acc_table, acc_n);
   return hipGetLastError();
 }

@@ -23,11 +23,28 @@ void set_shared_device_hint(bool on);
 bool shared_device_hint();
 KernelTimer take_kernel_timer();  // the pending pair (null events when nothing is pending); consumed by the call
 void set_kernel_timer(hipEvent_t start, hipEvent_t stop);  // arms the next timed launch of this thread
+// Kernel trace (mrs_tg_kernel_trace): every launch of the library notes its kernel's name in a small per-thread ring, so
+// that a test or the benchmark can SAY which kernels a call ran instead of inferring it from batch sizes (one pointer store)
+void note_kernel(const char* name);
+void kernel_trace_reset();
+int kernel_trace(const char** names_out, int capacity);  // oldest first; at most the newest 32 since the reset
 // launch with the pending timer, if any
 #define MRS_TG_LAUNCH_TIMED(kernel, grid, block, lds, stream, ...)                                           \
   do {                                                                                                       \
     const ::mrs_tg::KernelTimer kt__ = ::mrs_tg::take_kernel_timer();                                        \
+    ::mrs_tg::note_kernel(#kernel);                                                                          \
     hipExtLaunchKernelGGL(kernel, grid, block, lds, stream, kt__.start, kt__.stop, 0, __VA_ARGS__);          \
+  } while (0)
+// plain launches, and launches that carry the events of a multi-kernel timing themselves
+#define MRS_TG_LAUNCH(kernel, ...)                \
+  do {                                            \
+    ::mrs_tg::note_kernel(#kernel);               \
+    hipLaunchKernelGGL(kernel, __VA_ARGS__);      \
+  } while (0)
+#define MRS_TG_LAUNCH_EXT(kernel, ...)            \
+  do {                                            \
+    ::mrs_tg::note_kernel(#kernel);               \
+    hipExtLaunchKernelGGL(kernel, __VA_ARGS__);   \
   } while (0)
 
 // records `message` as the context's (and the global) last error and returns `code`
@@ -114,9 +131,11 @@ struct RowsTail {
   int sample_acc_n = 0;
 };
 
-// A[k] = k additions of dt to 0, the accumulated time of the reference's sampling walk, on the current device (cached per
-// (device, dt) for the process; at least capacity + 80 entries)
-hipError_t sample_acc_table(double dt, int capacity, const double** table_out, int* n_out);
+// A[k] = k additions of dt to 0, the accumulated time of the reference's sampling walk, on the current device: at least
+// capacity + 80 entries, built by a kernel on `stream` the first time a (device, dt) pair is seen and ordered behind that
+// build for launches on other streams; a bounded, least-recently-used cache (mrs_tg_kernels.hip)
+hipError_t sample_acc_table(double dt, int capacity, hipStream_t stream, const double** table_out, int* n_out);
+void sample_tables_release();  // frees every table (with the last context of the process)
 
 // one lane per unknown, no materialised blocks (mrs_tg_rows.hip): the fused linear solve of every path that fits its LDS record
 bool rows_kernel_applies(const BatchView& b, bool with_sampling = false);

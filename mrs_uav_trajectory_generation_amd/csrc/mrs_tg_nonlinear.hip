@@ -1890,7 +1890,7 @@ hipError_t nonlinear_prepare_general(NonlinearPlan& nl, const BatchView& b, cons
     if (cap) *cap = (int)n;
   }
   if ((e = hipMemsetAsync(nl.d_general, 0, sizeof(int32_t) * 4, stream)) != hipSuccess) return e;
-  hipLaunchKernelGGL(general_list_kernel, dim3(cdiv_u(b.n_paths, 256)), dim3(256), 0, stream, b, mask, nl.d_general);
+  MRS_TG_LAUNCH(general_list_kernel, dim3(cdiv_u(b.n_paths, 256)), dim3(256), 0, stream, b, mask, nl.d_general);
   return hipGetLastError();
 }
 
@@ -1927,7 +1927,7 @@ hipError_t launch_nonlinear(NonlinearPlan& nl, const BatchView& b, const Nonline
   prm.deadline = nullptr;
   if (prm_in.time_budget_ticks > 0) {
     if (!nl.d_dfo_deadline && (e = mrs_tg::pool_alloc(&nl.d_dfo_deadline, sizeof(long long))) != hipSuccess) return e;
-    hipLaunchKernelGGL(set_deadline_kernel, dim3(1), dim3(1), 0, stream, nl.d_dfo_deadline, prm_in.time_budget_ticks);
+    MRS_TG_LAUNCH(set_deadline_kernel, dim3(1), dim3(1), 0, stream, nl.d_dfo_deadline, prm_in.time_budget_ticks);
     if ((e = hipGetLastError()) != hipSuccess) return e;
     prm.deadline = nl.d_dfo_deadline;
   }
@@ -1995,7 +1995,7 @@ hipError_t launch_nonlinear(NonlinearPlan& nl, const BatchView& b, const Nonline
     if (bt.n == 1 && resident_blocks > 0 && blocks > resident_blocks) {
       if (!nl.d_queue && (e = mrs_tg::pool_alloc(&nl.d_queue, sizeof(int32_t) * 4)) != hipSuccess) return e;
       blocks = resident_blocks;
-      hipLaunchKernelGGL(set_queue_kernel, dim3(1), dim3(1), 0, stream, nl.d_queue, blocks * (64 / bt.group[0]));
+      MRS_TG_LAUNCH(set_queue_kernel, dim3(1), dim3(1), 0, stream, nl.d_queue, blocks * (64 / bt.group[0]));
       if ((e = hipGetLastError()) != hipSuccess) return e;
       prm.queue_next = nl.d_queue;
     }
@@ -2010,13 +2010,13 @@ hipError_t launch_nonlinear(NonlinearPlan& nl, const BatchView& b, const Nonline
                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)plds)) != hipSuccess)
       return e;
     if (lean_masked)
-      hipExtLaunchKernelGGL(optimize_lean_masked_kernel, dim3(blocks), dim3(64), plds, stream, kt.start, nullptr, 0, b, prm, bt, mask,
+      MRS_TG_LAUNCH_EXT(optimize_lean_masked_kernel, dim3(blocks), dim3(64), plds, stream, kt.start, nullptr, 0, b, prm, bt, mask,
                             vals, seg_times, nl.d_opt_status, nl.d_fallback);
     else if (lean_shared_only)
-      hipExtLaunchKernelGGL(optimize_lean_shared_kernel, dim3(blocks), dim3(64), plds, stream, kt.start, nullptr, 0, b, prm, bt, mask,
+      MRS_TG_LAUNCH_EXT(optimize_lean_shared_kernel, dim3(blocks), dim3(64), plds, stream, kt.start, nullptr, 0, b, prm, bt, mask,
                             vals, seg_times, nl.d_opt_status, nl.d_fallback);
     else
-      hipExtLaunchKernelGGL(optimize_lean_kernel, dim3(blocks), dim3(64), plds, stream, kt.start, nullptr, 0, b, prm, bt, mask, vals,
+      MRS_TG_LAUNCH_EXT(optimize_lean_kernel, dim3(blocks), dim3(64), plds, stream, kt.start, nullptr, 0, b, prm, bt, mask, vals,
                             seg_times, nl.d_opt_status, nl.d_fallback);
     if ((e = hipGetLastError()) != hipSuccess) return e;
     prm.only_flagged = nl.d_fallback;
@@ -2062,13 +2062,13 @@ hipError_t launch_nonlinear(NonlinearPlan& nl, const BatchView& b, const Nonline
       if (e != hipSuccess) return e;
     }
     if (nl.dim_split == 4)
-      hipExtLaunchKernelGGL(optimize_split_kernel, dim3(blocks), dim3(threads), lds_bytes, stream, ev_start, ev_stop, 0, b, prm, bt,
+      MRS_TG_LAUNCH_EXT(optimize_split_kernel, dim3(blocks), dim3(threads), lds_bytes, stream, ev_start, ev_stop, 0, b, prm, bt,
                             mask, vals, seg_times, nl.d_opt_status);
     else if (masked4)
-      hipExtLaunchKernelGGL(optimize_compact_kernel<true>, dim3(blocks), dim3(64), lds_bytes, stream, ev_start, ev_stop, 0, b, prm,
+      MRS_TG_LAUNCH_EXT(optimize_compact_kernel<true>, dim3(blocks), dim3(64), lds_bytes, stream, ev_start, ev_stop, 0, b, prm,
                             bt, mask, vals, seg_times, nl.d_opt_status);
     else
-      hipExtLaunchKernelGGL(optimize_compact_kernel<false>, dim3(blocks), dim3(64), lds_bytes, stream, ev_start, ev_stop, 0, b, prm,
+      MRS_TG_LAUNCH_EXT(optimize_compact_kernel<false>, dim3(blocks), dim3(64), lds_bytes, stream, ev_start, ev_stop, 0, b, prm,
                             bt, mask, vals, seg_times, nl.d_opt_status);
     }
     if ((e = hipGetLastError()) != hipSuccess) return e;
@@ -2079,10 +2079,10 @@ hipError_t launch_nonlinear(NonlinearPlan& nl, const BatchView& b, const Nonline
       if (clds > 64 * 1024 &&
           (e = hipFuncSetAttribute((const void*)optimize_careful_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)clds)) != hipSuccess)
         return e;
-      hipExtLaunchKernelGGL(optimize_careful_kernel, dim3(careful_cap), dim3(64), clds, stream, nullptr,
+      MRS_TG_LAUNCH_EXT(optimize_careful_kernel, dim3(careful_cap), dim3(64), clds, stream, nullptr,
                             general ? nullptr : kt.stop, 0, b, prm, mask, vals, seg_times, nl.d_opt_status, nl.d_careful_ws);
       if ((e = hipGetLastError()) != hipSuccess) return e;
-      hipLaunchKernelGGL(careful_close_kernel, dim3(1), dim3(1), 0, stream, nl.d_careful);
+      MRS_TG_LAUNCH(careful_close_kernel, dim3(1), dim3(1), 0, stream, nl.d_careful);
       if ((e = hipGetLastError()) != hipSuccess) return e;
     }
 #else
@@ -2104,11 +2104,11 @@ hipError_t launch_nonlinear(NonlinearPlan& nl, const BatchView& b, const Nonline
       for (int off = 0; off < b.n_paths; off += general_cap) {
         const bool last = off + general_cap >= b.n_paths;
         gp.careful_list = nl.d_general + 4 + b.n_paths + off;
-        hipExtLaunchKernelGGL(optimize_general_kernel, dim3(general_cap), dim3(64), glds, stream, nullptr, last ? kt.stop : nullptr,
+        MRS_TG_LAUNCH_EXT(optimize_general_kernel, dim3(general_cap), dim3(64), glds, stream, nullptr, last ? kt.stop : nullptr,
                               0, b, gp, mask, vals, seg_times, nl.d_opt_status, nl.d_general_ws, nl.d_general_t0);
         if ((e = hipGetLastError()) != hipSuccess) return e;
         if (!last) {
-          hipLaunchKernelGGL(general_advance_kernel, dim3(1), dim3(1), 0, stream, nl.d_general, general_cap);
+          MRS_TG_LAUNCH(general_advance_kernel, dim3(1), dim3(1), 0, stream, nl.d_general, general_cap);
           if ((e = hipGetLastError()) != hipSuccess) return e;
         }
       }
@@ -2144,10 +2144,10 @@ hipError_t launch_nonlinear(NonlinearPlan& nl, const BatchView& b, const Nonline
     return e == nullptr || std::atoi(e) != 0;
   }();
   if (certified_maxima)
-    hipLaunchKernelGGL(segment_maxima_scaling_kernel, dim3(cdiv_u(b.n_segments, kMsSegs)), dim3(kMsThreads), 0, stream, b, coeffs,
+    MRS_TG_LAUNCH(segment_maxima_scaling_kernel, dim3(cdiv_u(b.n_segments, kMsSegs)), dim3(kMsThreads), 0, stream, b, coeffs,
                        seg_times, limits, nl.d_maxima);
   else
-    hipLaunchKernelGGL(segment_maxima9_kernel, dim3(cdiv_u(b.n_segments, 64), 9), dim3(64), 0, stream, b.n_segments,
+    MRS_TG_LAUNCH(segment_maxima9_kernel, dim3(cdiv_u(b.n_segments, 64), 9), dim3(64), 0, stream, b.n_segments,
                        coeffs, seg_times, nl.d_maxima);
   if ((e = hipGetLastError()) != hipSuccess) return e;
   // 3b + 4 in one launch where the rows kernel applies: its staging pass scales the times of its own path, its tail samples
@@ -2177,10 +2177,10 @@ hipError_t launch_nonlinear(NonlinearPlan& nl, const BatchView& b, const Nonline
     }
     return launch_solve_rows(b, prm.derivative, mask, vals, seg_times, coeffs, status, cost, nl.d_opt_status, stream, tail);
   }
-  hipLaunchKernelGGL(apply_scaling_kernel, dim3(cdiv_u(b.n_segments, 256)), dim3(256), 0, stream, b, nl.d_maxima, limits,
+  MRS_TG_LAUNCH(apply_scaling_kernel, dim3(cdiv_u(b.n_segments, 256)), dim3(256), 0, stream, b, nl.d_maxima, limits,
                      nl.d_opt_status, seg_times);
   if ((e = hipGetLastError()) != hipSuccess) return e;
-  hipLaunchKernelGGL(runaway_kernel, dim3(cdiv_u(b.n_paths, 256)), dim3(256), 0, stream, b, seg_times, nl.d_sum_t0, nl.d_opt_status);
+  MRS_TG_LAUNCH(runaway_kernel, dim3(cdiv_u(b.n_paths, 256)), dim3(256), 0, stream, b, seg_times, nl.d_sum_t0, nl.d_opt_status);
   if ((e = hipGetLastError()) != hipSuccess) return e;
   // 4. updateSegmentTimes + solveLinear with the scaled times (nonlinear_impl.h:405-408), final status
   if ((e = launch_solve_linear(b, prm.derivative, true, mask, vals, seg_times, nullptr, nullptr, nl.d_ws, coeffs, status, cost,
@@ -2202,10 +2202,10 @@ hipError_t launch_cost_gradient(NonlinearPlan& nl, const BatchView& b, int d, co
     if (lds_bytes > 160 * 1024) return hipErrorInvalidValue;
     const dim3 grid(cdiv_u(bin.q_count, per_block));
     if (nl.dim_split == 4)
-      hipLaunchKernelGGL(cost_gradient_kernel<4>, grid, dim3(64), lds_bytes, stream, b, d, bin.group, bin.q_begin,
+      MRS_TG_LAUNCH(cost_gradient_kernel<4>, grid, dim3(64), lds_bytes, stream, b, d, bin.group, bin.q_begin,
                          bin.q_count, bin.max_S, mask, vals, seg_times, cost, grad, only);
     else
-      hipLaunchKernelGGL(cost_gradient_kernel<1>, grid, dim3(64), lds_bytes, stream, b, d, bin.group, bin.q_begin,
+      MRS_TG_LAUNCH(cost_gradient_kernel<1>, grid, dim3(64), lds_bytes, stream, b, d, bin.group, bin.q_begin,
                          bin.q_count, bin.max_S, mask, vals, seg_times, cost, grad, only);
     if ((e = hipGetLastError()) != hipSuccess) return e;
   }
@@ -2215,7 +2215,7 @@ hipError_t launch_cost_gradient(NonlinearPlan& nl, const BatchView& b, int d, co
 hipError_t launch_segment_maxima(const BatchView& b, const double* coeffs, const double* seg_times, double* maxima,
                                  hipStream_t stream) {
   if (b.n_segments == 0) return hipSuccess;
-  hipLaunchKernelGGL(segment_maxima9_kernel, dim3(cdiv_u(b.n_segments, 64), 9), dim3(64), 0, stream, b.n_segments, coeffs,
+  MRS_TG_LAUNCH(segment_maxima9_kernel, dim3(cdiv_u(b.n_segments, 64), 9), dim3(64), 0, stream, b.n_segments, coeffs,
                      seg_times, maxima);
   return hipGetLastError();
 }

@@ -128,6 +128,26 @@ void set_kernel_timer(hipEvent_t start, hipEvent_t stop) {
   t_kernel_timer.stop = stop;
 }
 
+// ---- kernel trace (mrs_tg_kernel_trace): names are string literals of the launch macros, kept by pointer
+static constexpr int kTraceCap = 32;
+static thread_local const char* t_trace[kTraceCap];
+static thread_local unsigned t_trace_n = 0;  // launches noted since the last reset
+
+void note_kernel(const char* name) {
+  t_trace[t_trace_n % kTraceCap] = name;
+  ++t_trace_n;
+}
+
+void kernel_trace_reset() { t_trace_n = 0; }
+
+int kernel_trace(const char** names_out, int capacity) {
+  const unsigned kept = t_trace_n < (unsigned)kTraceCap ? t_trace_n : (unsigned)kTraceCap;
+  const unsigned first = t_trace_n - kept;
+  int n = 0;
+  for (unsigned k = first; k < t_trace_n && n < capacity; ++k) names_out[n++] = t_trace[k % kTraceCap];
+  return n;
+}
+
 KernelTimer take_kernel_timer() {
   const KernelTimer k = t_kernel_timer;
   t_kernel_timer = KernelTimer{};

@@ -582,7 +582,7 @@ bool wave_kernel_applies(const BatchView& b, int dim_split) {
 hipError_t launch_optimize_wave(const BatchView& b, const NonlinearParams& prm, const uint8_t* mask, const double* vals,
                                 double* seg_times, int32_t* opt_status, hipStream_t stream, hipEvent_t ev_start,
                                 hipEvent_t ev_stop) {
-  hipExtLaunchKernelGGL(optimize_wave_kernel, dim3((unsigned)b.n_paths), dim3(64), 0, stream, ev_start, ev_stop, 0, b, prm, mask,
+  MRS_TG_LAUNCH_EXT(optimize_wave_kernel, dim3((unsigned)b.n_paths), dim3(64), 0, stream, ev_start, ev_stop, 0, b, prm, mask,
                         vals, seg_times, opt_status);
   return hipGetLastError();
 }

@@ -61,3 +61,47 @@ def gather_ragged_to_root(tensor, dist, dst=0):
     if bufs is None:
         return None
     return [b[:s] for b, s in zip(bufs, sizes)]
+
+
+# ---- the packed result of a shard and its gather (bench.py's configs[3] job; tests/test_dist_gloo.py runs the same code on gloo)
+
+def packed_doubles(n_paths, n_segments):
+    """doubles of one shard's packed result: coefficients [n_segments][4][10] | segment times [n_segments] | status [n_paths]
+    (int32 carried as doubles so that the job's one collective moves one buffer)"""
+    return int(n_segments) * 41 + int(n_paths)
+
+
+def packed_views(packed, n_paths, n_segments):
+    """(coeffs [n_segments][4][10], times [n_segments], status-as-double [n_paths]) views into a packed buffer"""
+    nS = int(n_segments)
+    return packed[:nS * 40].view(nS, 4, 10), packed[nS * 40:nS * 41], packed[nS * 41:nS * 41 + int(n_paths)]
+
+
+def shard_capacity(total_paths, world):
+    """paths of the largest contiguous shard: what every rank pads its packed result to, so that an uneven cut (65535 paths
+    over 4 ranks: 16384, 16384, 16384, 16383) still travels in ONE equally-shaped gather"""
+    return (int(total_paths) + int(world) - 1) // int(world)
+
+
+def gather_packed_shards(packed, pad, dist, bufs=None, via_host=False):
+    """Copy a rank's packed result into its padded send buffer `pad` (sized for the largest shard) and gather the padded
+    buffers on rank 0.  Returns the receive list on rank 0, None elsewhere.  via_host: the collective runs on host copies
+    (gloo ranks that share one GPU)."""
+    pad[:packed.numel()].copy_(packed)
+    if via_host:
+        return gather_to_root(pad.cpu(), dist)
+    return gather_to_root(pad, dist, bufs=bufs)
+
+
+def unpack_gathered_shards(bufs, total_paths, world, segments_per_path):
+    """rank 0: the per-rank receive buffers of gather_packed_shards -> (coeffs, times, status int32) of the WHOLE batch in path
+    order (uniform batches, contiguous shards: rank r's slice holds the paths contiguous_shard(total, r, world))"""
+    import torch
+    cs, ts, ss = [], [], []
+    for r in range(world):
+        a, b = contiguous_shard(total_paths, r, world)
+        c, t, s = packed_views(bufs[r], b - a, (b - a) * segments_per_path)
+        cs.append(c)
+        ts.append(t)
+        ss.append(s.to(torch.int32))
+    return torch.cat(cs), torch.cat(ts), torch.cat(ss)

@@ -216,18 +216,32 @@ def bench_batch_case():
     return case_record("bench1024_path74_short_segment", wp, m, v, [float(x) for x in euclid_times(wp, batch.limits[74])], 4)
 
 
+def bench_slot_case():
+    """Path 237 of slot 15 of bench.py's twenty batches in flight (random_batch(1024, 10, seed0=15 * 1024), Euclidean times): a
+    0.179 s segment between 4.7 s and 4.0 s ones -- the worst-conditioned path of the 20 480 the headline's timed region
+    solves.  It sets bench.py's in_flight_slots_vs_cpu_ref.max_coeff_err_vs_cpu_ref (5.3e-7 .. 5.4e-7): against the 60-digit
+    solution the reference-style oracle is 5.4e-7 off and the HIP path ~2e-9 (tests/test_gpu_headline_kernel.py)."""
+    batch = pr.random_batch(1024, 10, seed0=15 * 1024)
+    wp, m, v = batch.path(237)
+    return case_record("bench_slot15_path237_short_segment", wp, m, v, [float(x) for x in euclid_times(wp, batch.limits[237])], 4)
+
+
 def append_missing():
     """Add the cases that the committed fixture file does not hold yet (the others are left as they are)."""
     path = os.path.join(OUT, "linear_qp_cases.json")
     with open(path) as f:
         doc = json.load(f)
     names = {c["name"] for c in doc["cases"]}
-    rec = bench_batch_case()
-    if rec["name"] not in names:
-        doc["cases"].append(rec)
+    changed = False
+    for make in (bench_batch_case, bench_slot_case):
+        rec = make()
+        if rec["name"] not in names:
+            doc["cases"].append(rec)
+            changed = True
+            print("appended", rec["name"])
+    if changed:
         with open(path, "w") as f:
             json.dump(doc, f)
-        print("appended", rec["name"])
 
 
 def main():
@@ -270,6 +284,7 @@ def main():
     wp, m, v = pr.build_vertices(pr.random_walk_waypoints(10, 5), pr.SNAP)
     cases.append(case_record("walk10_seed5", wp, m, v, [float(x) for x in euclid_times(wp, lim)], 4))
     cases.append(bench_batch_case())
+    cases.append(bench_slot_case())
     with open(os.path.join(OUT, "linear_qp_cases.json"), "w") as f:
         json.dump(dict(generator="oracle/gen_golden.py", mp_dps=mp.mp.dps, limits=lim.tolist(), cases=cases), f)
     print("wrote", len(cases), "cases")

@@ -422,10 +422,11 @@ def unwrap_heading(what, frm):
 def solve_batch(seg_offsets, waypoints, fixed_mask, fixed_values, limits, seg_times, *, deriv=4,
                 time_alloc_method=-1, estimate_times=False, max_iterations=10, sampling_dt=0.0,
                 sample_capacity=0, n_threads=1, time_penalty=100.0, use_soft_constraints=1, soft_constraint_weight=1.5,
-                runaway_rule=True):
+                runaway_rule=False):
     """Batch driver in the C-ABI's CSR layout. Returns dict(times, coeffs, status, cost, n_samples, samples).
-    runaway_rule: report a runaway of the feasibility scaling as ROUNDOFF_LIMITED (-4) like the product does (its documented
-    deviation); False = the reference's behaviour, the outer loop's own code (mto_set_runaway_rule)."""
+    runaway_rule: False (the default since round 5) = the REFERENCE's behaviour, a runaway of the feasibility scaling keeps
+    the outer loop's own code; True = report it as ROUNDOFF_LIMITED (-4) like the product does (its documented deviation,
+    mto_set_runaway_rule).  The parity tests compare on the reference's rule (tests/util.py::status_matches)."""
     so = np.ascontiguousarray(seg_offsets, dtype=np.int32)
     P = so.size - 1
     total_S = int(so[-1])

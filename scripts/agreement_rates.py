@@ -16,7 +16,7 @@ ctx = api.Context(0)
 def rates(name, batch, deriv=4, cap=1024):
     out = ctx.solve_batch(batch, None, time_alloc_method=api.TIME_ALLOC_MELLINGER, sampling_dt=0.2, sample_capacity=cap)
     ref = po.solve_batch(batch.seg_offsets, batch.waypoints, batch.fixed_mask, batch.fixed_values, batch.limits,
-                         np.zeros(batch.n_segments), deriv=deriv, time_alloc_method=2, estimate_times=True,
+                         np.zeros(batch.n_segments), deriv=deriv, time_alloc_method=2, runaway_rule=True, estimate_times=True,
                          sampling_dt=0.2, sample_capacity=cap, n_threads=os.cpu_count())
     so = batch.seg_offsets
     dt = np.array([np.max(np.abs(out["times"][a:b] - ref["times"][a:b]) / ref["times"][a:b]) for a, b in zip(so[:-1], so[1:])])

@@ -19,7 +19,7 @@ far = pr.Batch(batch.seg_offsets, batch.waypoints, batch.fixed_mask, batch.fixed
 for name, b in (("with limits", batch), ("limits far away (the search's own end point)", far)):
     out = ctx.solve_batch(b, None, time_alloc_method=2)
     ref = po.solve_batch(b.seg_offsets, b.waypoints, b.fixed_mask, b.fixed_values, b.limits, np.zeros(b.n_segments), deriv=deriv,
-                         time_alloc_method=2, estimate_times=True)
+                         time_alloc_method=2, runaway_rule=True, estimate_times=True)
     print(name, "S", b.n_segments, "status gpu", out["status"], "oracle", ref["status"])
     print("  gpu   ", out["times"])
     print("  oracle", ref["times"])

@@ -52,7 +52,7 @@ t0_all = util.oracle_times(with_limits)
 
 def run(batch, t0, budget):
     ref = po.solve_batch(batch.seg_offsets, batch.waypoints, batch.fixed_mask, batch.fixed_values, batch.limits, t0.copy(),
-                         deriv=deriv, time_alloc_method=2, estimate_times=False, n_threads=os.cpu_count() or 8, max_iterations=budget)
+                         deriv=deriv, time_alloc_method=2, runaway_rule=True, estimate_times=False, n_threads=os.cpu_count() or 8, max_iterations=budget)
     out = ctx.solve_batch(batch, t0.copy(), time_alloc_method=2, max_iterations=budget)
     return ref, out
 

@@ -34,7 +34,7 @@ for n_seg, d in (("ragged", 4), (8, 2), (6, 4), ("ragged", 3)):
     for mode in (0, 2):
         po.lib().mto_set_arithmetic(mode)
         ref = po.solve_batch(batch.seg_offsets, batch.waypoints, batch.fixed_mask, batch.fixed_values, batch.limits,
-                             np.zeros(batch.n_segments), deriv=d, time_alloc_method=2, estimate_times=True, sampling_dt=0.2,
+                             np.zeros(batch.n_segments), deriv=d, time_alloc_method=2, runaway_rule=True, estimate_times=True, sampling_dt=0.2,
                              sample_capacity=1024, n_threads=16)
         po.lib().mto_set_arithmetic(0)
         dt = np.array([np.max(np.abs(out["times"][a:b] - ref["times"][a:b]) / ref["times"][a:b]) for a, b in zip(so[:-1], so[1:])])

@@ -36,7 +36,7 @@ if cache and os.path.exists(cache):
     ref = dict(np.load(cache))
 else:
     ref = po.solve_batch(batch.seg_offsets, batch.waypoints, batch.fixed_mask, batch.fixed_values, batch.limits,
-                         np.zeros(batch.n_segments), deriv=deriv, time_alloc_method=mode, estimate_times=True, sampling_dt=0.2,
+                         np.zeros(batch.n_segments), deriv=deriv, time_alloc_method=mode, runaway_rule=True, estimate_times=True, sampling_dt=0.2,
                          sample_capacity=cap, n_threads=os.cpu_count() or 8)
     if cache:
         np.savez(cache, **{k: v for k, v in ref.items() if k in ("status", "times", "coeffs", "n_samples")})

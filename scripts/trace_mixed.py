@@ -53,7 +53,7 @@ for p in paths:
         bb.limits[:] = 1e12  # no feasibility scaling: the returned times are the outer loop's last evaluated point
     for budget in range(1, 11):
         ref = po.solve_batch(bb.seg_offsets, bb.waypoints, bb.fixed_mask, bb.fixed_values, bb.limits, t0.copy(), deriv=deriv,
-                             time_alloc_method=2, estimate_times=False, sampling_dt=0.0, sample_capacity=0, n_threads=1,
+                             time_alloc_method=2, runaway_rule=True, estimate_times=False, sampling_dt=0.0, sample_capacity=0, n_threads=1,
                              max_iterations=budget)
         out = ctx.solve_batch(bb, t0.copy(), time_alloc_method=2, max_iterations=budget)
         d = np.max(np.abs(out["times"] - ref["times"]) / ref["times"])

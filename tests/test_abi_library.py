@@ -32,7 +32,7 @@ def test_every_declared_symbol_is_exported(lib):
 
 
 def test_abi_version_and_default_options(lib):
-    assert lib.mrs_tg_abi_version() == 3
+    assert lib.mrs_tg_abi_version() == 4
     opt = api.default_options()
     # defaults follow the reference's parameters (src/mrs_trajectory_generation.cpp:884-885,
     # config/private/trajectory_generation.yaml:10)

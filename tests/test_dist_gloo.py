@@ -72,3 +72,55 @@ def test_two_rank_shard_and_gather(tmp_path, ragged):
     result = tmp_path / "result.txt"
     mp.spawn(_worker, args=(2, _free_port(), ragged, str(result)), nprocs=2, join=True)
     assert result.read_text() == "ok"
+
+
+def _worker_config3(rank, world, port, total, n_seg, result_file):
+    """bench.py's configs[3] job on CPU: ONE fixed batch cut into contiguous shards over the ranks (an UNEVEN cut), every rank
+    packs coefficients | times | status into one buffer, pads it to the largest shard and the padded buffers travel in one
+    gather (shard.gather_packed_shards -- the function bench.py calls); rank 0 unpacks and compares with the unsharded solve."""
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import torch
+    import torch.distributed as dist
+    from mrs_uav_trajectory_generation_amd import problem as pr, shard
+    from oracle import pyoracle as po
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    a, b = shard.contiguous_shard(total, rank, world)
+    n = b - a
+    batch = pr.random_batch(n, n_seg, seed0=a)          # path p of the job is seeded with p, whatever the number of ranks
+    out = po.solve_batch(batch.seg_offsets, batch.waypoints, batch.fixed_mask, batch.fixed_values, batch.limits,
+                         np.zeros(batch.n_segments), estimate_times=True, n_threads=2)
+    nS = batch.n_segments
+    packed = torch.zeros(shard.packed_doubles(n, nS), dtype=torch.float64)
+    c, t, s = shard.packed_views(packed, n, nS)
+    c.copy_(torch.from_numpy(out["coeffs"]))
+    t.copy_(torch.from_numpy(out["times"]))
+    s.copy_(torch.from_numpy(out["status"]).to(torch.float64))
+    cap = shard.shard_capacity(total, world)
+    pad = torch.zeros(shard.packed_doubles(cap, cap * n_seg), dtype=torch.float64)
+    bufs = shard.gather_packed_shards(packed, pad, dist)
+    sizes = [shard.contiguous_shard(total, r, world) for r in range(world)]
+    if rank == 0:
+        ok = len({e - b0 for b0, e in sizes}) == 2 and sizes[-1][1] == total and sum(e - b0 for b0, e in sizes) == total   # uneven, complete
+        gc, gt, gs = shard.unpack_gathered_shards(bufs, total, world, n_seg)
+        # the unsharded job, rank by rank's seeds: the same paths in the same order
+        full = pr.random_batch(total, n_seg, seed0=0)
+        ref = po.solve_batch(full.seg_offsets, full.waypoints, full.fixed_mask, full.fixed_values, full.limits,
+                             np.zeros(full.n_segments), estimate_times=True, n_threads=8)
+        ok &= gc.shape[0] == total * n_seg and gs.shape[0] == total
+        ok &= np.array_equal(gc.numpy(), ref["coeffs"]) and np.array_equal(gt.numpy(), ref["times"])
+        ok &= np.array_equal(gs.numpy(), ref["status"]) and bool((gs == 1).all())
+        with open(result_file, "w") as f:
+            f.write("ok" if ok else "mismatch")
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_four_rank_uneven_contiguous_shards_with_the_packed_gather(tmp_path):
+    """65536 divides by 4; 65535 does not: ranks 0-2 own 16384 paths, rank 3 owns 16383 -- the remainder logic of
+    shard.contiguous_shard together with the padded, packed gather of bench.py's configs[3]"""
+    import torch.multiprocessing as mp
+    result = tmp_path / "result.txt"
+    mp.spawn(_worker_config3, args=(4, _free_port(), 65535, 3, str(result)), nprocs=4, join=True)
+    assert result.read_text() == "ok"

@@ -29,7 +29,7 @@ def _per_path(arr, offsets, p):
     return arr[offsets[p]:offsets[p + 1]]
 
 
-def _check_nonlinear(gpu_ctx, batch, n_oracle, min_good=0.99):
+def _check_nonlinear(gpu_ctx, batch, n_oracle, max_bad=1):
     out = gpu_ctx.solve_batch(batch, None, time_alloc_method=api.TIME_ALLOC_MELLINGER, sampling_dt=0.2, sample_capacity=CAP)
     P, so = batch.n_paths, batch.seg_offsets
     assert np.all(np.isin(out["status"], (1, 3, 4, 5, api.STATUS_ROUNDOFF_LIMITED)))
@@ -72,34 +72,49 @@ def _check_nonlinear(gpu_ctx, batch, n_oracle, min_good=0.99):
     good = 0
     for k, p in enumerate(idx):
         a, b = sub.seg_offsets[k], sub.seg_offsets[k + 1]
-        if out["status"][p] == ref["status"][k] and np.max(np.abs(st[a:b] - ref["times"][a:b]) / ref["times"][a:b]) < 1e-6 \
+        if util.status_matches(out["status"][p], ref["status"][k]) and np.max(np.abs(st[a:b] - ref["times"][a:b]) / ref["times"][a:b]) < 1e-6 \
                 and util.coeff_error(sc[a:b], ref["coeffs"][a:b]) < 1e-6:
             good += 1
     print("RATE baseline P=%d: %d / %d" % (P, good, len(idx)))
-    assert good >= min_good * len(idx), (good, len(idx))
+    # the gate is what is measured (every path of the subset on all three batches), less ONE path: a regression from 100 % to
+    # 99 % fails (round 4's gate was 0.99 of the subset)
+    assert good >= len(idx) - max_bad, (good, len(idx))
+    # statuses on the REFERENCE's rule (pyoracle's default): the product's -4 paths are the oracle's own runaways, which the
+    # reference hands back with a success code
+    sub_out = dict(status=out["status"][idx], times=st)
+    flagged = util.runaway_sets_agree(sub, sub_out, ref)
+    print("subset paths flagged ROUNDOFF_LIMITED where the reference's rule reports a success code: %d" % flagged)
     return good / len(idx)
 
 
 def test_config2_1024_paths_nonlinear(gpu_ctx):
     """BASELINE configs[2] at its own size: every one of the 1024 paths through the invariants, a strided 256 of them
     against the oracle (measured 256 / 256)."""
-    rate = _check_nonlinear(gpu_ctx, pr.random_batch(1024, 10, seed0=0), 256, min_good=0.99)
+    rate = _check_nonlinear(gpu_ctx, pr.random_batch(1024, 10, seed0=0), 256)
     print("configs[2] agreement with the oracle on the strided subset: %.4f" % rate)
 
 
 def test_config3_whole_65536_paths_nonlinear(gpu_ctx):
     batch = pr.random_batch(65536, 10, seed0=0)
-    _check_nonlinear(gpu_ctx, batch, 512, min_good=0.99)   # measured 512 / 512
+    _check_nonlinear(gpu_ctx, batch, 512)   # measured 512 / 512
     # path 8615 (a 2.7 s segment next to one scaled to 9e11 s) and its siblings, which round 2 returned as successes
-    out = gpu_ctx.solve_batch(batch.select([8615]), None, time_alloc_method=api.TIME_ALLOC_MELLINGER)
+    one = batch.select([8615])
+    out = gpu_ctx.solve_batch(one, None, time_alloc_method=api.TIME_ALLOC_MELLINGER)
     assert out["status"][0] == api.STATUS_ROUNDOFF_LIMITED and out["times"].sum() > 1e6
+    # the deviation itself, on the GPU: the REFERENCE's rule hands the same runaway back with the outer loop's code (a
+    # "success" its nodelet then discards by the length check), the product's rule names it
+    ref = po.solve_batch(one.seg_offsets, one.waypoints, one.fixed_mask, one.fixed_values, one.limits, np.zeros(10), deriv=4,
+                         time_alloc_method=2, estimate_times=True)
+    assert ref["status"][0] >= 1 and ref["times"].sum() > 1e6
+    assert util.status_matches(out["status"], ref["status"]).all() and out["status"][0] != ref["status"][0]
+    assert util.runaway_sets_agree(one, out, ref) == 1
 
 
 def test_config4_8192_ragged_paths_nonlinear(gpu_ctx):
     batch = pr.random_batch(8192, "ragged", seed0=0)
     counts = np.diff(batch.seg_offsets)
     assert counts.min() == 3 and counts.max() == 30
-    _check_nonlinear(gpu_ctx, batch, 512, min_good=0.99)   # measured 512 / 512 (round 2 ran 96 paths against a gate of 0.95)
+    _check_nonlinear(gpu_ctx, batch, 512)   # measured 512 / 512 (round 2 ran 96 paths against a gate of 0.95)
 
 
 def test_config1_at_65536_paths_linear_is_linear_in_the_waypoints(gpu_ctx):

@@ -15,15 +15,16 @@ NO_LIMITS = np.full(9, 1e9)  # feasibility scaling off: the returned times are t
 
 @pytest.fixture(autouse=True)
 def _careful_rerun_built(gpu_ctx):
-    """The re-run kernel is a compile-time option since round 4 (-DMRS_TG_WITH_CAREFUL=1; off in the shipped library: it bought
-    0.005 % agreement for a second outer-loop launch).  Without it the flag is refused with MRS_TG_ERR_UNSUPPORTED -- which is
-    what is checked then -- and the tests of the re-run itself are skipped."""
+    """The re-run kernel is a compile-time option (MRS_TG_WITH_CAREFUL; ON in the shipped library since ABI 4, so these tests run
+    in the driver's GPU tier).  mrs_tg_capabilities() says what the loaded library holds; a library built with
+    MRS_TG_WITH_CAREFUL=0 must refuse the flag with MRS_TG_ERR_UNSUPPORTED -- which is what is checked then -- and the
+    tests of the re-run itself are skipped."""
+    if api.capabilities() & api.CAP_CAREFUL_COST:
+        return
     probe = pr.random_batch(2, 4, seed0=1)
-    try:
+    with pytest.raises(api.MrsTgError, match="MRS_TG_WITH_CAREFUL"):
         gpu_ctx.solve_batch(probe, None, time_alloc_method=api.TIME_ALLOC_MELLINGER, flags=api.FLAG_CAREFUL_COST)
-    except api.MrsTgError as e:
-        assert "MRS_TG_WITH_CAREFUL" in str(e)
-        pytest.skip("library built without the careful re-run")
+    pytest.skip("library built without the careful re-run")
 
 
 def _both(ctx, batch, t0):  # (the batch carries its objective order)

@@ -36,7 +36,7 @@ def test_config3_shard_over_a_device_list_against_the_oracle(gpu_ctx):
         a, b = sub.seg_offsets[k], sub.seg_offsets[k + 1]
         t = many["times"][so[p]:so[p + 1]]
         c = many["coeffs"][so[p]:so[p + 1]]
-        same = (many["status"][p] == ref["status"][k] and many["n_samples"][p] == ref["n_samples"][k]
+        same = (util.status_matches(many["status"][p], ref["status"][k]) and many["n_samples"][p] == ref["n_samples"][k]
                 and np.max(np.abs(t - ref["times"][a:b]) / ref["times"][a:b]) < 1e-6
                 and util.coeff_error(c, ref["coeffs"][a:b]) < 1e-6)
         if same:
@@ -44,7 +44,7 @@ def test_config3_shard_over_a_device_list_against_the_oracle(gpu_ctx):
             same = np.max(np.abs(many["samples"][p, :n, :3] - ref["samples"][k, :n, :3])) < 1e-5
         good += bool(same)
     print("RATE device list [0, 0], 8192 x 10 Mellinger: %d / %d paths agree with the oracle" % (good, len(idx)))
-    assert good >= 0.99 * len(idx), (good, len(idx))
+    assert good >= len(idx) - 1, (good, len(idx))   # measured: every path of the subset
     # and with the single-device solve: the same outer-loop kernel per path, but the closing linear solve of 8192 paths in one
     # launch is the four-lanes-per-path kernel and that of a 4096-path shard the rows kernel -- agreement to rounding, not bit for bit
     one = gpu_ctx.solve_batch(batch, None, **opts)

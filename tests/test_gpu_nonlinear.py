@@ -146,7 +146,7 @@ def test_nonlinear_moving_start_end_to_end_vs_oracle(gpu_ctx):
     _check_invariants(batch, out)
     so = batch.seg_offsets
     dt = np.array([np.max(np.abs(out["times"][a:b] - ref["times"][a:b]) / ref["times"][a:b]) for a, b in zip(so[:-1], so[1:])])
-    same = (out["status"] == ref["status"]) & (out["n_samples"] == np.minimum(ref["n_samples"], cap + 1))
+    same = util.status_matches(out["status"], ref["status"]) & (out["n_samples"] == np.minimum(ref["n_samples"], cap + 1))
     print("RATE walk: 1e-6 %.4f" % (dt < 1e-6).mean())
     assert same.all(), same.mean()
     assert (dt < 1e-6).mean() >= 0.995, (dt < 1e-6).mean()   # measured 100 %
@@ -201,20 +201,23 @@ def test_nonlinear_end_to_end_vs_oracle(gpu_ctx, n_seg, n_paths):
         a, b = batch.seg_offsets[p], batch.seg_offsets[p + 1]
         dt = np.max(np.abs(out["times"][a:b] - ref["times"][a:b]) / ref["times"][a:b])
         dc = util.coeff_error(out["coeffs"][a:b], ref["coeffs"][a:b])
-        same = out["status"][p] == ref["status"][p] and out["n_samples"][p] == min(ref["n_samples"][p], cap + 1)
+        same = bool(util.status_matches(out["status"][p], ref["status"][p])) and out["n_samples"][p] == min(ref["n_samples"][p], cap + 1)
         ds = np.inf
         if same:
             n = min(out["n_samples"][p], cap)
             ds = np.max(np.abs(out["samples"][p, :n, :3] - ref["samples"][p, :n, :3])) if n else 0.0
         if dt < 1e-6 and dc < 1e-6 and same and ds < 1e-6:
             good += 1
-        if out["status"][p] == ref["status"][p]:
+        if out["status"][p] == ref["status"][p]:   # (equal codes: not the product's own -4 paths)
             worst_dt = max(worst_dt, dt)
     # measured: 100 % on every uniform batch, 94 of 96 on the ragged one (two paths take another branch of the line search on
     # a 1e-9 difference in J); the stopping reason and the sample count agree on ALL paths
     print("RATE end_to_end %s: %d / %d" % (n_seg, good, batch.n_paths))
     assert good >= (0.97 if n_seg == "ragged" else 1.0) * batch.n_paths, (good, batch.n_paths)
-    assert np.array_equal(out["status"], ref["status"])
+    # statuses on the REFERENCE's rule: equal on every path the product does not flag as a runaway, and the flagged set is
+    # the set of paths whose oracle result ran away too (the product's -4 against the reference's success code, visible here)
+    assert util.status_matches(out["status"], ref["status"]).all()
+    util.runaway_sets_agree(batch, out, ref)
     assert np.array_equal(out["n_samples"], np.minimum(ref["n_samples"], cap + 1))
     # paths that took the same branches but sit on badly conditioned time vectors (a 0.7 s segment between
     # 15 s ones) still agree to 1e-3: the forward-difference gradient of the reference-style oracle is only
@@ -355,7 +358,7 @@ def test_mixed_constraint_patterns_vs_oracle(gpu_ctx, deriv):
     assert np.all(np.isfinite(out["coeffs"])) and np.all(np.isfinite(out["times"]))
     so = batch.seg_offsets
     dt = np.array([np.max(np.abs(out["times"][a:b] - ref["times"][a:b]) / ref["times"][a:b]) for a, b in zip(so[:-1], so[1:])])
-    same = (out["status"] == ref["status"]) & (out["n_samples"] == np.minimum(ref["n_samples"], cap + 1))
+    same = util.status_matches(out["status"], ref["status"]) & (out["n_samples"] == np.minimum(ref["n_samples"], cap + 1))
     # measured (scripts/agreement_rates.py, 768 paths per objective): stopping reason and sample count 100 %; times to 1e-6 on
     # 99.5 % / 99.1 % / 99.3 % (d = 2 / 3 / 4), to 1e-3 on 100 % / 100 % / 99.9 %.  What is left are the trial points on the 0.01 s
     # bound, where the by-product cost has lost its digits and the kernel rejects what the oracle's 0.5 c^T Q c may accept
@@ -383,9 +386,11 @@ def test_mixed_constraint_patterns_through_the_one_wavefront_kernel(gpu_ctx, der
     assert np.all(np.isfinite(out["coeffs"])) and np.all(np.isfinite(out["times"]))
     so = batch.seg_offsets
     dt = np.array([np.max(np.abs(out["times"][a:b] - ref["times"][a:b]) / ref["times"][a:b]) for a, b in zip(so[:-1], so[1:])])
-    same = (out["status"] == ref["status"]) & (out["n_samples"] == np.minimum(ref["n_samples"], cap + 1))
-    print("RATE mixed <= 12 segments deriv %d: 1e-6 %.4f 1e-3 %.4f" % (deriv, (dt < 1e-6).mean(), (dt < 1e-3).mean()))
-    assert same.all(), same.mean()
+    same = util.status_matches(out["status"], ref["status"]) & (out["n_samples"] == np.minimum(ref["n_samples"], cap + 1))
+    print("RATE mixed <= 12 segments deriv %d: 1e-6 %.4f 1e-3 %.4f same %.4f" % (deriv, (dt < 1e-6).mean(), (dt < 1e-3).mean(), same.mean()))
+    # stopping reason and sample count: measured 100 % on these seeds, 99.95 % (1 of 2048) on the same batch family in
+    # profiles/round4_parity_sweep.txt -- a rate consistent with that, not equality that holds by the choice of seed
+    assert same.mean() >= 0.998, same.mean()
     assert (dt < 1e-6).mean() >= 0.988, (dt < 1e-6).mean()
     assert (dt < 1e-3).mean() >= 0.998, (dt < 1e-3).mean()
 
@@ -425,7 +430,8 @@ def test_nonlinear_end_to_end_vs_the_113_bit_oracle(gpu_ctx, gen, n_paths, deriv
     dc = np.array([util.coeff_error(out["coeffs"][a:b], ref["coeffs"][a:b]) for a, b in zip(so[:-1], so[1:])])
     print("RATE 113-bit oracle %s d=%d: times 1e-6 %.4f, coeffs 1e-6 %.4f, worst dt %.1e" %
           (gen, deriv, (dt < 1e-6).mean(), (dc < 1e-6).mean(), dt.max()))
-    assert np.array_equal(out["status"], ref["status"])
+    assert util.status_matches(out["status"], ref["status"]).all()   # (the reference's rule; the -4 set: runaway_sets_agree)
+    util.runaway_sets_agree(batch, out, ref)
     assert np.array_equal(out["n_samples"], np.minimum(ref["n_samples"], cap + 1))
     assert (dt < 1e-6).mean() >= 0.995 and (dc < 1e-6).mean() >= 0.995
     assert dt.max() < 1e-3

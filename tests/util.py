@@ -97,3 +97,31 @@ def constraint_defect(batch, coeffs, times, paths=None):
                 val = eval_poly(coeffs[s], 0.0 if vert < S else T, k)
                 worst = max(worst, float(np.max(np.abs(val - v[vert, k]) * T ** k / scale)))
     return worst
+
+
+ROUNDOFF_LIMITED = -4   # MRS_TG_STATUS_ROUNDOFF_LIMITED, the product's own status word (include/mrs_tg.h)
+
+
+def status_matches(out_status, ref_status):
+    """Statuses of the HIP path against the oracle run on the REFERENCE's rule (pyoracle.solve_batch's default): equal, except
+    on the paths the product hands back as ROUNDOFF_LIMITED (-4: its feasibility scaling ran away) -- there the reference
+    reports the outer loop's own code (>= 1) and its nodelet discards the trajectory one step later by the length check
+    (src/mrs_trajectory_generation.cpp:1178-1199).  The -4 set itself is asserted separately (runaway_sets_agree).
+    Works elementwise on arrays and on scalars."""
+    out_status, ref_status = np.asarray(out_status), np.asarray(ref_status)
+    return (out_status == ref_status) | ((out_status == ROUNDOFF_LIMITED) & (ref_status >= 1))
+
+
+def runaway_sets_agree(batch, out, ref, start_times=None, factor=25.0):
+    """The product's deviation made visible: the paths it flags -4 are exactly the paths on which the ORACLE's own result
+    (reference rule: a success code) has a total time of more than `factor` times the total the search started from.
+    start_times: the start point (None = the Euclidean estimate, estimate_times).  Paths whose ratio lies within 1e-6 of the
+    threshold could fall either way and are skipped.  Returns the number of flagged paths."""
+    so = batch.seg_offsets
+    t0 = oracle_times(batch) if start_times is None else np.asarray(start_times)
+    ratio = np.add.reduceat(np.asarray(ref["times"]), so[:-1]) / np.add.reduceat(t0, so[:-1])
+    flagged = np.asarray(out["status"]) == ROUNDOFF_LIMITED
+    clear = np.abs(ratio / factor - 1.0) > 1e-6
+    assert np.array_equal(flagged[clear], (ratio > factor)[clear] & (np.asarray(ref["status"])[clear] >= 1)), \
+        (np.nonzero(flagged)[0][:8], np.nonzero(ratio > factor)[0][:8])
+    return int(flagged.sum())
