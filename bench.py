@@ -570,11 +570,12 @@ def main():
                                    block_fn=block_for(args.workload))
     total_paths = P * world * args.steps
     value = total_paths / elapsed
+    own_elapsed_main = LAST_OWN_ELAPSED[0]   # this rank's own timed region (later measurements overwrite the global)
     # what every rank saw, so that a first multi-GPU curve can be read from the line alone: its own K-step time, the device it
     # ran on, and whether the dmabuf IPC mode the pool's driver needs was set in its environment
     props = torch.cuda.get_device_properties(dev)
     rank_info = dict(rank=rank, local_rank=local_rank, device_index=dev_index, device=props.name,
-                     arch=getattr(props, "gcnArchName", None), ms_per_step=LAST_OWN_ELAPSED[0] / args.steps * 1e3,
+                     arch=getattr(props, "gcnArchName", None), ms_per_step=own_elapsed_main / args.steps * 1e3,
                      gather_ms=(LAST_OWN_GATHER[0] * 1e3 if dist is not None else None),
                      hsa_enable_ipc_mode_legacy=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY"))
     per_rank = [rank_info]
@@ -602,7 +603,7 @@ def main():
         for c in lane_ctx:
             c.set_profiling(True)
         try:
-            block_for("linear")(max(200, 10 * n_group_slots))
+            block_for("linear")(max(1000, 50 * n_group_slots))
             torch.cuda.synchronize()
             hv = []
             for c in lane_ctx:
@@ -616,7 +617,7 @@ def main():
         comp_bytes = paths_disp * (40 * args.segments + 288 + 328 * args.segments)
         ach = comp_bytes / (h_mean * 1e-3) / 1e9
         # over the timed region itself: compulsory bytes of all K steps / the region's wall time (dispatches overlap on two streams)
-        ach_region = (P * args.steps * (40 * args.segments + 288 + 328 * args.segments)) / LAST_OWN_ELAPSED[0] / 1e9
+        ach_region = (P * args.steps * (40 * args.segments + 288 + 328 * args.segments)) / own_elapsed_main / 1e9
         roofline_headline = dict(
             kernel=head_kernel, kernels_of_one_round=traced, in_timed_region=True, bound="hbm", unit="GB/s", peak=HBM_PEAK_GBS,
             paths_per_dispatch=paths_disp, steps_per_dispatch=group_n,
