@@ -367,13 +367,16 @@ def main():
     t_fixed = t_init.clone()   # linear mode never writes the times
 
     # [0]: the batch has the device to itself; [1]: several batches in flight (MRS_TG_FLAG_SHARED_DEVICE, a launch-shape hint)
-    opt_lin = [api.default_options(derivative_to_optimize=4, flags=f) for f in (0, api.FLAG_SHARED_DEVICE)]
+    # (MRS_TG_FLAG_POSITIONS_ARE_WAYPOINTS: every vertex of these batches has its waypoint as position constraint, as every
+    # vertex findTrajectory builds; the saturated-device solve then reads the compact waypoint array -- checked at bind time)
+    opt_lin = [api.default_options(derivative_to_optimize=4, flags=f | api.FLAG_POSITIONS_ARE_WAYPOINTS) for f in (0, api.FLAG_SHARED_DEVICE)]
     opt_blocks = [api.default_options(derivative_to_optimize=4, flags=api.FLAG_MATERIALIZED_BLOCKS | f)
                   for f in (0, api.FLAG_SHARED_DEVICE)]
     # the nonlinear step is findTrajectory's: segment-time estimate from the waypoints, outer loop from there, scaling,
     # sampling (estimate_times=1: every step starts from the same point without a reset of the times in front of it)
     opt_nl = [api.default_options(derivative_to_optimize=4, time_alloc_method=api.TIME_ALLOC_MELLINGER, estimate_times=1,
-                                  sampling_dt=0.2, sample_capacity=512, flags=f) for f in (0, api.FLAG_SHARED_DEVICE)]
+                                  sampling_dt=0.2, sample_capacity=512, flags=f | api.FLAG_POSITIONS_ARE_WAYPOINTS)
+              for f in (0, api.FLAG_SHARED_DEVICE)]
 
     def gather(tensor, bufs):
         """the job's one collective: equally shaped per-rank results -> rank 0"""
@@ -431,7 +434,7 @@ def main():
 
     def slot_inputs(slot):
         i = slot if slot < len(slot_db) else 0
-        return slot_db[i].fixed_mask, slot_db[i].fixed_values, slot_t[i]
+        return slot_db[i].fixed_mask, slot_db[i].fixed_values, slot_t[i], slot_db[i].waypoints
 
     bound = {}
 
@@ -440,9 +443,10 @@ def main():
         key = (kind, slot, lane, sh)
         if key not in bound:
             if kind in ("linear", "blocks"):
-                s_mask, s_vals, s_times = slot_inputs(slot)
+                s_mask, s_vals, s_times, s_wp = slot_inputs(slot)
                 bound[key] = lane_plan[lane].bind_solve(opt_lin[sh] if kind == "linear" else opt_blocks[sh], s_mask, s_vals,
-                                                        s_times, out_coeffs[slot], status_i32[slot], slot_cost[slot])
+                                                        s_times, out_coeffs[slot], status_i32[slot], slot_cost[slot],
+                                                        waypoints=s_wp)
             else:
                 bound[key] = lane_plan[lane].bind_solve(opt_nl[sh], db.fixed_mask, db.fixed_values, out_times[slot], out_coeffs[slot],
                                                         status_i32[slot], slot_cost[slot], waypoints=db.waypoints,
@@ -702,7 +706,7 @@ def main():
     db.coeffs, db.seg_times, db.status = out_coeffs[0], out_times[0], status_i32[0]
 
     def launch_solve():
-        plan.solve(opt_lin[0], db.fixed_mask, db.fixed_values, t_fixed, out_coeffs[0], status_i32[0], slot_cost[0])
+        plan.solve(opt_lin[0], db.fixed_mask, db.fixed_values, t_fixed, out_coeffs[0], status_i32[0], slot_cost[0], waypoints=db.waypoints)
 
     def launch_nl():
         plan.solve(opt_nl[0], db.fixed_mask, db.fixed_values, out_times[0], out_coeffs[0], status_i32[0], slot_cost[0],
@@ -970,10 +974,11 @@ def main():
         # single small batch (four lanes per path with the factors in LDS once a launch carries >= 6144 paths, mrs_tg_quad.hip)
         if rank == 0:
             for _ in range(2):
-                plan3.solve(opt_lin[0], db3.fixed_mask, db3.fixed_values, t3, c3, st3, db3.cost)
+                plan3.solve(opt_lin[0], db3.fixed_mask, db3.fixed_values, t3, c3, st3, db3.cost, waypoints=db3.waypoints)
             torch.cuda.synchronize()
             m_sat, med_sat, _ = dispatch_stats(ctx, api.KERNEL_SOLVE_LINEAR,
-                                               lambda: plan3.solve(opt_lin[0], db3.fixed_mask, db3.fixed_values, t3, c3, st3, db3.cost), 10, torch)
+                                               lambda: plan3.solve(opt_lin[0], db3.fixed_mask, db3.fixed_values, t3, c3, st3, db3.cost,
+                                                                   waypoints=db3.waypoints), 10, torch)
             flop_sat = SOLVE_FLOP_PER_SEGMENT * n3 * args.segments
             extras["roofline_solve_saturated"] = dict(
                 kernel="solve_quad_kernel" if n3 >= 6144 else "solve_rows_kernel", paths=n3, bound="fp64 vector", unit="TFLOP/s",

@@ -122,6 +122,21 @@ enum {
                                          mrs_tg_capabilities() says which one is loaded */
 };
 
+enum {
+  MRS_TG_FLAG_POSITIONS_ARE_WAYPOINTS = 32 /* (ABI 4) the caller states that the position constraint of EVERY vertex is its
+                                         waypoint: fixed_mask[v][0] != 0 and fixed_values[v][0][:] == waypoints[v][:], bit for
+                                         bit -- what every vertex findTrajectory builds looks like
+                                         (src/mrs_trajectory_generation.cpp:944, 963, 967: addConstraint(POSITION,
+                                         waypoint.coords)).  `waypoints` must then be given, and kernels may read vertex
+                                         positions from that compact [vertex][4] array instead of from 8 bytes out of every
+                                         160 of fixed_values: the saturated-device solve (launches of >= 6144 paths) moves
+                                         1.03 instead of 1.34 times its compulsory bytes.  Results are bit-identical.
+                                         mrs_tg_plan_bind_solve CHECKS the statement once, on the arrays as they are at bind
+                                         time, and refuses the bind with MRS_TG_ERR_INVALID_ARG if it does not hold;
+                                         mrs_tg_plan_solve trusts it (a statement that is false gives the solution of the
+                                         waypoints' problem).  Other kernels ignore the flag */
+};
+
 /* mrs_tg_capabilities(): what this build of the library contains beyond the mandatory surface */
 enum {
   MRS_TG_CAP_CAREFUL_COST = 1 /* MRS_TG_FLAG_CAREFUL_COST is honoured (optimize_careful_kernel is built in) */

@@ -480,9 +480,12 @@ int mrs_tg_plan_solve(mrs_tg_plan* plan, const double* wp, const uint8_t* mask, 
   if ((opt->estimate_times || opt->time_alloc_method != MRS_TG_TIME_ALLOC_NONE) && !limits)
     return fail(ctx, MRS_TG_ERR_INVALID_ARG, "limits are required for time estimation and for every time-allocation mode");
   if (opt->estimate_times && !wp) return fail(ctx, MRS_TG_ERR_INVALID_ARG, "waypoints are required when estimate_times is set");
+  if ((opt->flags & MRS_TG_FLAG_POSITIONS_ARE_WAYPOINTS) && !wp)
+    return fail(ctx, MRS_TG_ERR_INVALID_ARG, "MRS_TG_FLAG_POSITIONS_ARE_WAYPOINTS needs the waypoints array");
   if (opt->sampling_dt > 0 && !n_samples) return fail(ctx, MRS_TG_ERR_INVALID_ARG, "n_samples_out is required when sampling");
   HIP_TRY(ctx, use_device(ctx->device));
   const mrs_tg::BatchView& b = plan->view;
+  const double* pos_wp = (opt->flags & MRS_TG_FLAG_POSITIONS_ARE_WAYPOINTS) ? wp : nullptr;
   const int d = opt->derivative_to_optimize;
   struct SharedDeviceScope {
     explicit SharedDeviceScope(bool on) { mrs_tg::set_shared_device_hint(on); }
@@ -527,6 +530,7 @@ int mrs_tg_plan_solve(mrs_tg_plan* plan, const double* wp, const uint8_t* mask, 
       prm.estimate_wp = wp;
       prm.estimate_limits = limits;
     }
+    prm.pos_wp = pos_wp;
     ProfileScope ps(ctx, 2);
     HIP_TRY(ctx, mrs_tg::launch_nonlinear(plan->nl, b, prm, mask, vals, limits, seg_times, coeffs, status, cost, ctx->stream,
                                           opt->sampling_dt, opt->sample_capacity, n_samples, samples, &sampled,
@@ -553,7 +557,7 @@ int mrs_tg_plan_solve(mrs_tg_plan* plan, const double* wp, const uint8_t* mask, 
       sampled = true;
     } else {
       HIP_TRY(ctx, mrs_tg::launch_solve_linear(b, d, fused, mask, vals, seg_times, plan->d_H, plan->d_Ainv, plan->d_ws,
-                                               coeffs, status, cost, nullptr, ctx->stream));
+                                               coeffs, status, cost, nullptr, ctx->stream, general ? nullptr : pos_wp));
     }
     // the paths the fast kernels sent back with status -2 (a vertex without a position constraint): 5 x 5 vertex blocks
     if (general)
@@ -589,6 +593,18 @@ int mrs_tg_plan_bind_solve(mrs_tg_plan* plan, const double* wp, const uint8_t* m
   *bound_out = nullptr;
   const int rc = check_options(plan->ctx, opt);
   if (rc != MRS_TG_OK) return rc;
+  if (opt->flags & MRS_TG_FLAG_POSITIONS_ARE_WAYPOINTS) {
+    // the caller's statement, checked once on the arrays as they are now (a blocking check: binding is not a hot path)
+    if (!wp || !mask || !vals) return fail(plan->ctx, MRS_TG_ERR_INVALID_ARG, "MRS_TG_FLAG_POSITIONS_ARE_WAYPOINTS needs waypoints, fixed_mask and fixed_values");
+    mrs_tg_ctx* ctx = plan->ctx;
+    HIP_TRY(ctx, use_device(ctx->device));
+    long long bad = 0;
+    HIP_TRY(ctx, mrs_tg::count_position_mismatches(plan->view, wp, mask, vals, ctx->stream, &bad));
+    if (bad != 0)
+      return fail(ctx, MRS_TG_ERR_INVALID_ARG,
+                  "MRS_TG_FLAG_POSITIONS_ARE_WAYPOINTS: %lld vertices whose position constraint is absent or differs from their waypoint",
+                  bad);
+  }
   mrs_tg_bound_solve* b = new (std::nothrow) mrs_tg_bound_solve{plan, wp, mask, vals, limits, *opt, seg_times, coeffs, status, cost,
                                                                 n_samples, samples};
   if (!b) return fail(plan->ctx, MRS_TG_ERR_NOMEM, "out of host memory");
@@ -805,6 +821,7 @@ int mrs_tg_bound_solve_launch_group(mrs_tg_bound_solve* const* bound, int32_t n_
       g.coeffs[g.n] = b->coeffs;
       g.status[g.n] = b->status;
       g.cost[g.n] = b->cost;
+      g.pos_wp[g.n] = (b->opt.flags & MRS_TG_FLAG_POSITIONS_ARE_WAYPOINTS) ? b->wp : nullptr;
     }
     if (plan->view.n_paths == 0) continue;
     HIP_TRY(ctx, use_device(ctx->device));

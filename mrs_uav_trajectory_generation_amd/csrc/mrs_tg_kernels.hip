@@ -242,10 +242,13 @@ static inline bool use_split_dims(int n_paths) { return n_paths <= 32768; }
 hipError_t launch_solve_linear(const BatchView& b, int d, bool fused, const uint8_t* mask, const double* vals,
                                const double* seg_times, const double* H, const double* Ainv, double* ws,
                                double* coeffs, int32_t* status, double* cost, const int32_t* status_in,
-                               hipStream_t stream) {
+                               hipStream_t stream, const double* pos_wp) {
   if (b.n_paths == 0) return hipSuccess;
-  if (fused && ws != nullptr && quad_kernel_applies(b, b.n_paths, false))  // saturated device: four lanes per path, factors in LDS
-    return launch_solve_quad(b, d, mask, vals, seg_times, coeffs, status, cost, status_in, ws, stream);
+  if (fused && ws != nullptr && quad_kernel_applies(b, b.n_paths, false)) {  // saturated device: four lanes per path, factors in LDS
+    RowsTail tail;
+    tail.pos_wp = pos_wp;
+    return launch_solve_quad(b, d, mask, vals, seg_times, coeffs, status, cost, status_in, ws, stream, tail);
+  }
   if (fused && rows_kernel_applies(b))
     return launch_solve_rows(b, d, mask, vals, seg_times, coeffs, status, cost, status_in, stream);
   if (tile_kernel_applies(b, fused))
@@ -497,6 +500,41 @@ hipError_t launch_sample_states(const BatchView& b, const double* coeffs, const 
                                 int32_t* n_samples, double* states, hipStream_t stream) {
   if (b.n_paths == 0) return hipSuccess;
   return launch_sample_n<kSampleStateOrders - 1>(b, coeffs, seg_times, dt, capacity, n_samples, states, stream);
+}
+
+__global__ void position_mismatch_kernel(int n_vertices, const double* __restrict__ wp, const uint8_t* __restrict__ mask,
+                                         const double* __restrict__ vals, unsigned long long* __restrict__ count) {
+  const int v = blockIdx.x * blockDim.x + threadIdx.x;
+  bool bad = false;
+  if (v < n_vertices) {
+    bad = mask[(size_t)v * kHalf] == 0;
+#pragma unroll
+    for (int q = 0; q < kD; ++q)  // bitwise: the solve must not depend on which array it read
+      bad = bad || __double_as_longlong(wp[(size_t)v * kD + q]) != __double_as_longlong(vals[(size_t)v * kHalf * kD + q]);
+  }
+  const unsigned long long n = __popcll(__ballot(bad));
+  if ((threadIdx.x & 63) == 0 && n != 0) atomicAdd(count, n);
+}
+
+hipError_t count_position_mismatches(const BatchView& b, const double* wp, const uint8_t* mask, const double* vals,
+                                     hipStream_t stream, long long* count_out) {
+  *count_out = 0;
+  const int n_vertices = b.n_segments + b.n_paths;
+  if (n_vertices == 0) return hipSuccess;
+  unsigned long long* d_count = nullptr;
+  hipError_t e = pool_alloc(&d_count, sizeof(unsigned long long));
+  if (e != hipSuccess) return e;
+  unsigned long long h = 0;
+  e = hipMemsetAsync(d_count, 0, sizeof(unsigned long long), stream);
+  if (e == hipSuccess) {
+    MRS_TG_LAUNCH(position_mismatch_kernel, dim3(cdiv(n_vertices, 256)), dim3(256), 0, stream, n_vertices, wp, mask, vals, d_count);
+    e = hipGetLastError();
+  }
+  if (e == hipSuccess) e = hipMemcpyAsync(&h, d_count, sizeof(h), hipMemcpyDeviceToHost, stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(stream);
+  pool_free(d_count);
+  *count_out = (long long)h;
+  return e;
 }
 
 size_t linear_workspace_doubles(const BatchView& b) {

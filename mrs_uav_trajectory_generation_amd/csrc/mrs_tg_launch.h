@@ -66,7 +66,7 @@ hipError_t launch_assemble(const BatchView& b, int d, const double* seg_times, d
 hipError_t launch_solve_linear(const BatchView& b, int d, bool fused, const uint8_t* mask, const double* vals,
                                const double* seg_times, const double* H, const double* Ainv, double* ws,
                                double* coeffs, int32_t* status, double* cost, const int32_t* status_in,
-                               hipStream_t stream);
+                               hipStream_t stream, const double* pos_wp = nullptr);
 // Up to kCopyMax flat copies in ONE launch: how mrs_tg_solve_batch moves arrays between pinned host memory (which the
 // GPU addresses directly) and the device -- a kernel launch costs the host ~3 us, a hipMemcpyAsync 10-25 us.
 constexpr int kCopyMax = 8;
@@ -98,6 +98,10 @@ constexpr int kSampleStateOrders = 5;
 hipError_t launch_sample_states(const BatchView& b, const double* coeffs, const double* seg_times, double dt, int capacity,
                                 int32_t* n_samples, double* states, hipStream_t stream);
 size_t linear_workspace_doubles(const BatchView& b);
+// MRS_TG_FLAG_POSITIONS_ARE_WAYPOINTS, checked: the number of vertices whose position is unconstrained or whose constrained
+// position differs (bitwise) from its waypoint.  Blocks until the count is on the host.
+hipError_t count_position_mismatches(const BatchView& b, const double* wp, const uint8_t* mask, const double* vals,
+                                     hipStream_t stream, long long* count_out);
 // any fixed / free pattern, position-free vertices included (mrs_tg_general.hip): solves the paths flagged in `only` (by
 // path, non-zero) or, without it, the paths whose status is -2; status out = 1 or opt_status' stopping reason
 size_t general_workspace_doubles(const BatchView& b);
@@ -129,6 +133,8 @@ struct RowsTail {
   double* samples = nullptr;
   const double* sample_acc = nullptr;    // the walk's accumulated times (sample_acc_table): filled in by launch_solve_rows
   int sample_acc_n = 0;
+  const double* pos_wp = nullptr;        // MRS_TG_FLAG_POSITIONS_ARE_WAYPOINTS: the compact [vertex][4] array the saturated-device
+                                         // solve reads vertex positions from (the other kernels read the value array)
 };
 
 // A[k] = k additions of dt to 0, the accumulated time of the reference's sampling walk, on the current device: at least
@@ -158,6 +164,7 @@ struct RowsGroup {
   double* coeffs[kRowsGroupMax];
   int32_t* status[kRowsGroupMax];
   double* cost[kRowsGroupMax];
+  const double* pos_wp[kRowsGroupMax];  // per batch: waypoints under MRS_TG_FLAG_POSITIONS_ARE_WAYPOINTS, else nullptr
   int n = 0;
 };
 hipError_t launch_solve_rows_group(const BatchView& b, int d, const RowsGroup& g, hipStream_t stream);

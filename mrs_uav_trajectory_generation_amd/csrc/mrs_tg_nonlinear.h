@@ -31,6 +31,7 @@ struct NonlinearParams {
   // every other outer-loop kernel launch_nonlinear launches estimate_times_kernel.  nullptr: start from seg_times.
   const double* estimate_wp = nullptr;
   const double* estimate_limits = nullptr;
+  const double* pos_wp = nullptr;  // MRS_TG_FLAG_POSITIONS_ARE_WAYPOINTS: where the saturated-device solves read vertex positions
 };
 
 // Paths are sorted by segment count (longest first), so every lane-group class is a contiguous range

@@ -2133,7 +2133,7 @@ hipError_t launch_nonlinear(NonlinearPlan& nl, const BatchView& b, const Nonline
   }
   // 2. trajectory of the last evaluated point (scaleSegmentTimesWithViolation works on poly_opt_'s state)
   if ((e = launch_solve_linear(b, prm.derivative, true, mask, vals, seg_times, nullptr, nullptr, nl.d_ws, coeffs, nullptr,
-                               nullptr, nullptr, stream)) != hipSuccess)
+                               nullptr, nullptr, stream, prm.pos_wp)) != hipSuccess)
     return e;
   if (general && (e = launch_solve_general(b, prm.derivative, mask, vals, seg_times, nl.d_general_solve_ws, coeffs, nullptr, nullptr,
                                            stream, general_flag, nullptr)) != hipSuccess)
@@ -2159,6 +2159,7 @@ hipError_t launch_nonlinear(NonlinearPlan& nl, const BatchView& b, const Nonline
     tail.opt_status = nl.d_opt_status;
     tail.sum_t0 = nl.d_sum_t0;
     tail.seg_times_out = seg_times;
+    tail.pos_wp = prm.pos_wp;
     return launch_solve_quad(b, prm.derivative, mask, vals, seg_times, coeffs, status, cost, nl.d_opt_status, nl.d_ws, stream, tail);
   }
   if (!general && rows_kernel_applies(b, want_samples)) {

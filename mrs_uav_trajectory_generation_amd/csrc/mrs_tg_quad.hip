@@ -55,8 +55,14 @@ constexpr int kQdPaths = 16;  // paths per wavefront
 // 16 doubles less per record: five wavefronts per CU instead of three at 10 segments)
 constexpr int kQdL = 0, kQdLinv = 6, kQdZ = 10, kQdRec = 26;
 
+// staging of a segment's coefficients on their way out (backward sweep): [path][dimension][10], 40 doubles per path.  It lies
+// over the records of vertices v - 1 and v, both consumed when segment v's coefficients exist (two records: 832 doubles)
+constexpr int kQdStage = kN * kD * kQdPaths;  // 640 doubles
+static_assert(2 * kQdRec * kQdPaths >= kQdStage, "two consumed vertex records hold one staged segment");
+
 __host__ __device__ constexpr size_t quad_lds_doubles(int Smax) {
-  return (size_t)(Smax > 1 ? Smax - 1 : 1) * kQdRec * kQdPaths + (size_t)Smax * kQdPaths;  // records | times
+  // records | times [segment][path] | per path: first segment and segment count (two ints each: 16 doubles in all)
+  return (size_t)(Smax > 1 ? Smax - 1 : 1) * kQdRec * kQdPaths + (size_t)Smax * kQdPaths + kQdPaths;
 }
 
 // T^(m + 1 - 2d), m = 0..8, the objective order as select masks (no branch tree per segment)
@@ -91,7 +97,7 @@ __device__ __forceinline__ void solve_quad_body(const BatchView& b, int d, const
                                                 const double* __restrict__ vals, const double* seg_times,
                                                 double* __restrict__ coeffs, int32_t* __restrict__ status,
                                                 double* __restrict__ cost, const int32_t* __restrict__ status_in, double* ws,
-                                                const RowsTail& tail, int block) {
+                                                const RowsTail& tail, int block, const double* __restrict__ pos_wp) {
   extern __shared__ double lds[];
   const int lane = threadIdx.x, pl = lane >> 2, dim = lane & 3;
   const int q = block * kQdPaths + pl;
@@ -100,7 +106,13 @@ __device__ __forceinline__ void solve_quad_body(const BatchView& b, int d, const
   const int S = pr.S;
   const int Smax = b.max_segments;
   double* rec0 = lds;
-  double* tbuf = lds + (size_t)(Smax > 1 ? Smax - 1 : 1) * kQdRec * kQdPaths;  // [segment][path]
+  const int n_rec = Smax > 1 ? Smax - 1 : 1;
+  double* tbuf = lds + (size_t)n_rec * kQdRec * kQdPaths;  // [segment][path]
+  int* pinfo = reinterpret_cast<int*>(tbuf + (size_t)Smax * kQdPaths);  // [path] first segment | [16 + path] segments (0: no path)
+  if (dim == 0) {
+    pinfo[pl] = pr.s0;
+    pinfo[kQdPaths + pl] = active ? S : 0;
+  }
 
   // ---- prologue: times (scaled, for the last solve of a Mellinger pipeline), plainness of the path
   const bool scaling = tail.maxima != nullptr;
@@ -166,12 +178,16 @@ __device__ __forceinline__ void solve_quad_body(const BatchView& b, int d, const
       for (int off = 32; off >= 4; off >>= 1) s = max(s, __shfl_xor(s, off, 64));
       Smx = __builtin_amdgcn_readfirstlane(s);
     }
-    const double* pv = vals + (size_t)pr.v0 * kHalf * kD + dim;  // position of vertex v, this dimension: pv[v * 20]
+    // position of vertex v, this dimension: pv[v * pstride].  From the caller's value array that is 8 bytes out of every 160
+    // (and whole cache lines come along: 137 MB read for 45 MB of inputs at 65536 x 10); under
+    // MRS_TG_FLAG_POSITIONS_ARE_WAYPOINTS from the compact [vertex][4] waypoint array, whose every byte is used
+    const double* pv = pos_wp != nullptr ? pos_wp + (size_t)pr.v0 * kD + dim : vals + (size_t)pr.v0 * kHalf * kD + dim;
+    const size_t pstride = pos_wp != nullptr ? (size_t)kD : (size_t)(kHalf * kD);
     // ---- forward: block Cholesky over the vertex chain
     double Sm[10], y[kNB];
     // positions are requested three segments ahead: with less than one wavefront per SIMD nothing else hides a trip to memory,
     // and a segment step is shorter than one
-    auto pos = [&](int v) { return (active && v <= S) ? pv[(size_t)v * kHalf * kD] : 0.0; };
+    auto pos = [&](int v) { return (active && v <= S) ? pv[(size_t)v * pstride] : 0.0; };
     double p_cur = pos(0), p_nxt = pos(1), p_a2 = pos(2), p_a3 = pos(3);
     for (int i = 0; i < Smx; ++i) {
       const bool on = active && i < S;
@@ -269,7 +285,7 @@ __device__ __forceinline__ void solve_quad_body(const BatchView& b, int d, const
     // ---- backward: x_v = L^-T (z - W x_{v+1}); coefficients and cost of segment v from x_v, x_{v+1}
     double xn[kNB] = {0.0, 0.0, 0.0, 0.0};  // the last vertex is fully constrained
     // (positions again, requested three vertices ahead of their use; a path shorter than the wavefront's longest joins late)
-    auto posb = [&](int v) { return (active && v >= 0 && v <= S) ? pv[(size_t)v * kHalf * kD] : 0.0; };
+    auto posb = [&](int v) { return (active && v >= 0 && v <= S) ? pv[(size_t)v * pstride] : 0.0; };
     double p_end = posb(S), p_b0 = posb(Smx - 1), p_b1 = posb(Smx - 2), p_b2 = posb(Smx - 3);
     for (int v = Smx - 1; v >= 0; --v) {
       const bool on = active && v < S;
@@ -337,12 +353,46 @@ __device__ __forceinline__ void solve_quad_body(const BatchView& b, int d, const
           c[k] = s * tik;
           tik *= ti;
         }
-        double2* out = reinterpret_cast<double2*>(coeffs + ((size_t)(pr.s0 + v) * kD + dim) * kN);
-#pragma unroll
-        for (int k = 0; k < kN; k += 2) out[k / 2] = make_double2(c[k], c[k + 1]);
         double p2[9];
         quad_powers(T, d1, d2, d4, p2);  // p2[0] = T^(1 - 2d)
         my_cost = fma(cost_quadratic_form_d(d, cb), p2[0], my_cost);
+        // ---- the coefficients leave.  A lane owns 80 consecutive bytes and its neighbours' are 80 bytes (dimension) or a
+        // whole path away: stored from the registers, a wave instruction is 64 pieces of 16 bytes in ~48 cache lines, and
+        // those 13 million requests -- not the arithmetic -- were what bounded the kernel (HISTORY.md).  Staged through the
+        // LDS space of the two vertex records this sweep has consumed, 16 lanes store 256 consecutive bytes of ONE path.
+        const int r_stage = v > 0 ? v - 1 : 0;
+        if (r_stage + 2 <= n_rec) {
+          double2* st = reinterpret_cast<double2*>(rec0 + (size_t)r_stage * kQdRec * kQdPaths + pl * (kN * kD) + dim * kN);
+#pragma unroll
+          for (int k = 0; k < kN; k += 2) st[k / 2] = make_double2(c[k], c[k + 1]);
+        } else {  // (the sweep's first step: one consumed record only)
+          double2* out = reinterpret_cast<double2*>(coeffs + ((size_t)(pr.s0 + v) * kD + dim) * kN);
+#pragma unroll
+          for (int k = 0; k < kN; k += 2) out[k / 2] = make_double2(c[k], c[k + 1]);
+        }
+      }
+      {
+        const int r_stage = v > 0 ? v - 1 : 0;
+        if (r_stage + 2 <= n_rec) {  // (uniform)
+          const double* stage = rec0 + (size_t)r_stage * kQdRec * kQdPaths;
+          quad_wave_sync();
+          // bytes 0..255 of a path's 320: 16 lanes per path, four paths per instruction
+#pragma unroll
+          for (int g = 0; g < 4; ++g) {
+            const int P = 4 * g + (lane >> 4), piece = lane & 15;
+            const int s0P = pinfo[P], SP = pinfo[kQdPaths + P];
+            if (v < SP) {
+              const double2 val = *reinterpret_cast<const double2*>(stage + P * (kN * kD) + piece * 2);
+              *reinterpret_cast<double2*>(coeffs + ((size_t)(s0P + v) * (kN * kD) + piece * 2)) = val;
+            }
+          }
+          // bytes 256..319: the path's own four lanes
+          if (on) {
+            const double2 val = *reinterpret_cast<const double2*>(stage + pl * (kN * kD) + 32 + dim * 2);
+            *reinterpret_cast<double2*>(coeffs + ((size_t)(pr.s0 + v) * (kN * kD) + 32 + dim * 2)) = val;
+          }
+          quad_wave_sync();  // (the next step stages over record v - 1 of this area)
+        }
       }
 #pragma unroll
       for (int r = 0; r < kNB; ++r) xn[r] = x[r];
@@ -374,7 +424,7 @@ __global__ __launch_bounds__(64, MRS_TG_QUAD_WAVES) void solve_quad_kernel(Batch
                                                         double* __restrict__ coeffs, int32_t* __restrict__ status,
                                                         double* __restrict__ cost, const int32_t* __restrict__ status_in,
                                                         double* ws, RowsTail tail) {
-  solve_quad_body(b, d, mask, vals, seg_times, coeffs, status, cost, status_in, ws, tail, (int)blockIdx.x);
+  solve_quad_body(b, d, mask, vals, seg_times, coeffs, status, cost, status_in, ws, tail, (int)blockIdx.x, tail.pos_wp);
 }
 
 // several batches of ONE plan in one launch (as solve_rows_group_kernel): workgroups [j * blocks_per_batch, ...) solve batch j
@@ -383,7 +433,7 @@ __global__ __launch_bounds__(64, MRS_TG_QUAD_GROUP_WAVES) void solve_quad_group_
                                                               int blocks_per_batch) {
   const int j = __builtin_amdgcn_readfirstlane((int)blockIdx.x / blocks_per_batch);
   solve_quad_body(b, d, g.mask[j], g.vals[j], g.seg_times[j], g.coeffs[j], g.status[j], g.cost[j], nullptr,
-                  ws + (size_t)j * ws_batch_doubles, RowsTail(), (int)blockIdx.x - j * blocks_per_batch);
+                  ws + (size_t)j * ws_batch_doubles, RowsTail(), (int)blockIdx.x - j * blocks_per_batch, g.pos_wp[j]);
 }
 
 // ---------------------------------------------------------------------------------------------

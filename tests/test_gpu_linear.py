@@ -70,6 +70,16 @@ def test_linear_golden_cases(gpu_ctx, golden, fused):
         oc = po.solve_linear(case["derivative_to_optimize"], batch.fixed_mask, batch.fixed_values, t)
         err_oracle = util.coeff_error(oc, exact)
         assert out["status"][0] == 1
+        if case["name"] == "bench_slot15_path237_short_segment":
+            # the worst-conditioned of the 20 480 paths of bench.py's twenty slots (a 0.179 s segment between 4.7 s and 4.0 s:
+            # 1e11 between neighbouring blocks).  Against the 60-digit solution: oracle 5.4e-7, HIP 4.1e-8 (fused) -- the
+            # figure bench.py reports as in_flight_slots_vs_cpu_ref is the ORACLE's error; the by-product cost of the
+            # materialised-block route loses the digits the conditioning takes (8e-7), the fused route's 0.5 c^T Q c 3e-9
+            primal = fused and os.environ.get("MRS_TG_ROWS_KERNEL") != "0"
+            assert abs(out["cost"][0] - case["cost"]) <= (1e-8 if primal else 3e-6) * abs(case["cost"])
+            assert err < 1e-7 and err < 0.25 * err_oracle, (err, err_oracle)
+            assert util.coeff_error(out["coeffs"], oc) <= 1.2 * err_oracle
+            continue
         if case["name"] == "bench1024_path74_short_segment":
             # (cost: the fused kernel evaluates 0.5 c^T Q c, 1e-10 here; the blocks kernel's elimination by-product
             # 0.5 (f^T H f - sum |z|^2) loses the digits the conditioning takes, 1e-8)

@@ -213,7 +213,7 @@ def test_nonlinear_end_to_end_vs_oracle(gpu_ctx, n_seg, n_paths):
     # measured: 100 % on every uniform batch, 94 of 96 on the ragged one (two paths take another branch of the line search on
     # a 1e-9 difference in J); the stopping reason and the sample count agree on ALL paths
     print("RATE end_to_end %s: %d / %d" % (n_seg, good, batch.n_paths))
-    assert good >= (0.97 if n_seg == "ragged" else 1.0) * batch.n_paths, (good, batch.n_paths)
+    assert good >= batch.n_paths - (3 if n_seg == "ragged" else 0), (good, batch.n_paths)   # (measured 94 / 96 on the ragged batch)
     # statuses on the REFERENCE's rule: equal on every path the product does not flag as a runaway, and the flagged set is
     # the set of paths whose oracle result ran away too (the product's -4 against the reference's success code, visible here)
     assert util.status_matches(out["status"], ref["status"]).all()
@@ -365,10 +365,10 @@ def test_mixed_constraint_patterns_vs_oracle(gpu_ctx, deriv):
     # 
     print("RATE mixed deriv %d: 1e-6 %.4f 1e-3 %.4f" % (deriv, (dt < 1e-6).mean(), (dt < 1e-3).mean()))
     assert same.all(), same.mean()
-    # round 3: 99.48 % / 99.09 % / 99.35 % to 1e-6, 100 % / 100 % / 99.87 % to 1e-3; where the rest comes from:
-    # profiles/round3_divergence_*.txt (scripts/divergence_histogram.py)
-    assert (dt < 1e-6).mean() >= 0.988, (dt < 1e-6).mean()
-    assert (dt < 1e-3).mean() >= 0.998, (dt < 1e-3).mean()
+    # rounds 3-5: 99.48 % / 99.09 % / 99.35 % to 1e-6 (764 / 761 / 763 of 768), 100 % / 100 % / 99.87 % to 1e-3; where the rest
+    # comes from: profiles/round3_divergence_*.txt (scripts/divergence_histogram.py).  Gates: the measured count less two paths
+    assert (dt < 1e-6).sum() >= {2: 762, 3: 759, 4: 761}[deriv], (dt < 1e-6).sum()
+    assert (dt < 1e-3).sum() >= {2: 767, 3: 767, 4: 765}[deriv], (dt < 1e-3).sum()
 
 
 @pytest.mark.parametrize("deriv", [2, 3, 4])
@@ -391,8 +391,9 @@ def test_mixed_constraint_patterns_through_the_one_wavefront_kernel(gpu_ctx, der
     # stopping reason and sample count: measured 100 % on these seeds, 99.95 % (1 of 2048) on the same batch family in
     # profiles/round4_parity_sweep.txt -- a rate consistent with that, not equality that holds by the choice of seed
     assert same.mean() >= 0.998, same.mean()
-    assert (dt < 1e-6).mean() >= 0.988, (dt < 1e-6).mean()
-    assert (dt < 1e-3).mean() >= 0.998, (dt < 1e-3).mean()
+    # measured (round 5): 767 / 767 / 764 of 768 to 1e-6, all to 1e-3; gates: the measured count less two paths
+    assert (dt < 1e-6).sum() >= {2: 765, 3: 765, 4: 762}[deriv], (dt < 1e-6).sum()
+    assert (dt < 1e-3).sum() >= 766, (dt < 1e-3).sum()
 
 
 @pytest.mark.parametrize("dt,cap", [(0.01, 16384), (0.05, 4096), (0.5, 256), (1.0, 128), (0.3, 512)])
