@@ -52,9 +52,6 @@
 
 namespace mrs_tg {
 
-#ifndef MRS_TG_LEAN_RELOAD
-#define MRS_TG_LEAN_RELOAD 0
-#endif
 #ifndef MRS_TG_MAXIMA_WAVES
 #define MRS_TG_MAXIMA_WAVES 4
 #endif
@@ -63,10 +60,10 @@ namespace mrs_tg {
 #endif
 // The careful re-run (MRS_TG_FLAG_CAREFUL_COST: a second outer-loop kernel with the primal cost for the paths whose by-product
 // cost failed the guard) moved 65536 x 10 from 99.9435 % to 99.9481 % agreement with the oracle at 2-3x the outer loop's time
-// (DESIGN.md section 5): it is not in the shipped library.  -DMRS_TG_WITH_CAREFUL=1 builds it in
-// (python -m mrs_uav_trajectory_generation_amd.build --variant careful -DMRS_TG_WITH_CAREFUL=1).
+// (DESIGN.md section 5): a compile-time option, ON in the shipped library since ABI 4 (build.py: MRS_TG_WITH_CAREFUL=0 in the
+// environment builds without it; mrs_tg_capabilities() reports which).
 #ifndef MRS_TG_WITH_CAREFUL
-#define MRS_TG_WITH_CAREFUL 0
+#define MRS_TG_WITH_CAREFUL 1
 #endif
 
 // ---- two-sided evaluation for small batches ------------------------------------------------------------------
@@ -391,6 +388,7 @@ __device__ __forceinline__ double evaluate_lean(const double* tabs, const double
     const int k = g + (r << g_shift);
     double Jk = 0.0, qfk = 0.0;
     if (!MASKED && active && k <= S && (k == 0 || S > 1)) {
+      // (the table: compile-time constants of order 4 -- the plain-path kernels never run another order; mrs_tg_sweep.hpp, PsTab)
       // The plain sweep (start | interior ... | end), written out for four dimensions per lane with the smallest live set
       // the step allows.  The right-hand-side brackets are not materialised per (dimension, row) (FastStep::w: 36 doubles
       // that lived across the whole step and pushed the kernel to 256 VGPRs + 116 bytes of scratch): row r of every
@@ -401,32 +399,20 @@ __device__ __forceinline__ double evaluate_lean(const double* tabs, const double
       double Sm[10], y[kNB][4], qf, red = 0.0;
       {  // segment 0: the start vertex is fully constrained, the state moves to vertex 1
         double p2[9];
-        segment_powers(perturbed_time(pt, 0, k, corr), d, p2);
+        segment_powers_c<4>(perturbed_time(pt, 0, k, corr), p2);
         qf = p2[0] * qs[0];
 #pragma unroll
         for (int r = 0; r < kNB; ++r) {
 #pragma unroll
-          for (int c = 0; c <= r; ++c) Sm[tri(r, c)] = tab[26 + tri(r, c)] * p2[r + c + 2];
-          const double cF = tab[40 + r] * p2[r + 1];
+          for (int c = 0; c <= r; ++c) Sm[tri(r, c)] = PsTab<4>::at(26 + tri(r, c)) * p2[r + c + 2];
+          const double cF = PsTab<4>::at(40 + r) * p2[r + 1];
 #pragma unroll
           for (int q = 0; q < 4; ++q) y[r][q] = -(cF * dp[q]);
         }
       }
       for (int i = 1; i < S; ++i) {
-#if MRS_TG_LEAN_RELOAD
-        // the far-block and coupling constants are read from LDS in every step (the pointer goes through an empty asm, so
-        // the loads cannot be hoisted out of the loop): hoisted, all 45 table constants live in 90 VGPRs across the sweep
-        const double* tabr = tab;
-        asm volatile("" : "+v"(tabr));
-#else
-        const double* tabr = tab;
-#endif
-        const double* tabn = MRS_TG_LEAN_RELOAD == 2 ? tabr : tab;  // 2: the near-block constants as well
-        const double* tabc = (MRS_TG_LEAN_RELOAD == 1 || MRS_TG_LEAN_RELOAD == 2 || MRS_TG_LEAN_RELOAD == 4) ? tabr : tab;  // coupling block
-        const double* tabf = (MRS_TG_LEAN_RELOAD == 1 || MRS_TG_LEAN_RELOAD == 2 || MRS_TG_LEAN_RELOAD == 5) ? tabr : tab;  // far block
-        const double* tabw = (MRS_TG_LEAN_RELOAD >= 1) ? tabr : tab;                                                        // far brackets (3: only these)
         double p2[9];
-        segment_powers(perturbed_time(pt, i, k, corr), d, p2);
+        segment_powers_c<4>(perturbed_time(pt, i, k, corr), p2);
         double dq[4];
 #pragma unroll
         for (int q = 0; q < 4; ++q) dq[q] = dp[i * 4 + q];
@@ -435,8 +421,8 @@ __device__ __forceinline__ double evaluate_lean(const double* tabs, const double
 #pragma unroll
         for (int r = 0; r < kNB; ++r) {
 #pragma unroll
-          for (int c = 0; c <= r; ++c) Sm[tri(r, c)] = fma(tabn[tri(r, c)], p2[r + c + 2], Sm[tri(r, c)]);
-          const double cN = tabn[36 + r] * p2[r + 1];
+          for (int c = 0; c <= r; ++c) Sm[tri(r, c)] = fma(PsTab<4>::at(tri(r, c)), p2[r + c + 2], Sm[tri(r, c)]);
+          const double cN = PsTab<4>::at(36 + r) * p2[r + 1];
 #pragma unroll
           for (int q = 0; q < 4; ++q) y[r][q] = fma(-cN, dq[q], y[r][q]);
         }
@@ -473,7 +459,7 @@ __device__ __forceinline__ double evaluate_lean(const double* tabs, const double
           for (int c = 0; c < kNB; ++c)
 #pragma unroll
             for (int rr = 0; rr < kNB; ++rr) {
-              double t = tabc[10 + rr * kNB + c] * p2[rr + c + 2];
+              double t = PsTab<4>::at(10 + rr * kNB + c) * p2[rr + c + 2];
 #pragma unroll
               for (int m = 0; m < rr; ++m) t = fma(-L[tri(rr, m)], W[m][c], t);
               W[rr][c] = t * Linv[rr];
@@ -482,12 +468,12 @@ __device__ __forceinline__ double evaluate_lean(const double* tabs, const double
           for (int rr = 0; rr < kNB; ++rr) {
 #pragma unroll
             for (int c = 0; c <= rr; ++c) {
-              double t = tabf[26 + tri(rr, c)] * p2[rr + c + 2];
+              double t = PsTab<4>::at(26 + tri(rr, c)) * p2[rr + c + 2];
 #pragma unroll
               for (int m = 0; m < kNB; ++m) t = fma(-W[m][rr], W[m][c], t);
               Sm[tri(rr, c)] = t;
             }
-            const double cF = tabw[40 + rr] * p2[rr + 1];
+            const double cF = PsTab<4>::at(40 + rr) * p2[rr + 1];
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
               double t = -(cF * dq[q]);
@@ -549,6 +535,14 @@ __device__ __forceinline__ double evaluate_lean(const double* tabs, const double
 // their partner's state to their own and factor the middle vertex.  For plain paths with 4 <= S and S + 4 <= G.
 //   lanes of the group: 0: x left | 1 .. m: vector k = lane, left | m + 1: B' left |
 //                       m + 2: x right | m + 2 + r: vector m + r, right (r = 1 .. S - m) | S + 3: B' right
+#ifndef MRS_TG_LEAN_CONST_TABLE
+#define MRS_TG_LEAN_CONST_TABLE 1
+#endif
+#if MRS_TG_LEAN_CONST_TABLE
+#define LEAN_TAB(e) PsTab<4>::at(e)
+#else
+#define LEAN_TAB(e) Tab_regs.at(e)
+#endif
 __device__ __forceinline__ double evaluate_lean_shared(const double* tabs, const double* ev, double* pub, int S, int Sb, int d,
                                                        const double* pt, double* grad, int g, int G, bool active, int* tripped) {
   const double* dp = ev;
@@ -561,12 +555,25 @@ __device__ __forceinline__ double evaluate_lean_shared(const double* tabs, const
   const bool pure = r == nhalf + 1, base = r == 0;
   const int k = base ? 0 : pure ? (left ? S : 1) : (left ? r : m + r);
   const double corr = kGradStep / ((double)S - 1.0);
-  double tab[kPsTable];
+  // the table: compile-time constants of order 4, the same for both directions (mrs_tg_sweep.hpp, PsTab): a right-to-left
+  // lane sweeps in sign-transformed variables and `flip` = -1 puts its state into the common frame where it meets a left one
+#if MRS_TG_LEAN_CONST_TABLE
+  using Tab = PsTab<4>;
+  const double flip = left ? 1.0 : -1.0;
+  (void)tabs;
+  (void)d;
+#else  // (A / B build: the per-lane table of its direction in 90 registers, as until round 4)
+  struct {
+    double t[kPsTable];
+    __device__ __forceinline__ double at(int e) const { return t[e]; }
+  } Tab_regs;
   {
     const double* tsrc = tabs + (left ? 0 : kPsTable);
 #pragma unroll
-    for (int e = 0; e < kPsTable; ++e) tab[e] = tsrc[e];
+    for (int e = 0; e < kPsTable; ++e) Tab_regs.t[e] = tsrc[e];
   }
+  const double flip = 1.0;
+#endif
   double Sm[10], y[kNB][4], qf = 0.0, red = 0.0;
 #pragma unroll
   for (int e = 0; e < 10; ++e) Sm[e] = 0.0;
@@ -581,7 +588,7 @@ __device__ __forceinline__ double evaluate_lean_shared(const double* tabs, const
       double T = pt[i];
       if (k > 0) T = (i == k - 1) ? T + kGradStep : fmax(T - corr, kTimeLowerBound);
       double p2[9];
-      segment_powers(T, d, p2);
+      segment_powers_c<4>(T, p2);
       double dq[4];
 #pragma unroll
       for (int q = 0; q < 4; ++q) dq[q] = dp[i * 4 + q];
@@ -590,8 +597,8 @@ __device__ __forceinline__ double evaluate_lean_shared(const double* tabs, const
 #pragma unroll
         for (int rr = 0; rr < kNB; ++rr) {
 #pragma unroll
-          for (int c = 0; c <= rr; ++c) Sm[tri(rr, c)] = tab[26 + tri(rr, c)] * p2[rr + c + 2];
-          const double cF = tab[40 + rr] * p2[rr + 1];
+          for (int c = 0; c <= rr; ++c) Sm[tri(rr, c)] = LEAN_TAB(26 + tri(rr, c)) * p2[rr + c + 2];
+          const double cF = LEAN_TAB(40 + rr) * p2[rr + 1];
 #pragma unroll
           for (int q = 0; q < 4; ++q) y[rr][q] = -(cF * dq[q]);
         }
@@ -600,8 +607,8 @@ __device__ __forceinline__ double evaluate_lean_shared(const double* tabs, const
 #pragma unroll
         for (int rr = 0; rr < kNB; ++rr) {
 #pragma unroll
-          for (int c = 0; c <= rr; ++c) Sm[tri(rr, c)] = fma(tab[tri(rr, c)], p2[rr + c + 2], Sm[tri(rr, c)]);
-          const double cN = tab[36 + rr] * p2[rr + 1];
+          for (int c = 0; c <= rr; ++c) Sm[tri(rr, c)] = fma(LEAN_TAB(tri(rr, c)), p2[rr + c + 2], Sm[tri(rr, c)]);
+          const double cN = LEAN_TAB(36 + rr) * p2[rr + 1];
 #pragma unroll
           for (int q = 0; q < 4; ++q) y[rr][q] = fma(-cN, dq[q], y[rr][q]);
         }
@@ -635,7 +642,7 @@ __device__ __forceinline__ double evaluate_lean_shared(const double* tabs, const
         for (int c = 0; c < kNB; ++c)
 #pragma unroll
           for (int rr = 0; rr < kNB; ++rr) {
-            double t = tab[10 + rr * kNB + c] * p2[rr + c + 2];
+            double t = LEAN_TAB(10 + rr * kNB + c) * p2[rr + c + 2];
 #pragma unroll
             for (int mm = 0; mm < rr; ++mm) t = fma(-L[tri(rr, mm)], W[mm][c], t);
             W[rr][c] = t * Linv[rr];
@@ -644,12 +651,12 @@ __device__ __forceinline__ double evaluate_lean_shared(const double* tabs, const
         for (int rr = 0; rr < kNB; ++rr) {
 #pragma unroll
           for (int c = 0; c <= rr; ++c) {
-            double t = tab[26 + tri(rr, c)] * p2[rr + c + 2];
+            double t = LEAN_TAB(26 + tri(rr, c)) * p2[rr + c + 2];
 #pragma unroll
             for (int mm = 0; mm < kNB; ++mm) t = fma(-W[mm][rr], W[mm][c], t);
             Sm[tri(rr, c)] = t;
           }
-          const double cF = tab[40 + rr] * p2[rr + 1];
+          const double cF = LEAN_TAB(40 + rr) * p2[rr + 1];
 #pragma unroll
           for (int q = 0; q < 4; ++q) {
             double t = -(cF * dq[q]);
@@ -666,6 +673,7 @@ __device__ __forceinline__ double evaluate_lean_shared(const double* tabs, const
   const bool base_right = !left && base;
   if (valid && (pure || base_right)) {
     double* ps = pub + (base_right ? 0 : (left ? 2 : 1)) * 28;
+    lean_flip_state(Sm, y, flip);  // a right lane's state leaves in the common (left-to-right) frame
 #pragma unroll
     for (int e = 0; e < 10; ++e) ps[e] = Sm[e];
 #pragma unroll
@@ -680,6 +688,7 @@ __device__ __forceinline__ double evaluate_lean_shared(const double* tabs, const
   double Jk = 0.0, qfk = 0.0;
   if (join) {
     const double* ps = pub + (left ? (base ? 0 : 1) : 2) * 28;
+    lean_flip_state(Sm, y, flip);  // a right lane joins in the common frame as well (the factorisation's |z|^2 is frame-independent)
 #pragma unroll
     for (int e = 0; e < 10; ++e) Sm[e] += ps[e];
 #pragma unroll
@@ -725,6 +734,7 @@ __device__ __forceinline__ double evaluate_lean_shared(const double* tabs, const
   return J0;
 }
 
+#undef LEAN_TAB
 // per-group LDS of the plain-path kernels and their staging
 __host__ __device__ constexpr int lean_group_doubles(int Sb) {
   return (5 + 2 * kLbfgsM) * Sb + (kLbfgsM + 1) + kTickState + lean_eval_doubles(Sb);

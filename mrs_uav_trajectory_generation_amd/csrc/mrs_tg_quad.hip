@@ -43,6 +43,9 @@
 #ifndef MRS_TG_QUAD_WAVES
 #define MRS_TG_QUAD_WAVES 1
 #endif
+#ifndef MRS_TG_QUAD_EXP
+#define MRS_TG_QUAD_EXP 0
+#endif
 #ifndef MRS_TG_QUAD_GROUP_WAVES
 #define MRS_TG_QUAD_GROUP_WAVES 2
 #endif
@@ -55,14 +58,12 @@ constexpr int kQdPaths = 16;  // paths per wavefront
 // 16 doubles less per record: five wavefronts per CU instead of three at 10 segments)
 constexpr int kQdL = 0, kQdLinv = 6, kQdZ = 10, kQdRec = 26;
 
-// staging of a segment's coefficients on their way out (backward sweep): [path][dimension][10], 40 doubles per path.  It lies
-// over the records of vertices v - 1 and v, both consumed when segment v's coefficients exist (two records: 832 doubles)
-constexpr int kQdStage = kN * kD * kQdPaths;  // 640 doubles
-static_assert(2 * kQdRec * kQdPaths >= kQdStage, "two consumed vertex records hold one staged segment");
-
 __host__ __device__ constexpr size_t quad_lds_doubles(int Smax) {
-  // records | times [segment][path] | per path: first segment and segment count (two ints each: 16 doubles in all)
-  return (size_t)(Smax > 1 ? Smax - 1 : 1) * kQdRec * kQdPaths + (size_t)Smax * kQdPaths + kQdPaths;
+  return (size_t)(Smax > 1 ? Smax - 1 : 1) * kQdRec * kQdPaths + (size_t)Smax * kQdPaths  // records | times
+#if MRS_TG_QUAD_EXP == 5
+         + kQdPaths  // per path: first segment and segment count (ints)
+#endif
+      ;
 }
 
 // T^(m + 1 - 2d), m = 0..8, the objective order as select masks (no branch tree per segment)
@@ -106,14 +107,15 @@ __device__ __forceinline__ void solve_quad_body(const BatchView& b, int d, const
   const int S = pr.S;
   const int Smax = b.max_segments;
   double* rec0 = lds;
+  double* tbuf = lds + (size_t)(Smax > 1 ? Smax - 1 : 1) * kQdRec * kQdPaths;  // [segment][path]
+#if MRS_TG_QUAD_EXP == 5
   const int n_rec = Smax > 1 ? Smax - 1 : 1;
-  double* tbuf = lds + (size_t)n_rec * kQdRec * kQdPaths;  // [segment][path]
-  int* pinfo = reinterpret_cast<int*>(tbuf + (size_t)Smax * kQdPaths);  // [path] first segment | [16 + path] segments (0: no path)
+  int* pinfo = reinterpret_cast<int*>(tbuf + (size_t)Smax * kQdPaths);
   if (dim == 0) {
     pinfo[pl] = pr.s0;
     pinfo[kQdPaths + pl] = active ? S : 0;
   }
-
+#endif
   // ---- prologue: times (scaled, for the last solve of a Mellinger pipeline), plainness of the path
   const bool scaling = tail.maxima != nullptr;
   double t_sum = 0.0;
@@ -284,7 +286,10 @@ __device__ __forceinline__ void solve_quad_body(const BatchView& b, int d, const
     quad_wave_sync();  // (lane 0 of a quad wrote L and W for the other three)
     // ---- backward: x_v = L^-T (z - W x_{v+1}); coefficients and cost of segment v from x_v, x_{v+1}
     double xn[kNB] = {0.0, 0.0, 0.0, 0.0};  // the last vertex is fully constrained
-    // (positions again, requested three vertices ahead of their use; a path shorter than the wavefront's longest joins late)
+    // (positions again, requested three vertices ahead of their use; a path shorter than the wavefront's longest joins late.
+    // Keeping a copy of the positions in LDS instead -- no global load in this loop, so no s_waitcnt vmcnt(0) in front of
+    // every step's stores -- was measured in round 5: no change at 65536 x 10, and the 5.6 KB it adds per wavefront cost
+    // the grouped launch its fifth wavefront per CU: HISTORY.md)
     auto posb = [&](int v) { return (active && v >= 0 && v <= S) ? pv[(size_t)v * pstride] : 0.0; };
     double p_end = posb(S), p_b0 = posb(Smx - 1), p_b1 = posb(Smx - 2), p_b2 = posb(Smx - 3);
     for (int v = Smx - 1; v >= 0; --v) {
@@ -356,44 +361,66 @@ __device__ __forceinline__ void solve_quad_body(const BatchView& b, int d, const
         double p2[9];
         quad_powers(T, d1, d2, d4, p2);  // p2[0] = T^(1 - 2d)
         my_cost = fma(cost_quadratic_form_d(d, cb), p2[0], my_cost);
-        // ---- the coefficients leave.  A lane owns 80 consecutive bytes and its neighbours' are 80 bytes (dimension) or a
-        // whole path away: stored from the registers, a wave instruction is 64 pieces of 16 bytes in ~48 cache lines, and
-        // those 13 million requests -- not the arithmetic -- were what bounded the kernel (HISTORY.md).  Staged through the
-        // LDS space of the two vertex records this sweep has consumed, 16 lanes store 256 consecutive bytes of ONE path.
-        const int r_stage = v > 0 ? v - 1 : 0;
-        if (r_stage + 2 <= n_rec) {
-          double2* st = reinterpret_cast<double2*>(rec0 + (size_t)r_stage * kQdRec * kQdPaths + pl * (kN * kD) + dim * kN);
+        // the coefficients leave as five 16-byte pieces per lane (a lane owns 80 consecutive bytes).  Staging them through
+        // the LDS of the consumed vertex records so that 16 lanes store 256 consecutive bytes of one path was built and
+        // measured in round 5: 65536 x 10 129 -> 156 us -- the LDS round trip and its two wavefront syncs per step cost a
+        // lone wavefront more than the 4x fewer write requests return (HISTORY.md)
+        double2* out = reinterpret_cast<double2*>(coeffs + ((size_t)(pr.s0 + v) * kD + dim) * kN);
+#if MRS_TG_QUAD_EXP == 5   // experiment: staged through the LDS of the consumed vertex records (256 B of one path per 16 lanes)
+        (void)out;
+        if ((v > 0 ? v - 1 : 0) + 2 <= n_rec) {
+          double2* st = reinterpret_cast<double2*>(rec0 + (size_t)(v > 0 ? v - 1 : 0) * kQdRec * kQdPaths + pl * (kN * kD) + dim * kN);
 #pragma unroll
           for (int k = 0; k < kN; k += 2) st[k / 2] = make_double2(c[k], c[k + 1]);
-        } else {  // (the sweep's first step: one consumed record only)
-          double2* out = reinterpret_cast<double2*>(coeffs + ((size_t)(pr.s0 + v) * kD + dim) * kN);
+        } else {
+          double2* o5 = reinterpret_cast<double2*>(coeffs + ((size_t)(pr.s0 + v) * kD + dim) * kN);
 #pragma unroll
-          for (int k = 0; k < kN; k += 2) out[k / 2] = make_double2(c[k], c[k + 1]);
+          for (int k = 0; k < kN; k += 2) o5[k / 2] = make_double2(c[k], c[k + 1]);
+        }
+#elif MRS_TG_QUAD_EXP == 1   // experiment: the coefficients are computed and not stored
+#pragma unroll
+        for (int k = 0; k < kN; ++k) asm volatile("" ::"v"(c[k]));
+        (void)out;
+#elif MRS_TG_QUAD_EXP == 3  // experiment: the same pieces into a 5 KB window per wavefront (L2 hits, no HBM write traffic)
+        double2* o3 = reinterpret_cast<double2*>(coeffs + (size_t)block * 640 + lane * 10);
+#pragma unroll
+        for (int k = 0; k < kN; k += 2) o3[k / 2] = make_double2(c[k], c[k + 1]);
+        (void)out;
+#elif MRS_TG_QUAD_EXP == 4  // experiment: perfectly coalesced (wrong) layout: instruction k writes 64 consecutive 16-byte pieces
+        double2* o4 = reinterpret_cast<double2*>(coeffs + ((size_t)block * Smax + v) * 640);
+#pragma unroll
+        for (int k = 0; k < kN; k += 2) o4[(k / 2) * 64 + lane] = make_double2(c[k], c[k + 1]);
+        (void)out;
+#elif MRS_TG_QUAD_EXP == 2  // experiment: streaming stores
+#pragma unroll
+        for (int k = 0; k < kN; k += 2) {
+          __builtin_nontemporal_store(c[k], reinterpret_cast<double*>(out) + k);
+          __builtin_nontemporal_store(c[k + 1], reinterpret_cast<double*>(out) + k + 1);
+        }
+#else
+#pragma unroll
+        for (int k = 0; k < kN; k += 2) out[k / 2] = make_double2(c[k], c[k + 1]);
+#endif
+      }
+#if MRS_TG_QUAD_EXP == 5
+      if ((v > 0 ? v - 1 : 0) + 2 <= n_rec) {  // (uniform)
+        const double* stage = rec0 + (size_t)(v > 0 ? v - 1 : 0) * kQdRec * kQdPaths;
+        quad_wave_sync();
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const int P = 4 * g + (lane >> 4), piece = lane & 15;
+          const int s0P = pinfo[P], SP = pinfo[kQdPaths + P];
+          if (v < SP) {
+            const double2 val = *reinterpret_cast<const double2*>(stage + P * (kN * kD) + piece * 2);
+            *reinterpret_cast<double2*>(coeffs + ((size_t)(s0P + v) * (kN * kD) + piece * 2)) = val;
+          }
+        }
+        if (on) {
+          const double2 val = *reinterpret_cast<const double2*>(stage + pl * (kN * kD) + 32 + dim * 2);
+          *reinterpret_cast<double2*>(coeffs + ((size_t)(pr.s0 + v) * (kN * kD) + 32 + dim * 2)) = val;
         }
       }
-      {
-        const int r_stage = v > 0 ? v - 1 : 0;
-        if (r_stage + 2 <= n_rec) {  // (uniform)
-          const double* stage = rec0 + (size_t)r_stage * kQdRec * kQdPaths;
-          quad_wave_sync();
-          // bytes 0..255 of a path's 320: 16 lanes per path, four paths per instruction
-#pragma unroll
-          for (int g = 0; g < 4; ++g) {
-            const int P = 4 * g + (lane >> 4), piece = lane & 15;
-            const int s0P = pinfo[P], SP = pinfo[kQdPaths + P];
-            if (v < SP) {
-              const double2 val = *reinterpret_cast<const double2*>(stage + P * (kN * kD) + piece * 2);
-              *reinterpret_cast<double2*>(coeffs + ((size_t)(s0P + v) * (kN * kD) + piece * 2)) = val;
-            }
-          }
-          // bytes 256..319: the path's own four lanes
-          if (on) {
-            const double2 val = *reinterpret_cast<const double2*>(stage + pl * (kN * kD) + 32 + dim * 2);
-            *reinterpret_cast<double2*>(coeffs + ((size_t)(pr.s0 + v) * (kN * kD) + 32 + dim * 2)) = val;
-          }
-          quad_wave_sync();  // (the next step stages over record v - 1 of this area)
-        }
-      }
+#endif
 #pragma unroll
       for (int r = 0; r < kNB; ++r) xn[r] = x[r];
       if (on) p_end = p_start;

@@ -472,6 +472,69 @@ __device__ __forceinline__ void stage_ps_tables(int d, double* tab, int tid, int
   }
 }
 
+// The left-to-right table of stage_ps_tables as COMPILE-TIME constants of objective order D (round 5).  The plain-path lean
+// kernels only ever run D = 4 (orders below snap leave slots free at the end vertices and take the masked kernel), and a
+// table that is the same in every lane need not live in 90 VGPRs per lane: a constant operand of a VOP3 instruction is an
+// SGPR pair the scalar unit sets up beside the vector work.  ONE table serves both sweep directions: reversing a segment's
+// time maps end-point derivative r to (-1)^r times the other end's, so every entry of the right-to-left table is the
+// left-to-right entry times sigma_r sigma_c, sigma_r = (-1)^r over the free slots r = 0..3 (velocity .. snap) -- exactly, the
+// constants being correctly rounded images of rationals with that symmetry (tests/test_oracle_golden.py checks the bits).
+// A right-to-left lane therefore runs the left-to-right arithmetic on x' = diag(sigma) x: its blocks are D A D, its
+// right-hand sides D y, its Cholesky factor D L D, z' = D z -- the same magnitudes, sign-flipped where r + c is odd, so the
+// cost terms (qf, |z|^2) are the SAME BITS as with the mirrored table; only where a state crosses between lanes of opposite
+// direction (the hand-over of evaluate_lean_shared) the signs are applied: lean_flip_state.
+constexpr double k_hbar_cx[kHalf][kN][kN] = MRS_TG_HBAR_INIT;
+
+template <int D>
+struct PsTab {
+  static __host__ __device__ constexpr int tri_row(int t) { return t < 1 ? 0 : t < 3 ? 1 : t < 6 ? 2 : 3; }
+  static __host__ __device__ constexpr double at(int i) {
+    if (i < 10) {
+      const int r = tri_row(i), c = i - r * (r + 1) / 2;
+      return k_hbar_cx[D][kSlot0 + r][kSlot0 + c];
+    }
+    if (i < 26) return k_hbar_cx[D][kSlot0 + (i - 10) / kNB][kHalf + kSlot0 + (i - 10) % kNB];
+    if (i < 36) {
+      const int t = i - 26, r = tri_row(t), c = t - r * (r + 1) / 2;
+      return k_hbar_cx[D][kHalf + kSlot0 + r][kHalf + kSlot0 + c];
+    }
+    if (i < 40) return k_hbar_cx[D][kSlot0 + (i - 36)][0];
+    if (i < 44) return k_hbar_cx[D][kHalf + kSlot0 + (i - 40)][0];
+    return k_hbar_cx[D][0][0];
+  }
+};
+
+// x' = diag(sigma) x for a half-sweep state (Sm packed lower, y[row][dimension]): entries with r + c odd and rows r = 1, 3
+// change sign when flip is -1.0 (a multiplication by +-1 is exact)
+__device__ __forceinline__ void lean_flip_state(double (&Sm)[10], double (&y)[kNB][4], double flip) {
+  Sm[tri(1, 0)] *= flip;
+  Sm[tri(2, 1)] *= flip;
+  Sm[tri(3, 0)] *= flip;
+  Sm[tri(3, 2)] *= flip;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    y[1][q] *= flip;
+    y[3][q] *= flip;
+  }
+}
+
+// p2[m] = T^(m + 1 - 2 D) for a compile-time objective order (segment_powers with its order folded)
+template <int D>
+__device__ __forceinline__ void segment_powers_c(double T, double (&p2)[9]) {
+  const double t2 = T * T;
+  const double td = (D == 0) ? 1.0 : (D == 1) ? T : (D == 2) ? t2 : (D == 3) ? t2 * T : t2 * t2;
+  const double t4 = t2 * t2;
+  p2[0] = T * rcp_refined(td * td);
+  p2[1] = p2[0] * T;
+  p2[2] = p2[0] * t2;
+  p2[3] = p2[1] * t2;
+  p2[4] = p2[0] * t4;
+  p2[5] = p2[1] * t4;
+  p2[6] = p2[2] * t4;
+  p2[7] = p2[3] * t4;
+  p2[8] = p2[4] * t4;
+}
+
 __device__ __forceinline__ void ps_wave_sync() {
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
   __builtin_amdgcn_wave_barrier();

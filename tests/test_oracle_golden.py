@@ -110,6 +110,25 @@ def test_unit_time_tables_equal_the_products_constants():
     assert np.array_equal(table("MRS_TG_HBAR_INIT").reshape(5, 10, 10), h)
 
 
+def test_unit_time_hessian_is_exactly_time_reversal_symmetric():
+    """Reversing a segment's time maps end-point derivative r to (-1)^r times the other end's, and the cost does not change:
+    HBAR = P^T HBAR P with P = [[0, D], [D, 0]], D = diag((-1)^r).  The rounded constants keep that symmetry to the last
+    bit, which is what lets the lean outer-loop kernels run their right-to-left half sweeps on the LEFT-to-right table in
+    sign-transformed variables (mrs_tg_sweep.hpp: PsTab, lean_flip_state) and still produce the bits of the mirrored
+    table: every entry the right-to-left table of stage_ps_tables holds is the left-to-right entry times sigma_r sigma_c."""
+    _, h = po.unit_tables()
+    sig = np.array([(-1.0) ** r for r in range(5)])
+    for d in range(5):
+        H = h[d]
+        ss, se, es, ee = H[:5, :5], H[:5, 5:], H[5:, :5], H[5:, 5:]
+        assert np.array_equal(ee, ss * np.outer(sig, sig))          # far block  = sigma_r sigma_c x near block
+        assert np.array_equal(es, se * np.outer(sig, sig))          # coupling, mirrored (= its transpose by symmetry of H)
+        assert np.array_equal(se, se.T * np.outer(sig, sig))
+        if d >= 1:   # (order 0 penalises the position itself)
+            assert np.array_equal(H[:, 5], -H[:, 0])                # a constant polynomial costs nothing
+            assert np.array_equal(H[5:, 0], -sig * H[:5, 0])        # position brackets: end rows from start rows
+
+
 def test_oracle_routes_against_the_ground_truth(golden):
     worst = {0: 0.0, 1: 0.0, 2: 0.0}
     for case in golden["cases"]:
