@@ -373,6 +373,18 @@ __device__ __forceinline__ double evaluate_general(const uint8_t* __restrict__ m
 constexpr int kLeanPub = 3 * 28;  // evaluate_lean_shared's hand-over area: three half-sweep states of 28 doubles
 __host__ __device__ constexpr int lean_eval_doubles(int Sb) { return 4 * Sb + 4 * (Sb + 1) + kLeanPub; }  // dp, staging area, hand-over
 
+// MRS_TG_LEAN_CONST_TABLE=1 (an A / B build, NOT the default): the 45 table constants as compile-time operands -- SGPR pairs the
+// scalar unit sets up -- instead of 90 VGPRs per lane, and ONE table for both sweep directions (mrs_tg_sweep.hpp, PsTab).
+// Bit-identical results; measured in round 5 (same box, scripts/lean_ab.py): optimize_lean_shared_kernel 256 VGPRs + 80 B of
+// scratch -> 202 VGPRs without scratch and 3 % SLOWER (8192 x 10: 126.4 -> 130.9 us, 65536 x 10: 569 -> 575 us), the mixed
+// kernel of ragged batches 9 % slower (334 -> 365 us); compiled for three wavefronts per SIMD (168 VGPRs + 80 B) slower again
+// (149 us).  The kernels issue one FP64 instruction per 6.2 SIMD cycles with two wavefronts resident against 4.9-5.1 at best
+// (scripts/dpp_probe.hip): bound by their instruction count, not by registers or occupancy -- and the two s_mov_b32 per
+// constant use are instructions too.
+#ifndef MRS_TG_LEAN_CONST_TABLE
+#define MRS_TG_LEAN_CONST_TABLE 0
+#endif
+#define LEAN1_TAB(e) (MRS_TG_LEAN_CONST_TABLE ? PsTab<4>::at(e) : tab[e])
 template <bool MASKED>
 __device__ __forceinline__ double evaluate_lean(const double* tabs, const double* ev, int S, int Sb, int d, const double* pt,
                                                 double* grad, int g, int G, bool active, int* tripped) {
@@ -404,8 +416,8 @@ __device__ __forceinline__ double evaluate_lean(const double* tabs, const double
 #pragma unroll
         for (int r = 0; r < kNB; ++r) {
 #pragma unroll
-          for (int c = 0; c <= r; ++c) Sm[tri(r, c)] = PsTab<4>::at(26 + tri(r, c)) * p2[r + c + 2];
-          const double cF = PsTab<4>::at(40 + r) * p2[r + 1];
+          for (int c = 0; c <= r; ++c) Sm[tri(r, c)] = LEAN1_TAB(26 + tri(r, c)) * p2[r + c + 2];
+          const double cF = LEAN1_TAB(40 + r) * p2[r + 1];
 #pragma unroll
           for (int q = 0; q < 4; ++q) y[r][q] = -(cF * dp[q]);
         }
@@ -421,8 +433,8 @@ __device__ __forceinline__ double evaluate_lean(const double* tabs, const double
 #pragma unroll
         for (int r = 0; r < kNB; ++r) {
 #pragma unroll
-          for (int c = 0; c <= r; ++c) Sm[tri(r, c)] = fma(PsTab<4>::at(tri(r, c)), p2[r + c + 2], Sm[tri(r, c)]);
-          const double cN = PsTab<4>::at(36 + r) * p2[r + 1];
+          for (int c = 0; c <= r; ++c) Sm[tri(r, c)] = fma(LEAN1_TAB(tri(r, c)), p2[r + c + 2], Sm[tri(r, c)]);
+          const double cN = LEAN1_TAB(36 + r) * p2[r + 1];
 #pragma unroll
           for (int q = 0; q < 4; ++q) y[r][q] = fma(-cN, dq[q], y[r][q]);
         }
@@ -459,7 +471,7 @@ __device__ __forceinline__ double evaluate_lean(const double* tabs, const double
           for (int c = 0; c < kNB; ++c)
 #pragma unroll
             for (int rr = 0; rr < kNB; ++rr) {
-              double t = PsTab<4>::at(10 + rr * kNB + c) * p2[rr + c + 2];
+              double t = LEAN1_TAB(10 + rr * kNB + c) * p2[rr + c + 2];
 #pragma unroll
               for (int m = 0; m < rr; ++m) t = fma(-L[tri(rr, m)], W[m][c], t);
               W[rr][c] = t * Linv[rr];
@@ -468,12 +480,12 @@ __device__ __forceinline__ double evaluate_lean(const double* tabs, const double
           for (int rr = 0; rr < kNB; ++rr) {
 #pragma unroll
             for (int c = 0; c <= rr; ++c) {
-              double t = PsTab<4>::at(26 + tri(rr, c)) * p2[rr + c + 2];
+              double t = LEAN1_TAB(26 + tri(rr, c)) * p2[rr + c + 2];
 #pragma unroll
               for (int m = 0; m < kNB; ++m) t = fma(-W[m][rr], W[m][c], t);
               Sm[tri(rr, c)] = t;
             }
-            const double cF = PsTab<4>::at(40 + rr) * p2[rr + 1];
+            const double cF = LEAN1_TAB(40 + rr) * p2[rr + 1];
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
               double t = -(cF * dq[q]);
@@ -535,9 +547,6 @@ __device__ __forceinline__ double evaluate_lean(const double* tabs, const double
 // their partner's state to their own and factor the middle vertex.  For plain paths with 4 <= S and S + 4 <= G.
 //   lanes of the group: 0: x left | 1 .. m: vector k = lane, left | m + 1: B' left |
 //                       m + 2: x right | m + 2 + r: vector m + r, right (r = 1 .. S - m) | S + 3: B' right
-#ifndef MRS_TG_LEAN_CONST_TABLE
-#define MRS_TG_LEAN_CONST_TABLE 1
-#endif
 #if MRS_TG_LEAN_CONST_TABLE
 #define LEAN_TAB(e) PsTab<4>::at(e)
 #else

@@ -472,8 +472,9 @@ __device__ __forceinline__ void stage_ps_tables(int d, double* tab, int tid, int
   }
 }
 
-// The left-to-right table of stage_ps_tables as COMPILE-TIME constants of objective order D (round 5).  The plain-path lean
-// kernels only ever run D = 4 (orders below snap leave slots free at the end vertices and take the masked kernel), and a
+// (Used by the A / B build -DMRS_TG_LEAN_CONST_TABLE=1 only: measured slower than the per-lane register table, see
+// mrs_tg_nonlinear.hip.)  The left-to-right table of stage_ps_tables as COMPILE-TIME constants of objective order D (round 5).
+// The plain-path lean kernels only ever run D = 4 (orders below snap leave slots free at the end vertices and take the masked kernel), and a
 // table that is the same in every lane need not live in 90 VGPRs per lane: a constant operand of a VOP3 instruction is an
 // SGPR pair the scalar unit sets up beside the vector work.  ONE table serves both sweep directions: reversing a segment's
 // time maps end-point derivative r to (-1)^r times the other end's, so every entry of the right-to-left table is the

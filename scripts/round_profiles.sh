@@ -16,6 +16,10 @@ python3 scripts/pmc_sq_json.py $O/${tag}_pmc_sq_linear.csv solve_rows_kernel 655
 python3 scripts/pmc_sq_json.py $O/${tag}_pmc_sq_nonlinear.csv optimize_wave_kernel 65536 1024 10 $O/${tag}_pmc_sq_outer_loop.json
 scripts/pmc_sq_nl.sh $tag 8192 > $O/${tag}_pmc_sq_nl_8192.log 2>&1
 scripts/pmc_solve_quad.sh $tag > $O/${tag}_pmc_solve_quad.log 2>&1
+scripts/pmc_headline.sh $tag > $O/${tag}_pmc_headline.log 2>&1            # the kernel the headline's timed region runs (grouped dispatch)
+scripts/pmc_sq_nl.sh $tag 65536 > $O/${tag}_pmc_sq_nl_65536.log 2>&1     # the lean outer loop with the device saturated
+python3 scripts/quad_ab.py 65536 8192 2>&1 | grep -v amdgpu.ids > $O/${tag}_quad_positions_ab.txt
+python3 scripts/scratch_sites.py > $O/${tag}_scratch_sites.txt 2>&1       # static: which functions hold the scratch instructions
 python3 scripts/measure_configs.py $tag > $O/${tag}_configs.txt 2>&1
 scripts/pipeline_stats.sh $tag > $O/${tag}_pipeline_stats.txt 2>&1
 python3 scripts/host_call_rate.py > $O/${tag}_host_call_rate.txt 2>&1
