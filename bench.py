@@ -604,6 +604,7 @@ def main():
         traced = api.kernel_trace()
         torch.cuda.synchronize()
         head_kernel = traced[-1] if traced else "unknown"
+        head_base = head_kernel.split("<")[0]   # (the counters under profiles/ carry the kernel's name without template arguments)
         for c in lane_ctx:
             c.set_profiling(True)
         try:
@@ -641,7 +642,7 @@ def main():
                     d = json.load(fh)
             except (OSError, ValueError):
                 continue
-            if d.get("paths_per_dispatch") == paths_disp and d.get("segments") == args.segments and d.get("kernel") == head_kernel:
+            if d.get("paths_per_dispatch") == paths_disp and d.get("segments") == args.segments and d.get("kernel") == head_base:
                 roofline_headline.update(traffic=d["hbm_bytes_per_dispatch"],
                                          traffic_over_compulsory=d["hbm_bytes_per_dispatch"] / float(comp_bytes),
                                          traffic_source=os.path.relpath(f, ROOT) + " (separate rocprofv3 --pmc passes; from "
@@ -652,7 +653,7 @@ def main():
                     d = json.load(fh)
             except (OSError, ValueError):
                 continue
-            if d.get("paths") == paths_disp and d.get("segments") == args.segments and head_kernel in d.get("kernel", ""):
+            if d.get("paths") == paths_disp and d.get("segments") == args.segments and head_base in d.get("kernel", ""):
                 c = d["counters"]
                 issue_peak_h = 256 * 4 * 2.4e9 / 4.0
                 roofline_headline.update(

@@ -94,6 +94,9 @@ __device__ __forceinline__ double quad_sum(double v) {  // over the four lanes o
   return v;
 }
 
+// WP: vertex positions from the compact waypoint array (MRS_TG_FLAG_POSITIONS_ARE_WAYPOINTS).  A template parameter, not a
+// run-time stride: with the stride in a register the value-array path lost 13 % (65536 x 10: 129 -> 147 us, same box)
+template <bool WP>
 __device__ __forceinline__ void solve_quad_body(const BatchView& b, int d, const uint8_t* __restrict__ mask,
                                                 const double* __restrict__ vals, const double* seg_times,
                                                 double* __restrict__ coeffs, int32_t* __restrict__ status,
@@ -183,8 +186,8 @@ __device__ __forceinline__ void solve_quad_body(const BatchView& b, int d, const
     // position of vertex v, this dimension: pv[v * pstride].  From the caller's value array that is 8 bytes out of every 160
     // (and whole cache lines come along: 137 MB read for 45 MB of inputs at 65536 x 10); under
     // MRS_TG_FLAG_POSITIONS_ARE_WAYPOINTS from the compact [vertex][4] waypoint array, whose every byte is used
-    const double* pv = pos_wp != nullptr ? pos_wp + (size_t)pr.v0 * kD + dim : vals + (size_t)pr.v0 * kHalf * kD + dim;
-    const size_t pstride = pos_wp != nullptr ? (size_t)kD : (size_t)(kHalf * kD);
+    const double* pv = WP ? pos_wp + (size_t)pr.v0 * kD + dim : vals + (size_t)pr.v0 * kHalf * kD + dim;
+    constexpr size_t pstride = WP ? (size_t)kD : (size_t)(kHalf * kD);
     // ---- forward: block Cholesky over the vertex chain
     double Sm[10], y[kNB];
     // positions are requested three segments ahead: with less than one wavefront per SIMD nothing else hides a trip to memory,
@@ -446,21 +449,24 @@ __device__ __forceinline__ void solve_quad_body(const BatchView& b, int d, const
   }
 }
 
+template <bool WP>
 __global__ __launch_bounds__(64, MRS_TG_QUAD_WAVES) void solve_quad_kernel(BatchView b, int d, const uint8_t* __restrict__ mask,
                                                         const double* __restrict__ vals, const double* seg_times,
                                                         double* __restrict__ coeffs, int32_t* __restrict__ status,
                                                         double* __restrict__ cost, const int32_t* __restrict__ status_in,
                                                         double* ws, RowsTail tail) {
-  solve_quad_body(b, d, mask, vals, seg_times, coeffs, status, cost, status_in, ws, tail, (int)blockIdx.x, tail.pos_wp);
+  solve_quad_body<WP>(b, d, mask, vals, seg_times, coeffs, status, cost, status_in, ws, tail, (int)blockIdx.x, tail.pos_wp);
 }
 
 // several batches of ONE plan in one launch (as solve_rows_group_kernel): workgroups [j * blocks_per_batch, ...) solve batch j
 // (ws: one factor store of ws_batch_doubles per batch, for wavefronts that take the general step)
+// (WP: every batch of the group states that its positions are its waypoints)
+template <bool WP>
 __global__ __launch_bounds__(64, MRS_TG_QUAD_GROUP_WAVES) void solve_quad_group_kernel(BatchView b, int d, RowsGroup g, double* ws, size_t ws_batch_doubles,
                                                               int blocks_per_batch) {
   const int j = __builtin_amdgcn_readfirstlane((int)blockIdx.x / blocks_per_batch);
-  solve_quad_body(b, d, g.mask[j], g.vals[j], g.seg_times[j], g.coeffs[j], g.status[j], g.cost[j], nullptr,
-                  ws + (size_t)j * ws_batch_doubles, RowsTail(), (int)blockIdx.x - j * blocks_per_batch, g.pos_wp[j]);
+  solve_quad_body<WP>(b, d, g.mask[j], g.vals[j], g.seg_times[j], g.coeffs[j], g.status[j], g.cost[j], nullptr,
+                      ws + (size_t)j * ws_batch_doubles, RowsTail(), (int)blockIdx.x - j * blocks_per_batch, g.pos_wp[j]);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -487,26 +493,39 @@ hipError_t launch_solve_quad(const BatchView& b, int d, const uint8_t* mask, con
                              double* coeffs, int32_t* status, double* cost, const int32_t* status_in, double* ws,
                              hipStream_t stream, const RowsTail& tail) {
   const size_t lds_bytes = quad_lds_doubles(b.max_segments) * sizeof(double);
+  const bool wp = tail.pos_wp != nullptr;
   if (lds_bytes > 64 * 1024) {
-    hipError_t e = hipFuncSetAttribute((const void*)solve_quad_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kQuadLdsBudget);
+    hipError_t e = hipFuncSetAttribute(wp ? (const void*)solve_quad_kernel<true> : (const void*)solve_quad_kernel<false>,
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)kQuadLdsBudget);
     if (e != hipSuccess) return e;
   }
   const unsigned grid = (unsigned)((b.n_paths + kQdPaths - 1) / kQdPaths);
-  MRS_TG_LAUNCH_TIMED(solve_quad_kernel, dim3(grid), dim3(64), lds_bytes, stream, b, d, mask, vals, seg_times, coeffs, status, cost,
-                      status_in, ws, tail);
+  if (wp)
+    MRS_TG_LAUNCH_TIMED(solve_quad_kernel<true>, dim3(grid), dim3(64), lds_bytes, stream, b, d, mask, vals, seg_times, coeffs, status,
+                        cost, status_in, ws, tail);
+  else
+    MRS_TG_LAUNCH_TIMED(solve_quad_kernel<false>, dim3(grid), dim3(64), lds_bytes, stream, b, d, mask, vals, seg_times, coeffs, status,
+                        cost, status_in, ws, tail);
   return hipGetLastError();
 }
 
 hipError_t launch_solve_quad_group(const BatchView& b, int d, const RowsGroup& g, double* ws, hipStream_t stream) {
   if (g.n < 1 || g.n > kRowsGroupMax) return hipErrorInvalidValue;
   const size_t lds_bytes = quad_lds_doubles(b.max_segments) * sizeof(double);
+  bool wp = true;
+  for (int j = 0; j < g.n; ++j) wp = wp && g.pos_wp[j] != nullptr;
   if (lds_bytes > 64 * 1024) {
-    hipError_t e = hipFuncSetAttribute((const void*)solve_quad_group_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kQuadLdsBudget);
+    hipError_t e = hipFuncSetAttribute(wp ? (const void*)solve_quad_group_kernel<true> : (const void*)solve_quad_group_kernel<false>,
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)kQuadLdsBudget);
     if (e != hipSuccess) return e;
   }
   const int per_batch = (b.n_paths + kQdPaths - 1) / kQdPaths;
-  MRS_TG_LAUNCH_TIMED(solve_quad_group_kernel, dim3((unsigned)(per_batch * g.n)), dim3(64), lds_bytes, stream, b, d, g, ws,
-                      linear_workspace_doubles(b), per_batch);
+  if (wp)
+    MRS_TG_LAUNCH_TIMED(solve_quad_group_kernel<true>, dim3((unsigned)(per_batch * g.n)), dim3(64), lds_bytes, stream, b, d, g, ws,
+                        linear_workspace_doubles(b), per_batch);
+  else
+    MRS_TG_LAUNCH_TIMED(solve_quad_group_kernel<false>, dim3((unsigned)(per_batch * g.n)), dim3(64), lds_bytes, stream, b, d, g, ws,
+                        linear_workspace_doubles(b), per_batch);
   return hipGetLastError();
 }
 

@@ -25,18 +25,19 @@ def measure(ctx, batch, nonlinear, reps):
     torch.cuda.synchronize()
     t0 = db.seg_times.clone()
     if nonlinear:
+        # (MRS_TG_FLAG_POSITIONS_ARE_WAYPOINTS: these batches' position constraints are their waypoints, as in bench.py)
         opt = api.default_options(derivative_to_optimize=4, time_alloc_method=api.TIME_ALLOC_MELLINGER, sampling_dt=0.2,
-                                  sample_capacity=512)
+                                  sample_capacity=512, flags=api.FLAG_POSITIONS_ARE_WAYPOINTS)
 
         def step():
             db.seg_times.copy_(t0)
-            plan.solve(opt, db.fixed_mask, db.fixed_values, db.seg_times, db.coeffs, db.status, db.cost, limits=db.limits,
-                       n_samples=db.n_samples, samples=db.samples)
+            plan.solve(opt, db.fixed_mask, db.fixed_values, db.seg_times, db.coeffs, db.status, db.cost, waypoints=db.waypoints,
+                       limits=db.limits, n_samples=db.n_samples, samples=db.samples)
     else:
-        opt = api.default_options(derivative_to_optimize=4)
+        opt = api.default_options(derivative_to_optimize=4, flags=api.FLAG_POSITIONS_ARE_WAYPOINTS)
 
         def step():
-            plan.solve(opt, db.fixed_mask, db.fixed_values, t0, db.coeffs, db.status, db.cost)
+            plan.solve(opt, db.fixed_mask, db.fixed_values, t0, db.coeffs, db.status, db.cost, waypoints=db.waypoints)
     for _ in range(3):
         step()
     torch.cuda.synchronize()

@@ -85,7 +85,9 @@ def _per_path_error(batch, got, ref):
 
 
 def test_the_dispatches_of_the_headline_are_the_quad_group_kernel(headline):
-    assert headline["trace"] == ["solve_quad_group_kernel"] * (SLOTS // GROUP), headline["trace"]
+    # (<false>: these slots do not state MRS_TG_FLAG_POSITIONS_ARE_WAYPOINTS; bench.py's do, and the last test of this file
+    # holds the two instantiations to the same bits)
+    assert headline["trace"] == ["solve_quad_group_kernel<false>"] * (SLOTS // GROUP), headline["trace"]
     for s in headline["slots"]:
         assert np.all(s["status"] == 1)
 
@@ -156,7 +158,7 @@ def test_grouped_dispatch_equals_one_launch_over_the_same_paths(headline):
     t = np.concatenate([s["times"] for s in headline["slots"][:GROUP]])
     api.kernel_trace_reset()
     out = ctx.solve_batch(big, t)
-    assert "solve_quad_kernel" in api.kernel_trace(), api.kernel_trace()
+    assert "solve_quad_kernel<false>" in api.kernel_trace(), api.kernel_trace()
     got = np.concatenate([s["coeffs"] for s in headline["slots"][:GROUP]])
     assert np.array_equal(out["coeffs"], got)
     assert np.array_equal(out["cost"], np.concatenate([s["cost"] for s in headline["slots"][:GROUP]]))
@@ -184,12 +186,23 @@ def test_positions_from_the_waypoint_array_give_the_same_bits_and_a_false_statem
             opt = api.default_options(derivative_to_optimize=4, flags=flags)
             api.kernel_trace_reset()
             plan.bind_solve(opt, db.fixed_mask, db.fixed_values, db.seg_times, db.coeffs, db.status, db.cost, waypoints=db.waypoints)()
-            assert api.kernel_trace()[-1] == "solve_quad_kernel", api.kernel_trace()
+            assert api.kernel_trace()[-1] == ("solve_quad_kernel<true>" if flags else "solve_quad_kernel<false>"), api.kernel_trace()
             torch.cuda.synchronize()
             got[name] = (db.coeffs.cpu().numpy().copy(), db.cost.cpu().numpy().copy(), db.status.cpu().numpy().copy())
         for a, b in zip(got["values"], got["waypoints"]):
             assert np.array_equal(a, b)
         assert np.all(got["values"][2] == 1)
+        # the grouped dispatch with the statement: two bound solves of this batch in one launch of solve_quad_group_kernel<true>
+        c2 = torch.zeros_like(db.coeffs)
+        opt_wp = api.default_options(derivative_to_optimize=4, flags=api.FLAG_POSITIONS_ARE_WAYPOINTS)
+        db.coeffs.zero_()
+        calls = [plan.bind_solve(opt_wp, db.fixed_mask, db.fixed_values, db.seg_times, cc, db.status, db.cost, waypoints=db.waypoints)
+                 for cc in (db.coeffs, c2)]
+        api.kernel_trace_reset()
+        api.RoundRobin(calls, grouped=True)(2)
+        assert api.kernel_trace() == ["solve_quad_group_kernel<true>"], api.kernel_trace()
+        torch.cuda.synchronize()
+        assert np.array_equal(db.coeffs.cpu().numpy(), got["values"][0]) and np.array_equal(c2.cpu().numpy(), got["values"][0])
         idx = list(range(0, batch.n_paths, 97))
         sub = batch.select(idx)
         t = db.seg_times.cpu().numpy()
