@@ -410,6 +410,39 @@ def test_sampling_other_sampling_periods(gpu_ctx, dt, cap):
         assert np.max(np.abs(out["samples"][p, :n, :3] - s[:n, :3])) < 1e-10
 
 
+def test_a_host_that_derives_its_sampling_period_per_request_gets_the_same_samples(gpu_ctx):
+    """The walk's accumulated-time table is built once per (device, dt) by a kernel on the call's stream and kept in a bounded
+    least-recently-used cache (32 tables; mrs_tg_kernels.hip).  A host that sends a different period with
+    every request goes through builds, evictions and rebuilds: 80 periods, each checked against the oracle's walk, then the
+    first ones again (evicted by then) with the samples of their first visit, bit for bit; and a capacity that outgrows a
+    table (1184 -> 2368 -> 4736 entries) gives the same samples where both fit."""
+    batch = pr.random_batch(6, 5, seed0=123)
+    first = {}
+    periods = [0.05 + 0.0037 * i for i in range(80)]
+    for i, dt in enumerate(periods + periods[:4]):
+        out = gpu_ctx.solve_batch(batch, None, sampling_dt=dt, sample_capacity=1024)
+        key = round(dt, 9)
+        if key in first:
+            assert np.array_equal(out["n_samples"], first[key][0]) and np.array_equal(out["samples"], first[key][1]), dt
+            continue
+        first[key] = (out["n_samples"].copy(), out["samples"].copy())
+        for p in (0, 5):
+            a, b = batch.seg_offsets[p], batch.seg_offsets[p + 1]
+            s, n = po.sample_trajectory(out["coeffs"][a:b], out["times"][a:b], dt, 0, 1024)
+            assert min(n, 1025) == out["n_samples"][p], (dt, p, n, out["n_samples"][p])
+            n = min(n, 1024)
+            assert np.max(np.abs(out["samples"][p, :n, :3] - s[:n, :3])) < 1e-10, (dt, p)
+    small = gpu_ctx.solve_batch(batch, None, sampling_dt=0.021, sample_capacity=1000)
+    for cap in (2000, 4500):
+        big = gpu_ctx.solve_batch(batch, None, sampling_dt=0.021, sample_capacity=cap)
+        for p in range(batch.n_paths):
+            n = min(int(small["n_samples"][p]), 1000)
+            assert np.array_equal(big["samples"][p, :n], small["samples"][p, :n]), (cap, p)
+            a, b = batch.seg_offsets[p], batch.seg_offsets[p + 1]
+            _, n_ref = po.sample_trajectory(big["coeffs"][a:b], big["times"][a:b], 0.021, 0, cap)
+            assert min(n_ref, cap + 1) == big["n_samples"][p]
+
+
 # ---- against the oracle with its linear solve in 113-bit arithmetic (po.QUAD_PRECISION, oracle/mto_linear.c) ----------------
 # The reference's algorithm, bar rounding: what the reference-style oracle and the HIP path both approximate.  Against it the
 # HIP path's agreement is set by its own error only -- measured on 8192-path batches (profiles/round3_parity_sweep.txt): 99.96 %

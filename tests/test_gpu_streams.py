@@ -113,3 +113,32 @@ def test_grouped_launch_packs_the_steps_of_a_round_into_one_dispatch(gpu_ctx):
             assert np.array_equal(dbs[s].coeffs.cpu().numpy(), refs[s][0]), s
         plan2.close()
         plan.close()
+
+
+def test_a_bind_reserves_no_factor_stores_for_a_group_it_may_never_launch(gpu_ctx):
+    """binding a fixed-times solve of a large plan reserved the factor stores of a 16-batch grouped launch
+    (1.26 GB at 8192 x 10, ten at 65536 x 10) whether or not the solve was ever launched in a group.  Now a bind of such a
+    plan reserves nothing, and mrs_tg_bound_solve_launch_group sizes the store for the group it launches (two batches here:
+    2 x 78.6 MB), with the results of the single launches."""
+    batch = pr.random_batch(8192, 10, seed0=4100)
+    plan = api.Plan(gpu_ctx, batch.seg_offsets)
+    db = api.DeviceBatch(batch, "cuda:0")
+    est = api.default_options(derivative_to_optimize=4, estimate_times=1)
+    plan.solve(est, db.fixed_mask, db.fixed_values, db.seg_times, db.coeffs, db.status, db.cost, waypoints=db.waypoints, limits=db.limits)
+    lin = api.default_options(derivative_to_optimize=4)
+    plan.solve(lin, db.fixed_mask, db.fixed_values, db.seg_times, db.coeffs, db.status, db.cost)
+    torch.cuda.synchronize()
+    ref = db.coeffs.cpu().numpy().copy()
+    c2 = torch.zeros_like(db.coeffs)
+    free0 = torch.cuda.mem_get_info()[0]
+    calls = [plan.bind_solve(lin, db.fixed_mask, db.fixed_values, db.seg_times, cc, db.status, db.cost) for cc in (db.coeffs, c2)]
+    torch.cuda.synchronize()
+    free1 = torch.cuda.mem_get_info()[0]
+    assert free0 - free1 < 64 << 20, (free0 - free1) >> 20          # (round 4: 1.26 GB here)
+    db.coeffs.zero_()
+    api.RoundRobin(calls, grouped=True)(2)
+    torch.cuda.synchronize()
+    free2 = torch.cuda.mem_get_info()[0]
+    assert free1 - free2 < 400 << 20, (free1 - free2) >> 20          # two stores of 78.6 MB (+ the pool's rounding), not sixteen
+    assert np.array_equal(db.coeffs.cpu().numpy(), ref) and np.array_equal(c2.cpu().numpy(), ref)
+    plan.close()
