@@ -223,7 +223,8 @@ def back_to_back_ms(launch_fn, reps, torch):
 def measured_traffic_solve_quad(n_paths, n_seg):
     """HBM traffic of solve_quad_kernel from the newest committed PMC summary (scripts/pmc_solve_quad.sh); not measured in this run"""
     best = None
-    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "round*_pmc_solve_quad_hbm_traffic.json"))):
+    # (bench.py's solves state MRS_TG_FLAG_POSITIONS_ARE_WAYPOINTS: the counters of solve_quad_kernel<true>)
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "round*_pmc_solve_quad_wp_hbm_traffic.json"))):
         try:
             with open(f) as fh:
                 d = json.load(fh)
@@ -982,7 +983,7 @@ def main():
                                                                    waypoints=db3.waypoints), 10, torch)
             flop_sat = SOLVE_FLOP_PER_SEGMENT * n3 * args.segments
             extras["roofline_solve_saturated"] = dict(
-                kernel="solve_quad_kernel" if n3 >= 6144 else "solve_rows_kernel", paths=n3, bound="fp64 vector", unit="TFLOP/s",
+                kernel="solve_quad_kernel<true>" if n3 >= 6144 else "solve_rows_kernel", paths=n3, bound="fp64 vector", unit="TFLOP/s",
                 peak=FP64_VECTOR_PEAK_TFLOPS, flop_per_launch=flop_sat, avg_launch_us=m_sat * 1e3, median_launch_us=med_sat * 1e3,
                 achieved=flop_sat / (m_sat * 1e-3) / 1e12, frac=flop_sat / (m_sat * 1e-3) / 1e12 / FP64_VECTOR_PEAK_TFLOPS,
                 trajectories_per_s=n3 / (m_sat * 1e-3),
@@ -996,9 +997,9 @@ def main():
                 extras["roofline_solve_saturated"].update(
                     traffic=tq[0]["hbm_bytes_per_launch"], traffic_source=tq[1] + " (separate rocprofv3 --pmc passes; from profiles/, not this run)",
                     traffic_over_compulsory=tq[0]["hbm_bytes_per_launch"] / float(n3 * (40 * args.segments + 288 + 328 * args.segments)),
-                    traffic_note="writes 211 MB = the coefficients; reads 137 MB for 45 MB of inputs: the position row of an interior "
-                                 "vertex is 32 bytes of a 160-byte record of the caller's [vertex][5][4] value array, and whole cache "
-                                 "lines come along")
+                    traffic_note="writes 211 MB = the coefficients; vertex positions from the compact waypoint array "
+                                 "(MRS_TG_FLAG_POSITIONS_ARE_WAYPOINTS): from the [vertex][5][4] value array the kernel reads 137 MB for "
+                                 "45 MB of inputs (ratio 1.34, profiles/round*_pmc_solve_quad_hbm_traffic.json) -- at the same speed")
         plan3.close()
         del db3, pk3, pad3, recv3
 

@@ -12,6 +12,7 @@
 #include <cfloat>
 #include <cmath>
 #include <cstdint>
+#include <cstdlib>
 #include <cstring>
 #include <algorithm>
 #include <map>
@@ -195,25 +196,28 @@ __global__ __launch_bounds__(64) void sample_kernel(BatchView b, const double* _
                                                     int32_t* __restrict__ n_samples, double* __restrict__ samples,
                                                     const double* __restrict__ acc_table, int acc_n) {
   extern __shared__ double s_T[];  // [max_segments] segment times | [S][4][10] coefficients of this path | sample buffer
-  const int q = blockIdx.x;
-  const PathRef pr = path_at(b, q);
-  const int S = pr.S;
   const int lane = threadIdx.x;
   double* s_c = s_T + b.max_segments;
   double* s_t = s_c + (size_t)b.max_segments * kD * kN;                         // [kSampleBuffer] time in segment
   unsigned short* s_seg = reinterpret_cast<unsigned short*>(s_t + kSampleBuffer);  // [kSampleBuffer] segment index
-  MRS_TG_PHASE_MARK(0);
-  for (int i = lane; i < S; i += 64) s_T[i] = seg_times[pr.s0 + i];
-  if (samples) {  // one coalesced pass instead of a global round trip per segment inside the walk
-    const double* __restrict__ cg = coeffs + (size_t)pr.s0 * kD * kN;
-    for (int e = lane; e < S * kD * kN; e += 64) s_c[e] = cg[e];
+  // (a launch may carry fewer workgroups than paths: a workgroup then walks the paths q, q + gridDim.x, ...)
+  for (int q = blockIdx.x; q < b.n_paths; q += gridDim.x) {
+    const PathRef pr = path_at(b, q);
+    const int S = pr.S;
+    MRS_TG_PHASE_MARK(0);
+    for (int i = lane; i < S; i += 64) s_T[i] = seg_times[pr.s0 + i];
+    if (samples) {  // one coalesced pass instead of a global round trip per segment inside the walk
+      const double* __restrict__ cg = coeffs + (size_t)pr.s0 * kD * kN;
+      for (int e = lane; e < S * kD * kN; e += 64) s_c[e] = cg[e];
+    }
+    __syncthreads();
+    MRS_TG_PHASE_MARK(1);
+    double* out = samples ? samples + (size_t)pr.p * capacity * (NDER + 1) * kD : nullptr;
+    const int n = sample_path_walk<NDER>(s_T, s_c, s_t, s_seg, S, dt, capacity, out, acc_table, acc_n);
+    MRS_TG_PHASE_MARK(2);
+    if (lane == 0 && n_samples) n_samples[pr.p] = n;
+    __syncthreads();  // (the next path's staging overwrites what this walk read)
   }
-  __syncthreads();
-  MRS_TG_PHASE_MARK(1);
-  double* out = samples ? samples + (size_t)pr.p * capacity * (NDER + 1) * kD : nullptr;
-  const int n = sample_path_walk<NDER>(s_T, s_c, s_t, s_seg, S, dt, capacity, out, acc_table, acc_n);
-  MRS_TG_PHASE_MARK(2);
-  if (lane == 0 && n_samples) n_samples[pr.p] = n;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -485,7 +489,9 @@ static hipError_t launch_sample_n(const BatchView& b, const double* coeffs, cons
   int acc_n = 0;
   hipError_t et = sample_acc_table(dt, capacity, stream, &acc_table, &acc_n);
   if (et != hipSuccess) return et;
-  MRS_TG_LAUNCH(sample_kernel<NDER>, dim3(b.n_paths), dim3(64), lds, stream, b, coeffs, seg_times, dt, capacity,
+  // one workgroup per path.  (Fewer, persistent workgroups that walk several paths each -- the kernel's loop allows it --
+  // were measured in round 5: 65536 x 10 pipeline 1328 -> 1347 / 1385 / 1384 us with 15360 / 7680 / 3840 workgroups.)
+  MRS_TG_LAUNCH(sample_kernel<NDER>, dim3((unsigned)b.n_paths), dim3(64), lds, stream, b, coeffs, seg_times, dt, capacity,
                      n_samples, samples, acc_table, acc_n);
   return hipGetLastError();
 }

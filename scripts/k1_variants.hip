@@ -17,6 +17,7 @@
 #include "../mrs_uav_trajectory_generation_amd/csrc/mrs_tg_kernels.hip"
 #include "../mrs_uav_trajectory_generation_amd/csrc/mrs_tg_tile.hip"
 #include "../mrs_uav_trajectory_generation_amd/csrc/mrs_tg_rows.hip"
+#include "../mrs_uav_trajectory_generation_amd/csrc/mrs_tg_quad.hip"
 #include "../mrs_uav_trajectory_generation_amd/csrc/mrs_tg_pool.hip"
 
 using namespace mrs_tg;

@@ -21,8 +21,11 @@ plan = api.Plan(ctx, batch.seg_offsets)
 db = api.DeviceBatch(batch, "cuda:0")
 est = api.default_options(derivative_to_optimize=4, estimate_times=1)
 plan.solve(est, db.fixed_mask, db.fixed_values, db.seg_times, db.coeffs, db.status, db.cost, waypoints=db.waypoints, limits=db.limits)
-opt = api.default_options(derivative_to_optimize=4)
-for _ in range(5):
-    plan.solve(opt, db.fixed_mask, db.fixed_values, db.seg_times, db.coeffs, db.status, db.cost)
-torch.cuda.synchronize()
+# vertex positions from the value array (solve_quad_kernel<false>) and, under MRS_TG_FLAG_POSITIONS_ARE_WAYPOINTS, from the compact
+# waypoint array (solve_quad_kernel<true>): the counter summaries keep the two kernels apart by name
+for flags in (0, api.FLAG_POSITIONS_ARE_WAYPOINTS):
+    opt = api.default_options(derivative_to_optimize=4, flags=flags)
+    for _ in range(5):
+        plan.solve(opt, db.fixed_mask, db.fixed_values, db.seg_times, db.coeffs, db.status, db.cost, waypoints=db.waypoints)
+    torch.cuda.synchronize()
 plan.close()
