@@ -11,7 +11,7 @@ mrs_tg_bound_solve_launch_group as two dispatches of ten batches.  What is asser
   * EVERY path of EVERY slot against the reference-style double oracle: 1e-8, and the named tolerance
     TOL_ORACLE_SHORT_SEGMENT on paths with a segment shorter than 0.5 s, where the ORACLE is the inaccurate side;
   * every path against the oracle's 113-bit route (the reference's algorithm without its rounding) -- the HIP path's own
-    error: median < 1e-13, at most 4 of the 20 480 paths above 1e-8, max < 1e-7 (measured: median 1e-14, two paths above 1e-8,
+    error: median < 1e-13, at most 4 of the 20 480 paths above 1e-8, max < 1e-7 (measured: median 1e-14, three paths above 1e-8,
     worst 4.8e-8), and on every path above 1e-9 the HIP path is at least 4x closer to the exact result than the double oracle;
   * the path behind bench.py's in_flight_slots_vs_cpu_ref = 5.3e-7 (slot 15, path 237: a 0.179 s segment between 4.7 s and
     4.0 s ones, (T_max / T_min)^7 = 1e11 between neighbouring blocks of R_pp) against its 60-digit solution (tests/golden,
@@ -34,7 +34,7 @@ TOL_ORACLE = 1e-8                 # SURVEY.md 8d, vs the reference-style restate
 TOL_ORACLE_SHORT_SEGMENT = 1e-6   # paths with min T < 0.5 s: the double oracle itself is up to 5.4e-7 off the exact solution there
 #                                   (tests/test_oracle_golden.py holds it to that on bench_slot15_path237_short_segment)
 TOL_113BIT_MAX, TOL_113BIT_MEDIAN = 1e-7, 1e-13   # max: measured 4.8e-8 on the worst-conditioned of the 20 480 paths (cond 1e11)
-MAX_PATHS_ABOVE_1E_8 = 4                          # measured 2 (slot 6 path 527: 2.1e-8, slot 15 path 237: 4.8e-8)
+MAX_PATHS_ABOVE_1E_8 = 4                          # measured 3 (slot 6 path 527: 2.1e-8, slot 11 path 859: 1.2e-8, slot 15 path 237: 4.8e-8)
 
 
 @pytest.fixture(scope="module")
