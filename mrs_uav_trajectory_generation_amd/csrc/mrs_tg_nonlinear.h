@@ -58,6 +58,11 @@ struct NonlinearBin {
 
 struct NonlinearPlan {
   std::vector<NonlinearBin> bins;
+  // the plain-path outer loop's bins when EVERY path of four or more segments gets the lanes of the shared half sweeps
+  // (G = pow2ceil(S + 4) instead of pow2ceil(S + 1): 5-7, 13-15 and 29-30 segments move to the next group width); chosen
+  // by launch_nonlinear while the launch is about as large as the device holds at once (see there)
+  std::vector<NonlinearBin> wide_bins;
+  int wide_blocks = 0;             // workgroups of a launch over wide_bins
   int dim_split = 1;               // lanes per time vector in the outer loop: 1 (compact) or 4 (one per dimension)
   double* d_ws = nullptr;          // factor store of the per-lane linear solve
   size_t ws_doubles = 0;

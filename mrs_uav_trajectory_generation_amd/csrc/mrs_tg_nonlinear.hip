@@ -1764,11 +1764,17 @@ __global__ __launch_bounds__(64) void cost_gradient_kernel(BatchView b, int d, i
 // host side
 
 // split the four dimensions over lanes while the batch is too small to fill the machine otherwise
-static int dim_split_for(int n_paths) {
+static int dim_split_for(int n_paths, int max_S) {
   if (const char* e = std::getenv("MRS_TG_DIM_SPLIT_MAX_PATHS")) return n_paths <= std::atoi(e) ? 4 : 1;  // tuning knob
+  // One lane per dimension pays while a path's (S + 1) x 4 lanes fit ONE wavefront: from 16 segments on the split kernel
+  // walks a path in several passes and the lean kernel's lane groups are 2-3x faster at every batch size (whole pipeline,
+  // scripts/measure_configs.py uniform<P>x<S>, profiles/round5_dim_split_crossover.txt: 256 x 16 0.378 vs 0.168 ms,
+  // 2048 x 30 1.290 vs 0.429 ms, 1024 ragged 3..30 0.681 vs 0.240 ms).
+  if (max_S > 15) return 1;
   // measured cross-over against the lean kernel of large batches (scripts/ps_step.py with MRS_TG_DIM_SPLIT_MAX_PATHS=0):
-  // outer-loop kernel 2048 paths 122 vs 143 us, 3072 paths 160 vs 150 us
-  return n_paths <= 2560 ? 4 : 1;
+  // outer-loop kernel 2048 paths 122 vs 143 us, 3072 paths 160 vs 150 us (10 segments); 13 segments: 1024 paths 0.152 vs
+  // 0.168 ms, 2048 paths 0.220 vs 0.192 ms (whole pipeline)
+  return n_paths <= (max_S > 12 ? 1536 : 2560) ? 4 : 1;
 }
 
 static int group_for(int S, int ds) {
@@ -1777,24 +1783,47 @@ static int group_for(int S, int ds) {
   return G;
 }
 
-int nonlinear_plan_build(NonlinearPlan& nl, const std::vector<int32_t>& so, const std::vector<int32_t>& order) {
-  nl.bins.clear();
+// lanes per path when the long paths get the S + 4 lanes of the shared half sweeps: 13-15 and 29-30 segments move to the next
+// group width.  (5-7 segments stay in groups of 8 and their one-sided sweeps: six steps against four do not pay for half
+// the paths per wavefront -- 8192 x 6: 0.190 ms narrow, 0.197 ms wide; 65536 x 6: 0.861 vs 1.015 ms.)
+static int group_for_wide(int S) {
+  int G = group_for(S, 1);
+  if (S >= 13 && G < S + 4 && G < 64) G <<= 1;
+  return G;
+}
+
+template <class GroupFor>
+static void build_bins(std::vector<NonlinearBin>& bins, const std::vector<int32_t>& so, const std::vector<int32_t>& order,
+                       GroupFor group_of) {
+  bins.clear();
   const int P = (int)order.size();
-  nl.dim_split = dim_split_for(P);
   int q = 0;
   while (q < P) {
     const int p = order[q];
     const int S = so[p + 1] - so[p];
     NonlinearBin bin;
-    bin.group = group_for(S, nl.dim_split);
+    bin.group = group_of(S);
     bin.q_begin = q;
     bin.max_S = S;  // sorted longest first: the first path of a bin is its longest
     int e = q;
-    while (e < P && group_for(so[order[e] + 1] - so[order[e]], nl.dim_split) == bin.group) ++e;
+    while (e < P && group_of(so[order[e] + 1] - so[order[e]]) == bin.group) ++e;
     bin.q_count = e - q;
     bin.min_S = so[order[e - 1] + 1] - so[order[e - 1]];  // ... and the last one its shortest
-    nl.bins.push_back(bin);
+    bins.push_back(bin);
     q = e;
+  }
+}
+
+int nonlinear_plan_build(NonlinearPlan& nl, const std::vector<int32_t>& so, const std::vector<int32_t>& order) {
+  const int P = (int)order.size();
+  nl.dim_split = dim_split_for(P, P > 0 ? so[order[0] + 1] - so[order[0]] : 0);  // (sorted longest first)
+  const int ds = nl.dim_split;
+  build_bins(nl.bins, so, order, [ds](int S) { return group_for(S, ds); });
+  nl.wide_bins.clear();
+  nl.wide_blocks = 0;
+  if (ds == 1) {
+    build_bins(nl.wide_bins, so, order, [](int S) { return group_for_wide(S); });
+    for (const NonlinearBin& bin : nl.wide_bins) nl.wide_blocks += (int)cdiv_u(bin.q_count, 64 / bin.group);
   }
   return 0;
 }
@@ -1982,17 +2011,41 @@ hipError_t launch_nonlinear(NonlinearPlan& nl, const BatchView& b, const Nonline
   auto plain_lds = [&](const NonlinearBin& bin) {
     return ((size_t)(64 / bin.group) * lean_group_doubles(bin.max_S) + 2 * kPsTable) * sizeof(double);
   };
+  // Which lane groups.  The shared half sweeps halve the steps of an evaluation but need S + 4 lanes, the next group width
+  // for 13-15 and 29-30 segments: half the paths per wavefront for (S/2 + 1)/S of the steps -- more instructions per path,
+  // so a launch of many residency rounds (a saturated device: the kernel is bound by its instruction count) keeps the
+  // narrow groups and their one-sided sweeps.  A launch of a few residency rounds lasts about as long as its slowest
+  // wavefronts -- ten evaluations of the longest paths -- and there the wide groups win: whole pipeline, wide vs narrow,
+  // 8192 ragged 0.57 vs 0.65 ms, 8192 x 14 0.395 vs 0.425, 16384 x 14 0.644 vs 0.674, 32768 x 30 3.33 vs 3.51,
+  // 32768 ragged 1.87 vs 1.89; past that narrow: 65536 x 14 2.03 vs 1.97 ms (profiles/round5_wide_groups_ab.txt).
+  // (MRS_TG_LEAN_WIDE=0 / 1 forces.)
+  static const int resident_waves = [] {
+    int dev = 0, cus = 256;
+    if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    return cus * 4 * MRS_TG_LEAN_WAVES;
+  }();
+  static const int wide_forced = [] {
+    const char* e = std::getenv("MRS_TG_LEAN_WIDE");
+    return e ? (std::atoi(e) != 0 ? 1 : 0) : -1;
+  }();
+  const bool lean_masked_order = prm_in.derivative < 4;
+  bool wide = !nl.wide_bins.empty() && (int)nl.wide_bins.size() <= 5 && !lean_masked_order && prm.lean_shared != 0 &&
+              (wide_forced >= 0 ? wide_forced == 1 : nl.wide_blocks <= 8 * resident_waves);
+  if (wide)
+    for (const NonlinearBin& bin : nl.wide_bins)
+      if (plain_lds(bin) > 160 * 1024) wide = false;
+  const std::vector<NonlinearBin>& lean_bins = wide ? nl.wide_bins : nl.bins;
   if (lean)
-    for (const NonlinearBin& bin : nl.bins)
+    for (const NonlinearBin& bin : lean_bins)
       if (plain_lds(bin) > 160 * 1024) lean = false;
   if (lean) {
     if ((e = ensure_fallback(nl, b)) != hipSuccess) return e;
     BinTable bt{};
-    bt.n = (int)nl.bins.size();
+    bt.n = (int)lean_bins.size();
     size_t plds = 0;
     int blocks = 0;
     for (int i = 0; i < bt.n; ++i) {
-      const NonlinearBin& bin = nl.bins[i];
+      const NonlinearBin& bin = lean_bins[i];
       bt.group[i] = bin.group;
       bt.q_begin[i] = bin.q_begin;
       bt.q_count[i] = bin.q_count;
@@ -2020,8 +2073,11 @@ hipError_t launch_nonlinear(NonlinearPlan& nl, const BatchView& b, const Nonline
     }
     const bool lean_masked = prm.derivative < 4;  // rest-to-rest paths end on vertices with free slots
     // shared half sweeps (evaluate_lean_shared) where every path of every bin has its S + 4 lanes
+    // (with a bin of paths shorter than four segments beside them the kernel that has both evaluations compiled in runs, the
+    // short paths in wavefronts of their own next to the others: handing them to the compact kernel BEHIND the launch cost
+    // 66 us on 8192 ragged paths, profiles/round5_wide_groups_ab.txt)
     bool lean_shared_only = prm.lean_shared != 0 && !lean_masked;
-    for (const NonlinearBin& bin : nl.bins)
+    for (const NonlinearBin& bin : lean_bins)
       if (bin.min_S < 4 || bin.max_S + 4 > bin.group) lean_shared_only = false;
     if (plds > 64 * 1024 &&
         (e = hipFuncSetAttribute(lean_masked ? (const void*)optimize_lean_masked_kernel

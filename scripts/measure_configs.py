@@ -58,6 +58,13 @@ def main():
     ctx.use_torch_stream()
     if len(sys.argv) > 2:   # one config only, few repetitions: the command to put under rocprofv3
         which = sys.argv[2]
+        if which.startswith("ragged"):   # ragged batch of any size: where the wide lane groups stop paying
+            print(which, measure(ctx, pr.random_batch(int(which[6:]), "ragged", seed0=0), True, 10))
+            return
+        if which.startswith("uniform"):  # uniform<paths>x<segments>
+            n, seg = which[7:].split("x")
+            print(which, measure(ctx, pr.random_batch(int(n), int(seg), seed0=0), True, 10))
+            return
         batch = {"config3": lambda: pr.random_batch(1024, 10, seed0=0), "config4": lambda: pr.random_batch(8192, 10, seed0=0),
                  "config5": lambda: pr.random_batch(8192, "ragged", seed0=0),
                  "config6": lambda: pr.random_batch(65536, 10, seed0=0)}[which]()
