@@ -185,12 +185,20 @@ def _check_invariants(batch, out, limits_tol=1.05):
     assert np.array_equal(ratio > api.RUNAWAY_TIME_FACTOR, out["status"] == api.STATUS_ROUNDOFF_LIMITED)
 
 
-# (20, 24) and (15, 32): one path per wavefront with / without enough lanes for the two-sided evaluation in one round
-@pytest.mark.parametrize("n_seg,n_paths", [(10, 256), (3, 64), ("ragged", 96), (20, 24), (15, 32), (4, 16)])
+# Which outer-loop kernel a small batch runs (the library's kernel trace says so): one wavefront per path up to 12 segments,
+# the lane-per-dimension kernel for 13-15 (one path per wavefront, a partner wavefront from the other end), and the lane-group
+# kernels from 16 segments on whatever the batch size (round 5: dim_split_for; they were the large batches' kernels before)
+OUTER_LOOP_KERNEL = {10: "optimize_wave_kernel", 3: "optimize_wave_kernel", 4: "optimize_wave_kernel", 15: "optimize_split_kernel",
+                     20: "optimize_lean_shared_kernel", 30: "optimize_lean_shared_kernel", "ragged": "optimize_lean_kernel"}
+
+
+@pytest.mark.parametrize("n_seg,n_paths", [(10, 256), (3, 64), ("ragged", 96), (20, 24), (30, 8), (15, 32), (4, 16)])
 def test_nonlinear_end_to_end_vs_oracle(gpu_ctx, n_seg, n_paths):
     batch = pr.random_batch(n_paths, n_seg, seed0=4242)
     cap = 1024
+    api.kernel_trace_reset()
     out = gpu_ctx.solve_batch(batch, None, time_alloc_method=api.TIME_ALLOC_MELLINGER, sampling_dt=0.2, sample_capacity=cap)
+    assert OUTER_LOOP_KERNEL[n_seg] in api.kernel_trace(), api.kernel_trace()
     ref = po.solve_batch(batch.seg_offsets, batch.waypoints, batch.fixed_mask, batch.fixed_values, batch.limits,
                          np.zeros(batch.n_segments), deriv=4, time_alloc_method=2, estimate_times=True,
                          sampling_dt=0.2, sample_capacity=cap, n_threads=8)
