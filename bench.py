@@ -43,6 +43,7 @@ its persistent thread pool on the configs[3]-sized batch -- with as many threads
 `cpu_quota_cpus`, when that is less than the hardware threads it sees).
 """
 import argparse
+import gc
 import glob
 import json
 import os
@@ -166,12 +167,16 @@ def time_steps(step_fn, steps, warmup, dist, torch, final_fn=None, block_fn=None
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
+    gc_was_on = gc.isenabled()
+    gc.disable()            # (a collection inside a 60 us region would be the measurement)
     t0 = time.perf_counter()
     run(steps)
     if gather_inside and final_fn is not None:
         final_fn()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
+    if gc_was_on:
+        gc.enable()
     LAST_OWN_ELAPSED[0] = elapsed   # this rank's own figure, before the MAX over ranks
     gather_s = 0.0
     if final_fn is not None and not gather_inside and dist is not None:
