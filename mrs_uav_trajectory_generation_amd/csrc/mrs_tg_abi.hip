@@ -62,6 +62,9 @@ struct mrs_tg_ctx {
   size_t d_arena_bytes = 0;
   void* h_arena = nullptr;
   size_t h_arena_bytes = 0;
+  // pinned host scratch of mrs_tg_optimize_paths (the arrays of its rounds), kept across calls
+  void* h_scratch = nullptr;
+  size_t h_scratch_bytes = 0;
 };
 
 struct mrs_tg_plan {
@@ -305,6 +308,7 @@ void mrs_tg_destroy(mrs_tg_ctx* ctx) {
   }
   if (ctx->d_arena) (void)mrs_tg::pool_free(ctx->d_arena);
   if (ctx->h_arena) (void)hipHostFree(ctx->h_arena);
+  if (ctx->h_scratch) (void)hipHostFree(ctx->h_scratch);
   if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
   delete ctx;
   if (--g_live_contexts == 0) {  // the sampling tables and the cached device blocks go with the last context
@@ -886,13 +890,59 @@ int mrs_tg_plan_sample_states(mrs_tg_plan* plan, const double* coeffs, const dou
 // ---- one-call host interface ------------------------------------------------------------------
 
 
+extern "C++" {
+namespace mrs_tg {
+
+void* ctx_host_scratch(mrs_tg_ctx* ctx, size_t bytes) {
+  if (!ctx) return nullptr;
+  if (ctx->h_scratch_bytes >= bytes && ctx->h_scratch) return ctx->h_scratch;
+  if (ctx->h_scratch) (void)hipHostFree(ctx->h_scratch);
+  ctx->h_scratch = nullptr;
+  ctx->h_scratch_bytes = 0;
+  const size_t want = bytes + bytes / 4;  // (a later round's arrays are a little larger: its paths have more waypoints)
+  if (hipHostMalloc(&ctx->h_scratch, want, hipHostMallocDefault) != hipSuccess) {
+    (void)hipGetLastError();
+    ctx->h_scratch = nullptr;
+    return nullptr;
+  }
+  ctx->h_scratch_bytes = want;
+  return ctx->h_scratch;
+}
+
+}  // namespace mrs_tg
+}  // extern "C++"
+
+static int solve_batch_impl(mrs_tg_ctx* ctx, int32_t n_paths, const int32_t* so, const double* wp, const uint8_t* mask,
+                            const double* vals, const double* limits, const mrs_tg_options* opt, double* seg_times,
+                            double* coeffs, int32_t* status, double* cost, int32_t* n_samples, double* samples,
+                            bool coeffs_required);
+
 int mrs_tg_solve_batch(mrs_tg_ctx* ctx, int32_t n_paths, const int32_t* so, const double* wp, const uint8_t* mask,
                        const double* vals, const double* limits, const mrs_tg_options* opt, double* seg_times,
                        double* coeffs, int32_t* status, double* cost, int32_t* n_samples, double* samples) {
+  return solve_batch_impl(ctx, n_paths, so, wp, mask, vals, limits, opt, seg_times, coeffs, status, cost, n_samples, samples, true);
+}
+
+extern "C++" {
+namespace mrs_tg {
+// mrs_tg_solve_batch for a caller that reads only the samples (the policy layer): the coefficients stay on the device
+int solve_batch_samples_only(mrs_tg_ctx* ctx, int32_t n_paths, const int32_t* so, const double* wp, const uint8_t* mask,
+                             const double* vals, const double* limits, const mrs_tg_options* opt, double* seg_times,
+                             int32_t* status, int32_t* n_samples, double* samples) {
+  return solve_batch_impl(ctx, n_paths, so, wp, mask, vals, limits, opt, seg_times, nullptr, status, nullptr, n_samples, samples,
+                          false);
+}
+}  // namespace mrs_tg
+}  // extern "C++"
+
+static int solve_batch_impl(mrs_tg_ctx* ctx, int32_t n_paths, const int32_t* so, const double* wp, const uint8_t* mask,
+                            const double* vals, const double* limits, const mrs_tg_options* opt, double* seg_times,
+                            double* coeffs, int32_t* status, double* cost, int32_t* n_samples, double* samples,
+                            bool coeffs_required) {
   if (!ctx) return fail(nullptr, MRS_TG_ERR_INVALID_ARG, "ctx is NULL");
   int rc = check_options(ctx, opt);
   if (rc != MRS_TG_OK) return rc;
-  if (!so || !mask || !vals || !seg_times || !coeffs || !status)
+  if (!so || !mask || !vals || !seg_times || (!coeffs && coeffs_required) || !status)
     return fail(ctx, MRS_TG_ERR_INVALID_ARG, "seg_offsets, fixed_mask, fixed_values, seg_times, coeffs_out, status_out are required");
   if (n_paths == 0) return MRS_TG_OK;
   const auto t_call = std::chrono::steady_clock::now();

@@ -49,6 +49,14 @@ int kernel_trace(const char** names_out, int capacity);  // oldest first; at mos
 
 // records `message` as the context's (and the global) last error and returns `code`
 int report_error(mrs_tg_ctx* ctx, int code, const char* fmt, ...);
+// pinned host scratch owned by the context (grown on demand, kept across calls, freed with the context); null when the
+// runtime refuses the allocation
+void* ctx_host_scratch(mrs_tg_ctx* ctx, size_t bytes);
+// mrs_tg_solve_batch for a caller that reads only times, statuses and samples: the coefficients are not downloaded
+int solve_batch_samples_only(mrs_tg_ctx* ctx, int32_t n_paths, const int32_t* seg_offsets, const double* waypoints,
+                             const uint8_t* fixed_mask, const double* fixed_values, const double* limits,
+                             const mrs_tg_options* opt, double* seg_times_inout, int32_t* status_out, int32_t* n_samples_out,
+                             double* samples_out);
 
 // Device-resident structure of a batch (built once per plan).
 struct BatchView {

@@ -14,10 +14,13 @@
 #include <algorithm>
 #include <cfloat>
 #include <cmath>
+#include <cstdio>
 #include <cstring>
+#include <thread>
 #include <vector>
 
 #include <chrono>
+#include <sched.h>
 
 #include "../../include/mrs_tg.h"
 #include "mrs_tg_launch.h"
@@ -142,6 +145,38 @@ void estimate_times_baca(int S, const double* wp, const double* lim, std::vector
     if (hf > t) t = hf;
     out[i] = t;
   }
+}
+
+// The policy's per-path host work (vertex building, Baca estimates, spatial validation, mid-point insertion) is independent
+// from path to path: batches of requests run it on a few threads.  Ranges of [0, n) in order, one per thread; small batches
+// (a nodelet's single request) stay on the calling thread.  MRS_TG_POLICY_THREADS=1 switches the threads off.
+int policy_threads() {
+  static const int n = [] {
+    if (const char* e = std::getenv("MRS_TG_POLICY_THREADS")) return std::max(1, std::atoi(e));
+    int cpus = (int)std::thread::hardware_concurrency();
+    cpu_set_t set;
+    if (sched_getaffinity(0, sizeof(set), &set) == 0) cpus = std::min(cpus > 0 ? cpus : 1 << 20, CPU_COUNT(&set));
+    return std::max(1, std::min(cpus, 16));
+  }();
+  return n;
+}
+
+template <class F>
+void parallel_ranges(size_t n, size_t min_per_thread, F&& body) {  // body(begin, end)
+  const size_t threads = std::min<size_t>((size_t)policy_threads(), n / std::max<size_t>(min_per_thread, 1));
+  if (threads <= 1) {
+    body((size_t)0, n);
+    return;
+  }
+  std::vector<std::thread> pool;
+  pool.reserve(threads - 1);
+  const size_t chunk = (n + threads - 1) / threads;
+  for (size_t t = 1; t < threads; ++t) {
+    const size_t b = std::min(n, t * chunk), e = std::min(n, b + chunk);
+    if (b < e) pool.emplace_back([&body, b, e] { body(b, e); });
+  }
+  body((size_t)0, std::min(n, chunk));
+  for (std::thread& th : pool) th.join();
 }
 
 struct PathState {
@@ -325,14 +360,23 @@ int mrs_tg_optimize_paths(mrs_tg_ctx* ctx, int32_t n_paths, const int32_t* wp_of
   const auto t_begin = std::chrono::steady_clock::now();
   auto elapsed = [&]() { return std::chrono::duration<double>(std::chrono::steady_clock::now() - t_begin).count(); };
   std::vector<PathState> st((size_t)n_paths);
-  for (int p = 0; p < n_paths; ++p) {
-    preprocess(waypoints + wp_offsets[p], wp_offsets[p + 1] - wp_offsets[p], o, st[p]);
-    if (st[p].n_wp <= 1) {  // "the path is empty (after postprocessing)" :676-681
-      st[p].done = true;
-      st[p].ok = false;
+  parallel_ranges((size_t)n_paths, 256, [&](size_t p0, size_t p1) {
+    for (size_t p = p0; p < p1; ++p) {
+      preprocess(waypoints + wp_offsets[p], wp_offsets[p + 1] - wp_offsets[p], o, st[p]);
+      if (st[p].n_wp <= 1) {  // "the path is empty (after postprocessing)" :676-681
+        st[p].done = true;
+        st[p].ok = false;
+      }
     }
-  }
+  });
   std::vector<int> active;
+  // MRS_TG_POLICY_TRACE=1: where the call's time went (host phases and the batched GPU call), on stderr
+  static const bool trace = [] {
+    const char* e = std::getenv("MRS_TG_POLICY_TRACE");
+    return e != nullptr && std::atoi(e) != 0;
+  }();
+  double t_build = 0, t_solve = 0, t_post = 0, t_validate = 0;
+  auto now = [&]() { return trace ? elapsed() : 0.0; };
   for (int round = 0; round <= o.max_deviation_iterations; ++round) {
     active.clear();
     for (int p = 0; p < n_paths; ++p)
@@ -378,92 +422,131 @@ int mrs_tg_optimize_paths(mrs_tg_ctx* ctx, int32_t n_paths, const int32_t* wp_of
         if (!st[p].ok) st[p].done = true;
       }
     } else {
-      // vertices exactly as findTrajectory builds them (:923-977)
-      std::vector<int32_t> so(active.size() + 1, 0);
-      for (size_t a = 0; a < active.size(); ++a) so[a + 1] = so[a] + st[active[a]].n_wp - 1;
-      const size_t nS = (size_t)so.back(), nV = nS + active.size();
-      std::vector<double> wp(nV * 4), vals(nV * 20, 0.0), lim(active.size() * 9), times(nS, 0.0), coeffs(nS * 40), cost(active.size());
-      std::vector<uint8_t> mask(nV * 5, 0);
-      std::vector<int32_t> status(active.size()), ns(active.size());
-      std::vector<double> smp(active.size() * (size_t)sample_capacity * 4);
-      for (size_t a = 0; a < active.size(); ++a) {
-        const int p = active[a];
-        const PathState& s = st[p];
-        const bool has_init = has_initial_state && has_initial_state[p] && initial_states;
-        const size_t v0 = (size_t)so[a] + a;
-        double last_heading = has_init ? initial_states[p].heading : s.wps[3];
-        for (int i = 0; i < s.n_wp; ++i) {
-          double* w = wp.data() + (v0 + i) * 4;
-          for (int k = 0; k < 3; ++k) w[k] = s.wps[(size_t)i * 4 + k];
-          w[3] = sradians_unwrap(s.wps[(size_t)i * 4 + 3], last_heading);
-          last_heading = w[3];
-          uint8_t* m = mask.data() + (v0 + i) * 5;
-          double* vv = vals.data() + (v0 + i) * 20;
-          m[0] = 1;
-          for (int k = 0; k < 4; ++k) vv[k] = w[k];
-          if (i == 0 || i == s.n_wp - 1) {
-            for (int k = 1; k <= d; ++k) m[k] = 1;
-            if (i == 0 && has_init) {
-              m[1] = m[2] = m[3] = 1;
-              for (int k = 0; k < 4; ++k) {
-                vv[4 + k] = initial_states[p].velocity[k];
-                vv[8 + k] = initial_states[p].acceleration[k];
-                vv[12 + k] = initial_states[p].jerk[k];
-              }
-            }
-          } else if (s.stop[i]) {
-            m[1] = m[2] = m[3] = 1;
-          }
-        }
-        for (int k = 0; k < 9; ++k) lim[a * 9 + k] = limits[(size_t)p * 9 + k];
-        if (relax_heading && relax_heading[p]) lim[a * 9 + 2] = lim[a * 9 + 5] = lim[a * 9 + 8] = (double)FLT_MAX;
-        std::vector<double> tb;
-        estimate_times_baca(s.n_wp - 1, wp.data() + v0 * 4, lim.data() + a * 9, tb);
-        double tot = 0;
-        for (double t : tb) tot += t;
-        st[p].baca_total = tot;
+      // vertices exactly as findTrajectory builds them (:923-977).  The arrays of the round live in ONE block of pinned
+      // host memory kept by the context (no allocation, no page faults and no clearing of a 64 KB sample buffer per
+      // request and round; the GPU reads and writes pinned arrays in place, and only the sample rows a path has produced
+      // travel); the coefficients, which the policy never reads, stay on the device
+      const double t0 = now();
+      const size_t A = active.size();
+      std::vector<int32_t> so(A + 1, 0);
+      for (size_t a = 0; a < A; ++a) so[a + 1] = so[a] + st[active[a]].n_wp - 1;
+      const size_t nS = (size_t)so.back(), nV = nS + A;
+      auto up = [](size_t bytes) { return (bytes + 255) & ~(size_t)255; };
+      const size_t b_wp = up(nV * 4 * sizeof(double)), b_vals = up(nV * 20 * sizeof(double)), b_lim = up(A * 9 * sizeof(double)),
+                   b_times = up(nS * sizeof(double)), b_smp = up(A * (size_t)sample_capacity * 4 * sizeof(double)),
+                   b_status = up(A * sizeof(int32_t)), b_ns = up(A * sizeof(int32_t)), b_mask = up(nV * 5);
+      const size_t need = b_wp + b_vals + b_lim + b_times + b_smp + b_status + b_ns + b_mask;
+      char* block = static_cast<char*>(mrs_tg::ctx_host_scratch(ctx, need));
+      std::vector<char> pageable;  // (the runtime refused that much pinned memory: ordinary memory, copied by the runtime)
+      if (!block) {
+        pageable.resize(need);
+        block = pageable.data();
       }
+      double* wp = reinterpret_cast<double*>(block);
+      double* vals = reinterpret_cast<double*>(block + b_wp);
+      double* lim = reinterpret_cast<double*>(block + b_wp + b_vals);
+      double* times = reinterpret_cast<double*>(block + b_wp + b_vals + b_lim);
+      double* smp = reinterpret_cast<double*>(block + b_wp + b_vals + b_lim + b_times);
+      int32_t* status = reinterpret_cast<int32_t*>(block + b_wp + b_vals + b_lim + b_times + b_smp);
+      int32_t* ns = reinterpret_cast<int32_t*>(block + b_wp + b_vals + b_lim + b_times + b_smp + b_status);
+      uint8_t* mask = reinterpret_cast<uint8_t*>(block + b_wp + b_vals + b_lim + b_times + b_smp + b_status + b_ns);
+      parallel_ranges(A, 128, [&](size_t a0, size_t a1) {
+        std::vector<double> tb;
+        for (size_t a = a0; a < a1; ++a) {
+          const int p = active[a];
+          const PathState& s = st[p];
+          const bool has_init = has_initial_state && has_initial_state[p] && initial_states;
+          const size_t v0 = (size_t)so[a] + a;
+          std::memset(vals + v0 * 20, 0, sizeof(double) * 20 * (size_t)s.n_wp);
+          std::memset(mask + v0 * 5, 0, 5 * (size_t)s.n_wp);
+          std::memset(times + so[a], 0, sizeof(double) * (size_t)(s.n_wp - 1));
+          double last_heading = has_init ? initial_states[p].heading : s.wps[3];
+          for (int i = 0; i < s.n_wp; ++i) {
+            double* w = wp + (v0 + i) * 4;
+            for (int k = 0; k < 3; ++k) w[k] = s.wps[(size_t)i * 4 + k];
+            w[3] = sradians_unwrap(s.wps[(size_t)i * 4 + 3], last_heading);
+            last_heading = w[3];
+            uint8_t* m = mask + (v0 + i) * 5;
+            double* vv = vals + (v0 + i) * 20;
+            m[0] = 1;
+            for (int k = 0; k < 4; ++k) vv[k] = w[k];
+            if (i == 0 || i == s.n_wp - 1) {
+              for (int k = 1; k <= d; ++k) m[k] = 1;
+              if (i == 0 && has_init) {
+                m[1] = m[2] = m[3] = 1;
+                for (int k = 0; k < 4; ++k) {
+                  vv[4 + k] = initial_states[p].velocity[k];
+                  vv[8 + k] = initial_states[p].acceleration[k];
+                  vv[12 + k] = initial_states[p].jerk[k];
+                }
+              }
+            } else if (s.stop[i]) {
+              m[1] = m[2] = m[3] = 1;
+            }
+          }
+          for (int k = 0; k < 9; ++k) lim[a * 9 + k] = limits[(size_t)p * 9 + k];
+          if (relax_heading && relax_heading[p]) lim[a * 9 + 2] = lim[a * 9 + 5] = lim[a * 9 + 8] = (double)FLT_MAX;
+          estimate_times_baca(s.n_wp - 1, wp + v0 * 4, lim + a * 9, tb);
+          double tot = 0;
+          for (double t : tb) tot += t;
+          st[p].baca_total = tot;
+        }
+      });
       mrs_tg_options so_opt = o.solver;
       so_opt.estimate_times = 1;
       so_opt.sample_capacity = sample_capacity;
       if (o.max_execution_time_s > 0) so_opt.max_time_s = 2.0 * 0.95 * budget_left;  // :899
-      const int rc = mrs_tg_solve_batch(ctx, (int32_t)active.size(), so.data(), wp.data(), mask.data(), vals.data(), lim.data(),
-                                        &so_opt, times.data(), coeffs.data(), status.data(), cost.data(), ns.data(), smp.data());
+      const double t1 = now();
+      t_build += t1 - t0;
+      const int rc = mrs_tg::solve_batch_samples_only(ctx, (int32_t)A, so.data(), wp, mask, vals, lim, &so_opt, times, status, ns, smp);
       if (rc != MRS_TG_OK) return rc;
+      const double t2 = now();
+      t_solve += t2 - t1;
       const bool late = overtime();  // findTrajectory's own checks behind optimize() and the sampler: "return {}" (:1085, :1156, :1171)
-      for (size_t a = 0; a < active.size(); ++a) {
-        const int p = active[a];
-        bool ok = !late && ((status[a] >= 1 && status[a] != 6) || status[a] == -1);  // :1138-1149
-        const double len = (double)ns[a] * dt;                            // :1178-1199
-        if (ok && len > 1.0 && (len > o.max_trajectory_len_factor * st[p].baca_total || len < o.min_trajectory_len_factor * st[p].baca_total))
-          ok = false;
-        if (ns[a] > sample_capacity) ok = false;
-        st[p].ok = ok;
-        st[p].n_samples = ok ? ns[a] : 0;
-        if (!ok) {
-          st[p].done = true;  // "failed to find trajectory" :720-727, :771-778
-        } else {
-          std::memcpy(samples_out + (size_t)p * sample_capacity * 4, smp.data() + a * (size_t)sample_capacity * 4,
-                      sizeof(double) * 4 * (size_t)ns[a]);
+      parallel_ranges(A, 128, [&](size_t a0, size_t a1) {
+        for (size_t a = a0; a < a1; ++a) {
+          const int p = active[a];
+          bool ok = !late && ((status[a] >= 1 && status[a] != 6) || status[a] == -1);  // :1138-1149
+          const double len = (double)ns[a] * dt;                            // :1178-1199
+          if (ok && len > 1.0 && (len > o.max_trajectory_len_factor * st[p].baca_total || len < o.min_trajectory_len_factor * st[p].baca_total))
+            ok = false;
+          if (ns[a] > sample_capacity) ok = false;
+          st[p].ok = ok;
+          st[p].n_samples = ok ? ns[a] : 0;
+          if (!ok) {
+            st[p].done = true;  // "failed to find trajectory" :720-727, :771-778
+          } else {
+            std::memcpy(samples_out + (size_t)p * sample_capacity * 4, smp + a * (size_t)sample_capacity * 4,
+                        sizeof(double) * 4 * (size_t)ns[a]);
+          }
         }
-      }
+      });
+      t_post += now() - t2;
     }
     if (round == o.max_deviation_iterations) break;  // the last re-solve is not validated again (:729)
     // ---- validate, subdivide the unsafe ones
-    std::vector<uint8_t> safe;
-    for (int p : active) {
-      if (st[p].done) continue;
-      double md = 0;
-      const bool is_safe = validate_spatial(samples_out + (size_t)p * sample_capacity * 4, st[p].n_samples, st[p], o, safe, md);
-      st[p].max_dev = md;
-      if (o.check_deviation_enabled && !is_safe) {
-        insert_midpoints(st[p], safe, o);
-        st[p].iterations = round + 1;
-      } else {
-        st[p].done = true;
+    const double t3 = now();
+    parallel_ranges(active.size(), 128, [&](size_t a0, size_t a1) {
+      std::vector<uint8_t> safe;
+      for (size_t a = a0; a < a1; ++a) {
+        const int p = active[a];
+        if (st[p].done) continue;
+        double md = 0;
+        const bool is_safe = validate_spatial(samples_out + (size_t)p * sample_capacity * 4, st[p].n_samples, st[p], o, safe, md);
+        st[p].max_dev = md;
+        if (o.check_deviation_enabled && !is_safe) {
+          insert_midpoints(st[p], safe, o);
+          st[p].iterations = round + 1;
+        } else {
+          st[p].done = true;
+        }
       }
-    }
+    });
+    t_validate += now() - t3;
   }
+  if (trace)
+    std::fprintf(stderr, "mrs_tg_optimize_paths: %d requests, %.3f ms: vertices + estimates %.3f, mrs_tg_solve_batch %.3f, results %.3f, "
+                 "validation + mid-points %.3f\n", n_paths, elapsed() * 1e3, t_build * 1e3, t_solve * 1e3, t_post * 1e3, t_validate * 1e3);
   for (int p = 0; p < n_paths; ++p) {
     const PathState& s = st[p];
     success_out[p] = s.ok ? 1 : 0;

@@ -92,3 +92,56 @@ def test_waypoint_trajectory_idxs(gpu_ctx):
     kr = po.lib().mto_waypoint_trajectory_idxs(po._dp(smp), n, po._dp(np.ascontiguousarray(wp)), wp.shape[0],
                                                ref.ctypes.data_as(C.POINTER(C.c_int32)))
     assert k == kr and np.array_equal(idx[:k], ref[:kr]) and k >= wp.shape[0] - 1
+
+
+# ---- batches of requests: the policy's per-path host work runs on several threads (mrs_tg_policy.hip::parallel_ranges, from a
+# few hundred requests on) and its arrays live in pinned scratch memory of the context.  The requests are independent, so the
+# results must be THE SAME BITS as on one thread (MRS_TG_POLICY_THREADS=1, read once per process: a child process), and a
+# strided subset must agree with the oracle as the small batches above do.
+POLICY_CHILD = r"""
+import sys
+sys.path.insert(0, %r)
+import numpy as np
+from mrs_uav_trajectory_generation_amd import api
+from tests.test_gpu_policy import _many_requests
+ctx = api.Context(0)
+out = _many_requests(ctx)
+np.savez(sys.argv[1], **out)
+"""
+
+
+def _many_requests(ctx):
+    paths = [(pr.random_box_waypoints if i % 3 else pr.random_walk_waypoints)(4 + (i % 6), 3100 + i) for i in range(700)]
+    stops = [[(i % 4 == 2 and 0 < k < len(p) - 1) for k in range(len(p))] for i, p in enumerate(paths)]
+    return api.optimize_paths(ctx, paths, stop_flags=stops, sample_capacity=1024)
+
+
+def test_batch_of_requests_on_threads_gives_the_bits_of_one_thread_and_agrees_with_the_oracle(gpu_ctx, tmp_path):
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = _many_requests(gpu_ctx)
+    again = _many_requests(gpu_ctx)            # the context's scratch block is reused: nothing of the first call may linger
+    for k in out:
+        assert np.array_equal(out[k], again[k]), k
+    ref_path = str(tmp_path / "one_thread.npz")
+    subprocess.run([sys.executable, "-c", POLICY_CHILD % root, ref_path], check=True, cwd=root, timeout=600,
+                   env=dict(os.environ, MRS_TG_POLICY_THREADS="1"))
+    ref = np.load(ref_path)
+    for k in out:
+        assert np.array_equal(out[k], ref[k]), k
+    assert out["success"].mean() > 0.98 and out["iterations"].max() >= 3      # (the subdivision rounds did run)
+    paths = [(pr.random_box_waypoints if i % 3 else pr.random_walk_waypoints)(4 + (i % 6), 3100 + i) for i in range(700)]
+    same = n_checked = 0
+    for p in range(0, 700, 35):
+        stops = [(p % 4 == 2 and 0 < k < len(paths[p]) - 1) for k in range(len(paths[p]))]
+        o = po.optimize_path(paths[p], stop_at=stops, limits=pr.DEFAULT_LIMITS, capacity=1024)
+        n_checked += 1
+        assert out["success"][p] == o["success"]
+        if (out["n_waypoints"][p] == o["n_waypoints"] and out["iterations"][p] == o["iterations"] and out["n_samples"][p] == o["n_samples"]):
+            n = o["n_samples"]
+            if n == 0 or np.max(np.abs(out["samples"][p, :n, :3] - o["samples"][:, :3])) < 1e-6:
+                same += 1
+    print("RATE policy batch of 700: %d / %d" % (same, n_checked))
+    assert same >= n_checked - 2, (same, n_checked)
