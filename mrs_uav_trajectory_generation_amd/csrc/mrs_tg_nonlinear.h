@@ -63,6 +63,9 @@ struct NonlinearPlan {
   // by launch_nonlinear while the launch is about as large as the device holds at once (see there)
   std::vector<NonlinearBin> wide_bins;
   int wide_blocks = 0;             // workgroups of a launch over wide_bins
+  // objective orders below snap (free slots at the end vertices): every path of four or more segments in a group of at least
+  // S + 4 lanes, for the shared half sweeps with free ends (optimize_lean_shared_ends_kernel); empty when a path is too long
+  std::vector<NonlinearBin> ends_bins;
   int dim_split = 1;               // lanes per time vector in the outer loop: 1 (compact) or 4 (one per dimension)
   double* d_ws = nullptr;          // factor store of the per-lane linear solve
   size_t ws_doubles = 0;

@@ -552,8 +552,15 @@ __device__ __forceinline__ double evaluate_lean(const double* tabs, const double
 #else
 #define LEAN_TAB(e) Tab_regs.at(e)
 #endif
+// ENDS: the two end vertices may leave derivative slots free (rest-to-rest paths under an objective order below snap: jerk
+// and / or snap stay free there; stage_ps leaves the two free masks in front of qs).  The first step of a half sweep then
+// eliminates the end vertex like any other vertex -- the block of the segment's near part with the rows and columns of the
+// constrained slots replaced by the identity, and their reciprocal pivots by zero, so that they contribute nothing to W, z
+// and the cost -- instead of moving the state to the next vertex; every other step is the plain one.
+template <bool ENDS>
 __device__ __forceinline__ double evaluate_lean_shared(const double* tabs, const double* ev, double* pub, int S, int Sb, int d,
                                                        const double* pt, double* grad, int g, int G, bool active, int* tripped) {
+  static_assert(!(ENDS && MRS_TG_LEAN_CONST_TABLE), "the compile-time table is the order-4 one");
   const double* dp = ev;
   const double* qs = ev + 4 * (size_t)Sb + 2;  // HBAR[0][0] |dp_i|^2 per segment (stage_ps)
   const int m = S >> 1, nL = m + 2;
@@ -592,17 +599,26 @@ __device__ __forceinline__ double evaluate_lean_shared(const double* tabs, const
     for (int q = 0; q < 4; ++q) y[rr][q] = 0.0;
   int i = left ? 0 : S - 1;
   const int di = left ? 1 : -1;
+  // ENDS: free slots of the end vertex this lane starts from (bit r: derivative r + 1), and the pivots' scale: 0 for a
+  // constrained slot of the end vertex in the first step, 1 everywhere else
+  unsigned fm = 0u;
+  double rs[kNB];
+#pragma unroll
+  for (int rr = 0; rr < kNB; ++rr) rs[rr] = 1.0;
+  if (ENDS) fm = (unsigned)ev[4 * (size_t)Sb + (left ? 0 : 1)] & 0xFu;
   for (int s = 0; __ballot(valid && s < nhalf) != 0ull; ++s) {
     if (valid && s < nhalf) {
       double T = pt[i];
       if (k > 0) T = (i == k - 1) ? T + kGradStep : fmax(T - corr, kTimeLowerBound);
       double p2[9];
-      segment_powers_c<4>(T, p2);
+      if (ENDS) segment_powers(T, d, p2);
+      else segment_powers_c<4>(T, p2);
       double dq[4];
 #pragma unroll
       for (int q = 0; q < 4; ++q) dq[q] = dp[i * 4 + q];
       qf = fma(p2[0], qs[i], qf);
-      if (s == 0) {  // the end vertex is fully constrained: the state moves to the next vertex
+      const bool free_end = ENDS && s == 0 && fm != 0u;
+      if (s == 0 && !free_end) {  // the end vertex is fully constrained: the state moves to the next vertex
 #pragma unroll
         for (int rr = 0; rr < kNB; ++rr) {
 #pragma unroll
@@ -613,6 +629,7 @@ __device__ __forceinline__ double evaluate_lean_shared(const double* tabs, const
         }
       } else {
         // the vertex the sweep stands on: its block and right-hand side are complete with this segment's near part
+        // (a free end vertex: Sm and y are still zero, the near part IS the block -- with the identity in the constrained slots)
 #pragma unroll
         for (int rr = 0; rr < kNB; ++rr) {
 #pragma unroll
@@ -621,6 +638,17 @@ __device__ __forceinline__ double evaluate_lean_shared(const double* tabs, const
 #pragma unroll
           for (int q = 0; q < 4; ++q) y[rr][q] = fma(-cN, dq[q], y[rr][q]);
         }
+        if (ENDS) {
+#pragma unroll
+          for (int rr = 0; rr < kNB; ++rr) rs[rr] = (free_end && !((fm >> rr) & 1u)) ? 0.0 : 1.0;
+          if (free_end) {
+#pragma unroll
+            for (int rr = 0; rr < kNB; ++rr)
+#pragma unroll
+              for (int c = 0; c <= rr; ++c)
+                if (!((fm >> rr) & 1u) || !((fm >> c) & 1u)) Sm[tri(rr, c)] = (rr == c) ? 1.0 : 0.0;
+          }
+        }
         double L[10], Linv[kNB], z[kNB][4], W[kNB][kNB];
 #pragma unroll
         for (int c = 0; c < kNB; ++c) {
@@ -628,7 +656,7 @@ __device__ __forceinline__ double evaluate_lean_shared(const double* tabs, const
 #pragma unroll
           for (int mm = 0; mm < c; ++mm) dsum = fma(-L[tri(c, mm)], L[tri(c, mm)], dsum);
           const double inv = rsqrt_refined(dsum);
-          Linv[c] = inv;
+          Linv[c] = ENDS ? inv * rs[c] : inv;
 #pragma unroll
           for (int rr = c + 1; rr < kNB; ++rr) {
             double t = Sm[tri(rr, c)];
@@ -901,7 +929,9 @@ __device__ __forceinline__ void optimize_body(const BatchView& b, const Nonlinea
   double t_first = 0.0;
   if (active && wave == 0 && g < S) t_first = start_time(prm, t_src, pr, g);
   if (LEAN) {  // vtx = the evaluation area: dp of every segment; the path's eligibility decides who runs it
-    const bool takes = stage_ps(mask, vals, pr.v0, S, Sb, vtx, g, G, active, 2, d, MASKED4);
+    // (the kernel of the shared half sweeps with free end slots runs every bin of a ragged plan, in groups of S + 4 lanes:
+    // paths of fewer than four segments are left to the sweeping kernel behind it)
+    const bool takes = stage_ps(mask, vals, pr.v0, S, Sb, vtx, g, G, active, (LEANSHARED && MASKED4) ? 4 : 2, d, MASKED4);
     if (active && g == 0) fallback[q] = takes ? 0 : 1;
     active = active && takes;
   } else {
@@ -1047,7 +1077,7 @@ __device__ __forceinline__ void optimize_body(const BatchView& b, const Nonlinea
             S = pr.S;
             active = true;
             double t_new = (g < S) ? start_time(prm, seg_times, pr, g) : 0.0;
-            const bool takes = stage_ps(mask, vals, pr.v0, S, Sb, vtx, g, G, true, 2, d, MASKED4);
+            const bool takes = stage_ps(mask, vals, pr.v0, S, Sb, vtx, g, G, true, (LEANSHARED && MASKED4) ? 4 : 2, d, MASKED4);
             if (g == 0) fallback[q] = takes ? 0 : 1;
             if (takes) {
               int okn = 1;
@@ -1110,9 +1140,9 @@ __device__ __forceinline__ void optimize_body(const BatchView& b, const Nonlinea
       // shared half sweeps when every path of the wavefront takes them (plain paths of 4 <= S <= G - 4 segments: S + 4 lanes)
       const bool shared_path = S >= 4 && S + 4 <= G;
       if (LEANSHARED)
-        fn = evaluate_lean_shared(hc, vtx, vtx + 4 * (size_t)Sb + 4 * ((size_t)Sb + 1), S, Sb, d, xn, gn, g, G, !done, tick_i + 4);
+        fn = evaluate_lean_shared<MASKED4>(hc, vtx, vtx + 4 * (size_t)Sb + 4 * ((size_t)Sb + 1), S, Sb, d, xn, gn, g, G, !done, tick_i + 4);
       else if (!MASKED4 && prm.lean_shared == 2 && __ballot(!done && !shared_path) == 0ull)
-        fn = evaluate_lean_shared(hc, vtx, vtx + 4 * (size_t)Sb + 4 * ((size_t)Sb + 1), S, Sb, d, xn, gn, g, G, !done, tick_i + 4);
+        fn = evaluate_lean_shared<false>(hc, vtx, vtx + 4 * (size_t)Sb + 4 * ((size_t)Sb + 1), S, Sb, d, xn, gn, g, G, !done, tick_i + 4);
       else
         fn = evaluate_lean<MASKED4>(hc, vtx, S, Sb, d, xn, gn, g, G, !done, tick_i + 4);
     } else if (GENERAL) {
@@ -1531,6 +1561,15 @@ __global__ __launch_bounds__(64, MRS_TG_LEAN_WAVES) void optimize_lean_shared_ke
   optimize_body<1, false, false, true, false, true>(b, prm, bins, mask, vals, seg_times, opt_status, nullptr, fallback);
 }
 
+// shared half sweeps with free slots at the end vertices (objective orders below snap; evaluate_lean_shared<true>): every bin
+// in groups of at least S + 4 lanes
+__global__ __launch_bounds__(64, MRS_TG_LEAN_WAVES) void optimize_lean_shared_ends_kernel(BatchView b, NonlinearParams prm, BinTable bins,
+                                                              const uint8_t* __restrict__ mask, const double* __restrict__ vals,
+                                                              double* __restrict__ seg_times, int32_t* __restrict__ opt_status,
+                                                              int32_t* __restrict__ fallback) {
+  optimize_body<1, true, false, true, false, true>(b, prm, bins, mask, vals, seg_times, opt_status, nullptr, fallback);
+}
+
 // the end vertices may leave slots free (launches whose objective order is below snap: the masked step at the two ends of
 // the sweep); one wavefront per SIMD -- at two it spills 96 registers and loses to the general kernel
 __global__ __launch_bounds__(64) void optimize_lean_masked_kernel(BatchView b, NonlinearParams prm, BinTable bins,
@@ -1792,6 +1831,15 @@ static int group_for_wide(int S) {
   return G;
 }
 
+// lanes per path when EVERY path of four or more segments gets its S + 4 lanes (0: no group is wide enough)
+static int group_for_ends(int S) {
+  if (S < 4) return group_for(S, 1);
+  if (S + 4 > 64) return 0;
+  int G = 8;
+  while (G < S + 4) G <<= 1;
+  return G;
+}
+
 template <class GroupFor>
 static void build_bins(std::vector<NonlinearBin>& bins, const std::vector<int32_t>& so, const std::vector<int32_t>& order,
                        GroupFor group_of) {
@@ -1825,6 +1873,9 @@ int nonlinear_plan_build(NonlinearPlan& nl, const std::vector<int32_t>& so, cons
     build_bins(nl.wide_bins, so, order, [](int S) { return group_for_wide(S); });
     for (const NonlinearBin& bin : nl.wide_bins) nl.wide_blocks += (int)cdiv_u(bin.q_count, 64 / bin.group);
   }
+  nl.ends_bins.clear();
+  if (ds == 1 && P > 0 && group_for_ends(so[order[0] + 1] - so[order[0]]) != 0)
+    build_bins(nl.ends_bins, so, order, [](int S) { return group_for_ends(S); });
   return 0;
 }
 
@@ -2034,7 +2085,13 @@ hipError_t launch_nonlinear(NonlinearPlan& nl, const BatchView& b, const Nonline
   if (wide)
     for (const NonlinearBin& bin : nl.wide_bins)
       if (plain_lds(bin) > 160 * 1024) wide = false;
-  const std::vector<NonlinearBin>& lean_bins = wide ? nl.wide_bins : nl.bins;
+  // objective orders below snap: the shared half sweeps with free end slots, every path in a group of S + 4 lanes at least
+  // (MRS_TG_LEAN_SHARED=0: the one-sided masked sweeps of optimize_lean_masked_kernel, as until round 5)
+  bool ends_shared = lean_masked_order && prm.lean_shared != 0 && !nl.ends_bins.empty() && (int)nl.ends_bins.size() <= 5;
+  if (ends_shared)
+    for (const NonlinearBin& bin : nl.ends_bins)
+      if (plain_lds(bin) > 160 * 1024) ends_shared = false;
+  const std::vector<NonlinearBin>& lean_bins = ends_shared ? nl.ends_bins : wide ? nl.wide_bins : nl.bins;
   if (lean)
     for (const NonlinearBin& bin : lean_bins)
       if (plain_lds(bin) > 160 * 1024) lean = false;
@@ -2080,11 +2137,15 @@ hipError_t launch_nonlinear(NonlinearPlan& nl, const BatchView& b, const Nonline
     for (const NonlinearBin& bin : lean_bins)
       if (bin.min_S < 4 || bin.max_S + 4 > bin.group) lean_shared_only = false;
     if (plds > 64 * 1024 &&
-        (e = hipFuncSetAttribute(lean_masked ? (const void*)optimize_lean_masked_kernel
+        (e = hipFuncSetAttribute(ends_shared ? (const void*)optimize_lean_shared_ends_kernel
+                                 : lean_masked ? (const void*)optimize_lean_masked_kernel
                                  : lean_shared_only ? (const void*)optimize_lean_shared_kernel : (const void*)optimize_lean_kernel,
                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)plds)) != hipSuccess)
       return e;
-    if (lean_masked)
+    if (ends_shared)
+      MRS_TG_LAUNCH_EXT(optimize_lean_shared_ends_kernel, dim3(blocks), dim3(64), plds, stream, kt.start, nullptr, 0, b, prm, bt,
+                            mask, vals, seg_times, nl.d_opt_status, nl.d_fallback);
+    else if (lean_masked)
       MRS_TG_LAUNCH_EXT(optimize_lean_masked_kernel, dim3(blocks), dim3(64), plds, stream, kt.start, nullptr, 0, b, prm, bt, mask,
                             vals, seg_times, nl.d_opt_status, nl.d_fallback);
     else if (lean_shared_only)

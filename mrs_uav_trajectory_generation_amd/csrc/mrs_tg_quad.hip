@@ -58,8 +58,9 @@ constexpr int kQdPaths = 16;  // paths per wavefront
 // 16 doubles less per record: five wavefronts per CU instead of three at 10 segments)
 constexpr int kQdL = 0, kQdLinv = 6, kQdZ = 10, kQdRec = 26;
 
-__host__ __device__ constexpr size_t quad_lds_doubles(int Smax) {
-  return (size_t)(Smax > 1 ? Smax - 1 : 1) * kQdRec * kQdPaths + (size_t)Smax * kQdPaths  // records | times
+// ends: records for the two end vertices as well (solve_quad_body<WP, true>: end vertices with free slots are eliminated)
+__host__ __device__ constexpr size_t quad_lds_doubles(int Smax, bool ends = false) {
+  return (size_t)(ends ? Smax + 1 : (Smax > 1 ? Smax - 1 : 1)) * kQdRec * kQdPaths + (size_t)Smax * kQdPaths  // records | times
 #if MRS_TG_QUAD_EXP == 5
          + kQdPaths  // per path: first segment and segment count (ints)
 #endif
@@ -96,7 +97,12 @@ __device__ __forceinline__ double quad_sum(double v) {  // over the four lanes o
 
 // WP: vertex positions from the compact waypoint array (MRS_TG_FLAG_POSITIONS_ARE_WAYPOINTS).  A template parameter, not a
 // run-time stride: with the stride in a register the value-array path lost 13 % (65536 x 10: 129 -> 147 us, same box)
-template <bool WP>
+// ENDS: the two end vertices may leave derivative slots free (rest-to-rest paths under an objective order below snap: jerk and
+// / or snap are unknowns there).  Such an end vertex is eliminated like an interior one -- its block is the near (far) part of
+// its only segment with the identity in the rows and columns of the constrained slots and zero in place of their reciprocal
+// pivots, so that they contribute nothing to W, z and x -- and has a record of its own: records for vertices 0 .. S instead
+// of 1 .. S - 1.  A fully constrained end takes the plain path's step.  Without ENDS such paths take the general step.
+template <bool WP, bool ENDS = false>
 __device__ __forceinline__ void solve_quad_body(const BatchView& b, int d, const uint8_t* __restrict__ mask,
                                                 const double* __restrict__ vals, const double* seg_times,
                                                 double* __restrict__ coeffs, int32_t* __restrict__ status,
@@ -110,7 +116,7 @@ __device__ __forceinline__ void solve_quad_body(const BatchView& b, int d, const
   const int S = pr.S;
   const int Smax = b.max_segments;
   double* rec0 = lds;
-  double* tbuf = lds + (size_t)(Smax > 1 ? Smax - 1 : 1) * kQdRec * kQdPaths;  // [segment][path]
+  double* tbuf = lds + (size_t)(ENDS ? Smax + 1 : (Smax > 1 ? Smax - 1 : 1)) * kQdRec * kQdPaths;  // [segment][path]
 #if MRS_TG_QUAD_EXP == 5
   const int n_rec = Smax > 1 ? Smax - 1 : 1;
   int* pinfo = reinterpret_cast<int*>(tbuf + (size_t)Smax * kQdPaths);
@@ -123,6 +129,7 @@ __device__ __forceinline__ void solve_quad_body(const BatchView& b, int d, const
   const bool scaling = tail.maxima != nullptr;
   double t_sum = 0.0;
   bool ok = S >= 2, pos_ok = true;
+  unsigned fm_first = 0u, fm_last = 0u;  // ENDS: free slots of the two end vertices (bit r: derivative r + 1)
   if (active) {
     const int opt_st = scaling ? tail.opt_status[pr.p] : 0;
     for (int i = dim; i < S; i += 4) {
@@ -146,11 +153,27 @@ __device__ __forceinline__ void solve_quad_body(const BatchView& b, int d, const
         double nz = 0.0;
 #pragma unroll
         for (int e = kD; e < kHalf * kD; ++e) nz += fabs(vrow[e]);
-        ok = ok && fixed == 0x1Fu && nz == 0.0;
+        // (the values of unconstrained slots are not read by anybody: only those of constrained ones must be zero)
+        if (ENDS) {
+          nz = 0.0;
+#pragma unroll
+          for (int k = 1; k < kHalf; ++k)
+#pragma unroll
+            for (int e = 0; e < kD; ++e) nz += ((fixed >> k) & 1u) ? fabs(vrow[k * kD + e]) : 0.0;
+          ok = ok && (fixed & 1u) && nz == 0.0;
+          if (v == 0) fm_first = (~fixed >> 1) & 0xFu;
+          if (v == S) fm_last = (~fixed >> 1) & 0xFu;
+        } else {
+          ok = ok && fixed == 0x1Fu && nz == 0.0;
+        }
       } else {
         ok = ok && fixed == 0x1u;
       }
     }
+  }
+  if (ENDS) {  // vertex 0 was read by lane 0 of the quad, vertex S by lane S mod 4
+    fm_first = (unsigned)__shfl((int)fm_first, lane & ~3, 64);
+    fm_last = (unsigned)__shfl((int)fm_last, (lane & ~3) + (S & 3), 64);
   }
   t_sum = quad_sum(t_sum);
   const bool plain_wave = __ballot(active && !ok) == 0ull;
@@ -202,7 +225,8 @@ __device__ __forceinline__ void solve_quad_body(const BatchView& b, int d, const
       quad_powers(T, d1, d2, d4, p2);
       const double dp = p_cur - p_nxt;
       if (on) {
-        if (i == 0) {  // the start vertex is fully constrained: the state moves to vertex 1
+        const bool free_start = ENDS && i == 0 && fm_first != 0u;
+        if (i == 0 && !free_start) {  // the start vertex is fully constrained: the state moves to vertex 1
 #pragma unroll
           for (int r = 0; r < kNB; ++r) {
 #pragma unroll
@@ -211,11 +235,23 @@ __device__ __forceinline__ void solve_quad_body(const BatchView& b, int d, const
           }
         } else {
           // vertex i: its block and right-hand side are complete with this segment's near part
+          // (a start vertex with free slots: the near part IS its block -- the identity in the constrained slots)
 #pragma unroll
           for (int r = 0; r < kNB; ++r) {
 #pragma unroll
-            for (int c = 0; c <= r; ++c) Sm[tri(r, c)] = fma(cNear[tri(r, c)], p2[r + c + 2], Sm[tri(r, c)]);
-            y[r] = fma(-(cN[r] * p2[r + 1]), dp, y[r]);
+            for (int c = 0; c <= r; ++c)
+              Sm[tri(r, c)] = free_start ? cNear[tri(r, c)] * p2[r + c + 2] : fma(cNear[tri(r, c)], p2[r + c + 2], Sm[tri(r, c)]);
+            y[r] = free_start ? -((cN[r] * p2[r + 1]) * dp) : fma(-(cN[r] * p2[r + 1]), dp, y[r]);
+          }
+          double rs[kNB];  // ENDS: 0 in place of the reciprocal pivot of a constrained slot
+#pragma unroll
+          for (int r = 0; r < kNB; ++r) rs[r] = (free_start && !((fm_first >> r) & 1u)) ? 0.0 : 1.0;
+          if (free_start) {
+#pragma unroll
+            for (int r = 0; r < kNB; ++r)
+#pragma unroll
+              for (int c = 0; c <= r; ++c)
+                if (!((fm_first >> r) & 1u) || !((fm_first >> c) & 1u)) Sm[tri(r, c)] = (r == c) ? 1.0 : 0.0;
           }
           double L[10], Linv[kNB], z[kNB];
 #pragma unroll
@@ -224,7 +260,7 @@ __device__ __forceinline__ void solve_quad_body(const BatchView& b, int d, const
 #pragma unroll
             for (int m = 0; m < c; ++m) dsum = fma(-L[tri(c, m)], L[tri(c, m)], dsum);
             const double inv = rsqrt_refined(dsum);
-            Linv[c] = inv;
+            Linv[c] = ENDS ? inv * rs[c] : inv;
 #pragma unroll
             for (int r = c + 1; r < kNB; ++r) {
               double t = Sm[tri(r, c)];
@@ -240,7 +276,7 @@ __device__ __forceinline__ void solve_quad_body(const BatchView& b, int d, const
             for (int m = 0; m < r; ++m) t = fma(-L[tri(r, m)], z[m], t);
             z[r] = t * Linv[r];
           }
-          double* rec = rec0 + (size_t)(i - 1) * kQdRec * kQdPaths + pl;
+          double* rec = rec0 + (size_t)(ENDS ? i : i - 1) * kQdRec * kQdPaths + pl;
           if (dim == 0) {
             rec[(kQdL + 0) * kQdPaths] = L[tri(1, 0)];
             rec[(kQdL + 1) * kQdPaths] = L[tri(2, 0)];
@@ -253,7 +289,8 @@ __device__ __forceinline__ void solve_quad_body(const BatchView& b, int d, const
           }
 #pragma unroll
           for (int r = 0; r < kNB; ++r) rec[(kQdZ + r * kD + dim) * kQdPaths] = z[r];
-          if (i < S - 1) {  // W = L^-1 E, then the Schur complement and right-hand side of vertex i + 1
+          // W = L^-1 E, then the Schur complement and right-hand side of vertex i + 1 (the last vertex: only when it has unknowns)
+          if (i < S - 1 || (ENDS && fm_last != 0u)) {
             double W[kNB][kNB];
 #pragma unroll
             for (int c = 0; c < kNB; ++c)
@@ -280,6 +317,50 @@ __device__ __forceinline__ void solve_quad_body(const BatchView& b, int d, const
             }
           }
         }
+        if (ENDS && i == S - 1 && fm_last != 0u) {
+          // the end vertex has unknowns: its block (the far part of the last segment, less what vertex S - 1 took) is complete
+#pragma unroll
+          for (int r = 0; r < kNB; ++r)
+#pragma unroll
+            for (int c = 0; c <= r; ++c)
+              if (!((fm_last >> r) & 1u) || !((fm_last >> c) & 1u)) Sm[tri(r, c)] = (r == c) ? 1.0 : 0.0;
+          double L[10], Linv[kNB], z[kNB];
+#pragma unroll
+          for (int c = 0; c < kNB; ++c) {
+            double dsum = Sm[tri(c, c)];
+#pragma unroll
+            for (int m = 0; m < c; ++m) dsum = fma(-L[tri(c, m)], L[tri(c, m)], dsum);
+            const double inv = rsqrt_refined(dsum);
+            Linv[c] = ((fm_last >> c) & 1u) ? inv : 0.0;
+#pragma unroll
+            for (int r = c + 1; r < kNB; ++r) {
+              double t = Sm[tri(r, c)];
+#pragma unroll
+              for (int m = 0; m < c; ++m) t = fma(-L[tri(r, m)], L[tri(c, m)], t);
+              L[tri(r, c)] = t * inv;
+            }
+          }
+#pragma unroll
+          for (int r = 0; r < kNB; ++r) {
+            double t = y[r];
+#pragma unroll
+            for (int m = 0; m < r; ++m) t = fma(-L[tri(r, m)], z[m], t);
+            z[r] = t * Linv[r];
+          }
+          double* rec = rec0 + (size_t)S * kQdRec * kQdPaths + pl;
+          if (dim == 0) {
+            rec[(kQdL + 0) * kQdPaths] = L[tri(1, 0)];
+            rec[(kQdL + 1) * kQdPaths] = L[tri(2, 0)];
+            rec[(kQdL + 2) * kQdPaths] = L[tri(2, 1)];
+            rec[(kQdL + 3) * kQdPaths] = L[tri(3, 0)];
+            rec[(kQdL + 4) * kQdPaths] = L[tri(3, 1)];
+            rec[(kQdL + 5) * kQdPaths] = L[tri(3, 2)];
+#pragma unroll
+            for (int r = 0; r < kNB; ++r) rec[(kQdLinv + r) * kQdPaths] = Linv[r];
+          }
+#pragma unroll
+          for (int r = 0; r < kNB; ++r) rec[(kQdZ + r * kD + dim) * kQdPaths] = z[r];
+        }
       }
       p_cur = p_nxt;
       p_nxt = p_a2;
@@ -288,7 +369,7 @@ __device__ __forceinline__ void solve_quad_body(const BatchView& b, int d, const
     }
     quad_wave_sync();  // (lane 0 of a quad wrote L and W for the other three)
     // ---- backward: x_v = L^-T (z - W x_{v+1}); coefficients and cost of segment v from x_v, x_{v+1}
-    double xn[kNB] = {0.0, 0.0, 0.0, 0.0};  // the last vertex is fully constrained
+    double xn[kNB] = {0.0, 0.0, 0.0, 0.0};  // the last vertex is fully constrained (ENDS: or solved below, when it has unknowns)
     // (positions again, requested three vertices ahead of their use; a path shorter than the wavefront's longest joins late.
     // Keeping a copy of the positions in LDS instead -- no global load in this loop, so no s_waitcnt vmcnt(0) in front of
     // every step's stores -- was measured in round 5: no change at 65536 x 10, and the 5.6 KB it adds per wavefront cost
@@ -302,8 +383,22 @@ __device__ __forceinline__ void solve_quad_body(const BatchView& b, int d, const
       p_b0 = p_b1;
       p_b1 = p_b2;
       p_b2 = posb(v - 3);
-      if (on && v >= 1) {
-        const double* rec = rec0 + (size_t)(v - 1) * kQdRec * kQdPaths + pl;
+      if (ENDS && active && v == S - 1 && fm_last != 0u) {  // x_S = L^-T z of the end vertex (zero in its constrained slots)
+        const double* rec = rec0 + (size_t)S * kQdRec * kQdPaths + pl;
+        const double l10 = rec[(kQdL + 0) * kQdPaths], l20 = rec[(kQdL + 1) * kQdPaths], l21 = rec[(kQdL + 2) * kQdPaths],
+                     l30 = rec[(kQdL + 3) * kQdPaths], l31 = rec[(kQdL + 4) * kQdPaths], l32 = rec[(kQdL + 5) * kQdPaths];
+        const double i0 = rec[(kQdLinv + 0) * kQdPaths], i1 = rec[(kQdLinv + 1) * kQdPaths], i2 = rec[(kQdLinv + 2) * kQdPaths],
+                     i3 = rec[(kQdLinv + 3) * kQdPaths];
+        double t[kNB];
+#pragma unroll
+        for (int r = 0; r < kNB; ++r) t[r] = rec[(kQdZ + r * kD + dim) * kQdPaths];
+        xn[3] = t[3] * i3;
+        xn[2] = fma(-l32, xn[3], t[2]) * i2;
+        xn[1] = fma(-l31, xn[3], fma(-l21, xn[2], t[1])) * i1;
+        xn[0] = fma(-l30, xn[3], fma(-l20, xn[2], fma(-l10, xn[1], t[0]))) * i0;
+      }
+      if (on && (v >= 1 || (ENDS && fm_first != 0u))) {
+        const double* rec = rec0 + (size_t)(ENDS ? v : v - 1) * kQdRec * kQdPaths + pl;
         double t[kNB];
 #pragma unroll
         for (int r = 0; r < kNB; ++r) t[r] = rec[(kQdZ + r * kD + dim) * kQdPaths];
@@ -311,7 +406,8 @@ __device__ __forceinline__ void solve_quad_body(const BatchView& b, int d, const
                      l30 = rec[(kQdL + 3) * kQdPaths], l31 = rec[(kQdL + 4) * kQdPaths], l32 = rec[(kQdL + 5) * kQdPaths];
         const double i0 = rec[(kQdLinv + 0) * kQdPaths], i1 = rec[(kQdLinv + 1) * kQdPaths], i2 = rec[(kQdLinv + 2) * kQdPaths],
                      i3 = rec[(kQdLinv + 3) * kQdPaths];
-        if (v < S - 1) {  // t = z - W x_{v+1},  W x = L^-1 (E x),  E[r][c] = HBAR[1+r][6+c] T_v^(r+c+2-2d)
+        // t = z - W x_{v+1},  W x = L^-1 (E x),  E[r][c] = HBAR[1+r][6+c] T_v^(r+c+2-2d)  (x_S = 0 unless the end vertex has unknowns)
+        if (v < S - 1 || (ENDS && fm_last != 0u)) {
           double pw[9];
           quad_powers(tbuf[v * kQdPaths + pl], d1, d2, d4, pw);
           double u[kNB];
@@ -449,13 +545,13 @@ __device__ __forceinline__ void solve_quad_body(const BatchView& b, int d, const
   }
 }
 
-template <bool WP>
+template <bool WP, bool ENDS = false>
 __global__ __launch_bounds__(64, MRS_TG_QUAD_WAVES) void solve_quad_kernel(BatchView b, int d, const uint8_t* __restrict__ mask,
                                                         const double* __restrict__ vals, const double* seg_times,
                                                         double* __restrict__ coeffs, int32_t* __restrict__ status,
                                                         double* __restrict__ cost, const int32_t* __restrict__ status_in,
                                                         double* ws, RowsTail tail) {
-  solve_quad_body<WP>(b, d, mask, vals, seg_times, coeffs, status, cost, status_in, ws, tail, (int)blockIdx.x, tail.pos_wp);
+  solve_quad_body<WP, ENDS>(b, d, mask, vals, seg_times, coeffs, status, cost, status_in, ws, tail, (int)blockIdx.x, tail.pos_wp);
 }
 
 // several batches of ONE plan in one launch (as solve_rows_group_kernel): workgroups [j * blocks_per_batch, ...) solve batch j
@@ -492,15 +588,30 @@ bool quad_kernel_applies(const BatchView& b, long long paths_in_launch, bool wit
 hipError_t launch_solve_quad(const BatchView& b, int d, const uint8_t* mask, const double* vals, const double* seg_times,
                              double* coeffs, int32_t* status, double* cost, const int32_t* status_in, double* ws,
                              hipStream_t stream, const RowsTail& tail) {
-  const size_t lds_bytes = quad_lds_doubles(b.max_segments) * sizeof(double);
+  // objective orders below snap leave jerk and / or snap free at the end vertices of a rest-to-rest path: the instantiation
+  // that eliminates such end vertices (two more records per path in LDS), while its LDS fits; MRS_TG_QUAD_ENDS=0: the general
+  // step for those paths, as until round 5
+  static const bool ends_allowed = [] {
+    const char* e = std::getenv("MRS_TG_QUAD_ENDS");
+    return e == nullptr || std::atoi(e) != 0;
+  }();
+  const bool ends = ends_allowed && d < 4 && quad_lds_doubles(b.max_segments, true) * sizeof(double) <= kQuadLdsBudget;
+  const size_t lds_bytes = quad_lds_doubles(b.max_segments, ends) * sizeof(double);
   const bool wp = tail.pos_wp != nullptr;
+  const void* fn = ends ? (wp ? (const void*)solve_quad_kernel<true, true> : (const void*)solve_quad_kernel<false, true>)
+                        : (wp ? (const void*)solve_quad_kernel<true> : (const void*)solve_quad_kernel<false>);
   if (lds_bytes > 64 * 1024) {
-    hipError_t e = hipFuncSetAttribute(wp ? (const void*)solve_quad_kernel<true> : (const void*)solve_quad_kernel<false>,
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)kQuadLdsBudget);
+    hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kQuadLdsBudget);
     if (e != hipSuccess) return e;
   }
   const unsigned grid = (unsigned)((b.n_paths + kQdPaths - 1) / kQdPaths);
-  if (wp)
+  if (ends && wp)
+    MRS_TG_LAUNCH_TIMED((solve_quad_kernel<true, true>), dim3(grid), dim3(64), lds_bytes, stream, b, d, mask, vals, seg_times, coeffs,
+                        status, cost, status_in, ws, tail);
+  else if (ends)
+    MRS_TG_LAUNCH_TIMED((solve_quad_kernel<false, true>), dim3(grid), dim3(64), lds_bytes, stream, b, d, mask, vals, seg_times, coeffs,
+                        status, cost, status_in, ws, tail);
+  else if (wp)
     MRS_TG_LAUNCH_TIMED(solve_quad_kernel<true>, dim3(grid), dim3(64), lds_bytes, stream, b, d, mask, vals, seg_times, coeffs, status,
                         cost, status_in, ws, tail);
   else

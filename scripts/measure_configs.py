@@ -16,17 +16,20 @@ sys.path.insert(0, ROOT)
 from mrs_uav_trajectory_generation_amd import api, problem as pr  # noqa: E402
 
 
+DERIV = int(os.environ.get("DERIV", "4"))   # objective order of the one-config mode (the nodelet's default config is 2)
+
+
 def measure(ctx, batch, nonlinear, reps):
     plan = api.Plan(ctx, batch.seg_offsets)
     db = api.DeviceBatch(batch, "cuda:0", sample_capacity=512)
-    est = api.default_options(derivative_to_optimize=4, estimate_times=1)
+    est = api.default_options(derivative_to_optimize=batch.derivative_to_optimize, estimate_times=1)
     plan.solve(est, db.fixed_mask, db.fixed_values, db.seg_times, db.coeffs, db.status, db.cost, waypoints=db.waypoints,
                limits=db.limits)
     torch.cuda.synchronize()
     t0 = db.seg_times.clone()
     if nonlinear:
         # (MRS_TG_FLAG_POSITIONS_ARE_WAYPOINTS: these batches' position constraints are their waypoints, as in bench.py)
-        opt = api.default_options(derivative_to_optimize=4, time_alloc_method=api.TIME_ALLOC_MELLINGER, sampling_dt=0.2,
+        opt = api.default_options(derivative_to_optimize=batch.derivative_to_optimize, time_alloc_method=api.TIME_ALLOC_MELLINGER, sampling_dt=0.2,
                                   sample_capacity=512, flags=api.FLAG_POSITIONS_ARE_WAYPOINTS)
 
         def step():
@@ -34,7 +37,7 @@ def measure(ctx, batch, nonlinear, reps):
             plan.solve(opt, db.fixed_mask, db.fixed_values, db.seg_times, db.coeffs, db.status, db.cost, waypoints=db.waypoints,
                        limits=db.limits, n_samples=db.n_samples, samples=db.samples)
     else:
-        opt = api.default_options(derivative_to_optimize=4, flags=api.FLAG_POSITIONS_ARE_WAYPOINTS)
+        opt = api.default_options(derivative_to_optimize=batch.derivative_to_optimize, flags=api.FLAG_POSITIONS_ARE_WAYPOINTS)
 
         def step():
             plan.solve(opt, db.fixed_mask, db.fixed_values, t0, db.coeffs, db.status, db.cost, waypoints=db.waypoints)
@@ -59,11 +62,11 @@ def main():
     if len(sys.argv) > 2:   # one config only, few repetitions: the command to put under rocprofv3
         which = sys.argv[2]
         if which.startswith("ragged"):   # ragged batch of any size: where the wide lane groups stop paying
-            print(which, measure(ctx, pr.random_batch(int(which[6:]), "ragged", seed0=0), True, 10))
+            print(which, measure(ctx, pr.random_batch(int(which[6:]), "ragged", seed0=0, derivative_to_optimize=DERIV), True, 10))
             return
         if which.startswith("uniform"):  # uniform<paths>x<segments>
             n, seg = which[7:].split("x")
-            print(which, measure(ctx, pr.random_batch(int(n), int(seg), seed0=0), True, 10))
+            print(which, measure(ctx, pr.random_batch(int(n), int(seg), seed0=0, derivative_to_optimize=DERIV), True, 10))
             return
         batch = {"config3": lambda: pr.random_batch(1024, 10, seed0=0), "config4": lambda: pr.random_batch(8192, 10, seed0=0),
                  "config5": lambda: pr.random_batch(8192, "ragged", seed0=0),
