@@ -24,6 +24,7 @@ struct NonlinearParams {
   int32_t* careful_list = nullptr;
   int careful_cap = 0;
   int32_t* queue_next = nullptr;  // lean kernel of a uniform batch larger than the device holds at once: next unclaimed position of the bin
+  int ends_min_segments = 2;  // optimize_lean_shared_ends_kernel: shorter paths are left to the sweeping kernel behind it
   int lean_shared = 0;  // lean kernels: shared half sweeps (evaluate_lean_shared) 1: in batches where every path has its S + 4 lanes (own kernel), 2: also wave by wave inside the mixed kernel
   double* sum_t0 = nullptr;  // [n_paths] by path: sum of the times the search starts from (the runaway test of the final solve)
   // The search starts from estimateSegmentTimesEuclidean of these waypoints ([n_vertices][4]) under estimate_limits

@@ -931,7 +931,7 @@ __device__ __forceinline__ void optimize_body(const BatchView& b, const Nonlinea
   if (LEAN) {  // vtx = the evaluation area: dp of every segment; the path's eligibility decides who runs it
     // (the kernel of the shared half sweeps with free end slots runs every bin of a ragged plan, in groups of S + 4 lanes:
     // paths of fewer than four segments are left to the sweeping kernel behind it)
-    const bool takes = stage_ps(mask, vals, pr.v0, S, Sb, vtx, g, G, active, (LEANSHARED && MASKED4) ? 4 : 2, d, MASKED4);
+    const bool takes = stage_ps(mask, vals, pr.v0, S, Sb, vtx, g, G, active, (LEANSHARED && MASKED4) ? prm.ends_min_segments : 2, d, MASKED4);
     if (active && g == 0) fallback[q] = takes ? 0 : 1;
     active = active && takes;
   } else {
@@ -1077,7 +1077,7 @@ __device__ __forceinline__ void optimize_body(const BatchView& b, const Nonlinea
             S = pr.S;
             active = true;
             double t_new = (g < S) ? start_time(prm, seg_times, pr, g) : 0.0;
-            const bool takes = stage_ps(mask, vals, pr.v0, S, Sb, vtx, g, G, true, (LEANSHARED && MASKED4) ? 4 : 2, d, MASKED4);
+            const bool takes = stage_ps(mask, vals, pr.v0, S, Sb, vtx, g, G, true, (LEANSHARED && MASKED4) ? prm.ends_min_segments : 2, d, MASKED4);
             if (g == 0) fallback[q] = takes ? 0 : 1;
             if (takes) {
               int okn = 1;
@@ -1831,9 +1831,16 @@ static int group_for_wide(int S) {
   return G;
 }
 
-// lanes per path when EVERY path of four or more segments gets its S + 4 lanes (0: no group is wide enough)
+// lanes per path when EVERY path of kEndsMinSegments or more segments gets its S + 4 lanes (0: no group is wide enough).
+// Two segments are enough for the shared half sweeps (one step per half); handing the 2- and 3-segment paths of a ragged
+// batch to the sweeping kernel BEHIND the launch instead cost 8192 ragged paths 0.67 instead of 0.58 ms (d = 2).
+// MRS_TG_ENDS_MIN_SEGMENTS: tuning / test knob, read once per process
+static const int kEndsMinSegments = [] {
+  const char* e = std::getenv("MRS_TG_ENDS_MIN_SEGMENTS");
+  return e ? std::max(2, std::atoi(e)) : 2;
+}();
 static int group_for_ends(int S) {
-  if (S < 4) return group_for(S, 1);
+  if (S < kEndsMinSegments) return group_for(S, 1);
   if (S + 4 > 64) return 0;
   int G = 8;
   while (G < S + 4) G <<= 1;
@@ -2021,6 +2028,7 @@ hipError_t launch_nonlinear(NonlinearPlan& nl, const BatchView& b, const Nonline
     return e == nullptr ? 2 : std::atoi(e);
   }();
   prm.lean_shared = lean_shared;
+  prm.ends_min_segments = kEndsMinSegments;
   if (!estimate_in_kernel) prm.estimate_wp = prm.estimate_limits = nullptr;
   prm.sum_t0 = nl.d_sum_t0;
   prm.deadline = nullptr;

@@ -153,7 +153,7 @@ def test_separate_sampler_equals_the_sampler_in_the_solve_kernels_tail(gpu_ctx):
                 assert np.array_equal(small["samples"][k, :n], big["samples"][p, :n]), p
 
 
-@pytest.mark.parametrize("deriv,ragged", [(2, False), (3, False), (2, True)])
+@pytest.mark.parametrize("deriv,ragged", [(2, False), (3, False), (2, True), (2, 2), (3, 3)])
 def test_objective_orders_below_snap_on_the_saturated_device_kernels(gpu_ctx, deriv, ragged):
     """Rest-to-rest paths under min-acceleration / min-jerk leave jerk and / or snap FREE at their end vertices
     (makeStartOrEnd(., derivative_to_optimize): the nodelet's default config is min-acceleration).  From 6144 paths per launch
@@ -162,11 +162,11 @@ def test_objective_orders_below_snap_on_the_saturated_device_kernels(gpu_ctx, de
     (optimize_lean_shared_ends_kernel).  Both against the oracle on a strided subset, every path through the invariants, and
     the same paths in a small batch (other kernels) to 1e-9."""
     n = 6400
-    batch = pr.random_batch(n, "ragged" if ragged else 10, seed0=9100, derivative_to_optimize=deriv)
+    batch = pr.random_batch(n, "ragged" if ragged is True else (ragged or 10), seed0=9100, derivative_to_optimize=deriv)   # (2, 3: that many segments)
     api.kernel_trace_reset()
     lin = gpu_ctx.solve_batch(batch, None)
     trace = api.kernel_trace()
-    if not ragged:   # (a ragged 3..30 batch does not fit the quad kernel's LDS records: rows kernel)
+    if ragged is not True:   # (a ragged 3..30 batch does not fit the quad kernel's LDS records: rows kernel)
         assert any("solve_quad_kernel" in k and "true>" in k.replace(" ", "") for k in trace), trace
     assert np.all(lin["status"] == 1)
     so = batch.seg_offsets
@@ -200,5 +200,5 @@ def test_objective_orders_below_snap_on_the_saturated_device_kernels(gpu_ctx, de
         if util.status_matches(out["status"][p], ref["status"][k]) and np.max(np.abs(t - ref["times"][a:b]) / ref["times"][a:b]) < 1e-6 \
                 and util.coeff_error(out["coeffs"][so[p]:so[p + 1]], ref["coeffs"][a:b]) < 1e-6:
             good += 1
-    print("RATE below-snap d=%d %s: %d / %d" % (deriv, "ragged" if ragged else "uniform", good, len(oidx)))
+    print("RATE below-snap d=%d %s: %d / %d" % (deriv, {True: "ragged", False: "10 segments"}.get(ragged, "%s segments" % ragged), good, len(oidx)))
     assert good >= len(oidx) - 3, (good, len(oidx))
