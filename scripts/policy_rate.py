@@ -13,8 +13,22 @@ sys.path.insert(0, ROOT)
 from mrs_uav_trajectory_generation_amd import api, problem as pr  # noqa: E402
 
 
+def oracle_rate(n=48):
+    """the CPU oracle's optimize() restatement (oracle/mto_policy.c) on the first n requests of each generator, one thread"""
+    from oracle import pyoracle as po
+    for gen, name in ((pr.random_walk_waypoints, "walk"), (pr.random_box_waypoints, "box")):
+        paths = [gen(4 + (i % 8), 7000 + i) for i in range(n)]
+        t = time.perf_counter()
+        rounds = [po.optimize_path(p, limits=pr.DEFAULT_LIMITS, capacity=2048)["iterations"] for p in paths]
+        dt = time.perf_counter() - t
+        print("%-4s CPU oracle, one thread, %d requests: %.2f ms per request, %.0f requests/s (rounds mean %.2f)" % (
+            name, n, dt / n * 1e3, n / dt, float(np.mean(rounds))))
+
+
 def main():
-    sizes = [int(a) for a in sys.argv[1:]] or [1, 16, 256, 1024, 4096]
+    args = sys.argv[1:]
+    with_oracle = "--oracle" in args
+    sizes = [int(a) for a in args if a != "--oracle"] or [1, 16, 256, 1024, 4096]
     ctx = api.Context(0)
     for n in sizes:
         for gen, name in ((pr.random_walk_waypoints, "walk"), (pr.random_box_waypoints, "box")):
@@ -30,6 +44,8 @@ def main():
                   "waypoints in %.1f -> out %.1f, samples mean %.0f" % (
                       name, n, dt * 1e3, dt / n * 1e6, n / dt, int(out["success"].sum()), out["iterations"].mean(),
                       out["iterations"].max(), np.mean([len(p) for p in paths]), out["n_waypoints"].mean(), out["n_samples"].mean()))
+    if with_oracle:
+        oracle_rate()
 
 
 if __name__ == "__main__":
