@@ -409,16 +409,22 @@ int mrs_tg_plan_create(mrs_tg_ctx* ctx, int32_t n_paths, const int32_t* so, mrs_
     mrs_tg_plan_destroy(plan);
     return code;
   };
+  // the three structure arrays in ONE device block, uploaded by one copy (a blocking copy costs the host 10-20 us whatever its
+  // size, and the nodelet's deviation loop makes a plan per round: three of them were a tenth of a one-request call)
   hipError_t e;
-  if ((e = mrs_tg::pool_alloc(&plan->d_seg_offsets, sizeof(int32_t) * (n_paths + 1))) != hipSuccess ||
-      (e = mrs_tg::pool_alloc(&plan->d_order, sizeof(int32_t) * std::max(n_paths, 1))) != hipSuccess ||
-      (e = mrs_tg::pool_alloc(&plan->d_slot_start, sizeof(int32_t) * (max_S + 1))) != hipSuccess ||
-      (e = hipMemcpy(plan->d_seg_offsets, so, sizeof(int32_t) * (n_paths + 1), hipMemcpyHostToDevice)) != hipSuccess ||
-      (n_paths > 0 && (e = hipMemcpy(plan->d_order, plan->order_host.data(), sizeof(int32_t) * n_paths,
-                                     hipMemcpyHostToDevice)) != hipSuccess) ||
-      (e = hipMemcpy(plan->d_slot_start, slot_start.data(), sizeof(int32_t) * (max_S + 1), hipMemcpyHostToDevice)) !=
-          hipSuccess)
+  std::vector<int32_t> packed;
+  packed.reserve((size_t)n_paths * 2 + 2 + (size_t)max_S + 1);
+  packed.insert(packed.end(), so, so + n_paths + 1);
+  const size_t off_order = packed.size();
+  packed.insert(packed.end(), plan->order_host.begin(), plan->order_host.end());
+  if (n_paths == 0) packed.push_back(0);
+  const size_t off_slot = packed.size();
+  packed.insert(packed.end(), slot_start.begin(), slot_start.end());
+  if ((e = mrs_tg::pool_alloc(&plan->d_seg_offsets, sizeof(int32_t) * packed.size())) != hipSuccess ||
+      (e = hipMemcpy(plan->d_seg_offsets, packed.data(), sizeof(int32_t) * packed.size(), hipMemcpyHostToDevice)) != hipSuccess)
     return cleanup(fail(ctx, MRS_TG_ERR_HIP, "plan allocation failed: %s", hipGetErrorString(e)));
+  plan->d_order = plan->d_seg_offsets + off_order;        // (parts of the one block: mrs_tg_plan_destroy frees d_seg_offsets)
+  plan->d_slot_start = plan->d_seg_offsets + off_slot;
   plan->view.n_paths = n_paths;
   plan->view.n_segments = so[n_paths];
   plan->view.max_segments = max_S;
@@ -438,8 +444,7 @@ void mrs_tg_plan_destroy(mrs_tg_plan* plan) {
   (void)hipStreamSynchronize(plan->ctx->stream);
   mrs_tg::nonlinear_plan_free(plan->nl);
   if (plan->d_seg_offsets) (void)mrs_tg::pool_free(plan->d_seg_offsets);
-  if (plan->d_order) (void)mrs_tg::pool_free(plan->d_order);
-  if (plan->d_slot_start) (void)mrs_tg::pool_free(plan->d_slot_start);
+  // (d_order and d_slot_start are parts of the block d_seg_offsets heads)
   if (plan->d_ws) (void)mrs_tg::pool_free(plan->d_ws);
   if (plan->d_H) (void)mrs_tg::pool_free(plan->d_H);
   if (plan->d_Ainv) (void)mrs_tg::pool_free(plan->d_Ainv);
