@@ -1008,6 +1008,58 @@ def main():
         plan3.close()
         del db3, pk3, pad3, recv3
 
+    # ---- two figures beside the BASELINE configs (rank 0, after every other measurement so that they disturb none)
+    if not args.no_extras and rank == 0 and world == 1:
+        # the policy layer around the solver (mrs_tg_optimize_paths = the reference's optimize(): preprocessing, solve, length
+        # check, spatial validation, mid-point subdivision rounds) for a batch of requests, host arrays in and out
+        try:
+            n_req = 1024
+            req = [pr.random_box_waypoints(4 + (i % 8), 7000 + i) for i in range(n_req)]
+            pol_out = api.optimize_paths(ctx, req, sample_capacity=2048)
+            t0 = time.perf_counter()
+            for _ in range(3):
+                pol_out = api.optimize_paths(ctx, req, sample_capacity=2048)
+            dt_pol = (time.perf_counter() - t0) / 3
+            extras["policy_layer"] = dict(value=n_req / dt_pol, unit="requests/s", requests=n_req, ms_per_call=dt_pol * 1e3,
+                                          succeeded=int(pol_out["success"].sum()), rounds_mean=float(pol_out["iterations"].mean()),
+                                          waypoints_out_mean=float(pol_out["n_waypoints"].mean()),
+                                          call="mrs_tg_optimize_paths through api.optimize_paths (its numpy marshalling included), "
+                                               "box-generator requests of 4-11 waypoints, the reference's default policy "
+                                               "(min-acceleration, max deviation 0.05 m, up to 6 subdivision rounds)")
+        except Exception as exc:   # (an extra: never the reason a bench line is missing)
+            extras["policy_layer"] = dict(error=repr(exc))
+        # the Mellinger pipeline under the nodelet's default objective (min-acceleration; the BASELINE configs are min-snap)
+        try:
+            b2 = pr.random_batch(P, args.segments, seed0=0, derivative_to_optimize=2)
+            db2 = api.DeviceBatch(b2, dev, sample_capacity=512)
+            plan2 = api.Plan(ctx, b2.seg_offsets)
+            est2 = api.default_options(derivative_to_optimize=2, estimate_times=1)
+            plan2.solve(est2, db2.fixed_mask, db2.fixed_values, db2.seg_times, db2.coeffs, db2.status, db2.cost,
+                        waypoints=db2.waypoints, limits=db2.limits)
+            torch.cuda.synchronize()
+            t_start2 = db2.seg_times.clone()
+            opt2 = api.default_options(derivative_to_optimize=2, time_alloc_method=api.TIME_ALLOC_MELLINGER, sampling_dt=0.2,
+                                       sample_capacity=512)
+
+            def step2():
+                db2.seg_times.copy_(t_start2)
+                plan2.solve(opt2, db2.fixed_mask, db2.fixed_values, db2.seg_times, db2.coeffs, db2.status, db2.cost,
+                            waypoints=db2.waypoints, limits=db2.limits, n_samples=db2.n_samples, samples=db2.samples)
+            for _ in range(3):
+                step2()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(10):
+                step2()
+            torch.cuda.synchronize()
+            dt2 = (time.perf_counter() - t0) / 10
+            extras["nonlinear_min_acceleration"] = dict(value=P / dt2, unit="trajectories/s", ms_per_step=dt2 * 1e3, steps=10,
+                                                        workload="%d x %d segments, derivative_to_optimize = 2 (the nodelet's default "
+                                                                 "config), Mellinger outer loop + feasibility scaling + sampling, one "
+                                                                 "batch in flight" % (P, args.segments))
+            plan2.close()
+        except Exception as exc:
+            extras["nonlinear_min_acceleration"] = dict(error=repr(exc))
     # ---- parity of this very batch against the oracle (max-coeff err vs CPU ref) + CPU baseline ----
     cpu = None
     err = None
