@@ -436,7 +436,11 @@ int mrs_tg_optimize_paths(mrs_tg_ctx* ctx, int32_t n_paths, const int32_t* wp_of
                    b_times = up(nS * sizeof(double)), b_smp = up(A * (size_t)sample_capacity * 4 * sizeof(double)),
                    b_status = up(A * sizeof(int32_t)), b_ns = up(A * sizeof(int32_t)), b_mask = up(nV * 5);
       const size_t need = b_wp + b_vals + b_lim + b_times + b_smp + b_status + b_ns + b_mask;
-      char* block = static_cast<char*>(mrs_tg::ctx_host_scratch(ctx, need));
+      static const bool pinned_allowed = [] {  // MRS_TG_POLICY_PINNED=0: ordinary memory (test knob, read once per process)
+        const char* e = std::getenv("MRS_TG_POLICY_PINNED");
+        return e == nullptr || std::atoi(e) != 0;
+      }();
+      char* block = pinned_allowed ? static_cast<char*>(mrs_tg::ctx_host_scratch(ctx, need)) : nullptr;
       std::vector<char> pageable;  // (the runtime refused that much pinned memory: ordinary memory, copied by the runtime)
       if (!block) {
         pageable.resize(need);

@@ -96,7 +96,8 @@ def test_waypoint_trajectory_idxs(gpu_ctx):
 
 # ---- batches of requests: the policy's per-path host work runs on several threads (mrs_tg_policy.hip::parallel_ranges, from a
 # few hundred requests on) and its arrays live in pinned scratch memory of the context.  The requests are independent, so the
-# results must be THE SAME BITS as on one thread (MRS_TG_POLICY_THREADS=1, read once per process: a child process), and a
+# results must be THE SAME BITS as on one thread with the rounds' arrays in ordinary memory (MRS_TG_POLICY_THREADS=1
+# MRS_TG_POLICY_PINNED=0 -- the route taken when the runtime refuses the pinned block --, read once per process: a child process), and a
 # strided subset must agree with the oracle as the small batches above do.
 POLICY_CHILD = r"""
 import sys
@@ -127,7 +128,7 @@ def test_batch_of_requests_on_threads_gives_the_bits_of_one_thread_and_agrees_wi
         assert np.array_equal(out[k], again[k]), k
     ref_path = str(tmp_path / "one_thread.npz")
     subprocess.run([sys.executable, "-c", POLICY_CHILD % root, ref_path], check=True, cwd=root, timeout=600,
-                   env=dict(os.environ, MRS_TG_POLICY_THREADS="1"))
+                   env=dict(os.environ, MRS_TG_POLICY_THREADS="1", MRS_TG_POLICY_PINNED="0"))   # (and ordinary memory for the rounds' arrays)
     ref = np.load(ref_path)
     for k in out:
         assert np.array_equal(out[k], ref[k]), k
