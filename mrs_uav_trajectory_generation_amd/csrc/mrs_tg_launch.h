@@ -35,6 +35,14 @@ int kernel_trace(const char** names_out, int capacity);  // oldest first; at mos
     ::mrs_tg::note_kernel(#kernel);                                                                          \
     hipExtLaunchKernelGGL(kernel, grid, block, lds, stream, kt__.start, kt__.stop, 0, __VA_ARGS__);          \
   } while (0)
+// the same for a kernel template of two arguments (a comma inside a macro argument needs parentheses, which would end up in the
+// noted name): MRS_TG_LAUNCH_TIMED_T2(kernel, A, B, grid, ...) launches kernel<A, B> and notes "kernel<A, B>"
+#define MRS_TG_LAUNCH_TIMED_T2(kernel, A, B, grid, block, lds, stream, ...)                                        \
+  do {                                                                                                             \
+    const ::mrs_tg::KernelTimer kt__ = ::mrs_tg::take_kernel_timer();                                              \
+    ::mrs_tg::note_kernel(#kernel "<" #A ", " #B ">");                                                             \
+    hipExtLaunchKernelGGL((kernel<A, B>), grid, block, lds, stream, kt__.start, kt__.stop, 0, __VA_ARGS__);        \
+  } while (0)
 // plain launches, and launches that carry the events of a multi-kernel timing themselves
 #define MRS_TG_LAUNCH(kernel, ...)                \
   do {                                            \

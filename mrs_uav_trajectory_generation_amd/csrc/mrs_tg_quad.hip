@@ -557,12 +557,12 @@ __global__ __launch_bounds__(64, MRS_TG_QUAD_WAVES) void solve_quad_kernel(Batch
 // several batches of ONE plan in one launch (as solve_rows_group_kernel): workgroups [j * blocks_per_batch, ...) solve batch j
 // (ws: one factor store of ws_batch_doubles per batch, for wavefronts that take the general step)
 // (WP: every batch of the group states that its positions are its waypoints)
-template <bool WP>
+template <bool WP, bool ENDS = false>
 __global__ __launch_bounds__(64, MRS_TG_QUAD_GROUP_WAVES) void solve_quad_group_kernel(BatchView b, int d, RowsGroup g, double* ws, size_t ws_batch_doubles,
                                                               int blocks_per_batch) {
   const int j = __builtin_amdgcn_readfirstlane((int)blockIdx.x / blocks_per_batch);
-  solve_quad_body<WP>(b, d, g.mask[j], g.vals[j], g.seg_times[j], g.coeffs[j], g.status[j], g.cost[j], nullptr,
-                      ws + (size_t)j * ws_batch_doubles, RowsTail(), (int)blockIdx.x - j * blocks_per_batch, g.pos_wp[j]);
+  solve_quad_body<WP, ENDS>(b, d, g.mask[j], g.vals[j], g.seg_times[j], g.coeffs[j], g.status[j], g.cost[j], nullptr,
+                            ws + (size_t)j * ws_batch_doubles, RowsTail(), (int)blockIdx.x - j * blocks_per_batch, g.pos_wp[j]);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -579,6 +579,15 @@ static long long quad_min_paths() {
   return v;
 }
 
+// MRS_TG_QUAD_ENDS=0: the general step for paths whose end vertices leave slots free, as until round 5 (read once per process)
+static bool quad_ends_allowed() {
+  static const bool v = [] {
+    const char* e = std::getenv("MRS_TG_QUAD_ENDS");
+    return e == nullptr || std::atoi(e) != 0;
+  }();
+  return v;
+}
+
 bool quad_kernel_applies(const BatchView& b, long long paths_in_launch, bool with_sampling) {
   if (b.n_paths == 0 || with_sampling) return false;
   if (paths_in_launch < quad_min_paths()) return false;
@@ -591,11 +600,7 @@ hipError_t launch_solve_quad(const BatchView& b, int d, const uint8_t* mask, con
   // objective orders below snap leave jerk and / or snap free at the end vertices of a rest-to-rest path: the instantiation
   // that eliminates such end vertices (two more records per path in LDS), while its LDS fits; MRS_TG_QUAD_ENDS=0: the general
   // step for those paths, as until round 5
-  static const bool ends_allowed = [] {
-    const char* e = std::getenv("MRS_TG_QUAD_ENDS");
-    return e == nullptr || std::atoi(e) != 0;
-  }();
-  const bool ends = ends_allowed && d < 4 && quad_lds_doubles(b.max_segments, true) * sizeof(double) <= kQuadLdsBudget;
+  const bool ends = quad_ends_allowed() && d < 4 && quad_lds_doubles(b.max_segments, true) * sizeof(double) <= kQuadLdsBudget;
   const size_t lds_bytes = quad_lds_doubles(b.max_segments, ends) * sizeof(double);
   const bool wp = tail.pos_wp != nullptr;
   const void* fn = ends ? (wp ? (const void*)solve_quad_kernel<true, true> : (const void*)solve_quad_kernel<false, true>)
@@ -606,10 +611,10 @@ hipError_t launch_solve_quad(const BatchView& b, int d, const uint8_t* mask, con
   }
   const unsigned grid = (unsigned)((b.n_paths + kQdPaths - 1) / kQdPaths);
   if (ends && wp)
-    MRS_TG_LAUNCH_TIMED((solve_quad_kernel<true, true>), dim3(grid), dim3(64), lds_bytes, stream, b, d, mask, vals, seg_times, coeffs,
+    MRS_TG_LAUNCH_TIMED_T2(solve_quad_kernel, true, true, dim3(grid), dim3(64), lds_bytes, stream, b, d, mask, vals, seg_times, coeffs,
                         status, cost, status_in, ws, tail);
   else if (ends)
-    MRS_TG_LAUNCH_TIMED((solve_quad_kernel<false, true>), dim3(grid), dim3(64), lds_bytes, stream, b, d, mask, vals, seg_times, coeffs,
+    MRS_TG_LAUNCH_TIMED_T2(solve_quad_kernel, false, true, dim3(grid), dim3(64), lds_bytes, stream, b, d, mask, vals, seg_times, coeffs,
                         status, cost, status_in, ws, tail);
   else if (wp)
     MRS_TG_LAUNCH_TIMED(solve_quad_kernel<true>, dim3(grid), dim3(64), lds_bytes, stream, b, d, mask, vals, seg_times, coeffs, status,
@@ -622,21 +627,27 @@ hipError_t launch_solve_quad(const BatchView& b, int d, const uint8_t* mask, con
 
 hipError_t launch_solve_quad_group(const BatchView& b, int d, const RowsGroup& g, double* ws, hipStream_t stream) {
   if (g.n < 1 || g.n > kRowsGroupMax) return hipErrorInvalidValue;
-  const size_t lds_bytes = quad_lds_doubles(b.max_segments) * sizeof(double);
+  const bool ends = quad_ends_allowed() && d < 4 && quad_lds_doubles(b.max_segments, true) * sizeof(double) <= kQuadLdsBudget;
+  const size_t lds_bytes = quad_lds_doubles(b.max_segments, ends) * sizeof(double);
   bool wp = true;
   for (int j = 0; j < g.n; ++j) wp = wp && g.pos_wp[j] != nullptr;
   if (lds_bytes > 64 * 1024) {
-    hipError_t e = hipFuncSetAttribute(wp ? (const void*)solve_quad_group_kernel<true> : (const void*)solve_quad_group_kernel<false>,
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)kQuadLdsBudget);
+    const void* fn = ends ? (wp ? (const void*)solve_quad_group_kernel<true, true> : (const void*)solve_quad_group_kernel<false, true>)
+                          : (wp ? (const void*)solve_quad_group_kernel<true> : (const void*)solve_quad_group_kernel<false>);
+    hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kQuadLdsBudget);
     if (e != hipSuccess) return e;
   }
   const int per_batch = (b.n_paths + kQdPaths - 1) / kQdPaths;
-  if (wp)
-    MRS_TG_LAUNCH_TIMED(solve_quad_group_kernel<true>, dim3((unsigned)(per_batch * g.n)), dim3(64), lds_bytes, stream, b, d, g, ws,
-                        linear_workspace_doubles(b), per_batch);
+  const dim3 grid((unsigned)(per_batch * g.n));
+  const size_t wsd = linear_workspace_doubles(b);
+  if (ends && wp)
+    MRS_TG_LAUNCH_TIMED_T2(solve_quad_group_kernel, true, true, grid, dim3(64), lds_bytes, stream, b, d, g, ws, wsd, per_batch);
+  else if (ends)
+    MRS_TG_LAUNCH_TIMED_T2(solve_quad_group_kernel, false, true, grid, dim3(64), lds_bytes, stream, b, d, g, ws, wsd, per_batch);
+  else if (wp)
+    MRS_TG_LAUNCH_TIMED(solve_quad_group_kernel<true>, grid, dim3(64), lds_bytes, stream, b, d, g, ws, wsd, per_batch);
   else
-    MRS_TG_LAUNCH_TIMED(solve_quad_group_kernel<false>, dim3((unsigned)(per_batch * g.n)), dim3(64), lds_bytes, stream, b, d, g, ws,
-                        linear_workspace_doubles(b), per_batch);
+    MRS_TG_LAUNCH_TIMED(solve_quad_group_kernel<false>, grid, dim3(64), lds_bytes, stream, b, d, g, ws, wsd, per_batch);
   return hipGetLastError();
 }
 

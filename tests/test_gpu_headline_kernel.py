@@ -219,3 +219,58 @@ def test_positions_from_the_waypoint_array_give_the_same_bits_and_a_false_statem
         with pytest.raises(api.MrsTgError, match="needs"):
             plan.bind_solve(opt, db.fixed_mask, db.fixed_values, db.seg_times, db.coeffs, db.status, db.cost)
         plan.close()
+
+
+@pytest.mark.parametrize("deriv", [2, 3])
+def test_grouped_dispatch_below_snap_takes_the_free_end_instantiation(gpu_ctx, deriv):
+    """The grouped dispatch under an objective order below snap (the nodelet's default config is min-acceleration): rest-to-rest
+    paths leave jerk and / or snap free at their end vertices, and solve_quad_group_kernel<., true> eliminates those end
+    vertices like interior ones (round 5; the general step with factors in global memory before).  Two bound solves of one
+    6400-path batch in one launch = the single launch's bits; a strided subset against the oracle; every path status 1."""
+    batch = pr.random_batch(6400, 10, seed0=4600, derivative_to_optimize=deriv)
+    plan = api.Plan(gpu_ctx, batch.seg_offsets)
+    db = api.DeviceBatch(batch, "cuda:0")
+    est = api.default_options(derivative_to_optimize=deriv, estimate_times=1)
+    plan.solve(est, db.fixed_mask, db.fixed_values, db.seg_times, db.coeffs, db.status, db.cost, waypoints=db.waypoints,
+               limits=db.limits)
+    torch.cuda.synchronize()
+    opt = api.default_options(derivative_to_optimize=deriv)
+    db.coeffs.zero_()
+    api.kernel_trace_reset()
+    plan.bind_solve(opt, db.fixed_mask, db.fixed_values, db.seg_times, db.coeffs, db.status, db.cost)()
+    single_trace = api.kernel_trace()
+    torch.cuda.synchronize()
+    assert single_trace[-1] == "solve_quad_kernel<false, true>", single_trace
+    single = db.coeffs.cpu().numpy().copy()
+    cost_single = db.cost.cpu().numpy().copy()
+    assert np.all(db.status.cpu().numpy() == 1)
+    c2 = torch.zeros_like(db.coeffs)
+    db.coeffs.zero_()
+    calls = [plan.bind_solve(opt, db.fixed_mask, db.fixed_values, db.seg_times, cc, db.status, db.cost) for cc in (db.coeffs, c2)]
+    api.kernel_trace_reset()
+    api.RoundRobin(calls, grouped=True)(2)
+    trace = api.kernel_trace()
+    torch.cuda.synchronize()
+    assert trace == ["solve_quad_group_kernel<false, true>"], trace
+    assert np.array_equal(db.coeffs.cpu().numpy(), single) and np.array_equal(c2.cpu().numpy(), single)
+    assert np.array_equal(db.cost.cpu().numpy(), cost_single)
+    idx = list(range(0, batch.n_paths, 61))
+    sub = batch.select(idx)
+    t = db.seg_times.cpu().numpy()
+    so = batch.seg_offsets
+    ts = np.concatenate([t[so[p]:so[p + 1]] for p in idx])
+    cs = np.concatenate([single[so[p]:so[p + 1]] for p in idx])
+    # against the oracle's 113-bit route (the reference's algorithm without its rounding: what the HIP path's own error is
+    # measured by, as for the headline slots above) and against the double-precision oracle with the tolerance its own
+    # rounding needs on short segments (one path of this subset: 3.8e-7 from the double oracle)
+    ref = util.oracle_linear(sub, ts)
+    with po.arithmetic(po.QUAD_PRECISION):
+        ref_q = util.oracle_linear(sub, ts)
+    e_q = util.coeff_error(cs, ref_q["coeffs"], sub.seg_offsets)
+    e_d = util.coeff_error(cs, ref["coeffs"], sub.seg_offsets)
+    e_od = util.coeff_error(ref["coeffs"], ref_q["coeffs"], sub.seg_offsets)
+    print("BELOW SNAP d=%d grouped: HIP vs 113-bit route %.2e, HIP vs double oracle %.2e, double oracle vs 113-bit route %.2e"
+          % (deriv, e_q, e_d, e_od))
+    assert e_q < 1e-10 and e_d < TOL_ORACLE_SHORT_SEGMENT, (e_q, e_d)   # (measured 1.4e-13 and 1.6e-12 vs the 113-bit route)
+    assert np.max(np.abs(cost_single[idx] - ref_q["cost"]) / np.abs(ref_q["cost"])) < 1e-8
+    plan.close()
