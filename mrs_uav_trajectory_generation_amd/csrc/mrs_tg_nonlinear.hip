@@ -371,7 +371,11 @@ __device__ __forceinline__ double evaluate_general(const uint8_t* __restrict__ m
 // kernels are bound by the dependent chain of a step, not by issue: the second wavefront runs in
 // the first one's idle issue slots.  Lane k of a group of G sweeps time vector k (k, k + G, ... when S + 1 > G).
 constexpr int kLeanPub = 3 * 28;  // evaluate_lean_shared's hand-over area: three half-sweep states of 28 doubles
-__host__ __device__ constexpr int lean_eval_doubles(int Sb) { return 4 * Sb + 4 * (Sb + 1) + kLeanPub; }  // dp, staging area, hand-over
+// behind it: the start vertex's constrained derivative values of a path that starts from a MOVING state (a replanning request
+// in flight: velocity / acceleration / jerk of the first vertex constrained to non-zero values) -- [0] non-zero = there are
+// such values, [2 + c * 4 + q] = derivative c + 1 of dimension q (zero where the slot is free)
+constexpr int kLeanMoving = 18;
+__host__ __device__ constexpr int lean_eval_doubles(int Sb) { return 4 * Sb + 4 * (Sb + 1) + kLeanPub + kLeanMoving; }  // dp, staging area, hand-over, moving start
 
 // MRS_TG_LEAN_CONST_TABLE=1 (an A / B build, NOT the default): the 45 table constants as compile-time operands -- SGPR pairs the
 // scalar unit sets up -- instead of 90 VGPRs per lane, and ONE table for both sweep directions (mrs_tg_sweep.hpp, PsTab).
@@ -557,10 +561,17 @@ __device__ __forceinline__ double evaluate_lean(const double* tabs, const double
 // eliminates the end vertex like any other vertex -- the block of the segment's near part with the rows and columns of the
 // constrained slots replaced by the identity, and their reciprocal pivots by zero, so that they contribute nothing to W, z
 // and the cost -- instead of moving the state to the next vertex; every other step is the plain one.
-template <bool ENDS>
+// MOVING: the path may start from a moving state (stage_ps has left the start vertex's constrained derivative values f behind
+// the hand-over area).  Nothing changes in the elimination; the first step of the half sweeps that start at vertex 0 gets
+// the terms of f -- right-hand side of vertex 1: - sum_c E[c][r] f_c T^(r+c+2-2d); of vertex 0's own free slots (ENDS):
+// - sum_c N[r][c] f_c T^(r+c+2-2d); f^T H f: sum_c 2 f_c N0[c] dp T^(c+1-2d) + sum_cc' f_c N[c][c'] f_c' T^(c+c'+2-2d) -- as
+// FastStep::start_state has them (mrs_tg_sweep.hpp), from the table entries instead of staged products.
+template <bool ENDS, bool MOVING = false>
 __device__ __forceinline__ double evaluate_lean_shared(const double* tabs, const double* ev, double* pub, int S, int Sb, int d,
                                                        const double* pt, double* grad, int g, int G, bool active, int* tripped) {
   static_assert(!(ENDS && MRS_TG_LEAN_CONST_TABLE), "the compile-time table is the order-4 one");
+  const double* mv = pub + kLeanPub;
+  const bool moving = MOVING && mv[0] != 0.0;
   const double* dp = ev;
   const double* qs = ev + 4 * (size_t)Sb + 2;  // HBAR[0][0] |dp_i|^2 per segment (stage_ps)
   const int m = S >> 1, nL = m + 2;
@@ -638,6 +649,16 @@ __device__ __forceinline__ double evaluate_lean_shared(const double* tabs, const
 #pragma unroll
           for (int q = 0; q < 4; ++q) y[rr][q] = fma(-cN, dq[q], y[rr][q]);
         }
+        if (ENDS && MOVING && free_end && moving && left) {  // the start vertex's own free slots see its constrained values
+#pragma unroll
+          for (int rr = 0; rr < kNB; ++rr)
+#pragma unroll
+            for (int c = 0; c < kNB; ++c) {
+              const double nrc = LEAN_TAB(rr >= c ? tri(rr, c) : tri(c, rr)) * p2[rr + c + 2];
+#pragma unroll
+              for (int q = 0; q < 4; ++q) y[rr][q] = fma(-nrc, mv[2 + c * 4 + q], y[rr][q]);
+            }
+        }
         if (ENDS) {
 #pragma unroll
           for (int rr = 0; rr < kNB; ++rr) rs[rr] = (free_end && !((fm >> rr) & 1u)) ? 0.0 : 1.0;
@@ -700,6 +721,29 @@ __device__ __forceinline__ double evaluate_lean_shared(const double* tabs, const
 #pragma unroll
             for (int mm = 0; mm < kNB; ++mm) t = fma(-W[mm][rr], z[mm][q], t);
             y[rr][q] = t;
+          }
+        }
+      }
+      if (MOVING && s == 0 && moving && left) {  // vertex 1's right-hand side and f^T H f: the terms of the moving start
+#pragma unroll
+        for (int c = 0; c < kNB; ++c) {
+          double fc[4];
+#pragma unroll
+          for (int q = 0; q < 4; ++q) fc[q] = mv[2 + c * 4 + q];
+#pragma unroll
+          for (int rr = 0; rr < kNB; ++rr) {
+            const double ecr = LEAN_TAB(10 + c * kNB + rr) * p2[rr + c + 2];  // near slot c (vertex 0) x far slot rr (vertex 1)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) y[rr][q] = fma(-ecr, fc[q], y[rr][q]);
+          }
+          const double n0 = 2.0 * (LEAN_TAB(36 + c) * p2[c + 1]);
+#pragma unroll
+          for (int q = 0; q < 4; ++q) qf = fma(n0 * fc[q], dq[q], qf);
+#pragma unroll
+          for (int c2 = 0; c2 < kNB; ++c2) {
+            const double ncc = LEAN_TAB(c >= c2 ? tri(c, c2) : tri(c2, c)) * p2[c + c2 + 2];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) qf = fma(ncc * fc[q], mv[2 + c2 * 4 + q], qf);
           }
         }
       }
@@ -780,9 +824,11 @@ __host__ __device__ constexpr int lean_group_doubles(int Sb) {
 // positions -> dp of every segment; returns whether the path is one the evaluation takes (group-uniform)
 // end_masks: the two end vertices may leave slots free (rest-to-rest paths under an objective order below snap: jerk and /
 // or snap stay free there); their free masks are left at ev[4 Sb] and ev[4 Sb + 1] for evaluate_lean<true>
+// moving: where the evaluation takes a start vertex whose constrained derivatives carry non-zero values (evaluate_lean_shared):
+// the area they are left in (kLeanMoving doubles), else nullptr and such a path is not taken
 __device__ __forceinline__ bool stage_ps(const uint8_t* __restrict__ mask, const double* __restrict__ vals, int v0, int S,
                                          int Sb, double* ev, int g, int G, bool active, int min_segments, int d,
-                                         bool end_masks = false) {
+                                         bool end_masks = false, double* moving = nullptr) {
   double* dp = ev;
   double* tmp = ev + 4 * (size_t)Sb;  // the record area, not in use yet
   int ok = (S >= min_segments) ? 1 : 0;
@@ -799,6 +845,14 @@ __device__ __forceinline__ bool stage_ps(const uint8_t* __restrict__ mask, const
         for (int q = 0; q < kD; ++q) nz += fabs(f[k][q]);
       const bool end = v == 0 || v == S;
       const bool pattern_ok = end ? (end_masks || fb == 0u) : fb == 0xFu;
+      if (v == 0 && moving != nullptr) {  // (load_vertex has zeroed the values of unconstrained slots)
+        moving[0] = nz;
+#pragma unroll
+        for (int k = 1; k < kHalf; ++k)
+#pragma unroll
+          for (int q = 0; q < kD; ++q) moving[2 + (k - 1) * kD + q] = f[k][q];
+        nz = 0.0;
+      }
       if (!(pf && nz == 0.0 && pattern_ok)) ok = 0;
       if (v == 0) fb_first = fb;
       if (v == S) fb_last = fb;
@@ -931,7 +985,8 @@ __device__ __forceinline__ void optimize_body(const BatchView& b, const Nonlinea
   if (LEAN) {  // vtx = the evaluation area: dp of every segment; the path's eligibility decides who runs it
     // (the kernel of the shared half sweeps with free end slots runs every bin of a ragged plan, in groups of S + 4 lanes:
     // paths of fewer than four segments are left to the sweeping kernel behind it)
-    const bool takes = stage_ps(mask, vals, pr.v0, S, Sb, vtx, g, G, active, (LEANSHARED && MASKED4) ? prm.ends_min_segments : 2, d, MASKED4);
+    const bool takes = stage_ps(mask, vals, pr.v0, S, Sb, vtx, g, G, active, (LEANSHARED && MASKED4) ? prm.ends_min_segments : 2, d, MASKED4,
+                                LEANSHARED ? vtx + 4 * (size_t)Sb + 4 * ((size_t)Sb + 1) + kLeanPub : nullptr);
     if (active && g == 0) fallback[q] = takes ? 0 : 1;
     active = active && takes;
   } else {
@@ -1077,7 +1132,8 @@ __device__ __forceinline__ void optimize_body(const BatchView& b, const Nonlinea
             S = pr.S;
             active = true;
             double t_new = (g < S) ? start_time(prm, seg_times, pr, g) : 0.0;
-            const bool takes = stage_ps(mask, vals, pr.v0, S, Sb, vtx, g, G, true, (LEANSHARED && MASKED4) ? prm.ends_min_segments : 2, d, MASKED4);
+            const bool takes = stage_ps(mask, vals, pr.v0, S, Sb, vtx, g, G, true, (LEANSHARED && MASKED4) ? prm.ends_min_segments : 2, d, MASKED4,
+                                        LEANSHARED ? vtx + 4 * (size_t)Sb + 4 * ((size_t)Sb + 1) + kLeanPub : nullptr);
             if (g == 0) fallback[q] = takes ? 0 : 1;
             if (takes) {
               int okn = 1;
@@ -1140,9 +1196,9 @@ __device__ __forceinline__ void optimize_body(const BatchView& b, const Nonlinea
       // shared half sweeps when every path of the wavefront takes them (plain paths of 4 <= S <= G - 4 segments: S + 4 lanes)
       const bool shared_path = S >= 4 && S + 4 <= G;
       if (LEANSHARED)
-        fn = evaluate_lean_shared<MASKED4>(hc, vtx, vtx + 4 * (size_t)Sb + 4 * ((size_t)Sb + 1), S, Sb, d, xn, gn, g, G, !done, tick_i + 4);
+        fn = evaluate_lean_shared<MASKED4, true>(hc, vtx, vtx + 4 * (size_t)Sb + 4 * ((size_t)Sb + 1), S, Sb, d, xn, gn, g, G, !done, tick_i + 4);
       else if (!MASKED4 && prm.lean_shared == 2 && __ballot(!done && !shared_path) == 0ull)
-        fn = evaluate_lean_shared<false>(hc, vtx, vtx + 4 * (size_t)Sb + 4 * ((size_t)Sb + 1), S, Sb, d, xn, gn, g, G, !done, tick_i + 4);
+        fn = evaluate_lean_shared<false, false>(hc, vtx, vtx + 4 * (size_t)Sb + 4 * ((size_t)Sb + 1), S, Sb, d, xn, gn, g, G, !done, tick_i + 4);
       else
         fn = evaluate_lean<MASKED4>(hc, vtx, S, Sb, d, xn, gn, g, G, !done, tick_i + 4);
     } else if (GENERAL) {
@@ -2099,7 +2155,16 @@ hipError_t launch_nonlinear(NonlinearPlan& nl, const BatchView& b, const Nonline
   if (ends_shared)
     for (const NonlinearBin& bin : nl.ends_bins)
       if (plain_lds(bin) > 160 * 1024) ends_shared = false;
-  const std::vector<NonlinearBin>& lean_bins = ends_shared ? nl.ends_bins : wide ? nl.wide_bins : nl.bins;
+  // min-snap launches of a few residency rounds: EVERY path of two or more segments in a group of S + 4 lanes (the bins of the
+  // free-end kernel), so that the kernel with only the shared half sweeps runs -- the one that takes moving starts; 5-7
+  // segments then pay 3-4 % for their wider groups when they start at rest (MRS_TG_LEAN_WIDE_ALL=0: only 13-15 and 29-30
+  // segments move up and a ragged batch runs the mixed kernel, whose one-sided sweeps leave moving starts to the sweeping kernel)
+  static const bool wide_all = [] {
+    const char* e = std::getenv("MRS_TG_LEAN_WIDE_ALL");
+    return e == nullptr || std::atoi(e) != 0;
+  }();
+  const bool wide_shared_all = wide && wide_all && !nl.ends_bins.empty() && (int)nl.ends_bins.size() <= 5;
+  const std::vector<NonlinearBin>& lean_bins = (ends_shared || wide_shared_all) ? nl.ends_bins : wide ? nl.wide_bins : nl.bins;
   if (lean)
     for (const NonlinearBin& bin : lean_bins)
       if (plain_lds(bin) > 160 * 1024) lean = false;
@@ -2142,8 +2207,8 @@ hipError_t launch_nonlinear(NonlinearPlan& nl, const BatchView& b, const Nonline
     // short paths in wavefronts of their own next to the others: handing them to the compact kernel BEHIND the launch cost
     // 66 us on 8192 ragged paths, profiles/round5_wide_groups_ab.txt)
     bool lean_shared_only = prm.lean_shared != 0 && !lean_masked;
-    for (const NonlinearBin& bin : lean_bins)
-      if (bin.min_S < 4 || bin.max_S + 4 > bin.group) lean_shared_only = false;
+    for (const NonlinearBin& bin : lean_bins)  // (a bin of one-segment paths: the kernel leaves them to the sweeping kernel behind it)
+      if (bin.max_S >= 2 && (bin.min_S < 2 || bin.max_S + 4 > bin.group)) lean_shared_only = false;
     if (plds > 64 * 1024 &&
         (e = hipFuncSetAttribute(ends_shared ? (const void*)optimize_lean_shared_ends_kernel
                                  : lean_masked ? (const void*)optimize_lean_masked_kernel

@@ -19,7 +19,25 @@ from mrs_uav_trajectory_generation_amd import api, problem as pr  # noqa: E402
 DERIV = int(os.environ.get("DERIV", "4"))   # objective order of the one-config mode (the nodelet's default config is 2)
 
 
+MOVING = int(os.environ.get("MOVING", "0"))  # 1: every path starts from a moving state (velocity / acceleration / jerk of its
+#                                               first vertex constrained to non-zero values: a replanning request in flight)
+
+
+def with_moving_starts(batch):
+    if not MOVING:
+        return batch
+    rng = np.random.default_rng(5)
+    parts = []
+    for p in range(batch.n_paths):
+        wp, _, _ = batch.path(p)
+        init = dict(heading=wp[0, 3], velocity=np.append(rng.uniform(-1, 1, 3), 0.1), acceleration=np.append(rng.uniform(-0.5, 0.5, 3), 0.0),
+                    jerk=np.zeros(4))
+        parts.append(pr.build_vertices(wp, batch.derivative_to_optimize, initial_state=init))
+    return pr.assemble_batch(parts, batch.limits, batch.derivative_to_optimize)
+
+
 def measure(ctx, batch, nonlinear, reps):
+    batch = with_moving_starts(batch)
     plan = api.Plan(ctx, batch.seg_offsets)
     db = api.DeviceBatch(batch, "cuda:0", sample_capacity=512)
     est = api.default_options(derivative_to_optimize=batch.derivative_to_optimize, estimate_times=1)

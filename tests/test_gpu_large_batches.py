@@ -202,3 +202,51 @@ def test_objective_orders_below_snap_on_the_saturated_device_kernels(gpu_ctx, de
             good += 1
     print("RATE below-snap d=%d %s: %d / %d" % (deriv, {True: "ragged", False: "10 segments"}.get(ragged, "%s segments" % ragged), good, len(oidx)))
     assert good >= len(oidx) - 3, (good, len(oidx))
+
+
+def _moving(batch, seed=5):
+    """every path starts from a moving state: velocity / acceleration / jerk of its first vertex constrained to non-zero values
+    (a replanning request of a vehicle in flight, /root/reference/src/mrs_trajectory_generation.cpp:946-957)"""
+    rng = np.random.default_rng(seed)
+    parts = []
+    for p in range(batch.n_paths):
+        wp, _, _ = batch.path(p)
+        init = dict(heading=wp[0, 3], velocity=np.append(rng.uniform(-1, 1, 3), 0.1),
+                    acceleration=np.append(rng.uniform(-0.5, 0.5, 3), 0.0), jerk=np.append(rng.uniform(-0.2, 0.2, 3), 0.0))
+        parts.append(pr.build_vertices(wp, batch.derivative_to_optimize, initial_state=init))
+    return pr.assemble_batch(parts, batch.limits, batch.derivative_to_optimize)
+
+
+@pytest.mark.parametrize("deriv,n_seg", [(4, 10), (2, 10), (3, 10), (2, "ragged"), (4, 20)])
+def test_moving_starts_on_the_saturated_device_kernels(gpu_ctx, deriv, n_seg):
+    """Paths that start from a moving state -- what a nodelet sends for every replanning request in flight -- in the large
+    batches' kernels (round 5: the shared half sweeps take the start vertex's constrained derivative values as right-hand-side
+    terms of their first step, with or without free slots beside them; the sweeping kernel behind the launch took such paths
+    before).  Mellinger pipeline against the oracle on a strided subset, the kernel trace says which outer loop ran."""
+    n = 6400 if n_seg != 20 else 3000
+    batch = _moving(pr.random_batch(n, n_seg, seed0=9300, derivative_to_optimize=deriv))
+    so = batch.seg_offsets
+    api.kernel_trace_reset()
+    out = gpu_ctx.solve_batch(batch, None, time_alloc_method=api.TIME_ALLOC_MELLINGER, sampling_dt=0.2, sample_capacity=192)
+    trace = api.kernel_trace()
+    if n_seg != "ragged" or deriv < 4:   # (a ragged min-snap batch runs the mixed kernel, whose one-sided sweeps do not take them)
+        assert ("optimize_lean_shared_ends_kernel" if deriv < 4 else "optimize_lean_shared_kernel") in trace, trace
+    oidx = list(range(0, n, n // 255))
+    osub = batch.select(oidx)
+    ref = po.solve_batch(osub.seg_offsets, osub.waypoints, osub.fixed_mask, osub.fixed_values, osub.limits,
+                         np.zeros(osub.n_segments), deriv=deriv, time_alloc_method=2, estimate_times=True, sampling_dt=0.2,
+                         sample_capacity=192, n_threads=8)
+    good = 0
+    for k, p in enumerate(oidx):
+        a, b = osub.seg_offsets[k], osub.seg_offsets[k + 1]
+        t = out["times"][so[p]:so[p + 1]]
+        if util.status_matches(out["status"][p], ref["status"][k]) and np.max(np.abs(t - ref["times"][a:b]) / ref["times"][a:b]) < 1e-6 \
+                and util.coeff_error(out["coeffs"][so[p]:so[p + 1]], ref["coeffs"][a:b]) < 1e-6:
+            good += 1
+    print("RATE moving starts d=%d %s: %d / %d" % (deriv, n_seg, good, len(oidx)))
+    assert good >= len(oidx) - 3, (good, len(oidx))
+    chk = list(range(0, n, 17))
+    sub = batch.select(chk)
+    tc = np.concatenate([out["times"][so[p]:so[p + 1]] for p in chk])
+    cc = np.concatenate([out["coeffs"][so[p]:so[p + 1]] for p in chk])
+    assert util.continuity_defect(sub, cc, tc) < 1e-9 and util.constraint_defect(sub, cc, tc) < 1e-9

@@ -189,7 +189,7 @@ def _check_invariants(batch, out, limits_tol=1.05):
 # the lane-per-dimension kernel for 13-15 (one path per wavefront, a partner wavefront from the other end), and the lane-group
 # kernels from 16 segments on whatever the batch size (round 5: dim_split_for; they were the large batches' kernels before)
 OUTER_LOOP_KERNEL = {10: "optimize_wave_kernel", 3: "optimize_wave_kernel", 4: "optimize_wave_kernel", 15: "optimize_split_kernel",
-                     20: "optimize_lean_shared_kernel", 30: "optimize_lean_shared_kernel", "ragged": "optimize_lean_kernel"}
+                     20: "optimize_lean_shared_kernel", 30: "optimize_lean_shared_kernel", "ragged": "optimize_lean_shared_kernel"}
 
 
 @pytest.mark.parametrize("n_seg,n_paths", [(10, 256), (3, 64), ("ragged", 96), (20, 24), (30, 8), (15, 32), (4, 16)])
