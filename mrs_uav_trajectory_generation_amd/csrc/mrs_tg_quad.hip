@@ -102,7 +102,10 @@ __device__ __forceinline__ double quad_sum(double v) {  // over the four lanes o
 // its only segment with the identity in the rows and columns of the constrained slots and zero in place of their reciprocal
 // pivots, so that they contribute nothing to W, z and x -- and has a record of its own: records for vertices 0 .. S instead
 // of 1 .. S - 1.  A fully constrained end takes the plain path's step.  Without ENDS such paths take the general step.
-template <bool WP, bool ENDS = false>
+// MOVING: a START vertex whose constrained derivatives carry non-zero values (a path that starts from a moving state) stays on
+// the fast road -- the single-launch kernels; the grouped launch (the headline's kernel) is compiled without it: the lines
+// below cost it 16 % (330 -> 300 M/s over 20 steps, 556 -> 469 over 200, same box) although no wavefront of it ever takes them
+template <bool WP, bool ENDS = false, bool MOVING = false>
 __device__ __forceinline__ void solve_quad_body(const BatchView& b, int d, const uint8_t* __restrict__ mask,
                                                 const double* __restrict__ vals, const double* seg_times,
                                                 double* __restrict__ coeffs, int32_t* __restrict__ status,
@@ -130,6 +133,7 @@ __device__ __forceinline__ void solve_quad_body(const BatchView& b, int d, const
   double t_sum = 0.0;
   bool ok = S >= 2, pos_ok = true;
   unsigned fm_first = 0u, fm_last = 0u;  // ENDS: free slots of the two end vertices (bit r: derivative r + 1)
+  bool moving_path = false;              // the start vertex's constrained derivatives carry non-zero values (lane 0 of the quad knows)
   if (active) {
     const int opt_st = scaling ? tail.opt_status[pr.p] : 0;
     for (int i = dim; i < S; i += 4) {
@@ -151,15 +155,23 @@ __device__ __forceinline__ void solve_quad_body(const BatchView& b, int d, const
       if (end) {
         const double* vrow = vals + (size_t)(pr.v0 + v) * kHalf * kD;
         double nz = 0.0;
+        // (the values of unconstrained slots are not read by anybody: only those of constrained ones count.  Every value is
+        // LOADED unconditionally, sixteen requests back to back -- written as a conditional expression around the load they
+        // became four branches with a trip to memory each: 65536 x 10 132 -> 147 us, the grouped headline -16 %)
+        double av[kHalf * kD];
 #pragma unroll
-        for (int e = kD; e < kHalf * kD; ++e) nz += fabs(vrow[e]);
-        // (the values of unconstrained slots are not read by anybody: only those of constrained ones must be zero)
-        if (ENDS) {
+        for (int e = kD; e < kHalf * kD; ++e) av[e] = fabs(vrow[e]);
+#pragma unroll
+        for (int k = 1; k < kHalf; ++k)
+#pragma unroll
+          for (int e = 0; e < kD; ++e) nz += ((fixed >> k) & 1u) ? av[k * kD + e] : 0.0;
+        // a START vertex whose constrained derivatives carry non-zero values (a path that starts from a moving state) stays on
+        // this road: the values are right-hand-side terms of the first step (below); the end vertex must be at rest
+        if (MOVING && v == 0) {
+          moving_path = nz != 0.0;
           nz = 0.0;
-#pragma unroll
-          for (int k = 1; k < kHalf; ++k)
-#pragma unroll
-            for (int e = 0; e < kD; ++e) nz += ((fixed >> k) & 1u) ? fabs(vrow[k * kD + e]) : 0.0;
+        }
+        if (ENDS) {
           ok = ok && (fixed & 1u) && nz == 0.0;
           if (v == 0) fm_first = (~fixed >> 1) & 0xFu;
           if (v == S) fm_last = (~fixed >> 1) & 0xFu;
@@ -176,6 +188,8 @@ __device__ __forceinline__ void solve_quad_body(const BatchView& b, int d, const
     fm_last = (unsigned)__shfl((int)fm_last, (lane & ~3) + (S & 3), 64);
   }
   t_sum = quad_sum(t_sum);
+  const bool any_moving = MOVING && __ballot(active && moving_path) != 0ull;  // (wave-uniform: a wavefront of paths at rest skips every line of it)
+  if (any_moving) moving_path = __shfl((int)moving_path, lane & ~3, 64) != 0;
   const bool plain_wave = __ballot(active && !ok) == 0ull;
   const unsigned long long pos_bad = __ballot(active && !pos_ok);
   const bool path_pos_ok = ((pos_bad >> (lane & ~3)) & 0xFull) == 0ull;
@@ -224,6 +238,16 @@ __device__ __forceinline__ void solve_quad_body(const BatchView& b, int d, const
       double p2[9];
       quad_powers(T, d1, d2, d4, p2);
       const double dp = p_cur - p_nxt;
+      // a moving start: this dimension's constrained derivative values of the start vertex (zero in free slots), from the
+      // caller's value array -- read here and again for the first segment's coefficients, not kept in between
+      double f0[kNB] = {0.0, 0.0, 0.0, 0.0};
+      if (any_moving && i == 0 && active && moving_path) {
+        const double* vrow0 = vals + (size_t)pr.v0 * kHalf * kD + dim;
+#pragma unroll
+        for (int r = 0; r < kNB; ++r) f0[r] = vrow0[(r + 1) * kD];
+#pragma unroll
+        for (int r = 0; r < kNB; ++r) f0[r] = (!ENDS || !((fm_first >> r) & 1u)) ? f0[r] : 0.0;
+      }
       if (on) {
         const bool free_start = ENDS && i == 0 && fm_first != 0u;
         if (i == 0 && !free_start) {  // the start vertex is fully constrained: the state moves to vertex 1
@@ -242,6 +266,13 @@ __device__ __forceinline__ void solve_quad_body(const BatchView& b, int d, const
             for (int c = 0; c <= r; ++c)
               Sm[tri(r, c)] = free_start ? cNear[tri(r, c)] * p2[r + c + 2] : fma(cNear[tri(r, c)], p2[r + c + 2], Sm[tri(r, c)]);
             y[r] = free_start ? -((cN[r] * p2[r + 1]) * dp) : fma(-(cN[r] * p2[r + 1]), dp, y[r]);
+          }
+          if (ENDS && free_start && any_moving) {  // the start vertex's own unknowns see its constrained values
+#pragma unroll
+            for (int r = 0; r < kNB; ++r)
+#pragma unroll
+              for (int c = 0; c < kNB; ++c)
+                y[r] = fma(-(cNear[r >= c ? tri(r, c) : tri(c, r)] * p2[r + c + 2]), f0[c], y[r]);
           }
           double rs[kNB];  // ENDS: 0 in place of the reciprocal pivot of a constrained slot
 #pragma unroll
@@ -316,6 +347,12 @@ __device__ __forceinline__ void solve_quad_body(const BatchView& b, int d, const
               y[r] = t;
             }
           }
+        }
+        if (any_moving && i == 0) {  // vertex 1's right-hand side: - sum_c E[c][r] T^(r+c+2-2d) f_c
+#pragma unroll
+          for (int r = 0; r < kNB; ++r)
+#pragma unroll
+            for (int c = 0; c < kNB; ++c) y[r] = fma(-(cCpl[c][r] * p2[r + c + 2]), f0[c], y[r]);
         }
         if (ENDS && i == S - 1 && fm_last != 0u) {
           // the end vertex has unknowns: its block (the far part of the last segment, less what vertex S - 1 took) is complete
@@ -430,6 +467,14 @@ __device__ __forceinline__ void solve_quad_body(const BatchView& b, int d, const
         x[2] = fma(-l32, x[3], t[2]) * i2;
         x[1] = fma(-l31, x[3], fma(-l21, x[2], t[1])) * i1;
         x[0] = fma(-l30, x[3], fma(-l20, x[2], fma(-l10, x[1], t[0]))) * i0;
+      }
+      if (any_moving && v == 0 && active && moving_path) {  // the start vertex's constrained derivative values
+        const double* vrow0 = vals + (size_t)pr.v0 * kHalf * kD + dim;
+#pragma unroll
+        for (int r = 0; r < kNB; ++r) {
+          const double fr = vrow0[(r + 1) * kD];
+          x[r] += (!ENDS || !((fm_first >> r) & 1u)) ? fr : 0.0;
+        }
       }
       if (on) {
         const double T = tbuf[v * kQdPaths + pl];
@@ -551,7 +596,7 @@ __global__ __launch_bounds__(64, MRS_TG_QUAD_WAVES) void solve_quad_kernel(Batch
                                                         double* __restrict__ coeffs, int32_t* __restrict__ status,
                                                         double* __restrict__ cost, const int32_t* __restrict__ status_in,
                                                         double* ws, RowsTail tail) {
-  solve_quad_body<WP, ENDS>(b, d, mask, vals, seg_times, coeffs, status, cost, status_in, ws, tail, (int)blockIdx.x, tail.pos_wp);
+  solve_quad_body<WP, ENDS, true>(b, d, mask, vals, seg_times, coeffs, status, cost, status_in, ws, tail, (int)blockIdx.x, tail.pos_wp);
 }
 
 // several batches of ONE plan in one launch (as solve_rows_group_kernel): workgroups [j * blocks_per_batch, ...) solve batch j

@@ -226,6 +226,27 @@ def test_moving_starts_on_the_saturated_device_kernels(gpu_ctx, deriv, n_seg):
     n = 6400 if n_seg != 20 else 3000
     batch = _moving(pr.random_batch(n, n_seg, seed0=9300, derivative_to_optimize=deriv))
     so = batch.seg_offsets
+    if n_seg == 10:
+        # the fixed-times solve: solve_quad_kernel keeps such paths on its fast road too (the start vertex's values are
+        # right-hand-side terms of its first step and the first segment's boundary values; the general step before)
+        api.kernel_trace_reset()
+        lin = gpu_ctx.solve_batch(batch, None)
+        assert ("solve_quad_kernel<false, true>" if deriv < 4 else "solve_quad_kernel<false>") in api.kernel_trace(), api.kernel_trace()
+        assert np.all(lin["status"] == 1)
+        idx = list(range(0, n, n // 127))
+        _subset_vs_oracle(batch, lin, idx, 1e-7)
+        small = batch.select(idx)
+        ts = np.concatenate([lin["times"][so[p]:so[p + 1]] for p in idx])
+        sout = gpu_ctx.solve_batch(small, ts)          # (127 paths: the rows kernel)
+        got = np.concatenate([lin["coeffs"][so[p]:so[p + 1]] for p in idx])
+        assert util.coeff_error(got, sout["coeffs"], small.seg_offsets) < 1e-9
+        assert np.max(np.abs(lin["cost"][idx] - sout["cost"]) / np.abs(sout["cost"])) < 1e-9
+        c13 = list(range(0, n, 13))
+        s13 = batch.select(c13)
+        assert util.continuity_defect(s13, np.concatenate([lin["coeffs"][so[p]:so[p + 1]] for p in c13]),
+                                      np.concatenate([lin["times"][so[p]:so[p + 1]] for p in c13])) < 1e-9
+        assert util.constraint_defect(s13, np.concatenate([lin["coeffs"][so[p]:so[p + 1]] for p in c13]),
+                                      np.concatenate([lin["times"][so[p]:so[p + 1]] for p in c13])) < 1e-9
     api.kernel_trace_reset()
     out = gpu_ctx.solve_batch(batch, None, time_alloc_method=api.TIME_ALLOC_MELLINGER, sampling_dt=0.2, sample_capacity=192)
     trace = api.kernel_trace()
