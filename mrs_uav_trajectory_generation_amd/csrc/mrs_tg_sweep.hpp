@@ -97,7 +97,7 @@ __device__ __forceinline__ double guarded_cost(double J, double qf, bool base) {
 // moving state has its own variant of the start step (kSegStartState below); any other mask / value pattern
 // (partially constrained stop vertices, a moving start straight into a stop) takes the general step.
 constexpr int kSegLds = 38;
-enum { kSegGeneral = 0, kSegStart = 1, kSegInterior = 2, kSegEnd = 3, kSegStartState = 4, kSegMasked = 5 };
+enum { kSegGeneral = 0, kSegStart = 1, kSegInterior = 2, kSegEnd = 3, kSegStartState = 4, kSegMasked = 5, kSegMaskedStartState = 6 };
 // kSegMasked: every constrained derivative value is zero (so the position brackets are the whole right-hand side) but
 // the free masks of the two vertices are not one of the three patterns above: the end vertices of a rest-to-rest path
 // under the minimum-acceleration or minimum-jerk objective (d = 2, the reference's shipping default, leaves jerk and
@@ -109,7 +109,12 @@ enum { kSegGeneral = 0, kSegStart = 1, kSegInterior = 2, kSegEnd = 3, kSegStartS
 // sum_c HBAR[6+r][c] f_c T^(r+1+c+1-2d) -- and so is f^T H f.  Their time-independent coefficients (per dimension 4 x 4
 // for the rows, 8 for the powers 1..8 of f^T H f; power 0 and the position bracket are the ordinary record) sit in
 // kStartExtra doubles in front of the segment records.
-constexpr int kStartExtraDim = 16 + 8;
+// kSegMaskedStartState: the same with free slots beside the constrained values (a moving start under an objective order
+// below snap -- the nodelet's default config: velocity, acceleration and jerk come from the vehicle's state, snap is an
+// unknown): the masked step, plus the terms above for vertex 1 and f^T H f, plus the start vertex's own right-hand side
+// -- row r gets sum_c HBAR[1+r][c] f_c T^(r+1+c+1-2d) -- whose coefficients are 16 more doubles per dimension.  Only
+// optimize_wave_kernel has a step for it; every other evaluation takes the general step.
+constexpr int kStartExtraDim = 16 + 8 + 16;
 constexpr int kStartExtra = kD * kStartExtraDim;
 
 __device__ __forceinline__ void stage_segments(const double* vtx, int S, int d, double* seg, int g, int G, bool extras) {
@@ -132,14 +137,15 @@ __device__ __forceinline__ void stage_segments(const double* vtx, int S, int d, 
       else if (fs == 0u && fe == 0xFu) kind = kSegStart;
       else if (fs == 0xFu && fe == 0u) kind = kSegEnd;
       else kind = kSegMasked;
-    } else if (extras && i == 0 && fs == 0u && fe == 0xFu && vs[21] != 0.0 && ve[21] != 0.0) {
+    } else if (extras && i == 0 && vs[21] != 0.0 && ve[21] != 0.0) {
+      // (the staged values of unconstrained slots are zero: load_vertex)
       double nze = 0.0;
 #pragma unroll
       for (int k = 1; k < kHalf; ++k)
 #pragma unroll
         for (int q = 0; q < kD; ++q) nze += fabs(ve[k * kD + q]);
       if (nze == 0.0) {
-        kind = kSegStartState;
+        kind = (fs == 0u && fe == 0xFu) ? kSegStartState : kSegMaskedStartState;
         double* ex = seg - kStartExtra;
 #pragma unroll
         for (int q = 0; q < kD; ++q) {
@@ -148,7 +154,10 @@ __device__ __forceinline__ void stage_segments(const double* vtx, int S, int d, 
 #pragma unroll
           for (int r = 0; r < kNB; ++r)
 #pragma unroll
-            for (int c = 1; c < kHalf; ++c) e[r * 4 + (c - 1)] = hb[kHalf + kSlot0 + r][c] * vs[c * kD + q];
+            for (int c = 1; c < kHalf; ++c) {
+              e[r * 4 + (c - 1)] = hb[kHalf + kSlot0 + r][c] * vs[c * kD + q];
+              e[24 + r * 4 + (c - 1)] = hb[kSlot0 + r][c] * vs[c * kD + q];
+            }
           double Q[9] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
 #pragma unroll
           for (int c = 1; c < kHalf; ++c) {
@@ -568,7 +577,8 @@ __device__ __forceinline__ double forward_cost(const double* vtx, const double* 
     // The four-dimensions-per-lane sweep (large batches) keeps the general step for moving starts and masked
     // vertices: their specialised steps would sit in the same loop as the plain ones and cost those ~10 % (register
     // allocation of a 440-VGPR kernel), which the BASELINE batches -- all plain -- would pay for nothing.
-    if (kind == kSegGeneral || (ND == 4 && (kind == kSegStartState || (kind == kSegMasked && !MASKED4)))) {
+    if (kind == kSegGeneral || kind == kSegMaskedStartState ||
+        (ND == 4 && (kind == kSegStartState || (kind == kSegMasked && !MASKED4)))) {
       double fs[kHalf][ND], fe[kHalf][ND];
       double L[10], z[kNB][ND], W[kNB][kNB];
       const unsigned free_s = staged_vertex<ND>(vtx, i, dim0, fs);

@@ -173,7 +173,31 @@ __device__ __forceinline__ double wave_evaluate(const double* lds, const WaveRol
       if (SPECIAL == 2 && ((special >> i) & 1u)) {
         const unsigned masks = (unsigned)seg[(size_t)i * kSegLds + 37];
         const unsigned ms = masks & 0xFu, me = masks >> 4;
+        // a moving start with free slots beside its constrained values (kSegMaskedStartState): the start vertex's own
+        // right-hand side in front of the masked step, vertex 1's and f^T H f behind it
+        const bool moving_first = s == 0 && w.left && (special >> 31);
+        const double* e = seg - kStartExtra + dim * kStartExtraDim;
+        if (moving_first) {
+#pragma unroll
+          for (int r = 0; r < kNB; ++r) {
+            double u = 0.0;
+#pragma unroll
+            for (int c = 1; c < kHalf; ++c) u = fma(e[24 + r * 4 + (c - 1)], p2[r + 1 + c], u);
+            st.y[r][0] -= u;
+          }
+        }
         fast.template masked_t<false>(st, tab, p2, w.left ? ms : me, w.left ? me : ms);
+        if (moving_first) {
+#pragma unroll
+          for (int r = 0; r < kNB; ++r) {
+            double u = 0.0;
+#pragma unroll
+            for (int c = 1; c < kHalf; ++c) u = fma(e[r * 4 + (c - 1)], p2[r + 1 + c], u);
+            st.y[r][0] -= ((me >> r) & 1u) ? u : 0.0;
+          }
+#pragma unroll
+          for (int mm = 1; mm < 9; ++mm) st.qf = fma(e[16 + (mm - 1)], p2[mm], st.qf);
+        }
       } else if (s == 0) {
         fast.template start_t<false>(st, tab, p2);
         if (SPECIAL != 0 && w.left && (special >> 31)) {  // the terms of the start vertex's derivative values (FastStep::start_state)
@@ -315,10 +339,10 @@ __global__ __launch_bounds__(64, MRS_TG_WAVE_WAVES) void optimize_wave_kernel(Ba
     int kind = kSegInterior;
     if (me) kind = (int)seg[(size_t)lane * kSegLds + 36];
     const bool first = lane == 0, last = lane == S - 1;
-    const bool kind_ok = !me || kind == kSegMasked || (first ? (kind == kSegStart || kind == kSegStartState)
+    const bool kind_ok = !me || kind == kSegMasked || (first ? (kind == kSegStart || kind == kSegStartState || kind == kSegMaskedStartState)
                                                              : last ? kind == kSegEnd : kind == kSegInterior);
-    const unsigned long long masked = __ballot(me && kind == kSegMasked);
-    const bool moving = __ballot(first && kind == kSegStartState) != 0ull;
+    const unsigned long long masked = __ballot(me && (kind == kSegMasked || kind == kSegMaskedStartState));
+    const bool moving = __ballot(first && (kind == kSegStartState || kind == kSegMaskedStartState)) != 0ull;
     if (__ballot(!kind_ok) == 0ull) {
       special = (unsigned)masked | (moving ? 1u << 31 : 0u);
       mode = masked ? 2 : moving ? 1 : 0;

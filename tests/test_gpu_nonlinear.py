@@ -477,3 +477,41 @@ def test_nonlinear_end_to_end_vs_the_113_bit_oracle(gpu_ctx, gen, n_paths, deriv
     assert np.array_equal(out["n_samples"], np.minimum(ref["n_samples"], cap + 1))
     assert (dt < 1e-6).mean() >= 0.995 and (dc < 1e-6).mean() >= 0.995
     assert dt.max() < 1e-3
+
+
+@pytest.mark.parametrize("deriv,n_seg,n_paths", [(2, 8, 300), (3, 10, 200), (2, 4, 64), (2, 12, 100), (4, 10, 200), (2, "ragged12", 240)])
+def test_moving_starts_below_snap_in_the_one_wavefront_kernel(gpu_ctx, deriv, n_seg, n_paths):
+    """The nodelet's everyday request: min-acceleration (its default config) from a MOVING state -- velocity, acceleration and
+    jerk of the first vertex constrained to the vehicle's values, snap an unknown there.  optimize_wave_kernel has a step for
+    that first segment since round 5 (kSegMaskedStartState: the masked step plus the terms of the constrained values; the
+    one-sided general sweeps behind a real call before).  Every path against the oracle."""
+    rng = np.random.default_rng(11)
+    base = pr.random_mixed_batch(n_paths, deriv, seed0=640, max_segments=12) if n_seg == "ragged12" else \
+        pr.random_batch(n_paths, n_seg, seed0=640, derivative_to_optimize=deriv)
+    parts = []
+    for p in range(base.n_paths):
+        wp, m, v = base.path(p)
+        if n_seg == "ragged12" and p % 3 == 0:
+            parts.append((wp, m, v))      # (some paths of the mixed batch keep their own constraint pattern)
+            continue
+        init = dict(heading=wp[0, 3], velocity=np.append(rng.uniform(-1, 1, 3), 0.1), acceleration=np.append(rng.uniform(-0.5, 0.5, 3), 0.0),
+                    jerk=np.append(rng.uniform(-0.2, 0.2, 3), 0.0))
+        parts.append(pr.build_vertices(wp, deriv, initial_state=init))
+    batch = pr.assemble_batch(parts, base.limits, deriv)
+    api.kernel_trace_reset()
+    out = gpu_ctx.solve_batch(batch, None, time_alloc_method=api.TIME_ALLOC_MELLINGER, sampling_dt=0.2, sample_capacity=512)
+    assert "optimize_wave_kernel" in api.kernel_trace(), api.kernel_trace()
+    ref = po.solve_batch(batch.seg_offsets, batch.waypoints, batch.fixed_mask, batch.fixed_values, batch.limits,
+                         np.zeros(batch.n_segments), deriv=deriv, time_alloc_method=2, estimate_times=True, sampling_dt=0.2,
+                         sample_capacity=512, n_threads=8)
+    so = batch.seg_offsets
+    good = 0
+    for p in range(batch.n_paths):
+        a, b = so[p], so[p + 1]
+        if util.status_matches(out["status"][p], ref["status"][p]) and np.max(np.abs(out["times"][a:b] - ref["times"][a:b]) / ref["times"][a:b]) < 1e-6 \
+                and util.coeff_error(out["coeffs"][a:b], ref["coeffs"][a:b]) < 1e-6:
+            good += 1
+    print("RATE moving below snap d=%d %s: %d / %d" % (deriv, n_seg, good, batch.n_paths))
+    assert good >= batch.n_paths - max(2, batch.n_paths // 100), (good, batch.n_paths)
+    assert util.continuity_defect(batch, out["coeffs"], out["times"]) < 1e-9
+    assert util.constraint_defect(batch, out["coeffs"], out["times"]) < 1e-9
