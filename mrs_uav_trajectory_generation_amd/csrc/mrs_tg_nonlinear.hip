@@ -628,7 +628,11 @@ __device__ __forceinline__ double evaluate_lean_shared(const double* tabs, const
 #pragma unroll
       for (int q = 0; q < 4; ++q) dq[q] = dp[i * 4 + q];
       qf = fma(p2[0], qs[i], qf);
-      const bool free_end = ENDS && s == 0 && fm != 0u;
+      // ENDS: the free mask of the vertex this step eliminates -- the end vertex the lane starts from (0: fully constrained,
+      // nothing to eliminate), else the vertex the sweep stands on (0xF unless it is a stop_at vertex)
+      unsigned fmv = fm;
+      if (ENDS && s > 0) fmv = (unsigned)ev[4 * (size_t)Sb + 2 + Sb + (left ? i : i + 1)] & 0xFu;
+      const bool free_end = ENDS && (s == 0 ? fm != 0u : fmv != 0xFu);  // (a step whose vertex has constrained slots)
       if (s == 0 && !free_end) {  // the end vertex is fully constrained: the state moves to the next vertex
 #pragma unroll
         for (int rr = 0; rr < kNB; ++rr) {
@@ -649,7 +653,7 @@ __device__ __forceinline__ double evaluate_lean_shared(const double* tabs, const
 #pragma unroll
           for (int q = 0; q < 4; ++q) y[rr][q] = fma(-cN, dq[q], y[rr][q]);
         }
-        if (ENDS && MOVING && free_end && moving && left) {  // the start vertex's own free slots see its constrained values
+        if (ENDS && MOVING && s == 0 && free_end && moving && left) {  // the start vertex's own free slots see its constrained values
 #pragma unroll
           for (int rr = 0; rr < kNB; ++rr)
 #pragma unroll
@@ -661,13 +665,13 @@ __device__ __forceinline__ double evaluate_lean_shared(const double* tabs, const
         }
         if (ENDS) {
 #pragma unroll
-          for (int rr = 0; rr < kNB; ++rr) rs[rr] = (free_end && !((fm >> rr) & 1u)) ? 0.0 : 1.0;
+          for (int rr = 0; rr < kNB; ++rr) rs[rr] = (free_end && !((fmv >> rr) & 1u)) ? 0.0 : 1.0;
           if (free_end) {
 #pragma unroll
             for (int rr = 0; rr < kNB; ++rr)
 #pragma unroll
               for (int c = 0; c <= rr; ++c)
-                if (!((fm >> rr) & 1u) || !((fm >> c) & 1u)) Sm[tri(rr, c)] = (rr == c) ? 1.0 : 0.0;
+                if (!((fmv >> rr) & 1u) || !((fmv >> c) & 1u)) Sm[tri(rr, c)] = (rr == c) ? 1.0 : 0.0;
           }
         }
         double L[10], Linv[kNB], z[kNB][4], W[kNB][kNB];
@@ -778,6 +782,18 @@ __device__ __forceinline__ double evaluate_lean_shared(const double* tabs, const
       for (int q = 0; q < 4; ++q) y[rr][q] += ps[10 + rr * 4 + q];
     qf += ps[26];
     red += ps[27];
+    // ENDS: the middle vertex may be a stop_at vertex too (identity in its constrained slots, zero for their reciprocal pivots)
+    unsigned fmm = 0xFu;
+    if (ENDS) {
+      fmm = (unsigned)ev[4 * (size_t)Sb + 2 + Sb + m] & 0xFu;
+      if (fmm != 0xFu) {
+#pragma unroll
+        for (int rr = 0; rr < kNB; ++rr)
+#pragma unroll
+          for (int c = 0; c <= rr; ++c)
+            if (!((fmm >> rr) & 1u) || !((fmm >> c) & 1u)) Sm[tri(rr, c)] = (rr == c) ? 1.0 : 0.0;
+      }
+    }
     double L[10], Linv[kNB], z[kNB][4];
 #pragma unroll
     for (int c = 0; c < kNB; ++c) {
@@ -785,7 +801,7 @@ __device__ __forceinline__ double evaluate_lean_shared(const double* tabs, const
 #pragma unroll
       for (int mm = 0; mm < c; ++mm) dsum = fma(-L[tri(c, mm)], L[tri(c, mm)], dsum);
       const double inv = rsqrt_refined(dsum);
-      Linv[c] = inv;
+      Linv[c] = (ENDS && !((fmm >> c) & 1u)) ? 0.0 : inv;
 #pragma unroll
       for (int rr = c + 1; rr < kNB; ++rr) {
         double t = Sm[tri(rr, c)];
@@ -828,11 +844,11 @@ __host__ __device__ constexpr int lean_group_doubles(int Sb) {
 // the area they are left in (kLeanMoving doubles), else nullptr and such a path is not taken
 __device__ __forceinline__ bool stage_ps(const uint8_t* __restrict__ mask, const double* __restrict__ vals, int v0, int S,
                                          int Sb, double* ev, int g, int G, bool active, int min_segments, int d,
-                                         bool end_masks = false, double* moving = nullptr) {
+                                         bool end_masks = false, double* moving = nullptr, bool interior_masks = false) {
   double* dp = ev;
   double* tmp = ev + 4 * (size_t)Sb;  // the record area, not in use yet
   int ok = (S >= min_segments) ? 1 : 0;
-  unsigned fb_first = 0u, fb_last = 0u;
+  unsigned fb_first = 0u, fb_last = 0u, my_fb = 0xFu;
   if (active)
     for (int v = g; v <= S; v += G) {
       double f[kHalf][kD];
@@ -844,7 +860,10 @@ __device__ __forceinline__ bool stage_ps(const uint8_t* __restrict__ mask, const
 #pragma unroll
         for (int q = 0; q < kD; ++q) nz += fabs(f[k][q]);
       const bool end = v == 0 || v == S;
-      const bool pattern_ok = end ? (end_masks || fb == 0u) : fb == 0xFu;
+      // (interior_masks: interior vertices may hold slots constrained to zero as well -- stop_at vertices: velocity =
+      // acceleration = jerk = 0, snap free; every vertex's free mask goes behind the f^T H f terms, tmp[2 + Sb + v])
+      const bool pattern_ok = end ? (end_masks || fb == 0u) : (interior_masks || fb == 0xFu);
+      my_fb = fb;  // (a group is at least S + 1 lanes wide: a lane loads at most one vertex)
       if (v == 0 && moving != nullptr) {  // (load_vertex has zeroed the values of unconstrained slots)
         moving[0] = nz;
 #pragma unroll
@@ -869,6 +888,7 @@ __device__ __forceinline__ bool stage_ps(const uint8_t* __restrict__ mask, const
   if (end_masks && active) {
     if (g == 0) tmp[0] = (double)fb_first;
     if (g == (S & (G - 1))) tmp[1] = (double)fb_last;  // the lane that loaded vertex S
+    if (g <= S) tmp[2 + Sb + g] = (double)my_fb;       // every vertex's free mask (interior: 0xF unless it is a stop_at vertex)
   }
   if (active) {  // f^T HBAR f of every segment (position terms only: all a plain path has), behind the two mask slots
     const double h00 = c_hbar[d][0][0];
@@ -986,7 +1006,7 @@ __device__ __forceinline__ void optimize_body(const BatchView& b, const Nonlinea
     // (the kernel of the shared half sweeps with free end slots runs every bin of a ragged plan, in groups of S + 4 lanes:
     // paths of fewer than four segments are left to the sweeping kernel behind it)
     const bool takes = stage_ps(mask, vals, pr.v0, S, Sb, vtx, g, G, active, (LEANSHARED && MASKED4) ? prm.ends_min_segments : 2, d, MASKED4,
-                                LEANSHARED ? vtx + 4 * (size_t)Sb + 4 * ((size_t)Sb + 1) + kLeanPub : nullptr);
+                                LEANSHARED ? vtx + 4 * (size_t)Sb + 4 * ((size_t)Sb + 1) + kLeanPub : nullptr, LEANSHARED && MASKED4);
     if (active && g == 0) fallback[q] = takes ? 0 : 1;
     active = active && takes;
   } else {
@@ -1133,7 +1153,7 @@ __device__ __forceinline__ void optimize_body(const BatchView& b, const Nonlinea
             active = true;
             double t_new = (g < S) ? start_time(prm, seg_times, pr, g) : 0.0;
             const bool takes = stage_ps(mask, vals, pr.v0, S, Sb, vtx, g, G, true, (LEANSHARED && MASKED4) ? prm.ends_min_segments : 2, d, MASKED4,
-                                        LEANSHARED ? vtx + 4 * (size_t)Sb + 4 * ((size_t)Sb + 1) + kLeanPub : nullptr);
+                                        LEANSHARED ? vtx + 4 * (size_t)Sb + 4 * ((size_t)Sb + 1) + kLeanPub : nullptr, LEANSHARED && MASKED4);
             if (g == 0) fallback[q] = takes ? 0 : 1;
             if (takes) {
               int okn = 1;

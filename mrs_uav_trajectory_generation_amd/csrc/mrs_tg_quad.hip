@@ -61,6 +61,7 @@ constexpr int kQdL = 0, kQdLinv = 6, kQdZ = 10, kQdRec = 26;
 // ends: records for the two end vertices as well (solve_quad_body<WP, true>: end vertices with free slots are eliminated)
 __host__ __device__ constexpr size_t quad_lds_doubles(int Smax, bool ends = false) {
   return (size_t)(ends ? Smax + 1 : (Smax > 1 ? Smax - 1 : 1)) * kQdRec * kQdPaths + (size_t)Smax * kQdPaths  // records | times
+         + (ends ? (size_t)(Smax + 1) * 2 : 0)  // ends: the free mask of every (vertex, path), one byte each
 #if MRS_TG_QUAD_EXP == 5
          + kQdPaths  // per path: first segment and segment count (ints)
 #endif
@@ -120,6 +121,7 @@ __device__ __forceinline__ void solve_quad_body(const BatchView& b, int d, const
   const int Smax = b.max_segments;
   double* rec0 = lds;
   double* tbuf = lds + (size_t)(ENDS ? Smax + 1 : (Smax > 1 ? Smax - 1 : 1)) * kQdRec * kQdPaths;  // [segment][path]
+  unsigned char* vmask = reinterpret_cast<unsigned char*>(tbuf + (size_t)Smax * kQdPaths);        // ENDS: [vertex][path] free masks
 #if MRS_TG_QUAD_EXP == 5
   const int n_rec = Smax > 1 ? Smax - 1 : 1;
   int* pinfo = reinterpret_cast<int*>(tbuf + (size_t)Smax * kQdPaths);
@@ -178,9 +180,27 @@ __device__ __forceinline__ void solve_quad_body(const BatchView& b, int d, const
         } else {
           ok = ok && fixed == 0x1Fu && nz == 0.0;
         }
+      } else if (ENDS) {
+        // an interior vertex may hold slots constrained to ZERO (a stop_at vertex: velocity = acceleration = jerk = 0): it is
+        // eliminated with the identity in those slots; its values are looked at only when it has such slots
+        bool zero = true;
+        if (fixed != 0x1u) {
+          const double* vrow = vals + (size_t)(pr.v0 + v) * kHalf * kD;
+          double av[kHalf * kD];
+#pragma unroll
+          for (int e = kD; e < kHalf * kD; ++e) av[e] = fabs(vrow[e]);
+          double nz = 0.0;
+#pragma unroll
+          for (int k = 1; k < kHalf; ++k)
+#pragma unroll
+            for (int e = 0; e < kD; ++e) nz += ((fixed >> k) & 1u) ? av[k * kD + e] : 0.0;
+          zero = nz == 0.0;
+        }
+        ok = ok && (fixed & 1u) && zero;
       } else {
         ok = ok && fixed == 0x1u;
       }
+      if (ENDS) vmask[v * kQdPaths + pl] = (unsigned char)((~fixed >> 1) & 0xFu);
     }
   }
   if (ENDS) {  // vertex 0 was read by lane 0 of the quad, vertex S by lane S mod 4
@@ -249,7 +269,11 @@ __device__ __forceinline__ void solve_quad_body(const BatchView& b, int d, const
         for (int r = 0; r < kNB; ++r) f0[r] = (!ENDS || !((fm_first >> r) & 1u)) ? f0[r] : 0.0;
       }
       if (on) {
+        // ENDS: the free mask of the vertex this step eliminates: the start vertex's (0: fully constrained, nothing to
+        // eliminate) or vertex i's (0xF unless it is a stop_at vertex)
+        const unsigned fmv = !ENDS ? 0xFu : (i == 0 ? fm_first : (unsigned)vmask[i * kQdPaths + pl]);
         const bool free_start = ENDS && i == 0 && fm_first != 0u;
+        const bool masked_step = ENDS && (i == 0 ? fm_first != 0u : fmv != 0xFu);
         if (i == 0 && !free_start) {  // the start vertex is fully constrained: the state moves to vertex 1
 #pragma unroll
           for (int r = 0; r < kNB; ++r) {
@@ -276,13 +300,13 @@ __device__ __forceinline__ void solve_quad_body(const BatchView& b, int d, const
           }
           double rs[kNB];  // ENDS: 0 in place of the reciprocal pivot of a constrained slot
 #pragma unroll
-          for (int r = 0; r < kNB; ++r) rs[r] = (free_start && !((fm_first >> r) & 1u)) ? 0.0 : 1.0;
-          if (free_start) {
+          for (int r = 0; r < kNB; ++r) rs[r] = (masked_step && !((fmv >> r) & 1u)) ? 0.0 : 1.0;
+          if (masked_step) {
 #pragma unroll
             for (int r = 0; r < kNB; ++r)
 #pragma unroll
               for (int c = 0; c <= r; ++c)
-                if (!((fm_first >> r) & 1u) || !((fm_first >> c) & 1u)) Sm[tri(r, c)] = (r == c) ? 1.0 : 0.0;
+                if (!((fmv >> r) & 1u) || !((fmv >> c) & 1u)) Sm[tri(r, c)] = (r == c) ? 1.0 : 0.0;
           }
           double L[10], Linv[kNB], z[kNB];
 #pragma unroll

@@ -23,7 +23,16 @@ MOVING = int(os.environ.get("MOVING", "0"))  # 1: every path starts from a movin
 #                                               first vertex constrained to non-zero values: a replanning request in flight)
 
 
+STOP = int(os.environ.get("STOP", "0"))      # 1: every interior waypoint is a stop_at vertex (velocity = acceleration = jerk = 0, snap free)
+
+
 def with_moving_starts(batch):
+    if STOP:
+        parts = []
+        for p in range(batch.n_paths):
+            wp, _, _ = batch.path(p)
+            parts.append(pr.build_vertices(wp, batch.derivative_to_optimize, stop_at=[True] * wp.shape[0]))
+        batch = pr.assemble_batch(parts, batch.limits, batch.derivative_to_optimize)
     if not MOVING:
         return batch
     rng = np.random.default_rng(5)

@@ -271,3 +271,62 @@ def test_moving_starts_on_the_saturated_device_kernels(gpu_ctx, deriv, n_seg):
     tc = np.concatenate([out["times"][so[p]:so[p + 1]] for p in chk])
     cc = np.concatenate([out["coeffs"][so[p]:so[p + 1]] for p in chk])
     assert util.continuity_defect(sub, cc, tc) < 1e-9 and util.constraint_defect(sub, cc, tc) < 1e-9
+
+
+@pytest.mark.parametrize("deriv,n_seg,every,moving", [(2, 10, 1, False), (3, 10, 2, False), (2, "ragged", 3, False), (2, 10, 2, True)])
+def test_stop_at_vertices_below_snap_on_the_saturated_device_kernels(gpu_ctx, deriv, n_seg, every, moving):
+    """stop_at waypoints (velocity = acceleration = jerk = 0 at an interior vertex, snap free;
+    /root/reference/src/mrs_trajectory_generation.cpp:969-973) under the objective orders below snap: the free-end
+    instantiations of the large batches' kernels eliminate such a vertex with the identity in its constrained slots (round 5;
+    the general steps before).  Every `every`-th interior vertex is one; optionally from a moving state.  Fixed-times solve
+    and Mellinger pipeline against the oracle on a strided subset, invariants on more paths."""
+    n = 6400
+    base = pr.random_batch(n, n_seg, seed0=9700, derivative_to_optimize=deriv)
+    rng = np.random.default_rng(3)
+    parts = []
+    for p in range(n):
+        wp, _, _ = base.path(p)
+        V = wp.shape[0]
+        stop = [(0 < i < V - 1) and (i % every == 0) for i in range(V)]
+        init = None
+        if moving:
+            init = dict(heading=wp[0, 3], velocity=np.append(rng.uniform(-1, 1, 3), 0.1), acceleration=np.append(rng.uniform(-0.5, 0.5, 3), 0.0),
+                        jerk=np.append(rng.uniform(-0.2, 0.2, 3), 0.0))
+        parts.append(pr.build_vertices(wp, deriv, stop_at=stop, initial_state=init))
+    batch = pr.assemble_batch(parts, base.limits, deriv)
+    so = batch.seg_offsets
+    if n_seg == 10:
+        api.kernel_trace_reset()
+        lin = gpu_ctx.solve_batch(batch, None)
+        assert "solve_quad_kernel<false, true>" in api.kernel_trace(), api.kernel_trace()
+        assert np.all(lin["status"] == 1)
+        idx = list(range(0, n, n // 127))
+        _subset_vs_oracle(batch, lin, idx, 1e-7)
+        small = batch.select(idx)
+        ts = np.concatenate([lin["times"][so[p]:so[p + 1]] for p in idx])
+        sout = gpu_ctx.solve_batch(small, ts)          # (127 paths: the rows kernel)
+        got = np.concatenate([lin["coeffs"][so[p]:so[p + 1]] for p in idx])
+        assert util.coeff_error(got, sout["coeffs"], small.seg_offsets) < 1e-9
+        assert np.max(np.abs(lin["cost"][idx] - sout["cost"]) / np.abs(sout["cost"])) < 1e-9
+    api.kernel_trace_reset()
+    out = gpu_ctx.solve_batch(batch, None, time_alloc_method=api.TIME_ALLOC_MELLINGER, sampling_dt=0.2, sample_capacity=192)
+    assert "optimize_lean_shared_ends_kernel" in api.kernel_trace(), api.kernel_trace()
+    oidx = list(range(0, n, n // 255))
+    osub = batch.select(oidx)
+    ref = po.solve_batch(osub.seg_offsets, osub.waypoints, osub.fixed_mask, osub.fixed_values, osub.limits,
+                         np.zeros(osub.n_segments), deriv=deriv, time_alloc_method=2, estimate_times=True, sampling_dt=0.2,
+                         sample_capacity=192, n_threads=8)
+    good = 0
+    for k, p in enumerate(oidx):
+        a, b = osub.seg_offsets[k], osub.seg_offsets[k + 1]
+        t = out["times"][so[p]:so[p + 1]]
+        if util.status_matches(out["status"][p], ref["status"][k]) and np.max(np.abs(t - ref["times"][a:b]) / ref["times"][a:b]) < 1e-6 \
+                and util.coeff_error(out["coeffs"][so[p]:so[p + 1]], ref["coeffs"][a:b]) < 1e-6:
+            good += 1
+    print("RATE stop_at d=%d %s every %d moving %s: %d / %d" % (deriv, n_seg, every, moving, good, len(oidx)))
+    assert good >= len(oidx) - 3, (good, len(oidx))
+    chk = list(range(0, n, 17))
+    sub = batch.select(chk)
+    tc = np.concatenate([out["times"][so[p]:so[p + 1]] for p in chk])
+    cc = np.concatenate([out["coeffs"][so[p]:so[p + 1]] for p in chk])
+    assert util.continuity_defect(sub, cc, tc) < 1e-9 and util.constraint_defect(sub, cc, tc) < 1e-9
