@@ -135,6 +135,15 @@ enum {
                                          time, and refuses the bind with MRS_TG_ERR_INVALID_ARG if it does not hold;
                                          mrs_tg_plan_solve trusts it (a statement that is false gives the solution of the
                                          waypoints' problem).  Other kernels ignore the flag */
+  ,
+  MRS_TG_FLAG_CONSTRAINED_SLOTS = 64  /* a HINT (results agree to rounding with and without it): beside the ends of its paths the
+                                         batch may hold vertices with derivative slots constrained to zero -- stop_at waypoints --
+                                         and the objective order is snap.  The min-snap launches of the large batches' kernels are
+                                         compiled for position-only interior vertices (they are the benchmark configs' kernels) and
+                                         hand other paths to the general steps; with the hint they run the instantiations that
+                                         eliminate such vertices inside the specialised sweeps (always the case below snap).
+                                         mrs_tg_solve_batch, mrs_tg_find_trajectory and mrs_tg_optimize_paths set it themselves
+                                         from the masks they hold in host memory */
 };
 
 /* mrs_tg_capabilities(): what this build of the library contains beyond the mandatory surface */

@@ -500,6 +500,10 @@ int mrs_tg_plan_solve(mrs_tg_plan* plan, const double* wp, const uint8_t* mask, 
     explicit SharedDeviceScope(bool on) { mrs_tg::set_shared_device_hint(on); }
     ~SharedDeviceScope() { mrs_tg::set_shared_device_hint(false); }
   } shared_scope((opt->flags & MRS_TG_FLAG_SHARED_DEVICE) != 0);
+  struct ConstrainedSlotsScope {
+    explicit ConstrainedSlotsScope(bool on) { mrs_tg::set_constrained_slots_hint(on); }
+    ~ConstrainedSlotsScope() { mrs_tg::set_constrained_slots_hint(false); }
+  } slots_scope((opt->flags & MRS_TG_FLAG_CONSTRAINED_SLOTS) != 0);
   bool sampled = false;  // the sampling rode on the final solve's launch
   // (the Mellinger pipeline takes the estimate as its start point itself: mrs_tg::NonlinearParams::estimate_wp)
   if (opt->estimate_times && opt->time_alloc_method != MRS_TG_TIME_ALLOC_MELLINGER)
@@ -1095,6 +1099,15 @@ static int solve_batch_impl(mrs_tg_ctx* ctx, int32_t n_paths, const int32_t* so,
         local.flags |= MRS_TG_FLAG_GENERAL_PATTERNS;
         break;
       }
+  }
+  if (!(local.flags & MRS_TG_FLAG_CONSTRAINED_SLOTS) && local.derivative_to_optimize == 4) {
+    // ... and an interior vertex with a constrained derivative slot (a stop_at waypoint) the instantiations that take it
+    for (int32_t p = 0; p < n_paths && !(local.flags & MRS_TG_FLAG_CONSTRAINED_SLOTS); ++p)
+      for (size_t v = (size_t)so[p] + p + 1; v < (size_t)so[p + 1] + p; ++v)
+        if (mask[v * 5 + 1] | mask[v * 5 + 2] | mask[v * 5 + 3] | mask[v * 5 + 4]) {
+          local.flags |= MRS_TG_FLAG_CONSTRAINED_SLOTS;
+          break;
+        }
   }
   // zero copy: one pass over every array (fixed times, default solve) and every array the caller passed is pinned
   bool zero_copy = zero_copy_allowed && local.time_alloc_method == MRS_TG_TIME_ALLOC_NONE && !local.estimate_times &&

@@ -21,6 +21,10 @@ struct KernelTimer {
 // launch shapes that leave wavefront slots free are preferred over the lowest latency of this launch alone.
 void set_shared_device_hint(bool on);
 bool shared_device_hint();
+// Hint of the calling thread's current ABI call (MRS_TG_FLAG_CONSTRAINED_SLOTS): the batch may hold vertices with constrained
+// derivative slots beside its paths' ends; min-snap launches then use the instantiations that take such vertices
+void set_constrained_slots_hint(bool on);
+bool constrained_slots_hint();
 KernelTimer take_kernel_timer();  // the pending pair (null events when nothing is pending); consumed by the call
 void set_kernel_timer(hipEvent_t start, hipEvent_t stop);  // arms the next timed launch of this thread
 // Kernel trace (mrs_tg_kernel_trace): every launch of the library notes its kernel's name in a small per-thread ring, so

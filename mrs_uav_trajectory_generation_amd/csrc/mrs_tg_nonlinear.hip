@@ -2171,7 +2171,10 @@ hipError_t launch_nonlinear(NonlinearPlan& nl, const BatchView& b, const Nonline
       if (plain_lds(bin) > 160 * 1024) wide = false;
   // objective orders below snap: the shared half sweeps with free end slots, every path in a group of S + 4 lanes at least
   // (MRS_TG_LEAN_SHARED=0: the one-sided masked sweeps of optimize_lean_masked_kernel, as until round 5)
-  bool ends_shared = lean_masked_order && prm.lean_shared != 0 && !nl.ends_bins.empty() && (int)nl.ends_bins.size() <= 5;
+  // (a min-snap launch whose caller says that interior vertices may hold constrained slots -- stop_at waypoints -- as well:
+  // MRS_TG_FLAG_CONSTRAINED_SLOTS)
+  bool ends_shared = (lean_masked_order || constrained_slots_hint()) && prm.lean_shared != 0 && !nl.ends_bins.empty() &&
+                     (int)nl.ends_bins.size() <= 5;
   if (ends_shared)
     for (const NonlinearBin& bin : nl.ends_bins)
       if (plain_lds(bin) > 160 * 1024) ends_shared = false;

@@ -121,6 +121,9 @@ static thread_local bool t_shared_device = false;
 
 void set_shared_device_hint(bool on) { t_shared_device = on; }
 bool shared_device_hint() { return t_shared_device; }
+static thread_local bool t_constrained_slots = false;
+void set_constrained_slots_hint(bool on) { t_constrained_slots = on; }
+bool constrained_slots_hint() { return t_constrained_slots; }
 
 
 void set_kernel_timer(hipEvent_t start, hipEvent_t stop) {

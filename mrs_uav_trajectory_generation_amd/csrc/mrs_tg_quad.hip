@@ -669,7 +669,8 @@ hipError_t launch_solve_quad(const BatchView& b, int d, const uint8_t* mask, con
   // objective orders below snap leave jerk and / or snap free at the end vertices of a rest-to-rest path: the instantiation
   // that eliminates such end vertices (two more records per path in LDS), while its LDS fits; MRS_TG_QUAD_ENDS=0: the general
   // step for those paths, as until round 5
-  const bool ends = quad_ends_allowed() && d < 4 && quad_lds_doubles(b.max_segments, true) * sizeof(double) <= kQuadLdsBudget;
+  const bool ends = quad_ends_allowed() && (d < 4 || constrained_slots_hint()) &&
+                    quad_lds_doubles(b.max_segments, true) * sizeof(double) <= kQuadLdsBudget;
   const size_t lds_bytes = quad_lds_doubles(b.max_segments, ends) * sizeof(double);
   const bool wp = tail.pos_wp != nullptr;
   const void* fn = ends ? (wp ? (const void*)solve_quad_kernel<true, true> : (const void*)solve_quad_kernel<false, true>)
@@ -696,7 +697,8 @@ hipError_t launch_solve_quad(const BatchView& b, int d, const uint8_t* mask, con
 
 hipError_t launch_solve_quad_group(const BatchView& b, int d, const RowsGroup& g, double* ws, hipStream_t stream) {
   if (g.n < 1 || g.n > kRowsGroupMax) return hipErrorInvalidValue;
-  const bool ends = quad_ends_allowed() && d < 4 && quad_lds_doubles(b.max_segments, true) * sizeof(double) <= kQuadLdsBudget;
+  const bool ends = quad_ends_allowed() && (d < 4 || constrained_slots_hint()) &&
+                    quad_lds_doubles(b.max_segments, true) * sizeof(double) <= kQuadLdsBudget;
   const size_t lds_bytes = quad_lds_doubles(b.max_segments, ends) * sizeof(double);
   bool wp = true;
   for (int j = 0; j < g.n; ++j) wp = wp && g.pos_wp[j] != nullptr;

@@ -273,13 +273,16 @@ def test_moving_starts_on_the_saturated_device_kernels(gpu_ctx, deriv, n_seg):
     assert util.continuity_defect(sub, cc, tc) < 1e-9 and util.constraint_defect(sub, cc, tc) < 1e-9
 
 
-@pytest.mark.parametrize("deriv,n_seg,every,moving", [(2, 10, 1, False), (3, 10, 2, False), (2, "ragged", 3, False), (2, 10, 2, True)])
+@pytest.mark.parametrize("deriv,n_seg,every,moving", [(2, 10, 1, False), (3, 10, 2, False), (2, "ragged", 3, False), (2, 10, 2, True),
+                                                      (4, 10, 2, False), (4, "ragged", 1, True)])
 def test_stop_at_vertices_below_snap_on_the_saturated_device_kernels(gpu_ctx, deriv, n_seg, every, moving):
     """stop_at waypoints (velocity = acceleration = jerk = 0 at an interior vertex, snap free;
     /root/reference/src/mrs_trajectory_generation.cpp:969-973) under the objective orders below snap: the free-end
     instantiations of the large batches' kernels eliminate such a vertex with the identity in its constrained slots (round 5;
     the general steps before).  Every `every`-th interior vertex is one; optionally from a moving state.  Fixed-times solve
-    and Mellinger pipeline against the oracle on a strided subset, invariants on more paths."""
+    and Mellinger pipeline against the oracle on a strided subset, invariants on more paths.  Under min-snap the same
+    instantiations run when the caller says so (MRS_TG_FLAG_CONSTRAINED_SLOTS) -- mrs_tg_solve_batch, which holds the masks in
+    host memory, says it by itself: the d = 4 cases."""
     n = 6400
     base = pr.random_batch(n, n_seg, seed0=9700, derivative_to_optimize=deriv)
     rng = np.random.default_rng(3)
