@@ -57,7 +57,7 @@ def measure(ctx, batch, nonlinear, reps):
     if nonlinear:
         # (MRS_TG_FLAG_POSITIONS_ARE_WAYPOINTS: these batches' position constraints are their waypoints, as in bench.py)
         opt = api.default_options(derivative_to_optimize=batch.derivative_to_optimize, time_alloc_method=api.TIME_ALLOC_MELLINGER, sampling_dt=0.2,
-                                  sample_capacity=512, flags=api.FLAG_POSITIONS_ARE_WAYPOINTS | (api.FLAG_CONSTRAINED_SLOTS if STOP else 0))
+                                  sample_capacity=512, flags=api.FLAG_POSITIONS_ARE_WAYPOINTS | (api.FLAG_CONSTRAINED_SLOTS if (STOP or os.environ.get('HINT')) else 0))
 
         def step():
             db.seg_times.copy_(t0)
