@@ -16,6 +16,9 @@
 #include <cmath>
 #include <cstdio>
 #include <cstring>
+#include <new>
+#include <stdexcept>
+#include <system_error>
 #include <thread>
 #include <vector>
 
@@ -171,11 +174,22 @@ void parallel_ranges(size_t n, size_t min_per_thread, F&& body) {  // body(begin
   std::vector<std::thread> pool;
   pool.reserve(threads - 1);
   const size_t chunk = (n + threads - 1) / threads;
+  size_t first_inline = threads;  // ranges [first_inline, threads) run on this thread: a thread that could not be started
   for (size_t t = 1; t < threads; ++t) {
     const size_t b = std::min(n, t * chunk), e = std::min(n, b + chunk);
-    if (b < e) pool.emplace_back([&body, b, e] { body(b, e); });
+    if (b >= e) continue;
+    try {
+      pool.emplace_back([&body, b, e] { body(b, e); });
+    } catch (const std::system_error&) {
+      first_inline = t;
+      break;
+    }
   }
   body((size_t)0, std::min(n, chunk));
+  for (size_t t = first_inline; t < threads; ++t) {
+    const size_t b = std::min(n, t * chunk), e = std::min(n, b + chunk);
+    if (b < e) body(b, e);
+  }
   for (std::thread& th : pool) th.join();
 }
 
@@ -339,11 +353,33 @@ void mrs_tg_default_policy_options(mrs_tg_policy_options* o) {
   o->max_execution_time_s = 0.0;
 }
 
+static int optimize_paths_impl(mrs_tg_ctx* ctx, int32_t n_paths, const int32_t* wp_offsets, const mrs_tg_waypoint* waypoints,
+                               const mrs_tg_initial_state* initial_states, const uint8_t* has_initial_state, const double* limits,
+                               const uint8_t* relax_heading, const mrs_tg_policy_options* opt, int32_t sample_capacity,
+                               int32_t* success_out, int32_t* n_samples_out, double* samples_out, double* max_deviation_out,
+                               int32_t* n_waypoints_out, int32_t* iterations_out);
+
 int mrs_tg_optimize_paths(mrs_tg_ctx* ctx, int32_t n_paths, const int32_t* wp_offsets, const mrs_tg_waypoint* waypoints,
                           const mrs_tg_initial_state* initial_states, const uint8_t* has_initial_state, const double* limits,
                           const uint8_t* relax_heading, const mrs_tg_policy_options* opt, int32_t sample_capacity,
                           int32_t* success_out, int32_t* n_samples_out, double* samples_out, double* max_deviation_out,
                           int32_t* n_waypoints_out, int32_t* iterations_out) {
+  try {  // (host containers sized by the batch: nothing crosses the C boundary)
+    return optimize_paths_impl(ctx, n_paths, wp_offsets, waypoints, initial_states, has_initial_state, limits, relax_heading, opt,
+                               sample_capacity, success_out, n_samples_out, samples_out, max_deviation_out, n_waypoints_out,
+                               iterations_out);
+  } catch (const std::bad_alloc&) {
+    return mrs_tg::report_error(ctx, MRS_TG_ERR_NOMEM, "out of host memory for %d requests of up to %d samples", n_paths, sample_capacity);
+  } catch (const std::exception& ex) {
+    return mrs_tg::report_error(ctx, MRS_TG_ERR_HIP, "mrs_tg_optimize_paths: %s", ex.what());
+  }
+}
+
+static int optimize_paths_impl(mrs_tg_ctx* ctx, int32_t n_paths, const int32_t* wp_offsets, const mrs_tg_waypoint* waypoints,
+                               const mrs_tg_initial_state* initial_states, const uint8_t* has_initial_state, const double* limits,
+                               const uint8_t* relax_heading, const mrs_tg_policy_options* opt, int32_t sample_capacity,
+                               int32_t* success_out, int32_t* n_samples_out, double* samples_out, double* max_deviation_out,
+                               int32_t* n_waypoints_out, int32_t* iterations_out) {
   if (!ctx) return mrs_tg::report_error(nullptr, MRS_TG_ERR_INVALID_ARG, "ctx is NULL");
   if (!wp_offsets || !waypoints || !limits || !opt || !success_out || !n_samples_out || !samples_out)
     return mrs_tg::report_error(ctx, MRS_TG_ERR_INVALID_ARG,
