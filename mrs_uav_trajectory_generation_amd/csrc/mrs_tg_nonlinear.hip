@@ -566,19 +566,22 @@ __device__ __forceinline__ double evaluate_lean(const double* tabs, const double
 // the terms of f -- right-hand side of vertex 1: - sum_c E[c][r] f_c T^(r+c+2-2d); of vertex 0's own free slots (ENDS):
 // - sum_c N[r][c] f_c T^(r+c+2-2d); f^T H f: sum_c 2 f_c N0[c] dp T^(c+1-2d) + sum_cc' f_c N[c][c'] f_c' T^(c+c'+2-2d) -- as
 // FastStep::start_state has them (mrs_tg_sweep.hpp), from the table entries instead of staged products.
-template <bool ENDS, bool MOVING = false>
-__device__ __forceinline__ double evaluate_lean_shared(const double* tabs, const double* ev, double* pub, int S, int Sb, int d,
-                                                       const double* pt, double* grad, int g, int G, bool active, int* tripped) {
+// One pass: lane `g` of the group runs the half sweep of VIRTUAL lane gv (the numbering above); `j0_lane` = the wavefront lane that
+// holds virtual lane 0 in this pass, or have_j0: the cost of x comes from an earlier pass (j0_in).
+template <bool ENDS, bool MOVING>
+__device__ __forceinline__ double evaluate_lean_shared_pass(const double* tabs, const double* ev, double* pub, int S, int Sb, int d,
+                                                            const double* pt, double* grad, int gv, bool active, int* tripped,
+                                                            int j0_lane, bool have_j0, double j0_in) {
   static_assert(!(ENDS && MRS_TG_LEAN_CONST_TABLE), "the compile-time table is the order-4 one");
   const double* mv = pub + kLeanPub;
   const bool moving = MOVING && mv[0] != 0.0;
   const double* dp = ev;
   const double* qs = ev + 4 * (size_t)Sb + 2;  // HBAR[0][0] |dp_i|^2 per segment (stage_ps)
   const int m = S >> 1, nL = m + 2;
-  const bool left = g < nL;
-  const int r = left ? g : g - nL;
+  const bool left = gv < nL;
+  const int r = left ? gv : gv - nL;
   const int nhalf = left ? m : S - m;
-  const bool valid = active && g < S + 4;
+  const bool valid = active && gv < S + 4;
   const bool pure = r == nhalf + 1, base = r == 0;
   const int k = base ? 0 : pure ? (left ? S : 1) : (left ? r : m + r);
   const double corr = kGradStep / ((double)S - 1.0);
@@ -826,8 +829,38 @@ __device__ __forceinline__ double evaluate_lean_shared(const double* tabs, const
   ps_wave_sync();  // (the area is written again by the next evaluation)
   Jk = guarded_cost(Jk, qfk, k == 0);
   if (tripped && join && Jk == kUnreliableCost) *tripped = 1;
-  const double J0 = __shfl(Jk, (int)(threadIdx.x & ~(unsigned)(G - 1)), 64);  // lane 0 of the group: x, joined
+  const double J0 = have_j0 ? j0_in : __shfl(Jk, j0_lane, 64);  // virtual lane 0: x, joined
   if (join && k >= 1) grad[k - 1] = (Jk - J0) / kGradStep;
+  return J0;
+}
+
+
+// The evaluation of one path.  S + 4 <= G: one pass, lane g = virtual lane g.  A path of 61 .. 121 segments has more half sweeps
+// than a wavefront has lanes (G = 64, one path per wavefront): TWO passes, each of which runs the three half sweeps that more
+// than one vector needs (virtual lanes m + 1, m + 2 and S + 3: their lanes publish them again -- three lanes of 64) next to
+// half of the other S + 1, so that every pass is complete in itself: S steps per evaluation where the one-sided sweeps of such
+// a path need 2 S (one 80-segment request 0.79 -> ms, round 5).
+// TWOPASS is a template parameter: the loop around the pass, even with one iteration, cost the min-snap kernel of the benchmark
+// configs 512 bytes of scratch per lane (16 -> 528); launches without such paths run the instantiations without it.
+template <bool ENDS, bool MOVING = false, bool TWOPASS = false>
+__device__ __forceinline__ double evaluate_lean_shared(const double* tabs, const double* ev, double* pub, int S, int Sb, int d,
+                                                       const double* pt, double* grad, int g, int G, bool active, int* tripped) {
+  const int lane0 = (int)(threadIdx.x & ~(unsigned)(G - 1));  // lane 0 of the group
+  if (!TWOPASS)
+    return evaluate_lean_shared_pass<ENDS, MOVING>(tabs, ev, pub, S, Sb, d, pt, grad, g, active, tripped, lane0, false, 0.0);
+  const bool two = G == 64 && __builtin_amdgcn_readfirstlane(S + 4 > G ? 1 : 0) != 0;  // (wave-uniform: one path per wavefront)
+  const int m = S >> 1;
+  double J0 = 0.0;
+  for (int pass = 0; pass < (two ? 2 : 1); ++pass) {
+    // two passes -- lanes 0 .. 2: the publishers; lane 3 + o: the o-th of the other virtual lanes ([0, m] and [m + 3, S + 2]),
+    // 61 per pass
+    const int o = g - 3 + pass * 61;
+    const int gv = !two ? g : (g == 0 ? m + 1 : g == 1 ? m + 2 : g == 2 ? S + 3 : (o <= m ? o : o + 2));
+    const bool on = !two || g < 3 || o <= S;
+    const double J = evaluate_lean_shared_pass<ENDS, MOVING>(tabs, ev, pub, S, Sb, d, pt, grad, on ? gv : S + 4, active, tripped,
+                                                            two ? lane0 + 3 : lane0, pass == 1, J0);
+    if (pass == 0) J0 = J;
+  }
   return J0;
 }
 
@@ -848,7 +881,7 @@ __device__ __forceinline__ bool stage_ps(const uint8_t* __restrict__ mask, const
   double* dp = ev;
   double* tmp = ev + 4 * (size_t)Sb;  // the record area, not in use yet
   int ok = (S >= min_segments) ? 1 : 0;
-  unsigned fb_first = 0u, fb_last = 0u, my_fb = 0xFu;
+  unsigned fb_first = 0u, fb_last = 0u, my_fb = 0xFu, my_fb2 = 0xFu;  // (my_fb, my_fb2: of vertex g and of vertex g + G)
   if (active)
     for (int v = g; v <= S; v += G) {
       double f[kHalf][kD];
@@ -863,7 +896,8 @@ __device__ __forceinline__ bool stage_ps(const uint8_t* __restrict__ mask, const
       // (interior_masks: interior vertices may hold slots constrained to zero as well -- stop_at vertices: velocity =
       // acceleration = jerk = 0, snap free; every vertex's free mask goes behind the f^T H f terms, tmp[2 + Sb + v])
       const bool pattern_ok = end ? (end_masks || fb == 0u) : (interior_masks || fb == 0xFu);
-      my_fb = fb;  // (a group is at least S + 1 lanes wide: a lane loads at most one vertex)
+      if (v == g) my_fb = fb;  // (a path has at most 2 G vertices where the masks are used: a lane loads at most two)
+      else my_fb2 = fb;
       if (v == 0 && moving != nullptr) {  // (load_vertex has zeroed the values of unconstrained slots)
         moving[0] = nz;
 #pragma unroll
@@ -889,6 +923,7 @@ __device__ __forceinline__ bool stage_ps(const uint8_t* __restrict__ mask, const
     if (g == 0) tmp[0] = (double)fb_first;
     if (g == (S & (G - 1))) tmp[1] = (double)fb_last;  // the lane that loaded vertex S
     if (g <= S) tmp[2 + Sb + g] = (double)my_fb;       // every vertex's free mask (interior: 0xF unless it is a stop_at vertex)
+    if (g + G <= S) tmp[2 + Sb + g + G] = (double)my_fb2;
   }
   if (active) {  // f^T HBAR f of every segment (position terms only: all a plain path has), behind the two mask slots
     const double h00 = c_hbar[d][0][0];
@@ -935,7 +970,8 @@ struct BinTable {
 // LEANSHARED (optimize_lean_shared_kernel, with LEAN): every bin of the launch holds paths of 4 <= S <= G - 4 segments only (the
 // host checks), so evaluate_lean_shared is the ONLY evaluation compiled in -- next to the one-sided sweeps it costs both their
 // registers (124 instead of 28 bytes of scratch).
-template <int DS, bool MASKED4 = false, bool CAREFUL = false, bool LEAN = false, bool GENERAL = false, bool LEANSHARED = false>
+template <int DS, bool MASKED4 = false, bool CAREFUL = false, bool LEAN = false, bool GENERAL = false, bool LEANSHARED = false,
+          bool TWOPASS = false>
 __device__ __forceinline__ void optimize_body(const BatchView& b, const NonlinearParams& prm, const BinTable& bins,
                                               const uint8_t* __restrict__ mask, const double* __restrict__ vals,
                                               double* __restrict__ seg_times, int32_t* __restrict__ opt_status,
@@ -1216,7 +1252,7 @@ __device__ __forceinline__ void optimize_body(const BatchView& b, const Nonlinea
       // shared half sweeps when every path of the wavefront takes them (plain paths of 4 <= S <= G - 4 segments: S + 4 lanes)
       const bool shared_path = S >= 4 && S + 4 <= G;
       if (LEANSHARED)
-        fn = evaluate_lean_shared<MASKED4, true>(hc, vtx, vtx + 4 * (size_t)Sb + 4 * ((size_t)Sb + 1), S, Sb, d, xn, gn, g, G, !done, tick_i + 4);
+        fn = evaluate_lean_shared<MASKED4, true, TWOPASS>(hc, vtx, vtx + 4 * (size_t)Sb + 4 * ((size_t)Sb + 1), S, Sb, d, xn, gn, g, G, !done, tick_i + 4);
       else if (!MASKED4 && prm.lean_shared == 2 && __ballot(!done && !shared_path) == 0ull)
         fn = evaluate_lean_shared<false, false>(hc, vtx, vtx + 4 * (size_t)Sb + 4 * ((size_t)Sb + 1), S, Sb, d, xn, gn, g, G, !done, tick_i + 4);
       else
@@ -1637,6 +1673,16 @@ __global__ __launch_bounds__(64, MRS_TG_LEAN_WAVES) void optimize_lean_shared_ke
   optimize_body<1, false, false, true, false, true>(b, prm, bins, mask, vals, seg_times, opt_status, nullptr, fallback);
 }
 
+// ... with paths of 61 .. 121 segments in the launch: two passes of the shared evaluation per wavefront (see there).  Min-snap
+// launches with such paths run this instantiation too (its table is the run-time order's): the min-snap body with the loop of
+// passes around it needs 528 bytes of scratch per lane and is slower than this one
+__global__ __launch_bounds__(64, MRS_TG_LEAN_WAVES) void optimize_lean_shared_ends_long_kernel(BatchView b, NonlinearParams prm, BinTable bins,
+                                                              const uint8_t* __restrict__ mask, const double* __restrict__ vals,
+                                                              double* __restrict__ seg_times, int32_t* __restrict__ opt_status,
+                                                              int32_t* __restrict__ fallback) {
+  optimize_body<1, true, false, true, false, true, true>(b, prm, bins, mask, vals, seg_times, opt_status, nullptr, fallback);
+}
+
 // shared half sweeps with free slots at the end vertices (objective orders below snap; evaluate_lean_shared<true>): every bin
 // in groups of at least S + 4 lanes
 __global__ __launch_bounds__(64, MRS_TG_LEAN_WAVES) void optimize_lean_shared_ends_kernel(BatchView b, NonlinearParams prm, BinTable bins,
@@ -1907,6 +1953,7 @@ static int group_for_wide(int S) {
   return G;
 }
 
+constexpr int kLeanTwoPassMaxS = 121;  // evaluate_lean_shared: 3 publishers + 61 other virtual lanes per pass, two passes
 // lanes per path when EVERY path of kEndsMinSegments or more segments gets its S + 4 lanes (0: no group is wide enough).
 // Two segments are enough for the shared half sweeps (one step per half); handing the 2- and 3-segment paths of a ragged
 // batch to the sweeping kernel BEHIND the launch instead cost 8192 ragged paths 0.67 instead of 0.58 ms (d = 2).
@@ -1917,7 +1964,7 @@ static const int kEndsMinSegments = [] {
 }();
 static int group_for_ends(int S) {
   if (S < kEndsMinSegments) return group_for(S, 1);
-  if (S + 4 > 64) return 0;
+  if (S + 4 > 64) return S <= kLeanTwoPassMaxS ? 64 : 0;  // a wavefront per path, two passes of the shared evaluation
   int G = 8;
   while (G < S + 4) G <<= 1;
   return G;
@@ -2231,14 +2278,23 @@ hipError_t launch_nonlinear(NonlinearPlan& nl, const BatchView& b, const Nonline
     // 66 us on 8192 ragged paths, profiles/round5_wide_groups_ab.txt)
     bool lean_shared_only = prm.lean_shared != 0 && !lean_masked;
     for (const NonlinearBin& bin : lean_bins)  // (a bin of one-segment paths: the kernel leaves them to the sweeping kernel behind it)
-      if (bin.max_S >= 2 && (bin.min_S < 2 || bin.max_S + 4 > bin.group)) lean_shared_only = false;
+      if (bin.max_S >= 2 && (bin.min_S < 2 || (bin.max_S + 4 > bin.group && !(bin.group == 64 && bin.max_S <= kLeanTwoPassMaxS))))
+        lean_shared_only = false;
+    bool long_paths = false;  // a bin whose paths have more half sweeps than a wavefront has lanes: the two-pass instantiations
+    for (const NonlinearBin& bin : lean_bins)
+      if (bin.max_S + 4 > bin.group && bin.group == 64) long_paths = true;
+    const bool ends_long = long_paths && (ends_shared || lean_shared_only);
     if (plds > 64 * 1024 &&
-        (e = hipFuncSetAttribute(ends_shared ? (const void*)optimize_lean_shared_ends_kernel
+        (e = hipFuncSetAttribute(ends_long ? (const void*)optimize_lean_shared_ends_long_kernel
+                                 : ends_shared ? (const void*)optimize_lean_shared_ends_kernel
                                  : lean_masked ? (const void*)optimize_lean_masked_kernel
                                  : lean_shared_only ? (const void*)optimize_lean_shared_kernel : (const void*)optimize_lean_kernel,
                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)plds)) != hipSuccess)
       return e;
-    if (ends_shared)
+    if (ends_long)
+      MRS_TG_LAUNCH_EXT(optimize_lean_shared_ends_long_kernel, dim3(blocks), dim3(64), plds, stream, kt.start, nullptr, 0, b, prm, bt,
+                            mask, vals, seg_times, nl.d_opt_status, nl.d_fallback);
+    else if (ends_shared)
       MRS_TG_LAUNCH_EXT(optimize_lean_shared_ends_kernel, dim3(blocks), dim3(64), plds, stream, kt.start, nullptr, 0, b, prm, bt,
                             mask, vals, seg_times, nl.d_opt_status, nl.d_fallback);
     else if (lean_masked)

@@ -333,3 +333,35 @@ def test_stop_at_vertices_below_snap_on_the_saturated_device_kernels(gpu_ctx, de
     tc = np.concatenate([out["times"][so[p]:so[p + 1]] for p in chk])
     cc = np.concatenate([out["coeffs"][so[p]:so[p + 1]] for p in chk])
     assert util.continuity_defect(sub, cc, tc) < 1e-9 and util.constraint_defect(sub, cc, tc) < 1e-9
+
+
+@pytest.mark.parametrize("deriv,n_seg,n_paths,moving", [(4, 80, 300, False), (2, 100, 200, True), (2, 61, 64, False), (3, 121, 40, False),
+                                                        (4, 64, 100, True)])
+def test_paths_of_61_to_121_segments_run_the_shared_half_sweeps_in_two_passes(gpu_ctx, deriv, n_seg, n_paths, moving):
+    """A path of more than 60 segments has more half sweeps (S + 4) than a wavefront has lanes: two passes of the shared
+    evaluation (each with the three published half sweeps and half of the others) instead of the one-sided sweeps -- what the
+    policy layer's subdivision rounds produce all the time (a third of its requests end above 60 waypoints).  Against the
+    oracle, every path."""
+    batch = pr.random_batch(n_paths, n_seg, seed0=9900, derivative_to_optimize=deriv)
+    if moving:
+        batch = _moving(batch, seed=9)
+    api.kernel_trace_reset()
+    out = gpu_ctx.solve_batch(batch, None, time_alloc_method=api.TIME_ALLOC_MELLINGER, sampling_dt=0.2, sample_capacity=2048)
+    trace = api.kernel_trace()
+    assert "optimize_lean_shared_ends_long_kernel" in trace, trace   # (every objective order: its table is the run-time order's)
+    idx = list(range(0, n_paths, max(1, n_paths // 48)))
+    sub = batch.select(idx)
+    ref = po.solve_batch(sub.seg_offsets, sub.waypoints, sub.fixed_mask, sub.fixed_values, sub.limits, np.zeros(sub.n_segments),
+                         deriv=deriv, time_alloc_method=2, estimate_times=True, sampling_dt=0.2, sample_capacity=2048, n_threads=8)
+    so = batch.seg_offsets
+    good = 0
+    for k, p in enumerate(idx):
+        a, b = sub.seg_offsets[k], sub.seg_offsets[k + 1]
+        t = out["times"][so[p]:so[p + 1]]
+        if util.status_matches(out["status"][p], ref["status"][k]) and np.max(np.abs(t - ref["times"][a:b]) / ref["times"][a:b]) < 1e-6 \
+                and util.coeff_error(out["coeffs"][so[p]:so[p + 1]], ref["coeffs"][a:b]) < 1e-6:
+            good += 1
+    print("RATE two passes d=%d S=%d moving %s: %d / %d" % (deriv, n_seg, moving, good, len(idx)))
+    assert good >= len(idx) - 2, (good, len(idx))
+    assert util.continuity_defect(batch, out["coeffs"], out["times"]) < 1e-9
+    assert util.constraint_defect(batch, out["coeffs"], out["times"]) < 1e-9
