@@ -1946,7 +1946,9 @@ static int group_for(int S, int ds) {
 
 // lanes per path when the long paths get the S + 4 lanes of the shared half sweeps: 13-15 and 29-30 segments move to the next
 // group width.  (5-7 segments stay in groups of 8 and their one-sided sweeps: six steps against four do not pay for half
-// the paths per wavefront -- 8192 x 6: 0.190 ms narrow, 0.197 ms wide; 65536 x 6: 0.861 vs 1.015 ms.)
+// the paths per wavefront -- 8192 x 6: 0.190 ms narrow, 0.197 ms wide; 65536 x 6: 0.861 vs 1.015 ms.)  These bins decide
+// WHETHER a launch is small enough for wide groups (wide_blocks) and are what MRS_TG_LEAN_WIDE_ALL=0 launches; by default
+// such a launch uses the bins of group_for_ends below (every path of two or more segments in S + 4 lanes: launch_nonlinear)
 static int group_for_wide(int S) {
   int G = group_for(S, 1);
   if (S >= 13 && G < S + 4 && G < 64) G <<= 1;
