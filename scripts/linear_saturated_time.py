@@ -1,3 +1,6 @@
+#!/usr/bin/env python3
+"""Back-to-back time of the bound fixed-times solve at 65536 x 10 and 8192 x 10 (solve_quad_kernel from the value array and from
+the waypoint array): the same-box A / B of a library against another one (MRS_TG_LIB_PATH=<other libmrs_tg.so>)."""
 import sys, time, os
 sys.path.insert(0, os.getcwd())
 import torch
