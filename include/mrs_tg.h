@@ -431,7 +431,10 @@ void mrs_tg_default_policy_options(mrs_tg_policy_options* opt);
  *   has_initial_state[p] != 0 (then initial_states[p] supplies the derivatives, :946-957).
  *   limits [n_paths][9]; relax_heading [n_paths] or NULL.
  *   samples_out [n_paths][sample_capacity][4] (x, y, z, heading); a path needing more samples fails.
- *   success_out [n_paths] 1/0; max_deviation_out, n_waypoints_out (after subdivision), iterations_out may be NULL. */
+ *   success_out [n_paths] 1/0; max_deviation_out, n_waypoints_out (after subdivision), iterations_out may be NULL.
+ * Batches of requests: the arrays of a round live in one block of PINNED host memory kept by the context until it is
+ * destroyed (about n_paths x sample_capacity x 32 bytes x 1.25 for the largest batch seen; ordinary memory when the runtime
+ * refuses it), and the per-path host work runs on up to 16 threads from a few hundred requests on (MRS_TG_POLICY_THREADS). */
 int mrs_tg_optimize_paths(mrs_tg_ctx* ctx, int32_t n_paths, const int32_t* wp_offsets, const mrs_tg_waypoint* waypoints,
                           const mrs_tg_initial_state* initial_states, const uint8_t* has_initial_state, const double* limits,
                           const uint8_t* relax_heading, const mrs_tg_policy_options* opt, int32_t sample_capacity,
