@@ -720,7 +720,11 @@ bool rows_pipeline_applies(const BatchView& b) {
   }();
   // up to one solving wavefront per SIMD (its helper shares the SIMD of another path's solver): 1024 x 10 pipeline 106.6 ->
   // 101.0 us; at 2048 paths two solvers share every SIMD and the separate launches win (153 vs 169 us)
-  return on && b.n_paths > 0 && b.n_paths <= 1024 && rows_lds_bytes(b.max_segments, 1, true, true) <= kRowsLdsBudget;
+  // (long paths: the separate launches again -- one 80-segment request 0.399 -> 0.379 ms, 64 x 80 0.706 -> 0.682, 48 / 49 segments
+  // on either side of a first threshold 0.182 / 0.176, equal at 30
+  // segments; the results are the same bits either way, tests/test_gpu_pipeline_shortcuts.py)
+  return on && b.n_paths > 0 && b.n_paths <= 1024 && b.max_segments <= 32 &&
+         rows_lds_bytes(b.max_segments, 1, true, true) <= kRowsLdsBudget;
 }
 
 hipError_t launch_solve_rows(const BatchView& b, int d, const uint8_t* mask, const double* vals, const double* seg_times,
