@@ -93,3 +93,17 @@ int main() {
     else:
         # no device: the constructor throws the library's loud error, nothing falls back to the CPU
         assert r.returncode == 3 and "no CPU fallback" in r.stdout, r.stdout + r.stderr
+
+
+def test_python_constants_are_the_headers():
+    """every MRS_TG_FLAG_* / MRS_TG_CAP_* / MRS_TG_ERR_* / MRS_TG_TIME_ALLOC_* of include/mrs_tg.h has the same value in the
+    ctypes mirror (api.py) -- a flag added on one side only would silently be another option"""
+    import re
+    from mrs_uav_trajectory_generation_amd import api
+    text = open(os.path.join(ROOT, "include", "mrs_tg.h")).read()
+    seen = 0
+    for name, value in re.findall(r"\bMRS_TG_((?:FLAG|CAP|TIME_ALLOC)_[A-Z0-9_]+)\s*=\s*(-?\d+)", text):
+        assert hasattr(api, name), name
+        assert getattr(api, name) == int(value), (name, getattr(api, name), value)
+        seen += 1
+    assert seen >= 10, seen
