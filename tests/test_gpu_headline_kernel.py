@@ -274,3 +274,41 @@ def test_grouped_dispatch_below_snap_takes_the_free_end_instantiation(gpu_ctx, d
     assert e_q < 1e-10 and e_d < TOL_ORACLE_SHORT_SEGMENT, (e_q, e_d)   # (measured 1.4e-13 and 1.6e-12 vs the 113-bit route)
     assert np.max(np.abs(cost_single[idx] - ref_q["cost"]) / np.abs(ref_q["cost"])) < 1e-8
     plan.close()
+
+
+def test_saturated_device_solve_against_the_60_digit_fixtures(gpu_ctx):
+    """Every fixture of tests/golden/linear_qp_cases.json -- min-snap paths, the mixed constraint patterns (moving start, stop_at
+    vertices) under d = 2, 3, 4, the rest-to-rest paths below snap -- replicated 6400 times, so that the launch runs
+    solve_quad_kernel (plain, with free slots, with a moving start: the trace says which): every replica gives the same bits,
+    and those agree with the 60-DIGIT solution as the rows kernel's do in tests/test_gpu_linear.py."""
+    import json
+    import os
+    golden = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "linear_qp_cases.json")))
+    n = 6400
+    seen = set()
+    for case in golden["cases"]:
+        one, t1 = util.case_batch(case)
+        if one.n_segments > 15 or one.n_segments < 2:
+            continue            # (the quad kernel's LDS record holds up to 15 segments; a one-segment path has no unknowns)
+        wp, m, v = one.path(0)
+        batch = pr.assemble_batch([(wp, m, v)] * n, np.tile(one.limits, (n, 1)), one.derivative_to_optimize)
+        t = np.tile(t1, n)
+        api.kernel_trace_reset()
+        out = gpu_ctx.solve_batch(batch, t)
+        kern = [k for k in api.kernel_trace() if k.startswith("solve_quad_kernel")]
+        assert kern, (case["name"], api.kernel_trace())
+        seen.add(kern[-1])
+        assert np.all(out["status"] == 1), case["name"]
+        c = out["coeffs"].reshape(n, -1)
+        assert np.all(c == c[0]), case["name"]               # 400 wavefronts, one answer
+        exact = np.array(case["coeffs"])
+        err = util.coeff_error(out["coeffs"][:one.n_segments], exact)
+        oc = po.solve_linear(case["derivative_to_optimize"], one.fixed_mask, one.fixed_values, t1)
+        err_oracle = util.coeff_error(oc, exact)
+        print("FIXTURE %-36s %-30s HIP %.1e  oracle %.1e" % (case["name"], kern[-1], err, err_oracle))
+        short = "short" in case["name"]
+        assert err < (1e-7 if short else 1e-9), (case["name"], err)
+        if short:   # (measured: 6.9e-9 against the oracle's 2.5e-8 on path 74, 4.8e-8 against 5.4e-7 on slot 15's path 237)
+            assert err < 0.5 * err_oracle, (case["name"], err, err_oracle)
+        assert abs(out["cost"][0] - case["cost"]) <= (1e-8 if short else 1e-9) * abs(case["cost"]), case["name"]
+    assert {"solve_quad_kernel<false>", "solve_quad_kernel<false, true>"} <= seen, seen
