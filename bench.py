@@ -68,6 +68,9 @@ def parse_args(argv=None):
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--regions", type=int, default=9,
+                    help="timed regions of --steps steps each (barrier + synchronize on both sides of every one): `value` is "
+                         "the MEDIAN region's throughput (BASELINE.md section 3: median of >= 5 repetitions)")
     ap.add_argument("--workload", choices=["linear", "nonlinear"], default="linear")
     ap.add_argument("--paths", type=int, default=1024, help="paths per GPU")
     ap.add_argument("--segments", type=int, default=10)
@@ -143,15 +146,18 @@ def self_launch(args, argv):
 
 LAST_OWN_ELAPSED = [0.0]
 LAST_OWN_GATHER = [0.0]
+LAST_OWN_REGIONS = [[0.0]]
 
 
-def time_steps(step_fn, steps, warmup, dist, torch, final_fn=None, block_fn=None, gather_inside=False):
-    """W untimed steps, then exactly K steps between barrier + synchronize pairs.  Every rank reads its own clock right after
-    its own synchronize (before the closing barrier, whose cost is a property of the collective library, not of the K steps);
-    the figure returned is the MAX over ranks.  final_fn, the job's closing gather, is timed on its own right behind the steps
-    (second return value, MAX over ranks; 0.0 without a collective) unless gather_inside, where it belongs to the timed
-    region (configs[3]: the fixed batch is not done before rank 0 holds the results).  block_fn(n), when given, issues n
-    steps (the host's issue loop in C, mrs_tg_bound_solve_launch_many) and replaces n calls of step_fn."""
+def time_regions(step_fn, steps, warmup, dist, torch, regions=1, final_fn=None, block_fn=None, gather_inside=False):
+    """W untimed steps, then `regions` timed regions of exactly K steps each, every region between its own barrier +
+    synchronize pairs ("steady-state median of >= 5 repetitions after 1 warm-up").  Every rank reads its
+    own clock right after its own synchronize (before the closing barrier, whose cost is a property of the collective library,
+    not of the K steps); the figures returned are, per region, the MAX over ranks.  final_fn, the job's closing gather, is
+    timed on its own right behind the LAST region's steps (second return value, MAX over ranks; 0.0 without a collective)
+    unless gather_inside, where it belongs to every timed region (configs[3]: the fixed batch is not done before rank 0
+    holds the results).  block_fn(n), when given, issues n steps (the host's issue loop in C,
+    mrs_tg_bound_solve_launch_many) and replaces n calls of step_fn.  Returns ([elapsed per region], gather_s)."""
     if block_fn is not None:
         def run(n):
             if n > 0:
@@ -163,21 +169,24 @@ def time_steps(step_fn, steps, warmup, dist, torch, final_fn=None, block_fn=None
     run(warmup)
     if final_fn is not None:
         final_fn()          # warm the collective up as well (communicator set-up is not part of a step)
-    torch.cuda.synchronize()
-    if dist is not None:
-        dist.barrier()
-    torch.cuda.synchronize()
+    own = []
     gc_was_on = gc.isenabled()
     gc.disable()            # (a collection inside a 60 us region would be the measurement)
-    t0 = time.perf_counter()
-    run(steps)
-    if gather_inside and final_fn is not None:
-        final_fn()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
+    for _ in range(max(1, regions)):
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        run(steps)
+        if gather_inside and final_fn is not None:
+            final_fn()
+        torch.cuda.synchronize()
+        own.append(time.perf_counter() - t0)
     if gc_was_on:
         gc.enable()
-    LAST_OWN_ELAPSED[0] = elapsed   # this rank's own figure, before the MAX over ranks
+    LAST_OWN_REGIONS[0] = list(own)   # this rank's own figures, before the MAX over ranks
+    LAST_OWN_ELAPSED[0] = own[0]
     gather_s = 0.0
     if final_fn is not None and not gather_inside and dist is not None:
         t1 = time.perf_counter()
@@ -188,12 +197,22 @@ def time_steps(step_fn, steps, warmup, dist, torch, final_fn=None, block_fn=None
     if dist is not None:
         dist.barrier()
         torch.cuda.synchronize()
-        t = torch.tensor([elapsed, gather_s], dtype=torch.float64, device="cuda")
-        if dist.get_backend() == "gloo":
-            t = t.cpu()
+        t = torch.tensor(own + [gather_s], dtype=torch.float64, device="cpu" if dist.get_backend() == "gloo" else "cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed, gather_s = float(t[0].item()), float(t[1].item())
-    return elapsed, gather_s
+        own, gather_s = [float(v) for v in t[:-1].tolist()], float(t[-1].item())
+    return own, gather_s
+
+
+def time_steps(step_fn, steps, warmup, dist, torch, final_fn=None, block_fn=None, gather_inside=False):
+    """one timed region of K steps (the secondary measurements): (elapsed, gather_s) of time_regions(..., regions=1)"""
+    own, gather_s = time_regions(step_fn, steps, warmup, dist, torch, 1, final_fn, block_fn, gather_inside)
+    return own[0], gather_s
+
+
+def median_of(values):
+    """the median as a value that was measured (the upper of the two middle ones for an even count)"""
+    v = sorted(values)
+    return v[len(v) // 2]
 
 
 def dispatch_stats(ctx, kernel_id, launch_fn, reps, torch):
@@ -576,11 +595,15 @@ def main():
         torch.cuda.synchronize()
     step_no[0] = 0
 
-    elapsed, gather_s = time_steps(steps_fn[args.workload], args.steps, args.warmup, dist, torch, final_gather,
-                                   block_fn=block_for(args.workload))
+    # R regions of K steps each, every one between its own barrier + synchronize pairs; the line's figure is the MEDIAN region
+    # (one 20-step region of the fixed-times workload is 60-80 us: a single one measures the moment, not the kernel)
+    region_s, gather_s = time_regions(steps_fn[args.workload], args.steps, args.warmup, dist, torch, max(1, args.regions),
+                                      final_gather, block_fn=block_for(args.workload))
     total_paths = P * world * args.steps
+    elapsed = median_of(region_s)
     value = total_paths / elapsed
-    own_elapsed_main = LAST_OWN_ELAPSED[0]   # this rank's own timed region (later measurements overwrite the global)
+    own_regions_main = list(LAST_OWN_REGIONS[0])   # this rank's own regions (later measurements overwrite the global)
+    own_elapsed_main = median_of(own_regions_main)
     # what every rank saw, so that a first multi-GPU curve can be read from the line alone: its own K-step time, the device it
     # ran on, and whether the dmabuf IPC mode the pool's driver needs was set in its environment
     props = torch.cuda.get_device_properties(dev)
@@ -806,12 +829,15 @@ def main():
         for _ in range(3):
             plan_big.assemble(4, t_big, Hb, Ab)
         torch.cuda.synchronize()
-        m_big, _, _ = dispatch_stats(ctx, api.KERNEL_ASSEMBLE, lambda: plan_big.assemble(4, t_big, Hb, Ab), 20, torch)
+        m_big, med_big, min_big = dispatch_stats(ctx, api.KERNEL_ASSEMBLE, lambda: plan_big.assemble(4, t_big, Hb, Ab), 20, torch)
         bytes_big = ASSEMBLY_BYTES_PER_SEGMENT * big_P * args.segments
         extras["roofline_large"] = dict(kernel="assemble_blocks_uniform_kernel", paths=big_P, bytes_per_launch=bytes_big,
-                                        avg_launch_us=m_big * 1e3, achieved=bytes_big / (m_big * 1e-3) / 1e9,
-                                        unit="GB/s", frac=bytes_big / (m_big * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                                        timing="per dispatch, 20 queued launches")
+                                        avg_launch_us=m_big * 1e3, median_launch_us=med_big * 1e3, min_launch_us=min_big * 1e3,
+                                        achieved=bytes_big / (med_big * 1e-3) / 1e9,
+                                        unit="GB/s", frac=bytes_big / (med_big * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                        frac_of_min_launch=bytes_big / (min_big * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                        frac_of_mean_launch=bytes_big / (m_big * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                        timing="per dispatch, 20 queued launches: achieved / frac from the MEDIAN launch")
         del Hb, Ab
         plan_big.close()
         # PCIe-inclusive rate of the one-call host interface (H2D + kernels + D2H; the plan and the context's transfer arenas
@@ -1213,10 +1239,15 @@ def main():
         line = dict(metric="trajectories/sec (batch of N-seg min-snap paths)", value=value, unit="trajectories/s",
                     n_gpus=world, ranks_seen=ranks_seen, steps=args.steps, warmup=args.warmup,
                     ms_per_step=elapsed / args.steps * 1e3,
+                    regions=len(region_s), ms_per_step_min=min(region_s) / args.steps * 1e3,
+                    ms_per_step_median=elapsed / args.steps * 1e3, ms_per_step_max=max(region_s) / args.steps * 1e3,
+                    ms_per_step_regions=[r / args.steps * 1e3 for r in region_s],
+                    value_first_region=total_paths / region_s[0], value_best_region=total_paths / min(region_s),
                     ms_per_step_by_rank=dict(min=min(r["ms_per_step"] for r in per_rank), max=max(r["ms_per_step"] for r in per_rank)),
                     ranks=per_rank,
-                    value_definition="paths of all ranks x K / MAX over ranks of a rank's own time between its two synchronizes "
-                                     "around its K steps; the closing gather is timed on its own (gather_ms) and is inside "
+                    value_definition="MEDIAN over the R timed regions of: paths of all ranks x K / MAX over ranks of a rank's own time "
+                                     "between its two synchronizes around the region's K steps (value_first_region: the single-region "
+                                     "figure of rounds 1-5); the closing gather is timed on its own (gather_ms) and is inside "
                                      "value_including_gather -- compare THAT figure across N when the collective matters",
                     gather_ms=(gather_s * 1e3 if dist is not None else None),
                     value_including_gather=(total_paths / (elapsed + gather_s) if dist is not None else None),

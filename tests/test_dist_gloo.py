@@ -124,3 +124,95 @@ def test_four_rank_uneven_contiguous_shards_with_the_packed_gather(tmp_path):
     result = tmp_path / "result.txt"
     mp.spawn(_worker_config3, args=(4, _free_port(), 65535, 3, str(result)), nprocs=4, join=True)
     assert result.read_text() == "ok"
+
+
+class _NoGpuCuda:
+    """stand-in for torch.cuda inside bench.time_regions on a CPU box: the synchronize is the step function's own return"""
+    @staticmethod
+    def synchronize():
+        return None
+
+
+class _TorchOnCpu:
+    def __init__(self, torch):
+        self._torch = torch
+        self.cuda = _NoGpuCuda()
+
+    def __getattr__(self, name):
+        return getattr(self._torch, name)
+
+
+def _worker_regions(rank, world, port, result_file):
+    """bench.py's repeated timed regions on four gloo ranks: the log of every rank must read
+    (barrier -> K steps -> own clock) x R -> closing gather, the figures returned are the MAX over ranks per region, and
+    every rank returns the same figures (round-5 VERDICT item 9)."""
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import time
+    import torch
+    import torch.distributed as dist
+    import bench
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    log = []
+    real_barrier = dist.barrier
+
+    class _Dist:
+        """torch.distributed with the barrier logged"""
+        def __getattr__(self, name):
+            return getattr(dist, name)
+
+        @staticmethod
+        def barrier():
+            log.append("barrier")
+            real_barrier()
+
+    K, R, W = 5, 7, 2
+    # rank r's step takes (1 + r) ms, and region 3 of rank 1 is disturbed (+ 30 ms): the MAX over ranks must carry both
+    region_no = [-1]
+    n_in_region = [0]
+
+    def step():
+        log.append("step")
+        time.sleep(1e-3 * (1 + rank))
+        n_in_region[0] += 1
+        if rank == 1 and len([x for x in log if x == "barrier"]) == 4 and n_in_region[0] % K == 1:
+            time.sleep(0.030)
+
+    def gather():
+        log.append("gather")
+        t = torch.full((4,), float(rank), dtype=torch.float64)
+        bufs = [torch.empty_like(t) for _ in range(world)] if rank == 0 else None
+        dist.gather(t, bufs, dst=0)
+
+    regions, gather_s = bench.time_regions(step, K, W, _Dist(), _TorchOnCpu(torch), regions=R, final_fn=gather)
+    own = list(bench.LAST_OWN_REGIONS[0])
+    # the order on this rank: W warm-up steps, the gather's warm-up, then R x (barrier, K steps), the timed gather, a closing barrier
+    expect = ["step"] * W + ["gather"]
+    for _ in range(R):
+        expect += ["barrier"] + ["step"] * K
+    expect += ["gather", "barrier"]
+    ok = log == expect
+    ok &= len(regions) == R and len(own) == R and gather_s > 0
+    # MAX over ranks: every region at least the slowest rank's K steps (4 ms each), and no rank's own figure above it
+    ok &= all(r >= K * 4e-3 * 0.95 for r in regions)
+    ok &= all(o <= r + 1e-9 for o, r in zip(own, regions))
+    # the disturbed region is visible in the per-region figures and absent from the median
+    ok &= regions[3] >= 0.030 and bench.median_of(regions) < 0.030 + K * 4e-3
+    allr = [None] * world
+    dist.all_gather_object(allr, (regions, gather_s))
+    ok &= all(a == allr[0] for a in allr)       # one figure for the job, on every rank
+    flags = [None] * world
+    dist.all_gather_object(flags, bool(ok))
+    if rank == 0:
+        with open(result_file, "w") as f:
+            f.write("ok" if all(flags) else "mismatch %r %r" % (flags, regions))
+    real_barrier()
+    dist.destroy_process_group()
+
+
+def test_four_rank_repeated_timed_regions_keep_the_barrier_steps_clock_gather_order(tmp_path):
+    import torch.multiprocessing as mp
+    result = tmp_path / "result.txt"
+    mp.spawn(_worker_regions, args=(4, _free_port(), str(result)), nprocs=4, join=True)
+    assert result.read_text() == "ok"
