@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define MRS_TG_ABI_VERSION 4
+#define MRS_TG_ABI_VERSION 5
 #define MRS_TG_N_COEFF 10
 #define MRS_TG_N_DIM 4
 #define MRS_TG_N_SLOT 5 /* derivative slots per vertex: position .. snap */
@@ -174,6 +174,13 @@ typedef struct mrs_tg_options {
                                      evaluation against the device's constant-rate clock; the budget starts when the
                                      search kernel starts, for mrs_tg_solve_batch minus the host time already spent in
                                      the call) */
+  /* (ABI 5) mrs_tg_find_trajectory only -- the temporal sanity check of findTrajectory (src/...cpp:1178-1199): a sampled
+   * trajectory longer than one second whose length n_samples * sampling_dt exceeds max_trajectory_len_factor times, or falls
+   * below min_trajectory_len_factor times, the path's Baca estimate (estimateSegmentTimesBaca summed, :1048-1056) is
+   * discarded.  Defaults 3.0 / 0.33 (config/public/trajectory_generation.yaml:35-36); <= 0 switches that side off.  The
+   * batched solve calls ignore both (they are handed vertices, not a path); mrs_tg_optimize_paths uses the pair in
+   * mrs_tg_policy_options */
+  double max_trajectory_len_factor, min_trajectory_len_factor;
 } mrs_tg_options;
 
 typedef struct mrs_tg_ctx mrs_tg_ctx;
@@ -384,15 +391,34 @@ typedef struct mrs_tg_initial_state { /* the TrackerCommand fields read at src/.
 } mrs_tg_initial_state;
 
 /* findTrajectory(waypoints, initial_state, sampling_dt, relax_heading) for one path
- * (src/mrs_trajectory_generation.cpp:857-1209): builds the vertices (:923-977), estimates times,
- * optimises, samples.  limits9 as above.  Returns MRS_TG_OK and *n_samples_out > 0 on success; the
- * nodelet's accept/reject gate on the nlopt code (:1138-1149) is applied: a rejected code yields
- * *n_samples_out = 0.  samples_out [sample_capacity][4]. initial_state may be NULL. */
+ * (src/mrs_trajectory_generation.cpp:857-1209), the WHOLE function: builds the vertices (:923-977), estimates the segment
+ * times and the Baca total (:1046-1056), optimises, samples, and applies BOTH of the reference's gates -- the accept / reject
+ * rule on the nlopt code (:1138-1149) and the temporal sanity check of the sampled trajectory against the Baca estimate
+ * (:1178-1199, opt->max_trajectory_len_factor / min_trajectory_len_factor).  limits9 as above.  Returns MRS_TG_OK and
+ * *n_samples_out > 0 exactly where the reference returns the states; *n_samples_out = 0 where it returns {} (status_out,
+ * seg_times_out and coeffs_out still hold what was computed; mrs_tg_last_error(ctx) has the reference's message and
+ * mrs_tg_find_trajectory_info says which gate).  samples_out [sample_capacity][4]; a trajectory with more samples than that
+ * which passes the gates is reported as sample_capacity + 1.  initial_state may be NULL. */
 int mrs_tg_find_trajectory(mrs_tg_ctx* ctx, const mrs_tg_waypoint* waypoints, int32_t n_waypoints,
                            const mrs_tg_initial_state* initial_state, const double* limits9,
                            const mrs_tg_options* opt, int32_t relax_heading, double* seg_times_out,
                            double* coeffs_out, int32_t* status_out, int32_t* n_samples_out, double* samples_out);
 
+/* (ABI 5) What the context's most recent mrs_tg_find_trajectory decided: *rejection_out = one of MRS_TG_FIND_*, and
+ * *baca_total_time_out = initial_total_time_baca (:1048-1056) of that path -- the figure the reference prints beside its
+ * "estimated/final trajectory length ratio" (:1201-1203).  Either pointer may be NULL. */
+enum {
+  MRS_TG_FIND_ACCEPTED = 0,
+  MRS_TG_FIND_REJECTED_CODE = 1,      /* the optimiser's code is one the nodelet rejects (:1146-1149) */
+  MRS_TG_FIND_REJECTED_TOO_LONG = 2,  /* "the final trajectory sampling is too long" (:1178-1186) */
+  MRS_TG_FIND_REJECTED_TOO_SHORT = 3  /* "the final trajectory sampling is too short" (:1188-1196) */
+};
+int mrs_tg_find_trajectory_info(const mrs_tg_ctx* ctx, int32_t* rejection_out, double* baca_total_time_out);
+
+/* (ABI 5) estimateSegmentTimesBaca (src/eth_trajectory_generation/vertex.cpp:301-485) for one path, as findTrajectory calls it
+ * (:1048-1049; also the clock of the fallback sampler, :1309): waypoints [n_waypoints][4] with headings already unwrapped
+ * along the path (:935), limits9 as above (after relax_heading), seg_times_out [n_waypoints - 1].  Host arithmetic, no device. */
+int mrs_tg_estimate_times_baca(const double* waypoints, int32_t n_waypoints, const double* limits9, double* seg_times_out);
 
 /* ---- path-policy layer: optimize() around findTrajectory(), for a batch of paths ------------- */
 

@@ -62,7 +62,11 @@ public:
 
   mrs_tg_options& options() { return opt_; }
 
-  // nullopt = failure, exactly where the reference returns {} (:1148, :1207)
+  // nullopt = failure, exactly where the reference returns {}: a rejected optimiser code (:1146-1149) and a sampled
+  // trajectory that fails the temporal sanity check against the Baca estimate (:1178-1199; the factors are
+  // options().max_trajectory_len_factor / min_trajectory_len_factor, the reference's parameters of the same names) --
+  // both gates are applied inside mrs_tg_find_trajectory, which builds the vertices and their Baca estimate itself.
+  // rejection() says which gate, lastError() carries the reference's message, bacaTotalTime() is initial_total_time_baca.
   std::optional<std::vector<TrajectoryPoint>> findTrajectory(const std::vector<Waypoint>& waypoints,
                                                              const std::optional<InitialState>& initial_state,
                                                              const DynamicsConstraints& constraints, double sampling_dt,
@@ -97,14 +101,23 @@ public:
       last_error_ = mrs_tg_last_error(ctx_);
       return std::nullopt;
     }
-    if (n <= 0) return std::nullopt;  // rejected nlopt code
-    if (n > sample_capacity) n = sample_capacity;
+    mrs_tg_find_trajectory_info(ctx_, &rejection_, &baca_total_time_);
+    if (n <= 0) {  // one of the reference's two gates (or an empty sampling)
+      last_error_ = mrs_tg_last_error(ctx_);
+      return std::nullopt;
+    }
+    if (n > sample_capacity) {  // the trajectory passed the gates but does not fit: the caller's capacity is too small
+      last_error_ = "the sampled trajectory needs more than sample_capacity samples";
+      return std::nullopt;
+    }
     std::vector<TrajectoryPoint> out(n);
     for (int i = 0; i < n; ++i) out[i] = {samples[4 * i], samples[4 * i + 1], samples[4 * i + 2], samples[4 * i + 3]};
     return out;
   }
 
   int status() const { return status_; }                                  // nlopt-style stopping reason
+  int rejection() const { return rejection_; }                            // MRS_TG_FIND_* of the last call
+  double bacaTotalTime() const { return baca_total_time_; }               // initial_total_time_baca (:1048-1056)
   const std::vector<double>& segmentTimes() const { return segment_times_; }  // Trajectory::getSegmentTimes
   const std::vector<double>& coefficients() const { return coefficients_; }   // [S][4][10], ascending powers
   const std::string& lastError() const { return last_error_; }
@@ -113,6 +126,8 @@ private:
   mrs_tg_ctx* ctx_ = nullptr;
   mrs_tg_options opt_{};
   int32_t status_ = MRS_TG_STATUS_FAILURE;
+  int32_t rejection_ = MRS_TG_FIND_ACCEPTED;
+  double baca_total_time_ = 0.0;
   std::vector<double> segment_times_, coefficients_;
   std::string last_error_;
 };

@@ -36,6 +36,9 @@ FLAG_CONSTRAINED_SLOTS = 64         # hint: interior vertices may hold constrain
 STATUS_ROUNDOFF_LIMITED = -4   # MRS_TG_STATUS_ROUNDOFF_LIMITED: the feasibility scaling ran away (include/mrs_tg.h)
 RUNAWAY_TIME_FACTOR = 25.0     # MRS_TG_RUNAWAY_TIME_FACTOR
 
+# mrs_tg_find_trajectory_info: which of findTrajectory's gates discarded the trajectory (MRS_TG_FIND_*)
+FIND_ACCEPTED, FIND_REJECTED_CODE, FIND_REJECTED_TOO_LONG, FIND_REJECTED_TOO_SHORT = 0, 1, 2, 3
+
 STATE_ORDERS = 5   # derivative orders 0..4 per sample of Plan.sample_states (MRS_TG_STATE_ORDERS)
 KERNEL_ASSEMBLE, KERNEL_SOLVE_LINEAR, KERNEL_NONLINEAR = 0, 1, 2
 
@@ -51,7 +54,8 @@ class Options(C.Structure):
                 ("sampling_dt", C.c_double), ("sample_capacity", C.c_int32), ("flags", C.c_int32),
                 ("time_penalty", C.c_double), ("soft_constraint_weight", C.c_double),
                 ("use_soft_constraints", C.c_int32), ("reserved_", C.c_int32), ("initial_stepsize_rel", C.c_double),
-                ("max_time_s", C.c_double)]
+                ("max_time_s", C.c_double),
+                ("max_trajectory_len_factor", C.c_double), ("min_trajectory_len_factor", C.c_double)]   # (ABI 5)
 
 
 class PolicyOptions(C.Structure):
@@ -84,7 +88,7 @@ EXPORTED_SYMBOLS = [
     "mrs_tg_bound_solve_destroy", "mrs_tg_host_alloc", "mrs_tg_host_free", "mrs_tg_host_register",
     "mrs_tg_host_unregister", "mrs_tg_plan_cost_gradient",
     "mrs_tg_plan_segment_maxima", "mrs_tg_plan_sample_states", "mrs_tg_plan_careful_count", "mrs_tg_set_profiling", "mrs_tg_last_kernel_ms", "mrs_tg_kernel_ms_history",
-    "mrs_tg_find_trajectory",
+    "mrs_tg_find_trajectory", "mrs_tg_find_trajectory_info", "mrs_tg_estimate_times_baca",
     "mrs_tg_default_policy_options", "mrs_tg_optimize_paths", "mrs_tg_waypoint_trajectory_idxs",
     "mrs_tg_create_multi", "mrs_tg_destroy_multi", "mrs_tg_multi_n_devices", "mrs_tg_multi_context", "mrs_tg_multi_shard",
     "mrs_tg_multi_solve_batch", "mrs_tg_multi_last_error",
@@ -181,6 +185,10 @@ def load_library():
     L.mrs_tg_last_kernel_ms.argtypes = [vp, C.c_int, C.POINTER(C.c_float)]
     L.mrs_tg_kernel_ms_history.restype = C.c_int
     L.mrs_tg_kernel_ms_history.argtypes = [vp, C.c_int, C.POINTER(C.c_float), C.c_int]
+    L.mrs_tg_find_trajectory_info.restype = C.c_int
+    L.mrs_tg_find_trajectory_info.argtypes = [vp, C.POINTER(C.c_int32), C.POINTER(C.c_double)]
+    L.mrs_tg_estimate_times_baca.restype = C.c_int
+    L.mrs_tg_estimate_times_baca.argtypes = [dp, C.c_int32, dp, dp]
     L.mrs_tg_find_trajectory.restype = C.c_int
     L.mrs_tg_find_trajectory.argtypes = [vp, C.POINTER(Waypoint), C.c_int32, C.POINTER(InitialState), dp,
                                          C.POINTER(Options), C.c_int32, dp, dp, ip, ip, dp]
@@ -239,6 +247,17 @@ def default_policy_options(solver=None, **overrides):
             raise TypeError("unknown policy option %r" % k)
         setattr(opt, k, v)
     return opt
+
+
+def estimate_times_baca(waypoints, limits9):
+    """estimateSegmentTimesBaca for one path (mrs_tg_estimate_times_baca): waypoints [V][4], headings already unwrapped"""
+    wp = np.ascontiguousarray(waypoints, dtype=np.float64).reshape(-1, 4)
+    lim = np.ascontiguousarray(limits9, dtype=np.float64)
+    out = np.zeros(wp.shape[0] - 1)
+    rc = load_library().mrs_tg_estimate_times_baca(_np_ptr(wp), wp.shape[0], _np_ptr(lim), _np_ptr(out))
+    if rc != 0:
+        raise MrsTgError("mrs_tg_estimate_times_baca failed (%d)" % rc)
+    return out
 
 
 def default_options(**overrides):
@@ -421,9 +440,15 @@ class Context:
             if rc:
                 check(rc, "mrs_tg_find_trajectory")
 
+        L = self._L
+
         def result():
+            rej, baca = C.c_int32(0), C.c_double(0.0)
+            L.mrs_tg_find_trajectory_info(h, C.byref(rej), C.byref(baca))
             return dict(times=times.copy(), coeffs=coeffs.copy(), status=status.value, n_samples=ns.value,
-                        samples=samples[:min(ns.value, sample_capacity)].copy())
+                        samples=samples[:min(ns.value, sample_capacity)].copy(), rejection=rej.value,
+                        baca_total_time=baca.value,
+                        message=(L.mrs_tg_last_error(h).decode() if rej.value else ""))
         return call, result
 
     def find_trajectory(self, waypoints, stop_at=None, initial_state=None, limits=None, relax_heading=False,

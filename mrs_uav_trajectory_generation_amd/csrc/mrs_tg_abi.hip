@@ -25,6 +25,7 @@
 #include "../../include/mrs_tg.h"
 #include "mrs_tg_launch.h"
 #include "mrs_tg_nonlinear.h"
+#include "mrs_tg_policy_host.hpp"
 
 namespace {
 
@@ -65,6 +66,9 @@ struct mrs_tg_ctx {
   // pinned host scratch of mrs_tg_optimize_paths (the arrays of its rounds), kept across calls
   void* h_scratch = nullptr;
   size_t h_scratch_bytes = 0;
+  // what the most recent mrs_tg_find_trajectory decided (mrs_tg_find_trajectory_info)
+  int32_t find_rejection = 0;
+  double find_baca_total = 0.0;
 };
 
 struct mrs_tg_plan {
@@ -203,22 +207,6 @@ struct DevBuf {
 };
 }  // namespace
 
-namespace {
-double wrap_pi_host(double a) {
-  const double two_pi = 2.0 * M_PI;
-  double r = std::fmod(a + M_PI, two_pi);
-  if (r < 0) r += two_pi;
-  return r - M_PI;
-}
-// mrs_lib sradians::unwrap(what, from) as used at src/mrs_trajectory_generation.cpp:935
-double unwrap_heading(double what, double from) {
-  const double two_pi = 2.0 * M_PI;
-  double d = wrap_pi_host(what) - wrap_pi_host(from);
-  if (d < -M_PI) d += two_pi;
-  else if (d >= M_PI) d -= two_pi;
-  return from + d;
-}
-}  // namespace
 
 extern "C" {
 
@@ -252,6 +240,8 @@ void mrs_tg_default_options(mrs_tg_options* opt) {
   opt->use_soft_constraints = 1;       // :5
   opt->initial_stepsize_rel = 0.1;     // src/mrs_trajectory_generation.cpp:893
   opt->max_time_s = 0.0;               // no deadline (the nodelet sets 2 * 0.95 * timeLeft(), :899)
+  opt->max_trajectory_len_factor = 3.0;   // config/public/trajectory_generation.yaml:35
+  opt->min_trajectory_len_factor = 0.33;  // :36
 }
 
 const char* mrs_tg_last_error(const mrs_tg_ctx* ctx) {
@@ -1225,47 +1215,64 @@ int mrs_tg_find_trajectory(mrs_tg_ctx* ctx, const mrs_tg_waypoint* wps, int32_t 
   if (n_wp < 2) return fail(ctx, MRS_TG_ERR_INVALID_ARG, "need at least 2 waypoints, got %d", n_wp);
   const int d = opt_in->derivative_to_optimize;
   if (d < 2 || d > 4) return fail(ctx, MRS_TG_ERR_INVALID_ARG, "derivative_to_optimize must be 2, 3 or 4");
+  namespace pol = mrs_tg::policy;
   const int V = n_wp, S = n_wp - 1;
-  std::vector<double> wp(V * 4), vals(V * 20, 0.0);
-  std::vector<uint8_t> mask(V * 5, 0);
-  // vertices: src/mrs_trajectory_generation.cpp:923-977
-  double last_heading = init ? init->heading : wps[0].coords[3];
-  for (int i = 0; i < V; ++i) {
-    for (int k = 0; k < 3; ++k) wp[i * 4 + k] = wps[i].coords[k];
-    const double heading = unwrap_heading(wps[i].coords[3], last_heading);
-    last_heading = heading;
-    wp[i * 4 + 3] = heading;
-    mask[i * 5 + 0] = 1;
-    for (int k = 0; k < 4; ++k) vals[(i * 5 + 0) * 4 + k] = wp[i * 4 + k];
-    if (i == 0 || i == V - 1) {
-      for (int k = 1; k <= d; ++k) mask[i * 5 + k] = 1;  // makeStartOrEnd: zeros
-      if (i == 0 && init) {
-        for (int k = 0; k < 4; ++k) {
-          vals[(0 * 5 + 1) * 4 + k] = init->velocity[k];
-          vals[(0 * 5 + 2) * 4 + k] = init->acceleration[k];
-          vals[(0 * 5 + 3) * 4 + k] = init->jerk[k];
-        }
-        mask[1] = mask[2] = mask[3] = 1;
-      }
-    } else if (wps[i].stop_at) {
-      mask[i * 5 + 1] = mask[i * 5 + 2] = mask[i * 5 + 3] = 1;
+  ctx->find_rejection = MRS_TG_FIND_ACCEPTED;
+  ctx->find_baca_total = 0.0;
+  *n_samples_out = 0;
+  try {
+    std::vector<double> raw(V * 4), wp(V * 4), vals(V * 20), baca;
+    std::vector<uint8_t> mask(V * 5), stop(V);
+    for (int i = 0; i < V; ++i) {
+      for (int k = 0; k < 4; ++k) raw[i * 4 + k] = wps[i].coords[k];
+      stop[i] = wps[i].stop_at;
+    }
+    // vertices: src/mrs_trajectory_generation.cpp:923-977; limits: :985-1038
+    pol::build_vertices(raw.data(), stop.data(), V, init, d, wp.data(), mask.data(), vals.data());
+    double lim[9];
+    pol::effective_limits(limits9, relax_heading != 0, lim);
+    // initial_total_time_baca (:1048-1056), from the same vertices and limits the optimiser sees
+    ctx->find_baca_total = pol::baca_total_time(S, wp.data(), lim, baca);
+    mrs_tg_options opt = *opt_in;
+    opt.estimate_times = 1;
+    const int32_t so[2] = {0, S};
+    double cost = 0.0;
+    int rc = mrs_tg_solve_batch(ctx, 1, so, wp.data(), mask.data(), vals.data(), lim, &opt, seg_times_out, coeffs_out,
+                                status_out, &cost, n_samples_out, samples_out);
+    if (rc != MRS_TG_OK) return rc;
+  } catch (const std::bad_alloc&) {
+    return fail(ctx, MRS_TG_ERR_NOMEM, "out of host memory for a path of %d waypoints", n_wp);
+  }
+  // accept >= 1 except MAXTIME(6), and -1 (src/mrs_trajectory_generation.cpp:1138-1149)
+  if (!pol::code_accepted(*status_out)) {
+    ctx->find_rejection = MRS_TG_FIND_REJECTED_CODE;
+    ctx->last_error = "optimization failed with code " + std::to_string(*status_out);
+    *n_samples_out = 0;
+    return MRS_TG_OK;
+  }
+  // "validate the temporal sampling of the trajectory" (:1178-1199): states.size() * sampling_dt against the Baca total.  A
+  // trajectory with more samples than samples_out holds is reported as capacity + 1: the count the check sees is then a
+  // LOWER bound of the real one, enough to reject "too long" whenever capacity * dt exceeds the allowed length
+  if (opt_in->sampling_dt > 0 && samples_out) {
+    const int verdict = pol::length_check(*n_samples_out, opt_in->sampling_dt, ctx->find_baca_total,
+                                          opt_in->max_trajectory_len_factor, opt_in->min_trajectory_len_factor);
+    if (verdict != 0) {
+      char msg[256];
+      std::snprintf(msg, sizeof(msg), "trajectory sampling failed: the final trajectory sampling is too %s = %.2f, initial 'baca' "
+                    "estimate = %.2f, allowed factor %.2f", verdict > 0 ? "long" : "short", *n_samples_out * opt_in->sampling_dt,
+                    ctx->find_baca_total, verdict > 0 ? opt_in->max_trajectory_len_factor : opt_in->min_trajectory_len_factor);
+      ctx->last_error = msg;
+      ctx->find_rejection = verdict > 0 ? MRS_TG_FIND_REJECTED_TOO_LONG : MRS_TG_FIND_REJECTED_TOO_SHORT;
+      *n_samples_out = 0;
     }
   }
-  double lim[9];
-  for (int k = 0; k < 9; ++k) lim[k] = limits9[k];
-  if (relax_heading) lim[2] = lim[5] = lim[8] = (double)FLT_MAX;  // src/...cpp:1030-1034
-  mrs_tg_options opt = *opt_in;
-  opt.estimate_times = 1;
-  const int32_t so[2] = {0, S};
-  double cost = 0.0;
-  *n_samples_out = 0;
-  int rc = mrs_tg_solve_batch(ctx, 1, so, wp.data(), mask.data(), vals.data(), lim, &opt, seg_times_out, coeffs_out,
-                              status_out, &cost, n_samples_out, samples_out);
-  if (rc != MRS_TG_OK) return rc;
-  // accept >= 1 except MAXTIME(6), and -1 (src/mrs_trajectory_generation.cpp:1138-1149)
-  const int st = *status_out;
-  const bool accepted = (st >= 1 && st != 6) || st == -1;
-  if (!accepted) *n_samples_out = 0;
+  return MRS_TG_OK;
+}
+
+int mrs_tg_find_trajectory_info(const mrs_tg_ctx* ctx, int32_t* rejection_out, double* baca_total_time_out) {
+  if (!ctx) return fail(nullptr, MRS_TG_ERR_INVALID_ARG, "ctx is NULL");
+  if (rejection_out) *rejection_out = ctx->find_rejection;
+  if (baca_total_time_out) *baca_total_time_out = ctx->find_baca_total;
   return MRS_TG_OK;
 }
 

@@ -1,327 +1,23 @@
-// mrs_tg_policy.hip -- host-side path-policy layer around the batched solver: what
-// MrsTrajectoryGeneration::optimize() does around findTrajectory()
-// (/root/reference/src/mrs_trajectory_generation.cpp:620-851), for a batch of independent paths:
-//   preprocessPath (:431-500) -> solve all paths in ONE batched GPU call -> length sanity check against the
-//   Baca estimate (:1178-1199) -> validateTrajectorySpatial (:1401-1455) -> insert mid-points into unsafe
-//   segments (:739-753) -> re-solve the still-unsafe paths as the next batch, up to max_iterations rounds;
-//   optional findTrajectoryFallback (:1215-1395) and override_heading_atan2 (:1582-1597).
-// The solver calls go through the same C ABI as everything else (mrs_tg_solve_batch); the policy itself is
-// host logic in the reference and stays host logic here.  ROS-only branches (tf, stamps, "path from the
-// future", MPC prediction splicing, wall-clock overtime) have no counterpart.
+// mrs_tg_policy.hip -- the path-policy layer's C entry points: mrs_tg_policy_host.hpp (what
+// MrsTrajectoryGeneration::optimize() does around findTrajectory(), /root/reference/src/mrs_trajectory_generation.cpp:620-851,
+// as pure host logic behind a solve callback) instantiated with the batched GPU solve -- all still-active paths of a round go
+// out as ONE call of the C ABI's own solver, the arrays of the round in the context's pinned scratch block.
 #include <hip/hip_runtime.h>
 
-
-#include <algorithm>
-#include <cfloat>
-#include <cmath>
-#include <cstdio>
-#include <cstring>
-#include <new>
-#include <stdexcept>
-#include <system_error>
-#include <thread>
-#include <vector>
-
-#include <chrono>
-#include <sched.h>
-
-#include "../../include/mrs_tg.h"
+#include "mrs_tg_policy_host.hpp"
 #include "mrs_tg_launch.h"
 
 namespace {
 
-double wrap_range(double a, double lo, double range) {
-  double r = std::fmod(a - lo, range);
-  if (r < 0) r += range;
-  return r + lo;
-}
-// mrs_lib radians::diff / radians::interp (angles in [0, 2 pi)), sradians::unwrap
-double radians_diff(double minuend, double subtrahend) {
-  const double two_pi = 2.0 * M_PI;
-  double d = wrap_range(minuend, 0.0, two_pi) - wrap_range(subtrahend, 0.0, two_pi);
-  if (d < -M_PI) d += two_pi;
-  else if (d >= M_PI) d -= two_pi;
-  return d;
-}
-double radians_interp(double from, double to, double coeff) {
-  return wrap_range(from + coeff * radians_diff(to, from), 0.0, 2.0 * M_PI);
-}
-double sradians_unwrap(double what, double from) {
-  const double two_pi = 2.0 * M_PI;
-  double d = wrap_range(what, -M_PI, two_pi) - wrap_range(from, -M_PI, two_pi);
-  if (d < -M_PI) d += two_pi;
-  else if (d >= M_PI) d -= two_pi;
-  return from + d;
-}
-double wrap_yaw(double y) { return std::atan2(std::sin(y), std::cos(y)); }
-
-double dist_from_segment(const double* p, const double* s1, const double* s2) {  // :1533-1554
-  const double sv[3] = {s2[0] - s1[0], s2[1] - s1[1], s2[2] - s1[2]};
-  const double len = std::sqrt(sv[0] * sv[0] + sv[1] * sv[1] + sv[2] * sv[2]);
-  double n[3] = {sv[0], sv[1], sv[2]};
-  if (len * len > 0) {
-    n[0] /= len;
-    n[1] /= len;
-    n[2] /= len;
+struct GpuHost {  // the Host of mrs_tg::policy::optimize_paths
+  mrs_tg_ctx* ctx;
+  void* scratch(size_t bytes) { return mrs_tg::ctx_host_scratch(ctx, bytes); }
+  int solve(int32_t n_paths, const int32_t* seg_offsets, const double* wp, const uint8_t* mask, const double* vals, const double* lim,
+            const mrs_tg_options* opt, double* times, int32_t* status, int32_t* n_samples, double* samples) {
+    return mrs_tg::solve_batch_samples_only(ctx, n_paths, seg_offsets, wp, mask, vals, lim, opt, times, status, n_samples, samples);
   }
-  const double d1[3] = {p[0] - s1[0], p[1] - s1[1], p[2] - s1[2]};
-  const double coord = n[0] * d1[0] + n[1] * d1[1] + n[2] * d1[2];
-  if (coord < 0) return std::sqrt(d1[0] * d1[0] + d1[1] * d1[1] + d1[2] * d1[2]);
-  if (coord > len) {
-    const double d2[3] = {p[0] - s2[0], p[1] - s2[1], p[2] - s2[2]};
-    return std::sqrt(d2[0] * d2[0] + d2[1] * d2[1] + d2[2] * d2[2]);
-  }
-  const double e[3] = {p[0] - (s1[0] + n[0] * coord), p[1] - (s1[1] + n[1] * coord), p[2] - (s1[2] + n[2] * coord)};
-  return std::sqrt(e[0] * e[0] + e[1] * e[1] + e[2] * e[2]);
-}
-
-void interpolate_point(const double* a, const double* b, double coeff, double* out) {  // :1612-1625
-  for (int k = 0; k < 3; ++k) out[k] = a[k] + coeff * (b[k] - a[k]);
-  out[3] = radians_interp(a[3], b[3], coeff);
-}
-
-double limit_for_inclination(double inclinator, double lim_v, double lim_h) {  // vertex.cpp:337-353
-  if (inclinator > std::atan2(lim_v, lim_h) || inclinator < -std::atan2(lim_v, lim_h)) return std::fabs(lim_v / std::sin(inclinator));
-  return std::fabs(lim_h / std::cos(inclinator));
-}
-
-void unit3(const double* a, const double* b, double* u) {
-  double v[3] = {b[0] - a[0], b[1] - a[1], b[2] - a[2]};
-  const double n = std::sqrt(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]);
-  if (n * n > 0) {
-    v[0] /= n;
-    v[1] /= n;
-    v[2] /= n;
-  }
-  u[0] = v[0];
-  u[1] = v[1];
-  u[2] = v[2];
-}
-
-// estimateSegmentTimesBaca, /root/reference/src/eth_trajectory_generation/vertex.cpp:301-485; wp [V][4] unwrapped
-void estimate_times_baca(int S, const double* wp, const double* lim, std::vector<double>& out) {
-  const double v_h = lim[0], v_v = lim[1], w_hdg = lim[2], a_h = lim[3], a_v = lim[4], a_hdg = lim[5], j_h = lim[6], j_v = lim[7];
-  const int V = S + 1;
-  out.assign(S, 0.0);
-  for (int i = 0; i < S; ++i) {
-    const double* s = wp + (size_t)i * 4;
-    const double* e = s + 4;
-    const double dx = e[0] - s[0], dy = e[1] - s[1], dz = e[2] - s[2];
-    const double distance = std::sqrt(dx * dx + dy * dy + dz * dz);
-    const double inclinator = std::atan2(dz, std::sqrt(dx * dx + dy * dy));
-    const double v_max = limit_for_inclination(inclinator, v_v, v_h);
-    const double a_max = limit_for_inclination(inclinator, a_v, a_h);
-    const double j_max = limit_for_inclination(inclinator, j_v, j_h);
-    double t1 = 0, t2 = 0;
-    const double full = (v_max / a_max) + (a_max / j_max);
-    if (i >= 1) {
-      double u1[3], u2[3];
-      unit3(wp + (size_t)(i - 1) * 4, s, u1);
-      unit3(s, e, u2);
-      const double dot = u1[0] * u2[0] + u1[1] * u2[1] + u1[2] * u2[2];
-      t1 = (1 - (dot < 0 ? 0.0 : dot)) * full;
-    }
-    if (i == 0) t1 = full;
-    if (i == V - 2) t2 = full;
-    if (i < V - 2) {
-      double u1[3], u2[3];
-      unit3(s, e, u1);
-      unit3(e, wp + (size_t)(i + 2) * 4, u2);
-      const double dot = u1[0] * u2[0] + u1[1] * u2[1] + u1[2] * u2[2];
-      t2 = (1 - (dot < 0 ? 0.0 : dot)) * full;
-    }
-    const double cap = std::sqrt(2 * distance / a_max);
-    t1 = std::min(t1, cap);
-    t2 = std::min(t2, cap);
-    double t = distance / v_max + t1 + t2;
-    if (t < 0.01) t = 0.01;
-    // heading rotation time (:457-480)
-    double dh = radians_diff(s[3], e[3]);
-    const double ang = std::fabs(dh);
-    double tv = 0, ta = 0;
-    if (w_hdg < (double)FLT_MAX && a_hdg < (double)FLT_MAX) {
-      const double reduced = (ang - 2 * (w_hdg * w_hdg) / a_hdg) / w_hdg;
-      tv = (reduced < 0) ? ang / w_hdg : reduced;
-      if (ang > M_PI / 4) ta = 2 * (w_hdg / a_hdg);
-    }
-    const double hf = 1.5 * (tv + ta);
-    if (hf > t) t = hf;
-    out[i] = t;
-  }
-}
-
-// The policy's per-path host work (vertex building, Baca estimates, spatial validation, mid-point insertion) is independent
-// from path to path: batches of requests run it on a few threads.  Ranges of [0, n) in order, one per thread; small batches
-// (a nodelet's single request) stay on the calling thread.  MRS_TG_POLICY_THREADS=1 switches the threads off.
-int policy_threads() {
-  static const int n = [] {
-    if (const char* e = std::getenv("MRS_TG_POLICY_THREADS")) return std::max(1, std::atoi(e));
-    int cpus = (int)std::thread::hardware_concurrency();
-    cpu_set_t set;
-    if (sched_getaffinity(0, sizeof(set), &set) == 0) cpus = std::min(cpus > 0 ? cpus : 1 << 20, CPU_COUNT(&set));
-    return std::max(1, std::min(cpus, 16));
-  }();
-  return n;
-}
-
-template <class F>
-void parallel_ranges(size_t n, size_t min_per_thread, F&& body) {  // body(begin, end)
-  const size_t threads = std::min<size_t>((size_t)policy_threads(), n / std::max<size_t>(min_per_thread, 1));
-  if (threads <= 1) {
-    body((size_t)0, n);
-    return;
-  }
-  std::vector<std::thread> pool;
-  pool.reserve(threads - 1);
-  const size_t chunk = (n + threads - 1) / threads;
-  size_t first_inline = threads;  // ranges [first_inline, threads) run on this thread: a thread that could not be started
-  for (size_t t = 1; t < threads; ++t) {
-    const size_t b = std::min(n, t * chunk), e = std::min(n, b + chunk);
-    if (b >= e) continue;
-    try {
-      pool.emplace_back([&body, b, e] { body(b, e); });
-    } catch (const std::system_error&) {
-      first_inline = t;
-      break;
-    }
-  }
-  body((size_t)0, std::min(n, chunk));
-  for (size_t t = first_inline; t < threads; ++t) {
-    const size_t b = std::min(n, t * chunk), e = std::min(n, b + chunk);
-    if (b < e) body(b, e);
-  }
-  for (std::thread& th : pool) th.join();
-}
-
-struct PathState {
-  std::vector<double> wps;     // [n][4] current waypoints (raw headings)
-  std::vector<uint8_t> stop;
-  int n_wp = 0;
-  bool done = false, ok = false;
-  int n_samples = 0, iterations = 0;
-  double max_dev = 0.0;
-  double baca_total = 0.0;
+  int fail(int code, const char* message) { return mrs_tg::report_error(ctx, code, "%s", message); }
 };
-
-void preprocess(const mrs_tg_waypoint* in, int n_in, const mrs_tg_policy_options& o, PathState& st) {  // :431-500
-  st.wps.clear();
-  st.stop.clear();
-  int last_added = 0;
-  for (int i = 0; i < n_in; ++i) {
-    const double* w = in[i].coords;
-    if (o.path_straightener_enabled && n_in >= 3 && i > 0 && i < n_in - 1) {
-      const double* first = in[last_added].coords;
-      const double* last = in[i + 1].coords;
-      bool segment_is_ok = true;
-      for (int j = last_added + 1; j < i + 1; ++j) {
-        const double* mid = in[j].coords;
-        // quirk B3 of the reference: fabs() wraps the comparison, so the heading test is signed
-        if (dist_from_segment(mid, first, last) > o.path_straightener_max_deviation ||
-            (radians_diff(first[3], mid[3]) > o.path_straightener_max_hdg_deviation) ||
-            (radians_diff(last[3], mid[3]) > o.path_straightener_max_hdg_deviation)) {
-          segment_is_ok = false;
-          break;
-        }
-      }
-      if (segment_is_ok) continue;
-    }
-    if (i > 0 && i < n_in - 1) {
-      const double* first = in[last_added].coords;
-      const double dx = first[0] - w[0], dy = first[1] - w[1], dz = first[2] - w[2];
-      if (std::sqrt(dx * dx + dy * dy + dz * dz) < o.min_waypoint_distance) continue;
-    }
-    st.wps.insert(st.wps.end(), w, w + 4);
-    st.stop.push_back(in[i].stop_at);
-    last_added = i;
-  }
-  st.n_wp = (int)st.stop.size();
-}
-
-// validateTrajectorySpatial :1401-1455
-bool validate_spatial(const double* samples, int n_samples, const PathState& st, const mrs_tg_policy_options& o,
-                      std::vector<uint8_t>& safe, double& max_dev) {
-  const int n_wp = st.n_wp;
-  safe.assign(std::max(n_wp - 1, 0), 1);
-  int widx = 0;
-  bool is_safe = true;
-  max_dev = 0;
-  for (int i = 0; i + 1 < n_samples; ++i) {
-    const double* sample = samples + (size_t)i * 4;
-    const double* next = sample + 4;
-    const double* s0 = st.wps.data() + (size_t)widx * 4;
-    const double* s1 = s0 + 4;
-    const double d_seg = dist_from_segment(sample, s0, s1);
-    const double d_end = dist_from_segment(s1, sample, next);
-    if (widx > 0 || o.max_deviation_first_segment || n_wp <= 2) {
-      if (d_seg > max_dev) max_dev = d_seg;
-      if (d_seg > o.max_deviation) {
-        safe[widx] = 0;
-        is_safe = false;
-      }
-    }
-    if (d_end < 0.05 && widx < n_wp - 2) ++widx;
-  }
-  return is_safe;
-}
-
-void insert_midpoints(PathState& st, const std::vector<uint8_t>& safe, const mrs_tg_policy_options& o) {  // :739-753
-  int w = 0, sidx = 0;
-  while (w < st.n_wp - 1) {
-    if (!safe[sidx] && (w > 0 || o.max_deviation_first_segment || st.n_wp <= 2)) {
-      double mid[4];
-      interpolate_point(st.wps.data() + (size_t)w * 4, st.wps.data() + (size_t)(w + 1) * 4, 0.5, mid);
-      st.wps.insert(st.wps.begin() + (size_t)(w + 1) * 4, mid, mid + 4);
-      st.stop.insert(st.stop.begin() + (w + 1), (uint8_t)0);
-      ++st.n_wp;
-      ++w;
-    }
-    ++sidx;
-    ++w;
-  }
-}
-
-// findTrajectoryFallback :1215-1395
-int fallback_sampling(const PathState& st, const double* limits9, bool relax_heading, const mrs_tg_policy_options& o, double dt,
-                      double* out, int capacity) {
-  const int n_wp = st.n_wp;
-  std::vector<double> wps(st.wps);
-  double last = wps[3];
-  for (int i = 0; i < n_wp; ++i) {
-    wps[(size_t)i * 4 + 3] = sradians_unwrap(st.wps[(size_t)i * 4 + 3], last);
-    last = wps[(size_t)i * 4 + 3];
-  }
-  double lim[9];
-  std::memcpy(lim, limits9, sizeof(lim));
-  lim[0] *= o.fallback_speed_factor;
-  lim[1] *= o.fallback_speed_factor;
-  lim[3] *= o.fallback_accel_factor;
-  lim[4] *= o.fallback_accel_factor;
-  if (relax_heading) lim[2] = lim[5] = lim[8] = (double)FLT_MAX;
-  std::vector<double> t_baca;
-  estimate_times_baca(n_wp - 1, wps.data(), lim, t_baca);
-  int count = 0;
-  for (int i = 0; i < n_wp - 1; ++i) {
-    int n_samples = 0;
-    double step = 0;
-    if (t_baca[i] > 1e-1) {
-      n_samples = (int)std::ceil(t_baca[i] / dt);
-      step = (n_samples > 0) ? 1.0 / (double)n_samples : 0.5;
-    }
-    if (n_samples > 0 && i == n_wp - 2) ++n_samples;
-    for (int j = 0; j < n_samples; ++j) {
-      double p[4];
-      interpolate_point(st.wps.data() + (size_t)i * 4, st.wps.data() + (size_t)(i + 1) * 4, j * step, p);
-      p[3] = wrap_yaw(p[3]);
-      int repeat = 1;
-      if (j == 0 && i > 0 && st.stop[i]) repeat += (int)std::round(o.fallback_stopping_time / dt);
-      for (int r = 0; r < repeat; ++r) {
-        if (count < capacity) std::memcpy(out + (size_t)count * 4, p, sizeof(p));
-        ++count;
-      }
-    }
-  }
-  return count;
-}
 
 }  // namespace
 
@@ -331,43 +27,21 @@ void mrs_tg_default_policy_options(mrs_tg_policy_options* o) {
   if (!o) return;
   std::memset(o, 0, sizeof(*o));
   mrs_tg_default_options(&o->solver);
-  o->solver.time_alloc_method = MRS_TG_TIME_ALLOC_MELLINGER;  // config/private/trajectory_generation.yaml:7
-  o->solver.derivative_to_optimize = 2;                       // :11 (0 -> acceleration)
-  o->solver.sampling_dt = 0.2;                                // config/public/trajectory_generation.yaml
-  o->check_deviation_enabled = 1;
-  o->max_deviation = 0.05;
-  o->max_deviation_iterations = 6;
-  o->max_deviation_first_segment = 1;
-  o->min_waypoint_distance = 0.05;
-  o->path_straightener_enabled = 0;
-  o->path_straightener_max_deviation = 0.05;
-  o->path_straightener_max_hdg_deviation = 0.1;
-  o->max_trajectory_len_factor = 3.0;
-  o->min_trajectory_len_factor = 0.33;
-  o->fallback_sampling = 0;
-  o->fallback_speed_factor = 1.0;
-  o->fallback_accel_factor = 1.0;
-  o->fallback_stopping_time = 2.0;
-  o->override_heading_atan2 = 0;
-  o->reserved_ = 0;
-  o->max_execution_time_s = 0.0;
+  mrs_tg::policy::default_policy_fields(o);
 }
-
-static int optimize_paths_impl(mrs_tg_ctx* ctx, int32_t n_paths, const int32_t* wp_offsets, const mrs_tg_waypoint* waypoints,
-                               const mrs_tg_initial_state* initial_states, const uint8_t* has_initial_state, const double* limits,
-                               const uint8_t* relax_heading, const mrs_tg_policy_options* opt, int32_t sample_capacity,
-                               int32_t* success_out, int32_t* n_samples_out, double* samples_out, double* max_deviation_out,
-                               int32_t* n_waypoints_out, int32_t* iterations_out);
 
 int mrs_tg_optimize_paths(mrs_tg_ctx* ctx, int32_t n_paths, const int32_t* wp_offsets, const mrs_tg_waypoint* waypoints,
                           const mrs_tg_initial_state* initial_states, const uint8_t* has_initial_state, const double* limits,
                           const uint8_t* relax_heading, const mrs_tg_policy_options* opt, int32_t sample_capacity,
                           int32_t* success_out, int32_t* n_samples_out, double* samples_out, double* max_deviation_out,
                           int32_t* n_waypoints_out, int32_t* iterations_out) {
-  try {  // (host containers sized by the batch: nothing crosses the C boundary)
-    return optimize_paths_impl(ctx, n_paths, wp_offsets, waypoints, initial_states, has_initial_state, limits, relax_heading, opt,
-                               sample_capacity, success_out, n_samples_out, samples_out, max_deviation_out, n_waypoints_out,
-                               iterations_out);
+  if (!ctx) return mrs_tg::report_error(nullptr, MRS_TG_ERR_INVALID_ARG, "ctx is NULL");
+  try {  // (host containers sized by the batch, on the calling thread and on the policy's worker threads, whose exceptions
+         // mrs_tg::policy::parallel_ranges carries back to this one: nothing crosses the C boundary)
+    GpuHost host{ctx};
+    return mrs_tg::policy::optimize_paths(host, n_paths, wp_offsets, waypoints, initial_states, has_initial_state, limits,
+                                          relax_heading, opt, sample_capacity, success_out, n_samples_out, samples_out,
+                                          max_deviation_out, n_waypoints_out, iterations_out);
   } catch (const std::bad_alloc&) {
     return mrs_tg::report_error(ctx, MRS_TG_ERR_NOMEM, "out of host memory for %d requests of up to %d samples", n_paths, sample_capacity);
   } catch (const std::exception& ex) {
@@ -375,252 +49,25 @@ int mrs_tg_optimize_paths(mrs_tg_ctx* ctx, int32_t n_paths, const int32_t* wp_of
   }
 }
 
-static int optimize_paths_impl(mrs_tg_ctx* ctx, int32_t n_paths, const int32_t* wp_offsets, const mrs_tg_waypoint* waypoints,
-                               const mrs_tg_initial_state* initial_states, const uint8_t* has_initial_state, const double* limits,
-                               const uint8_t* relax_heading, const mrs_tg_policy_options* opt, int32_t sample_capacity,
-                               int32_t* success_out, int32_t* n_samples_out, double* samples_out, double* max_deviation_out,
-                               int32_t* n_waypoints_out, int32_t* iterations_out) {
-  if (!ctx) return mrs_tg::report_error(nullptr, MRS_TG_ERR_INVALID_ARG, "ctx is NULL");
-  if (!wp_offsets || !waypoints || !limits || !opt || !success_out || !n_samples_out || !samples_out)
-    return mrs_tg::report_error(ctx, MRS_TG_ERR_INVALID_ARG,
-                                "wp_offsets, waypoints, limits, options, success_out, n_samples_out and samples_out are required");
-  if (n_paths < 0 || sample_capacity <= 0)
-    return mrs_tg::report_error(ctx, MRS_TG_ERR_INVALID_ARG, "n_paths %d / sample_capacity %d: need >= 0 / > 0", n_paths,
-                                sample_capacity);
-  const mrs_tg_policy_options& o = *opt;
-  const int d = o.solver.derivative_to_optimize;
-  if (d < 2 || d > 4)
-    return mrs_tg::report_error(ctx, MRS_TG_ERR_INVALID_ARG, "derivative_to_optimize must be 2, 3 or 4 (got %d)", d);
-  const double dt = o.solver.sampling_dt;
-  if (!(dt > 0)) return mrs_tg::report_error(ctx, MRS_TG_ERR_INVALID_ARG, "the policy layer needs sampling_dt > 0 (got %g)", dt);
-  const auto t_begin = std::chrono::steady_clock::now();
-  auto elapsed = [&]() { return std::chrono::duration<double>(std::chrono::steady_clock::now() - t_begin).count(); };
-  std::vector<PathState> st((size_t)n_paths);
-  parallel_ranges((size_t)n_paths, 256, [&](size_t p0, size_t p1) {
-    for (size_t p = p0; p < p1; ++p) {
-      preprocess(waypoints + wp_offsets[p], wp_offsets[p + 1] - wp_offsets[p], o, st[p]);
-      if (st[p].n_wp <= 1) {  // "the path is empty (after postprocessing)" :676-681
-        st[p].done = true;
-        st[p].ok = false;
-      }
-    }
-  });
-  std::vector<int> active;
-  // MRS_TG_POLICY_TRACE=1: where the call's time went (host phases and the batched GPU call), on stderr
-  static const bool trace = [] {
-    const char* e = std::getenv("MRS_TG_POLICY_TRACE");
-    return e != nullptr && std::atoi(e) != 0;
-  }();
-  double t_build = 0, t_solve = 0, t_post = 0, t_validate = 0;
-  auto now = [&]() { return trace ? elapsed() : 0.0; };
-  for (int round = 0; round <= o.max_deviation_iterations; ++round) {
-    active.clear();
-    for (int p = 0; p < n_paths; ++p)
-      if (!st[p].done) active.push_back(p);
-    if (active.empty()) break;
-    // optimize() picks the solver of a round in this order (:702-716, :754-768): fallback sampling when it was asked for,
-    // fallback sampling when overtime() says the request is running late ("executing fallback sampling, we are running
-    // over time" -- the request still succeeds), else findTrajectory.  Only the checks BEHIND the solve (:1085, :1156,
-    // :1171, :1516-1522) give a request up.
-    double budget_left = 0.0;  // timeLeft() :1749-1761
-    auto overtime = [&]() {    // overtime() :1730-1743 (OVERTIME_SAFETY_FACTOR 0.95, OVERTIME_SAFETY_OFFSET 0.01 s)
-      return o.max_execution_time_s > 0 && elapsed() > 0.95 * o.max_execution_time_s - 0.01;
-    };
-    bool use_fallback = o.fallback_sampling != 0;
-    if (!use_fallback && o.max_execution_time_s > 0) {
-      const double spent = elapsed();
-      budget_left = spent >= o.max_execution_time_s ? 0.0 : o.max_execution_time_s - spent;
-      use_fallback = overtime();
-    }
-    // the requests are independent: one that cannot be solved (its deviation loop has subdivided it beyond the longest
-    // path a plan takes; the reference has no such limit) fails on its own and leaves the others alone
-    if (!use_fallback) {
-      size_t kept = 0;
-      for (int p : active) {
-        if (st[p].n_wp - 1 > MRS_TG_MAX_SEGMENTS) {
-          st[p].done = true;
-          st[p].ok = false;
-          st[p].n_samples = 0;
-        } else {
-          active[kept++] = p;
-        }
-      }
-      active.resize(kept);
-      if (active.empty()) break;
-    }
-    // ---- solve every active path (one batched GPU call, or the fallback sampler on the host)
-    if (use_fallback) {
-      for (int p : active) {
-        double* out = samples_out + (size_t)p * sample_capacity * 4;
-        const int ns = fallback_sampling(st[p], limits + (size_t)p * 9, relax_heading && relax_heading[p], o, dt, out, sample_capacity);
-        st[p].n_samples = ns;
-        st[p].ok = ns <= sample_capacity;
-        if (!st[p].ok) st[p].done = true;
-      }
-    } else {
-      // vertices exactly as findTrajectory builds them (:923-977).  The arrays of the round live in ONE block of pinned
-      // host memory kept by the context (no allocation, no page faults and no clearing of a 64 KB sample buffer per
-      // request and round; the GPU reads and writes pinned arrays in place, and only the sample rows a path has produced
-      // travel); the coefficients, which the policy never reads, stay on the device
-      const double t0 = now();
-      const size_t A = active.size();
-      std::vector<int32_t> so(A + 1, 0);
-      for (size_t a = 0; a < A; ++a) so[a + 1] = so[a] + st[active[a]].n_wp - 1;
-      const size_t nS = (size_t)so.back(), nV = nS + A;
-      auto up = [](size_t bytes) { return (bytes + 255) & ~(size_t)255; };
-      const size_t b_wp = up(nV * 4 * sizeof(double)), b_vals = up(nV * 20 * sizeof(double)), b_lim = up(A * 9 * sizeof(double)),
-                   b_times = up(nS * sizeof(double)), b_smp = up(A * (size_t)sample_capacity * 4 * sizeof(double)),
-                   b_status = up(A * sizeof(int32_t)), b_ns = up(A * sizeof(int32_t)), b_mask = up(nV * 5);
-      const size_t need = b_wp + b_vals + b_lim + b_times + b_smp + b_status + b_ns + b_mask;
-      static const bool pinned_allowed = [] {  // MRS_TG_POLICY_PINNED=0: ordinary memory (test knob, read once per process)
-        const char* e = std::getenv("MRS_TG_POLICY_PINNED");
-        return e == nullptr || std::atoi(e) != 0;
-      }();
-      char* block = pinned_allowed ? static_cast<char*>(mrs_tg::ctx_host_scratch(ctx, need)) : nullptr;
-      std::vector<char> pageable;  // (the runtime refused that much pinned memory: ordinary memory, copied by the runtime)
-      if (!block) {
-        pageable.resize(need);
-        block = pageable.data();
-      }
-      double* wp = reinterpret_cast<double*>(block);
-      double* vals = reinterpret_cast<double*>(block + b_wp);
-      double* lim = reinterpret_cast<double*>(block + b_wp + b_vals);
-      double* times = reinterpret_cast<double*>(block + b_wp + b_vals + b_lim);
-      double* smp = reinterpret_cast<double*>(block + b_wp + b_vals + b_lim + b_times);
-      int32_t* status = reinterpret_cast<int32_t*>(block + b_wp + b_vals + b_lim + b_times + b_smp);
-      int32_t* ns = reinterpret_cast<int32_t*>(block + b_wp + b_vals + b_lim + b_times + b_smp + b_status);
-      uint8_t* mask = reinterpret_cast<uint8_t*>(block + b_wp + b_vals + b_lim + b_times + b_smp + b_status + b_ns);
-      parallel_ranges(A, 128, [&](size_t a0, size_t a1) {
-        std::vector<double> tb;
-        for (size_t a = a0; a < a1; ++a) {
-          const int p = active[a];
-          const PathState& s = st[p];
-          const bool has_init = has_initial_state && has_initial_state[p] && initial_states;
-          const size_t v0 = (size_t)so[a] + a;
-          std::memset(vals + v0 * 20, 0, sizeof(double) * 20 * (size_t)s.n_wp);
-          std::memset(mask + v0 * 5, 0, 5 * (size_t)s.n_wp);
-          std::memset(times + so[a], 0, sizeof(double) * (size_t)(s.n_wp - 1));
-          double last_heading = has_init ? initial_states[p].heading : s.wps[3];
-          for (int i = 0; i < s.n_wp; ++i) {
-            double* w = wp + (v0 + i) * 4;
-            for (int k = 0; k < 3; ++k) w[k] = s.wps[(size_t)i * 4 + k];
-            w[3] = sradians_unwrap(s.wps[(size_t)i * 4 + 3], last_heading);
-            last_heading = w[3];
-            uint8_t* m = mask + (v0 + i) * 5;
-            double* vv = vals + (v0 + i) * 20;
-            m[0] = 1;
-            for (int k = 0; k < 4; ++k) vv[k] = w[k];
-            if (i == 0 || i == s.n_wp - 1) {
-              for (int k = 1; k <= d; ++k) m[k] = 1;
-              if (i == 0 && has_init) {
-                m[1] = m[2] = m[3] = 1;
-                for (int k = 0; k < 4; ++k) {
-                  vv[4 + k] = initial_states[p].velocity[k];
-                  vv[8 + k] = initial_states[p].acceleration[k];
-                  vv[12 + k] = initial_states[p].jerk[k];
-                }
-              }
-            } else if (s.stop[i]) {
-              m[1] = m[2] = m[3] = 1;
-            }
-          }
-          for (int k = 0; k < 9; ++k) lim[a * 9 + k] = limits[(size_t)p * 9 + k];
-          if (relax_heading && relax_heading[p]) lim[a * 9 + 2] = lim[a * 9 + 5] = lim[a * 9 + 8] = (double)FLT_MAX;
-          estimate_times_baca(s.n_wp - 1, wp + v0 * 4, lim + a * 9, tb);
-          double tot = 0;
-          for (double t : tb) tot += t;
-          st[p].baca_total = tot;
-        }
-      });
-      mrs_tg_options so_opt = o.solver;
-      so_opt.estimate_times = 1;
-      so_opt.sample_capacity = sample_capacity;
-      if (o.max_execution_time_s > 0) so_opt.max_time_s = 2.0 * 0.95 * budget_left;  // :899
-      const double t1 = now();
-      t_build += t1 - t0;
-      const int rc = mrs_tg::solve_batch_samples_only(ctx, (int32_t)A, so.data(), wp, mask, vals, lim, &so_opt, times, status, ns, smp);
-      if (rc != MRS_TG_OK) return rc;
-      const double t2 = now();
-      t_solve += t2 - t1;
-      const bool late = overtime();  // findTrajectory's own checks behind optimize() and the sampler: "return {}" (:1085, :1156, :1171)
-      parallel_ranges(A, 128, [&](size_t a0, size_t a1) {
-        for (size_t a = a0; a < a1; ++a) {
-          const int p = active[a];
-          bool ok = !late && ((status[a] >= 1 && status[a] != 6) || status[a] == -1);  // :1138-1149
-          const double len = (double)ns[a] * dt;                            // :1178-1199
-          if (ok && len > 1.0 && (len > o.max_trajectory_len_factor * st[p].baca_total || len < o.min_trajectory_len_factor * st[p].baca_total))
-            ok = false;
-          if (ns[a] > sample_capacity) ok = false;
-          st[p].ok = ok;
-          st[p].n_samples = ok ? ns[a] : 0;
-          if (!ok) {
-            st[p].done = true;  // "failed to find trajectory" :720-727, :771-778
-          } else {
-            std::memcpy(samples_out + (size_t)p * sample_capacity * 4, smp + a * (size_t)sample_capacity * 4,
-                        sizeof(double) * 4 * (size_t)ns[a]);
-          }
-        }
-      });
-      t_post += now() - t2;
-    }
-    if (round == o.max_deviation_iterations) break;  // the last re-solve is not validated again (:729)
-    // ---- validate, subdivide the unsafe ones
-    const double t3 = now();
-    parallel_ranges(active.size(), 128, [&](size_t a0, size_t a1) {
-      std::vector<uint8_t> safe;
-      for (size_t a = a0; a < a1; ++a) {
-        const int p = active[a];
-        if (st[p].done) continue;
-        double md = 0;
-        const bool is_safe = validate_spatial(samples_out + (size_t)p * sample_capacity * 4, st[p].n_samples, st[p], o, safe, md);
-        st[p].max_dev = md;
-        if (o.check_deviation_enabled && !is_safe) {
-          insert_midpoints(st[p], safe, o);
-          st[p].iterations = round + 1;
-        } else {
-          st[p].done = true;
-        }
-      }
-    });
-    t_validate += now() - t3;
-  }
-  if (trace)
-    std::fprintf(stderr, "mrs_tg_optimize_paths: %d requests, %.3f ms: vertices + estimates %.3f, mrs_tg_solve_batch %.3f, results %.3f, "
-                 "validation + mid-points %.3f\n", n_paths, elapsed() * 1e3, t_build * 1e3, t_solve * 1e3, t_post * 1e3, t_validate * 1e3);
-  for (int p = 0; p < n_paths; ++p) {
-    const PathState& s = st[p];
-    success_out[p] = s.ok ? 1 : 0;
-    n_samples_out[p] = s.ok ? s.n_samples : 0;
-    if (max_deviation_out) max_deviation_out[p] = s.max_dev;
-    if (n_waypoints_out) n_waypoints_out[p] = s.n_wp;
-    if (iterations_out) iterations_out[p] = s.iterations;
-    if (s.ok && o.override_heading_atan2) {  // getTrajectoryReference :1582-1597
-      double* smp = samples_out + (size_t)p * sample_capacity * 4;
-      for (int it = 0; it + 1 < s.n_samples; ++it) {
-        double* a = smp + (size_t)it * 4;
-        const double* b = a + 4;
-        const double dist = std::hypot(b[1] - a[1], b[0] - a[0]);
-        if (dist < 0.05 && it > 0) a[3] = smp[(size_t)(it - 1) * 4 + 3];
-        else a[3] = std::atan2(b[1] - a[1], b[0] - a[0]);
-      }
-    }
-  }
-  return MRS_TG_OK;
-}
-
 // getWaypointInTrajectoryIdxs :1461-1499 for one path: returns the number of indices written
 int32_t mrs_tg_waypoint_trajectory_idxs(const double* samples, int32_t n_samples, const mrs_tg_waypoint* waypoints,
                                         int32_t n_waypoints, int32_t* idxs_out) {
-  if (!samples || !waypoints || !idxs_out) return 0;
-  int widx = 0, n = 0;
-  for (int i = 0; i + 1 < n_samples; ++i) {
-    if (dist_from_segment(waypoints[widx].coords, samples + (size_t)i * 4, samples + (size_t)(i + 1) * 4) < 0.1) {
-      idxs_out[n++] = i;
-      ++widx;
-    }
-    if (widx == n_waypoints) break;
+  return mrs_tg::policy::waypoint_trajectory_idxs(samples, n_samples, waypoints, n_waypoints, idxs_out);
+}
+
+// estimateSegmentTimesBaca (src/eth_trajectory_generation/vertex.cpp:301-485) for one path's vertices, as findTrajectory calls it
+// (:1048-1049): waypoints [n_waypoints][4] with headings ALREADY unwrapped, limits9 after relax_heading
+int mrs_tg_estimate_times_baca(const double* waypoints, int32_t n_waypoints, const double* limits9, double* seg_times_out) {
+  if (!waypoints || !limits9 || !seg_times_out || n_waypoints < 2)
+    return mrs_tg::report_error(nullptr, MRS_TG_ERR_INVALID_ARG, "mrs_tg_estimate_times_baca: need >= 2 waypoints, limits and an output array");
+  try {
+    std::vector<double> t;
+    mrs_tg::policy::estimate_times_baca(n_waypoints - 1, waypoints, limits9, t);
+    std::memcpy(seg_times_out, t.data(), sizeof(double) * t.size());
+  } catch (const std::bad_alloc&) {
+    return mrs_tg::report_error(nullptr, MRS_TG_ERR_NOMEM, "out of host memory");
   }
-  return n;
+  return MRS_TG_OK;
 }
 
 }  // extern "C"

@@ -33,7 +33,7 @@ extern "C" {
 #define MTO_N 10    /* coefficients per polynomial   (src/mrs_trajectory_generation.cpp:1063) */
 #define MTO_D 4     /* dimensions x,y,z,heading      (src/mrs_trajectory_generation.cpp:902)  */
 #define MTO_HALF 5  /* derivative slots per segment end (N/2) */
-#define MTO_MAX_SEG 128
+#define MTO_MAX_SEG 256 /* = MRS_TG_MAX_SEGMENTS of the product (include/mrs_tg.h) */
 #define MTO_RUNAWAY_TIME_FACTOR 25.0 /* see solve_one in mto_nonlinear.c */
 
 /* nlopt-style result codes (nlopt.h; gate at src/mrs_trajectory_generation.cpp:1138-1149) */
@@ -90,6 +90,10 @@ void mto_set_arithmetic(int mode);
  * reference, which returns the outer loop's code and discards the trajectory by the nodelet's length check); 0 (default): the
  * reference's behaviour. */
 void mto_set_runaway_rule(int on);
+/* 1: the QR solve of R_pp runs every loop over its full dense range; 0 (default): the same loops limited to the band of
+ * R_pp outside of which every operand is an exact zero -- bit-identical results (mto_linear.c qr_solve), O(n) instead of
+ * O(n^3) in the path length */
+void mto_set_dense_qr(int on);
 int mto_get_arithmetic(void);
 /* the unit-time tables of route 1: ABAR^-1 [10][10], HBAR_d [5][10][10] (113-bit arithmetic, rounded once) */
 void mto_unit_tables(double* abar_inv_out, double* hbar_out);
@@ -230,6 +234,13 @@ int mto_validate_trajectory_spatial(const double* samples, int n_samples, const 
 int mto_waypoint_trajectory_idxs(const double* samples, int n_samples, const double* wps, int n_wp, int32_t* idxs); /* :1461-1499 */
 int mto_fallback_sampling(const double* wps, const uint8_t* stop_at, int n_wp, const double* limits9, int relax_heading,
                           const mto_policy_params* prm, double dt, double* out, int capacity);    /* :1215-1395 */
+/* findTrajectory() :857-1209 for one (already preprocessed) path, both gates included: returns 1 where the reference returns
+ * the states.  seg_times_out / status_out / baca_total_out / raw_n_samples_out / rejection_out may be NULL
+ * (rejection: 0 accepted, 1 optimiser code, 2 too long, 3 too short, 4 more samples than capacity). */
+int mto_find_trajectory(const double* wps, const uint8_t* stop_at, int n_wp, const double* initial_state, const double* limits9,
+                        int relax_heading, const mto_options* sopt, const mto_policy_params* prm, double* samples_out,
+                        int capacity, int* n_samples_out, double* seg_times_out, int32_t* status_out, double* baca_total_out,
+                        int* raw_n_samples_out, int* rejection_out);
 /* optimize() :620-851 for one path. wps_in [n_in][4] (first = initial condition when initial_state != NULL),
  * initial_state = {heading, velocity[4], acceleration[4], jerk[4]} or NULL. samples_out [capacity][4].
  * Returns success (1/0). */

@@ -260,44 +260,80 @@ void mto_segment_hessian(int derivative, double T, double* Hout, double* Ainv_ou
   if (Ainv_out) memcpy(Ainv_out, Ai, sizeof(Ai));
 }
 
-/* dense Householder QR solve of M x = B (M n x n, B n x nrhs, both overwritten; X returned in B) */
+/* Dense Householder QR solve of M x = B (M n x n, B n x nrhs, both overwritten; X returned in B).
+ *
+ * R_pp is block-tridiagonal: outside a band of a few entries either side of the diagonal it holds EXACT
+ * zeros (never written after the zero fill).  The reflection of column c only mixes rows c .. c + bl (bl = lower band
+ * width) and, in those rows, columns c .. c + bl + bu (bu = upper band width: the fill of earlier reflections included);
+ * every operation outside that window multiplies by, adds or subtracts an exact zero and leaves its operand as it was.  The
+ * loops below are the dense algorithm with exactly those operations left out -- the same values to the last bit (only the
+ * sign of a structural zero can differ), in O(n (bl + bu)^2) instead of O(n^3), which is what lets the oracle follow the
+ * product to 256-segment paths (n = 1020).  mto_set_dense_qr(1) runs every loop over its full dense range again
+ * (tests/test_oracle_properties.py compares the two bit for bit). */
+static int g_dense_qr = 0;
+void mto_set_dense_qr(int on) { g_dense_qr = on; }
+
+static void band_widths(const double* M, int n, int* bl_out, int* bu_out) {
+  int bl = 0, bu = 0;
+  for (int r = 0; r < n; ++r) {
+    const double* row = M + (size_t)r * n;
+    for (int c = 0; c < r - bl; ++c)
+      if (row[c] != 0.0) {
+        bl = r - c;
+        break;
+      }
+    for (int c = n - 1; c > r + bu; --c)
+      if (row[c] != 0.0) {
+        bu = c - r;
+        break;
+      }
+  }
+  *bl_out = bl;
+  *bu_out = bu;
+}
+
 static int qr_solve(double* M, int n, double* B, int nrhs) {
   const mto_scratch_state mark = mto_scratch_mark();
   double* v = (double*)mto_scratch_alloc(sizeof(double) * (size_t)n, 0);
   if (!v) return -1;
+  int bl = n, bu = n;
+  if (!g_dense_qr) band_widths(M, n, &bl, &bu);
   for (int c = 0; c < n; ++c) {
+    const int rend = (c + bl < n - 1) ? c + bl + 1 : n;                 /* rows c .. rend - 1 */
+    const int jend = ((long)c + bl + bu < n - 1) ? c + bl + bu + 1 : n; /* columns c .. jend - 1 */
     double norm = 0.0;
-    for (int r = c; r < n; ++r) norm += M[r * n + c] * M[r * n + c];
+    for (int r = c; r < rend; ++r) norm += M[(size_t)r * n + c] * M[(size_t)r * n + c];
     norm = sqrt(norm);
     if (norm == 0.0) {
       mto_scratch_release(mark);
       return -2;
     }
-    const double alpha = (M[c * n + c] > 0) ? -norm : norm;
-    for (int r = c; r < n; ++r) v[r] = M[r * n + c];
+    const double alpha = (M[(size_t)c * n + c] > 0) ? -norm : norm;
+    for (int r = c; r < rend; ++r) v[r] = M[(size_t)r * n + c];
     v[c] -= alpha;
     double vnorm2 = 0.0;
-    for (int r = c; r < n; ++r) vnorm2 += v[r] * v[r];
+    for (int r = c; r < rend; ++r) vnorm2 += v[r] * v[r];
     if (vnorm2 > 0.0) {
-      for (int j = c; j < n; ++j) {
+      for (int j = c; j < jend; ++j) {
         double dot = 0.0;
-        for (int r = c; r < n; ++r) dot += v[r] * M[r * n + j];
+        for (int r = c; r < rend; ++r) dot += v[r] * M[(size_t)r * n + j];
         const double f = 2.0 * dot / vnorm2;
-        for (int r = c; r < n; ++r) M[r * n + j] -= f * v[r];
+        for (int r = c; r < rend; ++r) M[(size_t)r * n + j] -= f * v[r];
       }
       for (int j = 0; j < nrhs; ++j) {
         double dot = 0.0;
-        for (int r = c; r < n; ++r) dot += v[r] * B[r * nrhs + j];
+        for (int r = c; r < rend; ++r) dot += v[r] * B[(size_t)r * nrhs + j];
         const double f = 2.0 * dot / vnorm2;
-        for (int r = c; r < n; ++r) B[r * nrhs + j] -= f * v[r];
+        for (int r = c; r < rend; ++r) B[(size_t)r * nrhs + j] -= f * v[r];
       }
     }
   }
   for (int j = 0; j < nrhs; ++j)
     for (int r = n - 1; r >= 0; --r) {
-      double s = B[r * nrhs + j];
-      for (int k = r + 1; k < n; ++k) s -= M[r * n + k] * B[k * nrhs + j];
-      B[r * nrhs + j] = s / M[r * n + r];
+      const int kend = ((long)r + bl + bu < n - 1) ? r + bl + bu + 1 : n;
+      double s = B[(size_t)r * nrhs + j];
+      for (int k = r + 1; k < kend; ++k) s -= M[(size_t)r * n + k] * B[(size_t)k * nrhs + j];
+      B[(size_t)r * nrhs + j] = s / M[(size_t)r * n + r];
     }
   mto_scratch_release(mark);
   return 0;
@@ -314,39 +350,64 @@ static __thread struct {
   int valid;
 } tl_quad_cost;
 
+static void band_widths_q(const q_t* M, int n, int* bl_out, int* bu_out) {
+  int bl = 0, bu = 0;
+  for (int r = 0; r < n; ++r) {
+    const q_t* row = M + (size_t)r * n;
+    for (int c = 0; c < r - bl; ++c)
+      if (row[c] != 0) {
+        bl = r - c;
+        break;
+      }
+    for (int c = n - 1; c > r + bu; --c)
+      if (row[c] != 0) {
+        bu = c - r;
+        break;
+      }
+  }
+  *bl_out = bl;
+  *bu_out = bu;
+}
+
+/* (the band-limited loops of qr_solve, see there) */
 static int qr_solve_q(q_t* M, int n, q_t* B, int nrhs, q_t* v) {
+  int bl = n, bu = n;
+  if (!g_dense_qr) band_widths_q(M, n, &bl, &bu);
   for (int c = 0; c < n; ++c) {
+    const int rend = (c + bl < n - 1) ? c + bl + 1 : n;
+    const int jend = ((long)c + bl + bu < n - 1) ? c + bl + bu + 1 : n;
     q_t norm2 = 0;
-    for (int r = c; r < n; ++r) norm2 += M[r * n + c] * M[r * n + c];
+    for (int r = c; r < rend; ++r) norm2 += M[(size_t)r * n + c] * M[(size_t)r * n + c];
     if (norm2 == 0) return -2;
     /* sqrt by Newton from the double estimate */
     q_t norm = (q_t)sqrt((double)norm2);
     for (int it = 0; it < 3; ++it) norm = (norm + norm2 / norm) / 2;
-    const q_t alpha = (M[c * n + c] > 0) ? -norm : norm;
-    for (int r = c; r < n; ++r) v[r] = M[r * n + c];
+    const q_t alpha = (M[(size_t)c * n + c] > 0) ? -norm : norm;
+    for (int r = c; r < rend; ++r) v[r] = M[(size_t)r * n + c];
     v[c] -= alpha;
     q_t vnorm2 = 0;
-    for (int r = c; r < n; ++r) vnorm2 += v[r] * v[r];
+    for (int r = c; r < rend; ++r) vnorm2 += v[r] * v[r];
     if (vnorm2 > 0) {
-      for (int j = c; j < n; ++j) {
+      for (int j = c; j < jend; ++j) {
         q_t dot = 0;
-        for (int r = c; r < n; ++r) dot += v[r] * M[r * n + j];
+        for (int r = c; r < rend; ++r) dot += v[r] * M[(size_t)r * n + j];
         const q_t f = 2 * dot / vnorm2;
-        for (int r = c; r < n; ++r) M[r * n + j] -= f * v[r];
+        for (int r = c; r < rend; ++r) M[(size_t)r * n + j] -= f * v[r];
       }
       for (int j = 0; j < nrhs; ++j) {
         q_t dot = 0;
-        for (int r = c; r < n; ++r) dot += v[r] * B[r * nrhs + j];
+        for (int r = c; r < rend; ++r) dot += v[r] * B[(size_t)r * nrhs + j];
         const q_t f = 2 * dot / vnorm2;
-        for (int r = c; r < n; ++r) B[r * nrhs + j] -= f * v[r];
+        for (int r = c; r < rend; ++r) B[(size_t)r * nrhs + j] -= f * v[r];
       }
     }
   }
   for (int j = 0; j < nrhs; ++j)
     for (int r = n - 1; r >= 0; --r) {
-      q_t s = B[r * nrhs + j];
-      for (int k = r + 1; k < n; ++k) s -= M[r * n + k] * B[k * nrhs + j];
-      B[r * nrhs + j] = s / M[r * n + r];
+      const int kend = ((long)r + bl + bu < n - 1) ? r + bl + bu + 1 : n;
+      q_t s = B[(size_t)r * nrhs + j];
+      for (int k = r + 1; k < kend; ++k) s -= M[(size_t)r * n + k] * B[(size_t)k * nrhs + j];
+      B[(size_t)r * nrhs + j] = s / M[(size_t)r * n + r];
     }
   return 0;
 }

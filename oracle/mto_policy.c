@@ -217,10 +217,15 @@ void mto_default_policy_params(mto_policy_params* p) {
   p->override_heading_atan2 = 0;
 }
 
-/* findTrajectory for one waypoint list: vertices (:923-977), estimate, optimise, sample, length check */
-static int find_trajectory(const double* wps_raw, const uint8_t* stop_at, int n_wp, const double* init /*13 or NULL*/,
-                           const double* limits9, int relax_heading, const mto_options* sopt, const mto_policy_params* prm,
-                           double* samples, int capacity, int* n_samples_out) {
+/* findTrajectory for one waypoint list (src/mrs_trajectory_generation.cpp:857-1209): vertices (:923-977), limits (:985-1038),
+ * Euclidean + Baca estimates (:1046-1056), optimise (:1083), the gate on the optimiser's code (:1138-1149), sampling (:1169),
+ * the length check (:1178-1199).  Returns 1 where the reference returns the states, 0 where it returns {}.
+ * seg_times_out [n_wp - 1], status_out, baca_total_out, raw_n_samples_out (the sample count before the gates) may be NULL;
+ * *rejection_out: 0 accepted, 1 code, 2 too long, 3 too short, 4 more samples than `capacity`. */
+int mto_find_trajectory(const double* wps_raw, const uint8_t* stop_at, int n_wp, const double* init /*13 or NULL*/,
+                        const double* limits9, int relax_heading, const mto_options* sopt, const mto_policy_params* prm,
+                        double* samples, int capacity, int* n_samples_out, double* seg_times_out, int32_t* status_out,
+                        double* baca_total_out, int* raw_n_samples_out, int* rejection_out) {
   const int S = n_wp - 1, d = sopt->derivative_to_optimize;
   double* wp = (double*)malloc(sizeof(double) * 4 * (size_t)n_wp);
   uint8_t* mask = (uint8_t*)calloc((size_t)n_wp * 5, 1);
@@ -259,11 +264,27 @@ static int find_trajectory(const double* wps_raw, const uint8_t* stop_at, int n_
   mto_options o = *sopt;
   o.estimate_times = 1;
   mto_solve_batch(1, so, wp, mask, vals, lim, &o, times, coeffs, &status, &cost, &ns, samples, capacity, 1);
+  int rejection = 0;
   int ok = (status >= 1 && status != 6) || status == -1; /* :1138-1149 */
+  if (!ok) rejection = 1;
   const double len = (double)ns * sopt->sampling_dt;     /* :1178-1199 */
-  if (ok && len > 1.0 && (len > prm->max_trajectory_len_factor * total_baca || len < prm->min_trajectory_len_factor * total_baca)) ok = 0;
-  if (ns > capacity) ok = 0;
+  if (ok && len > 1.0 && len > prm->max_trajectory_len_factor * total_baca) {
+    ok = 0;
+    rejection = 2;
+  } else if (ok && len > 1.0 && len < prm->min_trajectory_len_factor * total_baca) {
+    ok = 0;
+    rejection = 3;
+  }
+  if (ok && ns > capacity) {
+    ok = 0;
+    rejection = 4;
+  }
   *n_samples_out = ok ? ns : 0;
+  if (seg_times_out) memcpy(seg_times_out, times, sizeof(double) * (size_t)S);
+  if (status_out) *status_out = status;
+  if (baca_total_out) *baca_total_out = total_baca;
+  if (raw_n_samples_out) *raw_n_samples_out = ns;
+  if (rejection_out) *rejection_out = rejection;
   free(wp);
   free(mask);
   free(vals);
@@ -271,6 +292,13 @@ static int find_trajectory(const double* wps_raw, const uint8_t* stop_at, int n_
   free(coeffs);
   free(t_baca);
   return ok;
+}
+
+static int find_trajectory(const double* wps_raw, const uint8_t* stop_at, int n_wp, const double* init /*13 or NULL*/,
+                           const double* limits9, int relax_heading, const mto_options* sopt, const mto_policy_params* prm,
+                           double* samples, int capacity, int* n_samples_out) {
+  return mto_find_trajectory(wps_raw, stop_at, n_wp, init, limits9, relax_heading, sopt, prm, samples, capacity, n_samples_out,
+                             NULL, NULL, NULL, NULL, NULL);
 }
 
 int mto_optimize_path(const double* wps_in, const uint8_t* stop_in, int n_in, const double* initial_state,

@@ -183,6 +183,33 @@ def optimize_path(waypoints, stop_at=None, initial_state=None, limits=None, rela
                 n_waypoints=nw.value, iterations=it.value)
 
 
+def find_trajectory(waypoints, stop_at=None, initial_state=None, limits=None, relax_heading=False, policy=None, deriv=2,
+                    time_alloc_method=2, max_iterations=10, sampling_dt=0.2, capacity=4096):
+    """findTrajectory() for one path, both gates included (mto_find_trajectory). Returns dict(success, samples, n_samples,
+    times, status, baca_total_time, raw_n_samples, rejection)."""
+    w = _f64(waypoints).reshape(-1, 4)
+    n = w.shape[0]
+    st = np.ascontiguousarray(stop_at if stop_at is not None else np.zeros(n), dtype=np.uint8)
+    init = None
+    if initial_state is not None:
+        init = _f64(np.concatenate([[initial_state["heading"]], initial_state["velocity"], initial_state["acceleration"],
+                                    initial_state["jerk"]]))
+    lim = _f64(limits)
+    pol = policy or default_policy()
+    opt = make_options(deriv, time_alloc_method, 1, max_iterations, sampling_dt)
+    out = np.zeros((capacity, 4))
+    times = np.zeros(n - 1)
+    ns, raw, rej, status = C.c_int(0), C.c_int(0), C.c_int(0), C.c_int32(0)
+    baca = C.c_double(0)
+    f = lib().mto_find_trajectory
+    f.restype = C.c_int
+    ok = f(_dp(w), st.ctypes.data_as(C.POINTER(C.c_uint8)), C.c_int(n), _dp(init) if init is not None else None, _dp(lim),
+           C.c_int(int(bool(relax_heading))), C.byref(opt), C.byref(pol), _dp(out), C.c_int(capacity), C.byref(ns), _dp(times),
+           C.byref(status), C.byref(baca), C.byref(raw), C.byref(rej))
+    return dict(success=int(ok), samples=out[:ns.value].copy(), n_samples=ns.value, times=times, status=status.value,
+                baca_total_time=baca.value, raw_n_samples=raw.value, rejection=rej.value)
+
+
 def _dp(a):
     return a.ctypes.data_as(C.POINTER(C.c_double))
 

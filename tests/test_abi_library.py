@@ -32,13 +32,15 @@ def test_every_declared_symbol_is_exported(lib):
 
 
 def test_abi_version_and_default_options(lib):
-    assert lib.mrs_tg_abi_version() == 4
+    assert lib.mrs_tg_abi_version() == 5
     opt = api.default_options()
     # defaults follow the reference's parameters (src/mrs_trajectory_generation.cpp:884-885,
     # config/private/trajectory_generation.yaml:10)
     assert (opt.f_rel, opt.x_rel, opt.max_iterations) == (0.05, 0.1, 10)
     assert opt.f_abs == -1.0 and opt.x_abs == -1.0 and opt.time_alloc_method == -1
-    assert C.sizeof(api.Options) == 104 and opt.max_time_s == 0.0 and opt.flags == 0
+    assert C.sizeof(api.Options) == 120 and opt.max_time_s == 0.0 and opt.flags == 0
+    # (ABI 5) the length check of the single-path seam: config/public/trajectory_generation.yaml:35-36
+    assert (opt.max_trajectory_len_factor, opt.min_trajectory_len_factor) == (3.0, 0.33)
     assert (opt.time_penalty, opt.soft_constraint_weight, opt.use_soft_constraints, opt.initial_stepsize_rel) == (100.0, 1.5, 1, 0.1)
 
 

@@ -76,10 +76,13 @@ def test_long_paths_one_per_tile(gpu_ctx):
     assert np.all(np.isin(nl["status"], (1, 3, 4, 5))) and np.all(np.isfinite(nl["coeffs"]))
 
 
-@pytest.mark.parametrize("n_seg", [129, 200, 218, 219])
+@pytest.mark.parametrize("n_seg", [129, 200, 218, 219, 256])
 def test_long_paths_tile_and_lane_kernels_agree(gpu_ctx, monkeypatch, n_seg):
-    """Beyond the oracle's 128 segments: an LDS tile holds a path of up to 218 segments (one path per workgroup);
-    longer ones go to the lane kernels.  Both must give the same trajectory, continuous and on its constraints."""
+    """129 .. 256 segments (MRS_TG_MAX_SEGMENTS; what the reference's subdivision loop can grow a request to): an LDS tile holds
+    a path of up to 218 segments (one path per workgroup); longer ones go to the lane kernels.  Both must give the same
+    trajectory, continuous and on its constraints -- and it must be the ORACLE's (round 6: the oracle follows the product to
+    256 segments; its QR solve skips the exact zeros outside R_pp's band, bit-identical to the dense loops), in the
+    reference's arithmetic and in the 113-bit route."""
     batch = pr.random_batch(3, n_seg, seed0=8300 + n_seg)
     out = gpu_ctx.solve_batch(batch, None, flags=api.FLAG_MATERIALIZED_BLOCKS)
     fused = gpu_ctx.solve_batch(batch, out["times"])
@@ -91,6 +94,51 @@ def test_long_paths_tile_and_lane_kernels_agree(gpu_ctx, monkeypatch, n_seg):
     assert util.coeff_error(fused["coeffs"], lane["coeffs"], batch.seg_offsets) < 1e-8
     assert util.continuity_defect(batch, out["coeffs"], out["times"]) < 1e-8
     assert util.constraint_defect(batch, out["coeffs"], out["times"]) < 1e-8
+    # the oracle at the same times: the reference-style double route (its own error grows with the path: 1e-6), and the
+    # 113-bit route, where what is left is the HIP path's error
+    assert np.array_equal(out["times"], util.oracle_times(batch))
+    ref = util.oracle_linear(batch, out["times"])
+    po.lib().mto_set_arithmetic(po.QUAD_PRECISION)
+    try:
+        refq = util.oracle_linear(batch, out["times"])
+    finally:
+        po.lib().mto_set_arithmetic(po.REFERENCE_ARITHMETIC)
+    for name, got in (("blocks", out), ("fused", fused), ("lane", lane)):
+        e, eq = util.coeff_error(got["coeffs"], ref["coeffs"], batch.seg_offsets), util.coeff_error(got["coeffs"], refq["coeffs"], batch.seg_offsets)
+        print("ERR long linear S=%d %s: vs oracle %.2e, vs 113-bit %.2e" % (n_seg, name, e, eq))
+        assert e < 1e-6 and eq < 1e-9, (name, e, eq)
+        assert np.max(np.abs(got["cost"] - refq["cost"]) / np.abs(refq["cost"])) < 1e-9
+
+
+@pytest.mark.parametrize("deriv,n_seg,moving", [(4, 129, False), (2, 200, True), (2, 256, False), (4, 256, True)])
+def test_long_paths_mellinger_vs_oracle(gpu_ctx, deriv, n_seg, moving):
+    """The whole Mellinger pipeline (outer loop, feasibility scaling, sampling) on paths of 129 .. 256 segments against the
+    oracle: status on the reference's rule, times 1e-6, coefficients 1e-6, sample counts equal, samples 1e-6 m.
+    (The oracle needs ~1-3 s per path of this length.)"""
+    batch = pr.random_batch(6, n_seg, seed0=8600 + n_seg, derivative_to_optimize=deriv)
+    if moving:
+        batch = _moving(batch, seed=11)
+    cap = 8192
+    out = gpu_ctx.solve_batch(batch, None, time_alloc_method=api.TIME_ALLOC_MELLINGER, sampling_dt=0.2, sample_capacity=cap)
+    ref = po.solve_batch(batch.seg_offsets, batch.waypoints, batch.fixed_mask, batch.fixed_values, batch.limits,
+                         np.zeros(batch.n_segments), deriv=deriv, time_alloc_method=2, estimate_times=True, sampling_dt=0.2,
+                         sample_capacity=cap, n_threads=6)
+    so = batch.seg_offsets
+    good = 0
+    for p in range(batch.n_paths):
+        a, b = so[p], so[p + 1]
+        ok = util.status_matches(out["status"][p], ref["status"][p])
+        ok &= np.max(np.abs(out["times"][a:b] - ref["times"][a:b]) / ref["times"][a:b]) < 1e-6
+        ok &= util.coeff_error(out["coeffs"][a:b], ref["coeffs"][a:b]) < 1e-6
+        ok &= int(out["n_samples"][p]) == int(ref["n_samples"][p])
+        if ok:
+            n = min(int(ref["n_samples"][p]), cap)
+            ok &= np.max(np.abs(out["samples"][p, :n, :3] - ref["samples"][p, :n, :3])) < 1e-6
+        good += bool(ok)
+    print("RATE long mellinger d=%d S=%d moving %s: %d / %d" % (deriv, n_seg, moving, good, batch.n_paths))
+    assert good >= batch.n_paths - 1, good
+    assert util.continuity_defect(batch, out["coeffs"], out["times"]) < 1e-8
+    assert util.constraint_defect(batch, out["coeffs"], out["times"]) < 1e-8
 
 
 def test_longest_accepted_path_and_one_beyond(gpu_ctx):
@@ -99,6 +147,10 @@ def test_longest_accepted_path_and_one_beyond(gpu_ctx):
                               sample_capacity=64)
     assert np.all(np.isin(out["status"], (1, 3, 4, 5))) and np.all(np.isfinite(out["coeffs"]))
     assert util.continuity_defect(batch, out["coeffs"], out["times"]) < 1e-8
+    ref = po.solve_batch(batch.seg_offsets, batch.waypoints, batch.fixed_mask, batch.fixed_values, batch.limits,
+                         np.zeros(batch.n_segments), deriv=4, time_alloc_method=2, estimate_times=True, max_iterations=3, n_threads=2)
+    assert all(util.status_matches(o, r) for o, r in zip(out["status"], ref["status"]))
+    assert np.max(np.abs(out["times"] - ref["times"]) / ref["times"]) < 1e-6
     with pytest.raises(api.MrsTgError, match="at most 256"):
         gpu_ctx.solve_batch(pr.random_batch(1, 257, seed0=1), None)
 

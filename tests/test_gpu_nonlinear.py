@@ -287,16 +287,98 @@ def test_start_below_lower_bound_reports_failure(gpu_ctx):
     assert out["status"][1] == -1 and np.all(out["status"][[0, 2, 3]] >= 1)
 
 
-def test_find_trajectory_single_path(gpu_ctx):
-    r = gpu_ctx.find_trajectory(pr.CONFIG1_WAYPOINTS)
-    assert r["status"] >= 1 and r["n_samples"] > 10
-    # the samples visit every waypoint within 0.5 m in order (get_path_test.h:10-11,27-87)
-    idx = 0
-    for w in pr.CONFIG1_WAYPOINTS:
-        dist = np.linalg.norm(r["samples"][idx:, :3] - w[:3], axis=1)
-        hit = np.nonzero(dist < 0.5)[0]
-        assert hit.size, w
-        idx += int(hit[0])
+def _find_vs_oracle(gpu_ctx, wp, deriv, **kw):
+    """mrs_tg_find_trajectory and the oracle's findTrajectory (oracle/mto_policy.c::mto_find_trajectory, the function its
+    optimize() loop calls per round) on one request; returns both results after the comparisons every case shares"""
+    pol = po.default_policy()
+    fac = {}
+    for k in ("max_trajectory_len_factor", "min_trajectory_len_factor"):
+        if k in kw:
+            setattr(pol, k, kw[k] if kw[k] > 0 else (1e300 if k.startswith("max") else 0.0))   # (<= 0 = off in the product)
+            fac[k] = kw[k]
+    okw = {k: v for k, v in kw.items() if k in ("stop_at", "initial_state", "relax_heading")}
+    got = gpu_ctx.find_trajectory(wp, derivative_to_optimize=deriv, sample_capacity=4096, **okw, **fac)
+    ref = po.find_trajectory(wp, limits=pr.DEFAULT_LIMITS, policy=pol, deriv=deriv, capacity=4096, **okw)
+    # the Baca total is host arithmetic on both sides, the same formulas in the same order
+    assert abs(got["baca_total_time"] - ref["baca_total_time"]) <= 1e-12 * ref["baca_total_time"]
+    assert util.status_matches(got["status"], ref["status"])
+    return got, ref
+
+
+@pytest.mark.parametrize("deriv", [4, 2])
+def test_find_trajectory_single_path_matches_the_oracle(gpu_ctx, deriv):
+    """The reference tests' 4-waypoint path (get_path_test.h) and three random requests (one with stop_at waypoints and a
+    moving start, one with relax_heading) through the single-path seam: accepted by both gates on both sides, segment times
+    1e-6, sample count equal, samples 1e-6 m (heading 1e-6 rad)."""
+    rng = np.random.default_rng(77)
+    init = dict(heading=0.3, velocity=np.append(rng.uniform(-1, 1, 3), 0.1), acceleration=np.append(rng.uniform(-0.5, 0.5, 3), 0.0),
+                jerk=np.append(rng.uniform(-0.2, 0.2, 3), 0.0))
+    cases = [(pr.CONFIG1_WAYPOINTS, {}), (pr.random_box_waypoints(10, 12345), {}),
+             (pr.random_box_waypoints(7, 4242), dict(stop_at=[0, 0, 1, 0, 1, 0, 0, 0], initial_state=init)),
+             (pr.random_box_waypoints(5, 99), dict(relax_heading=True))]
+    for wp, kw in cases:
+        got, ref = _find_vs_oracle(gpu_ctx, wp, deriv, **kw)
+        assert ref["success"] == 1 and ref["rejection"] == 0
+        assert got["rejection"] == api.FIND_ACCEPTED and got["message"] == ""
+        assert got["n_samples"] == ref["n_samples"] > 10
+        assert np.max(np.abs(got["times"] - ref["times"]) / ref["times"]) < 1e-6
+        n = ref["n_samples"]
+        assert np.max(np.abs(got["samples"][:n, :3] - ref["samples"][:n, :3])) < 1e-6
+        dy = np.abs(got["samples"][:n, 3] - ref["samples"][:n, 3])
+        assert np.max(np.minimum(dy, 2 * np.pi - dy)) < 1e-6
+
+
+@pytest.mark.parametrize("seed", [2843, 4660])
+def test_find_trajectory_discards_a_too_long_trajectory_like_the_reference(gpu_ctx, seed):
+    """findTrajectory's temporal sanity check (src/mrs_trajectory_generation.cpp:1178-1199) INSIDE the seam.  Paths 2843 and 4660
+    of the box generator: the outer loop ends on a point whose feasibility scaling stretches the trajectory to 4.2 / 3.9
+    times its Euclidean estimate (3.12 / 3.008 times the Baca estimate) -- an accepted nlopt code, far below the product's
+    runaway factor of 25, and longer than max_trajectory_len_factor = 3.0 allows: the reference returns {}."""
+    wp = pr.random_box_waypoints(10, seed)
+    got, ref = _find_vs_oracle(gpu_ctx, wp, 4)
+    assert ref["success"] == 0 and ref["rejection"] == 2 and ref["status"] >= 1
+    assert got["status"] >= 1 and got["rejection"] == api.FIND_REJECTED_TOO_LONG and got["n_samples"] == 0
+    assert "too long" in got["message"] and "trajectory sampling failed" in got["message"]
+    assert np.max(np.abs(got["times"] - ref["times"]) / ref["times"]) < 1e-6     # (what was computed is still handed back)
+    # with the check's upper side switched off the same request comes back, sampled, on both sides
+    got2, ref2 = _find_vs_oracle(gpu_ctx, wp, 4, max_trajectory_len_factor=0.0)
+    assert ref2["success"] == 1 and got2["rejection"] == api.FIND_ACCEPTED
+    assert got2["n_samples"] == ref2["n_samples"] == ref["raw_n_samples"]
+    assert got2["n_samples"] * 0.2 > 3.0 * got2["baca_total_time"]
+    assert np.max(np.abs(got2["samples"][:, :3] - ref2["samples"][:, :3])) < 1e-6
+
+
+def test_find_trajectory_discards_the_runaway_path_8615(gpu_ctx):
+    """Path 8615 of the 65536-path batch (the feasibility scaling runs away to 1e10 times the estimate): the reference returns
+    MAXEVAL_REACHED and its length check discards the trajectory; the product names the runaway ROUNDOFF_LIMITED, which the
+    gate on the code rejects before the length check is reached.  Either way: {}."""
+    wp = pr.random_box_waypoints(10, 8615)
+    got, ref = _find_vs_oracle(gpu_ctx, wp, 4)
+    assert ref["success"] == 0 and ref["rejection"] == 2
+    assert got["n_samples"] == 0 and got["rejection"] in (api.FIND_REJECTED_CODE, api.FIND_REJECTED_TOO_LONG)
+    assert got["status"] == api.STATUS_ROUNDOFF_LIMITED or got["rejection"] == api.FIND_REJECTED_TOO_LONG
+
+
+def test_find_trajectory_discards_a_too_short_trajectory(gpu_ctx):
+    """the lower side of the check (:1188-1196) -- no random path falls below 0.33 of its Baca estimate (16384 paths: minimum
+    0.947), so the factor is raised instead: min_trajectory_len_factor = 2 rejects what 0.33 accepts"""
+    wp = pr.CONFIG1_WAYPOINTS
+    got, ref = _find_vs_oracle(gpu_ctx, wp, 2, min_trajectory_len_factor=2.0)
+    assert ref["success"] == 0 and ref["rejection"] == 3
+    assert got["rejection"] == api.FIND_REJECTED_TOO_SHORT and got["n_samples"] == 0 and "too short" in got["message"]
+    # a trajectory of less than a second is never checked (:1178: "this check does not make much sense for the short ones")
+    tiny = np.array([[0, 0, 2, 0], [0.05, 0, 2, 0]], dtype=float)
+    got, ref = _find_vs_oracle(gpu_ctx, tiny, 2, min_trajectory_len_factor=50.0)
+    assert ref["success"] == 1 and got["rejection"] == api.FIND_ACCEPTED and got["n_samples"] == ref["n_samples"] > 0
+    assert got["n_samples"] * 0.2 <= 1.0
+
+
+def test_estimate_times_baca_matches_the_oracle():
+    """mrs_tg_estimate_times_baca (host arithmetic; estimateSegmentTimesBaca, vertex.cpp:301-485) against oracle/mto_nonlinear.c"""
+    for seed in range(40):
+        wp = pr.random_box_waypoints(3 + seed % 9, 500 + seed)
+        lim = pr.DEFAULT_LIMITS * (0.5 + 0.1 * (seed % 7))
+        assert np.allclose(api.estimate_times_baca(wp, lim), po.estimate_times(wp, lim, baca=True), rtol=1e-13, atol=0)
 
 
 def test_sample_overflow_is_reported_as_capacity_plus_one(gpu_ctx):

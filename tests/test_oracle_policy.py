@@ -73,3 +73,23 @@ def test_optimize_loop_subdivides_until_safe_or_budget():
 def test_single_waypoint_path_is_rejected():
     r = po.optimize_path(np.array([[1.0, 2.0, 3.0, 0.0]]), limits=pr.DEFAULT_LIMITS)
     assert r["success"] == 0 and r["n_samples"] == 0
+
+
+def test_find_trajectory_gates_of_the_oracle():
+    """mto_find_trajectory = findTrajectory() with both gates (src/mrs_trajectory_generation.cpp:1138-1149, 1178-1199); the
+    cases tests/test_gpu_nonlinear.py sends through mrs_tg_find_trajectory.  Paths 2843 / 4660 of the box generator end 3.12 /
+    3.008 times their Baca estimate long with an accepted code: "too long"; path 8615 is the runaway of the 65536-path batch."""
+    ok = po.find_trajectory(pr.CONFIG1_WAYPOINTS, limits=pr.DEFAULT_LIMITS, deriv=4)
+    assert ok["success"] == 1 and ok["rejection"] == 0 and ok["n_samples"] == ok["raw_n_samples"] > 10
+    assert 0.33 * ok["baca_total_time"] < ok["n_samples"] * 0.2 < 3.0 * ok["baca_total_time"]
+    for seed, lo, hi in ((2843, 3.0, 3.3), (4660, 3.0, 3.05), (8615, 1e6, 1e12)):
+        r = po.find_trajectory(pr.random_box_waypoints(10, seed), limits=pr.DEFAULT_LIMITS, deriv=4, capacity=4096)
+        assert r["success"] == 0 and r["rejection"] == 2 and r["n_samples"] == 0 and r["status"] >= 1
+        if seed != 8615:
+            assert lo < r["raw_n_samples"] * 0.2 / r["baca_total_time"] < hi
+    short = po.find_trajectory(pr.CONFIG1_WAYPOINTS, limits=pr.DEFAULT_LIMITS, deriv=2,
+                               policy=po.default_policy(min_trajectory_len_factor=2.0))
+    assert short["success"] == 0 and short["rejection"] == 3
+    # optimize() is a loop around exactly this function: one round without the deviation check gives the same samples
+    one = po.optimize_path(pr.CONFIG1_WAYPOINTS, limits=pr.DEFAULT_LIMITS, deriv=4, policy=po.default_policy(check_deviation_enabled=0))
+    assert one["n_samples"] == ok["n_samples"] and np.array_equal(one["samples"], ok["samples"])

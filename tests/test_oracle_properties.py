@@ -273,3 +273,56 @@ def test_sample_count_is_a_property_of_dt_and_the_total_time_only():
             assert n in (expect, expect - 1), (dt, times, n, expect)
             if n == expect - 1:
                 assert abs(acc[expect - 1] - t_end) < 1e-9 * max(1.0, t_end)
+
+
+def test_band_limited_qr_is_the_dense_qr_bit_for_bit():
+    """oracle/mto_linear.c qr_solve: R_pp is block-tridiagonal and holds exact zeros outside its band; the loops limited to the
+    window in which operands can be non-zero leave out only operations on exact zeros.  Same coefficients, costs, times and
+    samples to the last bit as the full dense loops, in the reference's arithmetic, with the exact tables and in 113 bits --
+    on min-snap / min-acceleration paths, stop_at vertices, moving starts (variable block sizes) and through the Mellinger loop."""
+    L = po.lib()
+    rng = np.random.default_rng(3)
+    parts = []
+    for seed, (n_seg, deriv) in enumerate([(3, 4), (10, 4), (17, 2), (30, 3), (45, 4), (64, 2)]):
+        wp = pr.random_box_waypoints(n_seg, 900 + seed)
+        stop = [(0 < i < n_seg) and (i % 3 == 0) and seed % 2 == 1 for i in range(n_seg + 1)]
+        init = None
+        if seed % 3 == 2:
+            init = dict(heading=wp[0, 3], velocity=np.append(rng.uniform(-1, 1, 3), 0.1), acceleration=np.zeros(4), jerk=np.zeros(4))
+        parts.append((deriv, pr.build_vertices(wp, deriv, stop_at=stop, initial_state=init)))
+    try:
+        for mode in (po.REFERENCE_ARITHMETIC, po.EXACT_CONSTANTS, po.QUAD_PRECISION):
+            L.mto_set_arithmetic(mode)
+            for deriv, part in parts:
+                batch = pr.assemble_batch([part], pr.DEFAULT_LIMITS[None, :], deriv)
+                res = []
+                for dense in (1, 0):
+                    L.mto_set_dense_qr(dense)
+                    res.append(po.solve_batch(batch.seg_offsets, batch.waypoints, batch.fixed_mask, batch.fixed_values, batch.limits,
+                                              np.zeros(batch.n_segments), deriv=deriv, estimate_times=True,
+                                              time_alloc_method=(2 if mode != po.QUAD_PRECISION else -1), sampling_dt=0.2,
+                                              sample_capacity=1024))
+                for k in ("coeffs", "times", "status", "cost", "n_samples", "samples"):
+                    assert np.array_equal(res[0][k], res[1][k]), (mode, deriv, batch.n_segments, k)
+    finally:
+        L.mto_set_arithmetic(po.REFERENCE_ARITHMETIC)
+        L.mto_set_dense_qr(0)
+
+
+def test_oracle_follows_the_product_to_256_segments():
+    """MTO_MAX_SEG = MRS_TG_MAX_SEGMENTS: a 256-segment path solves, continuously and on its constraints, in both arithmetic
+    routes, which agree with each other as far as the double route's own rounding goes"""
+    batch = pr.random_batch(1, 256, seed0=8200)
+    t = util.oracle_times(batch)
+    ref = util.oracle_linear(batch, t)
+    assert ref["status"][0] == 1
+    assert util.continuity_defect(batch, ref["coeffs"], t) < 1e-6 and util.constraint_defect(batch, ref["coeffs"], t) < 1e-6
+    po.lib().mto_set_arithmetic(po.QUAD_PRECISION)
+    try:
+        refq = util.oracle_linear(batch, t)
+    finally:
+        po.lib().mto_set_arithmetic(po.REFERENCE_ARITHMETIC)
+    assert util.continuity_defect(batch, refq["coeffs"], t) < 1e-9
+    assert util.coeff_error(ref["coeffs"], refq["coeffs"], batch.seg_offsets) < 1e-6
+    assert po.solve_batch(pr.random_batch(1, 257, seed0=1).seg_offsets, *[getattr(pr.random_batch(1, 257, seed0=1), k) for k in
+                          ("waypoints", "fixed_mask", "fixed_values", "limits")], np.ones(257))["status"][0] < 0
