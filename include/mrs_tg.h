@@ -144,6 +144,17 @@ enum {
                                          eliminate such vertices inside the specialised sweeps (always the case below snap).
                                          mrs_tg_solve_batch, mrs_tg_find_trajectory and mrs_tg_optimize_paths set it themselves
                                          from the masks they hold in host memory */
+  ,
+  MRS_TG_FLAG_REFERENCE_STATUS = 128  /* (ABI 5) Mellinger mode: the path's status is the outer loop's own stopping reason, as in
+                                         the reference -- the product's runaway rule (MRS_TG_STATUS_ROUNDOFF_LIMITED when the
+                                         feasibility scaling multiplied the total time by more than MRS_TG_RUNAWAY_TIME_FACTOR)
+                                         is switched off.  For callers that apply the reference's own answer to a runaway, the
+                                         length check against the Baca estimate (src/...cpp:1178-1199): mrs_tg_find_trajectory and
+                                         mrs_tg_optimize_paths set the flag themselves.  The rule measures against the Euclidean
+                                         estimate, which is 0.01-0.03 s for waypoints a few centimetres apart: such a path is
+                                         stretched 25-fold by a perfectly healthy scaling, and the reference never checks a
+                                         trajectory shorter than one second.  Coefficients, times and samples are the same bits
+                                         with and without the flag */
 };
 
 /* mrs_tg_capabilities(): what this build of the library contains beyond the mandatory surface */

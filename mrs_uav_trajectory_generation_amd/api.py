@@ -31,6 +31,7 @@ FLAG_GENERAL_PATTERNS = 16     # vertices without a position constraint may occu
 FLAG_CAREFUL_COST = 8          # Mellinger mode: re-run the paths whose fast cost evaluation failed its guard with primal costs
 FLAG_SHARED_DEVICE = 4         # hint: several batches are in flight on this device (results unaffected)
 FLAG_POSITIONS_ARE_WAYPOINTS = 32   # every vertex's position constraint is its waypoint (checked at bind time): read the compact array
+FLAG_REFERENCE_STATUS = 128         # Mellinger: the outer loop's own code, no runaway rule (MRS_TG_FLAG_REFERENCE_STATUS)
 FLAG_CONSTRAINED_SLOTS = 64         # hint: interior vertices may hold constrained derivative slots (stop_at) under min-snap
 
 STATUS_ROUNDOFF_LIMITED = -4   # MRS_TG_STATUS_ROUNDOFF_LIMITED: the feasibility scaling ran away (include/mrs_tg.h)

@@ -223,25 +223,7 @@ int mrs_tg_kernel_trace(const char** names_out, int capacity) {
 
 void mrs_tg_default_options(mrs_tg_options* opt) {
   if (!opt) return;
-  std::memset(opt, 0, sizeof(*opt));
-  opt->derivative_to_optimize = 4;
-  opt->time_alloc_method = MRS_TG_TIME_ALLOC_NONE;
-  opt->estimate_times = 0;
-  opt->max_iterations = 10;  // config/private/trajectory_generation.yaml:10
-  opt->f_rel = 0.05;         // src/mrs_trajectory_generation.cpp:884
-  opt->f_abs = -1.0;
-  opt->x_rel = 0.1;          // src/mrs_trajectory_generation.cpp:885
-  opt->x_abs = -1.0;
-  opt->sampling_dt = 0.0;
-  opt->sample_capacity = 0;
-  opt->flags = 0;
-  opt->time_penalty = 100.0;           // config/private/trajectory_generation.yaml:4
-  opt->soft_constraint_weight = 1.5;   // :6
-  opt->use_soft_constraints = 1;       // :5
-  opt->initial_stepsize_rel = 0.1;     // src/mrs_trajectory_generation.cpp:893
-  opt->max_time_s = 0.0;               // no deadline (the nodelet sets 2 * 0.95 * timeLeft(), :899)
-  opt->max_trajectory_len_factor = 3.0;   // config/public/trajectory_generation.yaml:35
-  opt->min_trajectory_len_factor = 0.33;  // :36
+  mrs_tg::policy::default_solver_options(opt);
 }
 
 const char* mrs_tg_last_error(const mrs_tg_ctx* ctx) {
@@ -534,6 +516,7 @@ int mrs_tg_plan_solve(mrs_tg_plan* plan, const double* wp, const uint8_t* mask, 
       prm.estimate_limits = limits;
     }
     prm.pos_wp = pos_wp;
+    prm.reference_status = (opt->flags & MRS_TG_FLAG_REFERENCE_STATUS) != 0;
     ProfileScope ps(ctx, 2);
     HIP_TRY(ctx, mrs_tg::launch_nonlinear(plan->nl, b, prm, mask, vals, limits, seg_times, coeffs, status, cost, ctx->stream,
                                           opt->sampling_dt, opt->sample_capacity, n_samples, samples, &sampled,
@@ -1235,6 +1218,9 @@ int mrs_tg_find_trajectory(mrs_tg_ctx* ctx, const mrs_tg_waypoint* wps, int32_t 
     ctx->find_baca_total = pol::baca_total_time(S, wp.data(), lim, baca);
     mrs_tg_options opt = *opt_in;
     opt.estimate_times = 1;
+    // the reference's own status rule: a runaway of the feasibility scaling keeps the outer loop's code and is discarded by
+    // the length check below, as at :1178-1199 (a 5 cm path whose estimate is 0.025 s is no runaway: it is never checked)
+    opt.flags |= MRS_TG_FLAG_REFERENCE_STATUS;
     const int32_t so[2] = {0, S};
     double cost = 0.0;
     int rc = mrs_tg_solve_batch(ctx, 1, so, wp.data(), mask.data(), vals.data(), lim, &opt, seg_times_out, coeffs_out,

@@ -33,6 +33,7 @@ struct NonlinearParams {
   const double* estimate_wp = nullptr;
   const double* estimate_limits = nullptr;
   const double* pos_wp = nullptr;  // MRS_TG_FLAG_POSITIONS_ARE_WAYPOINTS: where the saturated-device solves read vertex positions
+  bool reference_status = false;   // MRS_TG_FLAG_REFERENCE_STATUS: no runaway test, the outer loop's own code is the path's status
 };
 
 // Paths are sorted by segment count (longest first), so every lane-group class is a contiguous range

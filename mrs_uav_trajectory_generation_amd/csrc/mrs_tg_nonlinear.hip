@@ -2410,7 +2410,7 @@ hipError_t launch_nonlinear(NonlinearPlan& nl, const BatchView& b, const Nonline
     tail.maxima_in_launch = true;
     tail.limits = limits;
     tail.opt_status = nl.d_opt_status;
-    tail.sum_t0 = nl.d_sum_t0;
+    tail.sum_t0 = prm.reference_status ? nullptr : nl.d_sum_t0;  // (no runaway test: MRS_TG_FLAG_REFERENCE_STATUS)
     tail.seg_times_out = seg_times;
     if (sampling_dt > 0.0 && n_samples != nullptr) {
       tail.sampling_dt = sampling_dt;
@@ -2447,7 +2447,7 @@ hipError_t launch_nonlinear(NonlinearPlan& nl, const BatchView& b, const Nonline
     tail.maxima = nl.d_maxima;
     tail.limits = limits;
     tail.opt_status = nl.d_opt_status;
-    tail.sum_t0 = nl.d_sum_t0;
+    tail.sum_t0 = prm.reference_status ? nullptr : nl.d_sum_t0;  // (no runaway test: MRS_TG_FLAG_REFERENCE_STATUS)
     tail.seg_times_out = seg_times;
     tail.pos_wp = prm.pos_wp;
     return launch_solve_quad(b, prm.derivative, mask, vals, seg_times, coeffs, status, cost, nl.d_opt_status, nl.d_ws, stream, tail);
@@ -2457,7 +2457,7 @@ hipError_t launch_nonlinear(NonlinearPlan& nl, const BatchView& b, const Nonline
     tail.maxima = nl.d_maxima;
     tail.limits = limits;
     tail.opt_status = nl.d_opt_status;
-    tail.sum_t0 = nl.d_sum_t0;
+    tail.sum_t0 = prm.reference_status ? nullptr : nl.d_sum_t0;  // (no runaway test: MRS_TG_FLAG_REFERENCE_STATUS)
     tail.seg_times_out = seg_times;
     if (want_samples) {
       tail.sampling_dt = sampling_dt;
@@ -2471,8 +2471,10 @@ hipError_t launch_nonlinear(NonlinearPlan& nl, const BatchView& b, const Nonline
   MRS_TG_LAUNCH(apply_scaling_kernel, dim3(cdiv_u(b.n_segments, 256)), dim3(256), 0, stream, b, nl.d_maxima, limits,
                      nl.d_opt_status, seg_times);
   if ((e = hipGetLastError()) != hipSuccess) return e;
-  MRS_TG_LAUNCH(runaway_kernel, dim3(cdiv_u(b.n_paths, 256)), dim3(256), 0, stream, b, seg_times, nl.d_sum_t0, nl.d_opt_status);
-  if ((e = hipGetLastError()) != hipSuccess) return e;
+  if (!prm.reference_status) {
+    MRS_TG_LAUNCH(runaway_kernel, dim3(cdiv_u(b.n_paths, 256)), dim3(256), 0, stream, b, seg_times, nl.d_sum_t0, nl.d_opt_status);
+    if ((e = hipGetLastError()) != hipSuccess) return e;
+  }
   // 4. updateSegmentTimes + solveLinear with the scaled times (nonlinear_impl.h:405-408), final status
   if ((e = launch_solve_linear(b, prm.derivative, true, mask, vals, seg_times, nullptr, nullptr, nl.d_ws, coeffs, status, cost,
                                nl.d_opt_status, stream)) != hipSuccess)

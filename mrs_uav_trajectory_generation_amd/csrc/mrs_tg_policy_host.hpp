@@ -56,7 +56,13 @@ inline double sradians_unwrap(double what, double from) {
   else if (d >= M_PI) d -= two_pi;
   return from + d;
 }
-inline double wrap_yaw(double y) { return std::atan2(std::sin(y), std::cos(y)); }
+// the yaw a sample carries after EigenTrajectoryPoint::setFromYaw / getYaw (the nodelet reads it back at :1599):
+// quaternionFromYaw = (cos(yaw / 2), 0, 0, sin(yaw / 2)), yawFromQuaternion = atan2(2 (w z + x y), 1 - 2 (y^2 + z^2))
+// (include/eth_mav_msgs/common.h:130-140) -- the round trip's own arithmetic, not atan2(sin, cos), which differs in the last bit
+inline double wrap_yaw(double y) {
+  const double w = std::cos(y * 0.5), z = std::sin(y * 0.5);
+  return std::atan2(2.0 * (w * z), 1.0 - 2.0 * (z * z));
+}
 
 inline double dist_from_segment(const double* p, const double* s1, const double* s2) {  // :1533-1554
   const double sv[3] = {s2[0] - s1[0], s2[1] - s1[1], s2[2] - s1[2]};
@@ -172,6 +178,13 @@ inline int policy_threads() {
 // nothing escapes a std::thread (which would be std::terminate) and no joinable thread is ever destroyed.
 template <class F>
 void parallel_ranges(size_t n, size_t min_per_thread, F&& body) {
+  // MRS_TG_POLICY_GRAIN=k (test knob, read once): k items are enough for a thread, whatever the call site asks for -- lets a
+  // test put a few dozen requests on 16 threads (tests/host/policy_host_harness.cpp)
+  static const size_t grain_override = [] {
+    const char* e = std::getenv("MRS_TG_POLICY_GRAIN");
+    return e ? (size_t)std::max(1, std::atoi(e)) : (size_t)0;
+  }();
+  if (grain_override) min_per_thread = grain_override;
   const size_t threads = std::min<size_t>((size_t)policy_threads(), n / std::max<size_t>(min_per_thread, 1));
   if (threads <= 1) {
     body((size_t)0, n);
@@ -557,6 +570,7 @@ int optimize_paths(Host& host, int32_t n_paths, const int32_t* wp_offsets, const
       mrs_tg_options so_opt = o.solver;
       so_opt.estimate_times = 1;
       so_opt.sample_capacity = sample_capacity;
+      so_opt.flags |= MRS_TG_FLAG_REFERENCE_STATUS;  // the length check below is the reference's answer to a runaway (:1178-1199)
       if (o.max_execution_time_s > 0) so_opt.max_time_s = 2.0 * 0.95 * budget_left;  // :899
       const double t1 = now();
       t_build += t1 - t0;
@@ -641,6 +655,29 @@ inline int32_t waypoint_trajectory_idxs(const double* samples, int32_t n_samples
     if (widx == n_waypoints) break;
   }
   return n;
+}
+
+// mrs_tg_default_options: the reference's parameters where it has them
+inline void default_solver_options(mrs_tg_options* opt) {
+  std::memset(opt, 0, sizeof(*opt));
+  opt->derivative_to_optimize = 4;
+  opt->time_alloc_method = MRS_TG_TIME_ALLOC_NONE;
+  opt->estimate_times = 0;
+  opt->max_iterations = 10;  // config/private/trajectory_generation.yaml:10
+  opt->f_rel = 0.05;         // src/mrs_trajectory_generation.cpp:884
+  opt->f_abs = -1.0;
+  opt->x_rel = 0.1;          // src/mrs_trajectory_generation.cpp:885
+  opt->x_abs = -1.0;
+  opt->sampling_dt = 0.0;
+  opt->sample_capacity = 0;
+  opt->flags = 0;
+  opt->time_penalty = 100.0;           // config/private/trajectory_generation.yaml:4
+  opt->soft_constraint_weight = 1.5;   // :6
+  opt->use_soft_constraints = 1;       // :5
+  opt->initial_stepsize_rel = 0.1;     // src/mrs_trajectory_generation.cpp:893
+  opt->max_time_s = 0.0;               // no deadline (the nodelet sets 2 * 0.95 * timeLeft(), :899)
+  opt->max_trajectory_len_factor = 3.0;   // config/public/trajectory_generation.yaml:35
+  opt->min_trajectory_len_factor = 0.33;  // :36
 }
 
 // config/public/trajectory_generation.yaml + config/private/trajectory_generation.yaml; `solver` is filled by the caller

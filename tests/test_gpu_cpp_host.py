@@ -90,7 +90,7 @@ def test_plain_c99_host(tmp_path):
                            os.path.join(ROOT, "examples", "solve_batch_host.c"), "-o", exe, "-L", libdir, "-lmrs_tg",
                            "-Wl,-rpath," + libdir])
     r = json.loads(subprocess.run([exe], check=True, capture_output=True, text=True, timeout=300).stdout)
-    assert r["abi"] == 4 and len(r["paths"]) == 2
+    assert r["abi"] == 5 and len(r["paths"]) == 2
     # the device-list call (two contexts on this box's one GPU): a ragged batch is balanced on the segment count, and the
     # results are bit-identical to the single-device call
     assert r["multi"] == {"devices": 2, "shard": [0, 1], "identical": True}

@@ -350,13 +350,18 @@ def test_find_trajectory_discards_a_too_long_trajectory_like_the_reference(gpu_c
 
 def test_find_trajectory_discards_the_runaway_path_8615(gpu_ctx):
     """Path 8615 of the 65536-path batch (the feasibility scaling runs away to 1e10 times the estimate): the reference returns
-    MAXEVAL_REACHED and its length check discards the trajectory; the product names the runaway ROUNDOFF_LIMITED, which the
-    gate on the code rejects before the length check is reached.  Either way: {}."""
+    MAXEVAL_REACHED and its length check discards the trajectory -- and so does the seam (it solves under
+    MRS_TG_FLAG_REFERENCE_STATUS: the outer loop's own code, the reference's own answer to the runaway).  The batched solve
+    without the flag names the same path ROUNDOFF_LIMITED (the product's documented deviation, include/mrs_tg.h)."""
     wp = pr.random_box_waypoints(10, 8615)
     got, ref = _find_vs_oracle(gpu_ctx, wp, 4)
-    assert ref["success"] == 0 and ref["rejection"] == 2
-    assert got["n_samples"] == 0 and got["rejection"] in (api.FIND_REJECTED_CODE, api.FIND_REJECTED_TOO_LONG)
-    assert got["status"] == api.STATUS_ROUNDOFF_LIMITED or got["rejection"] == api.FIND_REJECTED_TOO_LONG
+    assert ref["success"] == 0 and ref["rejection"] == 2 and ref["status"] == 5
+    assert got["status"] == ref["status"] and got["n_samples"] == 0 and got["rejection"] == api.FIND_REJECTED_TOO_LONG
+    batch = pr.assemble_batch([pr.build_vertices(wp, pr.SNAP)], pr.DEFAULT_LIMITS[None, :])
+    plain = gpu_ctx.solve_batch(batch, None, time_alloc_method=api.TIME_ALLOC_MELLINGER)
+    flagged = gpu_ctx.solve_batch(batch, None, time_alloc_method=api.TIME_ALLOC_MELLINGER, flags=api.FLAG_REFERENCE_STATUS)
+    assert plain["status"][0] == api.STATUS_ROUNDOFF_LIMITED and flagged["status"][0] == 5
+    assert np.array_equal(plain["times"], flagged["times"]) and np.array_equal(plain["coeffs"], flagged["coeffs"])
 
 
 def test_find_trajectory_discards_a_too_short_trajectory(gpu_ctx):
