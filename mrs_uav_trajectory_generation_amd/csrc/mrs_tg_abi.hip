@@ -84,6 +84,9 @@ struct mrs_tg_plan {
   size_t ws_doubles = 0;
   double* d_H = nullptr;
   double* d_Ainv = nullptr;
+  // scratch of the two-kernel sampler (chunk descriptors), grown on demand
+  void* d_sample_scratch = nullptr;
+  size_t sample_scratch_bytes = 0;
   mrs_tg::NonlinearPlan nl;
 };
 
@@ -155,6 +158,25 @@ int ensure_ws(mrs_tg_plan* plan, size_t doubles) {
   plan->ws_doubles = 0;
   HIP_TRY(plan->ctx, mrs_tg::pool_alloc(&plan->d_ws, doubles * sizeof(double)));
   plan->ws_doubles = doubles;
+  return MRS_TG_OK;
+}
+
+// the sampler's scratch when the launch takes the two-kernel sampler, else nullptr (*out)
+int ensure_sample_scratch(mrs_tg_plan* plan, int capacity, void** out) {
+  *out = nullptr;
+  if (!mrs_tg::sample_split_applies(plan->view, capacity)) return MRS_TG_OK;
+  const size_t bytes = mrs_tg::sample_scratch_bytes(plan->view, capacity);
+  if (plan->sample_scratch_bytes < bytes) {
+    if (plan->d_sample_scratch) {
+      (void)hipStreamSynchronize(plan->ctx->stream);  // pool contract: no work in flight on a block that is given back
+      mrs_tg::pool_free(plan->d_sample_scratch);
+    }
+    plan->d_sample_scratch = nullptr;
+    plan->sample_scratch_bytes = 0;
+    HIP_TRY(plan->ctx, mrs_tg::pool_alloc_bytes(&plan->d_sample_scratch, bytes));
+    plan->sample_scratch_bytes = bytes;
+  }
+  *out = plan->d_sample_scratch;
   return MRS_TG_OK;
 }
 
@@ -420,6 +442,7 @@ void mrs_tg_plan_destroy(mrs_tg_plan* plan) {
   if (plan->d_ws) (void)mrs_tg::pool_free(plan->d_ws);
   if (plan->d_H) (void)mrs_tg::pool_free(plan->d_H);
   if (plan->d_Ainv) (void)mrs_tg::pool_free(plan->d_Ainv);
+  if (plan->d_sample_scratch) (void)mrs_tg::pool_free(plan->d_sample_scratch);
   delete plan;
 }
 
@@ -549,9 +572,12 @@ int mrs_tg_plan_solve(mrs_tg_plan* plan, const double* wp, const uint8_t* mask, 
     if (general)
       HIP_TRY(ctx, mrs_tg::launch_solve_general(b, d, mask, vals, seg_times, plan->d_ws, coeffs, status, cost, ctx->stream));
   }
-  if (opt->sampling_dt > 0 && !sampled)
+  if (opt->sampling_dt > 0 && !sampled) {
+    void* scratch = nullptr;
+    if ((rc = ensure_sample_scratch(plan, opt->sample_capacity, &scratch)) != MRS_TG_OK) return rc;
     HIP_TRY(ctx, mrs_tg::launch_sample(b, coeffs, seg_times, opt->sampling_dt, opt->sample_capacity, n_samples, samples,
-                                       ctx->stream));
+                                       ctx->stream, scratch));
+  }
   return MRS_TG_OK;
 }
 
@@ -864,8 +890,13 @@ int mrs_tg_plan_sample_states(mrs_tg_plan* plan, const double* coeffs, const dou
   if (!(sampling_dt > 0.0) || sample_capacity < 0 || (sample_capacity > 0 && !states))
     return fail(ctx, MRS_TG_ERR_INVALID_ARG, "sampling_dt must be positive and states_out_dev given for a positive capacity");
   HIP_TRY(ctx, use_device(ctx->device));
+  void* scratch = nullptr;
+  if (sample_capacity > 0) {
+    const int rcs = ensure_sample_scratch(plan, sample_capacity, &scratch);
+    if (rcs != MRS_TG_OK) return rcs;
+  }
   HIP_TRY(ctx, mrs_tg::launch_sample_states(plan->view, coeffs, seg_times, sampling_dt, sample_capacity, n_samples,
-                                            sample_capacity > 0 ? states : nullptr, ctx->stream));
+                                            sample_capacity > 0 ? states : nullptr, ctx->stream, scratch));
   return MRS_TG_OK;
 }
 

@@ -221,6 +221,214 @@ __global__ __launch_bounds__(64) void sample_kernel(BatchView b, const double* _
 }
 
 // ---------------------------------------------------------------------------------------------
+// The sampler of large launches, in two kernels (round 6).  sample_kernel spends a whole wavefront on a walk that is a
+// scalar, sequential algorithm: per path ~13 chunks, each a dependent chain of bookkeeping in front of the next (8 % of its
+// wave cycles had a VALU instruction in flight, a wavefront lived 66 k cycles: profiles/round5_pmc_sq_nonlinear_65536.csv).
+//   sample_walk_kernel: ONE LANE per path runs the reference's loop as written (trajectory.cpp:131-150: compare, carry,
+//     two additions per sample) and emits only CHUNK descriptors -- {index of the chunk's first sample, segment, time in
+//     segment of that sample, count <= 64}: a new chunk where the walk enters a segment and after 64 samples, ~13 per
+//     10-segment path -- and the sample count.
+//   sample_eval_kernel: one lane per SAMPLE, 256 samples of one path per workgroup: the lane finds its chunk (binary search
+//     over the path's descriptors in LDS), repeats the walk's own additions from the chunk's start value (k additions of
+//     dt for the chunk's k-th sample: the reference's running sum, bit for bit), evaluates the four polynomials from the
+//     coefficients staged in LDS and stores its 32 bytes next to its neighbours'.
+// Same samples and counts as sample_kernel to the last bit (tests/test_gpu_large_batches.py::
+// test_separate_sampler_equals_the_sampler_in_the_solve_kernels_tail).  Round 3's one-lane-per-path walk stored 16 bytes per
+// SAMPLE from the walking lane and was three times slower than the wavefront walk; this one stores 16 bytes per chunk.
+struct SampleChunk {
+  double tin;            // time in segment of the chunk's first sample
+  int32_t first;         // index of that sample
+  uint16_t seg, count;   // segment, samples in the chunk (1 .. 64)
+};
+static_assert(sizeof(SampleChunk) == 16, "chunk descriptor layout");
+
+constexpr int kWalkPaths = 64;         // paths per workgroup of the walk: one wavefront, a lane each
+constexpr int kWalkLdsSegments = 128;  // longest path whose segment times the walk keeps in LDS (64 paths x 128 x 8 B = 64 KB)
+constexpr int kEvalThreads = 256;      // samples per workgroup of the evaluation
+constexpr int kEvalSegCap = 48;        // segments whose coefficients an evaluation workgroup stages in LDS (15 KB)
+
+__host__ __device__ inline int sample_chunk_stride(int max_segments, int capacity) {
+  // a path enters at most S segments and closes a chunk after every 64 samples it emits: S + capacity / 64 + 1 chunks at most
+  return max_segments + capacity / 64 + 2;
+}
+
+template <bool LDS_TIMES>
+__global__ __launch_bounds__(kWalkPaths) void sample_walk_kernel(BatchView b, const double* __restrict__ seg_times, double dt,
+                                                                 int capacity, int32_t* __restrict__ n_samples,
+                                                                 SampleChunk* __restrict__ chunks, int32_t* __restrict__ n_chunks,
+                                                                 int chunk_stride) {
+  extern __shared__ double s_T[];  // LDS_TIMES: [max_segments][64]: segment i of the workgroup's path l at i * 64 + l
+  const int lane = threadIdx.x;
+  const int q = blockIdx.x * kWalkPaths + lane;
+  const bool live = q < b.n_paths;
+  const PathRef pr = path_at(b, live ? q : b.n_paths - 1);
+  const int S = pr.S;
+  const double* __restrict__ Tg = seg_times + pr.s0;
+  if (LDS_TIMES) {
+    if (b.uniform_S > 0) {  // the 64 paths' times are one contiguous run: coalesced
+      const int q0 = blockIdx.x * kWalkPaths;
+      const int total = min(kWalkPaths, b.n_paths - q0) * S;
+      const double* __restrict__ base = seg_times + (size_t)q0 * S;
+      for (int e = lane; e < total; e += kWalkPaths) s_T[(e % S) * kWalkPaths + e / S] = base[e];
+    } else {
+      for (int i = 0; i < S; ++i) s_T[i * kWalkPaths + lane] = Tg[i];
+    }
+    __syncthreads();
+  }
+  auto T_at = [&](int i) -> double { return LDS_TIMES ? s_T[i * kWalkPaths + lane] : Tg[i]; };
+  // t_end and the start segment as the reference computes them (trajectory.cpp:100-124 with t_start = 0)
+  double t_end = 0.0;
+  for (int i = 0; i < S; ++i) t_end += T_at(i);
+  int i = 0;
+  {
+    double cum = 0.0;
+    for (i = 0; i < S; ++i) {
+      cum += T_at(i);
+      if (cum > 0.0) break;
+    }
+  }
+  int n = 0, nch = 0;
+  SampleChunk* __restrict__ my = chunks ? chunks + (size_t)pr.p * chunk_stride : nullptr;
+  if (live && i < S) {
+    double tin = 0.0, acc = 0.0;
+    double Ti = T_at(i);
+    double Tnext = (i + 1 < S) ? T_at(i + 1) : 0.0;  // loaded one segment ahead: a carry does not wait for memory
+    int c_first = 0, c_count = 0;
+    double c_tin = 0.0;
+    while (acc < t_end) {  // trajectory.cpp:131
+      if (tin > Ti) {      // :132-139: carry the remainder into the next segment
+        if (c_count > 0 && my) {
+          my[nch] = SampleChunk{c_tin, c_first, (uint16_t)i, (uint16_t)c_count};
+          ++nch;
+          c_count = 0;
+        }
+        tin = tin - Ti;
+        ++i;
+        if (i >= S) break;
+        Ti = Tnext;
+        Tnext = (i + 1 < S) ? T_at(i + 1) : 0.0;
+        continue;
+      }
+      if (n >= capacity) {  // more samples than the caller's array holds: reported as capacity + 1, the walk ends here
+        ++n;
+        break;
+      }
+      if (c_count == 64 && my) {
+        my[nch] = SampleChunk{c_tin, c_first, (uint16_t)i, (uint16_t)64};
+        ++nch;
+        c_count = 0;
+      }
+      if (c_count == 0) {
+        c_first = n;
+        c_tin = tin;
+      }
+      ++c_count;
+      ++n;
+      tin += dt;   // :148-149
+      acc += dt;
+    }
+    if (c_count > 0 && my && i < S) {
+      my[nch] = SampleChunk{c_tin, c_first, (uint16_t)i, (uint16_t)c_count};
+      ++nch;
+    }
+  }
+  if (live) {
+    if (n_samples) n_samples[pr.p] = n;
+    if (n_chunks) n_chunks[pr.p] = nch;
+  }
+}
+
+template <int NDER>
+__global__ __launch_bounds__(kEvalThreads) void sample_eval_kernel(BatchView b, const double* __restrict__ coeffs, double dt,
+                                                                   int capacity, const int32_t* __restrict__ n_samples,
+                                                                   const SampleChunk* __restrict__ chunks,
+                                                                   const int32_t* __restrict__ n_chunks, int chunk_stride,
+                                                                   double* __restrict__ samples) {
+  extern __shared__ double s_eval[];  // [kEvalSegCap][4][10] coefficients | chunk descriptors of the path that touch this block
+  const int tid = threadIdx.x;
+  const PathRef pr = path_at(b, blockIdx.x);
+  const int n = min(n_samples[pr.p], capacity);
+  const int e0 = blockIdx.y * kEvalThreads;
+  if (e0 >= n) return;
+  double* s_c = s_eval;
+  SampleChunk* s_ch = reinterpret_cast<SampleChunk*>(s_eval + kEvalSegCap * kD * kN);
+  const SampleChunk* __restrict__ my = chunks + (size_t)pr.p * chunk_stride;
+  const int nch = n_chunks[pr.p];
+  // the chunks that hold samples of [e0, e0 + 256): chunks are sorted by `first`; d_lo = the last one that starts at or before e0
+  // (every lane runs the same search: wave-uniform loads)
+  int lo = 0, hi = nch;  // invariant: first[lo] <= e0 < first[hi]
+  while (hi - lo > 1) {
+    const int mid = (lo + hi) >> 1;
+    if (my[mid].first <= e0) lo = mid;
+    else hi = mid;
+  }
+  const int d_lo = lo;
+  const int e_end = min(e0 + kEvalThreads, n);
+  // at most 256 chunks can start inside the block: stage [d_lo, d_lo + 257) and let the lanes search that window
+  const int n_win = min(nch - d_lo, kEvalThreads + 1);
+  for (int d = tid; d < n_win; d += kEvalThreads) s_ch[d] = my[d_lo + d];
+  if (tid == 0 && n_win <= kEvalThreads) s_ch[n_win].first = 0x7fffffff;  // sentinel behind the window
+  __syncthreads();
+  // (the window is sorted: the last chunk that starts below e_end closes it)
+  int w_hi = 1;
+  {
+    int a = 0, c = n_win;  // first[a] < e_end <= first[c] (c may be the sentinel)
+    while (c - a > 1) {
+      const int mid = (a + c) >> 1;
+      if (s_ch[mid].first < e_end) a = mid;
+      else c = mid;
+    }
+    w_hi = c;  // chunks [0, w_hi) of the window touch the block
+  }
+  const int seg_lo = s_ch[0].seg, seg_hi = s_ch[w_hi - 1].seg;
+  const int n_stage = min(seg_hi - seg_lo + 1, kEvalSegCap);
+  {
+    const double* __restrict__ cg = coeffs + ((size_t)pr.s0 + seg_lo) * kD * kN;
+    for (int k = tid; k < n_stage * kD * kN; k += kEvalThreads) s_c[k] = cg[k];
+  }
+  __syncthreads();
+  const int e = e0 + tid;
+  const bool valid = e < n;
+  // my chunk: the last one of the window with first <= e
+  int a = 0;
+  {
+    int c = w_hi;
+    while (c - a > 1) {
+      const int mid = (a + c) >> 1;
+      if (s_ch[mid].first <= e) a = mid;
+      else c = mid;
+    }
+  }
+  const SampleChunk ch = s_ch[a];
+  const int k = valid ? e - ch.first : 0;
+  // the walk's own additions: the chunk's k-th sample is ((tin + dt) + dt) ... + dt, k times
+  double tj = ch.tin;
+  for (int r = 0; __builtin_amdgcn_ballot_w64(r < k) != 0ull; ++r)
+    if (r < k) tj += dt;
+  if (!valid) return;
+  const int sl = (int)ch.seg - seg_lo;
+  double* out = samples + ((size_t)pr.p * capacity + e) * (NDER + 1) * kD;
+  auto horner = [&](const double* __restrict__ c) {
+#pragma unroll
+    for (int kk = 0; kk <= NDER; ++kk) {
+      double v[kD];
+#pragma unroll
+      for (int dd = 0; dd < kD; ++dd) {
+        double accv = falling_factorial(kN - 1, kk) * c[dd * kN + kN - 1];
+#pragma unroll
+        for (int j = kN - 2; j >= kk; --j) accv = accv * tj + falling_factorial(j, kk) * c[dd * kN + j];
+        v[dd] = accv;
+      }
+      if (kk == 0) v[3] = wrap_heading(v[3]);
+#pragma unroll
+      for (int dd = 0; dd < kD; ++dd) out[kk * kD + dd] = v[dd];
+    }
+  };
+  if (sl < n_stage) horner(s_c + (size_t)sl * kD * kN);
+  else horner(coeffs + ((size_t)pr.s0 + ch.seg) * kD * kN);  // (a block that spans more segments than the stage holds)
+}
+
+// ---------------------------------------------------------------------------------------------
 // launchers
 
 static inline unsigned cdiv(long long a, long long b) { return (unsigned)((a + b - 1) / b); }
@@ -476,9 +684,50 @@ hipError_t sample_acc_table(double dt, int capacity, hipStream_t stream, const d
   return hipSuccess;
 }
 
+// scratch of the two-kernel sampler for a batch: chunk descriptors [n_paths][stride] + chunk counts [n_paths]
+size_t sample_scratch_bytes(const BatchView& b, int capacity) {
+  return ((size_t)b.n_paths * sample_chunk_stride(b.max_segments, capacity) * sizeof(SampleChunk) + 255) / 256 * 256 +
+         (size_t)b.n_paths * sizeof(int32_t);
+}
+
+bool sample_split_applies(const BatchView& b, int capacity) {
+  // MRS_TG_SAMPLE_SPLIT (tuning / test knob, read once): smallest launch, in paths, that takes the two-kernel sampler;
+  // 0 = never.  Default 2048: below it the walk kernel's wavefronts (64 paths each) do not fill the SIMDs
+  static const int min_paths = [] {
+    const char* e = std::getenv("MRS_TG_SAMPLE_SPLIT");
+    return e ? std::atoi(e) : 2048;
+  }();
+  return min_paths > 0 && b.n_paths >= min_paths && capacity >= 1 && b.max_segments <= 65535;
+}
+
 template <int NDER>
 static hipError_t launch_sample_n(const BatchView& b, const double* coeffs, const double* seg_times, double dt, int capacity,
-                                  int32_t* n_samples, double* samples, hipStream_t stream) {
+                                  int32_t* n_samples, double* samples, hipStream_t stream, void* scratch) {
+  if (scratch != nullptr && samples != nullptr && n_samples != nullptr && sample_split_applies(b, capacity)) {
+    const int stride = sample_chunk_stride(b.max_segments, capacity);
+    SampleChunk* chunks = static_cast<SampleChunk*>(scratch);
+    int32_t* n_chunks = reinterpret_cast<int32_t*>(static_cast<char*>(scratch) +
+                                                   ((size_t)b.n_paths * stride * sizeof(SampleChunk) + 255) / 256 * 256);
+    const unsigned walk_blocks = (unsigned)((b.n_paths + kWalkPaths - 1) / kWalkPaths);
+    if (b.max_segments <= kWalkLdsSegments) {
+      const size_t lds = sizeof(double) * (size_t)b.max_segments * kWalkPaths;
+      if (lds > 64 * 1024) return hipErrorInvalidValue;
+      MRS_TG_LAUNCH(sample_walk_kernel<true>, dim3(walk_blocks), dim3(kWalkPaths), lds, stream, b, seg_times, dt, capacity, n_samples,
+                    chunks, n_chunks, stride);
+    } else {
+      MRS_TG_LAUNCH(sample_walk_kernel<false>, dim3(walk_blocks), dim3(kWalkPaths), 0, stream, b, seg_times, dt, capacity, n_samples,
+                    chunks, n_chunks, stride);
+    }
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    const size_t lds_eval = sizeof(double) * kEvalSegCap * kD * kN + sizeof(SampleChunk) * (kEvalThreads + 2);
+    const unsigned blocks_per_path = (unsigned)((capacity + kEvalThreads - 1) / kEvalThreads);
+    // (paths along grid.x, which takes 2^31 - 1 workgroups; grid.y, limited to 65535, counts the 256-sample blocks of a path)
+    if (blocks_per_path > 65535u) return hipErrorInvalidValue;
+    MRS_TG_LAUNCH(sample_eval_kernel<NDER>, dim3((unsigned)b.n_paths, blocks_per_path), dim3(kEvalThreads), lds_eval, stream, b, coeffs,
+                  dt, capacity, n_samples, chunks, n_chunks, stride, samples);
+    return hipGetLastError();
+  }
   const size_t lds = sizeof(double) * ((size_t)b.max_segments * (1 + kD * kN) + kSampleBuffer) + sizeof(unsigned short) * kSampleBuffer;
   if (lds > 160 * 1024) return hipErrorInvalidValue;
   if (lds > 64 * 1024) {
@@ -497,15 +746,15 @@ static hipError_t launch_sample_n(const BatchView& b, const double* coeffs, cons
 }
 
 hipError_t launch_sample(const BatchView& b, const double* coeffs, const double* seg_times, double dt, int capacity,
-                         int32_t* n_samples, double* samples, hipStream_t stream) {
+                         int32_t* n_samples, double* samples, hipStream_t stream, void* scratch) {
   if (b.n_paths == 0) return hipSuccess;
-  return launch_sample_n<0>(b, coeffs, seg_times, dt, capacity, n_samples, samples, stream);
+  return launch_sample_n<0>(b, coeffs, seg_times, dt, capacity, n_samples, samples, stream, scratch);
 }
 
 hipError_t launch_sample_states(const BatchView& b, const double* coeffs, const double* seg_times, double dt, int capacity,
-                                int32_t* n_samples, double* states, hipStream_t stream) {
+                                int32_t* n_samples, double* states, hipStream_t stream, void* scratch) {
   if (b.n_paths == 0) return hipSuccess;
-  return launch_sample_n<kSampleStateOrders - 1>(b, coeffs, seg_times, dt, capacity, n_samples, states, stream);
+  return launch_sample_n<kSampleStateOrders - 1>(b, coeffs, seg_times, dt, capacity, n_samples, states, stream, scratch);
 }
 
 __global__ void position_mismatch_kernel(int n_vertices, const double* __restrict__ wp, const uint8_t* __restrict__ mask,

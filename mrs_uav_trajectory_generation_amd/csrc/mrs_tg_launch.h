@@ -111,12 +111,16 @@ hipError_t launch_copy_samples(const double* src, double* dst, const int32_t* n_
 
 hipError_t launch_estimate_times(const BatchView& b, const double* wp, const double* limits, double* seg_times,
                                  hipStream_t stream);
+// scratch: sample_scratch_bytes(b, capacity) bytes of device memory for the two-kernel sampler of large launches (lane-per-path
+// walk + sample-per-lane evaluation, mrs_tg_kernels.hip), or nullptr: the one-wavefront-per-path kernel whatever the size
 hipError_t launch_sample(const BatchView& b, const double* coeffs, const double* seg_times, double dt, int capacity,
-                         int32_t* n_samples, double* samples, hipStream_t stream);
+                         int32_t* n_samples, double* samples, hipStream_t stream, void* scratch = nullptr);
+size_t sample_scratch_bytes(const BatchView& b, int capacity);
+bool sample_split_applies(const BatchView& b, int capacity);
 // the same walk, every sample with its derivative orders 0..4: states [n_paths][capacity][kSampleStateOrders][4]
 constexpr int kSampleStateOrders = 5;
 hipError_t launch_sample_states(const BatchView& b, const double* coeffs, const double* seg_times, double dt, int capacity,
-                                int32_t* n_samples, double* states, hipStream_t stream);
+                                int32_t* n_samples, double* states, hipStream_t stream, void* scratch = nullptr);
 size_t linear_workspace_doubles(const BatchView& b);
 // MRS_TG_FLAG_POSITIONS_ARE_WAYPOINTS, checked: the number of vertices whose position is unconstrained or whose constrained
 // position differs (bitwise) from its waypoint.  Blocks until the count is on the host.
