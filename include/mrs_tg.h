@@ -133,8 +133,13 @@ enum {
                                          1.03 instead of 1.34 times its compulsory bytes.  Results are bit-identical.
                                          mrs_tg_plan_bind_solve CHECKS the statement once, on the arrays as they are at bind
                                          time, and refuses the bind with MRS_TG_ERR_INVALID_ARG if it does not hold;
-                                         mrs_tg_plan_solve trusts it (a statement that is false gives the solution of the
-                                         waypoints' problem).  Other kernels ignore the flag */
+                                         mrs_tg_plan_solve trusts it: the flag only changes launches that take the
+                                         saturated-device kernel (>= 6144 paths per dispatch), so a statement that is false -- or
+                                         has become false because the arrays of a bound solve were rewritten in place -- gives the
+                                         solution of the waypoints' problem there and of the caller's problem on smaller launches.
+                                         With MRS_TG_VERIFY_FLAGS=1 in the environment every mrs_tg_plan_solve re-checks the
+                                         statement (a blocking check, for debugging and tests) and fails with
+                                         MRS_TG_ERR_INVALID_ARG when it does not hold.  Other kernels ignore the flag */
   ,
   MRS_TG_FLAG_CONSTRAINED_SLOTS = 64  /* a HINT (results agree to rounding with and without it): beside the ends of its paths the
                                          batch may hold vertices with derivative slots constrained to zero -- stop_at waypoints --

@@ -489,6 +489,21 @@ int mrs_tg_plan_solve(mrs_tg_plan* plan, const double* wp, const uint8_t* mask, 
   if (opt->sampling_dt > 0 && !n_samples) return fail(ctx, MRS_TG_ERR_INVALID_ARG, "n_samples_out is required when sampling");
   HIP_TRY(ctx, use_device(ctx->device));
   const mrs_tg::BatchView& b = plan->view;
+  // MRS_TG_VERIFY_FLAGS=1 (debug / test knob, read once): the statement of MRS_TG_FLAG_POSITIONS_ARE_WAYPOINTS is checked on
+  // every solve, not only at bind time -- a blocking check; a false statement fails the call instead of solving the
+  // waypoints' problem on launches that take the saturated-device kernel and the caller's on the others
+  static const bool verify_flags = [] {
+    const char* e = std::getenv("MRS_TG_VERIFY_FLAGS");
+    return e != nullptr && std::atoi(e) != 0;
+  }();
+  if (verify_flags && (opt->flags & MRS_TG_FLAG_POSITIONS_ARE_WAYPOINTS)) {
+    long long bad = 0;
+    HIP_TRY(ctx, mrs_tg::count_position_mismatches(b, wp, mask, vals, ctx->stream, &bad));
+    if (bad != 0)
+      return fail(ctx, MRS_TG_ERR_INVALID_ARG,
+                  "MRS_TG_FLAG_POSITIONS_ARE_WAYPOINTS: %lld vertices whose position constraint is absent or differs from their waypoint",
+                  bad);
+  }
   const double* pos_wp = (opt->flags & MRS_TG_FLAG_POSITIONS_ARE_WAYPOINTS) ? wp : nullptr;
   const int d = opt->derivative_to_optimize;
   struct SharedDeviceScope {
@@ -823,6 +838,7 @@ int mrs_tg_bound_solve_launch_group(mrs_tg_bound_solve* const* bound, int32_t n_
     mrs_tg_plan* plan = first->plan;
     mrs_tg_ctx* ctx = plan->ctx;
     mrs_tg::RowsGroup g;
+    bool group_constrained_slots = false;
     for (; g.n < mrs_tg::kRowsGroupMax && k < n_launches; ++k, ++g.n) {
       const mrs_tg_bound_solve* b = bound[k % n_bound];
       if (b->plan != plan || b->opt.derivative_to_optimize != first->opt.derivative_to_optimize) break;
@@ -834,10 +850,17 @@ int mrs_tg_bound_solve_launch_group(mrs_tg_bound_solve* const* bound, int32_t n_
       g.status[g.n] = b->status;
       g.cost[g.n] = b->cost;
       g.pos_wp[g.n] = (b->opt.flags & MRS_TG_FLAG_POSITIONS_ARE_WAYPOINTS) ? b->wp : nullptr;
+      group_constrained_slots = group_constrained_slots || (b->opt.flags & MRS_TG_FLAG_CONSTRAINED_SLOTS) != 0;
     }
     if (plan->view.n_paths == 0) continue;
     HIP_TRY(ctx, use_device(ctx->device));
     ProfileScope ps(ctx, 1);
+    // MRS_TG_FLAG_CONSTRAINED_SLOTS of any batch of the group: the dispatch runs the instantiations that take stop_at vertices
+    // inside the specialised sweeps (the hint was only set by mrs_tg_plan_solve)
+    struct HintScope {
+      explicit HintScope(bool on) { mrs_tg::set_constrained_slots_hint(on); }
+      ~HintScope() { mrs_tg::set_constrained_slots_hint(false); }
+    } hint_scope(group_constrained_slots);
     if (mrs_tg::quad_kernel_applies(plan->view, (long long)plan->view.n_paths * g.n, false)) {
       // the dispatch carries more paths than the rows kernel has wavefront slots for: four lanes per path, factors in LDS
       // (one factor store per batch of THIS group; grows when a larger group comes, never shrinks)
@@ -1038,7 +1061,8 @@ static int solve_batch_impl(mrs_tg_ctx* ctx, int32_t n_paths, const int32_t* so,
     }
     return a;
   };
-  const bool want_wp = wp != nullptr && opt->estimate_times != 0;
+  // (the waypoints travel when something reads them: the time estimate, or kernels told that positions are the waypoints)
+  const bool want_wp = wp != nullptr && (opt->estimate_times != 0 || (opt->flags & MRS_TG_FLAG_POSITIONS_ARE_WAYPOINTS) != 0);
   enum { A_WP, A_MASK, A_VALS, A_LIM, A_T, A_C, A_ST, A_COST, A_NS, A_SMP, A_COUNT };
   Arr arr[A_COUNT] = {
       make(want_wp ? wp : nullptr, nullptr, want_wp ? nV * 4 * sizeof(double) : 0),

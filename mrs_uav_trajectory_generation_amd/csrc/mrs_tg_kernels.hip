@@ -578,56 +578,75 @@ __global__ void sample_acc_table_kernel(double* __restrict__ table, int n, doubl
 //     most 96 small tables;
 //   * sample_tables_release() (the last context of the process is destroyed) frees everything.
 namespace {
-struct AccEntry {
+struct AccBlock {  // a table's memory: lives until no cache entry names it AND no launch that was handed it is still to be enqueued
   double* d = nullptr;
+  int device = 0;
+  int pins = 0;  // (under g_acc_mu) callers between sample_acc_table's return and the enqueue of their kernel
+};
+struct AccEntry {
+  AccBlock* blk = nullptr;
   int n = 0;
   hipEvent_t ready = nullptr;  // recorded behind the build
   hipStream_t built_on = nullptr;
   bool ready_seen = false;
   unsigned long long stamp = 0;
 };
-struct AccRetired {
-  int device;
-  double* d;
-};
 constexpr size_t kAccCacheMax = 32, kAccRetiredMax = 64;
 std::mutex g_acc_mu;
 std::map<std::pair<int, unsigned long long>, AccEntry> g_acc_cache;
-std::vector<AccRetired> g_acc_retired;
+std::vector<AccBlock*> g_acc_retired;
 unsigned long long g_acc_clock = 0;
 
-void acc_retire(int device, AccEntry& en) {
+void acc_retire(AccEntry& en) {
   if (en.ready) (void)hipEventDestroy(en.ready);
-  if (en.d) g_acc_retired.push_back(AccRetired{device, en.d});
+  if (en.blk) g_acc_retired.push_back(en.blk);
   en = AccEntry{};
 }
 
-void acc_drain_retired() {  // (g_acc_mu held) no launch that reads a parked table is in flight after the synchronisations
+// (g_acc_mu held) After the synchronisations no ENQUEUED launch reads a parked table; a table some caller still holds a pin
+// on -- handed out, its kernel not enqueued yet -- stays parked for the next drain.  A device synchronisation is illegal while
+// the calling stream records a graph: the parked list then simply grows until a call outside a capture drains it.
+void acc_drain_retired(hipStream_t stream) {
   if (g_acc_retired.empty()) return;
+  hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+  if (stream != nullptr && hipStreamIsCapturing(stream, &cap) == hipSuccess && cap != hipStreamCaptureStatusNone) return;
+  (void)hipGetLastError();
   int cur = 0;
   (void)hipGetDevice(&cur);
   int last = -1;
-  for (const AccRetired& r : g_acc_retired) {
-    if (r.device != last) {
-      (void)hipSetDevice(r.device);
-      (void)hipDeviceSynchronize();
-      last = r.device;
+  std::vector<AccBlock*> kept;
+  for (AccBlock* r : g_acc_retired) {
+    if (r->pins > 0) {
+      kept.push_back(r);
+      continue;
     }
-    pool_free(r.d);
+    if (r->device != last) {
+      (void)hipSetDevice(r->device);
+      (void)hipDeviceSynchronize();
+      last = r->device;
+    }
+    pool_free(r->d);
+    delete r;
   }
-  g_acc_retired.clear();
+  g_acc_retired.swap(kept);
   (void)hipSetDevice(cur);
 }
 }  // namespace
 
-void sample_tables_release() {
+AccPin::~AccPin() {
+  if (!block) return;
   std::lock_guard<std::mutex> lock(g_acc_mu);
-  for (auto& kv : g_acc_cache) acc_retire(kv.first.first, kv.second);
-  g_acc_cache.clear();
-  acc_drain_retired();
+  --static_cast<AccBlock*>(block)->pins;
 }
 
-hipError_t sample_acc_table(double dt, int capacity, hipStream_t stream, const double** table_out, int* n_out) {
+void sample_tables_release() {
+  std::lock_guard<std::mutex> lock(g_acc_mu);
+  for (auto& kv : g_acc_cache) acc_retire(kv.second);
+  g_acc_cache.clear();
+  acc_drain_retired(nullptr);
+}
+
+hipError_t sample_acc_table(double dt, int capacity, hipStream_t stream, const double** table_out, int* n_out, AccPin* pin) {
   int dev = 0;
   hipError_t e = hipGetDevice(&dev);
   if (e != hipSuccess) return e;
@@ -644,27 +663,34 @@ hipError_t sample_acc_table(double dt, int capacity, hipStream_t stream, const d
         auto lru = g_acc_cache.begin();
         for (auto j = g_acc_cache.begin(); j != g_acc_cache.end(); ++j)
           if (j->second.stamp < lru->second.stamp) lru = j;
-        acc_retire(lru->first.first, lru->second);
+        acc_retire(lru->second);
         g_acc_cache.erase(lru);
       }
       it = g_acc_cache.emplace(key, AccEntry{}).first;
     } else {
-      acc_retire(dev, it->second);  // outgrown
+      acc_retire(it->second);  // outgrown
     }
-    if (g_acc_retired.size() >= kAccRetiredMax) acc_drain_retired();
+    if (g_acc_retired.size() >= kAccRetiredMax) acc_drain_retired(stream);
     AccEntry& en = it->second;
     int n = 1024 + 80;
     while (n < need) n *= 2;  // (growth by doubling: a caller that raises its capacity step by step rebuilds log2 times)
-    if ((e = pool_alloc(&en.d, sizeof(double) * (size_t)n)) != hipSuccess) {
+    en.blk = new (std::nothrow) AccBlock();
+    if (!en.blk) {
+      g_acc_cache.erase(it);
+      return hipErrorOutOfMemory;
+    }
+    en.blk->device = dev;
+    if ((e = pool_alloc(&en.blk->d, sizeof(double) * (size_t)n)) != hipSuccess) {
+      delete en.blk;
       g_acc_cache.erase(it);
       return e;
     }
     en.n = n;
-    MRS_TG_LAUNCH(sample_acc_table_kernel, dim3(1), dim3(64), 0, stream, en.d, n, dt);
+    MRS_TG_LAUNCH(sample_acc_table_kernel, dim3(1), dim3(64), 0, stream, en.blk->d, n, dt);
     if ((e = hipGetLastError()) == hipSuccess) e = hipEventCreateWithFlags(&en.ready, hipEventDisableTiming);
     if (e == hipSuccess) e = hipEventRecord(en.ready, stream);
     if (e != hipSuccess) {
-      acc_retire(dev, en);
+      acc_retire(en);
       g_acc_cache.erase(it);
       return e;
     }
@@ -676,11 +702,16 @@ hipError_t sample_acc_table(double dt, int capacity, hipStream_t stream, const d
     if (hipEventQuery(en.ready) == hipSuccess) {
       en.ready_seen = true;
     } else if (stream != en.built_on) {  // (the building stream itself is ordered behind the build)
+      (void)hipGetLastError();
       if ((e = hipStreamWaitEvent(stream, en.ready, 0)) != hipSuccess) return e;
     }
   }
-  *table_out = en.d;
+  *table_out = en.blk->d;
   *n_out = en.n;
+  if (pin && !pin->block) {  // the caller's launch is not enqueued yet: the block may be retired meanwhile, not recycled
+    pin->block = en.blk;
+    ++en.blk->pins;
+  }
   return hipSuccess;
 }
 
@@ -736,7 +767,8 @@ static hipError_t launch_sample_n(const BatchView& b, const double* coeffs, cons
   }
   const double* acc_table = nullptr;
   int acc_n = 0;
-  hipError_t et = sample_acc_table(dt, capacity, stream, &acc_table, &acc_n);
+  AccPin pin;  // (released when this function returns: behind the enqueue of the kernel that reads the table)
+  hipError_t et = sample_acc_table(dt, capacity, stream, &acc_table, &acc_n, &pin);
   if (et != hipSuccess) return et;
   // one workgroup per path.  (Fewer, persistent workgroups that walk several paths each -- the kernel's loop allows it --
   // were measured in round 5: 65536 x 10 pipeline 1328 -> 1347 / 1385 / 1384 us with 15360 / 7680 / 3840 workgroups.)

@@ -164,7 +164,18 @@ struct RowsTail {
 // A[k] = k additions of dt to 0, the accumulated time of the reference's sampling walk, on the current device: at least
 // capacity + 80 entries, built by a kernel on `stream` the first time a (device, dt) pair is seen and ordered behind that
 // build for launches on other streams; a bounded, least-recently-used cache (mrs_tg_kernels.hip)
-hipError_t sample_acc_table(double dt, int capacity, hipStream_t stream, const double** table_out, int* n_out);
+// `pin` keeps the table from being recycled between this call's return and the enqueue of the kernel that reads it (another
+// host thread may retire the entry in that window -- a new dt evicting the least recently used one, a larger capacity
+// outgrowing it -- and a drain of the retired list would hand the block to someone else): the caller declares an AccPin
+// before the call and lets it go out of scope behind its launch.
+struct AccPin {
+  void* block = nullptr;
+  AccPin() = default;
+  AccPin(const AccPin&) = delete;
+  AccPin& operator=(const AccPin&) = delete;
+  ~AccPin();
+};
+hipError_t sample_acc_table(double dt, int capacity, hipStream_t stream, const double** table_out, int* n_out, AccPin* pin);
 void sample_tables_release();  // frees every table (with the last context of the process)
 
 // one lane per unknown, no materialised blocks (mrs_tg_rows.hip): the fused linear solve of every path that fits its LDS record

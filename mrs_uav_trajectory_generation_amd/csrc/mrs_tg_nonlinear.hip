@@ -33,6 +33,9 @@
 // oracle/mto_nonlinear.c.
 #include <hip/hip_runtime.h>
 
+#include <map>
+#include <mutex>
+
 #include <algorithm>
 #include <cfloat>
 #include <cmath>
@@ -2203,11 +2206,23 @@ hipError_t launch_nonlinear(NonlinearPlan& nl, const BatchView& b, const Nonline
   // 8192 ragged 0.57 vs 0.65 ms, 8192 x 14 0.395 vs 0.425, 16384 x 14 0.644 vs 0.674, 32768 x 30 3.33 vs 3.51,
   // 32768 ragged 1.87 vs 1.89; past that narrow: 65536 x 14 2.03 vs 1.97 ms (profiles/round5_wide_groups_ab.txt).
   // (MRS_TG_LEAN_WIDE=0 / 1 forces.)
-  static const int resident_waves = [] {
-    int dev = 0, cus = 256;
-    if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-    return cus * 4 * MRS_TG_LEAN_WAVES;
-  }();
+  // (per device: a process may drive devices of different sizes or partitions, and the first call's figure is not theirs)
+  int resident_waves = 256 * 4 * MRS_TG_LEAN_WAVES;
+  {
+    static std::mutex mu;
+    static std::map<int, int> cus_of;  // device ordinal -> compute units
+    int dev = 0;
+    if (hipGetDevice(&dev) == hipSuccess) {
+      std::lock_guard<std::mutex> lock(mu);
+      auto it = cus_of.find(dev);
+      if (it == cus_of.end()) {
+        int cus = 256;
+        (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+        it = cus_of.emplace(dev, cus).first;
+      }
+      resident_waves = it->second * 4 * MRS_TG_LEAN_WAVES;
+    }
+  }
   static const int wide_forced = [] {
     const char* e = std::getenv("MRS_TG_LEAN_WIDE");
     return e ? (std::atoi(e) != 0 ? 1 : 0) : -1;

@@ -144,7 +144,8 @@ void note_kernel(const char* name) {
 void kernel_trace_reset() { t_trace_n = 0; }
 
 int kernel_trace(const char** names_out, int capacity) {
-  const unsigned kept = t_trace_n < (unsigned)kTraceCap ? t_trace_n : (unsigned)kTraceCap;
+  unsigned kept = t_trace_n < (unsigned)kTraceCap ? t_trace_n : (unsigned)kTraceCap;
+  if (capacity >= 0 && kept > (unsigned)capacity) kept = (unsigned)capacity;  // a small array receives the NEWEST names
   const unsigned first = t_trace_n - kept;
   int n = 0;
   for (unsigned k = first; k < t_trace_n && n < capacity; ++k) names_out[n++] = t_trace[k % kTraceCap];

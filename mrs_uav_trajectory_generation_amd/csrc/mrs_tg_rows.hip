@@ -732,8 +732,9 @@ hipError_t launch_solve_rows(const BatchView& b, int d, const uint8_t* mask, con
                              const RowsTail& tail) {
   const bool sampling = tail.sampling_dt > 0.0;
   RowsTail tail_k = tail;  // (the copy the kernel gets: with the sampling walk's table filled in)
+  AccPin pin;  // (released when this function returns: behind the enqueue of the kernel that reads the table)
   if (sampling) {
-    hipError_t et = sample_acc_table(tail.sampling_dt, tail.sample_capacity, stream, &tail_k.sample_acc, &tail_k.sample_acc_n);
+    hipError_t et = sample_acc_table(tail.sampling_dt, tail.sample_capacity, stream, &tail_k.sample_acc, &tail_k.sample_acc_n, &pin);
     if (et != hipSuccess) return et;
   }
   if (tail.maxima_in_launch) {
