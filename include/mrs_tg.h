@@ -393,6 +393,15 @@ int mrs_tg_kernel_ms_history(mrs_tg_ctx* ctx, int kernel_id, float* ms_out, int 
  * call ran instead of inferring them from the batch size. */
 void mrs_tg_kernel_trace_reset(void);
 int mrs_tg_kernel_trace(const char** names_out, int capacity);
+/* (ABI 5) The routing table, asked of the routers: the names of the kernels a call WOULD launch for this plan under these
+ * options, in launch order -- the calling thread runs the same launch functions in a dry mode in which every size rule,
+ * environment knob and hint takes effect and nothing is enqueued (no device work, no argument is dereferenced).
+ * group_size 0: what mrs_tg_plan_solve(plan, ..., opt, ...) launches; 1 .. 16: what one dispatch of
+ * mrs_tg_bound_solve_launch_group carrying that many batches of this plan launches.  names_out receives pointers to static
+ * strings; returns the number written (<= capacity) or a negative MRS_TG_ERR_*.  Resets the calling thread's kernel trace.
+ * tests/test_gpu_routing.py pins the route of every BASELINE config and of the nodelet's defaults with it; DESIGN.md section 4's
+ * table is its output (scripts/routing_table.py). */
+int mrs_tg_plan_explain(mrs_tg_plan* plan, const mrs_tg_options* opt, int32_t group_size, const char** names_out, int32_t capacity);
 
 /* ---- single-path convenience mirroring findTrajectory()'s signature ------------------------- */
 

@@ -81,7 +81,7 @@ class InitialState(C.Structure):
 
 EXPORTED_SYMBOLS = [
     "mrs_tg_create", "mrs_tg_destroy", "mrs_tg_last_error", "mrs_tg_abi_version", "mrs_tg_capabilities", "mrs_tg_default_options",
-    "mrs_tg_kernel_trace_reset", "mrs_tg_kernel_trace",
+    "mrs_tg_kernel_trace_reset", "mrs_tg_kernel_trace", "mrs_tg_plan_explain",
     "mrs_tg_set_stream", "mrs_tg_reset_stream", "mrs_tg_synchronize", "mrs_tg_solve_batch", "mrs_tg_plan_create", "mrs_tg_plan_destroy",
     "mrs_tg_plan_n_paths", "mrs_tg_plan_n_segments", "mrs_tg_plan_max_segments", "mrs_tg_plan_get_order",
     "mrs_tg_plan_assemble", "mrs_tg_plan_block_bytes", "mrs_tg_plan_solve", "mrs_tg_plan_bind_solve",
@@ -127,6 +127,8 @@ def load_library():
     L.mrs_tg_kernel_trace_reset.restype = None
     L.mrs_tg_kernel_trace.restype = C.c_int
     L.mrs_tg_kernel_trace.argtypes = [C.POINTER(C.c_char_p), C.c_int]
+    L.mrs_tg_plan_explain.restype = C.c_int
+    L.mrs_tg_plan_explain.argtypes = [vp, C.POINTER(Options), C.c_int32, C.POINTER(C.c_char_p), C.c_int32]
     L.mrs_tg_default_options.restype = None
     L.mrs_tg_default_options.argtypes = [C.POINTER(Options)]
     L.mrs_tg_host_alloc.restype = C.c_int
@@ -585,6 +587,15 @@ class Plan:
         ctx._check(self._L.mrs_tg_plan_get_order(h, _np_ptr(order)), "mrs_tg_plan_get_order")
         self.order = order[:self.n_paths]
         self._bound = []
+
+    def explain(self, opt, group_size=0):
+        """The kernels a solve of this plan under `opt` WOULD launch, in order (mrs_tg_plan_explain: the launchers run dry);
+        group_size 1 .. 16: one dispatch of the grouped issue carrying that many batches."""
+        buf = (C.c_char_p * 32)()
+        n = self._L.mrs_tg_plan_explain(self._h, C.byref(opt), int(group_size), buf, 32)
+        if n < 0:
+            self.ctx._check(n, "mrs_tg_plan_explain")
+        return [buf[i].decode() for i in range(n)]
 
     def close(self):
         if getattr(self, "_h", None):

@@ -84,9 +84,6 @@ struct mrs_tg_plan {
   size_t ws_doubles = 0;
   double* d_H = nullptr;
   double* d_Ainv = nullptr;
-  // scratch of the two-kernel sampler (chunk descriptors), grown on demand
-  void* d_sample_scratch = nullptr;
-  size_t sample_scratch_bytes = 0;
   mrs_tg::NonlinearPlan nl;
 };
 
@@ -158,25 +155,6 @@ int ensure_ws(mrs_tg_plan* plan, size_t doubles) {
   plan->ws_doubles = 0;
   HIP_TRY(plan->ctx, mrs_tg::pool_alloc(&plan->d_ws, doubles * sizeof(double)));
   plan->ws_doubles = doubles;
-  return MRS_TG_OK;
-}
-
-// the sampler's scratch when the launch takes the two-kernel sampler, else nullptr (*out)
-int ensure_sample_scratch(mrs_tg_plan* plan, int capacity, void** out) {
-  *out = nullptr;
-  if (!mrs_tg::sample_split_applies(plan->view, capacity)) return MRS_TG_OK;
-  const size_t bytes = mrs_tg::sample_scratch_bytes(plan->view, capacity);
-  if (plan->sample_scratch_bytes < bytes) {
-    if (plan->d_sample_scratch) {
-      (void)hipStreamSynchronize(plan->ctx->stream);  // pool contract: no work in flight on a block that is given back
-      mrs_tg::pool_free(plan->d_sample_scratch);
-    }
-    plan->d_sample_scratch = nullptr;
-    plan->sample_scratch_bytes = 0;
-    HIP_TRY(plan->ctx, mrs_tg::pool_alloc_bytes(&plan->d_sample_scratch, bytes));
-    plan->sample_scratch_bytes = bytes;
-  }
-  *out = plan->d_sample_scratch;
   return MRS_TG_OK;
 }
 
@@ -442,7 +420,6 @@ void mrs_tg_plan_destroy(mrs_tg_plan* plan) {
   if (plan->d_ws) (void)mrs_tg::pool_free(plan->d_ws);
   if (plan->d_H) (void)mrs_tg::pool_free(plan->d_H);
   if (plan->d_Ainv) (void)mrs_tg::pool_free(plan->d_Ainv);
-  if (plan->d_sample_scratch) (void)mrs_tg::pool_free(plan->d_sample_scratch);
   delete plan;
 }
 
@@ -496,7 +473,7 @@ int mrs_tg_plan_solve(mrs_tg_plan* plan, const double* wp, const uint8_t* mask, 
     const char* e = std::getenv("MRS_TG_VERIFY_FLAGS");
     return e != nullptr && std::atoi(e) != 0;
   }();
-  if (verify_flags && (opt->flags & MRS_TG_FLAG_POSITIONS_ARE_WAYPOINTS)) {
+  if (verify_flags && !mrs_tg::dry_run() && (opt->flags & MRS_TG_FLAG_POSITIONS_ARE_WAYPOINTS)) {
     long long bad = 0;
     HIP_TRY(ctx, mrs_tg::count_position_mismatches(b, wp, mask, vals, ctx->stream, &bad));
     if (bad != 0)
@@ -587,12 +564,9 @@ int mrs_tg_plan_solve(mrs_tg_plan* plan, const double* wp, const uint8_t* mask, 
     if (general)
       HIP_TRY(ctx, mrs_tg::launch_solve_general(b, d, mask, vals, seg_times, plan->d_ws, coeffs, status, cost, ctx->stream));
   }
-  if (opt->sampling_dt > 0 && !sampled) {
-    void* scratch = nullptr;
-    if ((rc = ensure_sample_scratch(plan, opt->sample_capacity, &scratch)) != MRS_TG_OK) return rc;
+  if (opt->sampling_dt > 0 && !sampled)
     HIP_TRY(ctx, mrs_tg::launch_sample(b, coeffs, seg_times, opt->sampling_dt, opt->sample_capacity, n_samples, samples,
-                                       ctx->stream, scratch));
-  }
+                                       ctx->stream));
   return MRS_TG_OK;
 }
 
@@ -874,6 +848,49 @@ int mrs_tg_bound_solve_launch_group(mrs_tg_bound_solve* const* bound, int32_t n_
   return MRS_TG_OK;
 }
 
+// The routing table, from the routers themselves: the calling thread runs the very launch functions a solve would run, in dry
+// mode -- every size rule, environment knob and hint takes effect, kernels are noted instead of enqueued.
+int mrs_tg_plan_explain(mrs_tg_plan* plan, const mrs_tg_options* opt, int32_t group_size, const char** names_out, int32_t capacity) {
+  if (!plan || !names_out || capacity <= 0) return fail(plan ? plan->ctx : nullptr, MRS_TG_ERR_INVALID_ARG, "plan, names_out and a positive capacity are required");
+  mrs_tg_ctx* ctx = plan->ctx;
+  int rc = check_options(ctx, opt);
+  if (rc != MRS_TG_OK) return rc;
+  if (group_size < 0 || group_size > mrs_tg::kRowsGroupMax)
+    return fail(ctx, MRS_TG_ERR_INVALID_ARG, "group_size %d: a dispatch carries 1 .. %d batches (0 = a single solve)", group_size, mrs_tg::kRowsGroupMax);
+  // stand-ins for the caller's device arrays: never dereferenced (nothing is enqueued), only tested against NULL
+  static double dummy_d[4];
+  static uint8_t dummy_b[4];
+  static int32_t dummy_i[4];
+  struct DryScope {
+    mrs_tg_ctx* c;
+    bool was_profiling;
+    explicit DryScope(mrs_tg_ctx* ctx_) : c(ctx_), was_profiling(ctx_->profiling) {
+      c->profiling = false;  // (no events are armed for launches that do not happen)
+      mrs_tg::set_dry_run(true);
+      mrs_tg::kernel_trace_reset();
+    }
+    ~DryScope() {
+      mrs_tg::set_dry_run(false);
+      c->profiling = was_profiling;
+    }
+  };
+  {
+    DryScope scope(ctx);
+    if (group_size == 0) {
+      rc = mrs_tg_plan_solve(plan, dummy_d, dummy_b, dummy_d, dummy_d, opt, dummy_d, dummy_d, dummy_i, dummy_d,
+                             opt->sampling_dt > 0 ? dummy_i : nullptr, opt->sampling_dt > 0 ? dummy_d : nullptr);
+    } else {
+      std::vector<mrs_tg_bound_solve> solves((size_t)group_size,
+                                             mrs_tg_bound_solve{plan, dummy_d, dummy_b, dummy_d, dummy_d, *opt, dummy_d, dummy_d, dummy_i, dummy_d, nullptr, nullptr});
+      std::vector<mrs_tg_bound_solve*> ptrs;
+      for (mrs_tg_bound_solve& b : solves) ptrs.push_back(&b);
+      rc = mrs_tg_bound_solve_launch_group(ptrs.data(), group_size, group_size);
+    }
+  }
+  if (rc != MRS_TG_OK) return rc;
+  return mrs_tg::kernel_trace(names_out, capacity);
+}
+
 int mrs_tg_plan_cost_gradient(mrs_tg_plan* plan, int32_t d, const uint8_t* mask, const double* vals,
                               const double* seg_times, double* cost, double* grad) {
   if (!plan || !mask || !vals || !seg_times || !cost || !grad)
@@ -913,13 +930,8 @@ int mrs_tg_plan_sample_states(mrs_tg_plan* plan, const double* coeffs, const dou
   if (!(sampling_dt > 0.0) || sample_capacity < 0 || (sample_capacity > 0 && !states))
     return fail(ctx, MRS_TG_ERR_INVALID_ARG, "sampling_dt must be positive and states_out_dev given for a positive capacity");
   HIP_TRY(ctx, use_device(ctx->device));
-  void* scratch = nullptr;
-  if (sample_capacity > 0) {
-    const int rcs = ensure_sample_scratch(plan, sample_capacity, &scratch);
-    if (rcs != MRS_TG_OK) return rcs;
-  }
   HIP_TRY(ctx, mrs_tg::launch_sample_states(plan->view, coeffs, seg_times, sampling_dt, sample_capacity, n_samples,
-                                            sample_capacity > 0 ? states : nullptr, ctx->stream, scratch));
+                                            sample_capacity > 0 ? states : nullptr, ctx->stream));
   return MRS_TG_OK;
 }
 
@@ -1137,6 +1149,22 @@ static int solve_batch_impl(mrs_tg_ctx* ctx, int32_t n_paths, const int32_t* so,
           break;
         }
   }
+  // ... and a path that starts from a moving state (non-zero constrained derivatives at its first vertex): a hint for the
+  // outer loop's launch shape only (small batches of 13-15 segments; launch_nonlinear)
+  bool moving_starts = false;
+  if (local.time_alloc_method == MRS_TG_TIME_ALLOC_MELLINGER && n_paths <= 1536 && plan->view.max_segments >= 13 &&
+      plan->view.max_segments <= 15) {
+    for (int32_t p = 0; p < n_paths && !moving_starts; ++p) {
+      const size_t v = (size_t)so[p] + p;
+      for (int k = 1; k < 5 && !moving_starts; ++k)
+        if (mask[v * 5 + k])
+          for (int q = 0; q < 4; ++q) moving_starts = moving_starts || vals[(v * 5 + k) * 4 + q] != 0.0;
+    }
+  }
+  struct MovingScope {
+    explicit MovingScope(bool on) { mrs_tg::set_moving_starts_hint(on); }
+    ~MovingScope() { mrs_tg::set_moving_starts_hint(false); }
+  } moving_scope(moving_starts);
   // zero copy: one pass over every array (fixed times, default solve) and every array the caller passed is pinned
   bool zero_copy = zero_copy_allowed && local.time_alloc_method == MRS_TG_TIME_ALLOC_NONE && !local.estimate_times &&
                    (local.flags & (MRS_TG_FLAG_GENERAL_PATTERNS | MRS_TG_FLAG_MATERIALIZED_BLOCKS)) == 0 &&

@@ -221,211 +221,175 @@ __global__ __launch_bounds__(64) void sample_kernel(BatchView b, const double* _
 }
 
 // ---------------------------------------------------------------------------------------------
-// The sampler of large launches, in two kernels (round 6).  sample_kernel spends a whole wavefront on a walk that is a
-// scalar, sequential algorithm: per path ~13 chunks, each a dependent chain of bookkeeping in front of the next (8 % of its
-// wave cycles had a VALU instruction in flight, a wavefront lived 66 k cycles: profiles/round5_pmc_sq_nonlinear_65536.csv).
-//   sample_walk_kernel: ONE LANE per path runs the reference's loop as written (trajectory.cpp:131-150: compare, carry,
-//     two additions per sample) and emits only CHUNK descriptors -- {index of the chunk's first sample, segment, time in
-//     segment of that sample, count <= 64}: a new chunk where the walk enters a segment and after 64 samples, ~13 per
-//     10-segment path -- and the sample count.
-//   sample_eval_kernel: one lane per SAMPLE, 256 samples of one path per workgroup: the lane finds its chunk (binary search
-//     over the path's descriptors in LDS), repeats the walk's own additions from the chunk's start value (k additions of
-//     dt for the chunk's k-th sample: the reference's running sum, bit for bit), evaluates the four polynomials from the
-//     coefficients staged in LDS and stores its 32 bytes next to its neighbours'.
-// Same samples and counts as sample_kernel to the last bit (tests/test_gpu_large_batches.py::
-// test_separate_sampler_equals_the_sampler_in_the_solve_kernels_tail).  Round 3's one-lane-per-path walk stored 16 bytes per
-// SAMPLE from the walking lane and was three times slower than the wavefront walk; this one stores 16 bytes per chunk.
-struct SampleChunk {
-  double tin;            // time in segment of the chunk's first sample
-  int32_t first;         // index of that sample
-  uint16_t seg, count;   // segment, samples in the chunk (1 .. 64)
-};
-static_assert(sizeof(SampleChunk) == 16, "chunk descriptor layout");
-
-constexpr int kWalkPaths = 64;         // paths per workgroup of the walk: one wavefront, a lane each
-constexpr int kWalkLdsSegments = 128;  // longest path whose segment times the walk keeps in LDS (64 paths x 128 x 8 B = 64 KB)
-constexpr int kEvalThreads = 256;      // samples per workgroup of the evaluation
-constexpr int kEvalSegCap = 48;        // segments whose coefficients an evaluation workgroup stages in LDS (15 KB)
-
-__host__ __device__ inline int sample_chunk_stride(int max_segments, int capacity) {
-  // a path enters at most S segments and closes a chunk after every 64 samples it emits: S + capacity / 64 + 1 chunks at most
-  return max_segments + capacity / 64 + 2;
+// The sampler of large launches (round 6): a GROUP of G = 8 or 16 lanes per path, 64 / G paths per wavefront, walk and
+// evaluation fused.  sample_kernel spends a whole wavefront on a walk that is a scalar, sequential algorithm: per path ~13
+// chunks, each with ~150 instructions of bookkeeping on all 64 lanes in front of the next (8 % of its wave cycles had a VALU
+// instruction in flight: profiles/round5_pmc_sq_nonlinear_65536.csv).  Here the same bookkeeping serves 64 / G paths at once:
+// per step lane j of a group adds dt to the group's time in segment j times (the reference's running sum, bit for bit), one
+// ballot finds in every group the first lane at which the walk stops (segment end, trajectory end, capacity), the lanes before
+// it evaluate the four polynomials of their path's segment (coefficients in LDS) and store their sample, and the stopping
+// lane's value seeds the group's next step; groups whose time has run over their segment carry it into the next one in a
+// predicated loop.  Same samples and counts as sample_kernel to the last bit
+// (tests/test_gpu_large_batches.py::test_separate_sampler_equals_the_sampler_in_the_solve_kernels_tail, test_gpu_round6.py).
+// (The round-5 verdict's proposal -- a lane-per-path walk that emits chunk descriptors + a sample-per-lane evaluation -- was
+// built first and measured 2.4 x SLOWER than sample_kernel at 65536 x 10: profiles/round6_sampler_two_kernel_ab.txt.)
+__host__ __device__ inline int sample_group_cstride(int Smax) {  // doubles between two groups' coefficients in LDS: 2 (mod 32)
+  const int n = Smax * (kD * kN);
+  return n + ((2 - n % 32) + 32) % 32;
 }
 
-template <bool LDS_TIMES>
-__global__ __launch_bounds__(kWalkPaths) void sample_walk_kernel(BatchView b, const double* __restrict__ seg_times, double dt,
-                                                                 int capacity, int32_t* __restrict__ n_samples,
-                                                                 SampleChunk* __restrict__ chunks, int32_t* __restrict__ n_chunks,
-                                                                 int chunk_stride) {
-  extern __shared__ double s_T[];  // LDS_TIMES: [max_segments][64]: segment i of the workgroup's path l at i * 64 + l
-  const int lane = threadIdx.x;
-  const int q = blockIdx.x * kWalkPaths + lane;
-  const bool live = q < b.n_paths;
-  const PathRef pr = path_at(b, live ? q : b.n_paths - 1);
+template <int G>
+__device__ __forceinline__ double group_lane_value(double v, int base, int idx) {  // lane base + idx of this wavefront
+  return __shfl(v, base + idx, 64);
+}
+
+template <int G, int NDER>
+__global__ __launch_bounds__(64) void sample_group_kernel(BatchView b, const double* __restrict__ coeffs,
+                                                          const double* __restrict__ seg_times, double dt, int capacity,
+                                                          int32_t* __restrict__ n_samples, double* __restrict__ samples,
+                                                          const double* __restrict__ acc_table, int acc_n) {
+  constexpr int P = 64 / G;        // paths per wavefront
+  extern __shared__ double lds[];  // [P][Smax] segment times | [P][Smax][4][10] coefficients
+  const int lane = threadIdx.x, g = lane / G, j = lane % G, base = g * G;
+  const int Smax = b.max_segments;
+  const int q = blockIdx.x * P + g;
+  const bool active = q < b.n_paths;
+  const PathRef pr = path_at(b, active ? q : b.n_paths - 1);
   const int S = pr.S;
-  const double* __restrict__ Tg = seg_times + pr.s0;
-  if (LDS_TIMES) {
-    if (b.uniform_S > 0) {  // the 64 paths' times are one contiguous run: coalesced
-      const int q0 = blockIdx.x * kWalkPaths;
-      const int total = min(kWalkPaths, b.n_paths - q0) * S;
-      const double* __restrict__ base = seg_times + (size_t)q0 * S;
-      for (int e = lane; e < total; e += kWalkPaths) s_T[(e % S) * kWalkPaths + e / S] = base[e];
-    } else {
-      for (int i = 0; i < S; ++i) s_T[i * kWalkPaths + lane] = Tg[i];
+  // coefficients of group g at g * cstride: a stride of 2 (mod 32) doubles puts the groups' 16-byte reads of one instruction
+  // on different banks (400 doubles = 3200 bytes apart, four of eight groups met on the same banks: a 4-way conflict on every
+  // one of the 20 reads per step -- it was the kernel's time)
+  const int cstride = sample_group_cstride(Smax);
+  double* s_T = lds + (size_t)g * Smax;
+  double* s_c = lds + (size_t)P * Smax + (size_t)g * cstride;
+  // 16-byte pieces, eight requests per lane in flight before the first is waited for (a copy loop of one 8-byte load per
+  // iteration is a chain of 50 memory round trips for the 25 KB of eight 10-segment paths: it WAS the kernel's time)
+  auto stage = [&](const double* __restrict__ src, double* dst, int n_doubles, int first, int stride) {
+    const double2* __restrict__ s2 = reinterpret_cast<const double2*>(src);
+    double2* d2 = reinterpret_cast<double2*>(dst);
+    const int n2 = n_doubles >> 1;   // (n_doubles is a multiple of 40)
+    for (int e0 = first; e0 < n2; e0 += 8 * stride) {
+      double2 v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int e = e0 + u * stride;
+        v[u] = s2[e < n2 ? e : n2 - 1];  // (unconditional: eight requests back to back, no branch around each)
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int e = e0 + u * stride;
+        if (e < n2) d2[e] = v[u];
+      }
     }
-    __syncthreads();
+  };
+  if (b.uniform_S > 0) {  // the wavefront's paths are one contiguous run of segments: coalesced over all 64 lanes
+    const int q0 = blockIdx.x * P;
+    const int np = min(P, b.n_paths - q0);
+    const double* __restrict__ tg = seg_times + (size_t)q0 * S;
+    for (int e = lane; e < np * S; e += 64) lds[e] = tg[e];
+    if (samples) {  // (the same pipelined copy, each path's run to its own padded place)
+      const double2* __restrict__ s2 = reinterpret_cast<const double2*>(coeffs + (size_t)q0 * S * (kD * kN));
+      double2* d2 = reinterpret_cast<double2*>(lds + (size_t)P * Smax);
+      const int per2 = S * (kD * kN) / 2, n2 = np * per2, cs2 = cstride / 2;
+      for (int e0 = lane; e0 < n2; e0 += 8 * 64) {
+        double2 v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const int e = e0 + u * 64;
+          v[u] = s2[e < n2 ? e : n2 - 1];
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const int e = e0 + u * 64;
+          if (e < n2) d2[(e / per2) * cs2 + e % per2] = v[u];
+        }
+      }
+    }
+  } else if (active) {
+    for (int e = j; e < S; e += G) s_T[e] = seg_times[pr.s0 + e];
+    if (samples) stage(coeffs + (size_t)pr.s0 * (kD * kN), s_c, S * (kD * kN), j, G);
   }
-  auto T_at = [&](int i) -> double { return LDS_TIMES ? s_T[i * kWalkPaths + lane] : Tg[i]; };
-  // t_end and the start segment as the reference computes them (trajectory.cpp:100-124 with t_start = 0)
+  __syncthreads();
+  // every lane of a group carries the group's walk state (i, Ti, tin, n): t_end and the start segment as the reference
+  // computes them (trajectory.cpp:100-120, t_start = 0); N = #{k : A[k] < t_end} from the accumulated-time table
+  // (mrs_tg_sampling.hpp: "accumulated < t_end" for sample k is "k < N")
   double t_end = 0.0;
-  for (int i = 0; i < S; ++i) t_end += T_at(i);
+  for (int i = 0; i < S; ++i) t_end += s_T[i];
+  const double inv_dt = 1.0 / dt;
+  int n_total = 0;
+  if (t_end == t_end) {  // (a t_end that is not a number ends the reference's loop at once: no sample)
+    int k = (int)fmin(fmax(t_end * inv_dt - 1.0, 0.0), (double)(acc_n - 1));
+    while (k > 0 && acc_table[k - 1] >= t_end) --k;
+    while (k < acc_n && acc_table[k] < t_end) ++k;   // the first k with A[k] >= t_end
+    n_total = (k >= acc_n) ? 0x3fffffff : k;         // (none in the table: more samples than any buffer it was built for holds)
+  }
   int i = 0;
   {
     double cum = 0.0;
     for (i = 0; i < S; ++i) {
-      cum += T_at(i);
+      cum += s_T[i];
       if (cum > 0.0) break;
     }
   }
-  int n = 0, nch = 0;
-  SampleChunk* __restrict__ my = chunks ? chunks + (size_t)pr.p * chunk_stride : nullptr;
-  if (live && i < S) {
-    double tin = 0.0, acc = 0.0;
-    double Ti = T_at(i);
-    double Tnext = (i + 1 < S) ? T_at(i + 1) : 0.0;  // loaded one segment ahead: a carry does not wait for memory
-    int c_first = 0, c_count = 0;
-    double c_tin = 0.0;
-    while (acc < t_end) {  // trajectory.cpp:131
-      if (tin > Ti) {      // :132-139: carry the remainder into the next segment
-        if (c_count > 0 && my) {
-          my[nch] = SampleChunk{c_tin, c_first, (uint16_t)i, (uint16_t)c_count};
-          ++nch;
-          c_count = 0;
-        }
+  bool done = !active || i >= S;
+  double dt_r[G];
+#pragma unroll
+  for (int r = 1; r < G; ++r) dt_r[r] = (j >= r) ? dt : 0.0;
+  double tin = 0.0;  // (t_start = 0: the walk enters the first segment of positive length at its start)
+  double Ti = done ? 0.0 : s_T[i];
+  int n = 0;
+  double* out = (samples && active) ? samples + (size_t)pr.p * capacity * (NDER + 1) * kD : nullptr;
+  for (;;) {
+    done = done || n >= n_total;  // trajectory.cpp:131
+    // carry the remainder into the next segment(s) (:132-139), group by group
+    while (__ballot(!done && tin > Ti) != 0ull) {
+      if (!done && tin > Ti) {
         tin = tin - Ti;
         ++i;
-        if (i >= S) break;
-        Ti = Tnext;
-        Tnext = (i + 1 < S) ? T_at(i + 1) : 0.0;
-        continue;
+        if (i >= S) done = true;
+        else Ti = s_T[i];
       }
-      if (n >= capacity) {  // more samples than the caller's array holds: reported as capacity + 1, the walk ends here
-        ++n;
-        break;
-      }
-      if (c_count == 64 && my) {
-        my[nch] = SampleChunk{c_tin, c_first, (uint16_t)i, (uint16_t)64};
-        ++nch;
-        c_count = 0;
-      }
-      if (c_count == 0) {
-        c_first = n;
-        c_tin = tin;
-      }
-      ++c_count;
-      ++n;
-      tin += dt;   // :148-149
-      acc += dt;
     }
-    if (c_count > 0 && my && i < S) {
-      my[nch] = SampleChunk{c_tin, c_first, (uint16_t)i, (uint16_t)c_count};
-      ++nch;
-    }
-  }
-  if (live) {
-    if (n_samples) n_samples[pr.p] = n;
-    if (n_chunks) n_chunks[pr.p] = nch;
-  }
-}
-
-template <int NDER>
-__global__ __launch_bounds__(kEvalThreads) void sample_eval_kernel(BatchView b, const double* __restrict__ coeffs, double dt,
-                                                                   int capacity, const int32_t* __restrict__ n_samples,
-                                                                   const SampleChunk* __restrict__ chunks,
-                                                                   const int32_t* __restrict__ n_chunks, int chunk_stride,
-                                                                   double* __restrict__ samples) {
-  extern __shared__ double s_eval[];  // [kEvalSegCap][4][10] coefficients | chunk descriptors of the path that touch this block
-  const int tid = threadIdx.x;
-  const PathRef pr = path_at(b, blockIdx.x);
-  const int n = min(n_samples[pr.p], capacity);
-  const int e0 = blockIdx.y * kEvalThreads;
-  if (e0 >= n) return;
-  double* s_c = s_eval;
-  SampleChunk* s_ch = reinterpret_cast<SampleChunk*>(s_eval + kEvalSegCap * kD * kN);
-  const SampleChunk* __restrict__ my = chunks + (size_t)pr.p * chunk_stride;
-  const int nch = n_chunks[pr.p];
-  // the chunks that hold samples of [e0, e0 + 256): chunks are sorted by `first`; d_lo = the last one that starts at or before e0
-  // (every lane runs the same search: wave-uniform loads)
-  int lo = 0, hi = nch;  // invariant: first[lo] <= e0 < first[hi]
-  while (hi - lo > 1) {
-    const int mid = (lo + hi) >> 1;
-    if (my[mid].first <= e0) lo = mid;
-    else hi = mid;
-  }
-  const int d_lo = lo;
-  const int e_end = min(e0 + kEvalThreads, n);
-  // at most 256 chunks can start inside the block: stage [d_lo, d_lo + 257) and let the lanes search that window
-  const int n_win = min(nch - d_lo, kEvalThreads + 1);
-  for (int d = tid; d < n_win; d += kEvalThreads) s_ch[d] = my[d_lo + d];
-  if (tid == 0 && n_win <= kEvalThreads) s_ch[n_win].first = 0x7fffffff;  // sentinel behind the window
-  __syncthreads();
-  // (the window is sorted: the last chunk that starts below e_end closes it)
-  int w_hi = 1;
-  {
-    int a = 0, c = n_win;  // first[a] < e_end <= first[c] (c may be the sentinel)
-    while (c - a > 1) {
-      const int mid = (a + c) >> 1;
-      if (s_ch[mid].first < e_end) a = mid;
-      else c = mid;
-    }
-    w_hi = c;  // chunks [0, w_hi) of the window touch the block
-  }
-  const int seg_lo = s_ch[0].seg, seg_hi = s_ch[w_hi - 1].seg;
-  const int n_stage = min(seg_hi - seg_lo + 1, kEvalSegCap);
-  {
-    const double* __restrict__ cg = coeffs + ((size_t)pr.s0 + seg_lo) * kD * kN;
-    for (int k = tid; k < n_stage * kD * kN; k += kEvalThreads) s_c[k] = cg[k];
-  }
-  __syncthreads();
-  const int e = e0 + tid;
-  const bool valid = e < n;
-  // my chunk: the last one of the window with first <= e
-  int a = 0;
-  {
-    int c = w_hi;
-    while (c - a > 1) {
-      const int mid = (a + c) >> 1;
-      if (s_ch[mid].first <= e) a = mid;
-      else c = mid;
-    }
-  }
-  const SampleChunk ch = s_ch[a];
-  const int k = valid ? e - ch.first : 0;
-  // the walk's own additions: the chunk's k-th sample is ((tin + dt) + dt) ... + dt, k times
-  double tj = ch.tin;
-  for (int r = 0; __builtin_amdgcn_ballot_w64(r < k) != 0ull; ++r)
-    if (r < k) tj += dt;
-  if (!valid) return;
-  const int sl = (int)ch.seg - seg_lo;
-  double* out = samples + ((size_t)pr.p * capacity + e) * (NDER + 1) * kD;
-  auto horner = [&](const double* __restrict__ c) {
+    if (__ballot(!done) == 0ull) break;
+    // lane j adds dt j times (the addends dt_r = j >= r ? dt : +0.0 are set up once: x + 0.0 is x, bit for bit, for x >= 0)
+    double tj = tin;
 #pragma unroll
-    for (int kk = 0; kk <= NDER; ++kk) {
-      double v[kD];
+    for (int r = 1; r < G; ++r) tj += dt_r[r];
+    const bool ok = !done && (n + j < n_total) && !(tj > Ti) && (n + j <= capacity);
+    const unsigned long long ball = __ballot(ok);
+    const unsigned bits = (unsigned)(ball >> base) & ((1u << G) - 1u);
+    const int m = (bits == (1u << G) - 1u) ? G : __builtin_ctz(~bits);  // lanes [0, m) of the group emit a sample
+    if (out && j < m && n + j < capacity) {
+      const double* c = s_c + (size_t)i * (kD * kN);
+      double* o = out + (size_t)(n + j) * (NDER + 1) * kD;
 #pragma unroll
-      for (int dd = 0; dd < kD; ++dd) {
-        double accv = falling_factorial(kN - 1, kk) * c[dd * kN + kN - 1];
+      for (int k = 0; k <= NDER; ++k) {
+        double v[kD];
 #pragma unroll
-        for (int j = kN - 2; j >= kk; --j) accv = accv * tj + falling_factorial(j, kk) * c[dd * kN + j];
-        v[dd] = accv;
+        for (int dd = 0; dd < kD; ++dd) {
+          double accv = falling_factorial(kN - 1, k) * c[dd * kN + kN - 1];
+#pragma unroll
+          for (int jj = kN - 2; jj >= k; --jj) accv = accv * tj + falling_factorial(jj, k) * c[dd * kN + jj];
+          v[dd] = accv;
+        }
+        if (k == 0) v[3] = wrap_heading(v[3]);
+#pragma unroll
+        for (int dd = 0; dd < kD; ++dd) o[k * kD + dd] = v[dd];
       }
-      if (kk == 0) v[3] = wrap_heading(v[3]);
-#pragma unroll
-      for (int dd = 0; dd < kD; ++dd) out[kk * kD + dd] = v[dd];
     }
-  };
-  if (sl < n_stage) horner(s_c + (size_t)sl * kD * kN);
-  else horner(coeffs + ((size_t)pr.s0 + ch.seg) * kD * kN);  // (a block that spans more segments than the stage holds)
+    if (!done) {
+      if (m == G) {  // every lane emitted: the step ran out before the walk stopped
+        tin = group_lane_value<G>(tj, base, G - 1) + dt;
+      } else {       // lane m is the first that did not emit: its value is the walk's state at the stop
+        tin = group_lane_value<G>(tj, base, m);
+      }
+      n += m;
+      if (n > capacity) done = true;  // overflow: reported as capacity + 1
+    } else {
+      (void)group_lane_value<G>(tj, base, 0);  // (the exchange is executed by all lanes)
+    }
+  }
+  if (active && j == 0 && n_samples) n_samples[pr.p] = n;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -715,48 +679,50 @@ hipError_t sample_acc_table(double dt, int capacity, hipStream_t stream, const d
   return hipSuccess;
 }
 
-// scratch of the two-kernel sampler for a batch: chunk descriptors [n_paths][stride] + chunk counts [n_paths]
-size_t sample_scratch_bytes(const BatchView& b, int capacity) {
-  return ((size_t)b.n_paths * sample_chunk_stride(b.max_segments, capacity) * sizeof(SampleChunk) + 255) / 256 * 256 +
-         (size_t)b.n_paths * sizeof(int32_t);
+static size_t sample_group_lds_bytes(int Smax, int G) {
+  return (size_t)(64 / G) * ((size_t)Smax + sample_group_cstride(Smax)) * sizeof(double);
 }
 
-bool sample_split_applies(const BatchView& b, int capacity) {
-  // MRS_TG_SAMPLE_SPLIT (tuning / test knob, read once): smallest launch, in paths, that takes the two-kernel sampler;
-  // 0 = never.  Default 2048: below it the walk kernel's wavefronts (64 paths each) do not fill the SIMDs
-  static const int min_paths = [] {
-    const char* e = std::getenv("MRS_TG_SAMPLE_SPLIT");
-    return e ? std::atoi(e) : 2048;
+// Which sampler a launch takes: 0 = one wavefront per path (sample_kernel), 8 / 16 = sample_group_kernel with that many lanes
+// per path.  The group kernels need 64 / G paths' coefficients in LDS (40 KB at most: four wavefronts per CU and more) and
+// enough paths to fill the SIMDs with 64 / G of them per wavefront.  MRS_TG_SAMPLE_GROUP=0 | 8 | 16 forces (read once).
+int sample_group_lanes(const BatchView& b) {
+  static const int forced = [] {
+    const char* e = std::getenv("MRS_TG_SAMPLE_GROUP");
+    return e ? std::atoi(e) : -1;
   }();
-  return min_paths > 0 && b.n_paths >= min_paths && capacity >= 1 && b.max_segments <= 65535;
+  auto fits = [&](int G) { return sample_group_lds_bytes(b.max_segments, G) <= 40 * 1024; };
+  if (forced == 0) return 0;
+  if (forced == 8 || forced == 16) return fits(forced) ? forced : 0;
+  if (b.n_paths >= 8192 && fits(8)) return 8;
+  if (b.n_paths >= 4096 && fits(16)) return 16;
+  return 0;
 }
 
 template <int NDER>
 static hipError_t launch_sample_n(const BatchView& b, const double* coeffs, const double* seg_times, double dt, int capacity,
-                                  int32_t* n_samples, double* samples, hipStream_t stream, void* scratch) {
-  if (scratch != nullptr && samples != nullptr && n_samples != nullptr && sample_split_applies(b, capacity)) {
-    const int stride = sample_chunk_stride(b.max_segments, capacity);
-    SampleChunk* chunks = static_cast<SampleChunk*>(scratch);
-    int32_t* n_chunks = reinterpret_cast<int32_t*>(static_cast<char*>(scratch) +
-                                                   ((size_t)b.n_paths * stride * sizeof(SampleChunk) + 255) / 256 * 256);
-    const unsigned walk_blocks = (unsigned)((b.n_paths + kWalkPaths - 1) / kWalkPaths);
-    if (b.max_segments <= kWalkLdsSegments) {
-      const size_t lds = sizeof(double) * (size_t)b.max_segments * kWalkPaths;
-      if (lds > 64 * 1024) return hipErrorInvalidValue;
-      MRS_TG_LAUNCH(sample_walk_kernel<true>, dim3(walk_blocks), dim3(kWalkPaths), lds, stream, b, seg_times, dt, capacity, n_samples,
-                    chunks, n_chunks, stride);
+                                  int32_t* n_samples, double* samples, hipStream_t stream) {
+  const double* acc_table = nullptr;
+  int acc_n = 0;
+  AccPin pin;  // (released when this function returns: behind the enqueue of the kernel that reads the table)
+  if (!dry_run()) {  // (a dry run builds no table: an entry whose build kernel was not enqueued must not enter the cache)
+    hipError_t et = sample_acc_table(dt, capacity, stream, &acc_table, &acc_n, &pin);
+    if (et != hipSuccess) return et;
+  }
+  const int G = sample_group_lanes(b);
+  if (G != 0) {
+    const int P = 64 / G;
+    const size_t lds_g = sample_group_lds_bytes(b.max_segments, G);
+    const unsigned grid = (unsigned)((b.n_paths + P - 1) / P);
+    if (G == 8) {
+      note_kernel(NDER == 0 ? "sample_group_kernel<8, 0>" : "sample_group_kernel<8, NDER>");
+      if (!dry_run()) hipLaunchKernelGGL((sample_group_kernel<8, NDER>), dim3(grid), dim3(64), lds_g, stream, b, coeffs, seg_times, dt, capacity,
+                         n_samples, samples, acc_table, acc_n);
     } else {
-      MRS_TG_LAUNCH(sample_walk_kernel<false>, dim3(walk_blocks), dim3(kWalkPaths), 0, stream, b, seg_times, dt, capacity, n_samples,
-                    chunks, n_chunks, stride);
+      note_kernel(NDER == 0 ? "sample_group_kernel<16, 0>" : "sample_group_kernel<16, NDER>");
+      if (!dry_run()) hipLaunchKernelGGL((sample_group_kernel<16, NDER>), dim3(grid), dim3(64), lds_g, stream, b, coeffs, seg_times, dt, capacity,
+                         n_samples, samples, acc_table, acc_n);
     }
-    hipError_t e = hipGetLastError();
-    if (e != hipSuccess) return e;
-    const size_t lds_eval = sizeof(double) * kEvalSegCap * kD * kN + sizeof(SampleChunk) * (kEvalThreads + 2);
-    const unsigned blocks_per_path = (unsigned)((capacity + kEvalThreads - 1) / kEvalThreads);
-    // (paths along grid.x, which takes 2^31 - 1 workgroups; grid.y, limited to 65535, counts the 256-sample blocks of a path)
-    if (blocks_per_path > 65535u) return hipErrorInvalidValue;
-    MRS_TG_LAUNCH(sample_eval_kernel<NDER>, dim3((unsigned)b.n_paths, blocks_per_path), dim3(kEvalThreads), lds_eval, stream, b, coeffs,
-                  dt, capacity, n_samples, chunks, n_chunks, stride, samples);
     return hipGetLastError();
   }
   const size_t lds = sizeof(double) * ((size_t)b.max_segments * (1 + kD * kN) + kSampleBuffer) + sizeof(unsigned short) * kSampleBuffer;
@@ -765,11 +731,6 @@ static hipError_t launch_sample_n(const BatchView& b, const double* coeffs, cons
     hipError_t e = hipFuncSetAttribute((const void*)sample_kernel<NDER>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
   }
-  const double* acc_table = nullptr;
-  int acc_n = 0;
-  AccPin pin;  // (released when this function returns: behind the enqueue of the kernel that reads the table)
-  hipError_t et = sample_acc_table(dt, capacity, stream, &acc_table, &acc_n, &pin);
-  if (et != hipSuccess) return et;
   // one workgroup per path.  (Fewer, persistent workgroups that walk several paths each -- the kernel's loop allows it --
   // were measured in round 5: 65536 x 10 pipeline 1328 -> 1347 / 1385 / 1384 us with 15360 / 7680 / 3840 workgroups.)
   MRS_TG_LAUNCH(sample_kernel<NDER>, dim3((unsigned)b.n_paths), dim3(64), lds, stream, b, coeffs, seg_times, dt, capacity,
@@ -778,15 +739,15 @@ static hipError_t launch_sample_n(const BatchView& b, const double* coeffs, cons
 }
 
 hipError_t launch_sample(const BatchView& b, const double* coeffs, const double* seg_times, double dt, int capacity,
-                         int32_t* n_samples, double* samples, hipStream_t stream, void* scratch) {
+                         int32_t* n_samples, double* samples, hipStream_t stream) {
   if (b.n_paths == 0) return hipSuccess;
-  return launch_sample_n<0>(b, coeffs, seg_times, dt, capacity, n_samples, samples, stream, scratch);
+  return launch_sample_n<0>(b, coeffs, seg_times, dt, capacity, n_samples, samples, stream);
 }
 
 hipError_t launch_sample_states(const BatchView& b, const double* coeffs, const double* seg_times, double dt, int capacity,
-                                int32_t* n_samples, double* states, hipStream_t stream, void* scratch) {
+                                int32_t* n_samples, double* states, hipStream_t stream) {
   if (b.n_paths == 0) return hipSuccess;
-  return launch_sample_n<kSampleStateOrders - 1>(b, coeffs, seg_times, dt, capacity, n_samples, states, stream, scratch);
+  return launch_sample_n<kSampleStateOrders - 1>(b, coeffs, seg_times, dt, capacity, n_samples, states, stream);
 }
 
 __global__ void position_mismatch_kernel(int n_vertices, const double* __restrict__ wp, const uint8_t* __restrict__ mask,

@@ -25,6 +25,11 @@ bool shared_device_hint();
 // derivative slots beside its paths' ends; min-snap launches then use the instantiations that take such vertices
 void set_constrained_slots_hint(bool on);
 bool constrained_slots_hint();
+// Hint of the calling thread's current ABI call: some paths start from a moving state (non-zero constrained derivatives at
+// their first vertex).  Set by mrs_tg_solve_batch from the values it holds in host memory (a device-resident caller has no
+// flag for it); read by launch_nonlinear's choice between the plan's dimension split and lane groups
+void set_moving_starts_hint(bool on);
+bool moving_starts_hint();
 KernelTimer take_kernel_timer();  // the pending pair (null events when nothing is pending); consumed by the call
 void set_kernel_timer(hipEvent_t start, hipEvent_t stop);  // arms the next timed launch of this thread
 // Kernel trace (mrs_tg_kernel_trace): every launch of the library notes its kernel's name in a small per-thread ring, so
@@ -32,12 +37,17 @@ void set_kernel_timer(hipEvent_t start, hipEvent_t stop);  // arms the next time
 void note_kernel(const char* name);
 void kernel_trace_reset();
 int kernel_trace(const char** names_out, int capacity);  // oldest first; at most the newest 32 since the reset
+// Dry run (mrs_tg_plan_explain): the calling thread's launchers run their routing -- every size rule, environment knob and
+// hint exactly as in a real call -- and NOTE the kernels they would launch, but enqueue nothing
+bool dry_run();
+void set_dry_run(bool on);
 // launch with the pending timer, if any
 #define MRS_TG_LAUNCH_TIMED(kernel, grid, block, lds, stream, ...)                                           \
   do {                                                                                                       \
     const ::mrs_tg::KernelTimer kt__ = ::mrs_tg::take_kernel_timer();                                        \
     ::mrs_tg::note_kernel(#kernel);                                                                          \
-    hipExtLaunchKernelGGL(kernel, grid, block, lds, stream, kt__.start, kt__.stop, 0, __VA_ARGS__);          \
+    if (!::mrs_tg::dry_run())                                                                                \
+      hipExtLaunchKernelGGL(kernel, grid, block, lds, stream, kt__.start, kt__.stop, 0, __VA_ARGS__);        \
   } while (0)
 // the same for a kernel template of two arguments (a comma inside a macro argument needs parentheses, which would end up in the
 // noted name): MRS_TG_LAUNCH_TIMED_T2(kernel, A, B, grid, ...) launches kernel<A, B> and notes "kernel<A, B>"
@@ -45,18 +55,19 @@ int kernel_trace(const char** names_out, int capacity);  // oldest first; at mos
   do {                                                                                                             \
     const ::mrs_tg::KernelTimer kt__ = ::mrs_tg::take_kernel_timer();                                              \
     ::mrs_tg::note_kernel(#kernel "<" #A ", " #B ">");                                                             \
-    hipExtLaunchKernelGGL((kernel<A, B>), grid, block, lds, stream, kt__.start, kt__.stop, 0, __VA_ARGS__);        \
+    if (!::mrs_tg::dry_run())                                                                                      \
+      hipExtLaunchKernelGGL((kernel<A, B>), grid, block, lds, stream, kt__.start, kt__.stop, 0, __VA_ARGS__);      \
   } while (0)
 // plain launches, and launches that carry the events of a multi-kernel timing themselves
 #define MRS_TG_LAUNCH(kernel, ...)                \
   do {                                            \
     ::mrs_tg::note_kernel(#kernel);               \
-    hipLaunchKernelGGL(kernel, __VA_ARGS__);      \
+    if (!::mrs_tg::dry_run()) hipLaunchKernelGGL(kernel, __VA_ARGS__);      \
   } while (0)
 #define MRS_TG_LAUNCH_EXT(kernel, ...)            \
   do {                                            \
     ::mrs_tg::note_kernel(#kernel);               \
-    hipExtLaunchKernelGGL(kernel, __VA_ARGS__);   \
+    if (!::mrs_tg::dry_run()) hipExtLaunchKernelGGL(kernel, __VA_ARGS__);   \
   } while (0)
 
 // records `message` as the context's (and the global) last error and returns `code`
@@ -111,16 +122,14 @@ hipError_t launch_copy_samples(const double* src, double* dst, const int32_t* n_
 
 hipError_t launch_estimate_times(const BatchView& b, const double* wp, const double* limits, double* seg_times,
                                  hipStream_t stream);
-// scratch: sample_scratch_bytes(b, capacity) bytes of device memory for the two-kernel sampler of large launches (lane-per-path
-// walk + sample-per-lane evaluation, mrs_tg_kernels.hip), or nullptr: the one-wavefront-per-path kernel whatever the size
+// (large launches: 8 or 16 lanes per path, 64 / G paths per wavefront -- sample_group_kernel; else one wavefront per path)
 hipError_t launch_sample(const BatchView& b, const double* coeffs, const double* seg_times, double dt, int capacity,
-                         int32_t* n_samples, double* samples, hipStream_t stream, void* scratch = nullptr);
-size_t sample_scratch_bytes(const BatchView& b, int capacity);
-bool sample_split_applies(const BatchView& b, int capacity);
+                         int32_t* n_samples, double* samples, hipStream_t stream);
+int sample_group_lanes(const BatchView& b);  // 0 | 8 | 16: which sampler a launch of this batch takes
 // the same walk, every sample with its derivative orders 0..4: states [n_paths][capacity][kSampleStateOrders][4]
 constexpr int kSampleStateOrders = 5;
 hipError_t launch_sample_states(const BatchView& b, const double* coeffs, const double* seg_times, double dt, int capacity,
-                                int32_t* n_samples, double* states, hipStream_t stream, void* scratch = nullptr);
+                                int32_t* n_samples, double* states, hipStream_t stream);
 size_t linear_workspace_doubles(const BatchView& b);
 // MRS_TG_FLAG_POSITIONS_ARE_WAYPOINTS, checked: the number of vertices whose position is unconstrained or whose constrained
 // position differs (bitwise) from its waypoint.  Blocks until the count is on the host.

@@ -60,6 +60,8 @@ struct NonlinearBin {
 
 struct NonlinearPlan {
   std::vector<NonlinearBin> bins;
+  std::vector<NonlinearBin> bins1;   // the one-lane-per-vector groups of a plan whose own choice is the dimension split (regroup_possible)
+  bool regroup_possible = false;     // a call may take the lane-group kernels instead of the split kernel (launch_nonlinear)
   // the plain-path outer loop's bins when EVERY path of four or more segments gets the lanes of the shared half sweeps
   // (G = pow2ceil(S + 4) instead of pow2ceil(S + 1): 5-7, 13-15 and 29-30 segments move to the next group width); chosen
   // by launch_nonlinear while the launch is about as large as the device holds at once (see there)

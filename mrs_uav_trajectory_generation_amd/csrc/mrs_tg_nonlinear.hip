@@ -2001,15 +2001,23 @@ int nonlinear_plan_build(NonlinearPlan& nl, const std::vector<int32_t>& so, cons
   const int P = (int)order.size();
   nl.dim_split = dim_split_for(P, P > 0 ? so[order[0] + 1] - so[order[0]] : 0);  // (sorted longest first)
   const int ds = nl.dim_split;
+  const int max_S = P > 0 ? so[order[0] + 1] - so[order[0]] : 0;
   build_bins(nl.bins, so, order, [ds](int S) { return group_for(S, ds); });
+  // The lane-group layouts as well where a CALL may prefer them to the plan's dimension split (launch_nonlinear: 13-15
+  // segments under an objective order below snap or with constrained slots / moving starts, whose paths the split kernel
+  // hands to its general step): the plan is built before the options are known
+  nl.regroup_possible = ds == 4 && max_S >= 13 && max_S <= 15;
+  const bool groups = ds == 1 || nl.regroup_possible;
+  nl.bins1.clear();
+  if (nl.regroup_possible) build_bins(nl.bins1, so, order, [](int S) { return group_for(S, 1); });
   nl.wide_bins.clear();
   nl.wide_blocks = 0;
-  if (ds == 1) {
+  if (groups) {
     build_bins(nl.wide_bins, so, order, [](int S) { return group_for_wide(S); });
     for (const NonlinearBin& bin : nl.wide_bins) nl.wide_blocks += (int)cdiv_u(bin.q_count, 64 / bin.group);
   }
   nl.ends_bins.clear();
-  if (ds == 1 && P > 0 && group_for_ends(so[order[0] + 1] - so[order[0]]) != 0)
+  if (groups && P > 0 && group_for_ends(max_S) != 0)
     build_bins(nl.ends_bins, so, order, [](int S) { return group_for_ends(S); });
   return 0;
 }
@@ -2089,9 +2097,9 @@ hipError_t nonlinear_ensure_buffers(NonlinearPlan& nl, const BatchView& b) {
 // Objective orders below snap leave slots free at the end vertices of a rest-to-rest path: optimize_lean_masked_kernel takes
 // those (masked step at the two ends of the sweep), at one wavefront per SIMD -- 256 + 74 registers; forced to two it spills
 // 96 and loses to the general kernel (8192 x 10 random-walk paths at d = 2: 429 vs 365 us; at one wavefront 332 us).
-static bool lean_applies(const NonlinearPlan& nl) {
+static bool lean_applies(int dim_split) {
   if (const char* e = std::getenv("MRS_TG_LEAN")) return std::atoi(e) != 0;
-  return nl.dim_split == 1;
+  return dim_split == 1;
 }
 
 static hipError_t ensure_fallback(NonlinearPlan& nl, const BatchView& b) {
@@ -2118,8 +2126,9 @@ hipError_t nonlinear_prepare_general(NonlinearPlan& nl, const BatchView& b, cons
     if (!nl.d_general_t0 &&
         (e = mrs_tg::pool_alloc(&nl.d_general_t0, sizeof(double) * (size_t)std::max(b.n_segments, 1))) != hipSuccess)
       return e;
-    if ((e = hipMemcpyAsync(nl.d_general_t0, seg_times, sizeof(double) * (size_t)b.n_segments, hipMemcpyDeviceToDevice, stream)) !=
-        hipSuccess)
+    if (!dry_run() &&
+        (e = hipMemcpyAsync(nl.d_general_t0, seg_times, sizeof(double) * (size_t)b.n_segments, hipMemcpyDeviceToDevice, stream)) !=
+            hipSuccess)
       return e;
     if (cap) *cap = (int)n;
   }
@@ -2194,7 +2203,20 @@ hipError_t launch_nonlinear(NonlinearPlan& nl, const BatchView& b, const Nonline
   // careful re-run)
   const KernelTimer kt = take_kernel_timer();
   // 1a. the lean kernel takes every plain path and flags the others for the sweeping kernel below
-  bool lean = lean_applies(nl) && (int)nl.bins.size() <= 5;
+  // The split of the four dimensions over lanes is the PLAN's choice (batch size and longest path); this CALL goes back to
+  // lane groups where the split kernel would hand its paths to the general step anyway and the groups are 10-25 % faster:
+  // 13-15 segments (<= 1536 paths) under an objective order below snap, or when the caller says that vertices hold
+  // constrained slots (stop_at waypoints: MRS_TG_FLAG_CONSTRAINED_SLOTS) or mrs_tg_solve_batch has seen a moving start in
+  // its host copy of the values.  MRS_TG_REGROUP=0 switches it off.
+  static const bool regroup_allowed = [] {
+    const char* e = std::getenv("MRS_TG_REGROUP");
+    return e == nullptr || std::atoi(e) != 0;
+  }();
+  const bool regroup = regroup_allowed && nl.regroup_possible &&
+                       (prm_in.derivative < 4 || constrained_slots_hint() || moving_starts_hint());
+  const int dim_split = regroup ? 1 : nl.dim_split;
+  const std::vector<NonlinearBin>& plan_bins = regroup ? nl.bins1 : nl.bins;
+  bool lean = lean_applies(dim_split) && (int)plan_bins.size() <= 5;
   auto plain_lds = [&](const NonlinearBin& bin) {
     return ((size_t)(64 / bin.group) * lean_group_doubles(bin.max_S) + 2 * kPsTable) * sizeof(double);
   };
@@ -2251,7 +2273,7 @@ hipError_t launch_nonlinear(NonlinearPlan& nl, const BatchView& b, const Nonline
     return e == nullptr || std::atoi(e) != 0;
   }();
   const bool wide_shared_all = wide && wide_all && !nl.ends_bins.empty() && (int)nl.ends_bins.size() <= 5;
-  const std::vector<NonlinearBin>& lean_bins = (ends_shared || wide_shared_all) ? nl.ends_bins : wide ? nl.wide_bins : nl.bins;
+  const std::vector<NonlinearBin>& lean_bins = (ends_shared || wide_shared_all) ? nl.ends_bins : wide ? nl.wide_bins : plan_bins;
   if (lean)
     for (const NonlinearBin& bin : lean_bins)
       if (plain_lds(bin) > 160 * 1024) lean = false;
@@ -2329,18 +2351,18 @@ hipError_t launch_nonlinear(NonlinearPlan& nl, const BatchView& b, const Nonline
   }
   {
     const hipEvent_t ev_start = lean ? nullptr : kt.start, ev_stop = (careful || general) ? nullptr : kt.stop;
-    if (!lean && wave_kernel_applies(b, nl.dim_split)) {
+    if (!lean && wave_kernel_applies(b, dim_split)) {
       // one wavefront per path, both directions of the two-sided evaluation in it (mrs_tg_wave.hip)
       if ((e = launch_optimize_wave(b, prm, mask, vals, seg_times, nl.d_opt_status, stream, ev_start, ev_stop)) != hipSuccess) return e;
     } else {
     BinTable bt{};
-    bt.n = (int)nl.bins.size();
+    bt.n = (int)plan_bins.size();
     if (bt.n > 5) return hipErrorInvalidValue;
     size_t lds_bytes = 0;
     int blocks = 0;
     bool all_single = true;
     for (int i = 0; i < bt.n; ++i) {
-      const NonlinearBin& bin = nl.bins[i];
+      const NonlinearBin& bin = plan_bins[i];
       const int per_block = 64 / bin.group;
       bt.group[i] = bin.group;
       bt.q_begin[i] = bin.q_begin;
@@ -2348,25 +2370,25 @@ hipError_t launch_nonlinear(NonlinearPlan& nl, const BatchView& b, const Nonline
       bt.max_S[i] = bin.max_S;
       bt.block_begin[i] = blocks;
       blocks += (int)cdiv_u(bin.q_count, per_block);
-      const size_t need = ((size_t)per_block * group_lds_doubles(bin.max_S, nl.dim_split == 4) + kBlockConsts) * sizeof(double);
+      const size_t need = ((size_t)per_block * group_lds_doubles(bin.max_S, dim_split == 4) + kBlockConsts) * sizeof(double);
       if (need > lds_bytes) lds_bytes = need;
       if (bin.group != 64) all_single = false;
     }
     // one path per block and one dimension per lane: a partner wavefront runs the other half of every sweep
-    const unsigned threads = (nl.dim_split == 4 && all_single) ? 128u : 64u;
+    const unsigned threads = (dim_split == 4 && all_single) ? 128u : 64u;
     if (threads == 128u) lds_bytes += (64 * kPairState + 2) * sizeof(double);  // hand-over area + flags
     if (lds_bytes > 160 * 1024) return hipErrorInvalidValue;
     // objective order below snap: the end vertices of rest-to-rest paths keep free slots, so the large-batch kernel is
     // launched with the masked step compiled in (the min-snap instantiation stays free of it)
     const bool masked4 = prm.derivative < 4;
     if (lds_bytes > 64 * 1024) {
-      const void* fn = nl.dim_split == 4 ? (const void*)optimize_split_kernel
+      const void* fn = dim_split == 4 ? (const void*)optimize_split_kernel
                        : masked4         ? (const void*)optimize_compact_kernel<true>
                                          : (const void*)optimize_compact_kernel<false>;
       e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
       if (e != hipSuccess) return e;
     }
-    if (nl.dim_split == 4)
+    if (dim_split == 4)
       MRS_TG_LAUNCH_EXT(optimize_split_kernel, dim3(blocks), dim3(threads), lds_bytes, stream, ev_start, ev_stop, 0, b, prm, bt,
                             mask, vals, seg_times, nl.d_opt_status);
     else if (masked4)

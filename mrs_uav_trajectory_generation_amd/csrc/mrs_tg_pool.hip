@@ -124,6 +124,12 @@ bool shared_device_hint() { return t_shared_device; }
 static thread_local bool t_constrained_slots = false;
 void set_constrained_slots_hint(bool on) { t_constrained_slots = on; }
 bool constrained_slots_hint() { return t_constrained_slots; }
+static thread_local bool t_moving_starts = false;
+bool moving_starts_hint() { return t_moving_starts; }
+void set_moving_starts_hint(bool on) { t_moving_starts = on; }
+static thread_local bool t_dry_run = false;
+bool dry_run() { return t_dry_run; }
+void set_dry_run(bool on) { t_dry_run = on; }
 
 
 void set_kernel_timer(hipEvent_t start, hipEvent_t stop) {

@@ -614,6 +614,418 @@ __device__ __forceinline__ void solve_quad_body(const BatchView& b, int d, const
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// The TWO-SIDED variant for launches that leave SIMDs idle (round 6).  A dispatch of 10240 paths is 640 quad wavefronts for
+// 1024 SIMDs, each walking the chain of S - 1 vertices forward and back with its latencies exposed (VALU issue 19.7 %, wait
+// share 45 %: profiles/round5_pmc_sq_solve_quad_group.json).  Here EIGHT lanes own a path -- side x dimension -- and a
+// wavefront holds 8 paths: side 0 eliminates vertices 1 .. m - 1 from the start, side 1 eliminates S - 1 .. m + 1 from the
+// end, the two meet at the middle vertex m = (S + 1) / 2: twice the wavefronts, half the dependent chain, the same LDS per CU.
+//
+// Side 1 runs the SAME instructions on the time-reversed path.  Reversing time maps a min-derivative problem onto itself:
+// p~(t) = p(T - t) has derivatives (-1)^k p^(k) at the vertices, the cost is unchanged, and the unit-time constants are those
+// of the forward problem.  So side 1 sees local vertex v = original vertex S - v, local segment i = original segment
+// S - 1 - i, and its unknowns are the original ones with the odd derivatives negated (x~ = D x, D = diag(-1, +1, -1, +1) over
+// the slots velocity .. snap).  At the join each side adds the other's Schur complement and right-hand side of the middle
+// vertex -- D S D and D y, exact sign flips -- and both solve the same 4 x 4 system (bit-identical up to those signs); then
+// each substitutes back through its own half and forms the coefficients of its own segments in FORWARD orientation from the
+// end-point derivatives (side 1: start and end swapped, odd derivatives negated back).
+// Plain paths only (position-only interior vertices, fully constrained ends; MOVING: a start vertex in motion, side 0's first
+// step as in solve_quad_body); a wavefront with any other path takes the general masked step on the lanes of side 0.
+// The results differ from solve_quad_body's in the last bits (another elimination order): same tolerances against the
+// oracle's 113-bit route (tests/test_gpu_headline_kernel.py).
+constexpr int kDuoPaths = 8;  // paths per wavefront
+
+__host__ __device__ constexpr size_t duo_lds_doubles(int Smax) {
+  return (size_t)(Smax > 1 ? Smax - 1 : 1) * kQdRec * kDuoPaths + (size_t)Smax * kDuoPaths;  // records | times
+}
+
+template <bool WP, bool MOVING = false>
+__device__ __forceinline__ void solve_duo_body(const BatchView& b, int d, const uint8_t* __restrict__ mask,
+                                               const double* __restrict__ vals, const double* seg_times,
+                                               double* __restrict__ coeffs, int32_t* __restrict__ status,
+                                               double* __restrict__ cost, const int32_t* __restrict__ status_in, double* ws,
+                                               const RowsTail& tail, int block, const double* __restrict__ pos_wp) {
+  extern __shared__ double lds[];
+  const int lane = threadIdx.x, pl = lane >> 3, side = (lane >> 2) & 1, dim = lane & 3, l8 = lane & 7;
+  const int q = block * kDuoPaths + pl;
+  const bool active = q < b.n_paths;
+  const PathRef pr = path_at(b, active ? q : b.n_paths - 1);
+  const int S = pr.S;
+  const int Smax = b.max_segments;
+  double* rec0 = lds;
+  double* tbuf = lds + (size_t)(Smax > 1 ? Smax - 1 : 1) * kQdRec * kDuoPaths;  // [segment][path]
+  // ---- prologue: times (scaled, for the last solve of a Mellinger pipeline), plainness of the path
+  const bool scaling = tail.maxima != nullptr;
+  double t_sum = 0.0;
+  bool ok = S >= 2, pos_ok = true;
+  bool moving_path = false;
+  if (active) {
+    const int opt_st = scaling ? tail.opt_status[pr.p] : 0;
+    for (int i = l8; i < S; i += 8) {
+      double T = seg_times[pr.s0 + i];
+      if (scaling) {  // scaleSegmentTimesToMeetConstraints (trajectory.cpp:625-657), then the solve at the scaled times
+        if (opt_st != -2) T *= violation_scaling(tail.maxima + (size_t)(pr.s0 + i) * 9, tail.limits + (size_t)pr.p * 9);
+        tail.seg_times_out[pr.s0 + i] = T;
+      }
+      tbuf[i * kDuoPaths + pl] = T;
+      t_sum += T;
+    }
+    for (int v = l8; v <= S; v += 8) {
+      const uint8_t* mrow = mask + (size_t)(pr.v0 + v) * kHalf;
+      const bool end = v == 0 || v == S;
+      unsigned fixed = 0;
+#pragma unroll
+      for (int k = 0; k < kHalf; ++k) fixed |= (mrow[k] != 0 ? 1u : 0u) << k;
+      pos_ok = pos_ok && (fixed & 1u);
+      if (end) {
+        const double* vrow = vals + (size_t)(pr.v0 + v) * kHalf * kD;
+        double nz = 0.0;
+        double av[kHalf * kD];
+#pragma unroll
+        for (int e = kD; e < kHalf * kD; ++e) av[e] = fabs(vrow[e]);  // (loaded unconditionally: see solve_quad_body)
+#pragma unroll
+        for (int k = 1; k < kHalf; ++k)
+#pragma unroll
+          for (int e = 0; e < kD; ++e) nz += ((fixed >> k) & 1u) ? av[k * kD + e] : 0.0;
+        if (MOVING && v == 0) {
+          moving_path = nz != 0.0;
+          nz = 0.0;
+        }
+        ok = ok && fixed == 0x1Fu && nz == 0.0;
+      } else {
+        ok = ok && fixed == 0x1u;
+      }
+    }
+  }
+  t_sum = quad_sum(t_sum);
+  t_sum += __shfl_xor(t_sum, 4, 64);
+  const bool any_moving = MOVING && __ballot(active && moving_path) != 0ull;
+  if (any_moving) moving_path = __shfl((int)moving_path, lane & ~7, 64) != 0 && side == 0;  // (vertex 0 was read by lane 0 of the eight)
+  const bool plain_wave = __ballot(active && !ok) == 0ull;
+  const unsigned long long pos_bad = __ballot(active && !pos_ok);
+  const bool path_pos_ok = ((pos_bad >> (lane & ~7)) & 0xFFull) == 0ull;
+  quad_wave_sync();
+
+  double my_cost = 0.0;
+  if (plain_wave) {
+    const double (*hb)[kN] = c_hbar[d];
+    double cNear[10], cCpl[kNB][kNB], cFar[10], cN[kNB], cF[kNB];
+#pragma unroll
+    for (int r = 0; r < kNB; ++r) {
+#pragma unroll
+      for (int c = 0; c <= r; ++c) {
+        cNear[tri(r, c)] = hb[kSlot0 + r][kSlot0 + c];
+        cFar[tri(r, c)] = hb[kHalf + kSlot0 + r][kHalf + kSlot0 + c];
+      }
+#pragma unroll
+      for (int c = 0; c < kNB; ++c) cCpl[r][c] = hb[kSlot0 + r][kHalf + kSlot0 + c];
+      cN[r] = hb[kSlot0 + r][0];
+      cF[r] = hb[kHalf + kSlot0 + r][0];
+    }
+    const bool d1 = (d & 1) != 0, d2 = (d & 2) != 0, d4 = (d & 4) != 0;
+    // this side's chain: local vertices 0 .. M (0: the path's end on this side, M: the middle vertex), local segments 0 .. M - 1
+    const int m_mid = (S + 1) >> 1;
+    const int M = side ? S - m_mid : m_mid;
+    int Mmx;
+    {
+      int s = active ? M : 0;
+      for (int off = 32; off >= 4; off >>= 1) s = max(s, __shfl_xor(s, off, 64));
+      Mmx = __builtin_amdgcn_readfirstlane(s);
+    }
+    auto oseg = [&](int i) { return side ? S - 1 - i : i; };   // original index of local segment i
+    auto overt = [&](int v) { return side ? S - v : v; };      // original index of local vertex v
+    const double* pv = WP ? pos_wp + (size_t)pr.v0 * kD + dim : vals + (size_t)pr.v0 * kHalf * kD + dim;
+    constexpr size_t pstride = WP ? (size_t)kD : (size_t)(kHalf * kD);
+    auto pos = [&](int v) { return (active && v >= 0 && v <= M) ? pv[(size_t)overt(v) * pstride] : 0.0; };
+    // ---- forward: this side's block Cholesky towards the middle
+    double Sm[10], y[kNB];
+#pragma unroll
+    for (int e = 0; e < 10; ++e) Sm[e] = 0.0;
+#pragma unroll
+    for (int r = 0; r < kNB; ++r) y[r] = 0.0;
+    double p_cur = pos(0), p_nxt = pos(1), p_a2 = pos(2), p_a3 = pos(3);
+    for (int i = 0; i < Mmx; ++i) {
+      const bool on = active && i < M;
+      const double T = on ? tbuf[oseg(i) * kDuoPaths + pl] : 1.0;
+      const double p_a4 = pos(i + 4);
+      double p2[9];
+      quad_powers(T, d1, d2, d4, p2);
+      const double dp = p_cur - p_nxt;
+      double f0[kNB] = {0.0, 0.0, 0.0, 0.0};
+      if (any_moving && i == 0 && active && moving_path) {  // (side 0 only: moving_path is false on side 1)
+        const double* vrow0 = vals + (size_t)pr.v0 * kHalf * kD + dim;
+#pragma unroll
+        for (int r = 0; r < kNB; ++r) f0[r] = vrow0[(r + 1) * kD];
+      }
+      if (on) {
+        if (i == 0) {  // the end vertex is fully constrained: the state moves to local vertex 1
+#pragma unroll
+          for (int r = 0; r < kNB; ++r) {
+#pragma unroll
+            for (int c = 0; c <= r; ++c) Sm[tri(r, c)] = cFar[tri(r, c)] * p2[r + c + 2];
+            y[r] = -((cF[r] * p2[r + 1]) * dp);
+          }
+          if (any_moving) {  // local vertex 1's right-hand side: - sum_c E[c][r] T^(r+c+2-2d) f_c
+#pragma unroll
+            for (int r = 0; r < kNB; ++r)
+#pragma unroll
+              for (int c = 0; c < kNB; ++c) y[r] = fma(-(cCpl[c][r] * p2[r + c + 2]), f0[c], y[r]);
+          }
+        } else {
+          // local vertex i: its block and right-hand side are complete with this segment's near part
+#pragma unroll
+          for (int r = 0; r < kNB; ++r) {
+#pragma unroll
+            for (int c = 0; c <= r; ++c) Sm[tri(r, c)] = fma(cNear[tri(r, c)], p2[r + c + 2], Sm[tri(r, c)]);
+            y[r] = fma(-(cN[r] * p2[r + 1]), dp, y[r]);
+          }
+          double L[10], Linv[kNB], z[kNB];
+#pragma unroll
+          for (int c = 0; c < kNB; ++c) {
+            double dsum = Sm[tri(c, c)];
+#pragma unroll
+            for (int mm = 0; mm < c; ++mm) dsum = fma(-L[tri(c, mm)], L[tri(c, mm)], dsum);
+            const double inv = rsqrt_refined(dsum);
+            Linv[c] = inv;
+#pragma unroll
+            for (int r = c + 1; r < kNB; ++r) {
+              double t = Sm[tri(r, c)];
+#pragma unroll
+              for (int mm = 0; mm < c; ++mm) t = fma(-L[tri(r, mm)], L[tri(c, mm)], t);
+              L[tri(r, c)] = t * inv;
+            }
+          }
+#pragma unroll
+          for (int r = 0; r < kNB; ++r) {
+            double t = y[r];
+#pragma unroll
+            for (int mm = 0; mm < r; ++mm) t = fma(-L[tri(r, mm)], z[mm], t);
+            z[r] = t * Linv[r];
+          }
+          double* rec = rec0 + (size_t)(overt(i) - 1) * kQdRec * kDuoPaths + pl;
+          if (dim == 0) {
+            rec[(kQdL + 0) * kDuoPaths] = L[tri(1, 0)];
+            rec[(kQdL + 1) * kDuoPaths] = L[tri(2, 0)];
+            rec[(kQdL + 2) * kDuoPaths] = L[tri(2, 1)];
+            rec[(kQdL + 3) * kDuoPaths] = L[tri(3, 0)];
+            rec[(kQdL + 4) * kDuoPaths] = L[tri(3, 1)];
+            rec[(kQdL + 5) * kDuoPaths] = L[tri(3, 2)];
+#pragma unroll
+            for (int r = 0; r < kNB; ++r) rec[(kQdLinv + r) * kDuoPaths] = Linv[r];
+          }
+#pragma unroll
+          for (int r = 0; r < kNB; ++r) rec[(kQdZ + r * kD + dim) * kDuoPaths] = z[r];
+          // W = L^-1 E, then the Schur complement and right-hand side of local vertex i + 1 (always an unknown: the next one
+          // of this side, or the middle vertex)
+          double W[kNB][kNB];
+#pragma unroll
+          for (int c = 0; c < kNB; ++c)
+#pragma unroll
+            for (int r = 0; r < kNB; ++r) {
+              double t = cCpl[r][c] * p2[r + c + 2];
+#pragma unroll
+              for (int mm = 0; mm < r; ++mm) t = fma(-L[tri(r, mm)], W[mm][c], t);
+              W[r][c] = t * Linv[r];
+            }
+#pragma unroll
+          for (int r = 0; r < kNB; ++r) {
+#pragma unroll
+            for (int c = 0; c <= r; ++c) {
+              double t = cFar[tri(r, c)] * p2[r + c + 2];
+#pragma unroll
+              for (int mm = 0; mm < kNB; ++mm) t = fma(-W[mm][r], W[mm][c], t);
+              Sm[tri(r, c)] = t;
+            }
+            double t = -((cF[r] * p2[r + 1]) * dp);
+#pragma unroll
+            for (int mm = 0; mm < kNB; ++mm) t = fma(-W[mm][r], z[mm], t);
+            y[r] = t;
+          }
+        }
+      }
+      p_cur = p_nxt;
+      p_nxt = p_a2;
+      p_a2 = p_a3;
+      p_a3 = p_a4;
+    }
+    // ---- the join: the middle vertex's block and right-hand side are this side's part plus the other side's, which arrives in
+    // the other orientation: D S D and D y with D = diag(-1, +1, -1, +1) -- exact sign flips, so both sides solve the same
+    // system and x~ = D x bit for bit
+    double xn[kNB];
+    {
+#pragma unroll
+      for (int r = 0; r < kNB; ++r) {
+#pragma unroll
+        for (int c = 0; c <= r; ++c) {
+          const double other = __shfl_xor(Sm[tri(r, c)], 4, 64);
+          Sm[tri(r, c)] += ((r + c) & 1) ? -other : other;
+        }
+        const double oy = __shfl_xor(y[r], 4, 64);
+        y[r] += (r & 1) ? oy : -oy;   // slot r is derivative r + 1: odd derivatives (r = 0, 2) change sign
+      }
+      double L[10], Linv[kNB], z[kNB];
+#pragma unroll
+      for (int c = 0; c < kNB; ++c) {
+        double dsum = Sm[tri(c, c)];
+#pragma unroll
+        for (int mm = 0; mm < c; ++mm) dsum = fma(-L[tri(c, mm)], L[tri(c, mm)], dsum);
+        const double inv = rsqrt_refined(dsum);
+        Linv[c] = inv;
+#pragma unroll
+        for (int r = c + 1; r < kNB; ++r) {
+          double t = Sm[tri(r, c)];
+#pragma unroll
+          for (int mm = 0; mm < c; ++mm) t = fma(-L[tri(r, mm)], L[tri(c, mm)], t);
+          L[tri(r, c)] = t * inv;
+        }
+      }
+#pragma unroll
+      for (int r = 0; r < kNB; ++r) {
+        double t = y[r];
+#pragma unroll
+        for (int mm = 0; mm < r; ++mm) t = fma(-L[tri(r, mm)], z[mm], t);
+        z[r] = t * Linv[r];
+      }
+      xn[3] = z[3] * Linv[3];
+      xn[2] = fma(-L[tri(3, 2)], xn[3], z[2]) * Linv[2];
+      xn[1] = fma(-L[tri(3, 1)], xn[3], fma(-L[tri(2, 1)], xn[2], z[1])) * Linv[1];
+      xn[0] = fma(-L[tri(3, 0)], xn[3], fma(-L[tri(2, 0)], xn[2], fma(-L[tri(1, 0)], xn[1], z[0]))) * Linv[0];
+    }
+    quad_wave_sync();  // (lane 0 of a side wrote L for the other three)
+    // ---- backward through this side's half: x_v = L^-T (z - W x_{v+1}); coefficients and cost of local segment v
+    double p_end = pos(M), p_b0 = pos(Mmx - 1), p_b1 = pos(Mmx - 2), p_b2 = pos(Mmx - 3);
+    for (int v = Mmx - 1; v >= 0; --v) {
+      const bool on = active && v < M;
+      double x[kNB] = {0.0, 0.0, 0.0, 0.0};
+      const double p_start = p_b0;
+      p_b0 = p_b1;
+      p_b1 = p_b2;
+      p_b2 = pos(v - 3);
+      if (on && v >= 1) {
+        const double* rec = rec0 + (size_t)(overt(v) - 1) * kQdRec * kDuoPaths + pl;
+        double t[kNB];
+#pragma unroll
+        for (int r = 0; r < kNB; ++r) t[r] = rec[(kQdZ + r * kD + dim) * kDuoPaths];
+        const double l10 = rec[(kQdL + 0) * kDuoPaths], l20 = rec[(kQdL + 1) * kDuoPaths], l21 = rec[(kQdL + 2) * kDuoPaths],
+                     l30 = rec[(kQdL + 3) * kDuoPaths], l31 = rec[(kQdL + 4) * kDuoPaths], l32 = rec[(kQdL + 5) * kDuoPaths];
+        const double i0 = rec[(kQdLinv + 0) * kDuoPaths], i1 = rec[(kQdLinv + 1) * kDuoPaths], i2 = rec[(kQdLinv + 2) * kDuoPaths],
+                     i3 = rec[(kQdLinv + 3) * kDuoPaths];
+        {  // t = z - W x_{v+1},  W x = L^-1 (E x)  (local vertex v + 1 is an unknown for every v <= M - 1)
+          double pw[9];
+          quad_powers(tbuf[oseg(v) * kDuoPaths + pl], d1, d2, d4, pw);
+          double u[kNB];
+#pragma unroll
+          for (int r = 0; r < kNB; ++r) {
+            u[r] = 0.0;
+#pragma unroll
+            for (int c = 0; c < kNB; ++c) u[r] = fma(cCpl[r][c] * pw[r + c + 2], xn[c], u[r]);
+          }
+          const double w0 = u[0] * i0;
+          const double w1 = fma(-l10, w0, u[1]) * i1;
+          const double w2 = fma(-l21, w1, fma(-l20, w0, u[2])) * i2;
+          const double w3 = fma(-l32, w2, fma(-l31, w1, fma(-l30, w0, u[3]))) * i3;
+          t[0] -= w0;
+          t[1] -= w1;
+          t[2] -= w2;
+          t[3] -= w3;
+        }
+        x[3] = t[3] * i3;
+        x[2] = fma(-l32, x[3], t[2]) * i2;
+        x[1] = fma(-l31, x[3], fma(-l21, x[2], t[1])) * i1;
+        x[0] = fma(-l30, x[3], fma(-l20, x[2], fma(-l10, x[1], t[0]))) * i0;
+      }
+      if (any_moving && v == 0 && active && moving_path) {  // the start vertex's constrained derivative values (side 0)
+        const double* vrow0 = vals + (size_t)pr.v0 * kHalf * kD + dim;
+#pragma unroll
+        for (int r = 0; r < kNB; ++r) x[r] += vrow0[(r + 1) * kD];
+      }
+      if (on) {
+        const double T = tbuf[oseg(v) * kDuoPaths + pl];
+        // the segment's end-point derivatives in FORWARD orientation: side 0 as they are, side 1 with start and end swapped
+        // and the odd derivatives negated back
+        const double s1 = side ? -1.0 : 1.0;
+        const double a0 = side ? p_end : p_start, b0 = side ? p_start : p_end;
+        double da[kNB], dbv[kNB];
+#pragma unroll
+        for (int r = 0; r < kNB; ++r) {
+          const double sg = (r & 1) ? 1.0 : s1;
+          da[r] = (side ? xn[r] : x[r]) * sg;
+          dbv[r] = (side ? x[r] : xn[r]) * sg;
+        }
+        const double dv[kN] = {a0, da[0], da[1], da[2], da[3], b0, dbv[0], dbv[1], dbv[2], dbv[3]};
+        double w[kHalf];
+        w[0] = 1.0;
+#pragma unroll
+        for (int k = 1; k < kHalf; ++k) w[k] = w[k - 1] * T;
+        double db[kN], cb[kN], c[kN];
+#pragma unroll
+        for (int j = 0; j < kN; ++j) db[j] = dv[j] * w[j % kHalf];
+        const double ti = 1.0 / T;
+        double tik = 1.0;
+#pragma unroll
+        for (int k = 0; k < kN; ++k) {
+          double sacc = 0.0;
+          if (k < kHalf) {
+            sacc = c_abar_inv[k][k] * db[k];  // the upper half of ABAR_INV is diag(1/k!)
+          } else {
+#pragma unroll
+            for (int j = 0; j < kN; ++j) sacc += c_abar_inv[k][j] * db[j];
+          }
+          cb[k] = sacc;
+          c[k] = sacc * tik;
+          tik *= ti;
+        }
+        double p2[9];
+        quad_powers(T, d1, d2, d4, p2);  // p2[0] = T^(1 - 2d)
+        my_cost = fma(cost_quadratic_form_d(d, cb), p2[0], my_cost);
+        double2* out = reinterpret_cast<double2*>(coeffs + ((size_t)(pr.s0 + oseg(v)) * kD + dim) * kN);
+#pragma unroll
+        for (int k = 0; k < kN; k += 2) out[k / 2] = make_double2(c[k], c[k + 1]);
+      }
+      if (on) {  // (a side shorter than the wavefront's longest joins late: until then xn is the middle vertex's solution)
+#pragma unroll
+        for (int r = 0; r < kNB; ++r) xn[r] = x[r];
+        p_end = p_start;
+      }
+    }
+  } else if (active && side == 0) {
+    // ---- any other constraint pattern: the general masked step on the four lanes of side 0, factors in the plan's workspace
+    bool pok = true;
+    BlockSource none{nullptr, nullptr, 0, 0};
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+    const double* times = (scaling ? tail.seg_times_out : seg_times) + pr.s0;
+    my_cost = solve_path<1, true>(mask, vals, pr.v0, S, d, times, dim, none, ws, (size_t)b.n_paths * 4,
+                                  (unsigned)q * 4u + (unsigned)dim, coeffs + (size_t)pr.s0 * kD * kN, pok);
+  }
+  my_cost = quad_sum(my_cost);
+  my_cost += __shfl_xor(my_cost, 4, 64);
+  if (active && l8 == 0) {
+    if (cost) cost[pr.p] = my_cost;
+    if (status) {
+      int st = merge_status(path_pos_ok, status_in, pr.p);
+      if (tail.sum_t0 != nullptr && st > 0 && t_sum > MRS_TG_RUNAWAY_TIME_FACTOR * tail.sum_t0[pr.p]) st = MRS_TG_STATUS_ROUNDOFF_LIMITED;
+      status[pr.p] = st;
+    }
+  }
+}
+
+template <bool WP>
+__global__ __launch_bounds__(64, MRS_TG_QUAD_WAVES) void solve_duo_kernel(BatchView b, int d, const uint8_t* __restrict__ mask,
+                                                       const double* __restrict__ vals, const double* seg_times,
+                                                       double* __restrict__ coeffs, int32_t* __restrict__ status,
+                                                       double* __restrict__ cost, const int32_t* __restrict__ status_in,
+                                                       double* ws, RowsTail tail) {
+  solve_duo_body<WP, true>(b, d, mask, vals, seg_times, coeffs, status, cost, status_in, ws, tail, (int)blockIdx.x, tail.pos_wp);
+}
+
+template <bool WP>
+__global__ __launch_bounds__(64, MRS_TG_QUAD_GROUP_WAVES) void solve_duo_group_kernel(BatchView b, int d, RowsGroup g, double* ws,
+                                                                                    size_t ws_batch_doubles, int blocks_per_batch) {
+  const int j = __builtin_amdgcn_readfirstlane((int)blockIdx.x / blocks_per_batch);
+  solve_duo_body<WP>(b, d, g.mask[j], g.vals[j], g.seg_times[j], g.coeffs[j], g.status[j], g.cost[j], nullptr,
+                     ws + (size_t)j * ws_batch_doubles, RowsTail(), (int)blockIdx.x - j * blocks_per_batch, g.pos_wp[j]);
+}
+
 template <bool WP, bool ENDS = false>
 __global__ __launch_bounds__(64, MRS_TG_QUAD_WAVES) void solve_quad_kernel(BatchView b, int d, const uint8_t* __restrict__ mask,
                                                         const double* __restrict__ vals, const double* seg_times,
@@ -657,6 +1069,18 @@ static bool quad_ends_allowed() {
   return v;
 }
 
+// The two-sided kernel takes a launch whose quad wavefronts (16 paths each) would leave SIMDs idle or barely covered: fewer than
+// 1.25 per SIMD.  MRS_TG_DUO=0: never, =1: whenever the pattern allows (tuning / test knob).
+static bool duo_pays(long long paths_in_launch) {
+  if (const char* e = std::getenv("MRS_TG_DUO")) return std::atoi(e) != 0;  // (read at every call: tests run both kernels)
+  static const int cus = [] {  // (of the first device used: the threshold is a tuning figure, results do not depend on it)
+    int dev = 0, n = 256;
+    if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
+    return n;
+  }();
+  return (paths_in_launch + kQdPaths - 1) / kQdPaths < (long long)cus * 4 * 5 / 4;
+}
+
 bool quad_kernel_applies(const BatchView& b, long long paths_in_launch, bool with_sampling) {
   if (b.n_paths == 0 || with_sampling) return false;
   if (paths_in_launch < quad_min_paths()) return false;
@@ -671,8 +1095,24 @@ hipError_t launch_solve_quad(const BatchView& b, int d, const uint8_t* mask, con
   // step for those paths, as until round 5
   const bool ends = quad_ends_allowed() && (d < 4 || constrained_slots_hint()) &&
                     quad_lds_doubles(b.max_segments, true) * sizeof(double) <= kQuadLdsBudget;
-  const size_t lds_bytes = quad_lds_doubles(b.max_segments, ends) * sizeof(double);
   const bool wp = tail.pos_wp != nullptr;
+  if (!ends && !(d < 4) && duo_pays(b.n_paths)) {  // few wavefronts: eight lanes per path, the chain cut in the middle
+    const size_t lds_duo = duo_lds_doubles(b.max_segments) * sizeof(double);
+    if (lds_duo > 64 * 1024) {
+      hipError_t e = hipFuncSetAttribute(wp ? (const void*)solve_duo_kernel<true> : (const void*)solve_duo_kernel<false>,
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)kQuadLdsBudget);
+      if (e != hipSuccess) return e;
+    }
+    const unsigned grid_duo = (unsigned)((b.n_paths + kDuoPaths - 1) / kDuoPaths);
+    if (wp)
+      MRS_TG_LAUNCH_TIMED(solve_duo_kernel<true>, dim3(grid_duo), dim3(64), lds_duo, stream, b, d, mask, vals, seg_times, coeffs, status,
+                          cost, status_in, ws, tail);
+    else
+      MRS_TG_LAUNCH_TIMED(solve_duo_kernel<false>, dim3(grid_duo), dim3(64), lds_duo, stream, b, d, mask, vals, seg_times, coeffs, status,
+                          cost, status_in, ws, tail);
+    return hipGetLastError();
+  }
+  const size_t lds_bytes = quad_lds_doubles(b.max_segments, ends) * sizeof(double);
   const void* fn = ends ? (wp ? (const void*)solve_quad_kernel<true, true> : (const void*)solve_quad_kernel<false, true>)
                         : (wp ? (const void*)solve_quad_kernel<true> : (const void*)solve_quad_kernel<false>);
   if (lds_bytes > 64 * 1024) {
@@ -702,6 +1142,22 @@ hipError_t launch_solve_quad_group(const BatchView& b, int d, const RowsGroup& g
   const size_t lds_bytes = quad_lds_doubles(b.max_segments, ends) * sizeof(double);
   bool wp = true;
   for (int j = 0; j < g.n; ++j) wp = wp && g.pos_wp[j] != nullptr;
+  if (!ends && !(d < 4) && duo_pays((long long)b.n_paths * g.n)) {
+    const size_t lds_duo = duo_lds_doubles(b.max_segments) * sizeof(double);
+    if (lds_duo > 64 * 1024) {
+      hipError_t e = hipFuncSetAttribute(wp ? (const void*)solve_duo_group_kernel<true> : (const void*)solve_duo_group_kernel<false>,
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)kQuadLdsBudget);
+      if (e != hipSuccess) return e;
+    }
+    const int per_batch_duo = (b.n_paths + kDuoPaths - 1) / kDuoPaths;
+    const dim3 grid_duo((unsigned)(per_batch_duo * g.n));
+    const size_t wsd_duo = linear_workspace_doubles(b);
+    if (wp)
+      MRS_TG_LAUNCH_TIMED(solve_duo_group_kernel<true>, grid_duo, dim3(64), lds_duo, stream, b, d, g, ws, wsd_duo, per_batch_duo);
+    else
+      MRS_TG_LAUNCH_TIMED(solve_duo_group_kernel<false>, grid_duo, dim3(64), lds_duo, stream, b, d, g, ws, wsd_duo, per_batch_duo);
+    return hipGetLastError();
+  }
   if (lds_bytes > 64 * 1024) {
     const void* fn = ends ? (wp ? (const void*)solve_quad_group_kernel<true, true> : (const void*)solve_quad_group_kernel<false, true>)
                           : (wp ? (const void*)solve_quad_group_kernel<true> : (const void*)solve_quad_group_kernel<false>);

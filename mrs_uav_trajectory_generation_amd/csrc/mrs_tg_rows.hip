@@ -733,7 +733,7 @@ hipError_t launch_solve_rows(const BatchView& b, int d, const uint8_t* mask, con
   const bool sampling = tail.sampling_dt > 0.0;
   RowsTail tail_k = tail;  // (the copy the kernel gets: with the sampling walk's table filled in)
   AccPin pin;  // (released when this function returns: behind the enqueue of the kernel that reads the table)
-  if (sampling) {
+  if (sampling && !dry_run()) {
     hipError_t et = sample_acc_table(tail.sampling_dt, tail.sample_capacity, stream, &tail_k.sample_acc, &tail_k.sample_acc_n, &pin);
     if (et != hipSuccess) return et;
   }

@@ -48,7 +48,8 @@ def with_moving_starts(batch):
 def measure(ctx, batch, nonlinear, reps):
     batch = with_moving_starts(batch)
     plan = api.Plan(ctx, batch.seg_offsets)
-    db = api.DeviceBatch(batch, "cuda:0", sample_capacity=512)
+    CAP = int(os.environ.get("CAP", "512"))
+    db = api.DeviceBatch(batch, "cuda:0", sample_capacity=CAP)
     est = api.default_options(derivative_to_optimize=batch.derivative_to_optimize, estimate_times=1)
     plan.solve(est, db.fixed_mask, db.fixed_values, db.seg_times, db.coeffs, db.status, db.cost, waypoints=db.waypoints,
                limits=db.limits)
@@ -57,7 +58,7 @@ def measure(ctx, batch, nonlinear, reps):
     if nonlinear:
         # (MRS_TG_FLAG_POSITIONS_ARE_WAYPOINTS: these batches' position constraints are their waypoints, as in bench.py)
         opt = api.default_options(derivative_to_optimize=batch.derivative_to_optimize, time_alloc_method=api.TIME_ALLOC_MELLINGER, sampling_dt=0.2,
-                                  sample_capacity=512, flags=api.FLAG_POSITIONS_ARE_WAYPOINTS | (api.FLAG_CONSTRAINED_SLOTS if (STOP or os.environ.get('HINT')) else 0))
+                                  sample_capacity=CAP, flags=api.FLAG_POSITIONS_ARE_WAYPOINTS | (api.FLAG_CONSTRAINED_SLOTS if (STOP or os.environ.get('HINT')) else 0))
 
         def step():
             db.seg_times.copy_(t0)

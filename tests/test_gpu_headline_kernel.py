@@ -1,4 +1,6 @@
-"""The kernel bench.py's timed region actually runs: `solve_quad_group_kernel` (mrs_tg_quad.hip), the fixed-times solve of a
+"""The kernel bench.py's timed region actually runs: `solve_duo_group_kernel` (mrs_tg_quad.hip; round 6: eight lanes per path, the
+vertex chain eliminated from both ends -- until round 5 `solve_quad_group_kernel`, four lanes per path, which still takes
+dispatches of >= 20480 paths and is tested below under MRS_TG_DUO=0), the fixed-times solve of a
 grouped dispatch that carries >= 6144 paths -- the replacement of constructR + solveLinear + updateSegmentsFromCompactConstraints
 + computeCost (/root/reference/include/eth_trajectory_generation/impl/polynomial_optimization_linear_impl.h:311-373, 264-282,
 128-141) for the headline's 10 x 1024 paths per dispatch.
@@ -7,7 +9,7 @@ The set-up is bench.py's own: twenty batches in flight with their own inputs (sl
 Euclidean times from the library's estimator), slots 0-9 bound to one plan / context / stream and 10-19 to a second, issued by
 mrs_tg_bound_solve_launch_group as two dispatches of ten batches.  What is asserted:
 
-  * the kernel trace says both dispatches were `solve_quad_group_kernel` (not inferred from the batch size);
+  * the kernel trace says both dispatches were `solve_duo_group_kernel` (not inferred from the batch size);
   * EVERY path of EVERY slot against the reference-style double oracle: 1e-8, and the named tolerance
     TOL_ORACLE_SHORT_SEGMENT on paths with a segment shorter than 0.5 s, where the ORACLE is the inaccurate side;
   * every path against the oracle's 113-bit route (the reference's algorithm without its rounding) -- the HIP path's own
@@ -87,7 +89,7 @@ def _per_path_error(batch, got, ref):
 def test_the_dispatches_of_the_headline_are_the_quad_group_kernel(headline):
     # (<false>: these slots do not state MRS_TG_FLAG_POSITIONS_ARE_WAYPOINTS; bench.py's do, and the last test of this file
     # holds the two instantiations to the same bits)
-    assert headline["trace"] == ["solve_quad_group_kernel<false>"] * (SLOTS // GROUP), headline["trace"]
+    assert headline["trace"] == ["solve_duo_group_kernel<false>"] * (SLOTS // GROUP), headline["trace"]
     for s in headline["slots"]:
         assert np.all(s["status"] == 1)
 
@@ -147,7 +149,7 @@ def test_the_worst_conditioned_slot_path_against_its_60_digit_solution(headline,
 
 
 def test_grouped_dispatch_equals_one_launch_over_the_same_paths(headline):
-    """slots 0..9 concatenated into ONE batch of 10 240 paths -> a single solve_quad_kernel launch: the same body on the same
+    """slots 0..9 concatenated into ONE batch of 10 240 paths -> a single solve_duo_kernel launch: the same body on the same
     numbers, so the same bits"""
     ctx, _ = headline["lanes"][0]
     parts = []
@@ -158,18 +160,21 @@ def test_grouped_dispatch_equals_one_launch_over_the_same_paths(headline):
     t = np.concatenate([s["times"] for s in headline["slots"][:GROUP]])
     api.kernel_trace_reset()
     out = ctx.solve_batch(big, t)
-    assert "solve_quad_kernel<false>" in api.kernel_trace(), api.kernel_trace()
+    assert "solve_duo_kernel<false>" in api.kernel_trace(), api.kernel_trace()
     got = np.concatenate([s["coeffs"] for s in headline["slots"][:GROUP]])
     assert np.array_equal(out["coeffs"], got)
     assert np.array_equal(out["cost"], np.concatenate([s["cost"] for s in headline["slots"][:GROUP]]))
 
 
-def test_positions_from_the_waypoint_array_give_the_same_bits_and_a_false_statement_is_refused(gpu_ctx):
+@pytest.mark.parametrize("kernel", ["solve_duo", "solve_quad"])
+def test_positions_from_the_waypoint_array_give_the_same_bits_and_a_false_statement_is_refused(gpu_ctx, monkeypatch, kernel):
     """MRS_TG_FLAG_POSITIONS_ARE_WAYPOINTS: the saturated-device solve reads vertex positions from the compact [vertex][4]
     waypoint array (every vertex findTrajectory builds has its waypoint as position constraint,
     /root/reference/src/mrs_trajectory_generation.cpp:944, 963, 967) -- same numbers in, same bits out, single launch and
     grouped dispatch, uniform and ragged (<= 15 segments: the quad kernel's LDS record); mrs_tg_plan_bind_solve checks the
     statement and refuses a batch for which it is false."""
+    if kernel == "solve_quad":
+        monkeypatch.setenv("MRS_TG_DUO", "0")   # the four-lanes-per-path kernel, which takes these launch sizes only when asked to
     ragged = pr.random_batch(14000, "ragged", seed0=8000)
     short = [p for p in range(ragged.n_paths) if ragged.seg_offsets[p + 1] - ragged.seg_offsets[p] <= 15][:6400]
     assert len(short) == 6400
@@ -186,7 +191,7 @@ def test_positions_from_the_waypoint_array_give_the_same_bits_and_a_false_statem
             opt = api.default_options(derivative_to_optimize=4, flags=flags)
             api.kernel_trace_reset()
             plan.bind_solve(opt, db.fixed_mask, db.fixed_values, db.seg_times, db.coeffs, db.status, db.cost, waypoints=db.waypoints)()
-            assert api.kernel_trace()[-1] == ("solve_quad_kernel<true>" if flags else "solve_quad_kernel<false>"), api.kernel_trace()
+            assert api.kernel_trace()[-1] == (kernel + "_kernel<true>" if flags else kernel + "_kernel<false>"), api.kernel_trace()
             torch.cuda.synchronize()
             got[name] = (db.coeffs.cpu().numpy().copy(), db.cost.cpu().numpy().copy(), db.status.cpu().numpy().copy())
         for a, b in zip(got["values"], got["waypoints"]):
@@ -200,7 +205,7 @@ def test_positions_from_the_waypoint_array_give_the_same_bits_and_a_false_statem
                  for cc in (db.coeffs, c2)]
         api.kernel_trace_reset()
         api.RoundRobin(calls, grouped=True)(2)
-        assert api.kernel_trace() == ["solve_quad_group_kernel<true>"], api.kernel_trace()
+        assert api.kernel_trace() == [kernel + "_group_kernel<true>"], api.kernel_trace()
         torch.cuda.synchronize()
         assert np.array_equal(db.coeffs.cpu().numpy(), got["values"][0]) and np.array_equal(c2.cpu().numpy(), got["values"][0])
         idx = list(range(0, batch.n_paths, 97))
@@ -276,13 +281,17 @@ def test_grouped_dispatch_below_snap_takes_the_free_end_instantiation(gpu_ctx, d
     plan.close()
 
 
-def test_saturated_device_solve_against_the_60_digit_fixtures(gpu_ctx):
+@pytest.mark.parametrize("duo", [False, True])
+def test_saturated_device_solve_against_the_60_digit_fixtures(gpu_ctx, monkeypatch, duo):
     """Every fixture of tests/golden/linear_qp_cases.json -- min-snap paths, the mixed constraint patterns (moving start, stop_at
     vertices) under d = 2, 3, 4, the rest-to-rest paths below snap -- replicated 6400 times, so that the launch runs
     solve_quad_kernel (plain, with free slots, with a moving start: the trace says which): every replica gives the same bits,
     and those agree with the 60-DIGIT solution as the rows kernel's do in tests/test_gpu_linear.py."""
     import json
     import os
+    # duo: the launch shape's default since round 6 (solve_duo_kernel where the pattern is plain or starts from a moving state;
+    # objective orders below snap and the other patterns stay with solve_quad_kernel / its general step); else MRS_TG_DUO=0
+    monkeypatch.setenv("MRS_TG_DUO", "1" if duo else "0")
     golden = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "linear_qp_cases.json")))
     n = 6400
     seen = set()
@@ -295,7 +304,7 @@ def test_saturated_device_solve_against_the_60_digit_fixtures(gpu_ctx):
         t = np.tile(t1, n)
         api.kernel_trace_reset()
         out = gpu_ctx.solve_batch(batch, t)
-        kern = [k for k in api.kernel_trace() if k.startswith("solve_quad_kernel")]
+        kern = [k for k in api.kernel_trace() if k.startswith("solve_quad_kernel") or k.startswith("solve_duo_kernel")]
         assert kern, (case["name"], api.kernel_trace())
         seen.add(kern[-1])
         assert np.all(out["status"] == 1), case["name"]
@@ -311,4 +320,5 @@ def test_saturated_device_solve_against_the_60_digit_fixtures(gpu_ctx):
         if short:   # (measured: 6.9e-9 against the oracle's 2.5e-8 on path 74, 4.8e-8 against 5.4e-7 on slot 15's path 237)
             assert err < 0.5 * err_oracle, (case["name"], err, err_oracle)
         assert abs(out["cost"][0] - case["cost"]) <= (1e-8 if short else 1e-9) * abs(case["cost"]), case["name"]
-    assert {"solve_quad_kernel<false>", "solve_quad_kernel<false, true>"} <= seen, seen
+    assert ({"solve_duo_kernel<false>", "solve_quad_kernel<false, true>"} if duo else
+            {"solve_quad_kernel<false>", "solve_quad_kernel<false, true>"}) <= seen, seen

@@ -287,7 +287,8 @@ def test_moving_starts_on_the_saturated_device_kernels(gpu_ctx, deriv, n_seg):
         # right-hand-side terms of its first step and the first segment's boundary values; the general step before)
         api.kernel_trace_reset()
         lin = gpu_ctx.solve_batch(batch, None)
-        assert ("solve_quad_kernel<false, true>" if deriv < 4 else "solve_quad_kernel<false>") in api.kernel_trace(), api.kernel_trace()
+        # (min-snap: the two-sided kernel, whose side 0 takes the moving start; below snap the quad kernel with free end slots)
+        assert ("solve_quad_kernel<false, true>" if deriv < 4 else "solve_duo_kernel<false>") in api.kernel_trace(), api.kernel_trace()
         assert np.all(lin["status"] == 1)
         idx = list(range(0, n, n // 127))
         _subset_vs_oracle(batch, lin, idx, 1e-7)

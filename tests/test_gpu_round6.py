@@ -78,13 +78,13 @@ except api.MrsTgError as ex:
     assert "first ok" in p.stdout and "second refused" in p.stdout and "1 vertices" in p.stdout, p.stdout
 
 
-@pytest.mark.parametrize("shape,n_paths,dt,cap", [(10, 6400, 0.2, 512), ("ragged", 4100, 0.2, 640), (10, 2304, 0.05, 1024),
-                                                  (3, 2560, 0.3, 96), (80, 2100, 0.2, 4096)])
-def test_two_kernel_sampler_against_the_oracles_walk(gpu_ctx, shape, n_paths, dt, cap):
-    """The sampler of launches of >= 2048 paths (sample_walk_kernel: one lane per path, the reference's loop, chunk descriptors;
-    sample_eval_kernel: one lane per sample) against the oracle's restatement of Trajectory::evaluateRange on the SAME
-    coefficients and times: sample counts equal (capacity + 1 where the trajectory does not fit), positions to 1e-11, heading
-    to 1e-11 on the circle -- and the kernel trace says that it is the two kernels that ran."""
+@pytest.mark.parametrize("shape,n_paths,dt,cap,kernel", [(10, 8192, 0.2, 512, "sample_group_kernel<8"), ("ragged", 4200, 0.2, 640, "sample_group_kernel<16"),
+                                                         (10, 4608, 0.05, 1024, "sample_group_kernel<16"), (3, 9000, 0.3, 96, "sample_group_kernel<8"),
+                                                         (15, 8200, 0.2, 300, "sample_group_kernel<8"), (30, 4100, 0.2, 2048, "sample_group_kernel<16")])
+def test_group_sampler_against_the_oracles_walk(gpu_ctx, shape, n_paths, dt, cap, kernel):
+    """The sampler of large launches (sample_group_kernel: 8 or 16 lanes per path, walk and evaluation fused) against the oracle's
+    restatement of Trajectory::evaluateRange on the SAME coefficients and times: sample counts equal (capacity + 1 where the
+    trajectory does not fit), positions to 1e-11, heading to 1e-11 on the circle -- and the kernel trace says which kernel ran."""
     batch = pr.random_batch(n_paths, shape, seed0=555)
     lin = gpu_ctx.solve_batch(batch, None)
     times = lin["times"].copy()
@@ -92,8 +92,7 @@ def test_two_kernel_sampler_against_the_oracles_walk(gpu_ctx, shape, n_paths, dt
     api.kernel_trace_reset()
     out = gpu_ctx.solve_batch(batch, times, sampling_dt=dt, sample_capacity=cap)
     trace = api.kernel_trace()
-    assert any("sample_walk_kernel" in k for k in trace) and any("sample_eval_kernel" in k for k in trace), trace
-    assert not any(k.startswith("sample_kernel") for k in trace), trace
+    assert any(k.startswith(kernel) for k in trace), trace
     so = batch.seg_offsets
     checked = overflow = 0
     for p in list(range(0, n_paths, max(1, n_paths // 150))) + [0, n_paths - 1]:
@@ -109,5 +108,55 @@ def test_two_kernel_sampler_against_the_oracles_walk(gpu_ctx, shape, n_paths, dt
         assert np.max(np.minimum(dy, 2 * np.pi - dy)) < 1e-11, p
         checked += 1
     assert checked > 100
-    if cap <= 640 and shape != 3:
-        assert overflow > 0 or shape == 10      # (some trajectories overflow the smaller capacities)
+    print("sampler %s x %d dt %g capacity %d: %d paths checked, %d overflow the capacity" % (shape, n_paths, dt, cap, checked, overflow))
+
+
+@pytest.mark.parametrize("shape,n_paths,moving", [(10, 6400, False), ("short", 7000, False), (2, 6400, False), (3, 8192, False),
+                                                  (11, 6400, True), (15, 6200, False)])
+def test_two_sided_solve_against_the_oracle(gpu_ctx, shape, n_paths, moving):
+    """solve_duo_kernel: eight lanes per path (side x dimension), the vertex chain eliminated from both ends towards the middle
+    vertex -- the launch shape of dispatches that would leave SIMDs idle as quad wavefronts (6144 .. 20479 paths).  Against the
+    oracle in the reference's arithmetic (1e-7; 1e-6 on paths with a segment below 0.5 s, where that route itself is off) and in
+    113 bits (the HIP path's own error: median below 1e-13, worst 1e-8), costs included; continuity and constraints on every path."""
+    if shape == "short":   # ragged, 3 .. 15 segments (the LDS record of the four- and eight-lane kernels holds 15)
+        rag = pr.random_batch(3 * n_paths, "ragged", seed0=777)
+        keep = [p for p in range(rag.n_paths) if rag.seg_offsets[p + 1] - rag.seg_offsets[p] <= 15][:n_paths]
+        assert len(keep) == n_paths
+        batch = rag.select(keep)
+    else:
+        batch = pr.random_batch(n_paths, shape, seed0=777)
+    if moving:
+        from tests.test_gpu_large_batches import _moving
+        batch = _moving(batch, seed=3)
+    api.kernel_trace_reset()
+    out = gpu_ctx.solve_batch(batch, None)
+    trace = api.kernel_trace()
+    assert any(k.startswith("solve_duo_kernel") for k in trace), trace
+    assert np.all(out["status"] == 1)
+    so = batch.seg_offsets
+    idx = list(range(0, n_paths, max(1, n_paths // 257)))
+    sub = batch.select(idx)
+    t = np.concatenate([out["times"][so[p]:so[p + 1]] for p in idx])
+    got = np.concatenate([out["coeffs"][so[p]:so[p + 1]] for p in idx])
+    ref = util.oracle_linear(sub, t)
+    po.lib().mto_set_arithmetic(po.QUAD_PRECISION)
+    try:
+        refq = util.oracle_linear(sub, t)
+    finally:
+        po.lib().mto_set_arithmetic(po.REFERENCE_ARITHMETIC)
+    errs, errq = [], []
+    for k in range(len(idx)):
+        a, b = sub.seg_offsets[k], sub.seg_offsets[k + 1]
+        e = util.coeff_error(got[a:b], ref["coeffs"][a:b])
+        assert e < (1e-7 if t[a:b].min() >= 0.5 else 1e-6), (idx[k], e)
+        errq.append(util.coeff_error(got[a:b], refq["coeffs"][a:b]))
+        errs.append(e)
+    print("ERR duo %s x %d moving %s: vs oracle max %.2e; vs 113-bit median %.2e max %.2e" % (shape, n_paths, moving, max(errs),
+                                                                                       float(np.median(errq)), max(errq)))
+    assert np.median(errq) < 1e-12 and max(errq) < 1e-8
+    assert np.max(np.abs(out["cost"][idx] - refq["cost"]) / np.abs(refq["cost"])) < 1e-9
+    chk = list(range(0, n_paths, 13))
+    csub = batch.select(chk)
+    tc = np.concatenate([out["times"][so[p]:so[p + 1]] for p in chk])
+    cc = np.concatenate([out["coeffs"][so[p]:so[p + 1]] for p in chk])
+    assert util.continuity_defect(csub, cc, tc) < 1e-9 and util.constraint_defect(csub, cc, tc) < 1e-9
