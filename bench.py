@@ -665,7 +665,7 @@ def main():
                    "dispatches overlap as in the timed region); *_over_timed_region: all K steps' compulsory bytes / the timed "
                    "region's wall time",
             traffic=None, traffic_over_compulsory=None, valu_issue_frac=None)
-        for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "round*_pmc_solve_quad_group_hbm_traffic.json"))):
+        for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "round*_pmc_solve_*_group_hbm_traffic.json"))):
             try:
                 with open(f) as fh:
                     d = json.load(fh)
@@ -676,7 +676,7 @@ def main():
                                          traffic_over_compulsory=d["hbm_bytes_per_dispatch"] / float(comp_bytes),
                                          traffic_source=os.path.relpath(f, ROOT) + " (separate rocprofv3 --pmc passes; from "
                                                                                    "profiles/, not this run)")
-        for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "round*_pmc_sq_solve_quad_group.json"))):
+        for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "round*_pmc_sq_solve_*_group.json"))):
             try:
                 with open(f) as fh:
                     d = json.load(fh)
@@ -1009,12 +1009,15 @@ def main():
             for _ in range(2):
                 plan3.solve(opt_lin[0], db3.fixed_mask, db3.fixed_values, t3, c3, st3, db3.cost, waypoints=db3.waypoints)
             torch.cuda.synchronize()
+            api.kernel_trace_reset()
+            plan3.solve(opt_lin[0], db3.fixed_mask, db3.fixed_values, t3, c3, st3, db3.cost, waypoints=db3.waypoints)
+            sat_kernel = (api.kernel_trace() or ["unknown"])[-1]   # (what the trace says: quad from 20480 paths, duo below, rows below 6144)
             m_sat, med_sat, _ = dispatch_stats(ctx, api.KERNEL_SOLVE_LINEAR,
                                                lambda: plan3.solve(opt_lin[0], db3.fixed_mask, db3.fixed_values, t3, c3, st3, db3.cost,
                                                                    waypoints=db3.waypoints), 10, torch)
             flop_sat = SOLVE_FLOP_PER_SEGMENT * n3 * args.segments
             extras["roofline_solve_saturated"] = dict(
-                kernel="solve_quad_kernel<true>" if n3 >= 6144 else "solve_rows_kernel", paths=n3, bound="fp64 vector", unit="TFLOP/s",
+                kernel=sat_kernel, paths=n3, bound="fp64 vector", unit="TFLOP/s",
                 peak=FP64_VECTOR_PEAK_TFLOPS, flop_per_launch=flop_sat, avg_launch_us=m_sat * 1e3, median_launch_us=med_sat * 1e3,
                 achieved=flop_sat / (m_sat * 1e-3) / 1e12, frac=flop_sat / (m_sat * 1e-3) / 1e12 / FP64_VECTOR_PEAK_TFLOPS,
                 trajectories_per_s=n3 / (m_sat * 1e-3),
@@ -1023,7 +1026,7 @@ def main():
                 note="flop model of SURVEY.md 8d (6e3 flop per segment: it counts the reference's two dense 10^3 products per segment, "
                      "which no kernel here executes), per dispatch with events on the launch; compulsory bytes = SURVEY 8d's "
                      "(40 S + 288) in + 328 S out per path")
-            tq = measured_traffic_solve_quad(n3, args.segments) if n3 >= 6144 else None
+            tq = measured_traffic_solve_quad(n3, args.segments) if sat_kernel.startswith("solve_quad_kernel") else None
             if tq is not None:
                 extras["roofline_solve_saturated"].update(
                     traffic=tq[0]["hbm_bytes_per_launch"], traffic_source=tq[1] + " (separate rocprofv3 --pmc passes; from profiles/, not this run)",
@@ -1273,9 +1276,11 @@ def main():
                                                          "one_batch_in_flight (one batch, one dispatch per step: the strict reading "
                                                          "of configs[1]) and value_200_steps, both top-level keys"),
                                 linear_solve="default of mrs_tg_plan_solve, blocks formed in registers (nothing materialised): "
-                                             "solve_rows_kernel for a launch of one batch, solve_quad_group_kernel for a "
-                                             "dispatch that carries >= 6144 paths (the grouped steps of the headline: %d x %d), "
-                                             "solve_rows_group_kernel for a smaller group; the assembly kernel is timed on its "
+                                             "solve_rows_kernel for a launch of one batch; a dispatch that carries >= 6144 paths (the "
+                                             "grouped steps of the headline: %d x %d) runs solve_duo_group_kernel (eight lanes per path, "
+                                             "the vertex chain eliminated from both ends; round 6) below 20480 paths and "
+                                             "solve_quad_group_kernel (four lanes per path) from there on -- roofline_headline.kernel is "
+                                             "what the trace says --, solve_rows_group_kernel a smaller group; the assembly kernel is timed on its "
                                              "own (roofline) and inside extras.materialized_blocks_step"
                                              % (max(1, min(args.group_size, n_group_slots)), P),
                                 clock_ramp_steps=ramp_steps, clock_ramp_ms=30,

@@ -233,10 +233,12 @@ __global__ __launch_bounds__(64) void sample_kernel(BatchView b, const double* _
 // (tests/test_gpu_large_batches.py::test_separate_sampler_equals_the_sampler_in_the_solve_kernels_tail, test_gpu_round6.py).
 // (The round-5 verdict's proposal -- a lane-per-path walk that emits chunk descriptors + a sample-per-lane evaluation -- was
 // built first and measured 2.4 x SLOWER than sample_kernel at 65536 x 10: profiles/round6_sampler_two_kernel_ab.txt.)
-__host__ __device__ inline int sample_group_cstride(int Smax) {  // doubles between two groups' coefficients in LDS: 2 (mod 32)
-  const int n = Smax * (kD * kN);
-  return n + ((2 - n % 32) + 32) % 32;
-}
+// LDS of a group: its path's segment times [Smax] and a RING of three segments' coefficients (the segment being walked, the
+// next one, and the slot the one after next is written to when the walk moves on).  With all S segments of every path staged
+// (26 KB per wavefront of eight 10-segment paths) a CU held six wavefronts and the SIMDs waited 62 % of their cycles
+// (profiles/round6_pmc_sampler.txt); the ring is 1 KB per path whatever its length.
+constexpr int kRingSlots = 3;
+__host__ __device__ constexpr int sample_group_ring_stride() { return kRingSlots * kD * kN + 10; }  // 130 doubles: 2 (mod 32), bank spread
 
 template <int G>
 __device__ __forceinline__ double group_lane_value(double v, int base, int idx) {  // lane base + idx of this wavefront
@@ -244,70 +246,29 @@ __device__ __forceinline__ double group_lane_value(double v, int base, int idx) 
 }
 
 template <int G, int NDER>
-__global__ __launch_bounds__(64) void sample_group_kernel(BatchView b, const double* __restrict__ coeffs,
-                                                          const double* __restrict__ seg_times, double dt, int capacity,
-                                                          int32_t* __restrict__ n_samples, double* __restrict__ samples,
-                                                          const double* __restrict__ acc_table, int acc_n) {
-  constexpr int P = 64 / G;        // paths per wavefront
-  extern __shared__ double lds[];  // [P][Smax] segment times | [P][Smax][4][10] coefficients
+__global__ __launch_bounds__(64, 4) void sample_group_kernel(BatchView b, const double* __restrict__ coeffs,
+                                                             const double* __restrict__ seg_times, double dt, int capacity,
+                                                             int32_t* __restrict__ n_samples, double* __restrict__ samples,
+                                                             const double* __restrict__ acc_table, int acc_n) {
+  constexpr int P = 64 / G;                       // paths per wavefront
+  constexpr int kPer = (kD * kN + G - 1) / G;     // coefficients a lane moves when its group's ring advances
+  extern __shared__ double lds[];                 // [P][Smax] segment times | [P] rings
   const int lane = threadIdx.x, g = lane / G, j = lane % G, base = g * G;
   const int Smax = b.max_segments;
   const int q = blockIdx.x * P + g;
   const bool active = q < b.n_paths;
   const PathRef pr = path_at(b, active ? q : b.n_paths - 1);
   const int S = pr.S;
-  // coefficients of group g at g * cstride: a stride of 2 (mod 32) doubles puts the groups' 16-byte reads of one instruction
-  // on different banks (400 doubles = 3200 bytes apart, four of eight groups met on the same banks: a 4-way conflict on every
-  // one of the 20 reads per step -- it was the kernel's time)
-  const int cstride = sample_group_cstride(Smax);
   double* s_T = lds + (size_t)g * Smax;
-  double* s_c = lds + (size_t)P * Smax + (size_t)g * cstride;
-  // 16-byte pieces, eight requests per lane in flight before the first is waited for (a copy loop of one 8-byte load per
-  // iteration is a chain of 50 memory round trips for the 25 KB of eight 10-segment paths: it WAS the kernel's time)
-  auto stage = [&](const double* __restrict__ src, double* dst, int n_doubles, int first, int stride) {
-    const double2* __restrict__ s2 = reinterpret_cast<const double2*>(src);
-    double2* d2 = reinterpret_cast<double2*>(dst);
-    const int n2 = n_doubles >> 1;   // (n_doubles is a multiple of 40)
-    for (int e0 = first; e0 < n2; e0 += 8 * stride) {
-      double2 v[8];
-#pragma unroll
-      for (int u = 0; u < 8; ++u) {
-        const int e = e0 + u * stride;
-        v[u] = s2[e < n2 ? e : n2 - 1];  // (unconditional: eight requests back to back, no branch around each)
-      }
-#pragma unroll
-      for (int u = 0; u < 8; ++u) {
-        const int e = e0 + u * stride;
-        if (e < n2) d2[e] = v[u];
-      }
-    }
-  };
+  double* s_ring = lds + (size_t)P * Smax + (size_t)g * sample_group_ring_stride();
+  const double* __restrict__ cg = coeffs + (size_t)pr.s0 * (kD * kN);
   if (b.uniform_S > 0) {  // the wavefront's paths are one contiguous run of segments: coalesced over all 64 lanes
     const int q0 = blockIdx.x * P;
     const int np = min(P, b.n_paths - q0);
     const double* __restrict__ tg = seg_times + (size_t)q0 * S;
     for (int e = lane; e < np * S; e += 64) lds[e] = tg[e];
-    if (samples) {  // (the same pipelined copy, each path's run to its own padded place)
-      const double2* __restrict__ s2 = reinterpret_cast<const double2*>(coeffs + (size_t)q0 * S * (kD * kN));
-      double2* d2 = reinterpret_cast<double2*>(lds + (size_t)P * Smax);
-      const int per2 = S * (kD * kN) / 2, n2 = np * per2, cs2 = cstride / 2;
-      for (int e0 = lane; e0 < n2; e0 += 8 * 64) {
-        double2 v[8];
-#pragma unroll
-        for (int u = 0; u < 8; ++u) {
-          const int e = e0 + u * 64;
-          v[u] = s2[e < n2 ? e : n2 - 1];
-        }
-#pragma unroll
-        for (int u = 0; u < 8; ++u) {
-          const int e = e0 + u * 64;
-          if (e < n2) d2[(e / per2) * cs2 + e % per2] = v[u];
-        }
-      }
-    }
   } else if (active) {
     for (int e = j; e < S; e += G) s_T[e] = seg_times[pr.s0 + e];
-    if (samples) stage(coeffs + (size_t)pr.s0 * (kD * kN), s_c, S * (kD * kN), j, G);
   }
   __syncthreads();
   // every lane of a group carries the group's walk state (i, Ti, tin, n): t_end and the start segment as the reference
@@ -332,23 +293,58 @@ __global__ __launch_bounds__(64) void sample_group_kernel(BatchView b, const dou
     }
   }
   bool done = !active || i >= S;
+  const bool eval = samples != nullptr;
+  // the ring: segments i and i + 1 into their slots (slot = segment mod 3), segment i + 2 requested into registers
+  double pre[kPer];
+  auto request = [&](int seg) {  // this lane's share of a segment's coefficients, global -> registers (no wait here)
+#pragma unroll
+    for (int u = 0; u < kPer; ++u) {
+      const int e = j * kPer + u;
+      pre[u] = (eval && !done && seg < S && e < kD * kN) ? cg[(size_t)seg * (kD * kN) + e] : 0.0;
+    }
+  };
+  auto deposit = [&](int seg) {  // ... registers -> the segment's slot
+    double* slot = s_ring + (seg % kRingSlots) * (kD * kN);
+#pragma unroll
+    for (int u = 0; u < kPer; ++u) {
+      const int e = j * kPer + u;
+      if (e < kD * kN) slot[e] = pre[u];
+    }
+  };
+  request(i);
+  deposit(i);
+  request(i + 1);
+  deposit(i + 1);
+  request(i + 2);
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
   double dt_r[G];
 #pragma unroll
   for (int r = 1; r < G; ++r) dt_r[r] = (j >= r) ? dt : 0.0;
   double tin = 0.0;  // (t_start = 0: the walk enters the first segment of positive length at its start)
   double Ti = done ? 0.0 : s_T[i];
   int n = 0;
-  double* out = (samples && active) ? samples + (size_t)pr.p * capacity * (NDER + 1) * kD : nullptr;
+  double* out = (eval && active) ? samples + (size_t)pr.p * capacity * (NDER + 1) * kD : nullptr;
   for (;;) {
     done = done || n >= n_total;  // trajectory.cpp:131
-    // carry the remainder into the next segment(s) (:132-139), group by group
+    // carry the remainder into the next segment(s) (:132-139), group by group; a group that moves on deposits the segment
+    // after next (requested one segment ago) into the slot the segment it leaves behind no longer needs, and requests another
     while (__ballot(!done && tin > Ti) != 0ull) {
       if (!done && tin > Ti) {
         tin = tin - Ti;
         ++i;
-        if (i >= S) done = true;
-        else Ti = s_T[i];
+        if (i >= S) {
+          done = true;
+        } else {
+          Ti = s_T[i];
+          deposit(i + 1);
+          request(i + 2);
+        }
       }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
     }
     if (__ballot(!done) == 0ull) break;
     // lane j adds dt j times (the addends dt_r = j >= r ? dt : +0.0 are set up once: x + 0.0 is x, bit for bit, for x >= 0)
@@ -360,7 +356,7 @@ __global__ __launch_bounds__(64) void sample_group_kernel(BatchView b, const dou
     const unsigned bits = (unsigned)(ball >> base) & ((1u << G) - 1u);
     const int m = (bits == (1u << G) - 1u) ? G : __builtin_ctz(~bits);  // lanes [0, m) of the group emit a sample
     if (out && j < m && n + j < capacity) {
-      const double* c = s_c + (size_t)i * (kD * kN);
+      const double* c = s_ring + (i % kRingSlots) * (kD * kN);
       double* o = out + (size_t)(n + j) * (NDER + 1) * kD;
 #pragma unroll
       for (int k = 0; k <= NDER; ++k) {
@@ -385,8 +381,6 @@ __global__ __launch_bounds__(64) void sample_group_kernel(BatchView b, const dou
       }
       n += m;
       if (n > capacity) done = true;  // overflow: reported as capacity + 1
-    } else {
-      (void)group_lane_value<G>(tj, base, 0);  // (the exchange is executed by all lanes)
     }
   }
   if (active && j == 0 && n_samples) n_samples[pr.p] = n;
@@ -680,23 +674,20 @@ hipError_t sample_acc_table(double dt, int capacity, hipStream_t stream, const d
 }
 
 static size_t sample_group_lds_bytes(int Smax, int G) {
-  return (size_t)(64 / G) * ((size_t)Smax + sample_group_cstride(Smax)) * sizeof(double);
+  return (size_t)(64 / G) * ((size_t)Smax + sample_group_ring_stride()) * sizeof(double);
 }
 
 // Which sampler a launch takes: 0 = one wavefront per path (sample_kernel), 8 / 16 = sample_group_kernel with that many lanes
 // per path.  The group kernels need 64 / G paths' coefficients in LDS (40 KB at most: four wavefronts per CU and more) and
-// enough paths to fill the SIMDs with 64 / G of them per wavefront.  MRS_TG_SAMPLE_GROUP=0 | 8 | 16 forces (read once).
+// enough paths to fill the SIMDs with 64 / G of them per wavefront.  MRS_TG_SAMPLE_GROUP=0 | 8 | 16 forces.
 int sample_group_lanes(const BatchView& b) {
-  static const int forced = [] {
-    const char* e = std::getenv("MRS_TG_SAMPLE_GROUP");
-    return e ? std::atoi(e) : -1;
-  }();
+  const char* env = std::getenv("MRS_TG_SAMPLE_GROUP");  // (read at every call: the tests run all three kernels)
+  const int forced = env ? std::atoi(env) : -1;
   auto fits = [&](int G) { return sample_group_lds_bytes(b.max_segments, G) <= 40 * 1024; };
   if (forced == 0) return 0;
   if (forced == 8 || forced == 16) return fits(forced) ? forced : 0;
-  if (b.n_paths >= 8192 && fits(8)) return 8;
-  if (b.n_paths >= 4096 && fits(16)) return 16;
-  return 0;
+  (void)fits;
+  return 0;  // measured slower than sample_kernel at every size so far (profiles/round6_sampler_group_ab.txt): on request only
 }
 
 template <int NDER>

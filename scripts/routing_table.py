@@ -56,12 +56,22 @@ def routes(ctx):
     return out
 
 
+def compress(names):
+    """kernel names in first-launch order; a kernel launched several times (the iterations of a gradient-free search) once, with its count"""
+    seen, order = {}, []
+    for n in names:
+        if n not in seen:
+            order.append(n)
+        seen[n] = seen.get(n, 0) + 1
+    return ["`%s`%s" % (n, " (x %d%s)" % (seen[n], "+" if len(names) >= 32 else "") if seen[n] > 1 else "") for n in order]
+
+
 def main():
     ctx = api.Context(0)
     print("| batch | options | kernels, in launch order |")
     print("|---|---|---|")
     for sname, oname, names in routes(ctx):
-        print("| %s | %s | %s |" % (sname, oname, " → ".join("`%s`" % n for n in names)))
+        print("| %s | %s | %s |" % (sname, oname, " → ".join(compress(names))))
     ctx.close()
 
 

@@ -81,10 +81,12 @@ except api.MrsTgError as ex:
 @pytest.mark.parametrize("shape,n_paths,dt,cap,kernel", [(10, 8192, 0.2, 512, "sample_group_kernel<8"), ("ragged", 4200, 0.2, 640, "sample_group_kernel<16"),
                                                          (10, 4608, 0.05, 1024, "sample_group_kernel<16"), (3, 9000, 0.3, 96, "sample_group_kernel<8"),
                                                          (15, 8200, 0.2, 300, "sample_group_kernel<8"), (30, 4100, 0.2, 2048, "sample_group_kernel<16")])
-def test_group_sampler_against_the_oracles_walk(gpu_ctx, shape, n_paths, dt, cap, kernel):
+def test_group_sampler_against_the_oracles_walk(gpu_ctx, monkeypatch, shape, n_paths, dt, cap, kernel):
     """The sampler of large launches (sample_group_kernel: 8 or 16 lanes per path, walk and evaluation fused) against the oracle's
     restatement of Trajectory::evaluateRange on the SAME coefficients and times: sample counts equal (capacity + 1 where the
     trajectory does not fit), positions to 1e-11, heading to 1e-11 on the circle -- and the kernel trace says which kernel ran."""
+    # (not the default: measured slower than the one-wavefront-per-path kernel, profiles/round6_sampler_group_ab.txt)
+    monkeypatch.setenv("MRS_TG_SAMPLE_GROUP", "8" if "<8" in kernel else "16")
     batch = pr.random_batch(n_paths, shape, seed0=555)
     lin = gpu_ctx.solve_batch(batch, None)
     times = lin["times"].copy()
