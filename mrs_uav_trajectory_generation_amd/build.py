@@ -13,7 +13,7 @@ from concurrent.futures import ThreadPoolExecutor
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libmrs_tg.so")
-SOURCES = ["mrs_tg_kernels.hip", "mrs_tg_tile.hip", "mrs_tg_rows.hip", "mrs_tg_quad.hip", "mrs_tg_general.hip", "mrs_tg_nonlinear.hip", "mrs_tg_wave.hip", "mrs_tg_dfo.hip", "mrs_tg_abi.hip", "mrs_tg_multi.hip", "mrs_tg_policy.hip",
+SOURCES = ["mrs_tg_kernels.hip", "mrs_tg_tile.hip", "mrs_tg_rows.hip", "mrs_tg_quad.hip", "mrs_tg_general.hip", "mrs_tg_nonlinear.hip", "mrs_tg_wave.hip", "mrs_tg_dfo.hip", "mrs_tg_abi.hip", "mrs_tg_multi.hip", "mrs_tg_policy.hip", "mrs_tg_policy_dev.hip",
            "mrs_tg_pool.hip"]
 # every header under csrc/ (a header that is split or added is picked up without editing this file) + the public ABI
 HEADERS = sorted(f for f in os.listdir(CSRC) if f.endswith((".h", ".hpp"))) + [os.path.join("..", "..", "include", "mrs_tg.h")]

@@ -965,6 +965,150 @@ static int solve_batch_impl(mrs_tg_ctx* ctx, int32_t n_paths, const int32_t* so,
                             double* coeffs, int32_t* status, double* cost, int32_t* n_samples, double* samples,
                             bool coeffs_required);
 
+// the plan of the previous call is kept: the same batch shape again (a server's fixed batch, the re-solves of the nodelet's
+// deviation loop) costs no analysis, no structure upload and no workspace allocation
+static int cached_plan_for(mrs_tg_ctx* ctx, int32_t n_paths, const int32_t* so, mrs_tg_plan** plan_out) {
+  mrs_tg_plan* plan = ctx->cached_plan;
+  if (plan && (plan->view.n_paths != n_paths ||
+               std::memcmp(plan->seg_offsets_host.data(), so, sizeof(int32_t) * ((size_t)n_paths + 1)) != 0)) {
+    ctx->cached_plan = nullptr;
+    mrs_tg_plan_destroy(plan);
+    plan = nullptr;
+  }
+  if (!plan) {
+    const int rc = mrs_tg_plan_create(ctx, n_paths, so, &plan);
+    if (rc != MRS_TG_OK) return rc;
+    ctx->cached_plan = plan;
+  }
+  *plan_out = plan;
+  return MRS_TG_OK;
+}
+
+extern "C++" {
+namespace mrs_tg {
+
+// One round of optimize() for the `n_paths` requests still active: vertex expansion, findTrajectory's solve (one batched
+// pipeline on the cached plan of this shape), both gates and validateTrajectorySpatial on the device.  `in.block` is the host
+// block of policy_round_layout (pinned: read and written by the GPU in place through ONE copy kernel each way; pageable: by the
+// runtime's copies); when the call returns its result region holds ok / n_samples / status / max_deviation / is_safe per
+// path, the safe flag of every segment, and the sample rows of the paths that are finished.
+int policy_round_device(mrs_tg_ctx* ctx, const PolicyRoundIn& in) {
+  if (!ctx || !in.block || in.n_paths <= 0) return fail(ctx, MRS_TG_ERR_INVALID_ARG, "policy round: nothing to solve");
+  const size_t A = (size_t)in.n_paths, nS = in.n_segments, nV = in.n_vertices;
+  const int cap = in.sample_capacity;
+  const PolicyRoundLayout L = policy_round_layout(A, nS, cap);
+  HIP_TRY(ctx, use_device(ctx->device));
+  hipStream_t s = ctx->stream;
+  mrs_tg_plan* plan = nullptr;
+  int rc = cached_plan_for(ctx, in.n_paths, in.seg_offsets, &plan);
+  if (rc != MRS_TG_OK) return rc;
+  // device arena: [the block's input region] | results (small) | mask | values | times | coefficients | cost | status | n | rows | samples
+  auto up = [](size_t bytes) { return (bytes + 255) & ~(size_t)255; };
+  size_t off = L.in_bytes;
+  const size_t o_res = off;
+  off += L.samples - L.in_bytes;  // the small results, laid out as in the block
+  const size_t o_mask = off;
+  off += up(nV * 5);
+  const size_t o_vals = off;
+  off += up(nV * 20 * sizeof(double));
+  const size_t o_t = off;
+  off += up(nS * sizeof(double));
+  const size_t o_c = off;
+  off += up(nS * 40 * sizeof(double));
+  const size_t o_cost = off;
+  off += up(A * sizeof(double));
+  const size_t o_st = off;
+  off += up(A * sizeof(int32_t));
+  const size_t o_ns = off;
+  off += up(A * sizeof(int32_t));
+  const size_t o_rows = off;
+  off += up(A * sizeof(int32_t));
+  const size_t o_smp = off;
+  off += up(A * (size_t)cap * 4 * sizeof(double));
+  if (ctx->d_arena_bytes < off) {
+    if (ctx->d_arena) {
+      (void)hipStreamSynchronize(s);  // pool contract: no work in flight on a block that is given back
+      (void)mrs_tg::pool_free(ctx->d_arena);
+    }
+    ctx->d_arena = nullptr;
+    ctx->d_arena_bytes = 0;
+    const size_t want = off + off / 2;  // (the next round's paths have more waypoints: one allocation for a request's rounds)
+    HIP_TRY(ctx, mrs_tg::pool_alloc(&ctx->d_arena, want));
+    ctx->d_arena_bytes = want;
+  }
+  char* d = static_cast<char*>(ctx->d_arena);
+  struct SyncOnExit {  // nothing of this call is in flight when it returns, on error paths as well (the arena is reused)
+    hipStream_t st;
+    ~SyncOnExit() { (void)hipStreamSynchronize(st); }
+  } sync_on_exit{s};
+  // is the block memory the GPU addresses (hipHostMalloc: ctx_host_scratch)?  Then one copy kernel moves the inputs, and the
+  // results are written into it directly
+  hipPointerAttribute_t at;
+  bool pinned = hipPointerGetAttributes(&at, in.block) == hipSuccess && at.type == hipMemoryTypeHost;
+  if (!pinned) (void)hipGetLastError();
+  char* blk_dev = pinned ? static_cast<char*>(at.devicePointer ? at.devicePointer : (void*)in.block) : nullptr;
+  if (pinned) {
+    mrs_tg::CopyList upl;
+    upl.add(blk_dev, d, L.in_bytes);
+    HIP_TRY(ctx, mrs_tg::launch_copy_many(upl, s));
+  } else {
+    HIP_TRY(ctx, hipMemcpyAsync(d, in.block, L.in_bytes, hipMemcpyHostToDevice, s));
+  }
+  const double* wp_d = reinterpret_cast<const double*>(d + L.wp);
+  uint8_t* mask_d = reinterpret_cast<uint8_t*>(d + o_mask);
+  double* vals_d = reinterpret_cast<double*>(d + o_vals);
+  HIP_TRY(ctx, mrs_tg::launch_policy_expand((int)nV, in.opt.derivative_to_optimize, wp_d, reinterpret_cast<const int32_t*>(d + L.vinfo),
+                                            reinterpret_cast<const double*>(d + L.init), mask_d, vals_d, s));
+  mrs_tg_options opt = in.opt;
+  opt.estimate_times = 1;
+  opt.sample_capacity = cap;
+  opt.flags |= MRS_TG_FLAG_REFERENCE_STATUS;  // the length check below is the reference's answer to a runaway (:1178-1199)
+  int32_t* st_d = reinterpret_cast<int32_t*>(d + o_st);
+  int32_t* ns_d = reinterpret_cast<int32_t*>(d + o_ns);
+  double* smp_d = reinterpret_cast<double*>(d + o_smp);
+  rc = mrs_tg_plan_solve(plan, wp_d, mask_d, vals_d, reinterpret_cast<const double*>(d + L.lim), &opt, reinterpret_cast<double*>(d + o_t),
+                         reinterpret_cast<double*>(d + o_c), st_d, reinterpret_cast<double*>(d + o_cost), ns_d, smp_d);
+  if (rc != MRS_TG_OK) return rc;
+  // gates + validateTrajectorySpatial where the samples are; the small results go where the host reads them
+  char* res = pinned ? blk_dev : d;  // (res + L.<field> addresses the field in either place: the arena mirrors the block)
+  (void)o_res;
+  mrs_tg::PolicyValidateArgs va{};
+  va.n_paths = in.n_paths;
+  va.seg_offsets = reinterpret_cast<const int32_t*>(d + L.so);
+  va.wp = wp_d;
+  va.samples = smp_d;
+  va.n_samples = ns_d;
+  va.status = st_d;
+  va.baca_total = reinterpret_cast<const double*>(d + L.baca);
+  va.dt = opt.sampling_dt;
+  va.max_len_factor = in.max_len_factor;
+  va.min_len_factor = in.min_len_factor;
+  va.max_deviation = in.max_deviation;
+  va.capacity = cap;
+  va.first_segment = in.first_segment;
+  va.check_enabled = in.check_enabled;
+  va.last_round = in.last_round;
+  va.ok_out = reinterpret_cast<int32_t*>(res + L.ok);
+  va.ns_out = reinterpret_cast<int32_t*>(res + L.ns);
+  va.status_out = reinterpret_cast<int32_t*>(res + L.status);
+  va.max_dev_out = reinterpret_cast<double*>(res + L.max_dev);
+  va.is_safe_out = reinterpret_cast<uint8_t*>(res + L.is_safe);
+  va.safe_out = reinterpret_cast<uint8_t*>(res + L.safe);
+  va.ns_copy = reinterpret_cast<int32_t*>(d + o_rows);
+  HIP_TRY(ctx, mrs_tg::launch_policy_validate(va, s));
+  if (pinned) {  // the finished paths' rows only
+    HIP_TRY(ctx, mrs_tg::launch_copy_samples(smp_d, reinterpret_cast<double*>(blk_dev + L.samples), va.ns_copy, in.n_paths, cap, s));
+  } else {
+    HIP_TRY(ctx, hipMemcpyAsync(in.block + L.ok, d + o_res, L.samples - L.ok, hipMemcpyDeviceToHost, s));
+    HIP_TRY(ctx, hipMemcpyAsync(in.block + L.samples, smp_d, A * (size_t)cap * 4 * sizeof(double), hipMemcpyDeviceToHost, s));
+  }
+  HIP_TRY(ctx, hipStreamSynchronize(s));
+  return MRS_TG_OK;
+}
+
+}  // namespace mrs_tg
+}  // extern "C++"
+
 int mrs_tg_solve_batch(mrs_tg_ctx* ctx, int32_t n_paths, const int32_t* so, const double* wp, const uint8_t* mask,
                        const double* vals, const double* limits, const mrs_tg_options* opt, double* seg_times,
                        double* coeffs, int32_t* status, double* cost, int32_t* n_samples, double* samples) {
@@ -994,19 +1138,8 @@ static int solve_batch_impl(mrs_tg_ctx* ctx, int32_t n_paths, const int32_t* so,
     return fail(ctx, MRS_TG_ERR_INVALID_ARG, "seg_offsets, fixed_mask, fixed_values, seg_times, coeffs_out, status_out are required");
   if (n_paths == 0) return MRS_TG_OK;
   const auto t_call = std::chrono::steady_clock::now();
-  // the plan of the previous call is kept: the same batch shape again (a server's fixed batch, the re-solves of the
-  // nodelet's deviation loop) costs no analysis, no structure upload and no workspace allocation
-  mrs_tg_plan* plan = ctx->cached_plan;
-  if (plan && (plan->view.n_paths != n_paths ||
-               std::memcmp(plan->seg_offsets_host.data(), so, sizeof(int32_t) * ((size_t)n_paths + 1)) != 0)) {
-    ctx->cached_plan = nullptr;
-    mrs_tg_plan_destroy(plan);
-    plan = nullptr;
-  }
-  if (!plan) {
-    if ((rc = mrs_tg_plan_create(ctx, n_paths, so, &plan)) != MRS_TG_OK) return rc;
-    ctx->cached_plan = plan;
-  }
+  mrs_tg_plan* plan = nullptr;
+  if ((rc = cached_plan_for(ctx, n_paths, so, &plan)) != MRS_TG_OK) return rc;
   const size_t nS = (size_t)so[n_paths], nV = nS + (size_t)n_paths;
   const bool sampling = opt->sampling_dt > 0;
   if (sampling && !n_samples) return fail(ctx, MRS_TG_ERR_INVALID_ARG, "n_samples_out is required when sampling");

@@ -130,6 +130,32 @@ int sample_group_lanes(const BatchView& b);  // 0 | 8 | 16: which sampler a laun
 constexpr int kSampleStateOrders = 5;
 hipError_t launch_sample_states(const BatchView& b, const double* coeffs, const double* seg_times, double dt, int capacity,
                                 int32_t* n_samples, double* states, hipStream_t stream);
+// ---- the policy layer's per-round device work (mrs_tg_policy_dev.hip) ----
+// constraint mask [n_vertices][5] and values [n_vertices][5][4] from the unwrapped waypoints [n_vertices][4], vinfo[v] = position of
+// the vertex's path in the round's batch << 4 | flags, and the initial states [n_paths][12] (velocity, acceleration, jerk)
+hipError_t launch_policy_expand(int n_vertices, int d, const double* wp, const int32_t* vinfo, const double* init, uint8_t* mask,
+                                double* vals, hipStream_t stream);
+struct PolicyValidateArgs {
+  int n_paths;
+  const int32_t* seg_offsets;   // [n_paths + 1] (device)
+  const double* wp;             // [sum V][4]
+  const double* samples;        // [n_paths][capacity][4]
+  const int32_t* n_samples;     // [n_paths] as the solve reported them
+  const int32_t* status;        // [n_paths]
+  const double* baca_total;     // [n_paths] initial_total_time_baca
+  double dt, max_len_factor, min_len_factor, max_deviation;
+  int capacity, first_segment, check_enabled, last_round;
+  // results (any address the device can write: pinned host memory)
+  int32_t* ok_out;
+  int32_t* ns_out;
+  int32_t* status_out;
+  double* max_dev_out;
+  uint8_t* is_safe_out;
+  uint8_t* safe_out;            // [sum S]
+  int32_t* ns_copy;             // [n_paths] (device) rows of the finished paths' samples that travel
+};
+hipError_t launch_policy_validate(const PolicyValidateArgs& args, hipStream_t stream);
+
 size_t linear_workspace_doubles(const BatchView& b);
 // MRS_TG_FLAG_POSITIONS_ARE_WAYPOINTS, checked: the number of vertices whose position is unconstrained or whose constrained
 // position differs (bitwise) from its waypoint.  Blocks until the count is on the host.

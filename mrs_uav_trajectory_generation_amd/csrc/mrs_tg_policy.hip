@@ -17,6 +17,18 @@ struct GpuHost {  // the Host of mrs_tg::policy::optimize_paths
     return mrs_tg::solve_batch_samples_only(ctx, n_paths, seg_offsets, wp, mask, vals, lim, opt, times, status, n_samples, samples);
   }
   int fail(int code, const char* message) { return mrs_tg::report_error(ctx, code, "%s", message); }
+  // the rounds' batch-sized work on the device (mrs_tg_abi.hip::policy_round_device); MRS_TG_POLICY_DEVICE=0: the host route
+  // above (vertices, gates and validation on the policy's host threads), as until round 5
+  // From 64 active requests on: below, a round's two extra launches and the second copy kernel cost a lone request more than
+  // its 36 KB of values and samples on the wire (one 5-round request: 1.15 ms on the host route, 1.97 on the device route).
+  bool device_round_enabled(size_t active_paths) const {
+    static const int min_paths = [] {
+      const char* e = std::getenv("MRS_TG_POLICY_DEVICE");   // 0: never; n >= 1: from n active requests on
+      return e == nullptr ? 64 : std::atoi(e);
+    }();
+    return min_paths > 0 && active_paths >= (size_t)min_paths;
+  }
+  int round(const mrs_tg::PolicyRoundIn& in) { return mrs_tg::policy_round_device(ctx, in); }
 };
 
 }  // namespace

@@ -24,13 +24,58 @@
 #include <stdexcept>
 #include <system_error>
 #include <thread>
+#include <type_traits>
 #include <vector>
 
 #include <sched.h>
 
 #include "../../include/mrs_tg.h"
 
+struct mrs_tg_ctx;
+
 namespace mrs_tg {
+
+// ---- one round of the policy loop on the device (mrs_tg_abi.hip::policy_round_device, kernels in mrs_tg_policy_dev.hip) ----
+// The host block of a round: inputs | results, every field 256-byte aligned.  Plain arithmetic, shared by the host code that
+// fills / reads the block and the device code that mirrors it in its arena.
+struct PolicyRoundLayout {
+  size_t wp, init, lim, baca, vinfo, so, in_bytes;                      // inputs (offsets in the block)
+  size_t ok, ns, status, max_dev, is_safe, safe, samples, total_bytes;   // results
+};
+inline PolicyRoundLayout policy_round_layout(size_t A, size_t nS, int32_t capacity) {
+  auto up = [](size_t bytes) { return (bytes + 255) & ~(size_t)255; };
+  const size_t nV = nS + A;
+  PolicyRoundLayout L{};
+  size_t off = 0;
+  L.wp = off, off += up(nV * 4 * sizeof(double));          // unwrapped waypoints [vertex][4]
+  L.init = off, off += up(A * 12 * sizeof(double));        // initial velocity / acceleration / jerk [path][3][4]
+  L.lim = off, off += up(A * 9 * sizeof(double));          // limits after relax_heading [path][9]
+  L.baca = off, off += up(A * sizeof(double));             // initial_total_time_baca [path]
+  L.vinfo = off, off += up(nV * sizeof(int32_t));          // position of the vertex's path << 4 | kVertex* flags
+  L.so = off, off += up((A + 1) * sizeof(int32_t));        // segment offsets
+  L.in_bytes = off;
+  L.ok = off, off += up(A * sizeof(int32_t));              // both gates passed (and the samples fit)
+  L.ns = off, off += up(A * sizeof(int32_t));
+  L.status = off, off += up(A * sizeof(int32_t));
+  L.max_dev = off, off += up(A * sizeof(double));
+  L.is_safe = off, off += up(A);
+  L.safe = off, off += up(nS ? nS : 1);                    // validateTrajectorySpatial's flag of every segment
+  L.samples = off, off += up(A * (size_t)capacity * 4 * sizeof(double));  // rows of the FINISHED paths only
+  L.total_bytes = off;
+  return L;
+}
+constexpr int kVertexFirst = 1, kVertexLast = 2, kVertexStop = 4, kVertexInit = 8;
+struct PolicyRoundIn {
+  int32_t n_paths;
+  const int32_t* seg_offsets;  // [n_paths + 1] (host; also at block + layout.so)
+  size_t n_segments, n_vertices;
+  char* block;                 // policy_round_layout(n_paths, n_segments, sample_capacity).total_bytes
+  mrs_tg_options opt;
+  double max_len_factor, min_len_factor, max_deviation;
+  int32_t first_segment, check_enabled, last_round, sample_capacity;
+};
+int policy_round_device(::mrs_tg_ctx* ctx, const PolicyRoundIn& in);  // (defined in mrs_tg_abi.hip: the GPU build only)
+
 namespace policy {
 
 inline double wrap_range(double a, double lo, double range) {
@@ -427,6 +472,12 @@ inline int length_check(int n_samples, double dt, double baca_total, double max_
 }
 
 
+// a Host with `int round(const PolicyRoundIn&)` and `bool device_round_enabled(size_t active_paths)` runs the rounds' batch-sized work on the device
+template <class H, class = void>
+struct HasDeviceRound : std::false_type {};
+template <class H>
+struct HasDeviceRound<H, std::void_t<decltype(&H::round)>> : std::true_type {};
+
 template <class Host, class... Args>
 int failf(Host& host, int code, const char* fmt, Args... args) {
   char buf[256];
@@ -510,6 +561,124 @@ int optimize_paths(Host& host, int32_t n_paths, const int32_t* wp_offsets, const
       }
       active.resize(kept);
       if (active.empty()) break;
+    }
+    // ---- a host that runs the round on the device (the GPU build): vertices expanded, gates and validateTrajectorySpatial
+    // applied where the samples are; the waypoints travel up, a few words per path and the FINISHED paths' samples come down
+    if constexpr (HasDeviceRound<Host>::value) {
+      if (!use_fallback && host.device_round_enabled(active.size())) {
+        const double t0 = now();
+        const size_t A = active.size();
+        std::vector<int32_t> so(A + 1, 0);
+        for (size_t a = 0; a < A; ++a) so[a + 1] = so[a] + st[active[a]].n_wp - 1;
+        const size_t nS = (size_t)so.back(), nV = nS + A;
+        const PolicyRoundLayout L = policy_round_layout(A, nS, sample_capacity);
+        static const bool pinned_allowed = [] {  // MRS_TG_POLICY_PINNED=0: ordinary memory (test knob, read once per process)
+          const char* e = std::getenv("MRS_TG_POLICY_PINNED");
+          return e == nullptr || std::atoi(e) != 0;
+        }();
+        char* block = pinned_allowed ? static_cast<char*>(host.scratch(L.total_bytes)) : nullptr;
+        std::vector<char> pageable;
+        if (!block) {
+          pageable.resize(L.total_bytes);
+          block = pageable.data();
+        }
+        double* wp = reinterpret_cast<double*>(block + L.wp);
+        double* init = reinterpret_cast<double*>(block + L.init);
+        double* lim = reinterpret_cast<double*>(block + L.lim);
+        double* baca = reinterpret_cast<double*>(block + L.baca);
+        int32_t* vinfo = reinterpret_cast<int32_t*>(block + L.vinfo);
+        std::memcpy(block + L.so, so.data(), sizeof(int32_t) * (A + 1));
+        bool any_stop = false;
+        for (size_t a = 0; a < A && !any_stop; ++a)
+          for (int i = 1; i + 1 < st[active[a]].n_wp && !any_stop; ++i) any_stop = st[active[a]].stop[i] != 0;
+        parallel_ranges(A, 128, [&](size_t a0, size_t a1) {
+          std::vector<double> tb;
+          for (size_t a = a0; a < a1; ++a) {
+            const int p = active[a];
+            const PathState& s = st[p];
+            const bool has_init = has_initial_state && has_initial_state[p] && initial_states;
+            const size_t v0 = (size_t)so[a] + a;
+            // headings unwrapped along the path from the initial state's heading (:925-936)
+            double last_heading = has_init ? initial_states[p].heading : s.wps[3];
+            for (int i = 0; i < s.n_wp; ++i) {
+              double* w = wp + (v0 + i) * 4;
+              for (int k = 0; k < 3; ++k) w[k] = s.wps[(size_t)i * 4 + k];
+              w[3] = sradians_unwrap(s.wps[(size_t)i * 4 + 3], last_heading);
+              last_heading = w[3];
+              vinfo[v0 + i] = (int32_t)(a << 4) | (i == 0 ? kVertexFirst : 0) | (i == s.n_wp - 1 ? kVertexLast : 0) |
+                              ((i > 0 && i < s.n_wp - 1 && s.stop[i]) ? kVertexStop : 0) | ((i == 0 && has_init) ? kVertexInit : 0);
+            }
+            for (int k = 0; k < 4; ++k) {
+              init[a * 12 + k] = has_init ? initial_states[p].velocity[k] : 0.0;
+              init[a * 12 + 4 + k] = has_init ? initial_states[p].acceleration[k] : 0.0;
+              init[a * 12 + 8 + k] = has_init ? initial_states[p].jerk[k] : 0.0;
+            }
+            effective_limits(limits + (size_t)p * 9, relax_heading && relax_heading[p], lim + a * 9);
+            st[p].baca_total = baca[a] = baca_total_time(s.n_wp - 1, wp + v0 * 4, lim + a * 9, tb);
+          }
+        });
+        PolicyRoundIn in{};
+        in.n_paths = (int32_t)A;
+        in.seg_offsets = so.data();
+        in.n_segments = nS;
+        in.n_vertices = nV;
+        in.block = block;
+        in.opt = o.solver;
+        if (any_stop && d == 4) in.opt.flags |= MRS_TG_FLAG_CONSTRAINED_SLOTS;
+        if (o.max_execution_time_s > 0) in.opt.max_time_s = 2.0 * 0.95 * budget_left;  // :899
+        in.max_len_factor = o.max_trajectory_len_factor;
+        in.min_len_factor = o.min_trajectory_len_factor;
+        in.max_deviation = o.max_deviation;
+        in.first_segment = o.max_deviation_first_segment;
+        in.check_enabled = o.check_deviation_enabled;
+        in.last_round = round == o.max_deviation_iterations;
+        in.sample_capacity = sample_capacity;
+        const double t1 = now();
+        t_build += t1 - t0;
+        const int rc = host.round(in);
+        if (rc != MRS_TG_OK) return rc;
+        const double t2 = now();
+        t_solve += t2 - t1;
+        const bool late = overtime();  // findTrajectory's own checks behind optimize() and the sampler: "return {}" (:1085, :1156, :1171)
+        const int32_t* r_ok = reinterpret_cast<const int32_t*>(block + L.ok);
+        const int32_t* r_ns = reinterpret_cast<const int32_t*>(block + L.ns);
+        const double* r_dev = reinterpret_cast<const double*>(block + L.max_dev);
+        const uint8_t* r_safe_path = reinterpret_cast<const uint8_t*>(block + L.is_safe);
+        const uint8_t* r_safe = reinterpret_cast<const uint8_t*>(block + L.safe);
+        const double* r_smp = reinterpret_cast<const double*>(block + L.samples);
+        const bool last = in.last_round != 0;
+        parallel_ranges(A, 128, [&](size_t a0, size_t a1) {
+          std::vector<uint8_t> safe;
+          for (size_t a = a0; a < a1; ++a) {
+            const int p = active[a];
+            const bool ok = !late && r_ok[a] != 0;
+            st[p].ok = ok;
+            st[p].n_samples = ok ? r_ns[a] : 0;
+            if (!ok) {
+              st[p].done = true;  // "failed to find trajectory" :720-727, :771-778
+              continue;
+            }
+            bool finished = last;
+            if (!last) {
+              st[p].max_dev = r_dev[a];
+              if (o.check_deviation_enabled && !r_safe_path[a]) {
+                safe.assign(r_safe + so[a], r_safe + so[a + 1]);
+                insert_midpoints(st[p], safe, o);
+                st[p].iterations = round + 1;
+              } else {
+                st[p].done = true;
+                finished = true;
+              }
+            }
+            if (finished)
+              std::memcpy(samples_out + (size_t)p * sample_capacity * 4, r_smp + a * (size_t)sample_capacity * 4,
+                          sizeof(double) * 4 * (size_t)r_ns[a]);
+          }
+        });
+        t_post += now() - t2;
+        if (last) break;
+        continue;
+      }
     }
     // ---- solve every active path (one batched GPU call, or the fallback sampler on the host)
     if (use_fallback) {

@@ -131,7 +131,11 @@ def test_batch_of_requests_on_threads_gives_the_bits_of_one_thread_and_agrees_wi
                    env=dict(os.environ, MRS_TG_POLICY_THREADS="1", MRS_TG_POLICY_PINNED="0"))   # (and ordinary memory for the rounds' arrays)
     ref = np.load(ref_path)
     for k in out:
-        assert np.array_equal(out[k], ref[k]), k
+        if k != "samples":
+            assert np.array_equal(out[k], ref[k]), k
+    for p in range(out["success"].size):   # (rows beyond a request's count are not part of the result)
+        n = int(out["n_samples"][p])
+        assert np.array_equal(out["samples"][p, :n], ref["samples"][p, :n]), p
     assert out["success"].mean() > 0.98 and out["iterations"].max() >= 3      # (the subdivision rounds did run)
     paths = [(pr.random_box_waypoints if i % 3 else pr.random_walk_waypoints)(4 + (i % 6), 3100 + i) for i in range(700)]
     same = n_checked = 0
@@ -146,3 +150,27 @@ def test_batch_of_requests_on_threads_gives_the_bits_of_one_thread_and_agrees_wi
                 same += 1
     print("RATE policy batch of 700: %d / %d" % (same, n_checked))
     assert same >= n_checked - 2, (same, n_checked)
+
+
+def test_device_rounds_give_the_bits_of_the_host_rounds(gpu_ctx, tmp_path):
+    """Round 6: the batch-sized work of a policy round -- vertex expansion, the two gates of findTrajectory, the scan of
+    validateTrajectorySpatial (/root/reference/src/mrs_trajectory_generation.cpp:923-977, 1138-1149, 1178-1199, 1401-1455) -- runs on
+    the device (mrs_tg_policy_dev.hip) from 64 active requests on; MRS_TG_POLICY_DEVICE=0 (read once per process: a child process)
+    keeps it on the policy's host threads as until round 5, MRS_TG_POLICY_DEVICE=1 sends single requests there too.  Same decisions, same deviations, same samples: bit for bit on every request (the arithmetic
+    of the scan is the host's, operation by operation).  Rows of the caller's sample array beyond a request's n_samples are not
+    compared: the host route leaves earlier rounds' longer trajectories there, the device route brings down the final one only."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = _many_requests(gpu_ctx)
+    ref_path = str(tmp_path / "host_rounds.npz")
+    subprocess.run([sys.executable, "-c", POLICY_CHILD % root, ref_path], check=True, cwd=root, timeout=600,
+                   env=dict(os.environ, MRS_TG_POLICY_DEVICE="0"))
+    ref = np.load(ref_path)
+    for k in ("success", "n_samples", "n_waypoints", "iterations", "max_deviation"):
+        assert np.array_equal(out[k], ref[k]), k
+    for p in range(out["success"].size):
+        n = int(out["n_samples"][p])
+        assert np.array_equal(out["samples"][p, :n], ref["samples"][p, :n]), p
+    assert out["success"].mean() > 0.98 and out["iterations"].max() >= 3
