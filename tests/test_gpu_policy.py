@@ -174,3 +174,55 @@ def test_device_rounds_give_the_bits_of_the_host_rounds(gpu_ctx, tmp_path):
         n = int(out["n_samples"][p])
         assert np.array_equal(out["samples"][p, :n], ref["samples"][p, :n]), p
     assert out["success"].mean() > 0.98 and out["iterations"].max() >= 3
+
+
+DEVICE_ROUTE_CHILD = r"""
+import sys
+sys.path.insert(0, %r)
+import numpy as np
+from mrs_uav_trajectory_generation_amd import api
+from tests.test_gpu_policy import _mixed_requests
+ctx = api.Context(0)
+np.savez(sys.argv[1], **_mixed_requests(ctx))
+"""
+
+
+def _mixed_requests(ctx):
+    """40 requests with everything a vertex can carry: stop_at waypoints, moving initial states, relaxed headings, per-request limits,
+    and under min-snap as well as the default min-acceleration -- two calls, results concatenated"""
+    paths = _paths(40, 900, pr.random_box_waypoints)
+    stops = [[(i % 3 == 1) for i in range(len(p))] for p in paths]
+    inits = [dict(heading=p[0, 3] + 0.4, velocity=[0.2, 0.1, -0.1, 0.05], acceleration=[0.1, 0.0, 0.05, 0.0], jerk=[0.0, 0.02, 0.0, 0.0])
+             if k % 2 == 0 else None for k, p in enumerate(paths)]
+    relax = np.array([k % 3 == 0 for k in range(len(paths))], dtype=np.uint8)
+    lim = np.stack([pr.DEFAULT_LIMITS * (0.7 + 0.1 * (k % 5)) for k in range(len(paths))])
+    out = {}
+    for d in (2, 4):
+        pol = api.default_policy_options(solver=dict(derivative_to_optimize=d))
+        r = api.optimize_paths(ctx, paths, limits=lim, stop_flags=stops, initial_states=inits, relax_heading=relax, policy=pol,
+                               sample_capacity=2048)
+        for k, v in r.items():
+            out["%s_d%d" % (k, d)] = v
+    return out
+
+
+def test_device_route_on_small_batches_with_initial_states_stop_at_and_relaxed_headings(gpu_ctx, tmp_path):
+    """MRS_TG_POLICY_DEVICE=1 sends every round to the device route, whatever its size (the default keeps fewer than 64 active
+    requests on the host route): policy_expand_kernel with moving initial states, stop_at flags, relaxed heading limits and
+    per-request limits, d = 2 and 4 -- the same bits as the host route of this process, and the oracle's decisions."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = _mixed_requests(gpu_ctx)          # 40 requests: the host route
+    ref_path = str(tmp_path / "device_route.npz")
+    subprocess.run([sys.executable, "-c", DEVICE_ROUTE_CHILD % root, ref_path], check=True, cwd=root, timeout=600,
+                   env=dict(os.environ, MRS_TG_POLICY_DEVICE="1"))
+    dev = np.load(ref_path)
+    for d in (2, 4):
+        for k in ("success", "n_samples", "n_waypoints", "iterations", "max_deviation"):
+            assert np.array_equal(out["%s_d%d" % (k, d)], dev["%s_d%d" % (k, d)]), (k, d)
+        for p in range(40):
+            n = int(out["n_samples_d%d" % d][p])
+            assert np.array_equal(out["samples_d%d" % d][p, :n], dev["samples_d%d" % d][p, :n]), (p, d)
+        assert out["success_d%d" % d].sum() >= 36
