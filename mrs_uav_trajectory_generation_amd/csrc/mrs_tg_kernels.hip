@@ -62,15 +62,30 @@ __device__ __forceinline__ void mapping_inverse_row(double T, int a, double (&ar
   for (int c = 0; c < kN; ++c) arow[c] = c_abar_inv[a][c] * w[c % kHalf] * tia;
 }
 
+// The blocks leave as STREAMING stores (round 6): 1 600 bytes per segment that the kernel itself never reads again.  Marked
+// non-temporal, a 16.5 MB launch takes 5.3 instead of 5.9 us (0.385 instead of 0.35 of the HBM peak), a 1.05 GB launch 154-157
+// instead of 161-165 us (0.84-0.85); the step that solves from the blocks right behind it finds fewer of them in the L2 and is
+// 0.5 us slower (12.7-13.5 -> 13.1-14.0 us per 1024 x 10 step).  -DMRS_TG_ASSEMBLE_NT=0: ordinary stores, as until round 5.
+#ifndef MRS_TG_ASSEMBLE_NT
+#define MRS_TG_ASSEMBLE_NT 1
+#endif
 __device__ __forceinline__ void store_block_rows(double T, int d, int a, size_t base, size_t P, double* __restrict__ Hout,
                                                  double* __restrict__ Aout) {
   double row[kN];
   hessian_row(T, d, a, row);
+#if MRS_TG_ASSEMBLE_NT
+#pragma unroll
+  for (int c = 0; c < kN; ++c) __builtin_nontemporal_store(row[c], &Hout[base + (size_t)c * P]);
+  mapping_inverse_row(T, a, row);
+#pragma unroll
+  for (int c = 0; c < kN; ++c) __builtin_nontemporal_store(row[c], &Aout[base + (size_t)c * P]);
+#else
 #pragma unroll
   for (int c = 0; c < kN; ++c) Hout[base + (size_t)c * P] = row[c];
   mapping_inverse_row(T, a, row);
 #pragma unroll
   for (int c = 0; c < kN; ++c) Aout[base + (size_t)c * P] = row[c];
+#endif
 }
 
 // general (ragged) batches: slot j holds the first slot_start[j+1] - slot_start[j] positions of the
@@ -237,6 +252,9 @@ __global__ __launch_bounds__(64) void sample_kernel(BatchView b, const double* _
 // next one, and the slot the one after next is written to when the walk moves on).  With all S segments of every path staged
 // (26 KB per wavefront of eight 10-segment paths) a CU held six wavefronts and the SIMDs waited 62 % of their cycles
 // (profiles/round6_pmc_sampler.txt); the ring is 1 KB per path whatever its length.
+#ifndef MRS_TG_SAMPLE_EXP
+#define MRS_TG_SAMPLE_EXP 0   // experiment builds of the group sampler (python -m ...build --variant NAME -DMRS_TG_SAMPLE_EXP=n)
+#endif
 constexpr int kRingSlots = 3;
 __host__ __device__ constexpr int sample_group_ring_stride() { return kRingSlots * kD * kN + 10; }  // 130 doubles: 2 (mod 32), bank spread
 
@@ -316,9 +334,9 @@ __global__ __launch_bounds__(64, 4) void sample_group_kernel(BatchView b, const 
   request(i + 1);
   deposit(i + 1);
   request(i + 2);
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
   __builtin_amdgcn_wave_barrier();
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
   double dt_r[G];
 #pragma unroll
   for (int r = 1; r < G; ++r) dt_r[r] = (j >= r) ? dt : 0.0;
@@ -342,9 +360,9 @@ __global__ __launch_bounds__(64, 4) void sample_group_kernel(BatchView b, const 
           request(i + 2);
         }
       }
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-      __builtin_amdgcn_wave_barrier();
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");   // (LDS only: over every address space the fence
+      __builtin_amdgcn_wave_barrier();                                    //  waits for the previous step's sample stores as well)
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
     }
     if (__ballot(!done) == 0ull) break;
     // lane j adds dt j times (the addends dt_r = j >= r ? dt : +0.0 are set up once: x + 0.0 is x, bit for bit, for x >= 0)
@@ -363,22 +381,43 @@ __global__ __launch_bounds__(64, 4) void sample_group_kernel(BatchView b, const 
         double v[kD];
 #pragma unroll
         for (int dd = 0; dd < kD; ++dd) {
+#if MRS_TG_SAMPLE_EXP == 2   // experiment: no evaluation (no LDS coefficient reads, no Horner): the walk and the stores only
+          v[dd] = tj + (double)dd;
+          (void)c;
+#else
           double accv = falling_factorial(kN - 1, k) * c[dd * kN + kN - 1];
 #pragma unroll
           for (int jj = kN - 2; jj >= k; --jj) accv = accv * tj + falling_factorial(jj, k) * c[dd * kN + jj];
           v[dd] = accv;
+#endif
         }
         if (k == 0) v[3] = wrap_heading(v[3]);
+#if MRS_TG_SAMPLE_EXP == 1   // experiment: the samples are computed and not stored
 #pragma unroll
-        for (int dd = 0; dd < kD; ++dd) o[k * kD + dd] = v[dd];
+        for (int dd = 0; dd < kD; ++dd) asm volatile("" ::"v"(v[dd]));
+        (void)o;
+#else
+        {  // (streaming stores, as sample_kernel's: mrs_tg_sampling.hpp)
+          typedef double sample_pair __attribute__((ext_vector_type(2)));
+          sample_pair* o2 = reinterpret_cast<sample_pair*>(o + k * kD);
+          sample_pair lo, hi;
+          lo.x = v[0], lo.y = v[1], hi.x = v[2], hi.y = v[3];
+          __builtin_nontemporal_store(lo, o2);
+          __builtin_nontemporal_store(hi, o2 + 1);
+        }
+#endif
       }
     }
     if (!done) {
+#if MRS_TG_SAMPLE_EXP == 3   // experiment: no cross-lane exchange (a wrong walk: every step advances by G samples' worth of time)
+      tin = tin + (double)(m > 0 ? m : 1) * dt;
+#else
       if (m == G) {  // every lane emitted: the step ran out before the walk stopped
         tin = group_lane_value<G>(tj, base, G - 1) + dt;
       } else {       // lane m is the first that did not emit: its value is the walk's state at the stop
         tin = group_lane_value<G>(tj, base, m);
       }
+#endif
       n += m;
       if (n > capacity) done = true;  // overflow: reported as capacity + 1
     }

@@ -7,6 +7,10 @@
 #pragma once
 #include "mrs_tg_device.hpp"
 
+#ifndef MRS_TG_SAMPLE_EXP
+#define MRS_TG_SAMPLE_EXP 0   // experiment builds of the samplers (python -m ...build --variant NAME -DMRS_TG_SAMPLE_EXP=n; HISTORY.md)
+#endif
+
 namespace mrs_tg {
 
 __device__ __forceinline__ double wrap_heading(double y) {
@@ -108,14 +112,36 @@ __device__ __forceinline__ int sample_path_walk(const double* s_T, const double*
         double v[kD];
 #pragma unroll
         for (int dd = 0; dd < kD; ++dd) {
+#if MRS_TG_SAMPLE_EXP == 12   // experiment: no evaluation (no coefficient reads, no Horner)
+          v[dd] = tj + (double)dd;
+          (void)c;
+#else
           double accv = falling_factorial(kN - 1, k) * c[dd * kN + kN - 1];
 #pragma unroll
           for (int j = kN - 2; j >= k; --j) accv = accv * tj + falling_factorial(j, k) * c[dd * kN + j];
           v[dd] = accv;
+#endif
         }
         if (k == 0) v[3] = wrap_heading(v[3]);
+#if MRS_TG_SAMPLE_EXP == 11   // experiment: the samples are computed and not stored
+#pragma unroll
+        for (int dd = 0; dd < kD; ++dd) asm volatile("" ::"v"(v[dd]));
+#elif MRS_TG_SAMPLE_EXP == 14  // experiment: ordinary (cached) stores, as until round 5
 #pragma unroll
         for (int dd = 0; dd < kD; ++dd) out[((size_t)e * (NDER + 1) + k) * kD + dd] = v[dd];
+#else
+        // STREAMING stores (round 6): the samples are written once and read by nobody on the device; as ordinary stores they
+        // went through the L2 like data that will be used again -- 65536 x 10: 327 -> 275 us with the stores marked
+        // non-temporal, 8192 x 10 46.4 -> 44.4 (profiles/round6_sampler_experiments.txt)
+        {
+          typedef double sample_pair __attribute__((ext_vector_type(2)));
+          sample_pair* o2 = reinterpret_cast<sample_pair*>(out + ((size_t)e * (NDER + 1) + k) * kD);
+          sample_pair lo, hi;
+          lo.x = v[0], lo.y = v[1], hi.x = v[2], hi.y = v[3];
+          __builtin_nontemporal_store(lo, o2);
+          __builtin_nontemporal_store(hi, o2 + 1);
+        }
+#endif
       }
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
