@@ -84,6 +84,24 @@ __device__ __forceinline__ void quad_powers(double T, bool d1, bool d2, bool d4,
   p2[8] = p2[4] * t4;
 }
 
+// a pair of coefficients (16 bytes).  MRS_TG_COEFF_NT=1 (experiment build): as a streaming store -- measured in round 6 after
+// the samples and the assembled blocks had gained from it: here it is 2.5-3 x SLOWER (headline dispatch 26 -> 73-81 us, 65536 x 10
+// 131 -> 335-339 us): a lane owns 80 consecutive bytes, so a store instruction writes 64 separate 16-byte pieces, and without the
+// L2 to combine them every piece is a partial-line write to HBM.  Streaming pays where an instruction writes whole lines.
+#ifndef MRS_TG_COEFF_NT
+#define MRS_TG_COEFF_NT 0
+#endif
+__device__ __forceinline__ void store_coeff_pair(double2* dst, double a, double b) {
+#if MRS_TG_COEFF_NT
+  typedef double coeff_pair __attribute__((ext_vector_type(2)));
+  coeff_pair v;
+  v.x = a, v.y = b;
+  __builtin_nontemporal_store(v, reinterpret_cast<coeff_pair*>(dst));
+#else
+  *dst = make_double2(a, b);
+#endif
+}
+
 __device__ __forceinline__ void quad_wave_sync() {
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
   __builtin_amdgcn_wave_barrier();
@@ -567,7 +585,7 @@ __device__ __forceinline__ void solve_quad_body(const BatchView& b, int d, const
         }
 #else
 #pragma unroll
-        for (int k = 0; k < kN; k += 2) out[k / 2] = make_double2(c[k], c[k + 1]);
+        for (int k = 0; k < kN; k += 2) store_coeff_pair(out + k / 2, c[k], c[k + 1]);
 #endif
       }
 #if MRS_TG_QUAD_EXP == 5
@@ -980,7 +998,7 @@ __device__ __forceinline__ void solve_duo_body(const BatchView& b, int d, const 
         my_cost = fma(cost_quadratic_form_d(d, cb), p2[0], my_cost);
         double2* out = reinterpret_cast<double2*>(coeffs + ((size_t)(pr.s0 + oseg(v)) * kD + dim) * kN);
 #pragma unroll
-        for (int k = 0; k < kN; k += 2) out[k / 2] = make_double2(c[k], c[k + 1]);
+        for (int k = 0; k < kN; k += 2) store_coeff_pair(out + k / 2, c[k], c[k + 1]);
       }
       if (on) {  // (a side shorter than the wavefront's longest joins late: until then xn is the middle vertex's solution)
 #pragma unroll
