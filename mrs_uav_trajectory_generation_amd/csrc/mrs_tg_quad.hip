@@ -657,6 +657,13 @@ __host__ __device__ constexpr size_t duo_lds_doubles(int Smax) {
   return (size_t)(Smax > 1 ? Smax - 1 : 1) * kQdRec * kDuoPaths + (size_t)Smax * kDuoPaths;  // records | times
 }
 
+#ifdef MRS_TG_DUO_STAMPS  // experiment builds (build.py --variant): the shader clock at the phase boundaries of each wavefront
+__device__ unsigned long long g_duo_stamps[2048 * 8];
+#define DUO_STAMP(k) (duo_stamp[k] = __builtin_readcyclecounter())
+#else
+#define DUO_STAMP(k)
+#endif
+
 template <bool WP, bool MOVING = false>
 __device__ __forceinline__ void solve_duo_body(const BatchView& b, int d, const uint8_t* __restrict__ mask,
                                                const double* __restrict__ vals, const double* seg_times,
@@ -672,6 +679,10 @@ __device__ __forceinline__ void solve_duo_body(const BatchView& b, int d, const 
   const int Smax = b.max_segments;
   double* rec0 = lds;
   double* tbuf = lds + (size_t)(Smax > 1 ? Smax - 1 : 1) * kQdRec * kDuoPaths;  // [segment][path]
+#ifdef MRS_TG_DUO_STAMPS
+  unsigned long long duo_stamp[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#endif
+  DUO_STAMP(0);
   // ---- prologue: times (scaled, for the last solve of a Mellinger pipeline), plainness of the path
   const bool scaling = tail.maxima != nullptr;
   double t_sum = 0.0;
@@ -723,6 +734,7 @@ __device__ __forceinline__ void solve_duo_body(const BatchView& b, int d, const 
   const unsigned long long pos_bad = __ballot(active && !pos_ok);
   const bool path_pos_ok = ((pos_bad >> (lane & ~7)) & 0xFFull) == 0ull;
   quad_wave_sync();
+  DUO_STAMP(1);
 
   double my_cost = 0.0;
   if (plain_wave) {
@@ -865,7 +877,11 @@ __device__ __forceinline__ void solve_duo_body(const BatchView& b, int d, const 
       p_nxt = p_a2;
       p_a2 = p_a3;
       p_a3 = p_a4;
+#ifdef MRS_TG_DUO_STAMPS
+      if (i == 0) DUO_STAMP(2);
+#endif
     }
+    DUO_STAMP(3);
     // ---- the join: the middle vertex's block and right-hand side are this side's part plus the other side's, which arrives in
     // the other orientation: D S D and D y with D = diag(-1, +1, -1, +1) -- exact sign flips, so both sides solve the same
     // system and x~ = D x bit for bit
@@ -910,6 +926,7 @@ __device__ __forceinline__ void solve_duo_body(const BatchView& b, int d, const 
       xn[0] = fma(-L[tri(3, 0)], xn[3], fma(-L[tri(2, 0)], xn[2], fma(-L[tri(1, 0)], xn[1], z[0]))) * Linv[0];
     }
     quad_wave_sync();  // (lane 0 of a side wrote L for the other three)
+    DUO_STAMP(4);
     // ---- backward through this side's half: x_v = L^-T (z - W x_{v+1}); coefficients and cost of local segment v
     double p_end = pos(M), p_b0 = pos(Mmx - 1), p_b1 = pos(Mmx - 2), p_b2 = pos(Mmx - 3);
     for (int v = Mmx - 1; v >= 0; --v) {
@@ -1006,6 +1023,7 @@ __device__ __forceinline__ void solve_duo_body(const BatchView& b, int d, const 
         p_end = p_start;
       }
     }
+    DUO_STAMP(5);
   } else if (active && side == 0) {
     // ---- any other constraint pattern: the general masked step on the four lanes of side 0, factors in the plan's workspace
     bool pok = true;
@@ -1025,7 +1043,20 @@ __device__ __forceinline__ void solve_duo_body(const BatchView& b, int d, const 
       status[pr.p] = st;
     }
   }
+#ifdef MRS_TG_DUO_STAMPS
+  DUO_STAMP(6);
+  __builtin_amdgcn_s_waitcnt(0);  // (every store acknowledged)
+  DUO_STAMP(7);
+  if (lane == 0 && blockIdx.x < 2048)
+    for (int k = 0; k < 8; ++k) g_duo_stamps[blockIdx.x * 8 + k] = duo_stamp[k];
+#endif
 }
+
+#ifdef MRS_TG_DUO_STAMPS
+extern "C" int mrs_tg_debug_duo_stamps(unsigned long long* out) {
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_duo_stamps), sizeof(unsigned long long) * 2048 * 8);
+}
+#endif
 
 template <bool WP>
 __global__ __launch_bounds__(64, MRS_TG_QUAD_WAVES) void solve_duo_kernel(BatchView b, int d, const uint8_t* __restrict__ mask,

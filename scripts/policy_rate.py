@@ -38,7 +38,7 @@ def main():
             reps = 3 if n >= 1024 else 10
             t = time.perf_counter()
             for _ in range(reps):
-                out = api.optimize_paths(ctx, paths, sample_capacity=cap)
+                out = api.optimize_paths(ctx, paths, sample_capacity=cap, out=out)   # (a server's loop: the response arrays stay)
             dt = (time.perf_counter() - t) / reps
             print("%-4s %5d requests: %9.3f ms per call, %8.1f us per request, %9.0f requests/s | success %d, rounds mean %.2f max %d, "
                   "waypoints in %.1f -> out %.1f, samples mean %.0f" % (

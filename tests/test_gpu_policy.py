@@ -85,9 +85,8 @@ def test_waypoint_trajectory_idxs(gpu_ctx):
     out = api.optimize_paths(gpu_ctx, [wp], sample_capacity=2048)
     n = int(out["n_samples"][0])
     smp = np.ascontiguousarray(out["samples"][0, :n])
-    arr, _ = api._waypoint_array([wp])
-    idx = np.zeros(16, dtype=np.int32)
-    k = gpu_ctx._L.mrs_tg_waypoint_trajectory_idxs(api._np_ptr(smp), n, arr, wp.shape[0], api._np_ptr(idx))
+    idx = api.waypoint_trajectory_idxs(smp, wp)
+    k = len(idx)
     ref = np.zeros(16, dtype=np.int32)
     kr = po.lib().mto_waypoint_trajectory_idxs(po._dp(smp), n, po._dp(np.ascontiguousarray(wp)), wp.shape[0],
                                                ref.ctypes.data_as(C.POINTER(C.c_int32)))

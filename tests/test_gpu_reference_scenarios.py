@@ -47,11 +47,7 @@ def check_waypoint_idxs(idxs, path):
 
 
 def _waypoint_idxs(ctx, samples, path):
-    arr, _ = api._waypoint_array([path])
-    idx = np.zeros(len(path) + 4, dtype=np.int32)
-    smp = np.ascontiguousarray(samples)
-    k = ctx._L.mrs_tg_waypoint_trajectory_idxs(api._np_ptr(smp), smp.shape[0], arr, len(path), api._np_ptr(idx))
-    return idx[:k].tolist()
+    return api.waypoint_trajectory_idxs(samples, path).tolist()
 
 
 # the UAV hovers at the take-off spot when the service is called; the nodelet prepends that state (:2095-2110)
