@@ -49,6 +49,14 @@
 #ifndef MRS_TG_QUAD_GROUP_WAVES
 #define MRS_TG_QUAD_GROUP_WAVES 2
 #endif
+// The two-sided group kernel: two as well.  Three (168 registers: the plain path fits, the general step spills) keep both
+// dispatches of the headline's timed region resident at once -- and lose: 25.9 us per dispatch against 24.4, the region 67-69 us
+// against 63 (same box, alternating runs).  One wavefront of this kernel keeps its SIMD's FP64 pipe about half busy (an FMA on
+// three vector registers issues every 8.7 clocks from one wavefront, every 4.4 from two: profiles/round6_issue_latencies.txt),
+// so a third one only adds contention.
+#ifndef MRS_TG_DUO_GROUP_WAVES
+#define MRS_TG_DUO_GROUP_WAVES 2
+#endif
 
 namespace mrs_tg {
 
@@ -654,15 +662,61 @@ __device__ __forceinline__ void solve_quad_body(const BatchView& b, int d, const
 constexpr int kDuoPaths = 8;  // paths per wavefront
 
 __host__ __device__ constexpr size_t duo_lds_doubles(int Smax) {
-  return (size_t)(Smax > 1 ? Smax - 1 : 1) * kQdRec * kDuoPaths + (size_t)Smax * kDuoPaths;  // records | times
+  return (size_t)(Smax > 1 ? Smax - 1 : 1) * kQdRec * kDuoPaths + (size_t)Smax * kDuoPaths +  // records | times
+         (size_t)(Smax + 1) * kD * kDuoPaths + kDuoPaths / 2;                                   // | position constraints | path indices
 }
 
 #ifdef MRS_TG_DUO_STAMPS  // experiment builds (build.py --variant): the shader clock at the phase boundaries of each wavefront
-__device__ unsigned long long g_duo_stamps[2048 * 8];
+__device__ unsigned long long g_duo_stamps[2048 * 16];
 #define DUO_STAMP(k) (duo_stamp[k] = __builtin_readcyclecounter())
 #else
 #define DUO_STAMP(k)
 #endif
+
+// The lane's index, formed where it is needed: under a register budget of three wavefronts per SIMD the compiler spills the
+// values it derived from threadIdx.x in the prologue (the path's slot, the side, the dimension, LDS byte offsets) to scratch and
+// reloads them inside the elimination loops -- vector-memory loads, which on gfx950 wait for the coefficient stores in flight
+// (one counter for both).  Two instructions here instead; valid while all 64 lanes are enabled (wave-uniform control flow).
+// (TAG: two statements with different tags are different instructions to the compiler, which therefore cannot merge the tails
+// of two branches that end in them -- see duo_finish)
+template <int TAG = 0>
+__device__ __forceinline__ int lane_now() {
+  int l;
+  asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0 ; %1" : "=v"(l) : "i"(TAG));
+  return l;
+}
+
+// the value of lane ^ 4 (the other side of the same path and dimension): ds_swizzle in bit-mask mode, no address register
+__device__ __forceinline__ double xor4(double v) {
+  constexpr int kSwap4 = (4 << 10) | 0x1F;  // and 0x1f, or 0, xor 4
+  const unsigned long long u = __builtin_bit_cast(unsigned long long, v);
+  const unsigned lo = (unsigned)__builtin_amdgcn_ds_swizzle((int)(unsigned)u, kSwap4);
+  const unsigned hi = (unsigned)__builtin_amdgcn_ds_swizzle((int)(unsigned)(u >> 32), kSwap4);
+  return __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
+}
+
+// The epilogue of solve_duo_body: cost and status of the eight paths.  Written once per branch (TAG) instead of once behind
+// both: behind the merge the compiler has to assume the general step's loads in flight and waits -- on gfx950 for all but the
+// last few of the plain path's coefficient STORES as well (one counter), a store's round trip before the last two stores go out.
+template <int TAG>
+__device__ __forceinline__ void duo_finish(double my_cost, bool active, unsigned long long pos_bad, const int* pidx,
+                                           double* __restrict__ cost, int32_t* __restrict__ status,
+                                           const int32_t* __restrict__ status_in, const RowsTail& tail, double t_sum) {
+  my_cost = quad_sum(my_cost);
+  my_cost += xor4(my_cost);
+  const int lane_late = lane_now<TAG + 1>();  // (the slot's address is formed HERE, not carried -- and spilled -- from the prologue)
+  if (active && (lane_late & 7) == 0) {
+    const bool path_pos_ok = ((pos_bad >> (lane_late & ~7)) & 0xFFull) == 0ull;
+    const int p_out = pidx[lane_late >> 3];
+    if (cost) cost[p_out] = my_cost;
+    if (status) {
+      int st = merge_status(path_pos_ok, status_in, p_out);
+      if (tail.sum_t0 != nullptr && st > 0 && t_sum > MRS_TG_RUNAWAY_TIME_FACTOR * tail.sum_t0[p_out]) st = MRS_TG_STATUS_ROUNDOFF_LIMITED;
+      status[p_out] = st;
+      asm volatile("; epilogue %0" ::"i"(TAG));  // (keeps the two copies' tails apart: see above)
+    }
+  }
+}
 
 template <bool WP, bool MOVING = false>
 __device__ __forceinline__ void solve_duo_body(const BatchView& b, int d, const uint8_t* __restrict__ mask,
@@ -680,61 +734,117 @@ __device__ __forceinline__ void solve_duo_body(const BatchView& b, int d, const 
   double* rec0 = lds;
   double* tbuf = lds + (size_t)(Smax > 1 ? Smax - 1 : 1) * kQdRec * kDuoPaths;  // [segment][path]
 #ifdef MRS_TG_DUO_STAMPS
-  unsigned long long duo_stamp[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  unsigned long long duo_stamp[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 #endif
   DUO_STAMP(0);
-  // ---- prologue: times (scaled, for the last solve of a Mellinger pipeline), plainness of the path
+  // ---- prologue: times (scaled, for the last solve of a Mellinger pipeline), plainness of the path, the position constraints
+  // into LDS.  Every global load of the kernel is issued HERE, in one round (branch-free, indices clamped into the path): on
+  // gfx950 loads and stores share one in-order counter (vmcnt), so a load inside the elimination loops makes each iteration
+  // wait until the previous iteration's coefficient stores are acknowledged -- measured with the phase clocks of
+  // -DMRS_TG_DUO_STAMPS: 3500 clocks per backward step, of which the arithmetic is a third (HISTORY.md, round 6).
   const bool scaling = tail.maxima != nullptr;
+  double* pbuf = tbuf + (size_t)Smax * kDuoPaths;  // [vertex][dimension][path]
+  int* pidx = reinterpret_cast<int*>(pbuf + (size_t)(Smax + 1) * kD * kDuoPaths);  // the paths' indices, for the epilogue: a register
+  if (l8 == 0) pidx[pl] = pr.p;                                                     // held that long is spilled to scratch, and the
+                                                                                    // reload is a vector-memory load (see above)
+  DUO_STAMP(1);
+  const double* pbase = WP ? pos_wp + (size_t)pr.v0 * kD : vals + (size_t)pr.v0 * kHalf * kD;
+  constexpr int pstride = WP ? kD : kHalf * kD;
+  const int n_pos = (S + 1) * kD;
   double t_sum = 0.0;
   bool ok = S >= 2, pos_ok = true;
   bool moving_path = false;
-  if (active) {
-    const int opt_st = scaling ? tail.opt_status[pr.p] : 0;
-    for (int i = l8; i < S; i += 8) {
-      double T = seg_times[pr.s0 + i];
-      if (scaling) {  // scaleSegmentTimesToMeetConstraints (trajectory.cpp:625-657), then the solve at the scaled times
-        if (opt_st != -2) T *= violation_scaling(tail.maxima + (size_t)(pr.s0 + i) * 9, tail.limits + (size_t)pr.p * 9);
-        tail.seg_times_out[pr.s0 + i] = T;
-      }
-      tbuf[i * kDuoPaths + pl] = T;
-      t_sum += T;
-    }
-    for (int v = l8; v <= S; v += 8) {
-      const uint8_t* mrow = mask + (size_t)(pr.v0 + v) * kHalf;
-      const bool end = v == 0 || v == S;
-      unsigned fixed = 0;
+  auto mask_bits = [&](int v) {
+    const uint8_t* mrow = mask + (size_t)(pr.v0 + v) * kHalf;
+    unsigned fixed = 0;
 #pragma unroll
-      for (int k = 0; k < kHalf; ++k) fixed |= (mrow[k] != 0 ? 1u : 0u) << k;
-      pos_ok = pos_ok && (fixed & 1u);
-      if (end) {
-        const double* vrow = vals + (size_t)(pr.v0 + v) * kHalf * kD;
-        double nz = 0.0;
-        double av[kHalf * kD];
+    for (int k = 0; k < kHalf; ++k) fixed |= (mrow[k] != 0 ? 1u : 0u) << k;
+    return fixed;
+  };
+  // the end vertices: even lanes of the eight read the start vertex's mask and constrained values, odd lanes the end vertex's
+  // (lanes 0 and 1 decide)
+  const int v_end = (l8 & 1) ? S : 0;
+  const unsigned f_end = mask_bits(v_end);
+  double av[kHalf * kD];
+  {
+    const double* vrow = vals + (size_t)(pr.v0 + v_end) * kHalf * kD;
 #pragma unroll
-        for (int e = kD; e < kHalf * kD; ++e) av[e] = fabs(vrow[e]);  // (loaded unconditionally: see solve_quad_body)
-#pragma unroll
-        for (int k = 1; k < kHalf; ++k)
-#pragma unroll
-          for (int e = 0; e < kD; ++e) nz += ((fixed >> k) & 1u) ? av[k * kD + e] : 0.0;
-        if (MOVING && v == 0) {
-          moving_path = nz != 0.0;
-          nz = 0.0;
-        }
-        ok = ok && fixed == 0x1Fu && nz == 0.0;
-      } else {
-        ok = ok && fixed == 0x1u;
-      }
-    }
+    for (int e = kD; e < kHalf * kD; ++e) av[e] = fabs(vrow[e]);
   }
+  const int opt_st = (scaling && active) ? tail.opt_status[pr.p] : 0;
+  auto trip = [&](int base) {               // sixteen segments and vertices of every path: two of each per lane
+    const int ia = base + l8, ib = ia + 8;
+    double Ta = seg_times[pr.s0 + min(ia, S - 1)], Tb = seg_times[pr.s0 + min(ib, S - 1)];
+    const unsigned fa = mask_bits(min(ia, S)), fb = mask_bits(min(ib, S));
+    double pe[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const int ic = min(base * kD + k * 8 + l8, n_pos - 1);
+      pe[k] = pbase[(size_t)(ic >> 2) * pstride + (ic & 3)];
+    }
+#ifdef MRS_TG_DUO_STAMPS
+    if (base == 0) DUO_STAMP(13);
+#endif
+    if (active) {
+      if (scaling) {  // scaleSegmentTimesToMeetConstraints (trajectory.cpp:625-657), then the solve at the scaled times
+        if (ia < S) {
+          if (opt_st != -2) Ta *= violation_scaling(tail.maxima + (size_t)(pr.s0 + ia) * 9, tail.limits + (size_t)pr.p * 9);
+          tail.seg_times_out[pr.s0 + ia] = Ta;
+        }
+        if (ib < S) {
+          if (opt_st != -2) Tb *= violation_scaling(tail.maxima + (size_t)(pr.s0 + ib) * 9, tail.limits + (size_t)pr.p * 9);
+          tail.seg_times_out[pr.s0 + ib] = Tb;
+        }
+      }
+      if (ia < S) {
+        tbuf[ia * kDuoPaths + pl] = Ta;
+        t_sum += Ta;
+      }
+      if (ib < S) {
+        tbuf[ib * kDuoPaths + pl] = Tb;
+        t_sum += Tb;
+      }
+      if (ia >= 1 && ia < S) {  // interior vertices: the position, nothing else
+        ok = ok && fa == 0x1u;
+        pos_ok = pos_ok && (fa & 1u);
+      }
+      if (ib < S) {
+        ok = ok && fb == 0x1u;
+        pos_ok = pos_ok && (fb & 1u);
+      }
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const int idx = base * kD + k * 8 + l8;
+        if (idx < n_pos) pbuf[idx * kDuoPaths + pl] = pe[k];
+      }
+    }
+  };
+  // (the first trip is straight-line code -- all there is for paths of up to 15 segments: inside a loop the compiler has to
+  // assume loads of the previous trip in flight and waits for the end vertices' values before it issues the positions' loads)
+  trip(0);
+  for (int base = 16; base <= Smax; base += 16) trip(base);
+  if (active && l8 < 2) {  // the end vertices: fully constrained, at rest (MOVING: the start vertex may be in motion)
+    double nz = 0.0;
+#pragma unroll
+    for (int k = 1; k < kHalf; ++k)
+#pragma unroll
+      for (int e = 0; e < kD; ++e) nz += ((f_end >> k) & 1u) ? av[k * kD + e] : 0.0;
+    if (MOVING && l8 == 0) {
+      moving_path = nz != 0.0;
+      nz = 0.0;
+    }
+    ok = ok && f_end == 0x1Fu && nz == 0.0;
+    pos_ok = pos_ok && (f_end & 1u);
+  }
+  DUO_STAMP(2);
   t_sum = quad_sum(t_sum);
-  t_sum += __shfl_xor(t_sum, 4, 64);
+  t_sum += xor4(t_sum);
   const bool any_moving = MOVING && __ballot(active && moving_path) != 0ull;
   if (any_moving) moving_path = __shfl((int)moving_path, lane & ~7, 64) != 0 && side == 0;  // (vertex 0 was read by lane 0 of the eight)
   const bool plain_wave = __ballot(active && !ok) == 0ull;
   const unsigned long long pos_bad = __ballot(active && !pos_ok);
-  const bool path_pos_ok = ((pos_bad >> (lane & ~7)) & 0xFFull) == 0ull;
   quad_wave_sync();
-  DUO_STAMP(1);
+  DUO_STAMP(3);
 
   double my_cost = 0.0;
   if (plain_wave) {
@@ -755,35 +865,43 @@ __device__ __forceinline__ void solve_duo_body(const BatchView& b, int d, const 
     const bool d1 = (d & 1) != 0, d2 = (d & 2) != 0, d4 = (d & 4) != 0;
     // this side's chain: local vertices 0 .. M (0: the path's end on this side, M: the middle vertex), local segments 0 .. M - 1
     const int m_mid = (S + 1) >> 1;
-    const int M = side ? S - m_mid : m_mid;
-    int Mmx;
-    {
-      int s = active ? M : 0;
-      for (int off = 32; off >= 4; off >>= 1) s = max(s, __shfl_xor(s, off, 64));
-      Mmx = __builtin_amdgcn_readfirstlane(s);
-    }
-    auto oseg = [&](int i) { return side ? S - 1 - i : i; };   // original index of local segment i
-    auto overt = [&](int v) { return side ? S - v : v; };      // original index of local vertex v
-    const double* pv = WP ? pos_wp + (size_t)pr.v0 * kD + dim : vals + (size_t)pr.v0 * kHalf * kD + dim;
-    constexpr size_t pstride = WP ? (size_t)kD : (size_t)(kHalf * kD);
-    auto pos = [&](int v) { return (active && v >= 0 && v <= M) ? pv[(size_t)overt(v) * pstride] : 0.0; };
+    // (wave-uniform trip count of both loops: the longest side the batch can hold -- a reduction over the wavefront's own paths
+    // costs four cross-lane exchanges and their waits; ragged batches are sorted by length, a wavefront's paths differ by little)
+    const int Mmx = (Smax + 1) >> 1;
+    const int m_mid_ = m_mid;
+    struct LaneIds { int pl, side, dim; };
+    auto ids_now = [&]() {  // (see lane_now)
+      const int l = lane_now();
+      return LaneIds{l >> 3, (l >> 2) & 1, l & 3};
+    };
+    auto oseg = [&](int sd, int i) { return sd ? S - 1 - i : i; };   // original index of local segment i
+    auto overt = [&](int sd, int v) { return sd ? S - v : v; };      // original index of local vertex v
+    auto side_len = [&](int sd) { return sd ? S - m_mid_ : m_mid_; };
+    auto pos = [&](const LaneIds& id, int v) {  // the position constraint of local vertex v (0 outside this side's chain)
+      const int Ms = side_len(id.side);
+      const int vc = min(max(v, 0), Ms);
+      const double r = pbuf[(overt(id.side, vc) * kD + id.dim) * kDuoPaths + id.pl];
+      return (active && v >= 0 && v <= Ms) ? r : 0.0;
+    };
     // ---- forward: this side's block Cholesky towards the middle
     double Sm[10], y[kNB];
 #pragma unroll
     for (int e = 0; e < 10; ++e) Sm[e] = 0.0;
 #pragma unroll
     for (int r = 0; r < kNB; ++r) y[r] = 0.0;
-    double p_cur = pos(0), p_nxt = pos(1), p_a2 = pos(2), p_a3 = pos(3);
+    double p_cur = pos(ids_now(), 0);
+    DUO_STAMP(4);
     for (int i = 0; i < Mmx; ++i) {
-      const bool on = active && i < M;
-      const double T = on ? tbuf[oseg(i) * kDuoPaths + pl] : 1.0;
-      const double p_a4 = pos(i + 4);
+      const LaneIds id = ids_now();
+      const bool on = active && i < side_len(id.side);
+      const double T = on ? tbuf[oseg(id.side, i) * kDuoPaths + id.pl] : 1.0;
+      const double p_nxt = pos(id, i + 1);
       double p2[9];
       quad_powers(T, d1, d2, d4, p2);
       const double dp = p_cur - p_nxt;
       double f0[kNB] = {0.0, 0.0, 0.0, 0.0};
       if (any_moving && i == 0 && active && moving_path) {  // (side 0 only: moving_path is false on side 1)
-        const double* vrow0 = vals + (size_t)pr.v0 * kHalf * kD + dim;
+        const double* vrow0 = vals + (size_t)pr.v0 * kHalf * kD + id.dim;
 #pragma unroll
         for (int r = 0; r < kNB; ++r) f0[r] = vrow0[(r + 1) * kD];
       }
@@ -832,8 +950,8 @@ __device__ __forceinline__ void solve_duo_body(const BatchView& b, int d, const 
             for (int mm = 0; mm < r; ++mm) t = fma(-L[tri(r, mm)], z[mm], t);
             z[r] = t * Linv[r];
           }
-          double* rec = rec0 + (size_t)(overt(i) - 1) * kQdRec * kDuoPaths + pl;
-          if (dim == 0) {
+          double* rec = rec0 + (size_t)(overt(id.side, i) - 1) * kQdRec * kDuoPaths + id.pl;
+          if (id.dim == 0) {
             rec[(kQdL + 0) * kDuoPaths] = L[tri(1, 0)];
             rec[(kQdL + 1) * kDuoPaths] = L[tri(2, 0)];
             rec[(kQdL + 2) * kDuoPaths] = L[tri(2, 1)];
@@ -844,7 +962,7 @@ __device__ __forceinline__ void solve_duo_body(const BatchView& b, int d, const 
             for (int r = 0; r < kNB; ++r) rec[(kQdLinv + r) * kDuoPaths] = Linv[r];
           }
 #pragma unroll
-          for (int r = 0; r < kNB; ++r) rec[(kQdZ + r * kD + dim) * kDuoPaths] = z[r];
+          for (int r = 0; r < kNB; ++r) rec[(kQdZ + r * kD + id.dim) * kDuoPaths] = z[r];
           // W = L^-1 E, then the Schur complement and right-hand side of local vertex i + 1 (always an unknown: the next one
           // of this side, or the middle vertex)
           double W[kNB][kNB];
@@ -874,14 +992,12 @@ __device__ __forceinline__ void solve_duo_body(const BatchView& b, int d, const 
         }
       }
       p_cur = p_nxt;
-      p_nxt = p_a2;
-      p_a2 = p_a3;
-      p_a3 = p_a4;
 #ifdef MRS_TG_DUO_STAMPS
-      if (i == 0) DUO_STAMP(2);
+      if (i == 0) DUO_STAMP(5);
+      if (i == 1) DUO_STAMP(6);
 #endif
     }
-    DUO_STAMP(3);
+    DUO_STAMP(7);
     // ---- the join: the middle vertex's block and right-hand side are this side's part plus the other side's, which arrives in
     // the other orientation: D S D and D y with D = diag(-1, +1, -1, +1) -- exact sign flips, so both sides solve the same
     // system and x~ = D x bit for bit
@@ -891,10 +1007,10 @@ __device__ __forceinline__ void solve_duo_body(const BatchView& b, int d, const 
       for (int r = 0; r < kNB; ++r) {
 #pragma unroll
         for (int c = 0; c <= r; ++c) {
-          const double other = __shfl_xor(Sm[tri(r, c)], 4, 64);
+          const double other = xor4(Sm[tri(r, c)]);
           Sm[tri(r, c)] += ((r + c) & 1) ? -other : other;
         }
-        const double oy = __shfl_xor(y[r], 4, 64);
+        const double oy = xor4(y[r]);
         y[r] += (r & 1) ? oy : -oy;   // slot r is derivative r + 1: odd derivatives (r = 0, 2) change sign
       }
       double L[10], Linv[kNB], z[kNB];
@@ -926,18 +1042,21 @@ __device__ __forceinline__ void solve_duo_body(const BatchView& b, int d, const 
       xn[0] = fma(-L[tri(3, 0)], xn[3], fma(-L[tri(2, 0)], xn[2], fma(-L[tri(1, 0)], xn[1], z[0]))) * Linv[0];
     }
     quad_wave_sync();  // (lane 0 of a side wrote L for the other three)
-    DUO_STAMP(4);
+    DUO_STAMP(8);
     // ---- backward through this side's half: x_v = L^-T (z - W x_{v+1}); coefficients and cost of local segment v
-    double p_end = pos(M), p_b0 = pos(Mmx - 1), p_b1 = pos(Mmx - 2), p_b2 = pos(Mmx - 3);
+    double p_end;
+    {
+      const LaneIds id = ids_now();
+      p_end = pos(id, side_len(id.side));
+    }
     for (int v = Mmx - 1; v >= 0; --v) {
-      const bool on = active && v < M;
+      const LaneIds id = ids_now();
+      const int side = id.side, dim = id.dim, pl = id.pl;  // (this iteration's: see lane_now)
+      const bool on = active && v < side_len(side);
       double x[kNB] = {0.0, 0.0, 0.0, 0.0};
-      const double p_start = p_b0;
-      p_b0 = p_b1;
-      p_b1 = p_b2;
-      p_b2 = pos(v - 3);
+      const double p_start = pos(id, v);
       if (on && v >= 1) {
-        const double* rec = rec0 + (size_t)(overt(v) - 1) * kQdRec * kDuoPaths + pl;
+        const double* rec = rec0 + (size_t)(overt(side, v) - 1) * kQdRec * kDuoPaths + pl;
         double t[kNB];
 #pragma unroll
         for (int r = 0; r < kNB; ++r) t[r] = rec[(kQdZ + r * kD + dim) * kDuoPaths];
@@ -947,7 +1066,7 @@ __device__ __forceinline__ void solve_duo_body(const BatchView& b, int d, const 
                      i3 = rec[(kQdLinv + 3) * kDuoPaths];
         {  // t = z - W x_{v+1},  W x = L^-1 (E x)  (local vertex v + 1 is an unknown for every v <= M - 1)
           double pw[9];
-          quad_powers(tbuf[oseg(v) * kDuoPaths + pl], d1, d2, d4, pw);
+          quad_powers(tbuf[oseg(side, v) * kDuoPaths + pl], d1, d2, d4, pw);
           double u[kNB];
 #pragma unroll
           for (int r = 0; r < kNB; ++r) {
@@ -975,7 +1094,7 @@ __device__ __forceinline__ void solve_duo_body(const BatchView& b, int d, const 
         for (int r = 0; r < kNB; ++r) x[r] += vrow0[(r + 1) * kD];
       }
       if (on) {
-        const double T = tbuf[oseg(v) * kDuoPaths + pl];
+        const double T = tbuf[oseg(side, v) * kDuoPaths + pl];
         // the segment's end-point derivatives in FORWARD orientation: side 0 as they are, side 1 with start and end swapped
         // and the odd derivatives negated back
         const double s1 = side ? -1.0 : 1.0;
@@ -1013,7 +1132,7 @@ __device__ __forceinline__ void solve_duo_body(const BatchView& b, int d, const 
         double p2[9];
         quad_powers(T, d1, d2, d4, p2);  // p2[0] = T^(1 - 2d)
         my_cost = fma(cost_quadratic_form_d(d, cb), p2[0], my_cost);
-        double2* out = reinterpret_cast<double2*>(coeffs + ((size_t)(pr.s0 + oseg(v)) * kD + dim) * kN);
+        double2* out = reinterpret_cast<double2*>(coeffs + ((size_t)(pr.s0 + oseg(side, v)) * kD + dim) * kN);
 #pragma unroll
         for (int k = 0; k < kN; k += 2) store_coeff_pair(out + k / 2, c[k], c[k + 1]);
       }
@@ -1022,9 +1141,14 @@ __device__ __forceinline__ void solve_duo_body(const BatchView& b, int d, const 
         for (int r = 0; r < kNB; ++r) xn[r] = x[r];
         p_end = p_start;
       }
+#ifdef MRS_TG_DUO_STAMPS
+      if (v == Mmx - 1) DUO_STAMP(9);
+#endif
     }
-    DUO_STAMP(5);
-  } else if (active && side == 0) {
+    DUO_STAMP(10);
+    duo_finish<0>(my_cost, active, pos_bad, pidx, cost, status, status_in, tail, t_sum);
+  } else {
+    if (active && side == 0) {
     // ---- any other constraint pattern: the general masked step on the four lanes of side 0, factors in the plan's workspace
     bool pok = true;
     BlockSource none{nullptr, nullptr, 0, 0};
@@ -1032,29 +1156,21 @@ __device__ __forceinline__ void solve_duo_body(const BatchView& b, int d, const 
     const double* times = (scaling ? tail.seg_times_out : seg_times) + pr.s0;
     my_cost = solve_path<1, true>(mask, vals, pr.v0, S, d, times, dim, none, ws, (size_t)b.n_paths * 4,
                                   (unsigned)q * 4u + (unsigned)dim, coeffs + (size_t)pr.s0 * kD * kN, pok);
-  }
-  my_cost = quad_sum(my_cost);
-  my_cost += __shfl_xor(my_cost, 4, 64);
-  if (active && l8 == 0) {
-    if (cost) cost[pr.p] = my_cost;
-    if (status) {
-      int st = merge_status(path_pos_ok, status_in, pr.p);
-      if (tail.sum_t0 != nullptr && st > 0 && t_sum > MRS_TG_RUNAWAY_TIME_FACTOR * tail.sum_t0[pr.p]) st = MRS_TG_STATUS_ROUNDOFF_LIMITED;
-      status[pr.p] = st;
     }
+    duo_finish<2>(my_cost, active, pos_bad, pidx, cost, status, status_in, tail, t_sum);
   }
 #ifdef MRS_TG_DUO_STAMPS
-  DUO_STAMP(6);
+  DUO_STAMP(11);
   __builtin_amdgcn_s_waitcnt(0);  // (every store acknowledged)
-  DUO_STAMP(7);
+  DUO_STAMP(12);
   if (lane == 0 && blockIdx.x < 2048)
-    for (int k = 0; k < 8; ++k) g_duo_stamps[blockIdx.x * 8 + k] = duo_stamp[k];
+    for (int k = 0; k < 16; ++k) g_duo_stamps[blockIdx.x * 16 + k] = duo_stamp[k];
 #endif
 }
 
 #ifdef MRS_TG_DUO_STAMPS
 extern "C" int mrs_tg_debug_duo_stamps(unsigned long long* out) {
-  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_duo_stamps), sizeof(unsigned long long) * 2048 * 8);
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_duo_stamps), sizeof(unsigned long long) * 2048 * 16);
 }
 #endif
 
@@ -1068,7 +1184,7 @@ __global__ __launch_bounds__(64, MRS_TG_QUAD_WAVES) void solve_duo_kernel(BatchV
 }
 
 template <bool WP>
-__global__ __launch_bounds__(64, MRS_TG_QUAD_GROUP_WAVES) void solve_duo_group_kernel(BatchView b, int d, RowsGroup g, double* ws,
+__global__ __launch_bounds__(64, MRS_TG_DUO_GROUP_WAVES) void solve_duo_group_kernel(BatchView b, int d, RowsGroup g, double* ws,
                                                                                     size_t ws_batch_doubles, int blocks_per_batch) {
   const int j = __builtin_amdgcn_readfirstlane((int)blockIdx.x / blocks_per_batch);
   solve_duo_body<WP>(b, d, g.mask[j], g.vals[j], g.seg_times[j], g.coeffs[j], g.status[j], g.cost[j], nullptr,
