@@ -659,6 +659,10 @@ __device__ __forceinline__ void solve_quad_body(const BatchView& b, int d, const
 // step as in solve_quad_body); a wavefront with any other path takes the general masked step on the lanes of side 0.
 // The results differ from solve_quad_body's in the last bits (another elimination order): same tolerances against the
 // oracle's 113-bit route (tests/test_gpu_headline_kernel.py).
+// Memory: every global load in the prologue, in one round; the position constraints, the times and the paths' indices wait in
+// LDS; no register is carried across the loops that the compiler would spill ("What bounds the two-sided
+// kernel": loads and stores share one in-order counter on gfx950, so a load or a scratch reload in the loops waits for the
+// coefficient stores in flight).  Min-snap only (the launchers send nothing else; the ABI sends paths of up to 15 segments).
 constexpr int kDuoPaths = 8;  // paths per wavefront
 
 __host__ __device__ constexpr size_t duo_lds_doubles(int Smax) {
@@ -848,7 +852,10 @@ __device__ __forceinline__ void solve_duo_body(const BatchView& b, int d, const 
 
   double my_cost = 0.0;
   if (plain_wave) {
-    const double (*hb)[kN] = c_hbar[d];
+    // (min-snap only: the launchers send no other objective order here -- with the order a constant the unit-time blocks are
+    // literals instead of scalar loads the first step waits for, and one cost form is compiled instead of five)
+    constexpr int kOrder = kHalf - 1;
+    const double (*hb)[kN] = c_hbar[kOrder];
     double cNear[10], cCpl[kNB][kNB], cFar[10], cN[kNB], cF[kNB];
 #pragma unroll
     for (int r = 0; r < kNB; ++r) {
@@ -862,7 +869,7 @@ __device__ __forceinline__ void solve_duo_body(const BatchView& b, int d, const 
       cN[r] = hb[kSlot0 + r][0];
       cF[r] = hb[kHalf + kSlot0 + r][0];
     }
-    const bool d1 = (d & 1) != 0, d2 = (d & 2) != 0, d4 = (d & 4) != 0;
+    constexpr bool d1 = (kOrder & 1) != 0, d2 = (kOrder & 2) != 0, d4 = (kOrder & 4) != 0;
     // this side's chain: local vertices 0 .. M (0: the path's end on this side, M: the middle vertex), local segments 0 .. M - 1
     const int m_mid = (S + 1) >> 1;
     // (wave-uniform trip count of both loops: the longest side the batch can hold -- a reduction over the wavefront's own paths
@@ -1131,7 +1138,7 @@ __device__ __forceinline__ void solve_duo_body(const BatchView& b, int d, const 
         }
         double p2[9];
         quad_powers(T, d1, d2, d4, p2);  // p2[0] = T^(1 - 2d)
-        my_cost = fma(cost_quadratic_form_d(d, cb), p2[0], my_cost);
+        my_cost = fma(cost_quadratic_form<kOrder>(cb), p2[0], my_cost);
         double2* out = reinterpret_cast<double2*>(coeffs + ((size_t)(pr.s0 + oseg(side, v)) * kD + dim) * kN);
 #pragma unroll
         for (int k = 0; k < kN; k += 2) store_coeff_pair(out + k / 2, c[k], c[k + 1]);
