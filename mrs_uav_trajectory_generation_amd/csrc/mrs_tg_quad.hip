@@ -49,11 +49,11 @@
 #ifndef MRS_TG_QUAD_GROUP_WAVES
 #define MRS_TG_QUAD_GROUP_WAVES 2
 #endif
-// The two-sided group kernel: two as well.  Three (168 registers: the plain path fits, the general step spills) keep both
-// dispatches of the headline's timed region resident at once -- and lose: 25.9 us per dispatch against 24.4, the region 67-69 us
-// against 63 (same box, alternating runs).  One wavefront of this kernel keeps its SIMD's FP64 pipe about half busy (an FMA on
-// three vector registers issues every 8.7 clocks from one wavefront, every 4.4 from two: profiles/round6_issue_latencies.txt),
-// so a third one only adds contention.
+// The two-sided group kernel: two as well.  Its 18.5 KB of LDS per wavefront (10 segments) let a CU hold eight wavefronts -- two
+// per SIMD -- whatever the register budget says, so a build for three (168 registers: the plain path fits, the general step
+// spills) only pays for the registers: 25.9 us per dispatch against 24.4, the region 67-69 us against 63 (same box, alternating
+// runs; profiles/round6_duo_group_waves_ab.txt).  One wavefront of this kernel keeps its SIMD's FP64 pipe about half busy (an
+// FMA on three vector registers issues every 8.7 clocks from one wavefront: profiles/round6_issue_latencies.txt).
 #ifndef MRS_TG_DUO_GROUP_WAVES
 #define MRS_TG_DUO_GROUP_WAVES 2
 #endif
