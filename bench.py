@@ -30,7 +30,10 @@ Steps are independent batches -- every step is a full pass over its own batch in
 of them (default 20) are kept in flight per GPU.  `--issue grouped` (default): `--group-size` (10) consecutive steps go out as
 ONE dispatch (mrs_tg_bound_solve_launch_group: the single-batch solve kernel's body, its workgroups divided among the
 batches), the dispatches alternating over two HIP streams; a runtime launch costs the host 3 us, so twenty one-step launches
-were half of the driver's 20-step timed region.  `--issue streams` is round 2's method -- one dispatch per step, round-robin over
+were half of the driver's 20-step timed region.  WHICH two streams (round 6): the runtime maps HIP streams onto a few hardware
+queues, and whether two streams' dispatches overlap depends on the pair and on the process (profiles/round6_stream_pairs.txt:
+49, 57-60 or 66 us for the same two dispatches); `--stream-candidates` (8) streams are created and an untimed calibration of the
+two-dispatch round picks the pair (config.issue_policy.stream_pair holds the table).  `--issue streams` is round 2's method -- one dispatch per step, round-robin over
 `--streams` (4 = the hardware queues the runtime gives a process) HIP streams with their own contexts and plans -- and is
 reported as extras.streams_in_flight; extras.one_batch_in_flight is one stream, every step waiting for the previous.  The
 nonlinear workload keeps one batch in flight per stream.
@@ -91,6 +94,10 @@ def parse_args(argv=None):
                          "nonlinear workload: one per HIP stream, at most --streams of them")
     ap.add_argument("--streams", type=int, default=4,
                     help="HIP streams (one context + plan each) per GPU: the hardware queues the runtime gives a process")
+    ap.add_argument("--stream-candidates", type=int, default=8,
+                    help="grouped issue: HIP streams created, of which the pair whose two dispatches overlap best carries the timed "
+                         "region (the runtime maps streams onto a few hardware queues; two streams on one queue serialize). "
+                         "<= 2: no calibration, the first two lanes as until round 6")
     ap.add_argument("--issue", choices=["grouped", "streams"], default="grouped",
                     help="how the K linear steps are issued: 'grouped' packs the steps of a round (one per batch in flight) into "
                          "ONE dispatch on one stream (mrs_tg_bound_solve_launch_group); 'streams' issues one dispatch per step, "
@@ -416,7 +423,11 @@ def main():
     # lanes = HIP streams (lane 0 = torch's current stream with ctx / plan, lanes 1.. = side streams with their own); slots =
     # sets of output arrays.  Stream-issued steps keep one batch in flight per lane; grouped steps --in-flight of them
     n_lanes = max(1, min(args.in_flight, args.streams))
-    lane_stream = [torch.cuda.current_stream()] + [torch.cuda.Stream(device=dev) for _ in range(n_lanes - 1)]
+    # grouped issue: a few more streams than it uses; group_lanes[g] = the lane that carries the g-th dispatch of a round, chosen by
+    # calibrate_group_lanes() below (lanes beyond n_lanes are candidates only: stream-issued steps never run on them)
+    n_cand = max(n_lanes, args.stream_candidates) if (args.issue == "grouped" and args.workload == "linear" and n_lanes > 1) else n_lanes
+    group_lanes = list(range(n_cand))
+    lane_stream = [torch.cuda.current_stream()] + [torch.cuda.Stream(device=dev) for _ in range(n_cand - 1)]
     lane_ctx, lane_plan = [ctx], [plan]
     for st in lane_stream[1:]:
         with torch.cuda.stream(st):
@@ -531,19 +542,19 @@ def main():
             slots = n_group_slots if grouped else max(lanes, 2 if dist is not None else 1)
             for slot in range(slots):       # a slot whose last result is still being gathered: its lane waits for that
                 if slot_free[slot] is not None:
-                    lane_stream[min(slot // max(1, min(args.group_size, slots)), lanes - 1) if grouped else slot % lanes].wait_event(slot_free[slot])
+                    lane_stream[group_lanes[min(slot // max(1, min(args.group_size, slots)), lanes - 1)] if grouped else slot % lanes].wait_event(slot_free[slot])
                     slot_free[slot] = None
-            key = (kind, lanes, slots, grouped)
+            key = (kind, lanes, slots, grouped, tuple(group_lanes[:lanes]) if grouped else None)
             if key not in round_robin:
-                if grouped:   # slot sl on lane sl // group size: consecutive slots of a lane go out as one dispatch
+                if grouped:   # slot sl on the lane of its group (sl // group size): consecutive slots of a lane go out as one dispatch
                     gs = max(1, min(args.group_size, slots))
-                    round_robin[key] = api.RoundRobin([slot_call(kind, sl, min(sl // gs, lanes - 1)) for sl in range(slots)], grouped=True)
+                    round_robin[key] = api.RoundRobin([slot_call(kind, sl, group_lanes[min(sl // gs, lanes - 1)]) for sl in range(slots)], grouped=True)
                 else:
                     round_robin[key] = api.RoundRobin([slot_call(kind, sl, sl % lanes) for sl in range(slots)],
                                                       threads=min(args.issue_threads, slots))
             round_robin[key](n)
             step_no[0] = n
-            last_slot[0] = ((n - 1) % slots, min(((n - 1) % slots) // max(1, min(args.group_size, slots)), lanes - 1) if grouped
+            last_slot[0] = ((n - 1) % slots, group_lanes[min(((n - 1) % slots) // max(1, min(args.group_size, slots)), lanes - 1)] if grouped
                             else ((n - 1) % slots) % lanes)
         return block
 
@@ -594,6 +605,41 @@ def main():
         ramp_steps += 96
         torch.cuda.synchronize()
     step_no[0] = 0
+
+    # Which two streams?  The runtime maps HIP streams onto a handful of hardware queues, and which pairs share one differs from
+    # process to process: on one box torch's current stream and the first side stream -- the pair of rounds 4-6 -- took 67 us for
+    # the two dispatches of a 20-step region in every process, other pairs 49, 60 or 66 us (one stream twice: 55;
+    # profiles/round6_stream_pairs.txt).  A host that keeps two dispatches in flight picks its streams: the pair with the
+    # shortest two-dispatch round of the timed region's own issue path, measured here, untimed, once.
+    stream_pairs = None
+
+    def calibrate_group_lanes():
+        gs = max(1, min(args.group_size, n_group_slots))
+        blk = block_for("linear")
+        if blk is None or n_cand <= 2 or args.stream_candidates <= 2 or n_group_slots < 2 * gs:
+            return None
+        table = {}
+        for a_ in range(n_cand):
+            for b_ in range(a_ + 1, n_cand):
+                group_lanes[:] = [a_, b_] + [l for l in range(n_cand) if l not in (a_, b_)]
+                for _ in range(3):
+                    blk(2 * gs)
+                torch.cuda.synchronize()
+                ts = []
+                for _ in range(9):
+                    t0_ = time.perf_counter()
+                    blk(2 * gs)
+                    torch.cuda.synchronize()
+                    ts.append(time.perf_counter() - t0_)
+                table[(a_, b_)] = median_of(ts) * 1e6
+        best = min(table, key=table.get)
+        group_lanes[:] = [best[0], best[1]] + [l for l in range(n_cand) if l not in best]
+        step_no[0] = 0
+        return dict(candidates=n_cand, chosen=list(best), two_dispatch_round_us={"%d,%d" % k: round(v, 1) for k, v in sorted(table.items())},
+                    lane_0="torch's current stream", note="lanes 1.. are torch side streams in creation order; rounds 4-6 used the pair 0,1")
+
+    if args.workload == "linear" and grouped_mode[0] and not gather_every[0]:
+        stream_pairs = calibrate_group_lanes()
 
     # R regions of K steps each, every one between its own barrier + synchronize pairs; the line's figure is the MEDIAN region
     # (one 20-step region of the fixed-times workload is 60-80 us: a single one measures the moment, not the kernel)
@@ -1279,7 +1325,13 @@ def main():
                                                   frozen="since round 4: 20 batches in flight, 10 steps per dispatch, two streams; "
                                                          "rounds 1-3 used 4 / 4 / 16 in flight (HISTORY.md) -- compare rounds on "
                                                          "one_batch_in_flight (one batch, one dispatch per step: the strict reading "
-                                                         "of configs[1]) and value_200_steps, both top-level keys"),
+                                                         "of configs[1]) and value_200_steps, both top-level keys",
+                                                  stream_pair=(stream_pairs if stream_pairs is not None else
+                                                               "the first two lanes (torch's current stream and the first side stream), as in rounds 4-6"),
+                                                  stream_pair_note="round 6: WHICH two streams carry the dispatches is chosen by an untimed calibration "
+                                                                   "of the two-dispatch round among --stream-candidates HIP streams (the runtime maps streams "
+                                                                   "onto a few hardware queues; pairs that share one serialize); the policy -- 20 in flight, "
+                                                                   "10 steps per dispatch, two streams -- is unchanged; --stream-candidates 2 = the pair of rounds 4-6"),
                                 linear_solve="default of mrs_tg_plan_solve, blocks formed in registers (nothing materialised): "
                                              "solve_rows_kernel for a launch of one batch; a dispatch that carries >= 6144 paths (the "
                                              "grouped steps of the headline: %d x %d) runs solve_duo_group_kernel (eight lanes per path, "
