@@ -1327,7 +1327,8 @@ def main():
                                                          "one_batch_in_flight (one batch, one dispatch per step: the strict reading "
                                                          "of configs[1]) and value_200_steps, both top-level keys",
                                                   stream_pair=(stream_pairs if stream_pairs is not None else
-                                                               "the first two lanes (torch's current stream and the first side stream), as in rounds 4-6"),
+                                                               ("the first two lanes (torch's current stream and the first side stream), as in rounds 4-6"
+                                                                if (grouped_mode[0] and args.workload == "linear" and n_lanes > 1) else None)),
                                                   stream_pair_note="round 6: WHICH two streams carry the dispatches is chosen by an untimed calibration "
                                                                    "of the two-dispatch round among --stream-candidates HIP streams (the runtime maps streams "
                                                                    "onto a few hardware queues; pairs that share one serialize); the policy -- 20 in flight, "
