@@ -79,6 +79,25 @@ def test_degenerate_and_overflowing_paths_fail_cleanly(gpu_ctx):
     assert np.all(out["n_samples"][out["success"] == 0] == 0)
 
 
+def test_response_arrays_kept_between_calls_hold_the_second_call_s_answers(gpu_ctx):
+    """api.optimize_paths(out=): a server's loop writes batch after batch into the same response arrays; a request that fails
+    in the second batch must not show the first batch's samples"""
+    first = [pr.random_box_waypoints(4 + (i % 5), 300 + i) for i in range(70)]
+    second = [pr.random_walk_waypoints(4 + (i % 6), 900 + i) for i in range(70)]
+    second[3] = np.array([[0.0, 0.0, 1.0, 0.0]])    # a single waypoint: no trajectory
+    kept = api.optimize_paths(gpu_ctx, first, sample_capacity=1024)
+    assert kept["success"].sum() >= 69
+    again = api.optimize_paths(gpu_ctx, second, sample_capacity=1024, out=kept)
+    fresh = api.optimize_paths(gpu_ctx, second, sample_capacity=1024)
+    assert again["samples"] is kept["samples"]
+    for k in ("success", "n_samples", "max_deviation", "n_waypoints", "iterations"):
+        assert np.array_equal(again[k], fresh[k]), k
+    assert again["success"][3] == 0 and again["n_samples"][3] == 0
+    for p in range(70):
+        n = int(fresh["n_samples"][p])
+        assert np.array_equal(again["samples"][p, :n], fresh["samples"][p, :n]), p
+
+
 def test_waypoint_trajectory_idxs(gpu_ctx):
     import ctypes as C
     wp = pr.random_walk_waypoints(5, 2)
