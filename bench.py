@@ -156,6 +156,17 @@ LAST_OWN_GATHER = [0.0]
 LAST_OWN_REGIONS = [[0.0]]
 
 
+def pick_stream_pair(n_candidates, measure_us):
+    """The pair of lanes (a < b) with the shortest two-dispatch round: measure_us(a, b) -> microseconds.  Returns (best pair,
+    {(a, b): us}).  (The choice among HIP streams of bench.py's grouped issue path, see calibrate_group_lanes in main().)"""
+    table = {}
+    for a in range(n_candidates):
+        for b in range(a + 1, n_candidates):
+            table[(a, b)] = float(measure_us(a, b))
+    best = min(sorted(table), key=table.get)
+    return best, table
+
+
 def time_regions(step_fn, steps, warmup, dist, torch, regions=1, final_fn=None, block_fn=None, gather_inside=False):
     """W untimed steps, then `regions` timed regions of exactly K steps each, every region between its own barrier +
     synchronize pairs ("steady-state median of >= 5 repetitions after 1 warm-up").  Every rank reads its
@@ -618,21 +629,20 @@ def main():
         blk = block_for("linear")
         if blk is None or n_cand <= 2 or args.stream_candidates <= 2 or n_group_slots < 2 * gs:
             return None
-        table = {}
-        for a_ in range(n_cand):
-            for b_ in range(a_ + 1, n_cand):
-                group_lanes[:] = [a_, b_] + [l for l in range(n_cand) if l not in (a_, b_)]
-                for _ in range(3):
-                    blk(2 * gs)
+        def round_us(a_, b_):
+            group_lanes[:] = [a_, b_] + [l for l in range(n_cand) if l not in (a_, b_)]
+            for _ in range(3):
+                blk(2 * gs)
+            torch.cuda.synchronize()
+            ts = []
+            for _ in range(9):
+                t0_ = time.perf_counter()
+                blk(2 * gs)
                 torch.cuda.synchronize()
-                ts = []
-                for _ in range(9):
-                    t0_ = time.perf_counter()
-                    blk(2 * gs)
-                    torch.cuda.synchronize()
-                    ts.append(time.perf_counter() - t0_)
-                table[(a_, b_)] = median_of(ts) * 1e6
-        best = min(table, key=table.get)
+                ts.append(time.perf_counter() - t0_)
+            return median_of(ts) * 1e6
+
+        best, table = pick_stream_pair(n_cand, round_us)
         group_lanes[:] = [best[0], best[1]] + [l for l in range(n_cand) if l not in best]
         step_no[0] = 0
         return dict(candidates=n_cand, chosen=list(best), two_dispatch_round_us={"%d,%d" % k: round(v, 1) for k, v in sorted(table.items())},

@@ -216,3 +216,20 @@ def test_four_rank_repeated_timed_regions_keep_the_barrier_steps_clock_gather_or
     result = tmp_path / "result.txt"
     mp.spawn(_worker_regions, args=(4, _free_port(), str(result)), nprocs=4, join=True)
     assert result.read_text() == "ok"
+
+
+def test_stream_pair_choice_takes_the_shortest_round_and_reports_every_pair():
+    """bench.py's calibration of the grouped issue path's two streams (round 6): every pair of the candidates is measured once,
+    the shortest two-dispatch round wins, ties go to the first pair"""
+    sys.path.insert(0, ROOT)
+    import bench
+    us = {(0, 1): 67.0, (0, 2): 60.5, (0, 3): 49.2, (1, 2): 49.2, (1, 3): 57.0, (2, 3): 66.0}
+    seen = []
+
+    def measure(a, b):
+        seen.append((a, b))
+        return us[(a, b)]
+    best, table = bench.pick_stream_pair(4, measure)
+    assert best == (0, 3) and table == us and seen == sorted(us)
+    best2, table2 = bench.pick_stream_pair(2, lambda a, b: 55.0)
+    assert best2 == (0, 1) and table2 == {(0, 1): 55.0}
