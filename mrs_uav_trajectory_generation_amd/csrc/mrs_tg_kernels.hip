@@ -108,13 +108,32 @@ __global__ __launch_bounds__(256) void assemble_blocks_kernel(BatchView b, int d
 // contiguous range (xcd_contiguous_index): the XCD that writes the blocks of paths [128 c, 128 c + 128) is then the XCD
 // whose tiles of the solve kernel read them (same partition of the paths over the XCDs), and finds them in its own L2.
 constexpr int kAssembleChunk = 128;
+#ifndef MRS_TG_ASSEMBLE_ORDER
+#define MRS_TG_ASSEMBLE_ORDER 2   // by size
+#endif
 __global__ __launch_bounds__(kAssembleChunk) void assemble_blocks_uniform_kernel(int n_paths, int S, int d,
                                                                                  const double* __restrict__ seg_times,
                                                                                  double* __restrict__ Hout,
                                                                                  double* __restrict__ Aout) {
-  const int logical = xcd_contiguous_index(blockIdx.x, gridDim.x);
-  const int per_chunk = kN * S;
-  const int chunk = logical / per_chunk, rem = logical - chunk * per_chunk;
+  // Which workgroup writes what.  Small launches (the headline's 1024 paths: 8 chunks): workgroups of one chunk of paths are
+  // neighbours in the XCD-contiguous numbering, so the XCD that writes the blocks of a chunk is the one whose solve tiles read
+  // them.  Large launches: the CHUNK varies fastest -- the workgroups in flight then write neighbouring 1 KB runs of the same few
+  // rows instead of runs scattered over the whole gigabyte (twenty arrays 512 KB apart per workgroup): 65536 x 10 on buffers the
+  // driver placed badly 0.63-0.66 -> 0.73-0.75 of the HBM peak, on well-placed ones 0.78 -> 0.80 (round 6,
+  // profiles/round6_assembly_placement.txt); MRS_TG_ASSEMBLE_ORDER=0 / 1: the first / second order at every size (A / B builds)
+  const int n_chunks = (n_paths + kAssembleChunk - 1) / kAssembleChunk;
+  const bool chunk_fastest = MRS_TG_ASSEMBLE_ORDER == 1 || (MRS_TG_ASSEMBLE_ORDER == 2 && n_chunks >= 64);
+  int chunk, rem;
+  if (chunk_fastest) {
+    const int logical = (int)blockIdx.x;
+    rem = logical / n_chunks;
+    chunk = logical - rem * n_chunks;
+  } else {
+    const int logical = xcd_contiguous_index(blockIdx.x, gridDim.x);
+    const int per_chunk = kN * S;
+    chunk = logical / per_chunk;
+    rem = logical - chunk * per_chunk;
+  }
   const int j = rem / kN, a = rem - j * kN;
   const int q = chunk * kAssembleChunk + threadIdx.x;
   if (q >= n_paths) return;

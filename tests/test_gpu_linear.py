@@ -60,6 +60,38 @@ def test_assemble_blocks_match_exact_and_oracle(gpu_ctx, golden):
         plan.close()
 
 
+def test_assemble_blocks_of_a_large_launch_are_the_bits_of_a_small_one(gpu_ctx):
+    """From 64 chunks of 128 paths on, the assembly kernel numbers its workgroups the other way round (the chunk of paths varies
+    fastest: mrs_tg_kernels.hip); the blocks must be the ones a small launch writes for the same segment times, bit for bit,
+    and the oracle's to 1e-7."""
+    P, S = 8200 + 77, 3        # 65 chunks, the last one partial
+    rng = np.random.default_rng(5)
+    t = rng.uniform(0.3, 4.0, P * S)
+    so = (np.arange(P + 1) * S).astype(np.int32)
+    plan = api.Plan(gpu_ctx, so)
+    H = torch.zeros(plan.block_doubles, dtype=torch.float64, device="cuda")
+    Ai = torch.zeros(plan.block_doubles, dtype=torch.float64, device="cuda")
+    plan.assemble(4, torch.from_numpy(t).cuda(), H, Ai)
+    torch.cuda.synchronize()
+    Hs, As = plan.blocks_to_segments(H), plan.blocks_to_segments(Ai)
+    plan.close()
+    paths = np.unique(np.concatenate([np.arange(0, 130), np.arange(8190, P), rng.integers(0, P, 200)]))
+    small = api.Plan(gpu_ctx, (np.arange(len(paths) + 1) * S).astype(np.int32))
+    ts = np.concatenate([t[p * S:(p + 1) * S] for p in paths])
+    H2 = torch.zeros(small.block_doubles, dtype=torch.float64, device="cuda")
+    A2 = torch.zeros(small.block_doubles, dtype=torch.float64, device="cuda")
+    small.assemble(4, torch.from_numpy(ts).cuda(), H2, A2)
+    torch.cuda.synchronize()
+    Hr, Ar = small.blocks_to_segments(H2), small.blocks_to_segments(A2)
+    small.close()
+    for k, p in enumerate(paths):
+        assert np.array_equal(Hs[p * S:(p + 1) * S], Hr[k * S:(k + 1) * S]), p
+        assert np.array_equal(As[p * S:(p + 1) * S], Ar[k * S:(k + 1) * S]), p
+    for s in (0, 1, 2, 8190 * S, P * S - 1):
+        Ho, Ao = po.segment_hessian(4, t[s])
+        assert np.max(np.abs(Hs[s] - Ho)) / np.max(np.abs(Ho)) < 1e-7 and np.max(np.abs(As[s] - Ao)) / np.max(np.abs(Ao)) < 1e-7
+
+
 @pytest.mark.parametrize("fused", [False, True])
 def test_linear_golden_cases(gpu_ctx, golden, fused):
     for case in golden["cases"]:
